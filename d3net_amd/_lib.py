@@ -1,0 +1,64 @@
+"""ctypes binding of libd3hip.so (declared in include/d3hip.h).  Fails loudly when missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libd3hip.so")
+
+ERRORS = {-1: "D3_ERR_WORKSPACE", -2: "D3_ERR_RANGE (coordinate/batch outside key range)",
+          -3: "D3_ERR_ARG", -4: "D3_ERR_OVERFLOW"}
+
+
+class D3Error(RuntimeError):
+    pass
+
+
+_lib = None
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+pi = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol include/d3hip.h declares
+SIGNATURES = {
+    "d3_version": (i32, []),
+    "d3_arch": (C.c_char_p, []),
+    "d3_sec_mean": (i32, [vp, vp, vp, i32, i32, vp]),
+    "d3_sec_min": (i32, [vp, vp, vp, i32, i32, vp]),
+    "d3_sec_max": (i32, [vp, vp, vp, i32, i32, vp]),
+    "d3_roipool_fp": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "d3_roipool_bp": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "d3_get_iou": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
+    "d3_voxelize_fp": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "d3_voxelize_bp": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "d3_point_recover_fp": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "d3_point_recover_bp": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "d3_voxelize_idx_ws_bytes": (sz, [i32]),
+    "d3_voxelize_idx_count": (i32, [vp, i32, i32, i32, vp, vp, sz, pi, pi, vp]),
+    "d3_voxelize_idx_fill": (i32, [vp, i32, i32, i32, vp, vp, sz, vp, vp, i32, i32, vp]),
+    "d3_ballquery_ws_bytes": (sz, [i32]),
+    "d3_ballquery_count": (i32, [vp, vp, vp, i32, f32, vp, vp, sz, pi, vp]),
+    "d3_ballquery_fill": (i32, [vp, vp, vp, i32, f32, vp, vp, sz, vp, i64, vp]),
+    "d3_bfs_cluster_ws_bytes": (sz, [i32]),
+    "d3_bfs_cluster_count": (i32, [vp, vp, vp, i32, i32, vp, sz, pi, pi, vp]),
+    "d3_bfs_cluster_fill": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, i32, i32, vp]),
+}
+
+
+def lib():
+    """Load libd3hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise D3Error("libd3hip.so not built (%s); run `python -m d3net_amd.build` -- "
+                          "d3net_amd has no CPU/eager fallback" % SO_PATH)
+        l = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise D3Error("%s failed: %s" % (what, ERRORS.get(rc, "hipError_t %d" % rc)))

@@ -1,0 +1,336 @@
+// cluster.hip -- same-label connected components over ball-query lists, in the reference's
+// FIFO-BFS order, entirely on the device (gfx950).
+//
+// Replaces PG_OP.bfs_cluster (reference: lib/pointgroup_ops/src/bfs_cluster/bfs_cluster.cpp:28-112),
+// which runs single-threaded on the host behind a D2H copy of the neighbour lists (up to
+// n*300*4 B), twice per forward (model/pointgroup.py:296-305).
+//
+// Reference semantics: for i = 0..n-1, if i is unvisited, FIFO-BFS from i over the DIRECTED
+// edges i -> list(i) restricted to equal semantic labels; keep the visited set if it has
+// >= threshold points; emit (cluster_id, point) in visitation order.  Lists are capped at
+// 1000 entries (smallest indices first), so edges are symmetric except where a list was cut.
+//
+// Parallel formulation (checked against the sequential oracle on the CPU by
+// tests/bfs_parallel_model.py, the numpy model of exactly these steps):
+//   1. owner(j) = smallest index that reaches j.  (The smallest ancestor is never claimed by an
+//      earlier seed, so it is a seed, and it is the first seed that reaches j.)
+//      a. lock-free min-hooking union-find over edges whose two lists are both complete
+//         (len < 1000) -- such edges are mutual, so a tree is a strongly connected set and its
+//         root is its smallest index;
+//      b. push labels root(i) -> root(j) over ALL edges with atomicMin until a fixpoint
+//         (needed only across truncated lists; 1-3 passes in practice).
+//   2. sizes by owner, keep >= threshold, cluster ids / offsets by exclusive scans in seed order.
+//   3. one 1024-thread workgroup per kept cluster replays the BFS level-synchronously: the queue
+//      segment of the level is expanded in three passes -- A: first discoverer of every node
+//      (atomicMin of the parent's queue position), B: children per parent, scan, C: children
+//      written in (parent position, list order) -- which is the FIFO order.
+// All passes stream the neighbour lists: bytes = 4*nActive per pass + 12*n, HBM/L2 bound.
+#include "common.h"
+
+#define CL_CAP 1000
+#define CL_BFS_THREADS 1024
+#define CL_INF 0x7FFFFFFF
+
+struct ClWs {
+    int *parent;   // n  union-find forest (phase 1), then root id per node
+    int *lab;      // n  label per root
+    int *own;      // n  owner (seed) per node
+    int *sizes;    // n  points per owner
+    int *flag;     // n  1 if owner kept
+    int *cid;      // n  exclusive scan of flag
+    int *ksz;      // n  kept size
+    int *koff;     // n  exclusive scan of ksz
+    int *seeds;    // n  seed of cluster c
+    int *par;      // n  BFS: queue position of the first discoverer
+    int *queue;    // n  BFS queues (cluster c at koff[seed])
+    int *fcnt;     // n  BFS: children per frontier entry / scanned
+    int *scalars;  // [0]=changed [1]=nCluster [2]=sumNPoint
+    void *temp; size_t temp_bytes;
+};
+
+static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
+    D3Carver c(ws, ws_bytes);
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    w.parent = c.take<int>(nn); w.lab = c.take<int>(nn); w.own = c.take<int>(nn); w.sizes = c.take<int>(nn);
+    w.flag = c.take<int>(nn); w.cid = c.take<int>(nn); w.ksz = c.take<int>(nn); w.koff = c.take<int>(nn);
+    w.seeds = c.take<int>(nn); w.par = c.take<int>(nn); w.queue = c.take<int>(nn); w.fcnt = c.take<int>(nn);
+    w.scalars = c.take<int>(64);
+    w.temp_bytes = d3_scan_temp_bytes(n);
+    w.temp = c.take<char>(w.temp_bytes);
+    return ws != nullptr && c.ok();
+}
+extern "C" size_t d3_bfs_cluster_ws_bytes(int n) {
+    D3Carver c(nullptr, 0);
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    for (int i = 0; i < 12; i++) c.take<int>(nn);
+    c.take<int>(64);
+    c.take<char>(d3_scan_temp_bytes(n));
+    return c.off + 256;
+}
+
+// L1-bypassing load/store for words other waves update inside the same launch
+__device__ __forceinline__ int ld_dev(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_dev(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void cl_init_kernel(int *parent, int *lab, int *sizes, int *par, int n, int *scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { parent[i] = i; lab[i] = i; sizes[i] = 0; par[i] = CL_INF; }
+    if (i < 8) scalars[i] = 0;
+}
+
+__device__ __forceinline__ int cl_find(int *parent, int x) {
+    int p = ld_dev(&parent[x]);
+    while (p != x) {
+        int gp = ld_dev(&parent[p]);
+        if (gp != p) atomicMin(&parent[x], gp);  // path halving; only ever lowers towards an ancestor
+        x = p; p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void cl_union(int *parent, int a, int b) {
+    for (;;) {
+        a = cl_find(parent, a); b = cl_find(parent, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&parent[b], a);  // hook the larger root under the smaller
+        if (old == b) return;                // b was still a root: done
+        b = old;                             // b had been hooked meanwhile: keep uniting with its old parent
+    }
+}
+
+// phase 1a: one wave per node, lanes over its list
+__global__ __launch_bounds__(256) void cl_union_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
+                                                      const int *__restrict__ start_len, int n, int *parent) {
+    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n) return;
+    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    if (ln >= CL_CAP) return;
+    const int si = sem[i];
+    for (int e = d3_lane(); e < ln; e += 64) {
+        const int j = idx[st + e];
+        if (j == i || sem[j] != si) continue;
+        if (start_len[j * 2 + 1] >= CL_CAP) continue;
+        if (j < i) continue;  // the edge is mutual (both lists complete): handle it once, from its smaller endpoint
+        cl_union(parent, i, j);
+    }
+}
+__global__ void cl_flatten_kernel(int *parent, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = i;
+    for (;;) { int p = ld_dev(&parent[r]); if (p == r) break; r = p; }
+    // every thread only writes its own entry with its root; roots keep parent[r]==r
+    if (r != i) st_dev(&parent[i], r);
+}
+
+__device__ __forceinline__ int cl_chase(const int *lab, int l) {
+    for (;;) { int m = ld_dev(&lab[l]); if (m >= l) return l; l = m; }
+}
+
+// phase 1b: push labels over all edges; root[] == parent[] after flatten
+__global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
+                                                     const int *__restrict__ start_len, int n,
+                                                     const int *__restrict__ root, int *lab, int *scalars) {
+    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n) return;
+    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    const int si = sem[i];
+    const int ri = root[i];
+    const int li = cl_chase(lab, ld_dev(&lab[ri]));
+    if (li < ld_dev(&lab[ri])) atomicMin(&lab[ri], li);
+    bool changed = false;
+    for (int e = d3_lane(); e < ln; e += 64) {
+        const int j = idx[st + e];
+        if (sem[j] != si) continue;
+        const int rj = root[j];
+        if (rj == ri) continue;
+        if (ld_dev(&lab[rj]) > li) { if (atomicMin(&lab[rj], li) > li) changed = true; }
+    }
+    if (__any(changed) && d3_lane() == 0) scalars[0] = 1;
+}
+
+__global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *sizes, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int o = cl_chase(lab, lab[root[i]]);
+    own[i] = o;
+    atomicAdd(&sizes[o], 1);
+}
+__global__ void cl_keep_kernel(const int *sizes, int *flag, int *ksz, int n, int threshold) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int k = sizes[i] >= threshold && sizes[i] > 0;
+    flag[i] = k; ksz[i] = k ? sizes[i] : 0;
+}
+__global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz, const int *koff, int n,
+                                 int *scalars) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        scalars[1] = cid[n - 1] + flag[n - 1];
+        scalars[2] = koff[n - 1] + ksz[n - 1];
+    }
+}
+
+extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
+                                    int n, int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host,
+                                    int *nCluster_host, void *stream) {
+    *sumNPoint_host = 0; *nCluster_host = 0;
+    if (n <= 0) return 0;
+    ClWs w;
+    if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
+    cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, n, w.scalars);
+    cl_union_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
+    cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
+    D3_LAUNCH_CHECK();
+    for (int it = 0; it < n + 2; it++) {
+        D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars);
+        int changed = 0;
+        D3_CHECK(hipMemcpyAsync(&changed, w.scalars, sizeof(int), hipMemcpyDeviceToHost, s));
+        D3_CHECK(hipStreamSynchronize(s));
+        if (!changed) break;
+    }
+    cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
+    cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);
+    int rc = d3_exclusive_scan_i32(w.flag, w.cid, n, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    rc = d3_exclusive_scan_i32(w.ksz, w.koff, n, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    cl_totals_kernel<<<1, 64, 0, s>>>(w.flag, w.cid, w.ksz, w.koff, n, w.scalars);
+    D3_LAUNCH_CHECK();
+    int h[3];
+    D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipStreamSynchronize(s));
+    *nCluster_host = h[1];
+    *sumNPoint_host = h[2];
+    return 0;
+}
+
+__global__ void cl_seed_kernel(const int *flag, const int *cid, const int *koff, int n, int *seeds,
+                               int *cluster_offsets, int nCluster, int sumNPoint) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cluster_offsets[nCluster] = sumNPoint;
+    if (i >= n || !flag[i]) return;
+    seeds[cid[i]] = i;
+    cluster_offsets[cid[i]] = koff[i];
+}
+
+// block-wide exclusive scan of a global int array segment (in place); returns the total.
+__device__ int cl_block_scan(int *a, int len, int *lds /* >= 32 ints */) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < len; base += blockDim.x) {
+        const int i = base + t;
+        int v = (i < len) ? ld_dev(&a[i]) : 0;
+        int x = v;  // inclusive wave scan
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) lds[wv] = x;
+        __syncthreads();
+        if (wv == 0) {
+            int wsum = (lane < nw) ? lds[lane] : 0;
+            int ws = wsum;
+            for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(ws, o); if (lane >= o) ws += y; }
+            if (lane < nw) lds[lane] = ws - wsum;  // exclusive wave offsets
+            if (lane == 63) lds[nw] = ws;          // chunk total
+        }
+        __syncthreads();
+        if (i < len) st_dev(&a[i], carry + lds[wv] + x - v);
+        carry += lds[nw];
+        __syncthreads();
+    }
+    return carry;
+}
+
+// phase 3: one workgroup per kept cluster
+__global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__restrict__ sem,
+                                                               const int *__restrict__ idx,
+                                                               const int *__restrict__ start_len,
+                                                               const int *__restrict__ own,
+                                                               const int *__restrict__ seeds,
+                                                               const int *__restrict__ koff,
+                                                               const int *__restrict__ sizes, int *par, int *queue,
+                                                               int *fcnt, int *cluster_idxs) {
+    __shared__ int lds[40];
+    const int c = blockIdx.x;
+    const int s = seeds[c];
+    const int base = koff[s];
+    const int size = sizes[s];
+    int *q = queue + base;
+    int *fc = fcnt + base;
+    const int lane = d3_lane(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long lt = d3_lanemask_lt();
+    if (threadIdx.x == 0) { st_dev(&q[0], s); st_dev(&par[s], -1); }
+    __syncthreads();
+    int lo = 0, hi = 1;
+    while (lo < hi && hi <= size) {
+        // pass A: first discoverer = smallest parent queue position
+        for (int f = lo + wv; f < hi; f += nw) {
+            const int u = ld_dev(&q[f]);
+            const int st = start_len[u * 2], ln = start_len[u * 2 + 1];
+            const int su = sem[u];
+            for (int e = lane; e < ln; e += 64) {
+                const int j = idx[st + e];
+                if (sem[j] == su && own[j] == s) { if (ld_dev(&par[j]) > f) atomicMin(&par[j], f); }
+            }
+        }
+        __syncthreads();
+        // pass B: children per frontier entry
+        for (int f = lo + wv; f < hi; f += nw) {
+            const int u = ld_dev(&q[f]);
+            const int st = start_len[u * 2], ln = start_len[u * 2 + 1];
+            const int su = sem[u];
+            int cnt = 0;
+            for (int e0 = 0; e0 < ln; e0 += 64) {
+                const int e = e0 + lane;
+                bool child = false;
+                if (e < ln) { const int j = idx[st + e]; child = (sem[j] == su) && (own[j] == s) && (ld_dev(&par[j]) == f); }
+                cnt += (int)__popcll(__ballot(child));
+            }
+            if (lane == 0) st_dev(&fc[f], cnt);
+        }
+        __syncthreads();
+        const int total = cl_block_scan(fc + lo, hi - lo, lds);
+        // pass C: children in (parent position, list order)
+        for (int f = lo + wv; f < hi; f += nw) {
+            const int u = ld_dev(&q[f]);
+            const int st = start_len[u * 2], ln = start_len[u * 2 + 1];
+            const int su = sem[u];
+            int pos = hi + ld_dev(&fc[f]);
+            for (int e0 = 0; e0 < ln; e0 += 64) {
+                const int e = e0 + lane;
+                bool child = false; int j = 0;
+                if (e < ln) { j = idx[st + e]; child = (sem[j] == su) && (own[j] == s) && (ld_dev(&par[j]) == f); }
+                const unsigned long long m = __ballot(child);
+                if (child) { const int p = pos + (int)__popcll(m & lt); if (p < size) st_dev(&q[p], j); }
+                pos += (int)__popcll(m);
+            }
+        }
+        __syncthreads();
+        lo = hi; hi += total;
+    }
+    for (int p = threadIdx.x; p < size; p += blockDim.x) {
+        cluster_idxs[(size_t)(base + p) * 2 + 0] = c;
+        cluster_idxs[(size_t)(base + p) * 2 + 1] = ld_dev(&q[p]);
+    }
+}
+
+extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
+                                   int n, void *ws, size_t ws_bytes, int *cluster_idxs, int *cluster_offsets,
+                                   int sumNPoint, int nCluster, void *stream) {
+    if (n <= 0) return 0;
+    ClWs w;
+    if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256, nb = (n + T - 1) / T;
+    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
+    if (nCluster > 0)
+        cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
+                                                         w.koff, w.sizes, w.par, w.queue, w.fcnt, cluster_idxs);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,51 @@
+// common.h -- shared helpers for the gfx950 kernels of libd3hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/d3hip.h"
+
+#define D3_WAVE 64
+
+#define D3_CHECK(expr)                                   \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return (int)_e;            \
+    } while (0)
+
+#define D3_LAUNCH_CHECK()                                \
+    do {                                                 \
+        hipError_t _e = hipGetLastError();               \
+        if (_e != hipSuccess) return (int)_e;            \
+    } while (0)
+
+static inline hipStream_t d3_stream(void *s) { return (hipStream_t)s; }
+
+static inline size_t d3_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// carve a typed region out of a workspace; returns nullptr when it does not fit
+struct D3Carver {
+    char *base; size_t cap; size_t off;
+    D3Carver(void *ws, size_t bytes) : base((char *)ws), cap(bytes), off(0) {}
+    template <typename T> T *take(size_t count) {
+        size_t bytes = d3_align(count * sizeof(T));
+        T *p = (T *)(base + off);
+        off += bytes;
+        return p;
+    }
+    bool ok() const { return base != nullptr && off <= cap; }
+};
+
+__device__ __forceinline__ int d3_lane() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ unsigned long long d3_lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// exclusive int32 scan / total via rocPRIM (implemented in scan_sort.hip)
+size_t d3_scan_temp_bytes(int n);
+int d3_exclusive_scan_i32(const int *in, int *out, int n, void *temp, size_t temp_bytes, hipStream_t s);
+size_t d3_sort_pairs_temp_bytes(int n);
+// stable ascending sort of (key,val) int32 pairs on the low `bits` bits of key
+int d3_sort_pairs_i32(const int *kin, int *kout, const int *vin, int *vout, int n, int bits, void *temp,
+                      size_t temp_bytes, hipStream_t s);

@@ -1,0 +1,41 @@
+// scan_sort.hip -- device-wide scan / stable radix sort used by the indexing ops.
+// rocPRIM (AMD's native primitives library) is used directly.
+#include "common.h"
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+
+size_t d3_scan_temp_bytes(int n) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const int *)nullptr, (int *)nullptr, 0, (size_t)(n > 0 ? n : 1),
+                            rocprim::plus<int>());
+    return d3_align(bytes + 256);
+}
+
+int d3_exclusive_scan_i32(const int *in, int *out, int n, void *temp, size_t temp_bytes, hipStream_t s) {
+    if (n <= 0) return 0;
+    size_t need = 0;
+    D3_CHECK(rocprim::exclusive_scan(nullptr, need, in, out, 0, (size_t)n, rocprim::plus<int>(), s));
+    if (need > temp_bytes) return D3_ERR_WORKSPACE;
+    D3_CHECK(rocprim::exclusive_scan(temp, need, in, out, 0, (size_t)n, rocprim::plus<int>(), s));
+    return 0;
+}
+
+size_t d3_sort_pairs_temp_bytes(int n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
+                              (int *)nullptr, (size_t)(n > 0 ? n : 1), 0, 32);
+    return d3_align(bytes + 256);
+}
+
+int d3_sort_pairs_i32(const int *kin, int *kout, const int *vin, int *vout, int n, int bits, void *temp,
+                      size_t temp_bytes, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (bits < 1) bits = 1;
+    if (bits > 31) bits = 31;
+    size_t need = 0;
+    D3_CHECK(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, (unsigned)bits, s));
+    if (need > temp_bytes) return D3_ERR_WORKSPACE;
+    D3_CHECK(rocprim::radix_sort_pairs(temp, need, kin, kout, vin, vout, (size_t)n, 0, (unsigned)bits, s));
+    return 0;
+}

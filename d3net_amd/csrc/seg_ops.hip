@@ -1,0 +1,212 @@
+// seg_ops.hip -- segment reductions over cluster point lists (gfx950).
+//
+// Replaces PG_OP.sec_mean/sec_min/sec_max, roipool_fp/bp and get_iou
+// (reference: lib/pointgroup_ops/src/sec_mean/sec_mean.cu:12-86, src/roipool/roipool.cu:12-57,
+//  src/get_iou/get_iou.cu:12-38).  The reference launches min(C,32) threads per segment and
+// walks the segment serially (3 threads for the only sec_* caller, C=3).  Here one 256-thread
+// workgroup owns a segment and reads it as one flat, fully coalesced stream of rows*C floats;
+// lane t always sees channel t % C (the active thread count is rounded down to a multiple of C).
+// All of these are HBM-bound: algorithmic bytes = 4*(rows*C) in + 4*(P*C) out + 4*(P+1).
+#include "common.h"
+
+#define SEG_THREADS 256
+
+// ----------------------------------------------------------------------------- min / max
+template <bool IS_MAX>
+__global__ __launch_bounds__(SEG_THREADS) void sec_minmax_kernel(const float *__restrict__ inp,
+                                                                const int *__restrict__ offsets,
+                                                                float *__restrict__ out, int nProposal, int C) {
+    __shared__ float red[SEG_THREADS];
+    const int active = (SEG_THREADS / C) * C;  // C <= SEG_THREADS checked on the host
+    const int t = threadIdx.x;
+    for (int p = blockIdx.x; p < nProposal; p += gridDim.x) {
+        const int start = offsets[p], end = offsets[p + 1];
+        const long long base = (long long)start * C;
+        const long long total = (long long)(end - start) * C;
+        float v = IS_MAX ? -INFINITY : INFINITY;  // reference: +-1e50 -> +-inf in float
+        if (t < active) {
+            for (long long f = t; f < total; f += active) {
+                float x = inp[base + f];
+                if (IS_MAX ? (x > v) : (x < v)) v = x;  // same comparison as the reference (NaN never wins)
+            }
+        }
+        red[t] = v;
+        __syncthreads();
+        if (t < C) {
+            float r = red[t];
+            for (int k = t + C; k < active; k += C) {
+                float x = red[k];
+                if (IS_MAX ? (x > r) : (x < r)) r = x;
+            }
+            out[(long long)p * C + t] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------- mean
+// The reference accumulates inp[i]/count term by term in row order (sec_mean.cu:19-23); fp32
+// addition is not associative, so to stay BIT-EXACT the additions are kept serial per channel:
+// the workgroup streams a chunk of the segment into LDS (coalesced, divisions in parallel) and
+// C lanes then add their column in row order.  Cost: one dependent fp32 add per row.
+#define MEAN_CHUNK 2048  // floats staged per round
+__global__ __launch_bounds__(SEG_THREADS) void sec_mean_kernel(const float *__restrict__ inp,
+                                                              const int *__restrict__ offsets,
+                                                              float *__restrict__ out, int nProposal, int C) {
+    __shared__ float stage[MEAN_CHUNK];
+    const int t = threadIdx.x;
+    const int rows_per_chunk = MEAN_CHUNK / C;
+    for (int p = blockIdx.x; p < nProposal; p += gridDim.x) {
+        const int start = offsets[p], end = offsets[p + 1];
+        const float count = (float)(end - start);
+        float mean = 0.f;
+        for (int r0 = start; r0 < end; r0 += rows_per_chunk) {
+            const int rows = min(rows_per_chunk, end - r0);
+            const int nflt = rows * C;
+            const long long base = (long long)r0 * C;
+            for (int f = t; f < nflt; f += SEG_THREADS) stage[f] = __fdiv_rn(inp[base + f], count);  // IEEE divide
+            __syncthreads();
+            if (t < C) {
+                for (int r = 0; r < rows; r++) mean = __fadd_rn(mean, stage[r * C + t]);
+            }
+            __syncthreads();
+        }
+        if (t < C) out[(long long)p * C + t] = mean;
+    }
+}
+
+// -------------------------------------------------------------------------------- roipool
+// max + FIRST argmax per (proposal, channel): strict '>' in ascending row order in the
+// reference (roipool.cu:20-25).  Per-thread partials keep the earliest row of their maximum;
+// the cross-thread combine breaks value ties towards the smaller row index.
+__global__ __launch_bounds__(SEG_THREADS) void roipool_fp_kernel(const float *__restrict__ feats,
+                                                                const int *__restrict__ offsets,
+                                                                float *__restrict__ out_feats,
+                                                                int *__restrict__ out_maxidx, int nProposal, int C) {
+    __shared__ float redv[SEG_THREADS];
+    __shared__ int redi[SEG_THREADS];
+    const int active = (SEG_THREADS / C) * C;
+    const int rows_per_pass = active / C;
+    const int t = threadIdx.x;
+    for (int p = blockIdx.x; p < nProposal; p += gridDim.x) {
+        const int start = offsets[p], end = offsets[p + 1];
+        float v = -INFINITY;
+        int a = -1;
+        if (t < active) {
+            const int c = t % C;
+            for (int r = start + t / C; r < end; r += rows_per_pass) {
+                float x = feats[(long long)r * C + c];
+                if (x > v) { v = x; a = r; }
+            }
+        }
+        redv[t] = v; redi[t] = a;
+        __syncthreads();
+        if (t < C) {
+            float bv = redv[t]; int bi = redi[t];
+            for (int k = t + C; k < active; k += C) {
+                float x = redv[k]; int xi = redi[k];
+                if (x > bv || (x == bv && xi < bi)) { bv = x; bi = xi; }
+            }
+            out_feats[(long long)p * C + t] = bv;
+            out_maxidx[(long long)p * C + t] = bi;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void roipool_bp_kernel(float *__restrict__ d_feats, const int *__restrict__ maxidx,
+                                  const float *__restrict__ d_out, long long total, int C) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int a = maxidx[e];
+    if (a >= 0) atomicAdd(&d_feats[(long long)a * C + (int)(e % C)], d_out[e]);
+}
+
+// -------------------------------------------------------------------------------- get_iou
+// Reference: every (proposal, instance) thread re-reads the whole proposal: O(S*nInst) loads.
+// Here a workgroup histograms its proposal's instance labels in LDS once (O(S) loads), then
+// forms the ratios.  `+ 1e-5` is a double literal in the reference, so the quotient is
+// evaluated in double and rounded to float (get_iou.cu:25).
+#define IOU_BINS 8192
+__global__ __launch_bounds__(SEG_THREADS) void get_iou_kernel(const int *__restrict__ proposals_idx,
+                                                             const int *__restrict__ offsets,
+                                                             const int64_t *__restrict__ instance_labels,
+                                                             const int *__restrict__ instance_pointnum,
+                                                             float *__restrict__ iou, int nInstance, int nProposal) {
+    __shared__ int hist[IOU_BINS];
+    const int t = threadIdx.x;
+    for (int p = blockIdx.x; p < nProposal; p += gridDim.x) {
+        const int start = offsets[p], end = offsets[p + 1];
+        const int proposal_total = end - start;
+        for (int w0 = 0; w0 < nInstance; w0 += IOU_BINS) {
+            const int wn = min(IOU_BINS, nInstance - w0);
+            for (int b = t; b < wn; b += SEG_THREADS) hist[b] = 0;
+            __syncthreads();
+            for (int i = start + t; i < end; i += SEG_THREADS) {
+                int lab = (int)instance_labels[proposals_idx[i]] - w0;  // (int) cast as in the reference
+                if (lab >= 0 && lab < wn) atomicAdd(&hist[lab], 1);
+            }
+            __syncthreads();
+            for (int b = t; b < wn; b += SEG_THREADS) {
+                int inter = hist[b];
+                int instance_total = instance_pointnum[w0 + b];
+                double denom = (double)(float)(proposal_total + instance_total - inter) + 1e-5;
+                iou[(long long)p * nInstance + w0 + b] = (float)((double)(float)inter / denom);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ C entry points
+static inline int seg_grid(int nProposal) { return nProposal < 65535 ? nProposal : 65535; }
+
+extern "C" int d3_sec_mean(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream) {
+    if (nProposal <= 0) return 0;
+    if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
+    sec_mean_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_sec_min(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream) {
+    if (nProposal <= 0) return 0;
+    if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
+    sec_minmax_kernel<false><<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_sec_max(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream) {
+    if (nProposal <= 0) return 0;
+    if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
+    sec_minmax_kernel<true><<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_roipool_fp(const float *feats, const int *proposals_offset, float *output_feats,
+                             int *output_maxidx, int nProposal, int C, void *stream) {
+    if (nProposal <= 0) return 0;
+    if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
+    roipool_fp_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(feats, proposals_offset, output_feats,
+                                                                               output_maxidx, nProposal, C);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_roipool_bp(float *d_feats, const int *proposals_offset, const int *output_maxidx,
+                             const float *d_output_feats, int nProposal, int C, void *stream) {
+    (void)proposals_offset;
+    long long total = (long long)nProposal * C;
+    if (total <= 0) return 0;
+    int blocks = (int)((total + 255) / 256);
+    roipool_bp_kernel<<<blocks, 256, 0, d3_stream(stream)>>>(d_feats, output_maxidx, d_output_feats, total, C);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_get_iou(const int *proposals_idx, const int *proposals_offset, const int64_t *instance_labels,
+                          const int *instance_pointnum, float *proposals_iou, int nInstance, int nProposal,
+                          void *stream) {
+    if (nProposal <= 0 || nInstance <= 0) return 0;
+    get_iou_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(
+        proposals_idx, proposals_offset, instance_labels, instance_pointnum, proposals_iou, nInstance, nProposal);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

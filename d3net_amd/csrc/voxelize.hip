@@ -1,0 +1,299 @@
+// voxelize.hip -- point<->voxel pooling and the point->voxel index build (gfx950).
+//
+// Replaces PG_OP.voxelize_fp/bp, point_recover_fp/bp (reference:
+// lib/pointgroup_ops/src/voxelize/voxelize.cu:10-53, voxelize.cpp:155-202) and the CPU
+// hash pass PG_OP.voxelize_idx (voxelize.cpp:10-152), which the reference runs single-threaded
+// on the host inside the forward (model/pointgroup.py:166-169).
+//
+// Pooling kernels: one thread per (voxel row, channel) element of the flat (M*C) output, so
+// stores are fully coalesced and each gathered point row is read as a contiguous C-float run.
+// The sum over a voxel's points is kept in rule order with separately rounded mul and add
+// (the reference does atomicAdd(out, multiplier*inp) with one thread per channel, i.e. the
+// same serial order), so the result is bit-exact against the oracle.
+// HBM bound: bytes = 4*N*C (points) + 4*M*(maxActive+1) (rules) + 4*M*C (voxels).
+#include "common.h"
+
+// ------------------------------------------------------------------------- pooling kernels
+__global__ void voxelize_fp_kernel(const float *__restrict__ feats, float *__restrict__ out,
+                                   const int *__restrict__ rules, long long total, int maxActive, int nPlanes,
+                                   bool average) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int row = (int)(e / nPlanes), plane = (int)(e % nPlanes);
+    const int *r = rules + (long long)row * (maxActive + 1);
+    const int nActive = r[0];
+    const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
+    float acc = out[e];
+    for (int i = 1; i <= nActive; i++)
+        acc = __fadd_rn(acc, __fmul_rn(multiplier, feats[(long long)r[i] * nPlanes + plane]));
+    out[e] = acc;
+}
+
+// scatter: d_feats[r[i], plane] += multiplier * d_out[row, plane]   (voxelize.cu:35-53)
+__global__ void voxelize_bp_kernel(const float *__restrict__ d_out, float *__restrict__ d_feats,
+                                   const int *__restrict__ rules, long long total, int maxActive, int nPlanes,
+                                   bool average) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int row = (int)(e / nPlanes), plane = (int)(e % nPlanes);
+    const int *r = rules + (long long)row * (maxActive + 1);
+    const int nActive = r[0];
+    const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
+    const float g = __fmul_rn(multiplier, d_out[e]);
+    for (int i = 1; i <= nActive; i++) atomicAdd(&d_feats[(long long)r[i] * nPlanes + plane], g);
+}
+
+static int launch_fp(const float *feats, float *out, const int *rules, int nActive, int maxActive, int nPlane,
+                     bool average, void *stream) {
+    long long total = (long long)nActive * nPlane;
+    if (total <= 0) return 0;
+    voxelize_fp_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(feats, out, rules, total, maxActive,
+                                                                                nPlane, average);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_bp(const float *d_out, float *d_feats, const int *rules, int nActive, int maxActive, int nPlane,
+                     bool average, void *stream) {
+    long long total = (long long)nActive * nPlane;
+    if (total <= 0) return 0;
+    voxelize_bp_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(d_out, d_feats, rules, total,
+                                                                                maxActive, nPlane, average);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_voxelize_fp(const float *feats, float *output_feats, const int *output_map, int mode, int nActive,
+                              int maxActive, int nPlane, void *stream) {
+    return launch_fp(feats, output_feats, output_map, nActive, maxActive, nPlane, mode == 4, stream);
+}
+extern "C" int d3_voxelize_bp(const float *d_output_feats, float *d_feats, const int *output_map, int mode,
+                              int nActive, int maxActive, int nPlane, void *stream) {
+    return launch_bp(d_output_feats, d_feats, output_map, nActive, maxActive, nPlane, mode == 4, stream);
+}
+// point_recover_fp == voxelize_bp(average=false); point_recover_bp == voxelize_fp(average=false)
+// (reference: voxelize.cpp:181-202)
+extern "C" int d3_point_recover_fp(const float *feats, float *output_feats, const int *idx_map, int nActive,
+                                   int maxActive, int nPlane, void *stream) {
+    return launch_bp(feats, output_feats, idx_map, nActive, maxActive, nPlane, false, stream);
+}
+extern "C" int d3_point_recover_bp(const float *d_output_feats, float *d_feats, const int *idx_map, int nActive,
+                                   int maxActive, int nPlane, void *stream) {
+    return launch_fp(d_output_feats, d_feats, idx_map, nActive, maxActive, nPlane, false, stream);
+}
+
+// ------------------------------------------------------------------------------ voxelize_idx
+// Device restatement of voxelize_idx<3>: voxel ids in FIRST-OCCURRENCE order of the points.
+//   1. open-addressing hash insert of a packed 64-bit (batch,x,y,z) key; each slot keeps the
+//      minimum point index that hit it (= the voxel's first point);
+//   2. flag the first points, exclusive-scan the flags -> voxel id (ascending first point =
+//      first-occurrence order, exactly what `nActive++` produces in voxelize.cpp:78,99);
+//   3. p2v[i] = id of i's slot; per-voxel counts; maxActive = max count;
+//   4. (fill) stable radix sort of (voxel id, point id) -> point lists in ascending point order
+//      (= push_back order, voxelize.cpp:81,103), then the rule rows and the voxel coordinates
+//      (coordinate row of the first listed point, voxelize.cpp:34-49).
+#define VI_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct VoxIdxWs {
+    unsigned long long *keys;  // cap
+    int *first;                // cap   min point index per slot
+    int *slot_vid;             // cap   voxel id per slot
+    int *slot_of;              // n     slot of each point
+    int *flag;                 // n     1 if point is the first of its voxel
+    int *scan;                 // n     exclusive scan of flag
+    int *cnt;                  // n     points per voxel (first M entries used)
+    int *vstart;               // n     exclusive scan of cnt
+    int *sorted_pts;           // n
+    int *sorted_keys;          // n
+    int *scalars;              // [0]=M-helper [1]=maxActive [2]=range error
+    void *temp; size_t temp_bytes;
+    size_t cap;
+};
+
+static size_t vi_cap(int n) { size_t c = 1024; while (c < (size_t)n * 2) c <<= 1; return c; }
+
+static bool vi_carve(void *ws, size_t ws_bytes, int n, VoxIdxWs &w) {
+    D3Carver c(ws, ws_bytes);
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    w.cap = vi_cap(n);
+    w.keys = c.take<unsigned long long>(w.cap);
+    w.first = c.take<int>(w.cap);
+    w.slot_vid = c.take<int>(w.cap);
+    w.slot_of = c.take<int>(nn);
+    w.flag = c.take<int>(nn);
+    w.scan = c.take<int>(nn);
+    w.cnt = c.take<int>(nn);
+    w.vstart = c.take<int>(nn);
+    w.sorted_pts = c.take<int>(nn);
+    w.sorted_keys = c.take<int>(nn);
+    w.scalars = c.take<int>(64);
+    size_t t1 = d3_scan_temp_bytes(n), t2 = d3_sort_pairs_temp_bytes(n);
+    w.temp_bytes = t1 > t2 ? t1 : t2;
+    w.temp = c.take<char>(w.temp_bytes);
+    return ws == nullptr ? false : c.ok();
+}
+
+extern "C" size_t d3_voxelize_idx_ws_bytes(int n) {
+    VoxIdxWs w;
+    D3Carver c(nullptr, 0);
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    size_t cap = vi_cap(n);
+    c.take<unsigned long long>(cap); c.take<int>(cap); c.take<int>(cap);
+    for (int i = 0; i < 7; i++) c.take<int>(nn);
+    c.take<int>(64);
+    size_t t1 = d3_scan_temp_bytes(n), t2 = d3_sort_pairs_temp_bytes(n);
+    c.take<char>(t1 > t2 ? t1 : t2);
+    (void)w;
+    return c.off + 256;
+}
+
+__device__ __forceinline__ unsigned long long vi_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+// key layout: batch 19 bits | x 15 | y 15 | z 15 (x,y,z biased by 2^14)
+__device__ __forceinline__ bool vi_pack(const int64_t *c, int ncols, unsigned long long &key) {
+    int b = 0, x, y, z;
+    if (ncols == 4) { b = (int)c[0]; x = (int)c[1]; y = (int)c[2]; z = (int)c[3]; }  // long -> Int truncation
+    else { x = (int)c[0]; y = (int)c[1]; z = (int)c[2]; }
+    const int B = 1 << 14;
+    bool ok = (b >= 0 && b < (1 << 19)) && (x >= -B && x < B) && (y >= -B && y < B) && (z >= -B && z < B);
+    key = ((unsigned long long)(unsigned)b << 45) | ((unsigned long long)(unsigned)(x + B) << 30) |
+          ((unsigned long long)(unsigned)(y + B) << 15) | (unsigned long long)(unsigned)(z + B);
+    return ok;
+}
+
+__global__ void vi_init_kernel(unsigned long long *keys, int *first, size_t cap, int *cnt, int n, int *scalars) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = VI_EMPTY; first[i] = 0x7FFFFFFF; }
+    if (i < (size_t)n) cnt[i] = 0;
+    if (i < 8) scalars[i] = 0;
+}
+
+__global__ void vi_insert_kernel(const int64_t *__restrict__ coords, int n, int ncols, unsigned long long *keys,
+                                 int *first, size_t cap, int *slot_of, int *scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key;
+    if (!vi_pack(coords + (size_t)i * ncols, ncols, key)) { scalars[2] = 1; key &= ~(1ull << 63); }
+    size_t slot = vi_hash(key) & (cap - 1);
+    for (size_t probe = 0; probe < cap; probe++) {
+        unsigned long long prev = atomicCAS(&keys[slot], VI_EMPTY, key);
+        if (prev == VI_EMPTY || prev == key) {
+            atomicMin(&first[slot], i);
+            slot_of[i] = (int)slot;
+            return;
+        }
+        slot = (slot + 1) & (cap - 1);
+    }
+    scalars[2] = 2;  // table full (cannot happen with cap >= 2n)
+    slot_of[i] = 0;
+}
+
+__global__ void vi_flag_kernel(const int *first, const int *slot_of, int *flag, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (first[slot_of[i]] == i) ? 1 : 0;
+}
+__global__ void vi_assign_kernel(const int *flag, const int *scan, const int *slot_of, int *slot_vid, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) slot_vid[slot_of[i]] = scan[i];
+}
+__global__ void vi_p2v_kernel(const int *slot_of, const int *slot_vid, int *input_map, int *cnt, int n,
+                              int *scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int v = slot_vid[slot_of[i]];
+    input_map[i] = v;
+    int c = atomicAdd(&cnt[v], 1) + 1;
+    atomicMax(&scalars[1], c);
+}
+__global__ void vi_total_kernel(const int *flag, const int *scan, int n, int *scalars) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) scalars[0] = n > 0 ? scan[n - 1] + flag[n - 1] : 0;
+}
+
+extern "C" int d3_voxelize_idx_count(const int64_t *coords, int n, int ncols, int mode, int *input_map, void *ws,
+                                     size_t ws_bytes, int *M_host, int *maxActive_host, void *stream) {
+    if (ncols != 3 && ncols != 4) return D3_ERR_ARG;
+    if (mode < 0 || mode > 4) return D3_ERR_ARG;
+    *M_host = 0; *maxActive_host = 1;
+    if (n <= 0) return 0;
+    VoxIdxWs w;
+    if (!vi_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256;
+    size_t initn = w.cap > (size_t)n ? w.cap : (size_t)n;
+    vi_init_kernel<<<(int)((initn + T - 1) / T), T, 0, s>>>(w.keys, w.first, w.cap, w.cnt, n, w.scalars);
+    const int nb = (n + T - 1) / T;
+    vi_insert_kernel<<<nb, T, 0, s>>>(coords, n, ncols, w.keys, w.first, w.cap, w.slot_of, w.scalars);
+    vi_flag_kernel<<<nb, T, 0, s>>>(w.first, w.slot_of, w.flag, n);
+    int rc = d3_exclusive_scan_i32(w.flag, w.scan, n, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    vi_assign_kernel<<<nb, T, 0, s>>>(w.flag, w.scan, w.slot_of, w.slot_vid, n);
+    vi_p2v_kernel<<<nb, T, 0, s>>>(w.slot_of, w.slot_vid, input_map, w.cnt, n, w.scalars);
+    vi_total_kernel<<<1, 64, 0, s>>>(w.flag, w.scan, n, w.scalars);
+    D3_LAUNCH_CHECK();
+    int h[3];
+    D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipStreamSynchronize(s));
+    if (h[2] == 1) return D3_ERR_RANGE;
+    if (h[2] == 2) return D3_ERR_OVERFLOW;
+    *M_host = h[0];
+    *maxActive_host = (mode == 3 || mode == 4) ? (h[1] > 1 ? h[1] : 1) : 1;  // voxelize.cpp:141-145
+    return 0;
+}
+
+// one thread per element of the (M, maxActive+1) rule table: coalesced stores
+__global__ void vi_rules_kernel(int mode, const int *__restrict__ cnt, const int *__restrict__ vstart,
+                                const int *__restrict__ sorted_pts, int *__restrict__ out_map, long long total,
+                                int maxActive) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int w = maxActive + 1;
+    const int v = (int)(e / w), j = (int)(e % w);
+    const int c = cnt[v];
+    const int *pts = sorted_pts + vstart[v];
+    int val;
+    if (mode == 3 || mode == 4) val = (j == 0) ? c : (j - 1 < c ? pts[j - 1] : 0);  // zero padded (voxelize.cpp:151)
+    else val = (j == 0) ? 1 : ((mode == 2) ? pts[c - 1] : pts[0]);  // mode 1: front(), mode 2: back() (:130-140)
+    out_map[e] = val;
+}
+// voxel coordinate = coordinate row of the first listed point (voxelize_outputmap, voxelize.cpp:34-49)
+__global__ void vi_coords_kernel(const int64_t *__restrict__ coords, int ncols, int mode,
+                                 const int *__restrict__ cnt, const int *__restrict__ vstart,
+                                 const int *__restrict__ sorted_pts, int64_t *__restrict__ out_coords, int M) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * ncols) return;
+    const int v = e / ncols, j = e % ncols;
+    const int *pts = sorted_pts + vstart[v];
+    const int firstListed = (mode == 2) ? pts[cnt[v] - 1] : pts[0];
+    out_coords[e] = coords[(size_t)firstListed * ncols + j];
+}
+
+__global__ void vi_iota_kernel(int *a, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
+extern "C" int d3_voxelize_idx_fill(const int64_t *coords, int n, int ncols, int mode, const int *input_map,
+                                    void *ws, size_t ws_bytes, int64_t *output_coords, int *output_map, int M,
+                                    int maxActive, void *stream) {
+    if (n <= 0 || M <= 0) return 0;
+    VoxIdxWs w;
+    if (!vi_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256;
+    int rc = d3_exclusive_scan_i32(w.cnt, w.vstart, M, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    // stable sort of point ids by voxel id; w.flag is reused as the iota payload
+    vi_iota_kernel<<<(n + T - 1) / T, T, 0, s>>>(w.flag, n);
+    int bits = 1; while ((1ll << bits) < (long long)M && bits < 31) bits++;
+    rc = d3_sort_pairs_i32(input_map, w.sorted_keys, w.flag, w.sorted_pts, n, bits, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    long long total = (long long)M * (maxActive + 1);
+    vi_rules_kernel<<<(int)((total + T - 1) / T), T, 0, s>>>(mode, w.cnt, w.vstart, w.sorted_pts, output_map, total,
+                                                           maxActive);
+    vi_coords_kernel<<<(M * ncols + T - 1) / T, T, 0, s>>>(coords, ncols, mode, w.cnt, w.vstart, w.sorted_pts,
+                                                         output_coords, M);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

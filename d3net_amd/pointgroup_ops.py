@@ -1,0 +1,361 @@
+"""PointGroup operators on MI355X -- same names, arguments and return values as the reference's
+`lib.pointgroup_ops.functions.pointgroup_ops` (reference:
+lib/pointgroup_ops/functions/pointgroup_ops.py:39,75,112,150,182,221,253,281,309,337), each one a
+thin autograd wrapper over the C ABI of libd3hip.so (include/d3hip.h).
+
+Differences from the reference, all at the edges:
+  * `voxelization_idx` and `bfs_cluster` run on the device (the reference runs them on the host).
+    CPU inputs are accepted as in the reference -- they are moved to the current device, processed
+    there, and CPU tensors are returned; device inputs stay on the device (the fast path used by
+    d3net_amd.pointgroup).
+  * `ballquery_batch_p` is count -> allocate -> fill instead of guess-and-retry; `start` values
+    are the exclusive prefix sum of `len` (the reference's depend on thread scheduling).
+There is no CPU implementation here: without a GPU these functions raise.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check
+
+_ws_cache = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _workspace(nbytes, device, tag):
+    """A cached, growing device scratch buffer per (device, tag)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _device_of(*tensors):
+    for t in tensors:
+        if t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise _lib.D3Error("d3net_amd.pointgroup_ops needs a GPU (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Voxelization_Idx(Function):
+    @staticmethod
+    def forward(ctx, coords, batchsize, mode=4):
+        """
+        :param coords:  long (N, dimension + 1) or (N, dimension), dimension = 3
+        :param batchsize: int (unused by the algorithm, as in the reference beyond pre-sizing)
+        :param mode: int 4=mean
+        :return: output_coords long (M, dimension + 1); input_map int (N,); output_map int (M, maxActive + 1)
+        """
+        assert coords.is_contiguous()
+        assert coords.dtype == torch.int64
+        on_cpu = not coords.is_cuda
+        dev = _device_of(coords)
+        c = coords.to(dev) if on_cpu else coords
+        N, ncols = c.shape
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            input_map = torch.zeros(N, dtype=torch.int32, device=dev)
+            ws = _workspace(L.d3_voxelize_idx_ws_bytes(N), dev, "vi")
+            M, mA = C.c_int(0), C.c_int(1)
+            check(L.d3_voxelize_idx_count(_ptr(c), N, ncols, int(mode), _ptr(input_map), _ptr(ws), ws.numel(),
+                                          C.byref(M), C.byref(mA), _stream()), "voxelize_idx_count")
+            M, mA = M.value, mA.value
+            output_coords = torch.zeros((M, ncols), dtype=torch.int64, device=dev)
+            output_map = torch.zeros((M, mA + 1), dtype=torch.int32, device=dev)
+            check(L.d3_voxelize_idx_fill(_ptr(c), N, ncols, int(mode), _ptr(input_map), _ptr(ws), ws.numel(),
+                                         _ptr(output_coords), _ptr(output_map), M, mA, _stream()),
+                  "voxelize_idx_fill")
+        if on_cpu:
+            return output_coords.cpu(), input_map.cpu(), output_map.cpu()
+        return output_coords, input_map, output_map
+
+    @staticmethod
+    def backward(ctx, a=None, b=None, c=None):
+        return None
+
+
+voxelization_idx = Voxelization_Idx.apply
+
+
+class Voxelization(Function):
+    @staticmethod
+    def forward(ctx, feats, map_rule, mode=4):
+        """
+        :param map_rule: cuda int (M, maxActive + 1)
+        :param feats: cuda float (N, C)
+        :return: output_feats: cuda float (M, C)
+        """
+        assert map_rule.is_contiguous() and map_rule.is_cuda and map_rule.dtype == torch.int32
+        assert feats.is_contiguous() and feats.is_cuda and feats.dtype == torch.float32
+        N, Cc = feats.size()
+        M = map_rule.size(0)
+        maxActive = map_rule.size(1) - 1
+        output_feats = torch.zeros((M, Cc), dtype=torch.float32, device=feats.device)
+        ctx.for_backwards = (map_rule, mode, maxActive, N)
+        with torch.cuda.device(feats.device):
+            check(_lib.lib().d3_voxelize_fp(_ptr(feats), _ptr(output_feats), _ptr(map_rule), int(mode), M, maxActive,
+                                            Cc, _stream()), "voxelize_fp")
+        return output_feats
+
+    @staticmethod
+    def backward(ctx, d_output_feats):
+        map_rule, mode, maxActive, N = ctx.for_backwards
+        M, Cc = d_output_feats.size()
+        d_output_feats = d_output_feats.contiguous()
+        d_feats = torch.zeros((N, Cc), dtype=torch.float32, device=d_output_feats.device)
+        with torch.cuda.device(d_feats.device):
+            check(_lib.lib().d3_voxelize_bp(_ptr(d_output_feats), _ptr(d_feats), _ptr(map_rule), int(mode), M,
+                                            maxActive, Cc, _stream()), "voxelize_bp")
+        return d_feats, None, None
+
+
+voxelization = Voxelization.apply
+
+
+class PointRecover(Function):
+    @staticmethod
+    def forward(ctx, feats, map_rule, nPoint):
+        """
+        :param feats: cuda float M * C
+        :param map_rule: cuda int M * (maxActive + 1)
+        :param nPoint: int
+        :return: output_feats: cuda float N * C
+        """
+        assert map_rule.is_contiguous() and map_rule.is_cuda
+        assert feats.is_contiguous() and feats.is_cuda
+        M, Cc = feats.size()
+        maxActive = map_rule.size(1) - 1
+        output_feats = torch.zeros((nPoint, Cc), dtype=torch.float32, device=feats.device)
+        ctx.for_backwards = (map_rule, maxActive, M)
+        with torch.cuda.device(feats.device):
+            check(_lib.lib().d3_point_recover_fp(_ptr(feats), _ptr(output_feats), _ptr(map_rule), M, maxActive, Cc,
+                                                 _stream()), "point_recover_fp")
+        return output_feats
+
+    @staticmethod
+    def backward(ctx, d_output_feats):
+        map_rule, maxActive, M = ctx.for_backwards
+        N, Cc = d_output_feats.size()
+        d_output_feats = d_output_feats.contiguous()
+        d_feats = torch.zeros((M, Cc), dtype=torch.float32, device=d_output_feats.device)
+        with torch.cuda.device(d_feats.device):
+            check(_lib.lib().d3_point_recover_bp(_ptr(d_output_feats), _ptr(d_feats), _ptr(map_rule), M, maxActive,
+                                                 Cc, _stream()), "point_recover_bp")
+        return d_feats, None, None
+
+
+point_recover = PointRecover.apply
+
+
+class BallQueryBatchP(Function):
+    @staticmethod
+    def forward(ctx, coords, batch_idxs, batch_offsets, radius, meanActive):
+        """
+        :param coords: (n, 3) float
+        :param batch_idxs: (n) int
+        :param batch_offsets: (B+1) int
+        :param radius: float
+        :param meanActive: int (only a sizing hint in the reference; unused here)
+        :return: idx (nActive), int
+        :return: start_len (n, 2), int
+        """
+        n = coords.size(0)
+        assert coords.is_contiguous() and coords.is_cuda and coords.dtype == torch.float32
+        assert batch_idxs.is_contiguous() and batch_idxs.is_cuda and batch_idxs.dtype == torch.int32
+        assert batch_offsets.is_contiguous() and batch_offsets.is_cuda and batch_offsets.dtype == torch.int32
+        dev = coords.device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            start_len = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+            ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bq")
+            nActive = C.c_int(0)
+            check(L.d3_ballquery_count(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius),
+                                       _ptr(start_len), _ptr(ws), ws.numel(), C.byref(nActive), _stream()),
+                  "ballquery_count")
+            nActive = nActive.value
+            idx = torch.zeros(max(nActive, 1), dtype=torch.int32, device=dev)
+            check(L.d3_ballquery_fill(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius),
+                                      _ptr(start_len), _ptr(ws), ws.numel(), _ptr(idx), nActive, _stream()),
+                  "ballquery_fill")
+        return idx[:nActive], start_len
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None
+
+
+ballquery_batch_p = BallQueryBatchP.apply
+
+
+class BFSCluster(Function):
+    @staticmethod
+    def forward(ctx, semantic_label, ball_query_idxs, start_len, threshold):
+        """
+        :param semantic_label: (N), int
+        :param ball_query_idxs: (nActive), int
+        :param start_len: (N, 2), int
+        :return: cluster_idxs:  int (sumNPoint, 2), dim 0 for cluster_id, dim 1 for corresponding point idxs in N
+        :return: cluster_offsets: int (nCluster + 1)
+        """
+        N = start_len.size(0)
+        assert semantic_label.is_contiguous() and semantic_label.dtype == torch.int32
+        assert ball_query_idxs.is_contiguous() and ball_query_idxs.dtype == torch.int32
+        assert start_len.is_contiguous() and start_len.dtype == torch.int32
+        on_cpu = not semantic_label.is_cuda
+        dev = _device_of(semantic_label, ball_query_idxs, start_len)
+        sem, idx, sl = (t.to(dev) for t in (semantic_label, ball_query_idxs, start_len))
+        if idx.numel() == 0:
+            idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            ws = _workspace(L.d3_bfs_cluster_ws_bytes(N), dev, "cl")
+            S, P = C.c_int(0), C.c_int(0)
+            check(L.d3_bfs_cluster_count(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(),
+                                         C.byref(S), C.byref(P), _stream()), "bfs_cluster_count")
+            S, P = S.value, P.value
+            cluster_idxs = torch.zeros((S, 2), dtype=torch.int32, device=dev)
+            cluster_offsets = torch.zeros(P + 1, dtype=torch.int32, device=dev)
+            check(L.d3_bfs_cluster_fill(_ptr(sem), _ptr(idx), _ptr(sl), N, _ptr(ws), ws.numel(), _ptr(cluster_idxs),
+                                        _ptr(cluster_offsets), S, P, _stream()), "bfs_cluster_fill")
+        if on_cpu:
+            return cluster_idxs.cpu(), cluster_offsets.cpu()
+        return cluster_idxs, cluster_offsets
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None
+
+
+bfs_cluster = BFSCluster.apply
+
+
+class RoiPool(Function):
+    @staticmethod
+    def forward(ctx, feats, proposals_offset):
+        """
+        :param feats: (sumNPoint, C) float
+        :param proposals_offset: (nProposal + 1) int
+        :return: output_feats (nProposal, C) float
+        """
+        nProposal = proposals_offset.size(0) - 1
+        sumNPoint, Cc = feats.size()
+        assert feats.is_contiguous() and feats.is_cuda and feats.dtype == torch.float32
+        assert proposals_offset.is_contiguous() and proposals_offset.is_cuda and proposals_offset.dtype == torch.int32
+        output_feats = torch.zeros((nProposal, Cc), dtype=torch.float32, device=feats.device)
+        output_maxidx = torch.zeros((nProposal, Cc), dtype=torch.int32, device=feats.device)
+        with torch.cuda.device(feats.device):
+            check(_lib.lib().d3_roipool_fp(_ptr(feats), _ptr(proposals_offset), _ptr(output_feats),
+                                           _ptr(output_maxidx), nProposal, Cc, _stream()), "roipool_fp")
+        ctx.for_backwards = (output_maxidx, proposals_offset, sumNPoint)
+        return output_feats
+
+    @staticmethod
+    def backward(ctx, d_output_feats):
+        nProposal, Cc = d_output_feats.size()
+        output_maxidx, proposals_offset, sumNPoint = ctx.for_backwards
+        d_output_feats = d_output_feats.contiguous()
+        d_feats = torch.zeros((sumNPoint, Cc), dtype=torch.float32, device=d_output_feats.device)
+        with torch.cuda.device(d_feats.device):
+            check(_lib.lib().d3_roipool_bp(_ptr(d_feats), _ptr(proposals_offset), _ptr(output_maxidx),
+                                           _ptr(d_output_feats), nProposal, Cc, _stream()), "roipool_bp")
+        return d_feats, None
+
+
+roipool = RoiPool.apply
+
+
+class GetIoU(Function):
+    @staticmethod
+    def forward(ctx, proposals_idx, proposals_offset, instance_labels, instance_pointnum):
+        """
+        :param proposals_idx: (sumNPoint), int
+        :param proposals_offset: (nProposal + 1), int
+        :param instance_labels: (N), long, 0~total_nInst-1, -1
+        :param instance_pointnum: (total_nInst), int
+        :return: proposals_iou: (nProposal, total_nInst), float
+        """
+        nInstance = instance_pointnum.size(0)
+        nProposal = proposals_offset.size(0) - 1
+        assert proposals_idx.is_contiguous() and proposals_idx.is_cuda and proposals_idx.dtype == torch.int32
+        assert proposals_offset.is_contiguous() and proposals_offset.is_cuda and proposals_offset.dtype == torch.int32
+        assert instance_labels.is_contiguous() and instance_labels.is_cuda and instance_labels.dtype == torch.int64
+        assert instance_pointnum.is_contiguous() and instance_pointnum.is_cuda and instance_pointnum.dtype == torch.int32
+        proposals_iou = torch.zeros((nProposal, nInstance), dtype=torch.float32, device=proposals_idx.device)
+        with torch.cuda.device(proposals_idx.device):
+            check(_lib.lib().d3_get_iou(_ptr(proposals_idx), _ptr(proposals_offset), _ptr(instance_labels),
+                                        _ptr(instance_pointnum), _ptr(proposals_iou), nInstance, nProposal,
+                                        _stream()), "get_iou")
+        return proposals_iou
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+get_iou = GetIoU.apply
+
+
+def _sec(name, inp, offsets):
+    nProposal = offsets.size(0) - 1
+    Cc = inp.size(1)
+    assert inp.is_contiguous() and inp.is_cuda and inp.dtype == torch.float32
+    assert offsets.is_contiguous() and offsets.is_cuda and offsets.dtype == torch.int32
+    out = torch.zeros((nProposal, Cc), dtype=torch.float32, device=inp.device)
+    with torch.cuda.device(inp.device):
+        check(getattr(_lib.lib(), name)(_ptr(inp), _ptr(offsets), _ptr(out), nProposal, Cc, _stream()), name)
+    return out
+
+
+class SecMean(Function):
+    @staticmethod
+    def forward(ctx, inp, offsets):
+        """:param inp: (N, C) float  :param offsets: (nProposal + 1) int  :return: out (nProposal, C) float"""
+        return _sec("d3_sec_mean", inp, offsets)
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+sec_mean = SecMean.apply
+
+
+class SecMin(Function):
+    @staticmethod
+    def forward(ctx, inp, offsets):
+        """:param inp: (N, C) float  :param offsets: (nProposal + 1) int  :return: out (nProposal, C) float"""
+        return _sec("d3_sec_min", inp, offsets)
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+sec_min = SecMin.apply
+
+
+class SecMax(Function):
+    @staticmethod
+    def forward(ctx, inp, offsets):
+        """:param inp: (N, C) float  :param offsets: (nProposal + 1) int  :return: out (nProposal, C) float"""
+        return _sec("d3_sec_max", inp, offsets)
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+sec_max = SecMax.apply

@@ -1,0 +1,109 @@
+/*
+ * d3hip.h -- C ABI of libd3hip.so, the MI355X (gfx950) implementation of D3Net's
+ * PointGroup hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     stream-ordered on it;
+ *   - return value: 0 = success, >0 = hipError_t, <0 = D3_ERR_* below;
+ *   - no hidden allocation: ops that need scratch take `ws`/`ws_bytes` and have a
+ *     `*_ws_bytes()` query; data-dependent output sizes use a two-phase
+ *     `*_count` (writes sizes to `*_host`, synchronises the stream) / `*_fill` pair so
+ *     the caller allocates, exactly as the reference's python layer does
+ *     (reference: lib/pointgroup_ops/functions/pointgroup_ops.py).
+ *
+ * Each entry point cites the reference interface it replaces.  Paths are relative to
+ * the reference root; `PG_OP.x` is the pybind symbol of
+ * lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-24.
+ */
+#ifndef D3HIP_H
+#define D3HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3_ERR_WORKSPACE (-1) /* ws_bytes too small                          */
+#define D3_ERR_RANGE     (-2) /* coordinate / batch index outside key range  */
+#define D3_ERR_ARG       (-3) /* unsupported argument (mode, channel count)  */
+#define D3_ERR_OVERFLOW  (-4) /* hash table / queue overflow                 */
+
+int d3_version(void);
+const char *d3_arch(void); /* "gfx950" */
+
+/* ---- segment ops ------------------------------------------------------------------ */
+/* PG_OP.sec_mean / sec_min / sec_max  (lib/pointgroup_ops/src/sec_mean/sec_mean.cu:12-86) */
+int d3_sec_mean(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
+int d3_sec_min(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
+int d3_sec_max(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
+/* PG_OP.roipool_fp / roipool_bp  (src/roipool/roipool.cu:12-57) */
+int d3_roipool_fp(const float *feats, const int *proposals_offset, float *output_feats, int *output_maxidx,
+                  int nProposal, int C, void *stream);
+int d3_roipool_bp(float *d_feats, const int *proposals_offset, const int *output_maxidx,
+                  const float *d_output_feats, int nProposal, int C, void *stream);
+/* PG_OP.get_iou  (src/get_iou/get_iou.cu:12-38) */
+int d3_get_iou(const int *proposals_idx, const int *proposals_offset, const int64_t *instance_labels,
+               const int *instance_pointnum, float *proposals_iou, int nInstance, int nProposal, void *stream);
+
+/* ---- voxelize --------------------------------------------------------------------- */
+/* PG_OP.voxelize_fp / voxelize_bp / point_recover_fp / point_recover_bp
+ * (src/voxelize/voxelize.cu:10-53, src/voxelize/voxelize.cpp:155-202).  Outputs are
+ * accumulated into (the caller zero-fills them, as functions/pointgroup_ops.py:57,70 do). */
+int d3_voxelize_fp(const float *feats, float *output_feats, const int *output_map, int mode, int nActive,
+                   int maxActive, int nPlane, void *stream);
+int d3_voxelize_bp(const float *d_output_feats, float *d_feats, const int *output_map, int mode, int nActive,
+                   int maxActive, int nPlane, void *stream);
+int d3_point_recover_fp(const float *feats, float *output_feats, const int *idx_map, int nActive,
+                        int maxActive, int nPlane, void *stream);
+int d3_point_recover_bp(const float *d_output_feats, float *d_feats, const int *idx_map, int nActive,
+                        int maxActive, int nPlane, void *stream);
+
+/* PG_OP.voxelize_idx  (src/voxelize/voxelize.cpp:10-152), on the device, two-phase.
+ * coords (n, ncols) int64, ncols in {3,4} (column 0 = batch index when 4).
+ * count: fills input_map (n) and writes M and maxActive to the host.
+ * fill : writes output_coords (M, ncols) int64 and output_map (M, maxActive+1) int32
+ *        (voxels in first-occurrence order, point ids ascending, zero padded).
+ * Key range: batch in [0, 2^19), x/y/z in [-2^14, 2^14) after the reference's
+ * int64->int32 truncation, else D3_ERR_RANGE. */
+size_t d3_voxelize_idx_ws_bytes(int n);
+int d3_voxelize_idx_count(const int64_t *coords, int n, int ncols, int mode, int *input_map, void *ws,
+                          size_t ws_bytes, int *M_host, int *maxActive_host, void *stream);
+int d3_voxelize_idx_fill(const int64_t *coords, int n, int ncols, int mode, const int *input_map, void *ws,
+                         size_t ws_bytes, int64_t *output_coords, int *output_map, int M, int maxActive,
+                         void *stream);
+
+/* ---- ball query + clustering -------------------------------------------------------- */
+/* PG_OP.ballquery_batch_p  (src/bfs_cluster/bfs_cluster.cu:15-90), two-phase, no retry loop.
+ * count: per-point hit count (strict d2<r2, capped at 1000, same batch item only) ->
+ *        start_len (n,2) with start = exclusive prefix sum of len in point order (the
+ *        reference's starts come from atomicAdd and are scheduling dependent);
+ *        *nActive_host = total.
+ * fill : neighbour indices in ascending order; entries at positions >= idx_capacity are
+ *        dropped exactly as the reference truncates at n*meanActive (bfs_cluster.cu:51-59). */
+size_t d3_ballquery_ws_bytes(int n);
+int d3_ballquery_count(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
+                       int *start_len, void *ws, size_t ws_bytes, int *nActive_host, void *stream);
+int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
+                      const int *start_len, const void *ws, size_t ws_bytes, int *idx, long long idx_capacity,
+                      void *stream);
+
+/* PG_OP.bfs_cluster  (src/bfs_cluster/bfs_cluster.cpp:28-112), on the device, two-phase.
+ * count: connected components (same semantic label, directed ball-query lists, seeds in
+ *        ascending index) with size >= threshold -> *sumNPoint_host, *nCluster_host.
+ * fill : cluster_idxs (sumNPoint,2) = (cluster_id, point_idx) in the reference's FIFO-BFS
+ *        visitation order, cluster_offsets (nCluster+1). */
+size_t d3_bfs_cluster_ws_bytes(int n);
+int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n,
+                         int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host, int *nCluster_host,
+                         void *stream);
+int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n,
+                        void *ws, size_t ws_bytes, int *cluster_idxs, int *cluster_offsets, int sumNPoint,
+                        int nCluster, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3HIP_H */

@@ -1,0 +1,44 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/d3hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = set()
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        if h.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", h)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names |= set(re.findall(r"\b(d3_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_every_declared_symbol_is_exported(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    decl = _declared()
+    assert len(decl) >= 20
+    missing = [n for n in sorted(decl) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header(built_lib):
+    from d3net_amd import _lib
+    assert set(_lib.SIGNATURES) == _declared()
+    l = _lib.lib()
+    assert l.d3_arch() == b"gfx950"
+    assert l.d3_version() >= 100
+
+
+def test_product_never_imports_oracle():
+    """d3net_amd/ must not reference oracle/ (no CPU fallback through the checker)."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "d3net_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|libpgoracle|pg_oracle", t, flags=re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,254 @@
+"""GPU parity tests: d3net_amd.pointgroup_ops (HIP, through the C ABI) vs the CPU oracle.
+
+Bit-exact for every operator here (integer / index results, min / max / argmax, and the fp32 ops
+whose summation order is pinned by the reference: sec_mean, voxelize fp/bp, get_iou).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pg_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def ragged_offsets(rng, total, nseg, with_empty=True):
+    cuts = np.sort(rng.integers(0, total + 1, nseg - 1))
+    off = np.concatenate([[0], cuts, [total]]).astype(np.int32)
+    if with_empty and nseg > 2:
+        off[2] = off[1]  # an empty segment
+        off = np.sort(off).astype(np.int32)
+    return off
+
+
+@pytest.mark.parametrize("C", [1, 3, 16, 20])
+def test_sec_ops_bit_exact(dev, C):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(10 + C)
+    S = 20000
+    x = rng.standard_normal((S, C)).astype(np.float32)
+    off = ragged_offsets(rng, S, 37)
+    off[-2] = off[-1] - 9000 if off[-1] - 9000 > off[-3] else off[-2]  # one long segment
+    for name in ("sec_mean", "sec_min", "sec_max"):
+        got = N(getattr(P, name)(T(x, dev), T(off, dev)))
+        ref = getattr(o, name)(x, off)
+        assert np.array_equal(got, ref), name
+
+
+@pytest.mark.parametrize("C", [3, 16])
+def test_roipool_fwd_bwd_bit_exact(dev, C):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(20 + C)
+    S = 30000
+    f = rng.integers(-3, 4, (S, C)).astype(np.float32)  # heavy ties: first argmax must win
+    f[rng.random((S, C)) < 0.3] += rng.standard_normal()
+    off = ragged_offsets(rng, S, 50)
+    ft = T(f, dev).requires_grad_(True)
+    out = P.roipool(ft, T(off, dev))
+    ref, refidx = o.roipool(f, off)
+    assert np.array_equal(N(out), ref)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    g[np.isinf(ref)] = 0
+    out.backward(T(g, dev))
+    assert np.array_equal(N(ft.grad), o.roipool_bp(g, off, refidx, S))
+
+
+def test_get_iou_bit_exact(dev):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(30)
+    Npts, nInst, S = 50000, 37, 30000
+    inst = rng.integers(-1, nInst, Npts).astype(np.int64)
+    pn = np.bincount(inst[inst >= 0], minlength=nInst).astype(np.int32)
+    pidx = rng.integers(0, Npts, S).astype(np.int32)
+    off = ragged_offsets(rng, S, 25)
+    got = N(P.get_iou(T(pidx, dev), T(off, dev), T(inst, dev), T(pn, dev)))
+    assert np.array_equal(got, o.get_iou(pidx, off, inst, pn))
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_voxelization_fwd_bwd_bit_exact(dev, mode):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(40 + mode)
+    n, C = 20000, 19
+    c = rng.integers(0, 24, (n, 4)).astype(np.int64); c[:, 0] = rng.integers(0, 2, n)
+    _, p2v, v2p = o.voxelization_idx(c, 2, mode)
+    f = rng.standard_normal((n, C)).astype(np.float32)
+    ft = T(f, dev).requires_grad_(True)
+    out = P.voxelization(ft, T(v2p, dev), mode)
+    ref = o.voxelization(f, v2p, mode)
+    assert np.array_equal(N(out), ref)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    assert np.array_equal(N(ft.grad), o.voxelization_bp(g, v2p, n, mode))
+
+
+@pytest.mark.parametrize("ncols", [3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_voxelization_idx_bit_exact(dev, ncols, mode):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(50 + mode + 10 * ncols)
+    n = 30000
+    c = rng.integers(-5, 30, (n, ncols)).astype(np.int64)
+    if ncols == 4:
+        c[:, 0] = rng.integers(0, 3, n)
+    # device input -> device output
+    oc, p2v, v2p = P.voxelization_idx(T(c, dev), 3, mode)
+    roc, rp2v, rv2p = o.voxelization_idx(c, 3, mode)
+    assert np.array_equal(N(oc), roc) and np.array_equal(N(p2v), rp2v) and np.array_equal(N(v2p), rv2p)
+    # CPU input (the reference's calling convention) -> CPU output
+    oc2, p2v2, v2p2 = P.voxelization_idx(torch.from_numpy(c), 3, mode)
+    assert not oc2.is_cuda and np.array_equal(N(oc2), roc) and np.array_equal(N(v2p2), rv2p)
+
+
+def test_voxelization_idx_cluster_shaped(dev):
+    """clusters_voxelization-shaped input: column 0 = cluster id, 14^3 grid, many points per voxel."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(60)
+    n = 60000
+    c = np.concatenate([np.sort(rng.integers(0, 40, (n, 1))), rng.integers(0, 14, (n, 3))], 1).astype(np.int64)
+    got = P.voxelization_idx(T(c, dev), 40, 4)
+    ref = o.voxelization_idx(c, 40, 4)
+    for g, r in zip(got, ref):
+        assert np.array_equal(N(g), r)
+
+
+def test_voxelization_idx_range_error(dev):
+    from d3net_amd import pointgroup_ops as P, _lib
+    c = np.array([[0, 1, 2, 1 << 20]], np.int64)
+    with pytest.raises(_lib.D3Error):
+        P.voxelization_idx(T(c, dev), 1, 4)
+
+
+def _scene_points(rng, n, spread):
+    xyz = rng.random((n, 3)).astype(np.float32) * np.asarray(spread, np.float32)
+    order = np.lexsort((xyz[:, 2], xyz[:, 1], (xyz[:, 0] * 20).astype(int)))  # coarse raster order
+    return xyz[order]
+
+
+def test_ballquery_bit_exact(dev):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(70)
+    n1, n2 = 9000, 6000
+    xyz = np.concatenate([_scene_points(rng, n1, (2, 1.5, 0.3)), _scene_points(rng, n2, (1, 1, 0.3))])
+    bi = np.concatenate([np.zeros(n1, np.int32), np.ones(n2, np.int32)]); bo = np.array([0, n1, n1 + n2], np.int32)
+    idx, sl = P.ballquery_batch_p(T(xyz, dev), T(bi, dev), T(bo, dev), 0.05, 50)
+    ridx, rsl = o.ballquery_batch_p(xyz, bi, bo, 0.05, 50)
+    assert np.array_equal(N(sl), rsl)
+    assert np.array_equal(N(idx), ridx)
+
+
+def test_ballquery_random_order_and_cap(dev):
+    """Incoherent point order (culling useless) + a collapsed blob that hits the 1000 cap."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(71)
+    n = 6000
+    xyz = rng.random((n, 3)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+    xyz[rng.permutation(n)[:2500]] = np.array([0.5, 0.5, 0.1], np.float32) + rng.normal(0, 0.004, (2500, 3)).astype(np.float32)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = P.ballquery_batch_p(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, 300)
+    ridx, rsl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
+    assert rsl[:, 1].max() == 1000
+    assert np.array_equal(N(sl), rsl) and np.array_equal(N(idx), ridx)
+
+
+def test_ballquery_empty_batch_item_and_tiny(dev):
+    from d3net_amd import pointgroup_ops as P
+    xyz = np.array([[0, 0, 0], [0.01, 0, 0], [1, 1, 1]], np.float32)
+    bi = np.array([0, 0, 2], np.int32); bo = np.array([0, 2, 2, 3], np.int32)
+    idx, sl = P.ballquery_batch_p(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, 50)
+    ridx, rsl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 50)
+    assert np.array_equal(N(sl), rsl) and np.array_equal(N(idx), ridx)
+
+
+@pytest.mark.parametrize("seed", [80, 81])
+def test_bfs_cluster_bit_exact(dev, seed):
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(seed)
+    n = 12000
+    xyz = _scene_points(rng, n, (2, 1.5, 0.2))
+    sem = (1 + (xyz[:, 0] * 2).astype(np.int32) % 3 + (rng.random(n) < 0.05)).astype(np.int32)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.04, 50)
+    rci, rco = o.bfs_cluster(sem, idx, sl, 20)
+    assert len(rco) > 3
+    # device inputs
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 20)
+    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+    # CPU inputs (reference calling convention)
+    ci2, co2 = P.bfs_cluster(torch.from_numpy(sem), torch.from_numpy(idx), torch.from_numpy(sl), 20)
+    assert not ci2.is_cuda and np.array_equal(N(ci2), rci) and np.array_equal(N(co2), rco)
+
+
+def test_bfs_cluster_truncated_lists(dev):
+    """Capped, asymmetric lists (collapsed blobs) -- the shifted-coordinate regime of PointGroup."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(82)
+    n = 5000
+    xyz = rng.normal(0, 0.008, (n, 3)).astype(np.float32)
+    xyz[:, 0] += (rng.integers(0, 3, n) * 0.03).astype(np.float32)
+    sem = rng.integers(1, 3, n).astype(np.int32)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
+    assert (sl[:, 1] >= 1000).sum() > 500
+    rci, rco = o.bfs_cluster(sem, idx, sl, 10)
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 10)
+    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+
+
+def test_bfs_cluster_no_clusters(dev):
+    from d3net_amd import pointgroup_ops as P
+    sem = np.array([1, 2, 3], np.int32); idx = np.array([0, 1, 2], np.int32)
+    sl = np.array([[0, 1], [1, 1], [2, 1]], np.int32)
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50)
+    assert ci.shape == (0, 2) and N(co).tolist() == [0]
+
+
+def test_full_size_ballquery_and_cluster_properties(dev):
+    """Canonical 164k-point scene (BASELINE config 2): size-independent properties, no oracle."""
+    from d3net_amd import pointgroup_ops as P, synthetic as S
+    sc = S.canonical_scene(n_feat=1)
+    keep = sc["sem_labels"] > 0
+    xyz = sc["locs"][keep]; sem = sc["sem_labels"][keep].astype(np.int32)
+    n = xyz.shape[0]
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = P.ballquery_batch_p(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, 50)
+    idx, sl = N(idx), N(sl)
+    assert (sl[:, 1] >= 1).all() and sl[:, 1].max() < 1000
+    assert np.array_equal(sl[:, 0], np.concatenate([[0], np.cumsum(sl[:, 1])[:-1]]))
+    owner = np.repeat(np.arange(n), sl[:, 1])
+    # every list is strictly ascending and contains the point itself
+    same = owner[1:] == owner[:-1]
+    assert (idx[1:][same] > idx[:-1][same]).all()
+    assert np.isin(np.arange(n) * (1 << 20) + np.arange(n), owner.astype(np.int64) * (1 << 20) + idx).all()
+    # symmetry: (i,j) listed <=> (j,i) listed (no list was capped)
+    a = np.sort(owner.astype(np.int64) * (1 << 20) + idx); b = np.sort(idx.astype(np.int64) * (1 << 20) + owner)
+    assert np.array_equal(a, b)
+    # spot-check 200 points against brute force
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, n, 200):
+        d = xyz[i] - xyz
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert np.array_equal(idx[sl[i, 0]:sl[i, 0] + sl[i, 1]], np.nonzero(d2 < np.float32(0.03) * np.float32(0.03))[0])
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50)
+    ci, co = N(ci), N(co)
+    # clusters partition a subset of the points, are label-pure, sized >= 50, seeds ascending
+    assert len(np.unique(ci[:, 1])) == len(ci)
+    sizes = np.diff(co)
+    assert (sizes >= 50).all() and co[-1] == len(ci)
+    assert (ci[:, 0] == np.repeat(np.arange(len(sizes)), sizes)).all()
+    seeds = ci[co[:-1], 1]
+    assert (np.diff(seeds) > 0).all()
+    for c in range(len(sizes)):
+        pts = ci[co[c]:co[c + 1], 1]
+        assert len(np.unique(sem[pts])) == 1 and pts[0] == pts.min()
+    # the full-size result equals the sequential oracle BFS (cheap: O(nActive))
+    rci, rco = o.bfs_cluster(sem, idx, sl, 50)
+    assert np.array_equal(ci, rci) and np.array_equal(co, rco)
