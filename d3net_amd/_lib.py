@@ -40,6 +40,15 @@ SIGNATURES = {
     "d3_bfs_cluster_ws_bytes": (sz, [i32]),
     "d3_bfs_cluster_count": (i32, [vp, vp, vp, i32, i32, vp, sz, pi, pi, vp]),
     "d3_bfs_cluster_fill": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, i32, i32, vp]),
+    "d3_coordmap_ws_bytes": (sz, [i32]),
+    "d3_kmap_k3": (i32, [vp, i32, i32, vp, sz, vp, vp]),
+    "d3_kmap_down_count": (i32, [vp, i32, i32, vp, sz, vp, vp, pi, vp]),
+    "d3_kmap_down_fill": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, i32, vp]),
+    "d3_spconv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "d3_spconv_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "d3_bn_stats": (i32, [vp, i32, i32, vp, vp, vp, sz, vp]),
+    "d3_bn_relu_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "d3_bn_relu_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, sz, vp]),
 }
 
 

@@ -1,0 +1,174 @@
+// bn.hip -- MinkowskiBatchNorm (+ MinkowskiReLU) over the rows of an (M,C) feature matrix (gfx950).
+//
+// Reference: sp_norm = MinkowskiBatchNorm(eps=1e-4, momentum=0.1) followed by MinkowskiReLU
+// (model/pointgroup.py:65,72-73; model/common.py:36-40,62-63,87-89,95-97), i.e. BatchNorm1d with
+// per-rank batch statistics in training.  Pure streaming kernels: bytes = 4*M*C read for the
+// statistics, 8*M*C for the normalise pass; the backward reads x, dy twice and writes dx.
+#include "common.h"
+
+#define BN_T 256
+
+// per-channel sum / sum of squares -> fp64 accumulators ws[0..C), ws[C..2C)
+__global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict__ x, int M, int C, double *acc) {
+    __shared__ float s1[BN_T], s2[BN_T];
+    const int t = threadIdx.x;
+    const int active = (BN_T / C) * C, rpp = active / C;
+    float a = 0.f, b = 0.f;
+    if (t < active) {
+        const int c = t % C;
+        for (long long r = (long long)blockIdx.x * rpp + t / C; r < M; r += (long long)gridDim.x * rpp) {
+            const float v = x[r * C + c];
+            a += v; b = fmaf(v, v, b);
+        }
+    }
+    s1[t] = a; s2[t] = b;
+    __syncthreads();
+    if (t < C) {
+        double da = 0., db = 0.;
+        for (int k = t; k < active; k += C) { da += (double)s1[k]; db += (double)s2[k]; }
+        atomicAdd(&acc[t], da);
+        atomicAdd(&acc[C + t], db);
+    }
+}
+__global__ void bn_finalize_kernel(const double *acc, int M, int C, float *mean, float *var) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = acc[c] / (double)M;
+    double v = acc[C + c] / (double)M - m * m;
+    if (v < 0.) v = 0.;
+    mean[c] = (float)m; var[c] = (float)v;  // biased variance (what the normalisation uses)
+}
+
+__global__ void bn_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                   const float *__restrict__ var, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float *__restrict__ y, long long total4, int C,
+                                   float eps, int relu) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread (C % 4 == 0)
+    if (e >= total4) return;
+    const int c = (int)((e * 4) % C);
+    const float4 v = ((const float4 *)x)[e];
+    float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float inv = rsqrtf(var[c + j] + eps);
+        float r = fmaf((in[j] - mean[c + j]) * inv, gamma[c + j], beta[c + j]);
+        o[j] = (relu && r < 0.f) ? 0.f : r;
+    }
+    ((float4 *)y)[e] = make_float4(o[0], o[1], o[2], o[3]);
+}
+__global__ void bn_relu_fwd_scalar_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                          const float *__restrict__ var, const float *__restrict__ gamma,
+                                          const float *__restrict__ beta, float *__restrict__ y, long long total,
+                                          int C, float eps, int relu) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C);
+    float r = fmaf((x[e] - mean[c]) * rsqrtf(var[c] + eps), gamma[c], beta[c]);
+    y[e] = (relu && r < 0.f) ? 0.f : r;
+}
+
+// backward reductions: sum g, sum g*xhat with g = dy * relu'(y)
+__global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ dy,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ var,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int M, int C, float eps,
+                                                            int relu, double *acc) {
+    __shared__ float s1[BN_T], s2[BN_T];
+    const int t = threadIdx.x;
+    const int active = (BN_T / C) * C, rpp = active / C;
+    float a = 0.f, b = 0.f;
+    if (t < active) {
+        const int c = t % C;
+        const float mu = mean[c], inv = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
+        for (long long r = (long long)blockIdx.x * rpp + t / C; r < M; r += (long long)gridDim.x * rpp) {
+            const float xh = (x[r * C + c] - mu) * inv;
+            float g = dy[r * C + c];
+            if (relu && fmaf(xh, ga, be) <= 0.f) g = 0.f;
+            a += g; b = fmaf(g, xh, b);
+        }
+    }
+    s1[t] = a; s2[t] = b;
+    __syncthreads();
+    if (t < C) {
+        double da = 0., db = 0.;
+        for (int k = t; k < active; k += C) { da += (double)s1[k]; db += (double)s2[k]; }
+        atomicAdd(&acc[t], da);
+        atomicAdd(&acc[C + t], db);
+    }
+}
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                    const float *__restrict__ mean, const float *__restrict__ var,
+                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                    const double *__restrict__ acc, float *__restrict__ dx, long long total, int M,
+                                    int C, float eps, int relu) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C);
+    const float inv = rsqrtf(var[c] + eps), ga = gamma[c];
+    const float xh = (x[e] - mean[c]) * inv;
+    float g = dy[e];
+    if (relu && fmaf(xh, ga, beta[c]) <= 0.f) g = 0.f;
+    const float mg = (float)(acc[c] / (double)M), mgx = (float)(acc[C + c] / (double)M);
+    dx[e] = ga * inv * (g - mg - xh * mgx);
+}
+__global__ void bn_bwd_params_kernel(const double *acc, int C, float *dgamma, float *dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] += (float)acc[c];
+    dgamma[c] += (float)acc[C + c];
+}
+
+static int bn_grid(int M, int C) {
+    const int rpp = (BN_T / C);
+    long long blocks = ((long long)M + rpp - 1) / rpp;
+    blocks = (blocks + 15) / 16;  // >= 16 row passes per block
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    return (int)blocks;
+}
+
+extern "C" int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, void *ws, size_t ws_bytes,
+                           void *stream) {
+    if (M <= 0) return 0;
+    if (C < 1 || C > BN_T) return D3_ERR_ARG;
+    if (ws == nullptr || ws_bytes < 2 * (size_t)C * sizeof(double)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    D3_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(double), s));
+    bn_stats_kernel<<<bn_grid(M, C), BN_T, 0, s>>>(x, M, C, (double *)ws);
+    bn_finalize_kernel<<<(C + 63) / 64, 64, 0, s>>>((const double *)ws, M, C, mean, var);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_bn_relu_fwd(const float *x, const float *mean, const float *var, const float *gamma,
+                              const float *beta, float *y, int M, int C, float eps, int relu, void *stream) {
+    if (M <= 0) return 0;
+    hipStream_t s = d3_stream(stream);
+    long long total = (long long)M * C;
+    if ((C & 3) == 0) {
+        long long t4 = total / 4;
+        bn_relu_fwd_kernel<<<(int)((t4 + 255) / 256), 256, 0, s>>>(x, mean, var, gamma, beta, y, t4, C, eps, relu);
+    } else {
+        bn_relu_fwd_scalar_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, mean, var, gamma, beta, y, total, C,
+                                                                           eps, relu);
+    }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const float *var,
+                              const float *gamma, const float *beta, float *dx, float *dgamma, float *dbeta, int M,
+                              int C, float eps, int relu, void *ws, size_t ws_bytes, void *stream) {
+    if (M <= 0) return 0;
+    if (C < 1 || C > BN_T) return D3_ERR_ARG;
+    if (ws == nullptr || ws_bytes < 2 * (size_t)C * sizeof(double)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    D3_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(double), s));
+    bn_bwd_reduce_kernel<<<bn_grid(M, C), BN_T, 0, s>>>(x, dy, mean, var, gamma, beta, M, C, eps, relu, (double *)ws);
+    long long total = (long long)M * C;
+    bn_bwd_apply_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, dy, mean, var, gamma, beta, (const double *)ws,
+                                                                 dx, total, M, C, eps, relu);
+    bn_bwd_params_kernel<<<(C + 63) / 64, 64, 0, s>>>((const double *)ws, C, dgamma, dbeta);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

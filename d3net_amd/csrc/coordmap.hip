@@ -1,0 +1,216 @@
+// coordmap.hip -- coordinate hash + kernel maps for the sparse convolutions (gfx950).
+//
+// Stands in for the part of MinkowskiEngine's CoordinateManager the reference exercises
+// (reference call sites: model/common.py:38,41,66,90,98; model/pointgroup.py:70,176,268): the
+// neighbour table of a kernel-3 stride-1 convolution and the parent/child maps of the kernel-2
+// stride-2 convolution and its transpose.  MinkowskiEngine is not vendored or pinned by the
+// reference, so the semantics are the build's own (oracle/sparse_oracle.py, pinned to dense conv3d).
+//
+// Kernel maps are stored output-stationary as dense int32 tables (Mout, K): the convolution then
+// needs no scatter and no atomics (d3net_amd/csrc/spconv.hip).  Table builds are hash-probe bound:
+// bytes = 16*M (coords) + 4*M*K (table) against an L2-resident 12-byte-per-slot hash.
+#include "common.h"
+
+#define CM_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct CmWs {
+    unsigned long long *keys;  // cap
+    int *first;                // cap   min row index per slot (= the row for unique coordinates)
+    int *slot_vid;             // cap
+    int *slot_of;              // M
+    int *flag;                 // M
+    int *scan;                 // M
+    int *scalars;              // 8
+    void *temp; size_t temp_bytes;
+    size_t cap;
+};
+static size_t cm_cap(int n) { size_t c = 1024; while (c < (size_t)n * 2) c <<= 1; return c; }
+static size_t cm_layout(void *ws, size_t ws_bytes, int M, CmWs &w) {
+    D3Carver c(ws, ws_bytes);
+    size_t nn = (size_t)(M > 0 ? M : 1);
+    w.cap = cm_cap(M);
+    w.keys = c.take<unsigned long long>(w.cap);
+    w.first = c.take<int>(w.cap);
+    w.slot_vid = c.take<int>(w.cap);
+    w.slot_of = c.take<int>(nn);
+    w.flag = c.take<int>(nn);
+    w.scan = c.take<int>(nn);
+    w.scalars = c.take<int>(64);
+    w.temp_bytes = d3_scan_temp_bytes(M);
+    w.temp = c.take<char>(w.temp_bytes);
+    return c.off;
+}
+extern "C" size_t d3_coordmap_ws_bytes(int M) {
+    CmWs w;
+    return cm_layout(nullptr, 0, M, w) + 256;
+}
+
+__device__ __forceinline__ unsigned long long cm_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+// key layout: batch 19 bits | x 15 | y 15 | z 15 (x,y,z biased by 2^14)
+__device__ __forceinline__ bool cm_pack(int b, int x, int y, int z, unsigned long long &key) {
+    const int B = 1 << 14;
+    bool ok = (b >= 0 && b < (1 << 19)) && (x >= -B && x < B) && (y >= -B && y < B) && (z >= -B && z < B);
+    key = ((unsigned long long)(unsigned)b << 45) | ((unsigned long long)(unsigned)(x + B) << 30) |
+          ((unsigned long long)(unsigned)(y + B) << 15) | (unsigned long long)(unsigned)(z + B);
+    return ok;
+}
+__device__ __forceinline__ int floor_div(int a, int s) { return (a >= 0) ? a / s : -((-a + s - 1) / s); }
+
+__global__ void cm_init_kernel(unsigned long long *keys, int *first, size_t cap, int *scalars) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = CM_EMPTY; first[i] = 0x7FFFFFFF; }
+    if (i < 8) scalars[i] = 0;
+}
+// insert coords[i] quantised to step q (q == 0: as is)
+__global__ void cm_insert_kernel(const int *__restrict__ coords, int M, int q, unsigned long long *keys, int *first,
+                                 size_t cap, int *slot_of, int *scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    int b = coords[i * 4], x = coords[i * 4 + 1], y = coords[i * 4 + 2], z = coords[i * 4 + 3];
+    if (q > 0) { x = floor_div(x, q) * q; y = floor_div(y, q) * q; z = floor_div(z, q) * q; }
+    unsigned long long key;
+    if (!cm_pack(b, x, y, z, key)) { scalars[2] = 1; key &= ~(1ull << 63); }
+    size_t slot = cm_hash(key) & (cap - 1);
+    for (size_t probe = 0; probe < cap; probe++) {
+        unsigned long long prev = atomicCAS(&keys[slot], CM_EMPTY, key);
+        if (prev == CM_EMPTY || prev == key) { atomicMin(&first[slot], i); slot_of[i] = (int)slot; return; }
+        slot = (slot + 1) & (cap - 1);
+    }
+    scalars[2] = 2;
+    slot_of[i] = 0;
+}
+__device__ __forceinline__ int cm_lookup(const unsigned long long *keys, const int *vals, size_t cap,
+                                         unsigned long long key) {
+    size_t slot = cm_hash(key) & (cap - 1);
+    for (size_t probe = 0; probe < cap; probe++) {
+        unsigned long long k = keys[slot];
+        if (k == key) return vals[slot];
+        if (k == CM_EMPTY) return -1;
+        slot = (slot + 1) & (cap - 1);
+    }
+    return -1;
+}
+
+// one thread per (row, offset): coalesced table stores
+__global__ void cm_k3_kernel(const int *__restrict__ coords, int M, int ts, const unsigned long long *keys,
+                             const int *first, size_t cap, int *__restrict__ nbr) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)M * 27) return;
+    const int u = (int)(e / 27), k = (int)(e % 27);
+    const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+    unsigned long long key;
+    int r = -1;
+    if (cm_pack(coords[u * 4], coords[u * 4 + 1] + ox * ts, coords[u * 4 + 2] + oy * ts, coords[u * 4 + 3] + oz * ts, key))
+        r = cm_lookup(keys, first, cap, key);
+    nbr[e] = r;
+}
+
+static int cm_build_hash(const int *coords, int M, int q, CmWs &w, hipStream_t s) {
+    const int T = 256;
+    cm_init_kernel<<<(int)((w.cap + T - 1) / T), T, 0, s>>>(w.keys, w.first, w.cap, w.scalars);
+    cm_insert_kernel<<<(M + T - 1) / T, T, 0, s>>>(coords, M, q, w.keys, w.first, w.cap, w.slot_of, w.scalars);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *stream) {
+    if (M <= 0) return 0;
+    if (ts <= 0) return D3_ERR_ARG;
+    CmWs w;
+    if (ws == nullptr || cm_layout(ws, ws_bytes, M, w) > ws_bytes) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    int rc = cm_build_hash(coords, M, 0, w, s);
+    if (rc) return rc;
+    long long total = (long long)M * 27;
+    cm_k3_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(coords, M, ts, w.keys, w.first, w.cap, nbr);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void cm_flag_kernel(const int *first, const int *slot_of, int *flag, int M) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) flag[i] = (first[slot_of[i]] == i) ? 1 : 0;
+}
+__global__ void cm_assign_kernel(const int *flag, const int *scan, const int *slot_of, int *slot_vid, int M,
+                                 int *scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (flag[i]) slot_vid[slot_of[i]] = scan[i];
+    if (i == M - 1) scalars[0] = scan[i] + flag[i];
+}
+__global__ void cm_parent_kernel(const int *__restrict__ coords, int M, int ts, const int *slot_of,
+                                 const int *slot_vid, int *parent, int *kidx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    parent[i] = slot_vid[slot_of[i]];
+    const int s2 = 2 * ts;
+    const int x = coords[i * 4 + 1], y = coords[i * 4 + 2], z = coords[i * 4 + 3];
+    const int dx = (x - floor_div(x, s2) * s2) / ts, dy = (y - floor_div(y, s2) * s2) / ts,
+              dz = (z - floor_div(z, s2) * s2) / ts;
+    kidx[i] = dx + 2 * dy + 4 * dz;
+}
+
+extern "C" int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *parent,
+                                  int *kidx, int *Mout_host, void *stream) {
+    *Mout_host = 0;
+    if (M <= 0) return 0;
+    if (ts <= 0) return D3_ERR_ARG;
+    CmWs w;
+    if (ws == nullptr || cm_layout(ws, ws_bytes, M, w) > ws_bytes) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256, nb = (M + T - 1) / T;
+    int rc = cm_build_hash(coords, M, 2 * ts, w, s);
+    if (rc) return rc;
+    cm_flag_kernel<<<nb, T, 0, s>>>(w.first, w.slot_of, w.flag, M);
+    rc = d3_exclusive_scan_i32(w.flag, w.scan, M, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    cm_assign_kernel<<<nb, T, 0, s>>>(w.flag, w.scan, w.slot_of, w.slot_vid, M, w.scalars);
+    cm_parent_kernel<<<nb, T, 0, s>>>(coords, M, ts, w.slot_of, w.slot_vid, parent, kidx);
+    D3_LAUNCH_CHECK();
+    int h[3];
+    D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipStreamSynchronize(s));
+    if (h[2] == 1) return D3_ERR_RANGE;
+    if (h[2] == 2) return D3_ERR_OVERFLOW;
+    *Mout_host = h[0];
+    return 0;
+}
+
+__global__ void cm_fill_neg_kernel(int *a, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = -1;
+}
+__global__ void cm_down_fill_kernel(const int *__restrict__ coords, int M, int ts, const int *__restrict__ parent,
+                                    const int *__restrict__ kidx, const int *__restrict__ flag, int *out_coords,
+                                    int *child, int *up) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int p = parent[i], k = kidx[i];
+    child[p * 8 + k] = i;
+    up[i * 8 + k] = p;
+    if (flag[i]) {  // first row of its parent cell: defines the output coordinate
+        const int s2 = 2 * ts;
+        out_coords[p * 4 + 0] = coords[i * 4];
+        out_coords[p * 4 + 1] = floor_div(coords[i * 4 + 1], s2) * s2;
+        out_coords[p * 4 + 2] = floor_div(coords[i * 4 + 2], s2) * s2;
+        out_coords[p * 4 + 3] = floor_div(coords[i * 4 + 3], s2) * s2;
+    }
+}
+
+extern "C" int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,
+                                 const int *kidx, int *out_coords, int *child, int *up, int Mout, void *stream) {
+    if (M <= 0 || Mout <= 0) return 0;
+    CmWs w;
+    if (ws == nullptr || cm_layout(ws, ws_bytes, M, w) > ws_bytes) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256;
+    long long nc = (long long)Mout * 8, nu = (long long)M * 8;
+    cm_fill_neg_kernel<<<(int)((nc + T - 1) / T), T, 0, s>>>(child, nc);
+    cm_fill_neg_kernel<<<(int)((nu + T - 1) / T), T, 0, s>>>(up, nu);
+    cm_down_fill_kernel<<<(M + T - 1) / T, T, 0, s>>>(coords, M, ts, parent, kidx, w.flag, out_coords, child, up);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

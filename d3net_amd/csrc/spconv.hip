@@ -1,0 +1,319 @@
+// spconv.hip -- sparse 3-D convolution as output-stationary gather -> LDS -> MFMA (gfx950).
+//
+// Stands in for MinkowskiConvolution / MinkowskiConvolutionTranspose forward, data gradient and
+// weight gradient (reference call sites: model/common.py:32,38,41,66,90,98; model/pointgroup.py:70).
+//
+//   out[u,:] = sum_k x[tbl[u,k],:] @ W[k]            tbl: dense (Mout,K) kernel map (coordmap.hip)
+//
+// Every convolution of the U-Net is this one contraction with a different table:
+//   kernel-3 fwd: tbl=nbr(27)          dgrad: tbl=nbr, W[26-k]^T            wgrad: tbl=nbr
+//   down k2s2   : tbl=child(8)         dgrad: tbl=up,    W[k]^T             wgrad: tbl=child
+//   up   k2s2^T : tbl=up(8)            dgrad: tbl=child, W[k]^T             wgrad: tbl=up
+//   1x1         : tbl=NULL (identity)
+// Output-stationary: a workgroup owns 64 output rows and all Cout channels, walks the K offsets,
+// gathers the 64 input rows of the offset into LDS as bf16 (fp32 in HBM), multiplies by W[k] on the
+// matrix cores (v_mfma_f32_16x16x16_bf16, fp32 accumulate) and writes each output row once: no
+// scatter, no atomics, deterministic.  Offsets no row of the tile uses are skipped.
+// Roofline: HBM.  Algorithmic bytes per launch = 4*(Min*Cin + Mout*Cout) + 4*K*Cin*Cout + 4*Mout*K
+// (features once, weights once, table once); FLOPs = 2*pairs*Cin*Cout, AI 8..56 FLOP/B << 300.
+#include "common.h"
+
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+    unsigned int u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+// ------------------------------------------------------------------------------ exact fp32 kernels
+// One thread per output element; used for D3_CONV_EXACT (validation / fp32 mode).
+__global__ void spconv_fwd_exact_kernel(const float *__restrict__ x, const int *__restrict__ tbl,
+                                        const float *__restrict__ W, float *__restrict__ out, int Mout, int K,
+                                        int Cin, int Cout, int flipk, int transw) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)Mout * Cout) return;
+    const int u = (int)(e / Cout), co = (int)(e % Cout);
+    float acc = 0.f;
+    for (int k = 0; k < K; k++) {
+        const int idx = tbl ? tbl[(long long)u * K + k] : u;
+        if (idx < 0) continue;
+        const int wk = flipk ? (K - 1 - k) : k;
+        const float *xr = x + (long long)idx * Cin;
+        const float *w = W + (long long)wk * Cin * Cout;
+        if (transw) { for (int ci = 0; ci < Cin; ci++) acc = fmaf(xr[ci], w[(long long)co * Cin + ci], acc); }
+        else { for (int ci = 0; ci < Cin; ci++) acc = fmaf(xr[ci], w[(long long)ci * Cout + co], acc); }
+    }
+    out[e] = acc;
+}
+// one thread per weight element, serial over rows (validation only)
+__global__ void spconv_wgrad_exact_kernel(const float *__restrict__ x, const int *__restrict__ tbl,
+                                          const float *__restrict__ dy, float *__restrict__ dW, int Mout, int K,
+                                          int Cin, int Cout) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)K * Cin * Cout) return;
+    const int k = (int)(e / ((long long)Cin * Cout)), ci = (int)((e / Cout) % Cin), co = (int)(e % Cout);
+    float acc = 0.f;
+    for (int u = 0; u < Mout; u++) {
+        const int idx = tbl ? tbl[(long long)u * K + k] : u;
+        if (idx >= 0) acc = fmaf(x[(long long)idx * Cin + ci], dy[(long long)u * Cout + co], acc);
+    }
+    dW[e] += acc;
+}
+
+// ------------------------------------------------------------------------------ MFMA forward / dgrad
+#define CV_BM 64      // output rows per workgroup
+#define CV_KC 32      // reduction chunk (input channels) per stage
+#define CV_LD 40      // LDS row stride in bf16 (80 B: conflict-free ds_read_b64 fragments)
+#define CV_MAXK 27
+
+template <int NT, bool TRANSW>
+__global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__restrict__ x,
+                                                             const int *__restrict__ tbl,
+                                                             const float *__restrict__ W, float *__restrict__ out,
+                                                             int Mout, int K, int Cin, int flipk) {
+    constexpr int Cout = NT * 16;
+    __shared__ int tblS[CV_BM * CV_MAXK];
+    __shared__ __attribute__((aligned(16))) unsigned short As[CV_BM * CV_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bt[NT * 16 * CV_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * CV_BM;
+    // kernel-map rows of this tile, coalesced
+    for (int e = t; e < CV_BM * K; e += 256) {
+        const int r = e / K, k = e % K;
+        const int u = row0 + r;
+        tblS[e] = (u < Mout) ? (tbl ? tbl[(long long)u * K + k] : u) : -1;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int arow = t >> 2, aq = t & 3;  // staging role: row, 8-channel group
+    const bool cin4 = (Cin & 3) == 0;
+    for (int k = 0; k < K; k++) {
+        const int idx = tblS[arow * K + k];
+        if (!__syncthreads_or(idx >= 0)) continue;  // no row of the tile uses this offset
+        const int wk = flipk ? (K - 1 - k) : k;
+        const float *Wk = W + (long long)wk * Cin * Cout;
+        for (int c0 = 0; c0 < Cin; c0 += CV_KC) {
+            // ---- stage A: 64 gathered rows x 32 channels -> bf16
+            {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = 0.f;
+                const int c = c0 + aq * 8;
+                if (idx >= 0) {
+                    const float *src = x + (long long)idx * Cin + c;
+                    if (cin4) {
+                        if (c + 4 <= Cin) { float4 f = *(const float4 *)src; v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+                        if (c + 8 <= Cin) { float4 f = *(const float4 *)(src + 4); v[4] = f.x; v[5] = f.y; v[6] = f.z; v[7] = f.w; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (c + 2 * j + 2 <= Cin) { float2 f = *(const float2 *)(src + 2 * j); v[2 * j] = f.x; v[2 * j + 1] = f.y; }
+                    }
+                }
+                uint4 pk;
+                pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+                *(uint4 *)&As[arow * CV_LD + aq * 8] = pk;
+            }
+            // ---- stage B: W chunk (32 x Cout) -> Bt[n][kk] bf16, two kk per 32-bit store
+            for (int e = t; e < 16 * Cout; e += 256) {
+                int n, kp;
+                float w0 = 0.f, w1 = 0.f;
+                if (TRANSW) {  // W laid out (K, Cout, Cin): contiguous along the reduction index
+                    n = e >> 4; kp = e & 15;
+                    const int c = c0 + 2 * kp;
+                    if (c + 2 <= Cin) { float2 f = *(const float2 *)(Wk + (long long)n * Cin + c); w0 = f.x; w1 = f.y; }
+                } else {       // W laid out (K, Cin, Cout): coalesced along n
+                    kp = e / Cout; n = e % Cout;
+                    const int c = c0 + 2 * kp;
+                    if (c < Cin) w0 = Wk[(long long)c * Cout + n];
+                    if (c + 1 < Cin) w1 = Wk[(long long)(c + 1) * Cout + n];
+                }
+                *(unsigned int *)&Bt[n * CV_LD + 2 * kp] = pack2bf(w0, w1);
+            }
+            __syncthreads();
+            const int ksteps = (Cin - c0 > 16) ? 2 : 1;
+            for (int ks = 0; ks < ksteps; ks++) {
+                const bf16x4 a = *(const bf16x4 *)&As[(wave * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
+#pragma unroll
+                for (int n = 0; n < NT; n++) {
+                    const bf16x4 b = *(const bf16x4 *)&Bt[(n * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[n], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int u = row0 + wave * 16 + (lane >> 4) * 4 + r;
+            if (u < Mout) out[(long long)u * Cout + n * 16 + (lane & 15)] = acc[n][r];
+        }
+    }
+}
+
+template <bool TRANSW>
+static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
+                           int Cout, int flipk, hipStream_t s) {
+    const int grid = (Mout + CV_BM - 1) / CV_BM;
+#define CV_CASE(NTV)                                                                                        \
+    case NTV:                                                                                               \
+        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, flipk);     \
+        break;
+    switch (Cout / 16) {
+        CV_CASE(1) CV_CASE(2) CV_CASE(3) CV_CASE(4) CV_CASE(5) CV_CASE(6) CV_CASE(7) CV_CASE(8) CV_CASE(9)
+        CV_CASE(10) CV_CASE(11) CV_CASE(12) CV_CASE(13) CV_CASE(14)
+        default: return D3_ERR_ARG;
+    }
+#undef CV_CASE
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
+                             int Cout, int flags, void *stream) {
+    if (Mout <= 0) return 0;
+    if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
+    if (tbl == nullptr && K != 1) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    const int flipk = (flags & D3_CONV_FLIPK) ? 1 : 0, transw = (flags & D3_CONV_TRANSW) ? 1 : 0;
+    if (flags & D3_CONV_EXACT) {
+        long long total = (long long)Mout * Cout;
+        spconv_fwd_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk,
+                                                                         transw);
+        D3_LAUNCH_CHECK();
+        return 0;
+    }
+    if ((Cout & 15) != 0 || (Cin & 1) != 0 || Cout > 224) return D3_ERR_ARG;
+    return transw ? launch_fwd_mfma<true>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s)
+                  : launch_fwd_mfma<false>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s);
+}
+
+// ------------------------------------------------------------------------------ MFMA weight gradient
+// dW[k][ci][co] += sum_u x[tbl[u,k]][ci] * dy[u][co]:  M-dim = ci, N-dim = co, reduction = rows.
+// grid = (row blocks, K).  Each wave owns a quarter of the block's rows, stages 32 rows at a time
+// TRANSPOSED into its private LDS region (Xt[ci][row], DYt[co][row]) so that both MFMA operands are
+// contiguous 8-byte reads, keeps up to WG_MAXT 16x16 accumulators, and the workgroup's four
+// partial results are added to dW with fp32 atomics (order-dependent rounding in the last bits).
+#define WG_ROWS 4096   // rows per workgroup (1024 per wave)
+#define WG_RC 32       // rows per stage
+#define WG_MAXT 16     // accumulator tiles per pass
+
+__global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__restrict__ x,
+                                                               const int *__restrict__ tbl,
+                                                               const float *__restrict__ dy, float *__restrict__ dW,
+                                                               int Mout, int K, int Cin, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned short *Xt = smem + (size_t)wave * (CinP + CoutP) * CV_LD;
+    unsigned short *DYt = Xt + (size_t)CinP * CV_LD;
+    const int k = blockIdx.y;
+    const int rb0 = blockIdx.x * WG_ROWS;
+    const int rows_blk = min(WG_ROWS, Mout - rb0);
+    const int per_wave = (rows_blk + 3) / 4;
+    const int w0 = rb0 + wave * per_wave;                     // this wave's rows [w0, w1)
+    const int w1 = min(rb0 + rows_blk, w0 + per_wave);
+    const int nchunks = (per_wave + WG_RC - 1) / WG_RC;       // uniform over the block
+    const int mt = CinP / 16, nt = CoutP / 16, ntiles = mt * nt;
+    const int srow = lane >> 1, shalf = lane & 1;             // staging role: row of the chunk, channel phase
+    float *dWk = dW + (long long)k * Cin * Cout;
+
+    for (int tile0 = 0; tile0 < ntiles; tile0 += WG_MAXT) {
+        f32x4 acc[WG_MAXT];
+#pragma unroll
+        for (int i = 0; i < WG_MAXT; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bool any_valid = false;
+        for (int ch = 0; ch < nchunks; ch++) {
+            const int u = w0 + ch * WG_RC + srow;
+            int idx = -1;
+            if (u < w1) idx = tbl ? tbl[(long long)u * K + k] : u;
+            const bool chunk_valid = __syncthreads_or(idx >= 0) != 0;
+            if (!chunk_valid) continue;   // uniform
+            any_valid = true;
+            // stage x (gathered) and dy, transposed: element (c, row) at [c*CV_LD + row]
+            for (int c = shalf * 2; c < CinP; c += 4) {
+                float a = 0.f, b = 0.f;
+                if (idx >= 0 && c + 2 <= Cin) { float2 f = *(const float2 *)(x + (long long)idx * Cin + c); a = f.x; b = f.y; }
+                else if (idx >= 0 && c < Cin) { a = x[(long long)idx * Cin + c]; }
+                Xt[c * CV_LD + srow] = f2bf(a);
+                Xt[(c + 1) * CV_LD + srow] = f2bf(b);
+            }
+            for (int c = shalf * 2; c < CoutP; c += 4) {
+                float a = 0.f, b = 0.f;
+                if (idx >= 0 && c + 2 <= Cout) { float2 f = *(const float2 *)(dy + (long long)u * Cout + c); a = f.x; b = f.y; }
+                else if (idx >= 0 && c < Cout) { a = dy[(long long)u * Cout + c]; }
+                DYt[c * CV_LD + srow] = f2bf(a);
+                DYt[(c + 1) * CV_LD + srow] = f2bf(b);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < WG_MAXT; i++) {
+                const int tile = tile0 + i;
+                if (tile < ntiles) {
+                    const int mi = tile / nt, ni = tile % nt;
+#pragma unroll
+                    for (int ks = 0; ks < WG_RC / 16; ks++) {
+                        const bf16x4 a = *(const bf16x4 *)&Xt[(mi * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
+                        const bf16x4 b = *(const bf16x4 *)&DYt[(ni * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (any_valid) {
+#pragma unroll
+            for (int i = 0; i < WG_MAXT; i++) {
+                const int tile = tile0 + i;
+                if (tile < ntiles) {
+                    const int mi = tile / nt, ni = tile % nt;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int ci = mi * 16 + (lane >> 4) * 4 + r, co = ni * 16 + (lane & 15);
+                        if (ci < Cin && co < Cout) atomicAdd(&dWk[(long long)ci * Cout + co], acc[i][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Mout, int K,
+                               int Cin, int Cout, int flags, void *stream) {
+    if (Mout <= 0) return 0;
+    if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
+    if (tbl == nullptr && K != 1) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    if (flags & D3_CONV_EXACT) {
+        long long total = (long long)K * Cin * Cout;
+        spconv_wgrad_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, dy, dW, Mout, K, Cin, Cout);
+        D3_LAUNCH_CHECK();
+        return 0;
+    }
+    if ((Cin & 1) != 0 || (Cout & 1) != 0) return D3_ERR_ARG;
+    const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
+    size_t lds = (size_t)4 * (CinP + CoutP) * CV_LD * sizeof(unsigned short);
+    if (lds > 160 * 1024) return D3_ERR_ARG;
+    dim3 grid((Mout + WG_ROWS - 1) / WG_ROWS, K);
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+            attr_set = true;
+        }
+    }
+    spconv_wgrad_mfma_kernel<<<grid, 256, lds, s>>>(x, tbl, dy, dW, Mout, K, Cin, Cout);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,326 @@
+"""The MinkowskiEngine API subset the reference's detector calls, on MI355X.
+
+Same constructor signatures, attribute names and state-dict keys as the calls in the reference
+(reference: model/common.py:13-15,32,36-41,64-66,88-90,96-98,114; model/pointgroup.py:65,70,73,91,176,268):
+
+    ME.SparseTensor(features=, coordinates=)      .features / .F / .coordinates / .C, `x += y`
+    ME.MinkowskiConvolution(in, out, kernel_size=, stride=, bias=False, dimension=3)   -> .kernel
+    ME.MinkowskiConvolutionTranspose(in, out, kernel_size=2, stride=2, bias=False, dimension=3)
+    ME.MinkowskiBatchNorm(C, eps=, momentum=)     -> .bn.{weight,bias,running_mean,running_var,num_batches_tracked}
+    ME.MinkowskiReLU(inplace=True)
+    ME.cat(a, b)
+
+All arithmetic runs in libd3hip.so (csrc/coordmap.hip, spconv.hip, bn.hip).  MinkowskiEngine is an
+unpinned third-party dependency of the reference; the semantics implemented here are those of
+oracle/sparse_oracle.py (pinned against dense conv3d).  Kernel offset k = ox + Kd*oy + Kd^2*oz; a real
+ME checkpoint may need `kernel_permutation` (unverifiable offline).
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check
+from .pointgroup_ops import _ptr, _stream, _workspace
+
+D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT = 1, 2, 4
+
+_EXACT = False  # True: fp32 FMA kernels (validation); False: bf16 MFMA with fp32 accumulate
+
+
+def set_exact(flag):
+    """Select the exact-fp32 convolution kernels (slow; for validation) instead of bf16 MFMA."""
+    global _EXACT
+    _EXACT = bool(flag)
+
+
+def _mode_flag():
+    return D3_CONV_EXACT if _EXACT else 0
+
+
+# ------------------------------------------------------------------------------ coordinate manager
+class CoordinateManager:
+    """Coordinate sets and kernel maps per tensor stride (cached, shared by all layers of a forward)."""
+
+    def __init__(self, coordinates):
+        assert coordinates.is_cuda and coordinates.dtype == torch.int32 and coordinates.dim() == 2 and coordinates.size(1) == 4
+        self.device = coordinates.device
+        self.coords = {1: coordinates.contiguous()}
+        self._k3 = {}
+        self._down = {}
+
+    def _ws(self, M):
+        return _workspace(_lib.lib().d3_coordmap_ws_bytes(M), self.device, "cm")
+
+    def k3(self, ts):
+        if ts not in self._k3:
+            c = self.coords[ts]
+            M = c.size(0)
+            nbr = torch.empty((M, 27), dtype=torch.int32, device=self.device)
+            ws = self._ws(M)
+            with torch.cuda.device(self.device):
+                check(_lib.lib().d3_kmap_k3(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _stream()), "kmap_k3")
+            self._k3[ts] = nbr
+        return self._k3[ts]
+
+    def down(self, ts):
+        """-> (child (Mout,8), up (M,8), Mout); registers the coordinates of stride 2*ts."""
+        if ts not in self._down:
+            c = self.coords[ts]
+            M = c.size(0)
+            parent = torch.empty(M, dtype=torch.int32, device=self.device)
+            kidx = torch.empty(M, dtype=torch.int32, device=self.device)
+            ws = self._ws(M)
+            L = _lib.lib()
+            with torch.cuda.device(self.device):
+                Mo = C.c_int(0)
+                check(L.d3_kmap_down_count(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(parent), _ptr(kidx),
+                                           C.byref(Mo), _stream()), "kmap_down_count")
+                Mo = Mo.value
+                oc = torch.empty((Mo, 4), dtype=torch.int32, device=self.device)
+                child = torch.empty((Mo, 8), dtype=torch.int32, device=self.device)
+                up = torch.empty((M, 8), dtype=torch.int32, device=self.device)
+                check(L.d3_kmap_down_fill(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(parent), _ptr(kidx), _ptr(oc),
+                                          _ptr(child), _ptr(up), Mo, _stream()), "kmap_down_fill")
+            self.coords[2 * ts] = oc
+            self._down[ts] = (child, up, Mo, parent, kidx)
+        return self._down[ts][:3]
+
+
+class SparseTensor:
+    def __init__(self, features, coordinates=None, coordinate_manager=None, tensor_stride=1):
+        assert features.is_cuda, "d3net_amd.minkowski runs on the GPU only (no CPU fallback)"
+        if coordinate_manager is None:
+            coordinate_manager = CoordinateManager(coordinates.int().contiguous())
+        self.F = features
+        self.coordinate_manager = coordinate_manager
+        self.tensor_stride = tensor_stride
+        self._relu_done = False
+
+    @property
+    def features(self):
+        return self.F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.coords[self.tensor_stride]
+
+    coordinates = C
+
+    def _like(self, feats, stride=None):
+        return SparseTensor(feats, coordinate_manager=self.coordinate_manager,
+                            tensor_stride=self.tensor_stride if stride is None else stride)
+
+    def __iadd__(self, other):
+        assert other.tensor_stride == self.tensor_stride
+        self.F = self.F + other.F
+        self._relu_done = False
+        return self
+
+    def __add__(self, other):
+        return self._like(self.F + other.F)
+
+
+def cat(*tensors):
+    """ME.cat: channel concatenation of tensors on the same coordinate map (reference: model/common.py:114)."""
+    s = tensors[0].tensor_stride
+    assert all(t.tensor_stride == s and t.coordinate_manager is tensors[0].coordinate_manager for t in tensors)
+    return tensors[0]._like(torch.cat([t.F for t in tensors], 1))
+
+
+# ------------------------------------------------------------------------------------- autograd ops
+def _conv_call(x, tbl, W3, Mout, K, Cin, Cout, flags):
+    out = torch.empty((Mout, Cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().d3_spconv_fwd(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(W3), _ptr(out), Mout, K,
+                                       Cin, Cout, flags | _mode_flag(), _stream()), "spconv_fwd")
+    return out
+
+
+class SparseConvFunction(Function):
+    """out = sum_k x[tbl_f[:,k]] @ W[k];  backward through tbl_b (the transposed kernel map)."""
+
+    @staticmethod
+    def forward(ctx, x, W, tbl_f, tbl_b, Mout, bwd_flags):
+        x = x.contiguous()
+        W3 = W if W.dim() == 3 else W.unsqueeze(0)
+        K, Cin, Cout = W3.shape
+        assert x.size(1) == Cin and x.dtype == torch.float32 and W3.is_contiguous()
+        out = _conv_call(x, tbl_f, W3, Mout, K, Cin, Cout, 0)
+        ctx.save_for_backward(x, W)
+        ctx.maps = (tbl_f, tbl_b, Mout, bwd_flags)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        tbl_f, tbl_b, Mout, bwd_flags = ctx.maps
+        dy = dy.contiguous()
+        W3 = W if W.dim() == 3 else W.unsqueeze(0)
+        K, Cin, Cout = W3.shape
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            # data gradient: the same contraction over the transposed map with W^T (Cout -> Cin)
+            dx = _conv_call(dy, tbl_b, W3, x.size(0), K, Cout, Cin, bwd_flags | D3_CONV_TRANSW)
+        if ctx.needs_input_grad[1]:
+            dW = torch.zeros_like(W3)
+            with torch.cuda.device(x.device):
+                check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl_f) if tbl_f is not None else None, _ptr(dy),
+                                                 _ptr(dW), Mout, K, Cin, Cout, _mode_flag(), _stream()),
+                      "spconv_wgrad")
+            dW = dW.view_as(W)
+        return dx, dW, None, None, None, None
+
+
+class BatchNormReLUFunction(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        x = x.contiguous()
+        M, Cc = x.shape
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        var = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        ws = _workspace(2 * Cc * 8, x.device, "bn")
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            check(L.d3_bn_stats(_ptr(x), M, Cc, _ptr(mean), _ptr(var), _ptr(ws), ws.numel(), _stream()), "bn_stats")
+            check(L.d3_bn_relu_fwd(_ptr(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), _ptr(y), M, Cc, eps,
+                                   int(relu), _stream()), "bn_relu_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, var)
+        ctx.cfg = (eps, relu)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, gamma, beta, mean, var = ctx.saved_tensors
+        eps, relu = ctx.cfg
+        dy = dy.contiguous()
+        M, Cc = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(beta)
+        ws = _workspace(2 * Cc * 8, x.device, "bn")
+        with torch.cuda.device(x.device):
+            check(_lib.lib().d3_bn_relu_bwd(_ptr(x), _ptr(dy), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
+                                            _ptr(dx), _ptr(dgamma), _ptr(dbeta), M, Cc, eps, int(relu), _ptr(ws),
+                                            ws.numel(), _stream()), "bn_relu_bwd")
+        return dx, dgamma, dbeta, None, None
+
+
+class BatchNormEvalFunction(Function):
+    """eval mode: normalise with the running statistics (no batch reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, relu):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().d3_bn_relu_fwd(_ptr(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), _ptr(y),
+                                            x.size(0), x.size(1), eps, int(relu), _stream()), "bn_relu_fwd")
+        return y
+
+
+# ------------------------------------------------------------------------------------------ modules
+class MinkowskiConvolution(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
+        super().__init__()
+        assert dimension == 3 and dilation == 1 and not bias, "only what the reference uses is implemented"
+        assert (kernel_size, stride) in ((3, 1), (2, 2), (1, 1)), (kernel_size, stride)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        self.kernel_volume = kernel_size ** 3
+        shape = (in_channels, out_channels) if self.kernel_volume == 1 else (self.kernel_volume, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = None
+        self.reset_parameters()
+
+    def reset_parameters(self, is_transpose=False):
+        n = (self.out_channels if is_transpose else self.in_channels) * self.kernel_volume
+        stdv = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+
+    def forward(self, x):
+        cm, ts = x.coordinate_manager, x.tensor_stride
+        if self.kernel_size == 3:
+            nbr = cm.k3(ts)
+            f = SparseConvFunction.apply(x.F, self.kernel, nbr, nbr, nbr.size(0), D3_CONV_FLIPK)
+            return x._like(f)
+        if self.kernel_size == 1:
+            f = SparseConvFunction.apply(x.F, self.kernel, None, None, x.F.size(0), 0)
+            return x._like(f)
+        child, up, Mo = cm.down(ts)
+        f = SparseConvFunction.apply(x.F, self.kernel, child, up, Mo, 0)
+        return x._like(f, 2 * ts)
+
+    def extra_repr(self):
+        return "in=%d, out=%d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels, self.kernel_size, self.stride)
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
+        assert (kernel_size, stride) == (2, 2)
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, dimension)
+        self.reset_parameters(True)
+
+    def forward(self, x):
+        cm, ts = x.coordinate_manager, x.tensor_stride
+        assert ts % 2 == 0, "transposed conv lands on the cached finer coordinates"
+        child, up, Mo = cm.down(ts // 2)
+        assert Mo == x.F.size(0)
+        f = SparseConvFunction.apply(x.F, self.kernel, up, child, up.size(0), 0)
+        return x._like(f, ts // 2)
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """BatchNorm1d over the rows; parameters live in `.bn` exactly as in MinkowskiEngine."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+        self.fused_relu = False  # set by fuse_bn_relu(): the following MinkowskiReLU becomes a no-op
+
+    def forward(self, x):
+        bn = self.bn
+        if self.training or not bn.track_running_stats:
+            y, mean, var = BatchNormReLUFunction.apply(x.F, bn.weight, bn.bias, bn.eps, self.fused_relu)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    M = x.F.size(0)
+                    m = bn.momentum
+                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                    bn.running_var.mul_(1 - m).add_(var, alpha=m * M / max(M - 1, 1))
+                    bn.num_batches_tracked += 1
+        else:
+            y = BatchNormEvalFunction.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                            self.fused_relu)
+        out = x._like(y)
+        out._relu_done = self.fused_relu
+        return out
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        if x._relu_done:
+            return x
+        return x._like(torch.relu(x.F))
+
+
+def fuse_bn_relu(module):
+    """Mark every MinkowskiBatchNorm that is directly followed by a MinkowskiReLU inside an nn.Sequential so
+    that one kernel applies both (the module tree and its state-dict keys are unchanged)."""
+    for m in module.modules():
+        if isinstance(m, nn.Sequential):
+            kids = list(m.children())
+            for a, b in zip(kids[:-1], kids[1:]):
+                if isinstance(a, MinkowskiBatchNorm) and isinstance(b, MinkowskiReLU):
+                    a.fused_relu = True
+    return module

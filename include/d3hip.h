@@ -103,6 +103,53 @@ int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, c
                         void *ws, size_t ws_bytes, int *cluster_idxs, int *cluster_offsets, int sumNPoint,
                         int nCluster, void *stream);
 
+/* ---- sparse 3-D convolution (MinkowskiEngine subset) ---------------------------------- */
+/* Coordinates are (M,4) int32 rows [batch, x, y, z] (ME.SparseTensor(coordinates=...),
+ * reference: model/pointgroup.py:176,268).  Key range as for voxelize_idx.
+ * A kernel map is a dense table tbl (Mout, K) int32: tbl[u][k] = input row feeding output row u
+ * through kernel offset k, or -1.  k = ox + Kd*oy + Kd*Kd*oz (x fastest).
+ *
+ * d3_kmap_k3      : K=27 neighbour table of a kernel-3 stride-1 conv at tensor stride ts
+ *                   (MinkowskiConvolution(kernel_size=3): model/common.py:38,41,66; model/pointgroup.py:70).
+ * d3_kmap_down_*  : kernel-2 stride-2 maps (MinkowskiConvolution(kernel_size=2, stride=2) and its
+ *                   MinkowskiConvolutionTranspose: model/common.py:90,98): output coordinates
+ *                   floor(c/(2ts))*2ts in first-occurrence order, parent/kidx per input row,
+ *                   child (Mout,8) for the strided conv, up (M,8) for the transposed conv. */
+size_t d3_coordmap_ws_bytes(int M);
+int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *stream);
+int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *parent, int *kidx,
+                       int *Mout_host, void *stream);
+int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,
+                      const int *kidx, int *out_coords, int *child, int *up, int Mout, void *stream);
+
+/* Gather-GEMM convolution  out[u,:] = sum_k x[tbl[u,k],:] @ Wk   (tbl == NULL: identity map, K = 1).
+ * flags: D3_CONV_FLIPK  -> Wk = W[K-1-k]      (data gradient of a kernel-3 conv)
+ *        D3_CONV_TRANSW -> W is laid out (K, Cout, Cin) and used transposed (data gradients)
+ *        D3_CONV_EXACT  -> fp32 FMA kernel instead of the bf16-MFMA kernel (fp32 accumulate in both)
+ * x (Min,Cin) f32, W (K,Cin,Cout) f32 [or (K,Cout,Cin) with TRANSW], out (Mout,Cout) f32.
+ * MFMA path needs Cout % 16 == 0 and Cin % 2 == 0, else D3_ERR_ARG. */
+#define D3_CONV_FLIPK 1
+#define D3_CONV_TRANSW 2
+#define D3_CONV_EXACT 4
+int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
+                  int Cout, int flags, void *stream);
+/* Weight gradient  dW[k] += sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32, accumulated into). */
+int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Mout, int K, int Cin,
+                    int Cout, int flags, void *stream);
+
+/* MinkowskiBatchNorm (+ MinkowskiReLU) over the rows of an (M,C) feature matrix
+ * (reference: model/pointgroup.py:65,72-73; model/common.py:36-40).  Training-mode batch statistics.
+ * stats : mean (C) and biased var (C) in fp32 (fp64 accumulation); ws >= 2*C doubles.
+ * fwd   : y = [relu]((x-mean)*rsqrt(var+eps)*gamma+beta)
+ * bwd   : dx from dy (the relu mask is recomputed from x), dgamma/dbeta accumulated into;
+ *         ws >= 2*C doubles. */
+int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, void *ws, size_t ws_bytes, void *stream);
+int d3_bn_relu_fwd(const float *x, const float *mean, const float *var, const float *gamma, const float *beta,
+                   float *y, int M, int C, float eps, int relu, void *stream);
+int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const float *var, const float *gamma,
+                   const float *beta, float *dx, float *dgamma, float *dbeta, int M, int C, float eps, int relu,
+                   void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

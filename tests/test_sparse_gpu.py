@@ -1,0 +1,199 @@
+"""GPU parity: sparse convolution / batch-norm kernels and the whole U-Net vs the fp32 CPU oracle.
+
+Kernel maps are integer work: bit-exact.  Convolutions: the exact-fp32 kernels within 1e-4 (relative to the
+output scale), the bf16-MFMA kernels (bf16 operands, fp32 accumulate) within 2e-2 -- bf16 has 8 mantissa
+bits, so a K-term dot product of unit-scale operands carries ~2^-9*sqrt(K) relative error.
+"""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_coords(rng, dims, occ, batch=2):
+    cs = []
+    for b in range(batch):
+        c = np.argwhere(rng.random(dims) < occ)
+        c = c[rng.permutation(len(c))] - np.array([3, 0, 2])  # some negative coordinates too
+        cs.append(np.concatenate([np.full((len(c), 1), b), c], 1))
+    return np.concatenate(cs).astype(np.int64)
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_kernel_maps_bit_exact(dev):
+    from d3net_amd import minkowski as ME
+    rng = np.random.default_rng(0)
+    coords = rand_coords(rng, (40, 30, 20), 0.08)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).int().to(dev))
+    ocm = so.OracleCoords(coords)
+    ts = 1
+    for level in range(4):
+        nbr = cm.k3(ts).cpu().numpy()
+        assert np.array_equal(nbr, ocm.get_k3(ts)), level
+        child, up, Mo = cm.down(ts)
+        parent, kidx, oMo = ocm.get_down(ts)
+        assert Mo == oMo
+        assert np.array_equal(cm.coords[2 * ts].cpu().numpy(), ocm.levels[2 * ts])
+        child, up = child.cpu().numpy(), up.cpu().numpy()
+        M = len(parent)
+        ref_up = np.full((M, 8), -1); ref_up[np.arange(M), kidx] = parent
+        ref_child = np.full((Mo, 8), -1); ref_child[parent, kidx] = np.arange(M)
+        assert np.array_equal(up, ref_up) and np.array_equal(child, ref_child)
+        ts *= 2
+
+
+CONV_CASES = [("k3", 16, 16), ("k3", 134, 16), ("k3", 32, 48), ("k3", 224, 112), ("down", 16, 32), ("down", 96, 112),
+              ("up", 32, 16), ("up", 112, 96), ("k1", 32, 16), ("k1", 224, 112)]
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("kind,cin,cout", CONV_CASES)
+def test_conv_fwd_bwd_vs_oracle(dev, kind, cin, cout, exact):
+    from d3net_amd import minkowski as ME
+    ME.set_exact(exact)
+    try:
+        rng = np.random.default_rng(hash((kind, cin, cout)) % 1000)
+        coords = rand_coords(rng, (24, 20, 12), 0.15)
+        cm = ME.CoordinateManager(torch.from_numpy(coords).int().to(dev))
+        ocm = so.OracleCoords(coords)
+        M = coords.shape[0]
+        parent, kidx, Mo = ocm.get_down(1)
+        cm.down(1)
+        if kind == "k3":
+            layer = ME.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=3); Min, ts_in = M, 1
+        elif kind == "down":
+            layer = ME.MinkowskiConvolution(cin, cout, kernel_size=2, stride=2, dimension=3); Min, ts_in = M, 1
+        elif kind == "up":
+            layer = ME.MinkowskiConvolutionTranspose(cin, cout, kernel_size=2, stride=2, dimension=3); Min, ts_in = Mo, 2
+        else:
+            layer = ME.MinkowskiConvolution(cin, cout, kernel_size=1, dimension=3); Min, ts_in = M, 1
+        layer = layer.to(dev)
+        x = torch.from_numpy(rng.standard_normal((Min, cin)).astype(np.float32))
+        W = layer.kernel.detach().cpu().clone().requires_grad_(True)
+        xo = x.clone().requires_grad_(True)
+        if kind == "k3":
+            ref = so.conv_k3(xo, W, ocm.get_k3(1))
+        elif kind == "down":
+            ref = so.conv_down(xo, W, parent, kidx, Mo)
+        elif kind == "up":
+            ref = so.conv_up(xo, W, parent, kidx)
+        else:
+            ref = xo @ W
+        g = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        ref.backward(g)
+        xd = x.to(dev).requires_grad_(True)
+        out = layer(ME.SparseTensor(xd, coordinate_manager=cm, tensor_stride=ts_in))
+        out.F.backward(g.to(dev))
+        tol = 1e-4 if exact else 2e-2
+        assert out.F.shape == ref.shape
+        assert relerr(out.F, ref) < tol
+        assert relerr(xd.grad, xo.grad) < tol
+        assert relerr(layer.kernel.grad, W.grad) < tol
+    finally:
+        ME.set_exact(False)
+
+
+@pytest.mark.parametrize("C,relu", [(16, True), (48, False), (112, True)])
+def test_batchnorm_relu_fwd_bwd(dev, C, relu):
+    from d3net_amd import minkowski as ME
+    rng = np.random.default_rng(C)
+    M = 5000
+    x = torch.from_numpy((rng.standard_normal((M, C)) * 2 + 0.5).astype(np.float32))
+    gamma = torch.from_numpy(rng.random(C).astype(np.float32) + 0.5); beta = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.3)
+    xo = x.clone().requires_grad_(True); go = gamma.clone().requires_grad_(True); bo = beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ref = so.bn_relu(xo, go, bo, 1e-4, relu, (rm, rv))
+    g = torch.from_numpy(rng.standard_normal((M, C)).astype(np.float32))
+    ref.backward(g)
+    bn = ME.MinkowskiBatchNorm(C, eps=1e-4, momentum=0.1).to(dev)
+    bn.fused_relu = relu
+    with torch.no_grad():
+        bn.bn.weight.copy_(gamma); bn.bn.bias.copy_(beta)
+    xd = x.to(dev).requires_grad_(True)
+    coords = torch.zeros((M, 4), dtype=torch.int32, device=dev); coords[:, 1] = torch.arange(M, device=dev) % 16000
+    out = bn(ME.SparseTensor(xd, coordinates=coords))
+    out.F.backward(g.to(dev))
+    assert relerr(out.F, ref) < 1e-5
+    assert relerr(xd.grad, xo.grad) < 1e-4
+    assert relerr(bn.bn.weight.grad, go.grad) < 1e-4 and relerr(bn.bn.bias.grad, bo.grad) < 1e-4
+    assert relerr(bn.bn.running_mean, rm) < 1e-5 and relerr(bn.bn.running_var, rv) < 1e-5
+
+
+def _shared_unet(dev, planes, cin):
+    """the HIP backbone and the oracle backbone on the same parameters"""
+    from d3net_amd import minkowski as ME, common
+    torch.manual_seed(123)
+    norm = functools.partial(ME.MinkowskiBatchNorm, eps=1e-4, momentum=0.1)
+    net = torch.nn.Sequential(ME.MinkowskiConvolution(cin, planes[0], kernel_size=3, bias=False, dimension=3),
+                              common.UBlock(planes, norm, 2, common.ResidualBlock), norm(planes[0]),
+                              ME.MinkowskiReLU(inplace=True))
+    ME.fuse_bn_relu(net)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("bn.weight"):
+                p.uniform_(0.5, 1.5)
+            if n.endswith("bn.bias"):
+                p.uniform_(-0.2, 0.2)
+    params = {n: p.detach().clone().requires_grad_(True) for n, p in net.named_parameters()}
+    return net.to(dev), params
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_unet_forward_backward_vs_oracle(dev, exact):
+    from d3net_amd import minkowski as ME
+    ME.set_exact(exact)
+    try:
+        rng = np.random.default_rng(7)
+        planes, cin = [16, 32, 48, 64], 134
+        coords = rand_coords(rng, (40, 32, 20), 0.12)
+        x = torch.from_numpy(rng.standard_normal((len(coords), cin)).astype(np.float32))
+        net, params = _shared_unet(dev, planes, cin)
+        # oracle
+        ocm = so.OracleCoords(coords)
+        xo = x.clone().requires_grad_(True)
+        h = so.conv_k3(xo, params["0.kernel"], ocm.get_k3(1))
+        h = so.OracleUNet(params, planes).forward(h, ocm)
+        ref = so.bn_relu(h, params["2.bn.weight"], params["2.bn.bias"], 1e-4, True)
+        g = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        ref.backward(g)
+        # HIP
+        xd = x.to(dev).requires_grad_(True)
+        out = net(ME.SparseTensor(xd, coordinates=torch.from_numpy(coords).int().to(dev)))
+        out.F.backward(g.to(dev))
+        tol = 2e-3 if exact else 6e-2
+        assert relerr(out.F, ref) < tol
+        assert relerr(xd.grad, xo.grad) < tol
+        worst = max(relerr(p.grad, params[n].grad) for n, p in net.named_parameters())
+        assert worst < (5e-3 if exact else 1e-1), worst
+    finally:
+        ME.set_exact(False)
+
+
+def test_canonical_scene_maps(dev):
+    """Full-size (BASELINE config 2) coordinate maps: level sizes and pair counts of SURVEY.md row A3."""
+    from d3net_amd import minkowski as ME, synthetic as S
+    occ, _, _, _ = S.occupancy_grid()
+    vox = np.argwhere(occ)
+    coords = np.concatenate([np.zeros((len(vox), 1), np.int64), vox], 1)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).int().to(dev))
+    Ms, Ps, ts = [], [], 1
+    for _ in range(7):
+        nbr = cm.k3(ts)
+        Ms.append(nbr.size(0)); Ps.append(int((nbr >= 0).sum()))
+        # symmetry of the neighbour table: nbr[nbr[u,k], 26-k] == u
+        u = torch.arange(nbr.size(0), device=dev)
+        for k in (0, 5, 13, 20):
+            v = nbr[:, k].long(); m = v >= 0
+            assert torch.equal(nbr[v[m], 26 - k].long(), u[m])
+        cm.down(ts); ts *= 2
+    assert Ms == [142920, 35127, 8282, 1945, 460, 104, 22]
+    assert Ps == [1332424, 355069, 88232, 22779, 5710, 1236, 212]
