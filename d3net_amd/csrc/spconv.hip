@@ -30,6 +30,49 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
     return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
 }
 
+// ------------------------------------------------------------------------------ launch timing (bench.py)
+// When enabled, every MFMA convolution launch is bracketed by two HIP events on its own stream and tagged
+// with its algorithmic byte / flop count; d3_prof_collect() resolves them after the timed region.
+#include <vector>
+struct ProfRec { hipEvent_t a, b; int family; double bytes, flops; };
+static std::vector<ProfRec> g_prof;
+static size_t g_prof_used = 0;
+static int g_prof_on = 0;
+#define PROF_MAX 200000
+
+extern "C" int d3_prof_enable(int on) {
+    g_prof_on = on;
+    g_prof_used = 0;
+    return 0;
+}
+static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s) {
+    if (!g_prof_on || g_prof_used >= PROF_MAX) return nullptr;
+    if (g_prof_used == g_prof.size()) {
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+        g_prof.push_back(r);
+    }
+    ProfRec *r = &g_prof[g_prof_used++];
+    r->family = family; r->bytes = bytes; r->flops = flops;
+    hipEventRecord(r->a, s);
+    return r;
+}
+static void prof_end(ProfRec *r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
+// family: 0 = spconv_fwd_mfma (forward + data gradient), 1 = spconv_wgrad_mfma
+extern "C" int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes,
+                               double *total_flops) {
+    *launches = 0; *total_ms = 0; *total_bytes = 0; *total_flops = 0;
+    for (size_t i = 0; i < g_prof_used; i++) {
+        ProfRec &r = g_prof[i];
+        if (r.family != family) continue;
+        D3_CHECK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        D3_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        *launches += 1; *total_ms += ms; *total_bytes += r.bytes; *total_flops += r.flops;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ exact fp32 kernels
 // One thread per output element; used for D3_CONV_EXACT (validation / fp32 mode).
 __global__ void spconv_fwd_exact_kernel(const float *__restrict__ x, const int *__restrict__ tbl,
@@ -75,8 +118,8 @@ template <int NT, bool TRANSW>
 __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__restrict__ x,
                                                              const int *__restrict__ tbl,
                                                              const float *__restrict__ W, float *__restrict__ out,
-                                                             int Mout, int K, int Cin, int flipk) {
-    constexpr int Cout = NT * 16;
+                                                             int Mout, int K, int Cin, int Cout, int flipk) {
+    constexpr int CoutP = NT * 16;  // Cout rounded up to the MFMA tile; columns >= Cout are zero / not stored
     __shared__ int tblS[CV_BM * CV_MAXK];
     __shared__ __attribute__((aligned(16))) unsigned short As[CV_BM * CV_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Bt[NT * 16 * CV_LD];
@@ -122,18 +165,18 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
                 *(uint4 *)&As[arow * CV_LD + aq * 8] = pk;
             }
             // ---- stage B: W chunk (32 x Cout) -> Bt[n][kk] bf16, two kk per 32-bit store
-            for (int e = t; e < 16 * Cout; e += 256) {
+            for (int e = t; e < 16 * CoutP; e += 256) {
                 int n, kp;
                 float w0 = 0.f, w1 = 0.f;
                 if (TRANSW) {  // W laid out (K, Cout, Cin): contiguous along the reduction index
                     n = e >> 4; kp = e & 15;
                     const int c = c0 + 2 * kp;
-                    if (c + 2 <= Cin) { float2 f = *(const float2 *)(Wk + (long long)n * Cin + c); w0 = f.x; w1 = f.y; }
+                    if (n < Cout && c + 2 <= Cin) { float2 f = *(const float2 *)(Wk + (long long)n * Cin + c); w0 = f.x; w1 = f.y; }
                 } else {       // W laid out (K, Cin, Cout): coalesced along n
-                    kp = e / Cout; n = e % Cout;
+                    kp = e / CoutP; n = e % CoutP;
                     const int c = c0 + 2 * kp;
-                    if (c < Cin) w0 = Wk[(long long)c * Cout + n];
-                    if (c + 1 < Cin) w1 = Wk[(long long)(c + 1) * Cout + n];
+                    if (n < Cout && c < Cin) w0 = Wk[(long long)c * Cout + n];
+                    if (n < Cout && c + 1 < Cin) w1 = Wk[(long long)(c + 1) * Cout + n];
                 }
                 *(unsigned int *)&Bt[n * CV_LD + 2 * kp] = pack2bf(w0, w1);
             }
@@ -156,7 +199,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int u = row0 + wave * 16 + (lane >> 4) * 4 + r;
-            if (u < Mout) out[(long long)u * Cout + n * 16 + (lane & 15)] = acc[n][r];
+            const int col = n * 16 + (lane & 15);
+            if (u < Mout && col < Cout) out[(long long)u * Cout + col] = acc[n][r];
         }
     }
 }
@@ -167,9 +211,9 @@ static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float
     const int grid = (Mout + CV_BM - 1) / CV_BM;
 #define CV_CASE(NTV)                                                                                        \
     case NTV:                                                                                               \
-        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, flipk);     \
+        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk); \
         break;
-    switch (Cout / 16) {
+    switch ((Cout + 15) / 16) {
         CV_CASE(1) CV_CASE(2) CV_CASE(3) CV_CASE(4) CV_CASE(5) CV_CASE(6) CV_CASE(7) CV_CASE(8) CV_CASE(9)
         CV_CASE(10) CV_CASE(11) CV_CASE(12) CV_CASE(13) CV_CASE(14)
         default: return D3_ERR_ARG;
@@ -179,8 +223,8 @@ static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float
     return 0;
 }
 
-extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
-                             int Cout, int flags, void *stream) {
+extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K,
+                             int Cin, int Cout, int flags, void *stream) {
     if (Mout <= 0) return 0;
     if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -193,14 +237,20 @@ extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, flo
         D3_LAUNCH_CHECK();
         return 0;
     }
-    if ((Cout & 15) != 0 || (Cin & 1) != 0 || Cout > 224) return D3_ERR_ARG;
-    return transw ? launch_fwd_mfma<true>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s)
-                  : launch_fwd_mfma<false>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s);
+    if ((Cin & 1) != 0 || Cout > 224) return D3_ERR_ARG;
+    // algorithmic traffic: features in once, out once, weights once, one table entry per (row, offset)
+    const double bytes = 4.0 * ((double)Min * Cin + (double)Mout * Cout + (double)K * Cin * Cout) +
+                         (tbl ? 4.0 * (double)Mout * K : 0.0);
+    ProfRec *pr = prof_begin(0, bytes, 0.0, s);
+    int rc = transw ? launch_fwd_mfma<true>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s)
+                    : launch_fwd_mfma<false>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s);
+    prof_end(pr, s);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------ MFMA weight gradient
 // dW[k][ci][co] += sum_u x[tbl[u,k]][ci] * dy[u][co]:  M-dim = ci, N-dim = co, reduction = rows.
-// grid = (row blocks, K).  Each wave owns a quarter of the block's rows, stages 32 rows at a time
+// grid = (row blocks, K).  Each wave owns an equal share of the block's rows, stages 32 rows at a time
 // TRANSPOSED into its private LDS region (Xt[ci][row], DYt[co][row]) so that both MFMA operands are
 // contiguous 8-byte reads, keeps up to WG_MAXT 16x16 accumulators, and the workgroup's four
 // partial results are added to dW with fp32 atomics (order-dependent rounding in the last bits).
@@ -214,13 +264,13 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__r
                                                                int Mout, int K, int Cin, int Cout) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
     unsigned short *Xt = smem + (size_t)wave * (CinP + CoutP) * CV_LD;
     unsigned short *DYt = Xt + (size_t)CinP * CV_LD;
     const int k = blockIdx.y;
     const int rb0 = blockIdx.x * WG_ROWS;
     const int rows_blk = min(WG_ROWS, Mout - rb0);
-    const int per_wave = (rows_blk + 3) / 4;
+    const int per_wave = (rows_blk + nwaves - 1) / nwaves;
     const int w0 = rb0 + wave * per_wave;                     // this wave's rows [w0, w1)
     const int w1 = min(rb0 + rows_blk, w0 + per_wave);
     const int nchunks = (per_wave + WG_RC - 1) / WG_RC;       // uniform over the block
@@ -288,7 +338,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__r
     }
 }
 
-extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Mout, int K,
+extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Min, int Mout, int K,
                                int Cin, int Cout, int flags, void *stream) {
     if (Mout <= 0) return 0;
     if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
@@ -302,18 +352,17 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
     }
     if ((Cin & 1) != 0 || (Cout & 1) != 0) return D3_ERR_ARG;
     const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
-    size_t lds = (size_t)4 * (CinP + CoutP) * CV_LD * sizeof(unsigned short);
-    if (lds > 160 * 1024) return D3_ERR_ARG;
+    // 64 KB of dynamic LDS per workgroup: wide layers run with fewer waves (each wave stages its own rows)
+    int nwaves = 4;
+    while (nwaves > 1 && (size_t)nwaves * (CinP + CoutP) * CV_LD * sizeof(unsigned short) > 64 * 1024) nwaves >>= 1;
+    size_t lds = (size_t)nwaves * (CinP + CoutP) * CV_LD * sizeof(unsigned short);
+    if (lds > 64 * 1024) return D3_ERR_ARG;
     dim3 grid((Mout + WG_ROWS - 1) / WG_ROWS, K);
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-            attr_set = true;
-        }
-    }
-    spconv_wgrad_mfma_kernel<<<grid, 256, lds, s>>>(x, tbl, dy, dW, Mout, K, Cin, Cout);
+    const double bytes = 4.0 * ((double)Min * Cin + (double)Mout * Cout + (double)K * Cin * Cout) +
+                         (tbl ? 4.0 * (double)Mout * K : 0.0);
+    ProfRec *pr = prof_begin(1, bytes, 0.0, s);
+    spconv_wgrad_mfma_kernel<<<grid, nwaves * 64, lds, s>>>(x, tbl, dy, dW, Mout, K, Cin, Cout);
+    prof_end(pr, s);
     D3_LAUNCH_CHECK();
     return 0;
 }

@@ -135,8 +135,8 @@ def cat(*tensors):
 def _conv_call(x, tbl, W3, Mout, K, Cin, Cout, flags):
     out = torch.empty((Mout, Cout), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib().d3_spconv_fwd(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(W3), _ptr(out), Mout, K,
-                                       Cin, Cout, flags | _mode_flag(), _stream()), "spconv_fwd")
+        check(_lib.lib().d3_spconv_fwd(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(W3), _ptr(out),
+                                       x.size(0), Mout, K, Cin, Cout, flags | _mode_flag(), _stream()), "spconv_fwd")
     return out
 
 
@@ -169,7 +169,7 @@ class SparseConvFunction(Function):
             dW = torch.zeros_like(W3)
             with torch.cuda.device(x.device):
                 check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl_f) if tbl_f is not None else None, _ptr(dy),
-                                                 _ptr(dW), Mout, K, Cin, Cout, _mode_flag(), _stream()),
+                                                 _ptr(dW), x.size(0), Mout, K, Cin, Cout, _mode_flag(), _stream()),
                       "spconv_wgrad")
             dW = dW.view_as(W)
         return dx, dW, None, None, None, None

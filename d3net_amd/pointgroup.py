@@ -1,0 +1,376 @@
+"""PointGroup detector on MI355X: the reference's `model.pointgroup.PointGroup` with the same constructor,
+methods (`feed`, `forward`, `parse_feed_ret`, `loss`, `clusters_voxelization`, `convert_stack_to_batch`,
+`get_object_assignments`, `get_batch_offsets`), `data_dict` keys and state-dict layout
+(reference: model/pointgroup.py:24-541; key flow in SURVEY.md Appendix A), rebuilt so that the whole
+forward stays on the device:
+
+  reference (model/pointgroup.py)                          here
+  ----------------------------------------------------    ---------------------------------------------
+  :112-122 python loop + .sum() sync per scene             bincount + cumsum on the device
+  :296-305 ball query on GPU, D2H of the lists, CPU BFS    HIP ball query + HIP clustering, no D2H
+  :166-169 D2H of cluster coords, CPU hash voxelisation    HIP voxelization_idx on the device
+  :342-344 python loop over proposals, O(P*S) on the CPU   proposals_offset[1:] - proposals_offset[:-1]
+  :233-235 numpy box corners on the CPU                    fp64 corner arithmetic on the device
+Host RNG draws the reference makes (`torch.rand(3)` x2 at :161, `torch.randperm(128)` at :251) are drawn
+from the same CPU generator in the same order, so a seeded run is comparable with the oracle.
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import common
+from . import minkowski as ME
+from . import pointgroup_ops
+
+
+class PointGroup(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.task = cfg.general.task
+        in_channel = cfg.model.use_color * 3 + cfg.model.use_normal * 3 + cfg.model.use_coords * 3 + \
+            cfg.model.use_multiview * 128
+        m = cfg.model.m
+        D = 3
+        classes = cfg.data.classes
+        block = common.ResidualBlock if cfg.model.block_residual else common.VGGBlock
+
+        self.requires_gt_mask = cfg.data.requires_gt_mask
+        self.cluster_radius = cfg.cluster.cluster_radius
+        self.cluster_meanActive = cfg.cluster.cluster_meanActive
+        self.cluster_shift_meanActive = cfg.cluster.cluster_shift_meanActive
+        self.cluster_npoint_thre = cfg.cluster.cluster_npoint_thre
+        self.freeze_backbone = cfg.cluster.freeze_backbone
+        self.score_scale = cfg.train.score_scale
+        self.score_fullscale = cfg.train.score_fullscale
+        self.mode = cfg.train.score_mode
+        self.prepare_epochs = cfg.cluster.prepare_epochs
+        self.current_epoch = 0
+
+        sp_norm = functools.partial(ME.MinkowskiBatchNorm, eps=1e-4, momentum=0.1)
+        norm = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+
+        # backbone: stem conv, 7-level U-Net, BN, ReLU                       (reference :69-74)
+        self.backbone = nn.Sequential(
+            ME.MinkowskiConvolution(in_channel, m, kernel_size=3, bias=False, dimension=D),
+            common.UBlock([m * c for c in cfg.model.blocks], sp_norm, cfg.model.block_reps, block),
+            sp_norm(m),
+            ME.MinkowskiReLU(inplace=True))
+        self.sem_seg = nn.Linear(m, classes)                                # (reference :77)
+        self.offset_net = nn.Sequential(nn.Linear(m, m), norm(m), nn.ReLU(inplace=True), nn.Linear(m, 3))  # :80-85
+        self.score_net = nn.Sequential(                                     # (reference :88-92)
+            common.UBlock([m * c for c in cfg.model.cluster_blocks], sp_norm, 2, block),
+            sp_norm(m),
+            ME.MinkowskiReLU(inplace=True))
+        if cfg.model.pred_bbox:
+            raise NotImplementedError("pred_bbox=True is not on the hot path (conf/pointgroup.yaml: pred_bbox False)")
+        self.score_linear = nn.Linear(m, 1)                                 # (reference :108)
+        ME.fuse_bn_relu(self)
+
+        # test hooks: override predictions before clustering ("teacher" switch of SURVEY.md 8(d))
+        self.teacher = False
+
+    # ------------------------------------------------------------------------------------- helpers
+    @staticmethod
+    def get_batch_offsets(batch_idxs, batch_size):
+        """(B+1) int32 offsets of the (sorted) batch index column (reference :110-122), without host syncs."""
+        counts = torch.bincount(batch_idxs.long(), minlength=batch_size)[:batch_size]
+        offsets = torch.zeros(batch_size + 1, dtype=torch.int32, device=batch_idxs.device)
+        offsets[1:] = torch.cumsum(counts, 0).int()
+        return offsets
+
+    def clusters_voxelization(self, clusters_idx, clusters_offset, feats, coords, fullscale, scale, mode, rand=None):
+        """Normalise every cluster into a <= fullscale^3 grid and voxelise it (reference :125-178).
+        clusters_idx (S,2) int32, clusters_offset (P+1) int32 -- on the device here.
+        rand: optional (2,3) tensor standing in for the two `torch.rand(3)` draws of the reference (:161)."""
+        dev = feats.device
+        c_idxs = clusters_idx[:, 1].long()
+        cid = clusters_idx[:, 0].long()
+        clusters_feats = feats[c_idxs]
+        clusters_coords = coords[c_idxs]
+
+        clusters_coords_mean = pointgroup_ops.sec_mean(clusters_coords, clusters_offset)      # (P,3)
+        clusters_coords = clusters_coords - torch.index_select(clusters_coords_mean, 0, cid)
+        clusters_coords_min = pointgroup_ops.sec_min(clusters_coords, clusters_offset)
+        clusters_coords_max = pointgroup_ops.sec_max(clusters_coords, clusters_offset)
+
+        clusters_size = clusters_coords_max - clusters_coords_min
+        clusters_center = (clusters_coords_max + clusters_coords_min) / 2 + clusters_coords_mean
+
+        clusters_scale = 1 / ((clusters_coords_max - clusters_coords_min) / fullscale).max(1)[0] - 0.01
+        clusters_scale = torch.clamp(clusters_scale, min=None, max=scale)
+        min_xyz = clusters_coords_min * clusters_scale.unsqueeze(-1)
+        max_xyz = clusters_coords_max * clusters_scale.unsqueeze(-1)
+        clusters_scale = torch.index_select(clusters_scale, 0, cid)
+        clusters_coords = clusters_coords * clusters_scale.unsqueeze(-1)
+
+        rng = max_xyz - min_xyz
+        if rand is None:
+            r0, r1 = torch.rand(3), torch.rand(3)   # CPU generator, same order as the reference
+        else:
+            r0, r1 = rand[0].cpu(), rand[1].cpu()
+        offset = - min_xyz + torch.clamp(fullscale - rng - 0.001, min=0) * r0.to(dev) + \
+            torch.clamp(fullscale - rng + 0.001, max=0) * r1.to(dev)
+        clusters_coords = clusters_coords + torch.index_select(offset, 0, cid)
+
+        clusters_coords = clusters_coords.long()                                               # truncation (:166)
+        clusters_coords = torch.cat([cid.view(-1, 1), clusters_coords], 1).contiguous()        # (S,4) on the device
+        n_clusters = int(clusters_offset.numel() - 1)
+        voxel_coords, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(clusters_coords, n_clusters, mode)
+        voxel_feats = pointgroup_ops.voxelization(clusters_feats, v2p_map, mode)
+        voxel_feats = ME.SparseTensor(features=voxel_feats, coordinates=voxel_coords.int())
+        return voxel_feats, p2v_map, (clusters_center, clusters_size)
+
+    def get_object_assignments(self, data_dict):
+        """nearest GT centre in L1 for every proposal slot (reference :216-221; lib/utils/nn_distance.py:32-59)."""
+        pc1, pc2 = data_dict["proposal_center_batched"], data_dict["center_label"]
+        dist = (pc1.unsqueeze(2) - pc2.unsqueeze(1)).abs().sum(-1)
+        data_dict["object_assignment"] = dist.min(2)[1]
+        return data_dict
+
+    @staticmethod
+    def _box_corners(center, size):
+        """lib/utils/bbox.py:54-74 (get_3d_box_batch) for heading 0, in fp64 like the numpy original."""
+        c = center.double(); s = size.double()
+        sx = torch.tensor([1, 1, -1, -1, 1, 1, -1, -1], dtype=torch.float64, device=c.device)
+        sy = torch.tensor([1, -1, -1, 1, 1, -1, -1, 1], dtype=torch.float64, device=c.device)
+        sz = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], dtype=torch.float64, device=c.device)
+        corners = torch.stack([s[:, 0:1] / 2 * sx, s[:, 1:2] / 2 * sy, s[:, 2:3] / 2 * sz], -1)  # (P,8,3)
+        return corners + c.unsqueeze(1)
+
+    def convert_stack_to_batch(self, data_dict, perms=None):
+        """stacked proposals -> (B,128,.) padded + shuffled tensors (reference :223-263)."""
+        batch_size = len(data_dict["batch_offsets"]) - 1
+        K = self.cfg.model.max_num_proposal
+        pf = data_dict["proposal_feats"]
+        dev = pf.device
+        crop = data_dict["proposal_crop_bbox"]
+        corners = self._box_corners(crop[:, :3].detach(), crop[:, 3:6].detach()).to(pf.dtype)
+        out = {
+            "proposal_feats_batched": pf.new_zeros(batch_size, K, self.cfg.model.m),
+            "proposal_bbox_batched": pf.new_zeros(batch_size, K, 8, 3),
+            "proposal_center_batched": pf.new_zeros(batch_size, K, 3),
+            "proposal_sem_cls_batched": pf.new_zeros(batch_size, K),
+            "proposal_scores_batched": pf.new_zeros(batch_size, K),
+            "proposal_batch_mask": pf.new_zeros(batch_size, K),
+        }
+        bids = data_dict["proposals_batchId"]
+        for b in range(batch_size):
+            idx = torch.nonzero(bids == b).squeeze(-1)[:K]
+            n = idx.numel()
+            rows = {
+                "proposal_feats_batched": pf[idx], "proposal_bbox_batched": corners[idx],
+                "proposal_center_batched": crop[idx, :3], "proposal_sem_cls_batched": crop[idx, 7],
+                "proposal_scores_batched": data_dict["proposal_objectness_scores"][idx],
+            }
+            perm = (torch.randperm(K) if perms is None else perms[b]).to(dev)   # slot shuffle (:251)
+            for k, v in rows.items():
+                buf = out[k][b].clone()
+                buf[:n] = v
+                out[k][b] = buf[perm]
+            mask = pf.new_zeros(K); mask[:n] = 1
+            out["proposal_batch_mask"][b] = mask[perm]
+        data_dict.update(out)
+        if self.cfg.general.task != "test":
+            data_dict = self.get_object_assignments(data_dict)
+        return data_dict
+
+    # ------------------------------------------------------------------------------------- forward
+    def forward(self, data_dict):
+        batch_size = len(data_dict["batch_offsets"]) - 1
+        x = ME.SparseTensor(features=data_dict["voxel_feats"], coordinates=data_dict["voxel_locs"].int())
+        out = self.backbone(x)
+        pt_feats = out.features[data_dict["p2v_map"].long()]                       # (N, m) "devoxelize"
+
+        semantic_scores = self.sem_seg(pt_feats)
+        semantic_preds = semantic_scores.max(1)[1]
+        data_dict["semantic_scores"] = semantic_scores
+        pt_offsets = self.offset_net(pt_feats)
+        data_dict["pt_offsets"] = pt_offsets
+
+        if data_dict["epoch"] > self.prepare_epochs or self.freeze_backbone:
+            if self.teacher:   # benchmark/test switch: cluster on the labels instead of the (random-init) predictions
+                semantic_preds = data_dict["sem_labels"].clamp(min=0)
+                cluster_offsets = (data_dict["instance_info"][:, 0:3] - data_dict["locs"]).detach()
+                cluster_offsets = torch.where((data_dict["instance_ids"] >= 0).unsqueeze(1), cluster_offsets,
+                                              torch.zeros_like(cluster_offsets))
+            else:
+                cluster_offsets = pt_offsets
+            batch_idxs = data_dict["locs_scaled"][:, 0].int()
+            if not self.requires_gt_mask:
+                object_idxs = torch.nonzero(semantic_preds > 0, as_tuple=False).view(-1)   # ">0" as in the reference (:288)
+                batch_idxs_ = batch_idxs[object_idxs].contiguous()
+                batch_offsets_ = self.get_batch_offsets(batch_idxs_, batch_size)
+                coords_ = data_dict["locs"][object_idxs].contiguous()
+                pt_offsets_ = cluster_offsets[object_idxs]
+                semantic_preds_ = semantic_preds[object_idxs].int().contiguous()
+
+                # shifted coordinates (:296-299)
+                idx_shift, start_len_shift = pointgroup_ops.ballquery_batch_p(
+                    (coords_ + pt_offsets_).detach().contiguous(), batch_idxs_, batch_offsets_, self.cluster_radius,
+                    self.cluster_shift_meanActive)
+                proposals_idx_shift, proposals_offset_shift = pointgroup_ops.bfs_cluster(
+                    semantic_preds_, idx_shift, start_len_shift, self.cluster_npoint_thre)
+                proposals_idx_shift[:, 1] = object_idxs[proposals_idx_shift[:, 1].long()].int()
+                proposals_batchId_shift_all = batch_idxs[proposals_idx_shift[:, 1].long()].int()
+                # original coordinates (:304-307)
+                idx, start_len = pointgroup_ops.ballquery_batch_p(coords_, batch_idxs_, batch_offsets_,
+                                                                  self.cluster_radius, self.cluster_meanActive)
+                proposals_idx, proposals_offset = pointgroup_ops.bfs_cluster(semantic_preds_, idx, start_len,
+                                                                             self.cluster_npoint_thre)
+                proposals_idx[:, 1] = object_idxs[proposals_idx[:, 1].long()].int()
+                proposals_batchId_all = batch_idxs[proposals_idx[:, 1].long()].int()
+                # merge (:312-316), including the reference's one-element-short batch-id concat
+                proposals_idx_shift[:, 0] += (proposals_offset.size(0) - 1)
+                proposals_offset_shift += proposals_offset[-1]
+                proposals_idx = torch.cat((proposals_idx, proposals_idx_shift), dim=0)
+                proposals_offset = torch.cat((proposals_offset, proposals_offset_shift[1:]))
+                proposals_batchId_all = torch.cat((proposals_batchId_all, proposals_batchId_shift_all[1:]))
+            else:
+                proposals_idx = data_dict["gt_proposals_idx"].to(pt_feats.device)
+                proposals_offset = data_dict["gt_proposals_offset"].to(pt_feats.device)
+                proposals_batchId_all = batch_idxs[proposals_idx[:, 1].long()].int()
+
+            num_proposals = proposals_offset.shape[0] - 1
+            data_dict["num_raw_proposals"] = num_proposals
+            if num_proposals == 0:
+                return self._no_proposals(data_dict, pt_feats)
+
+            proposals_voxel_feats, proposals_p2v_map, (proposals_center, proposals_size) = self.clusters_voxelization(
+                proposals_idx, proposals_offset, pt_feats, data_dict["locs"], self.score_fullscale, self.score_scale,
+                self.mode, rand=data_dict.get("cluster_rand"))
+
+            score_feats = self.score_net(proposals_voxel_feats)
+            pt_score_feats = score_feats.features[proposals_p2v_map.long()]
+            proposals_score_feats = pointgroup_ops.roipool(pt_score_feats, proposals_offset)   # (P, m)
+            scores = self.score_linear(proposals_score_feats)
+            data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset)
+
+            proposals_npoint = (proposals_offset[1:] - proposals_offset[:-1]).float()           # == the loop at :342-344
+            sig = torch.sigmoid(scores.view(-1))
+            thres_mask = torch.logical_and(sig > self.cfg.test.TEST_SCORE_THRESH,
+                                           proposals_npoint > self.cfg.test.TEST_NPOINT_THRESH)
+            data_dict["proposals_npoint"] = proposals_npoint
+            data_dict["proposal_thres_mask"] = thres_mask
+
+            # NOTE the reference reads the one-short batch-id vector at the cluster starts (:349); cluster starts of
+            # the shifted set therefore read element start+1 of that set -- same cluster, same batch id.
+            starts = proposals_offset[:-1].long().clamp(max=max(proposals_batchId_all.numel() - 1, 0))
+            proposals_batchId = proposals_batchId_all[starts][thres_mask]
+            data_dict["proposals_batchId"] = proposals_batchId
+            data_dict["proposal_feats"] = proposals_score_feats[thres_mask]
+            data_dict["proposal_objectness_scores"] = sig[thres_mask]
+
+            if self.cfg.model.crop_bbox:
+                crop = scores.new_zeros(num_proposals, 9)
+                crop[:, :3] = proposals_center
+                crop[:, 3:6] = proposals_size
+                crop[:, 7] = semantic_preds[proposals_idx[proposals_offset[:-1].long(), 1].long()].to(crop.dtype)
+                crop[:, 8] = sig
+                data_dict["proposal_crop_bbox"] = crop[thres_mask]
+        return data_dict
+
+    def _no_proposals(self, data_dict, pt_feats):
+        dev = pt_feats.device
+        m = self.cfg.model.m
+        z = lambda *s: torch.zeros(*s, device=dev)
+        data_dict["proposal_scores"] = (z(0, 1), torch.zeros((0, 2), dtype=torch.int32, device=dev),
+                                        torch.zeros(1, dtype=torch.int32, device=dev))
+        data_dict["proposals_npoint"] = z(0)
+        data_dict["proposal_thres_mask"] = torch.zeros(0, dtype=torch.bool, device=dev)
+        data_dict["proposals_batchId"] = torch.zeros(0, dtype=torch.int32, device=dev)
+        data_dict["proposal_feats"] = z(0, m)
+        data_dict["proposal_objectness_scores"] = z(0)
+        data_dict["proposal_crop_bbox"] = z(0, 9)
+        return data_dict
+
+    # ---------------------------------------------------------------------------------------- loss
+    def loss(self, data_dict, epoch):
+        """semantic CE + offset L1 / direction + soft-IoU score BCE (reference :387-463)."""
+        def get_segmented_scores(scores, fg_thresh=1.0, bg_thresh=0.0):
+            fg_mask = scores > fg_thresh
+            bg_mask = scores < bg_thresh
+            interval_mask = (fg_mask == 0) & (bg_mask == 0)
+            segmented = (fg_mask > 0).float()
+            k = 1 / (fg_thresh - bg_thresh)
+            b = bg_thresh / (bg_thresh - fg_thresh)
+            segmented[interval_mask] = scores[interval_mask] * k + b
+            return segmented
+
+        semantic_scores, semantic_labels = data_dict["semantic_scores"]
+        semantic_loss = nn.functional.cross_entropy(semantic_scores, semantic_labels, ignore_index=self.cfg.data.ignore_label)
+        data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
+
+        pt_offsets, coords, instance_info, instance_ids = data_dict["pt_offsets"]
+        gt_offsets = instance_info[:, 0:3] - coords
+        pt_diff = pt_offsets - gt_offsets
+        pt_dist = torch.sum(torch.abs(pt_diff), dim=-1)
+        valid = (instance_ids != self.cfg.data.ignore_label).float()
+        offset_norm_loss = torch.sum(pt_dist * valid) / (torch.sum(valid) + 1e-6)
+        gt_offsets_norm = torch.norm(gt_offsets, p=2, dim=1)
+        gt_offsets_ = gt_offsets / (gt_offsets_norm.unsqueeze(-1) + 1e-8)
+        pt_offsets_norm = torch.norm(pt_offsets, p=2, dim=1)
+        pt_offsets_ = pt_offsets / (pt_offsets_norm.unsqueeze(-1) + 1e-8)
+        direction_diff = - (gt_offsets_ * pt_offsets_).sum(-1)
+        offset_dir_loss = torch.sum(direction_diff * valid) / (torch.sum(valid) + 1e-6)
+        data_dict["offset_norm_loss"] = (offset_norm_loss, valid.sum())
+        data_dict["offset_dir_loss"] = (offset_dir_loss, valid.sum())
+
+        w = self.cfg.train.loss_weight
+        loss = w[0] * semantic_loss + w[1] * offset_norm_loss + w[2] * offset_dir_loss
+        if epoch > self.cfg.cluster.prepare_epochs:
+            scores, proposals_idx, proposals_offset, instance_pointnum = data_dict["proposal_scores"]
+            if scores.shape[0] > 0:
+                ious = pointgroup_ops.get_iou(proposals_idx[:, 1].contiguous(), proposals_offset, instance_ids,
+                                              instance_pointnum)
+                gt_ious, _ = ious.max(1)
+                gt_scores = get_segmented_scores(gt_ious, self.cfg.train.fg_thresh, self.cfg.train.bg_thresh)
+                score_loss = nn.functional.binary_cross_entropy_with_logits(scores.view(-1), gt_scores, reduction="none").mean()
+            else:  # the reference would produce NaN (mean of an empty tensor); keep the step finite
+                gt_ious = scores.new_zeros(0)
+                score_loss = scores.sum() * 0
+            data_dict["score_loss"] = (score_loss, gt_ious.shape[0])
+            loss = loss + w[3] * score_loss
+        data_dict["total_loss"] = (loss, semantic_labels.shape[0])
+        return data_dict
+
+    # ------------------------------------------------------------------------------- entry points
+    def feed(self, data_dict, epoch=0):
+        """(reference :466-479)"""
+        data_dict["epoch"] = epoch
+        if self.cfg.model.use_coords:
+            data_dict["feats"] = torch.cat((data_dict["feats"], data_dict["locs"]), 1)
+        data_dict["voxel_feats"] = pointgroup_ops.voxelization(data_dict["feats"].contiguous(), data_dict["v2p_map"],
+                                                               self.cfg.data.mode)
+        data_dict = self.forward(data_dict)
+        if data_dict["epoch"] > self.prepare_epochs or self.freeze_backbone:
+            data_dict = self.convert_stack_to_batch(data_dict, perms=data_dict.get("slot_perms"))
+        return data_dict
+
+    def parse_feed_ret(self, data_dict, epoch=0):
+        """(reference :481-510)"""
+        semantic_scores = data_dict["semantic_scores"]
+        pt_offsets = data_dict["pt_offsets"]
+        preds = {"semantic": semantic_scores, "pt_offsets": pt_offsets}
+        if self.mode != "test":
+            data_dict["semantic_scores"] = (semantic_scores, data_dict["sem_labels"])
+            data_dict["pt_offsets"] = (pt_offsets, data_dict["locs"], data_dict["instance_info"], data_dict["instance_ids"])
+        if epoch > self.cfg.cluster.prepare_epochs:
+            scores, proposals_idx, proposals_offset = data_dict["proposal_scores"]
+            preds["score"] = scores
+            preds["proposals"] = (proposals_idx, proposals_offset)
+            preds["proposal_crop_bboxes"] = data_dict["proposal_crop_bbox"]
+            if self.mode != "test":
+                data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset, data_dict["instance_num_point"])
+                if self.cfg.model.crop_bbox:
+                    data_dict["proposal_crop_bboxes"] = data_dict["proposal_crop_bbox"]
+        return preds, data_dict
+
+    def training_step(self, data_dict, idx=0):
+        """(reference :513-528) minus the Lightning logging."""
+        data_dict = self.feed(data_dict, self.current_epoch)
+        _, data_dict = self.parse_feed_ret(data_dict, self.current_epoch)
+        data_dict = self.loss(data_dict, self.current_epoch)
+        return data_dict["total_loss"][0], data_dict

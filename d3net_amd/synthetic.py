@@ -132,3 +132,15 @@ def to_device(batch, device):
     for k, v in batch.items():
         out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device) if isinstance(v, np.ndarray) else v
     return out
+
+
+def make_batch(scenes, device, mode=4):
+    """collate + device voxelisation: the tensors `PointGroup.feed` consumes (sparse_collate_fn's contract,
+    reference lib/dataset/pipeline.py:917-994; the reference computes voxel_locs / p2v_map / v2p_map with the CPU
+    voxelization_idx inside the loader, :992 -- here the same operator runs on the device)."""
+    import torch
+    from . import pointgroup_ops
+    batch = to_device(collate(scenes), device)
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(batch["locs_scaled"].contiguous(), len(scenes), mode)
+    batch["voxel_locs"], batch["p2v_map"], batch["v2p_map"] = voxel_locs, p2v_map, v2p_map
+    return batch

@@ -126,16 +126,21 @@ int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_byte
  * flags: D3_CONV_FLIPK  -> Wk = W[K-1-k]      (data gradient of a kernel-3 conv)
  *        D3_CONV_TRANSW -> W is laid out (K, Cout, Cin) and used transposed (data gradients)
  *        D3_CONV_EXACT  -> fp32 FMA kernel instead of the bf16-MFMA kernel (fp32 accumulate in both)
- * x (Min,Cin) f32, W (K,Cin,Cout) f32 [or (K,Cout,Cin) with TRANSW], out (Mout,Cout) f32.
- * MFMA path needs Cout % 16 == 0 and Cin % 2 == 0, else D3_ERR_ARG. */
+ * x (Min,Cin) f32 (Min = rows of x, used for bounds / traffic accounting), W (K,Cin,Cout) f32 [or (K,Cout,Cin) with TRANSW], out (Mout,Cout) f32.
+ * MFMA path needs Cin % 2 == 0 and Cout <= 224, else D3_ERR_ARG. */
 #define D3_CONV_FLIPK 1
 #define D3_CONV_TRANSW 2
 #define D3_CONV_EXACT 4
-int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
+int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
                   int Cout, int flags, void *stream);
 /* Weight gradient  dW[k] += sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32, accumulated into). */
-int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Mout, int K, int Cin,
+int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Min, int Mout, int K, int Cin,
                     int Cout, int flags, void *stream);
+
+/* Launch timing for bench.py: with profiling on, each MFMA convolution launch is bracketed by HIP events on
+ * its stream.  family 0 = forward/data-gradient kernel, 1 = weight-gradient kernel.  collect() synchronises. */
+int d3_prof_enable(int on);
+int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes, double *total_flops);
 
 /* MinkowskiBatchNorm (+ MinkowskiReLU) over the rows of an (M,C) feature matrix
  * (reference: model/pointgroup.py:65,72-73; model/common.py:36-40).  Training-mode batch statistics.

@@ -71,6 +71,41 @@ def kmap_down(coords, ts=1):
     return out_coords, parent.astype(np.int64), kidx.astype(np.int64)
 
 
+# ------------------------------------------------------------------------------- arithmetic modes
+# "fp32": plain fp32 matmuls (the reference's precision).
+# "bf16": the arithmetic of the product's MFMA kernels, restated exactly: both matmul operands rounded to
+#         bf16 (round-to-nearest-even), products exact, fp32 accumulation -- in the forward (x, W), the data
+#         gradient (dy, W) and the weight gradient (x, dy).  Only the summation order differs from the kernels.
+_PRECISION = "fp32"
+
+
+def set_precision(p):
+    global _PRECISION
+    assert p in ("fp32", "bf16")
+    _PRECISION = p
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+class _MM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return _rb(x) @ _rb(W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dyr = _rb(dy)
+        return dyr @ _rb(W).t(), _rb(x).t() @ dyr
+
+
+def mm(x, W):
+    return _MM.apply(x, W) if _PRECISION == "bf16" else x @ W
+
+
 def conv_k3(x, W, tbl):
     """x (M,Cin), W (27,Cin,Cout), tbl (M,27) -> (M,Cout)"""
     out = x.new_zeros((x.shape[0], W.shape[2]))
@@ -79,7 +114,7 @@ def conv_k3(x, W, tbl):
         col = tbl_t[:, k]
         o = torch.nonzero(col >= 0).squeeze(1)
         if o.numel():
-            out = out.index_add(0, o, x[col[o]] @ W[k])
+            out = out.index_add(0, o, mm(x[col[o]], W[k]))
     return out
 
 
@@ -90,7 +125,7 @@ def conv_down(x, W, parent, kidx, Mout):
     for k in range(8):
         i = torch.nonzero(kidx_t == k).squeeze(1)
         if i.numel():
-            out = out.index_add(0, parent_t[i], x[i] @ W[k])
+            out = out.index_add(0, parent_t[i], mm(x[i], W[k]))
     return out
 
 
@@ -101,7 +136,7 @@ def conv_up(x, W, parent, kidx):
     for k in range(8):
         i = torch.nonzero(kidx_t == k).squeeze(1)
         if i.numel():
-            out = out.index_copy(0, i, x[parent_t[i]] @ W[k])
+            out = out.index_copy(0, i, mm(x[parent_t[i]], W[k]))
     return out
 
 
@@ -157,7 +192,7 @@ class OracleUNet(torch.nn.Module):
         h = self._bn(h, name + ".conv_branch.3")
         h = conv_k3(h, self.p[name + ".conv_branch.5.kernel"], cm.get_k3(ts))
         if cin != cout:
-            identity = identity @ self.p[name + ".downsample.0.kernel"]  # (Cin,Cout): ME stores a 1x1 kernel 2-D
+            identity = mm(identity, self.p[name + ".downsample.0.kernel"])  # (Cin,Cout): ME stores a 1x1 kernel 2-D
         return h + identity
 
     def ublock(self, x, cm, ts, planes, name):

@@ -1,8 +1,10 @@
 """GPU parity: sparse convolution / batch-norm kernels and the whole U-Net vs the fp32 CPU oracle.
 
-Kernel maps are integer work: bit-exact.  Convolutions: the exact-fp32 kernels within 1e-4 (relative to the
-output scale), the bf16-MFMA kernels (bf16 operands, fp32 accumulate) within 2e-2 -- bf16 has 8 mantissa
-bits, so a K-term dot product of unit-scale operands carries ~2^-9*sqrt(K) relative error.
+Kernel maps are integer work: bit-exact.  Convolutions: the exact-fp32 kernels within 1e-4 of the fp32 oracle
+(relative to the output scale); the bf16-MFMA kernels (bf16 operands, fp32 accumulate) within 2e-2 of the fp32
+oracle -- bf16 has 8 mantissa bits, so a K-term dot product of unit-scale operands carries ~2^-9*sqrt(K)
+relative error -- and within 1e-3 of the oracle's "bf16" mode, which restates the kernels' arithmetic exactly
+(operands rounded to bf16, exact products, fp32 accumulation; only the summation order differs).
 """
 import functools
 
@@ -27,6 +29,11 @@ def rand_coords(rng, dims, occ, batch=2):
 def relerr(a, b):
     a = a.detach().cpu().double(); b = b.detach().cpu().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def l2err(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
 
 
 def test_kernel_maps_bit_exact(dev):
@@ -98,8 +105,24 @@ def test_conv_fwd_bwd_vs_oracle(dev, kind, cin, cout, exact):
         assert relerr(out.F, ref) < tol
         assert relerr(xd.grad, xo.grad) < tol
         assert relerr(layer.kernel.grad, W.grad) < tol
+        if not exact:  # against the exact restatement of the kernel arithmetic
+            so.set_precision("bf16")
+            xb = x.clone().requires_grad_(True); Wb = W.detach().clone().requires_grad_(True)
+            if kind == "k3":
+                refb = so.conv_k3(xb, Wb, ocm.get_k3(1))
+            elif kind == "down":
+                refb = so.conv_down(xb, Wb, parent, kidx, Mo)
+            elif kind == "up":
+                refb = so.conv_up(xb, Wb, parent, kidx)
+            else:
+                refb = so.mm(xb, Wb)
+            refb.backward(g)
+            assert relerr(out.F, refb) < 1e-4
+            assert relerr(xd.grad, xb.grad) < 1e-4
+            assert relerr(layer.kernel.grad, Wb.grad) < 1e-4
     finally:
         ME.set_exact(False)
+        so.set_precision("fp32")
 
 
 @pytest.mark.parametrize("C,relu", [(16, True), (48, False), (112, True)])
@@ -151,6 +174,7 @@ def _shared_unet(dev, planes, cin):
 def test_unet_forward_backward_vs_oracle(dev, exact):
     from d3net_amd import minkowski as ME
     ME.set_exact(exact)
+    so.set_precision("fp32" if exact else "bf16")
     try:
         rng = np.random.default_rng(7)
         planes, cin = [16, 32, 48, 64], 134
@@ -169,13 +193,49 @@ def test_unet_forward_backward_vs_oracle(dev, exact):
         xd = x.to(dev).requires_grad_(True)
         out = net(ME.SparseTensor(xd, coordinates=torch.from_numpy(coords).int().to(dev)))
         out.F.backward(g.to(dev))
-        tol = 2e-3 if exact else 6e-2
-        assert relerr(out.F, ref) < tol
-        assert relerr(xd.grad, xo.grad) < tol
-        worst = max(relerr(p.grad, params[n].grad) for n, p in net.named_parameters())
-        assert worst < (5e-3 if exact else 1e-1), worst
+        # Exact mode: relative L2 error.  The ReLU mask of a pre-activation within rounding of 0 may flip, which
+        # moves single gradient entries by O(1) (each worth ~1/sqrt(numel) = 0.3 % here), so a max-norm bound is
+        # meaningless for the deep net and a handful of flips is expected even between two fp32 summation orders.
+        # bf16 mode: rounding operands to bf16 is itself discontinuous, so two implementations that differ only in
+        # fp32 summation order decorrelate down to the bf16 noise floor after a few layers (forward ~1e-2), ~0.5 %
+        # of the ReLU masks then differ and the end-to-end gradient is only statistically comparable: the bound is
+        # a cosine similarity.  The kernels themselves are pinned per layer to 1e-4 against the exact restatement
+        # of their arithmetic (test_conv_fwd_bwd_vs_oracle) and the plumbing is shared with the exact mode.
+        def cos(a, b):
+            a = a.detach().cpu().double().flatten(); b = b.detach().cpu().double().flatten()
+            return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        if exact:
+            assert l2err(out.F, ref) < 1e-3, l2err(out.F, ref)
+            assert l2err(xd.grad, xo.grad) < 2e-2, l2err(xd.grad, xo.grad)
+            errs = {n: l2err(p.grad, params[n].grad) for n, p in net.named_parameters()}
+            worst = max(errs, key=errs.get)
+            assert errs[worst] < 5e-2, (worst, errs[worst])
+        else:
+            assert l2err(out.F, ref) < 3e-2, l2err(out.F, ref)
+            assert cos(xd.grad, xo.grad) > 0.9, cos(xd.grad, xo.grad)
+            cs = {n: cos(p.grad, params[n].grad) for n, p in net.named_parameters()}
+            worst = min(cs, key=cs.get)
+            assert cs[worst] > 0.8, (worst, cs[worst])
     finally:
         ME.set_exact(False)
+        so.set_precision("fp32")
+
+
+def test_unet_bf16_forward_close_to_fp32_oracle(dev):
+    """stated tolerance of the bf16-MFMA backbone against the fp32 reference arithmetic: 5e-2 relative L2"""
+    from d3net_amd import minkowski as ME
+    rng = np.random.default_rng(8)
+    planes, cin = [16, 32, 48], 134
+    coords = rand_coords(rng, (40, 32, 20), 0.12)
+    x = torch.from_numpy(rng.standard_normal((len(coords), cin)).astype(np.float32))
+    net, params = _shared_unet(dev, planes, cin)
+    ocm = so.OracleCoords(coords)
+    with torch.no_grad():
+        h = so.conv_k3(x, params["0.kernel"], ocm.get_k3(1))
+        h = so.OracleUNet(params, planes).forward(h, ocm)
+        ref = so.bn_relu(h, params["2.bn.weight"], params["2.bn.bias"], 1e-4, True)
+        out = net(ME.SparseTensor(x.to(dev), coordinates=torch.from_numpy(coords).int().to(dev)))
+    assert l2err(out.F, ref) < 5e-2, l2err(out.F, ref)
 
 
 def test_canonical_scene_maps(dev):
