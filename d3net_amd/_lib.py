@@ -62,6 +62,9 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise D3Error("libd3hip.so not built (%s); run `python -m d3net_amd.build` -- "
                           "d3net_amd has no CPU/eager fallback" % SO_PATH)
+        # torch first: libd3hip.so and torch must share ONE HIP runtime (torch bundles libamdhip64.so.7; loading
+        # /opt/rocm's copy first gives the process two runtimes and HIP reports "no device" to one of them)
+        import torch  # noqa: F401
         l = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the symbol is missing

@@ -196,6 +196,7 @@ static int bq_boxes(const float *xyz, int n, BqWs &w, hipStream_t s) {
 extern "C" int d3_ballquery_count(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n,
                                   float radius, int *start_len, void *ws, size_t ws_bytes, int *nActive_host,
                                   void *stream) {
+    D3_CLEAR();
     *nActive_host = 0;
     if (n <= 0) return 0;
     BqWs w;
@@ -217,6 +218,7 @@ extern "C" int d3_ballquery_count(const float *xyz, const int *batch_idxs, const
 extern "C" int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n,
                                  float radius, const int *start_len, const void *ws, size_t ws_bytes, int *idx,
                                  long long idx_capacity, void *stream) {
+    D3_CLEAR();
     (void)start_len;
     if (n <= 0) return 0;
     BqWs w;

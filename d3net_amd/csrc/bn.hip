@@ -131,6 +131,7 @@ static int bn_grid(int M, int C) {
 
 extern "C" int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, void *ws, size_t ws_bytes,
                            void *stream) {
+    D3_CLEAR();
     if (M <= 0) return 0;
     if (C < 1 || C > BN_T) return D3_ERR_ARG;
     if (ws == nullptr || ws_bytes < 2 * (size_t)C * sizeof(double)) return D3_ERR_WORKSPACE;
@@ -143,6 +144,7 @@ extern "C" int d3_bn_stats(const float *x, int M, int C, float *mean, float *var
 }
 extern "C" int d3_bn_relu_fwd(const float *x, const float *mean, const float *var, const float *gamma,
                               const float *beta, float *y, int M, int C, float eps, int relu, void *stream) {
+    D3_CLEAR();
     if (M <= 0) return 0;
     hipStream_t s = d3_stream(stream);
     long long total = (long long)M * C;
@@ -159,6 +161,7 @@ extern "C" int d3_bn_relu_fwd(const float *x, const float *mean, const float *va
 extern "C" int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const float *var,
                               const float *gamma, const float *beta, float *dx, float *dgamma, float *dbeta, int M,
                               int C, float eps, int relu, void *ws, size_t ws_bytes, void *stream) {
+    D3_CLEAR();
     if (M <= 0) return 0;
     if (C < 1 || C > BN_T) return D3_ERR_ARG;
     if (ws == nullptr || ws_bytes < 2 * (size_t)C * sizeof(double)) return D3_ERR_WORKSPACE;

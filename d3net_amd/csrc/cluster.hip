@@ -177,6 +177,7 @@ __global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz
 extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
                                     int n, int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host,
                                     int *nCluster_host, void *stream) {
+    D3_CLEAR();
     *sumNPoint_host = 0; *nCluster_host = 0;
     if (n <= 0) return 0;
     ClWs w;
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__res
 extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
                                    int n, void *ws, size_t ws_bytes, int *cluster_idxs, int *cluster_offsets,
                                    int sumNPoint, int nCluster, void *stream) {
+    D3_CLEAR();
     if (n <= 0) return 0;
     ClWs w;
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;

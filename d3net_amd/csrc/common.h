@@ -19,6 +19,9 @@
         if (_e != hipSuccess) return (int)_e;            \
     } while (0)
 
+// drop a stale (sticky) error left by an earlier, unrelated HIP call so that launch checks report our own
+#define D3_CLEAR() (void)hipGetLastError()
+
 static inline hipStream_t d3_stream(void *s) { return (hipStream_t)s; }
 
 static inline size_t d3_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

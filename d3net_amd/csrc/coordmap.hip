@@ -117,6 +117,7 @@ static int cm_build_hash(const int *coords, int M, int q, CmWs &w, hipStream_t s
 }
 
 extern "C" int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *stream) {
+    D3_CLEAR();
     if (M <= 0) return 0;
     if (ts <= 0) return D3_ERR_ARG;
     CmWs w;
@@ -155,6 +156,7 @@ __global__ void cm_parent_kernel(const int *__restrict__ coords, int M, int ts, 
 
 extern "C" int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *parent,
                                   int *kidx, int *Mout_host, void *stream) {
+    D3_CLEAR();
     *Mout_host = 0;
     if (M <= 0) return 0;
     if (ts <= 0) return D3_ERR_ARG;
@@ -202,6 +204,7 @@ __global__ void cm_down_fill_kernel(const int *__restrict__ coords, int M, int t
 
 extern "C" int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,
                                  const int *kidx, int *out_coords, int *child, int *up, int Mout, void *stream) {
+    D3_CLEAR();
     if (M <= 0 || Mout <= 0) return 0;
     CmWs w;
     if (ws == nullptr || cm_layout(ws, ws_bytes, M, w) > ws_bytes) return D3_ERR_WORKSPACE;

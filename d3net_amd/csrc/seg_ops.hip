@@ -162,6 +162,7 @@ __global__ __launch_bounds__(SEG_THREADS) void get_iou_kernel(const int *__restr
 static inline int seg_grid(int nProposal) { return nProposal < 65535 ? nProposal : 65535; }
 
 extern "C" int d3_sec_mean(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream) {
+    D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
     sec_mean_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
@@ -169,6 +170,7 @@ extern "C" int d3_sec_mean(const float *inp, const int *offsets, float *out, int
     return 0;
 }
 extern "C" int d3_sec_min(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream) {
+    D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
     sec_minmax_kernel<false><<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
@@ -176,6 +178,7 @@ extern "C" int d3_sec_min(const float *inp, const int *offsets, float *out, int 
     return 0;
 }
 extern "C" int d3_sec_max(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream) {
+    D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
     sec_minmax_kernel<true><<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
@@ -184,6 +187,7 @@ extern "C" int d3_sec_max(const float *inp, const int *offsets, float *out, int 
 }
 extern "C" int d3_roipool_fp(const float *feats, const int *proposals_offset, float *output_feats,
                              int *output_maxidx, int nProposal, int C, void *stream) {
+    D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
     roipool_fp_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(feats, proposals_offset, output_feats,
@@ -193,6 +197,7 @@ extern "C" int d3_roipool_fp(const float *feats, const int *proposals_offset, fl
 }
 extern "C" int d3_roipool_bp(float *d_feats, const int *proposals_offset, const int *output_maxidx,
                              const float *d_output_feats, int nProposal, int C, void *stream) {
+    D3_CLEAR();
     (void)proposals_offset;
     long long total = (long long)nProposal * C;
     if (total <= 0) return 0;
@@ -204,6 +209,7 @@ extern "C" int d3_roipool_bp(float *d_feats, const int *proposals_offset, const 
 extern "C" int d3_get_iou(const int *proposals_idx, const int *proposals_offset, const int64_t *instance_labels,
                           const int *instance_pointnum, float *proposals_iou, int nInstance, int nProposal,
                           void *stream) {
+    D3_CLEAR();
     if (nProposal <= 0 || nInstance <= 0) return 0;
     get_iou_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(
         proposals_idx, proposals_offset, instance_labels, instance_pointnum, proposals_iou, nInstance, nProposal);

@@ -41,6 +41,7 @@ static int g_prof_on = 0;
 #define PROF_MAX 200000
 
 extern "C" int d3_prof_enable(int on) {
+    D3_CLEAR();
     g_prof_on = on;
     g_prof_used = 0;
     return 0;
@@ -61,6 +62,7 @@ static void prof_end(ProfRec *r, hipStream_t s) { if (r) hipEventRecord(r->b, s)
 // family: 0 = spconv_fwd_mfma (forward + data gradient), 1 = spconv_wgrad_mfma
 extern "C" int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes,
                                double *total_flops) {
+    D3_CLEAR();
     *launches = 0; *total_ms = 0; *total_bytes = 0; *total_flops = 0;
     for (size_t i = 0; i < g_prof_used; i++) {
         ProfRec &r = g_prof[i];
@@ -225,6 +227,7 @@ static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float
 
 extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K,
                              int Cin, int Cout, int flags, void *stream) {
+    D3_CLEAR();
     if (Mout <= 0) return 0;
     if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__r
 
 extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Min, int Mout, int K,
                                int Cin, int Cout, int flags, void *stream) {
+    D3_CLEAR();
     if (Mout <= 0) return 0;
     if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;

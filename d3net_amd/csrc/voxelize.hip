@@ -64,20 +64,24 @@ static int launch_bp(const float *d_out, float *d_feats, const int *rules, int n
 
 extern "C" int d3_voxelize_fp(const float *feats, float *output_feats, const int *output_map, int mode, int nActive,
                               int maxActive, int nPlane, void *stream) {
+    D3_CLEAR();
     return launch_fp(feats, output_feats, output_map, nActive, maxActive, nPlane, mode == 4, stream);
 }
 extern "C" int d3_voxelize_bp(const float *d_output_feats, float *d_feats, const int *output_map, int mode,
                               int nActive, int maxActive, int nPlane, void *stream) {
+    D3_CLEAR();
     return launch_bp(d_output_feats, d_feats, output_map, nActive, maxActive, nPlane, mode == 4, stream);
 }
 // point_recover_fp == voxelize_bp(average=false); point_recover_bp == voxelize_fp(average=false)
 // (reference: voxelize.cpp:181-202)
 extern "C" int d3_point_recover_fp(const float *feats, float *output_feats, const int *idx_map, int nActive,
                                    int maxActive, int nPlane, void *stream) {
+    D3_CLEAR();
     return launch_bp(feats, output_feats, idx_map, nActive, maxActive, nPlane, false, stream);
 }
 extern "C" int d3_point_recover_bp(const float *d_output_feats, float *d_feats, const int *idx_map, int nActive,
                                    int maxActive, int nPlane, void *stream) {
+    D3_CLEAR();
     return launch_fp(d_output_feats, d_feats, idx_map, nActive, maxActive, nPlane, false, stream);
 }
 
@@ -213,6 +217,7 @@ __global__ void vi_total_kernel(const int *flag, const int *scan, int n, int *sc
 
 extern "C" int d3_voxelize_idx_count(const int64_t *coords, int n, int ncols, int mode, int *input_map, void *ws,
                                      size_t ws_bytes, int *M_host, int *maxActive_host, void *stream) {
+    D3_CLEAR();
     if (ncols != 3 && ncols != 4) return D3_ERR_ARG;
     if (mode < 0 || mode > 4) return D3_ERR_ARG;
     *M_host = 0; *maxActive_host = 1;
@@ -277,6 +282,7 @@ __global__ void vi_iota_kernel(int *a, int n) {
 extern "C" int d3_voxelize_idx_fill(const int64_t *coords, int n, int ncols, int mode, const int *input_map,
                                     void *ws, size_t ws_bytes, int64_t *output_coords, int *output_map, int M,
                                     int maxActive, void *stream) {
+    D3_CLEAR();
     if (n <= 0 || M <= 0) return 0;
     VoxIdxWs w;
     if (!vi_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
