@@ -87,12 +87,11 @@ def main():
     model = PointGroup(cfg).to(dev).train()
     model.teacher = not args.no_teacher
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)
+    opt = torch.optim.AdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay, fused=True)
+    from d3net_amd.distributed import FlatGradAllReduce, broadcast_module
     if world > 1:  # identical replicas
-        for p in model.parameters():
-            dist.broadcast(p.data, 0)
-        for b in model.buffers():
-            dist.broadcast(b.data, 0)
+        broadcast_module(model)
+    grad_sync = FlatGradAllReduce(params, dev) if world > 1 else None
 
     if args.small:
         occ, sem, inst, _ = S.occupancy_grid((100, 75, 50), 4, (8, 30), (8, 25), 0)
@@ -102,24 +101,14 @@ def main():
         scene = S.scene_from_grid(occ, sem, inst, feat_seed=2 + rank)   # same geometry, per-rank features
     batch = S.make_batch([scene], dev)
     n_points, n_voxels = int(batch["locs"].shape[0]), int(batch["voxel_locs"].shape[0])
-    flat = torch.zeros(sum(p.numel() for p in params), device=dev) if world > 1 else None
 
     def step():
         d = dict(batch)
         opt.zero_grad(set_to_none=True)
         loss, d = model.training_step(d)
         loss.backward()
-        if world > 1:   # one fused gradient all-reduce over RCCL (sum -> mean), gradients only
-            off = 0
-            for p in params:
-                n = p.numel()
-                flat[off:off + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).view(-1)); off += n
-            dist.all_reduce(flat)
-            flat.div_(world)
-            off = 0
-            for p in params:
-                n = p.numel()
-                p.grad = flat[off:off + n].view_as(p).clone(); off += n
+        if grad_sync is not None:   # one fused gradient all-reduce over RCCL (sum -> mean), gradients only
+            grad_sync()
         opt.step()
         return loss, d
 

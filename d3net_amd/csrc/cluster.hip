@@ -155,10 +155,14 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
 
 __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *sizes, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) return;   // tail lanes simply drop out of the ballots below
     int o = cl_chase(lab, lab[root[i]]);
     own[i] = o;
-    atomicAdd(&sizes[o], 1);
+    // neighbouring points mostly share an owner: one atomic per wave when they all agree
+    const int o0 = __shfl(o, 0);
+    const unsigned long long act = __ballot(1);
+    if (__ballot(o == o0) == act) { if ((threadIdx.x & 63) == 0) atomicAdd(&sizes[o0], (int)__popcll(act)); }
+    else atomicAdd(&sizes[o], 1);
 }
 __global__ void cl_keep_kernel(const int *sizes, int *flag, int *ksz, int n, int threshold) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,33 +225,32 @@ __global__ void cl_seed_kernel(const int *flag, const int *cid, const int *koff,
     cluster_offsets[cid[i]] = koff[i];
 }
 
-// block-wide exclusive scan of a global int array segment (in place); returns the total.
-__device__ int cl_block_scan(int *a, int len, int *lds /* >= 32 ints */) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
-    int carry = 0;
-    for (int base = 0; base < len; base += blockDim.x) {
-        const int i = base + t;
-        int v = (i < len) ? ld_dev(&a[i]) : 0;
-        int x = v;  // inclusive wave scan
-        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
-        if (lane == 63) lds[wv] = x;
-        __syncthreads();
-        if (wv == 0) {
-            int wsum = (lane < nw) ? lds[lane] : 0;
-            int ws = wsum;
-            for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(ws, o); if (lane >= o) ws += y; }
-            if (lane < nw) lds[lane] = ws - wsum;  // exclusive wave offsets
-            if (lane == 63) lds[nw] = ws;          // chunk total
-        }
-        __syncthreads();
-        if (i < len) st_dev(&a[i], carry + lds[wv] + x - v);
-        carry += lds[nw];
-        __syncthreads();
+// block-wide exclusive scan of one int per thread; `total` = sum over the block.  wsum: >= 18 ints of LDS.
+__device__ __forceinline__ int cl_blk_scan(int v, int *wsum, int &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    if (wv == 0) {
+        int w = (lane < nw) ? wsum[lane] : 0, ws = w;
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(ws, o); if (lane >= o) ws += y; }
+        if (lane < nw) wsum[lane] = ws - w;
+        if (lane == 63) wsum[nw] = ws;
     }
-    return carry;
+    __syncthreads();
+    const int r = wsum[wv] + x - v;
+    total = wsum[nw];
+    __syncthreads();
+    return r;
 }
 
-// phase 3: one workgroup per kept cluster
+// phase 3: one workgroup per kept cluster replays the FIFO BFS level by level, EDGE-parallel:
+// the frontier's list lengths are prefix-summed in LDS, every thread takes flat edge ids (binary search for
+// the owning frontier entry), so a level of F nodes / E edges costs ~E/1024 iterations whatever the list
+// lengths are.  Flat edge order == (parent queue position, list position) == the FIFO discovery order, so
+// pass C is a plain ordered compaction of the "first discoverer" edges.
+#define CL_FCH 1024
 __global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__restrict__ sem,
                                                                const int *__restrict__ idx,
                                                                const int *__restrict__ start_len,
@@ -256,65 +259,75 @@ __global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__res
                                                                const int *__restrict__ koff,
                                                                const int *__restrict__ sizes, int *par, int *queue,
                                                                int *fcnt, int *cluster_idxs) {
-    __shared__ int lds[40];
+    __shared__ int s_st[CL_FCH], s_sem[CL_FCH], s_off[CL_FCH + 1], s_w[24];
+    (void)fcnt;
     const int c = blockIdx.x;
     const int s = seeds[c];
     const int base = koff[s];
     const int size = sizes[s];
     int *q = queue + base;
-    int *fc = fcnt + base;
-    const int lane = d3_lane(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const unsigned long long lt = d3_lanemask_lt();
-    if (threadIdx.x == 0) { st_dev(&q[0], s); st_dev(&par[s], -1); }
+    const int tid = threadIdx.x;
+    if (tid == 0) { st_dev(&q[0], s); st_dev(&par[s], -1); }
     __syncthreads();
     int lo = 0, hi = 1;
     while (lo < hi && hi <= size) {
-        // pass A: first discoverer = smallest parent queue position
-        for (int f = lo + wv; f < hi; f += nw) {
-            const int u = ld_dev(&q[f]);
-            const int st = start_len[u * 2], ln = start_len[u * 2 + 1];
-            const int su = sem[u];
-            for (int e = lane; e < ln; e += 64) {
-                const int j = idx[st + e];
-                if (sem[j] == su && own[j] == s) { if (ld_dev(&par[j]) > f) atomicMin(&par[j], f); }
+        const bool single = (hi - lo) <= CL_FCH;
+        int E = 0;
+        // ---- pass A: first discoverer of every neighbour = smallest parent queue position
+        for (int fb = lo; fb < hi; fb += CL_FCH) {
+            const int nf = min(CL_FCH, hi - fb);
+            int ln = 0;
+            if (tid < nf) {
+                const int u = ld_dev(&q[fb + tid]);
+                s_st[tid] = start_len[u * 2]; ln = start_len[u * 2 + 1]; s_sem[tid] = sem[u];
             }
-        }
-        __syncthreads();
-        // pass B: children per frontier entry
-        for (int f = lo + wv; f < hi; f += nw) {
-            const int u = ld_dev(&q[f]);
-            const int st = start_len[u * 2], ln = start_len[u * 2 + 1];
-            const int su = sem[u];
-            int cnt = 0;
-            for (int e0 = 0; e0 < ln; e0 += 64) {
-                const int e = e0 + lane;
-                bool child = false;
-                if (e < ln) { const int j = idx[st + e]; child = (sem[j] == su) && (own[j] == s) && (ld_dev(&par[j]) == f); }
-                cnt += (int)__popcll(__ballot(child));
+            const int off = cl_blk_scan(ln, s_w, E);
+            if (tid < nf) s_off[tid] = off;
+            if (tid == 0) s_off[nf] = E;
+            __syncthreads();
+            for (int e = tid; e < E; e += CL_BFS_THREADS) {
+                int a = 0, b = nf;  // largest f with s_off[f] <= e
+                while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
+                const int j = idx[s_st[a] + e - s_off[a]];
+                if (sem[j] == s_sem[a] && own[j] == s) { const int gp = fb + a; if (ld_dev(&par[j]) > gp) atomicMin(&par[j], gp); }
             }
-            if (lane == 0) st_dev(&fc[f], cnt);
+            __syncthreads();
         }
-        __syncthreads();
-        const int total = cl_block_scan(fc + lo, hi - lo, lds);
-        // pass C: children in (parent position, list order)
-        for (int f = lo + wv; f < hi; f += nw) {
-            const int u = ld_dev(&q[f]);
-            const int st = start_len[u * 2], ln = start_len[u * 2 + 1];
-            const int su = sem[u];
-            int pos = hi + ld_dev(&fc[f]);
-            for (int e0 = 0; e0 < ln; e0 += 64) {
-                const int e = e0 + lane;
-                bool child = false; int j = 0;
-                if (e < ln) { j = idx[st + e]; child = (sem[j] == su) && (own[j] == s) && (ld_dev(&par[j]) == f); }
-                const unsigned long long m = __ballot(child);
-                if (child) { const int p = pos + (int)__popcll(m & lt); if (p < size) st_dev(&q[p], j); }
-                pos += (int)__popcll(m);
+        // ---- pass C: children in flat edge order
+        int tail = hi;
+        for (int fb = lo; fb < hi; fb += CL_FCH) {
+            const int nf = min(CL_FCH, hi - fb);
+            if (!single) {  // several frontier chunks: rebuild this chunk's LDS tables
+                int ln = 0;
+                if (tid < nf) {
+                    const int u = ld_dev(&q[fb + tid]);
+                    s_st[tid] = start_len[u * 2]; ln = start_len[u * 2 + 1]; s_sem[tid] = sem[u];
+                }
+                const int off = cl_blk_scan(ln, s_w, E);
+                if (tid < nf) s_off[tid] = off;
+                if (tid == 0) s_off[nf] = E;
+                __syncthreads();
             }
+            for (int e0 = 0; e0 < E; e0 += CL_BFS_THREADS) {
+                const int e = e0 + tid;
+                int child = 0, j = 0;
+                if (e < E) {
+                    int a = 0, b = nf;
+                    while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
+                    j = idx[s_st[a] + e - s_off[a]];
+                    child = (sem[j] == s_sem[a] && own[j] == s && ld_dev(&par[j]) == fb + a) ? 1 : 0;
+                }
+                if (!__syncthreads_or(child)) continue;
+                int tot;
+                const int pos = cl_blk_scan(child, s_w, tot);
+                if (child && tail + pos < size) st_dev(&q[tail + pos], j);
+                tail += tot;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        lo = hi; hi += total;
+        lo = hi; hi = tail;
     }
-    for (int p = threadIdx.x; p < size; p += blockDim.x) {
+    for (int p = tid; p < size; p += blockDim.x) {
         cluster_idxs[(size_t)(base + p) * 2 + 0] = c;
         cluster_idxs[(size_t)(base + p) * 2 + 1] = ld_dev(&q[p]);
     }

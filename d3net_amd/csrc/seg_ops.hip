@@ -66,8 +66,16 @@ __global__ __launch_bounds__(SEG_THREADS) void sec_mean_kernel(const float *__re
             const long long base = (long long)r0 * C;
             for (int f = t; f < nflt; f += SEG_THREADS) stage[f] = __fdiv_rn(inp[base + f], count);  // IEEE divide
             __syncthreads();
-            if (t < C) {
-                for (int r = 0; r < rows; r++) mean = __fadd_rn(mean, stage[r * C + t]);
+            if (t < C) {  // serial add chain; the LDS reads are issued 8 at a time ahead of it
+                int r = 0;
+                for (; r + 8 <= rows; r += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = stage[(r + j) * C + t];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, v[j]);
+                }
+                for (; r < rows; r++) mean = __fadd_rn(mean, stage[r * C + t]);
             }
             __syncthreads();
         }

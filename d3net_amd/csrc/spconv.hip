@@ -97,17 +97,20 @@ __global__ void spconv_fwd_exact_kernel(const float *__restrict__ x, const int *
 }
 // one thread per weight element, serial over rows (validation only)
 __global__ void spconv_wgrad_exact_kernel(const float *__restrict__ x, const int *__restrict__ tbl,
-                                          const float *__restrict__ dy, float *__restrict__ dW, int Mout, int K,
-                                          int Cin, int Cout) {
+                                          const float *__restrict__ dy, float *__restrict__ dW, int rows, int K,
+                                          int Cin, int Cout, int xstat, int flipk) {
     long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)K * Cin * Cout) return;
     const int k = (int)(e / ((long long)Cin * Cout)), ci = (int)((e / Cout) % Cin), co = (int)(e % Cout);
     float acc = 0.f;
-    for (int u = 0; u < Mout; u++) {
-        const int idx = tbl ? tbl[(long long)u * K + k] : u;
-        if (idx >= 0) acc = fmaf(x[(long long)idx * Cin + ci], dy[(long long)u * Cout + co], acc);
+    for (int r = 0; r < rows; r++) {
+        const int idx = tbl ? tbl[(long long)r * K + k] : r;
+        if (idx < 0) continue;
+        const int xr = xstat ? r : idx, dr = xstat ? idx : r;
+        acc = fmaf(x[(long long)xr * Cin + ci], dy[(long long)dr * Cout + co], acc);
     }
-    dW[e] += acc;
+    const int wk = flipk ? (K - 1 - k) : k;
+    dW[(long long)wk * Cin * Cout + (long long)ci * Cout + co] += acc;
 }
 
 // ------------------------------------------------------------------------------ MFMA forward / dgrad
@@ -120,7 +123,7 @@ template <int NT, bool TRANSW>
 __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__restrict__ x,
                                                              const int *__restrict__ tbl,
                                                              const float *__restrict__ W, float *__restrict__ out,
-                                                             int Mout, int K, int Cin, int Cout, int flipk) {
+                                                             int Mout, int K, int Cin, int Cout, int flipk, int kper) {
     constexpr int CoutP = NT * 16;  // Cout rounded up to the MFMA tile; columns >= Cout are zero / not stored
     __shared__ int tblS[CV_BM * CV_MAXK];
     __shared__ __attribute__((aligned(16))) unsigned short As[CV_BM * CV_LD];
@@ -139,7 +142,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
     __syncthreads();
     const int arow = t >> 2, aq = t & 3;  // staging role: row, 8-channel group
     const bool cin4 = (Cin & 3) == 0;
-    for (int k = 0; k < K; k++) {
+    // gridDim.y > 1: the K offsets are split over workgroups (small Mout: the serial offset loop is pure
+    // latency) and the partial sums are added atomically into a zero-filled output
+    const int k_begin = blockIdx.y * kper, k_end = min(K, k_begin + kper);
+    for (int k = k_begin; k < k_end; k++) {
         const int idx = tblS[arow * K + k];
         if (!__syncthreads_or(idx >= 0)) continue;  // no row of the tile uses this offset
         const int wk = flipk ? (K - 1 - k) : k;
@@ -202,7 +208,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
         for (int r = 0; r < 4; r++) {
             const int u = row0 + wave * 16 + (lane >> 4) * 4 + r;
             const int col = n * 16 + (lane & 15);
-            if (u < Mout && col < Cout) out[(long long)u * Cout + col] = acc[n][r];
+            if (u < Mout && col < Cout) {
+                if (gridDim.y == 1) out[(long long)u * Cout + col] = acc[n][r];
+                else atomicAdd(&out[(long long)u * Cout + col], acc[n][r]);
+            }
         }
     }
 }
@@ -210,10 +219,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
 template <bool TRANSW>
 static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
                            int Cout, int flipk, hipStream_t s) {
-    const int grid = (Mout + CV_BM - 1) / CV_BM;
-#define CV_CASE(NTV)                                                                                        \
-    case NTV:                                                                                               \
-        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk); \
+    const int tiles = (Mout + CV_BM - 1) / CV_BM;
+    // enough workgroups to cover the chip: split the offsets when there are few row tiles
+    int ksplit = 1;
+    if (K > 1 && tiles < 256) { ksplit = 512 / tiles; if (ksplit > K) ksplit = K; if (ksplit < 1) ksplit = 1; }
+    const int kper = (K + ksplit - 1) / ksplit;
+    ksplit = (K + kper - 1) / kper;
+    if (ksplit > 1) D3_CHECK(hipMemsetAsync(out, 0, (size_t)Mout * Cout * sizeof(float), s));
+    const dim3 grid(tiles, ksplit);
+#define CV_CASE(NTV)                                                                                              \
+    case NTV:                                                                                                     \
+        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, kper); \
         break;
     switch ((Cout + 15) / 16) {
         CV_CASE(1) CV_CASE(2) CV_CASE(3) CV_CASE(4) CV_CASE(5) CV_CASE(6) CV_CASE(7) CV_CASE(8) CV_CASE(9)
@@ -253,35 +269,40 @@ extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, flo
 
 // ------------------------------------------------------------------------------ MFMA weight gradient
 // dW[k][ci][co] += sum_u x[tbl[u,k]][ci] * dy[u][co]:  M-dim = ci, N-dim = co, reduction = rows.
-// grid = (row blocks, K).  Each wave owns an equal share of the block's rows, stages 32 rows at a time
+// Two equivalent row orders: dy-stationary (rows u of dy are contiguous, x rows gathered through tbl) or, with
+// D3_CONV_XSTAT, x-stationary (rows v of x contiguous, dy rows gathered through the TRANSPOSED map, dW index
+// flipped for a kernel-3 conv): the wider operand is the one read contiguously.
+// grid = (row blocks, K, tile passes).  Each wave owns an equal share of the block's rows, stages 32 rows at a time
 // TRANSPOSED into its private LDS region (Xt[ci][row], DYt[co][row]) so that both MFMA operands are
 // contiguous 8-byte reads, keeps up to WG_MAXT 16x16 accumulators, and the workgroup's four
 // partial results are added to dW with fp32 atomics (order-dependent rounding in the last bits).
-#define WG_ROWS 4096   // rows per workgroup (1024 per wave)
+#define WG_ROWS_MAX 4096   // rows per workgroup (chosen by the host so that the grid covers the chip)
 #define WG_RC 32       // rows per stage
 #define WG_MAXT 16     // accumulator tiles per pass
 
 __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__restrict__ x,
                                                                const int *__restrict__ tbl,
                                                                const float *__restrict__ dy, float *__restrict__ dW,
-                                                               int Mout, int K, int Cin, int Cout) {
+                                                               int Mout, int K, int Cin, int Cout, int rows_per_block,
+                                                               int xstat, int flipk) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
     unsigned short *Xt = smem + (size_t)wave * (CinP + CoutP) * CV_LD;
     unsigned short *DYt = Xt + (size_t)CinP * CV_LD;
     const int k = blockIdx.y;
-    const int rb0 = blockIdx.x * WG_ROWS;
-    const int rows_blk = min(WG_ROWS, Mout - rb0);
+    const int rb0 = blockIdx.x * rows_per_block;       // Mout = number of stationary rows
+    const int rows_blk = min(rows_per_block, Mout - rb0);
     const int per_wave = (rows_blk + nwaves - 1) / nwaves;
     const int w0 = rb0 + wave * per_wave;                     // this wave's rows [w0, w1)
     const int w1 = min(rb0 + rows_blk, w0 + per_wave);
     const int nchunks = (per_wave + WG_RC - 1) / WG_RC;       // uniform over the block
     const int mt = CinP / 16, nt = CoutP / 16, ntiles = mt * nt;
     const int srow = lane >> 1, shalf = lane & 1;             // staging role: row of the chunk, channel phase
-    float *dWk = dW + (long long)k * Cin * Cout;
+    float *dWk = dW + (long long)(flipk ? (K - 1 - k) : k) * Cin * Cout;
 
-    for (int tile0 = 0; tile0 < ntiles; tile0 += WG_MAXT) {
+    {   // one pass of up to WG_MAXT accumulator tiles per workgroup; passes are spread over gridDim.z
+        const int tile0 = blockIdx.z * WG_MAXT;
         f32x4 acc[WG_MAXT];
 #pragma unroll
         for (int i = 0; i < WG_MAXT; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -293,18 +314,19 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__r
             const bool chunk_valid = __syncthreads_or(idx >= 0) != 0;
             if (!chunk_valid) continue;   // uniform
             any_valid = true;
+            const int xrow = xstat ? u : idx, dyrow = xstat ? idx : u;
             // stage x (gathered) and dy, transposed: element (c, row) at [c*CV_LD + row]
             for (int c = shalf * 2; c < CinP; c += 4) {
                 float a = 0.f, b = 0.f;
-                if (idx >= 0 && c + 2 <= Cin) { float2 f = *(const float2 *)(x + (long long)idx * Cin + c); a = f.x; b = f.y; }
-                else if (idx >= 0 && c < Cin) { a = x[(long long)idx * Cin + c]; }
+                if (idx >= 0 && c + 2 <= Cin) { float2 f = *(const float2 *)(x + (long long)xrow * Cin + c); a = f.x; b = f.y; }
+                else if (idx >= 0 && c < Cin) { a = x[(long long)xrow * Cin + c]; }
                 Xt[c * CV_LD + srow] = f2bf(a);
                 Xt[(c + 1) * CV_LD + srow] = f2bf(b);
             }
             for (int c = shalf * 2; c < CoutP; c += 4) {
                 float a = 0.f, b = 0.f;
-                if (idx >= 0 && c + 2 <= Cout) { float2 f = *(const float2 *)(dy + (long long)u * Cout + c); a = f.x; b = f.y; }
-                else if (idx >= 0 && c < Cout) { a = dy[(long long)u * Cout + c]; }
+                if (idx >= 0 && c + 2 <= Cout) { float2 f = *(const float2 *)(dy + (long long)dyrow * Cout + c); a = f.x; b = f.y; }
+                else if (idx >= 0 && c < Cout) { a = dy[(long long)dyrow * Cout + c]; }
                 DYt[c * CV_LD + srow] = f2bf(a);
                 DYt[(c + 1) * CV_LD + srow] = f2bf(b);
             }
@@ -348,9 +370,12 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
     if (K < 1 || K > CV_MAXK || Cin < 1 || Cout < 1) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
     hipStream_t s = d3_stream(stream);
+    const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0, flipk = (flags & D3_CONV_FLIPK) ? 1 : 0;
+    const int rows = xstat ? Min : Mout;   // stationary rows == rows of tbl
     if (flags & D3_CONV_EXACT) {
         long long total = (long long)K * Cin * Cout;
-        spconv_wgrad_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, dy, dW, Mout, K, Cin, Cout);
+        spconv_wgrad_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, dy, dW, rows, K, Cin, Cout, xstat,
+                                                                           flipk);
         D3_LAUNCH_CHECK();
         return 0;
     }
@@ -361,11 +386,17 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
     while (nwaves > 1 && (size_t)nwaves * (CinP + CoutP) * CV_LD * sizeof(unsigned short) > 64 * 1024) nwaves >>= 1;
     size_t lds = (size_t)nwaves * (CinP + CoutP) * CV_LD * sizeof(unsigned short);
     if (lds > 64 * 1024) return D3_ERR_ARG;
-    dim3 grid((Mout + WG_ROWS - 1) / WG_ROWS, K);
+    const int passes = ((CinP / 16) * (CoutP / 16) + WG_MAXT - 1) / WG_MAXT;
+    // rows per workgroup: aim at ~3000 workgroups (latency hiding by occupancy), 64..1024 rows per wave
+    long long want = ((long long)rows * K * passes + 2999) / 3000;
+    int rpb = (int)((want + nwaves * WG_RC - 1) / (nwaves * WG_RC)) * nwaves * WG_RC;
+    if (rpb < nwaves * 2 * WG_RC) rpb = nwaves * 2 * WG_RC;
+    if (rpb > WG_ROWS_MAX) rpb = WG_ROWS_MAX;
+    dim3 grid((rows + rpb - 1) / rpb, K, passes);
     const double bytes = 4.0 * ((double)Min * Cin + (double)Mout * Cout + (double)K * Cin * Cout) +
                          (tbl ? 4.0 * (double)Mout * K : 0.0);
     ProfRec *pr = prof_begin(1, bytes, 0.0, s);
-    spconv_wgrad_mfma_kernel<<<grid, nwaves * 64, lds, s>>>(x, tbl, dy, dW, Mout, K, Cin, Cout);
+    spconv_wgrad_mfma_kernel<<<grid, nwaves * 64, lds, s>>>(x, tbl, dy, dW, rows, K, Cin, Cout, rpb, xstat, flipk);
     prof_end(pr, s);
     D3_LAUNCH_CHECK();
     return 0;

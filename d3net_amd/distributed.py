@@ -1,0 +1,51 @@
+"""Scene-parallel data parallelism: one process per GPU, gradients only.
+
+The reference trains with Lightning DDP over NCCL (scripts/train.py:265-268: `gpus=-1,
+strategy="ddp_find_unused_parameters_false"`), i.e. bucketed gradient all-reduce and nothing else on the data path
+(SURVEY.md section 8e).  Here: one fused all-reduce of a flat gradient buffer per step over RCCL/xGMI
+(backend "nccl" on ROCm), averaged over ranks; BatchNorm statistics stay per rank, as in the reference.
+Works on any backend (the CPU tests use gloo)."""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReduce:
+    """Averages the gradients of `params` across ranks with ONE collective on a persistent flat buffer."""
+
+    def __init__(self, params, device=None):
+        self.params = [p for p in params if p.requires_grad]
+        dev = device if device is not None else self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def __call__(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        dist.all_reduce(self.flat)
+        self.flat.div_(dist.get_world_size())
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+def broadcast_module(module, src=0):
+    """identical replicas at start (what DDP does at construction)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def shard_scenes(n_scenes, rank, world):
+    """rank r gets scenes r, r+W, ... (DistributedSampler order without shuffling)"""
+    return list(range(rank, n_scenes, world))

@@ -26,7 +26,7 @@ from . import _lib
 from ._lib import check
 from .pointgroup_ops import _ptr, _stream, _workspace
 
-D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT = 1, 2, 4
+D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT, D3_CONV_XSTAT = 1, 2, 4, 8
 
 _EXACT = False  # True: fp32 FMA kernels (validation); False: bf16 MFMA with fp32 accumulate
 
@@ -167,10 +167,15 @@ class SparseConvFunction(Function):
             dx = _conv_call(dy, tbl_b, W3, x.size(0), K, Cout, Cin, bwd_flags | D3_CONV_TRANSW)
         if ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W3)
+            # read the wider operand contiguously: x-stationary over the transposed map when Cin > Cout
+            if tbl_b is not None and Cin > Cout:
+                tbl, wflags = tbl_b, D3_CONV_XSTAT | (bwd_flags & D3_CONV_FLIPK)
+            else:
+                tbl, wflags = tbl_f, 0
             with torch.cuda.device(x.device):
-                check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl_f) if tbl_f is not None else None, _ptr(dy),
-                                                 _ptr(dW), x.size(0), Mout, K, Cin, Cout, _mode_flag(), _stream()),
-                      "spconv_wgrad")
+                check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(dy),
+                                                 _ptr(dW), x.size(0), Mout, K, Cin, Cout, wflags | _mode_flag(),
+                                                 _stream()), "spconv_wgrad")
             dW = dW.view_as(W)
         return dx, dW, None, None, None, None
 

@@ -67,14 +67,14 @@ class Voxelization_Idx(Function):
         N, ncols = c.shape
         L = _lib.lib()
         with torch.cuda.device(dev):
-            input_map = torch.zeros(N, dtype=torch.int32, device=dev)
+            input_map = torch.empty(N, dtype=torch.int32, device=dev)
             ws = _workspace(L.d3_voxelize_idx_ws_bytes(N), dev, "vi")
             M, mA = C.c_int(0), C.c_int(1)
             check(L.d3_voxelize_idx_count(_ptr(c), N, ncols, int(mode), _ptr(input_map), _ptr(ws), ws.numel(),
                                           C.byref(M), C.byref(mA), _stream()), "voxelize_idx_count")
             M, mA = M.value, mA.value
-            output_coords = torch.zeros((M, ncols), dtype=torch.int64, device=dev)
-            output_map = torch.zeros((M, mA + 1), dtype=torch.int32, device=dev)
+            output_coords = torch.empty((M, ncols), dtype=torch.int64, device=dev)
+            output_map = torch.empty((M, mA + 1), dtype=torch.int32, device=dev)
             check(L.d3_voxelize_idx_fill(_ptr(c), N, ncols, int(mode), _ptr(input_map), _ptr(ws), ws.numel(),
                                          _ptr(output_coords), _ptr(output_map), M, mA, _stream()),
                   "voxelize_idx_fill")
@@ -179,14 +179,14 @@ class BallQueryBatchP(Function):
         dev = coords.device
         L = _lib.lib()
         with torch.cuda.device(dev):
-            start_len = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+            start_len = torch.empty((n, 2), dtype=torch.int32, device=dev)
             ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bq")
             nActive = C.c_int(0)
             check(L.d3_ballquery_count(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius),
                                        _ptr(start_len), _ptr(ws), ws.numel(), C.byref(nActive), _stream()),
                   "ballquery_count")
             nActive = nActive.value
-            idx = torch.zeros(max(nActive, 1), dtype=torch.int32, device=dev)
+            idx = torch.empty(max(nActive, 1), dtype=torch.int32, device=dev)
             check(L.d3_ballquery_fill(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius),
                                       _ptr(start_len), _ptr(ws), ws.numel(), _ptr(idx), nActive, _stream()),
                   "ballquery_fill")
@@ -226,8 +226,8 @@ class BFSCluster(Function):
             check(L.d3_bfs_cluster_count(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(),
                                          C.byref(S), C.byref(P), _stream()), "bfs_cluster_count")
             S, P = S.value, P.value
-            cluster_idxs = torch.zeros((S, 2), dtype=torch.int32, device=dev)
-            cluster_offsets = torch.zeros(P + 1, dtype=torch.int32, device=dev)
+            cluster_idxs = torch.empty((S, 2), dtype=torch.int32, device=dev)
+            cluster_offsets = torch.empty(P + 1, dtype=torch.int32, device=dev)
             check(L.d3_bfs_cluster_fill(_ptr(sem), _ptr(idx), _ptr(sl), N, _ptr(ws), ws.numel(), _ptr(cluster_idxs),
                                         _ptr(cluster_offsets), S, P, _stream()), "bfs_cluster_fill")
         if on_cpu:
@@ -254,8 +254,8 @@ class RoiPool(Function):
         sumNPoint, Cc = feats.size()
         assert feats.is_contiguous() and feats.is_cuda and feats.dtype == torch.float32
         assert proposals_offset.is_contiguous() and proposals_offset.is_cuda and proposals_offset.dtype == torch.int32
-        output_feats = torch.zeros((nProposal, Cc), dtype=torch.float32, device=feats.device)
-        output_maxidx = torch.zeros((nProposal, Cc), dtype=torch.int32, device=feats.device)
+        output_feats = torch.empty((nProposal, Cc), dtype=torch.float32, device=feats.device)
+        output_maxidx = torch.empty((nProposal, Cc), dtype=torch.int32, device=feats.device)
         with torch.cuda.device(feats.device):
             check(_lib.lib().d3_roipool_fp(_ptr(feats), _ptr(proposals_offset), _ptr(output_feats),
                                            _ptr(output_maxidx), nProposal, Cc, _stream()), "roipool_fp")
@@ -293,7 +293,7 @@ class GetIoU(Function):
         assert proposals_offset.is_contiguous() and proposals_offset.is_cuda and proposals_offset.dtype == torch.int32
         assert instance_labels.is_contiguous() and instance_labels.is_cuda and instance_labels.dtype == torch.int64
         assert instance_pointnum.is_contiguous() and instance_pointnum.is_cuda and instance_pointnum.dtype == torch.int32
-        proposals_iou = torch.zeros((nProposal, nInstance), dtype=torch.float32, device=proposals_idx.device)
+        proposals_iou = torch.empty((nProposal, nInstance), dtype=torch.float32, device=proposals_idx.device)
         with torch.cuda.device(proposals_idx.device):
             check(_lib.lib().d3_get_iou(_ptr(proposals_idx), _ptr(proposals_offset), _ptr(instance_labels),
                                         _ptr(instance_pointnum), _ptr(proposals_iou), nInstance, nProposal,
@@ -313,7 +313,7 @@ def _sec(name, inp, offsets):
     Cc = inp.size(1)
     assert inp.is_contiguous() and inp.is_cuda and inp.dtype == torch.float32
     assert offsets.is_contiguous() and offsets.is_cuda and offsets.dtype == torch.int32
-    out = torch.zeros((nProposal, Cc), dtype=torch.float32, device=inp.device)
+    out = torch.empty((nProposal, Cc), dtype=torch.float32, device=inp.device)
     with torch.cuda.device(inp.device):
         check(getattr(_lib.lib(), name)(_ptr(inp), _ptr(offsets), _ptr(out), nProposal, Cc, _stream()), name)
     return out

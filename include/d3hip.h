@@ -131,9 +131,13 @@ int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_byte
 #define D3_CONV_FLIPK 1
 #define D3_CONV_TRANSW 2
 #define D3_CONV_EXACT 4
+#define D3_CONV_XSTAT 8
 int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
                   int Cout, int flags, void *stream);
-/* Weight gradient  dW[k] += sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32, accumulated into). */
+/* Weight gradient  dW[k] += sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32, accumulated into).
+ * With D3_CONV_XSTAT, tbl is the TRANSPOSED map (one row per x row, entries = dy rows):
+ * dW[k'] += sum_v x[v,:]^T dy[tbl[v,k],:], k' = K-1-k with D3_CONV_FLIPK else k -- same result, but the
+ * wide operand (x) is read contiguously and the narrow one gathered. */
 int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Min, int Mout, int K, int Cin,
                     int Cout, int flags, void *stream);
 

@@ -1,0 +1,48 @@
+"""world_size-2 gloo test of the N>1 path: flat gradient all-reduce == mean of the per-rank gradients,
+replica broadcast, scene sharding.  Runs on CPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3net_amd.distributed import FlatGradAllReduce, broadcast_module, shard_scenes
+    torch.manual_seed(rank)  # different init per rank -> broadcast must equalise
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 3))
+    broadcast_module(net)
+    w0 = net[0].weight.detach().clone()
+    torch.manual_seed(100 + rank)  # different data per rank (one "scene" each)
+    x = torch.randn(16, 5)
+    loss = net(x).pow(2).sum()
+    loss.backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    FlatGradAllReduce(net.parameters())()
+    ret[rank] = dict(w0=w0, local=local, avg=[p.grad.clone() for p in net.parameters()],
+                     shard=shard_scenes(7, rank, world), rm=net[1].running_mean.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert torch.equal(r0["w0"], r1["w0"])                      # identical replicas
+    for a0, a1, l0, l1 in zip(r0["avg"], r1["avg"], r0["local"], r1["local"]):
+        assert torch.allclose(a0, a1)                           # every rank holds the same averaged gradient
+        assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6)     # which is the mean of the local ones
+    assert r0["shard"] == [0, 2, 4, 6] and r1["shard"] == [1, 3, 5]
+    assert not torch.allclose(r0["rm"], r1["rm"])               # BN statistics stay per rank (no SyncBN)
