@@ -32,21 +32,32 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-teacher", action="store_true", help="cluster on the network's own predictions")
     ap.add_argument("--small", action="store_true", help="quarter-size scene (debug)")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, state_dict, scene):
-    """The oracle (CPU restatement of the reference step) timed on this host: one forward+loss+backward of the
-    SAME scene.  Reported baseline only."""
+CPU_THREADS = 8   # torch-CPU sparse conv is fastest at ~8 threads (256 threads on the GPU box: 1000x slower)
+
+
+def cpu_baseline_child():
+    """`bench.py --cpu-baseline-only`: the oracle (CPU restatement of the reference step) timed on this host:
+    one forward+loss+backward of the SAME canonical scene.  Never touches the GPU.  Prints one JSON object."""
     import numpy as np
     import torch
     from d3net_amd import synthetic as S
+    from d3net_amd.config import default_conf
+    from d3net_amd.pointgroup import PointGroup
     from oracle import pg_oracle as pg
     from oracle.pointgroup_oracle import PointGroupOracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(cores)
+    cfg = default_conf()
+    torch.manual_seed(cfg.general.manual_seed)
+    state_dict = PointGroup(cfg).state_dict()          # same random init as the GPU run (CPU tensors)
+    occ, sem, inst, _ = S.occupancy_grid()
+    scene = S.scene_from_grid(occ, sem, inst)
     b = S.collate([scene])
     vl, p2v, v2p = pg.voxelization_idx(b["locs_scaled"], 1, 4)   # loader-side work, not timed (as on the GPU)
     b["voxel_locs"], b["p2v_map"], b["v2p_map"] = vl, p2v, v2p
@@ -57,14 +68,30 @@ def cpu_baseline(cfg, state_dict, scene):
     d = orc.loss(orc.feed(cpu, 0))
     d["total_loss"].backward()
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "scenes/sec", "cores": cores, "kind": "port",
-            "sample": "1 step (forward+loss+backward, no optimizer) of the same %d-point scene through oracle/ "
-                      "(torch-CPU sparse conv with %d threads; C ball query / BFS / segment ops single-threaded), %.1f s"
-                      % (cpu["locs"].shape[0], cores, dt)}
+    print(json.dumps({"value": 1.0 / dt, "unit": "scenes/sec", "cores": cores, "kind": "port",
+                      "sample": "1 step (forward+loss+backward, no optimizer) of the same %d-point canonical scene "
+                                "through oracle/ (torch-CPU gather-mm sparse conv, %d threads; C ball query / BFS / "
+                                "segment ops single-threaded): %.1f s" % (cpu["locs"].shape[0], cores, dt)}), flush=True)
+
+
+def cpu_baseline(limit_s=420):
+    """run the baseline in a child process (bounded; it must never take the GPU number down with it)"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                           text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(CPU_THREADS)))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "cpu baseline exceeded %d s" % limit_s}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        return cpu_baseline_child()
     import torch
     import torch.distributed as dist
 
@@ -168,10 +195,7 @@ def main():
                                    for k, v in prof.items() if k != dom}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict(), scene)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -49,7 +49,8 @@ SIGNATURES = {
     "d3_prof_enable": (i32, [i32]),
     "d3_prof_collect": (i32, [i32, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
-    "d3_bn_stats": (i32, [vp, i32, i32, vp, vp, vp, sz, vp]),
+    "d3_bn_ws_bytes": (sz, [i32]),
+    "d3_bn_stats": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "d3_bn_relu_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "d3_bn_relu_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, sz, vp]),
 }

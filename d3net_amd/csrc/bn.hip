@@ -8,7 +8,8 @@
 
 #define BN_T 256
 
-// per-channel sum / sum of squares -> fp64 accumulators ws[0..C), ws[C..2C)
+// per-channel sum / sum of squares -> per-workgroup fp64 partials ws[block][2C] (no memset, no atomics,
+// deterministic); the finalize kernel adds the partials
 __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict__ x, int M, int C, double *acc) {
     __shared__ float s1[BN_T], s2[BN_T];
     const int t = threadIdx.x;
@@ -26,17 +27,26 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict_
     if (t < C) {
         double da = 0., db = 0.;
         for (int k = t; k < active; k += C) { da += (double)s1[k]; db += (double)s2[k]; }
-        atomicAdd(&acc[t], da);
-        atomicAdd(&acc[C + t], db);
+        acc[(size_t)blockIdx.x * 2 * C + t] = da;
+        acc[(size_t)blockIdx.x * 2 * C + C + t] = db;
     }
 }
-__global__ void bn_finalize_kernel(const double *acc, int M, int C, float *mean, float *var) {
+// mean / biased variance + (optionally) the running-statistics update of nn.BatchNorm1d in training mode:
+// running = (1-momentum)*running + momentum*stat, with the UNBIASED variance (M/(M-1))
+__global__ void bn_finalize_kernel(const double *acc, int nblocks, int M, int C, float *mean, float *var,
+                                   float *running_mean, float *running_var, float momentum) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = acc[c] / (double)M;
-    double v = acc[C + c] / (double)M - m * m;
+    double sa = 0., sb = 0.;
+    for (int b = 0; b < nblocks; b++) { sa += acc[(size_t)b * 2 * C + c]; sb += acc[(size_t)b * 2 * C + C + c]; }
+    const double m = sa / (double)M;
+    double v = sb / (double)M - m * m;
     if (v < 0.) v = 0.;
     mean[c] = (float)m; var[c] = (float)v;  // biased variance (what the normalisation uses)
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+    }
 }
 
 __global__ void bn_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mean,
@@ -94,9 +104,20 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(const float *__rest
     if (t < C) {
         double da = 0., db = 0.;
         for (int k = t; k < active; k += C) { da += (double)s1[k]; db += (double)s2[k]; }
-        atomicAdd(&acc[t], da);
-        atomicAdd(&acc[C + t], db);
+        acc[(size_t)blockIdx.x * 2 * C + t] = da;
+        acc[(size_t)blockIdx.x * 2 * C + C + t] = db;
     }
+}
+// adds the partials: sums[0..C) = sum g, sums[C..2C) = sum g*xhat (fp64), and writes dbeta / dgamma
+__global__ void bn_bwd_params_kernel(const double *acc, int nblocks, int C, double *sums, float *dgamma,
+                                     float *dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sa = 0., sb = 0.;
+    for (int b = 0; b < nblocks; b++) { sa += acc[(size_t)b * 2 * C + c]; sb += acc[(size_t)b * 2 * C + C + c]; }
+    sums[c] = sa; sums[C + c] = sb;
+    dbeta[c] = (float)sa;
+    dgamma[c] = (float)sb;
 }
 __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                     const float *__restrict__ mean, const float *__restrict__ var,
@@ -113,13 +134,6 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
     const float mg = (float)(acc[c] / (double)M), mgx = (float)(acc[C + c] / (double)M);
     dx[e] = ga * inv * (g - mg - xh * mgx);
 }
-__global__ void bn_bwd_params_kernel(const double *acc, int C, float *dgamma, float *dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    dbeta[c] += (float)acc[c];
-    dgamma[c] += (float)acc[C + c];
-}
-
 static int bn_grid(int M, int C) {
     const int rpp = (BN_T / C);
     long long blocks = ((long long)M + rpp - 1) / rpp;
@@ -129,16 +143,22 @@ static int bn_grid(int M, int C) {
     return (int)blocks;
 }
 
-extern "C" int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, void *ws, size_t ws_bytes,
-                           void *stream) {
+#define BN_MAXBLK 512
+static int bn_blocks(int M, int C) { int g = bn_grid(M, C); return g > BN_MAXBLK ? BN_MAXBLK : g; }
+
+extern "C" size_t d3_bn_ws_bytes(int C) { return (size_t)(BN_MAXBLK + 1) * 2 * C * sizeof(double); }
+
+extern "C" int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, float *running_mean,
+                           float *running_var, float momentum, void *ws, size_t ws_bytes, void *stream) {
     D3_CLEAR();
     if (M <= 0) return 0;
     if (C < 1 || C > BN_T) return D3_ERR_ARG;
-    if (ws == nullptr || ws_bytes < 2 * (size_t)C * sizeof(double)) return D3_ERR_WORKSPACE;
+    if (ws == nullptr || ws_bytes < d3_bn_ws_bytes(C)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
-    D3_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(double), s));
-    bn_stats_kernel<<<bn_grid(M, C), BN_T, 0, s>>>(x, M, C, (double *)ws);
-    bn_finalize_kernel<<<(C + 63) / 64, 64, 0, s>>>((const double *)ws, M, C, mean, var);
+    const int nb = bn_blocks(M, C);
+    bn_stats_kernel<<<nb, BN_T, 0, s>>>(x, M, C, (double *)ws);
+    bn_finalize_kernel<<<(C + 63) / 64, 64, 0, s>>>((const double *)ws, nb, M, C, mean, var, running_mean, running_var,
+                                                  momentum);
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -164,14 +184,15 @@ extern "C" int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean
     D3_CLEAR();
     if (M <= 0) return 0;
     if (C < 1 || C > BN_T) return D3_ERR_ARG;
-    if (ws == nullptr || ws_bytes < 2 * (size_t)C * sizeof(double)) return D3_ERR_WORKSPACE;
+    if (ws == nullptr || ws_bytes < d3_bn_ws_bytes(C)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
-    D3_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)C * sizeof(double), s));
-    bn_bwd_reduce_kernel<<<bn_grid(M, C), BN_T, 0, s>>>(x, dy, mean, var, gamma, beta, M, C, eps, relu, (double *)ws);
+    const int nb = bn_blocks(M, C);
+    double *partials = (double *)ws, *sums = partials + (size_t)BN_MAXBLK * 2 * C;
+    bn_bwd_reduce_kernel<<<nb, BN_T, 0, s>>>(x, dy, mean, var, gamma, beta, M, C, eps, relu, partials);
+    bn_bwd_params_kernel<<<(C + 63) / 64, 64, 0, s>>>(partials, nb, C, sums, dgamma, dbeta);
     long long total = (long long)M * C;
-    bn_bwd_apply_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, dy, mean, var, gamma, beta, (const double *)ws,
-                                                                 dx, total, M, C, eps, relu);
-    bn_bwd_params_kernel<<<(C + 63) / 64, 64, 0, s>>>((const double *)ws, C, dgamma, dbeta);
+    bn_bwd_apply_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, dy, mean, var, gamma, beta, sums, dx, total, M, C,
+                                                                 eps, relu);
     D3_LAUNCH_CHECK();
     return 0;
 }

@@ -372,6 +372,7 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
     hipStream_t s = d3_stream(stream);
     const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0, flipk = (flags & D3_CONV_FLIPK) ? 1 : 0;
     const int rows = xstat ? Min : Mout;   // stationary rows == rows of tbl
+    if (!(flags & D3_CONV_ACCUM)) D3_CHECK(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), s));
     if (flags & D3_CONV_EXACT) {
         long long total = (long long)K * Cin * Cout;
         spconv_wgrad_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, dy, dW, rows, K, Cin, Cout, xstat,

@@ -166,7 +166,7 @@ class SparseConvFunction(Function):
             # data gradient: the same contraction over the transposed map with W^T (Cout -> Cin)
             dx = _conv_call(dy, tbl_b, W3, x.size(0), K, Cout, Cin, bwd_flags | D3_CONV_TRANSW)
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros_like(W3)
+            dW = torch.empty_like(W3)   # cleared inside d3_spconv_wgrad
             # read the wider operand contiguously: x-stationary over the transposed map when Cin > Cout
             if tbl_b is not None and Cin > Cout:
                 tbl, wflags = tbl_b, D3_CONV_XSTAT | (bwd_flags & D3_CONV_FLIPK)
@@ -182,38 +182,41 @@ class SparseConvFunction(Function):
 
 class BatchNormReLUFunction(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, running_mean, running_var, momentum):
         x = x.contiguous()
         M, Cc = x.shape
-        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
-        var = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        stats = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        mean, var = stats[0], stats[1]
         y = torch.empty_like(x)
-        ws = _workspace(2 * Cc * 8, x.device, "bn")
         L = _lib.lib()
+        ws = _workspace(L.d3_bn_ws_bytes(Cc), x.device, "bn")
         with torch.cuda.device(x.device):
-            check(L.d3_bn_stats(_ptr(x), M, Cc, _ptr(mean), _ptr(var), _ptr(ws), ws.numel(), _stream()), "bn_stats")
+            check(L.d3_bn_stats(_ptr(x), M, Cc, _ptr(mean), _ptr(var),
+                                _ptr(running_mean) if running_mean is not None else None,
+                                _ptr(running_var) if running_var is not None else None, float(momentum or 0.0),
+                                _ptr(ws), ws.numel(), _stream()), "bn_stats")
             check(L.d3_bn_relu_fwd(_ptr(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), _ptr(y), M, Cc, eps,
                                    int(relu), _stream()), "bn_relu_fwd")
-        ctx.save_for_backward(x, gamma, beta, mean, var)
+        ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (eps, relu)
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        return y
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
-        x, gamma, beta, mean, var = ctx.saved_tensors
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        mean, var = stats[0], stats[1]
         eps, relu = ctx.cfg
         dy = dy.contiguous()
         M, Cc = x.shape
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(beta)
-        ws = _workspace(2 * Cc * 8, x.device, "bn")
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        ws = _workspace(_lib.lib().d3_bn_ws_bytes(Cc), x.device, "bn")
         with torch.cuda.device(x.device):
             check(_lib.lib().d3_bn_relu_bwd(_ptr(x), _ptr(dy), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
                                             _ptr(dx), _ptr(dgamma), _ptr(dbeta), M, Cc, eps, int(relu), _ptr(ws),
                                             ws.numel(), _stream()), "bn_relu_bwd")
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
 class BatchNormEvalFunction(Function):
@@ -289,18 +292,26 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
         self.fused_relu = False  # set by fuse_bn_relu(): the following MinkowskiReLU becomes a no-op
+        self._steps = 0
+        self._register_state_dict_hook(MinkowskiBatchNorm._sync_counter)
+
+    @staticmethod
+    def _sync_counter(module, state_dict, prefix, local_metadata):
+        # num_batches_tracked is only bookkeeping (momentum is not None): keep it exact without a launch per step
+        if module._steps:
+            module.bn.num_batches_tracked += module._steps
+            module._steps = 0
+            state_dict[prefix + "bn.num_batches_tracked"] = module.bn.num_batches_tracked
 
     def forward(self, x):
         bn = self.bn
         if self.training or not bn.track_running_stats:
-            y, mean, var = BatchNormReLUFunction.apply(x.F, bn.weight, bn.bias, bn.eps, self.fused_relu)
-            if bn.track_running_stats:
-                with torch.no_grad():
-                    M = x.F.size(0)
-                    m = bn.momentum
-                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                    bn.running_var.mul_(1 - m).add_(var, alpha=m * M / max(M - 1, 1))
-                    bn.num_batches_tracked += 1
+            track = bn.track_running_stats
+            y = BatchNormReLUFunction.apply(x.F, bn.weight, bn.bias, bn.eps, self.fused_relu,
+                                            bn.running_mean if track else None, bn.running_var if track else None,
+                                            bn.momentum)   # running statistics are updated inside the stats kernel
+            if track:
+                self._steps += 1   # num_batches_tracked is synchronised lazily (state_dict / eval)
         else:
             y = BatchNormEvalFunction.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                             self.fused_relu)

@@ -132,9 +132,11 @@ int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_byte
 #define D3_CONV_TRANSW 2
 #define D3_CONV_EXACT 4
 #define D3_CONV_XSTAT 8
+#define D3_CONV_ACCUM 16
 int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
                   int Cout, int flags, void *stream);
-/* Weight gradient  dW[k] += sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32, accumulated into).
+/* Weight gradient  dW[k] = sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32; cleared here unless
+ * D3_CONV_ACCUM is set, then accumulated into).
  * With D3_CONV_XSTAT, tbl is the TRANSPOSED map (one row per x row, entries = dy rows):
  * dW[k'] += sum_v x[v,:]^T dy[tbl[v,k],:], k' = K-1-k with D3_CONV_FLIPK else k -- same result, but the
  * wide operand (x) is read contiguously and the narrow one gathered. */
@@ -148,11 +150,14 @@ int d3_prof_collect(int family, long long *launches, double *total_ms, double *t
 
 /* MinkowskiBatchNorm (+ MinkowskiReLU) over the rows of an (M,C) feature matrix
  * (reference: model/pointgroup.py:65,72-73; model/common.py:36-40).  Training-mode batch statistics.
- * stats : mean (C) and biased var (C) in fp32 (fp64 accumulation); ws >= 2*C doubles.
+ * stats : mean (C) and biased var (C) in fp32 (deterministic fp64 two-stage reduction); when running_mean /
+ *         running_var are non-NULL they are updated like nn.BatchNorm1d in training mode
+ *         (running = (1-momentum)*running + momentum*stat, unbiased variance).  ws >= d3_bn_ws_bytes(C).
  * fwd   : y = [relu]((x-mean)*rsqrt(var+eps)*gamma+beta)
- * bwd   : dx from dy (the relu mask is recomputed from x), dgamma/dbeta accumulated into;
- *         ws >= 2*C doubles. */
-int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, void *ws, size_t ws_bytes, void *stream);
+ * bwd   : dx from dy (the relu mask is recomputed from x); dgamma / dbeta are WRITTEN. */
+size_t d3_bn_ws_bytes(int C);
+int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, float *running_mean, float *running_var,
+                float momentum, void *ws, size_t ws_bytes, void *stream);
 int d3_bn_relu_fwd(const float *x, const float *mean, const float *var, const float *gamma, const float *beta,
                    float *y, int M, int C, float eps, int relu, void *stream);
 int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const float *var, const float *gamma,
