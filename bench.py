@@ -173,6 +173,15 @@ def main():
         pd = prof[dom]
         avg_ms = pd["total_ms"] / max(pd["launches"], 1)
         achieved = (pd["bytes"] / max(pd["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch of the dominant kernel from the PMC counters (cannot be sampled from inside this
+        # process): the committed rocprofv3 --pmc measurement of this same command (tools/gpu_round.sh)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pmc[dom]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2*FETCH+WRITE)*1024)"
+        except Exception:
+            pass
         out = {
             "metric": "scenes/sec fwd+bwd (PointGroup detector)", "value": world * args.steps / elapsed,
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,7 +195,8 @@ def main():
                        "precision": "fp32 storage, bf16 MFMA operands, fp32 accumulate"},
             "final_loss": float(loss),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": pd["bytes"] / max(pd["launches"], 1),
                          "launches_per_step": pd["launches"] / args.steps, "avg_launch_us": avg_ms * 1e3,
                          "share_of_step": pd["total_ms"] / (1e3 * elapsed),
                          "other": {k: {"launches_per_step": v["launches"] / args.steps,
