@@ -1,0 +1,311 @@
+"""Listener (grounding) head on MI355X: `LangModule`, `MultiHeadAttention`, `TransformerMatchModule`, `ListenerNet`
+with the reference's constructors, `data_dict` keys and state-dict layout
+(reference: model/lang_module.py:8-178, model/transformer/attention.py:7-77,134-176, model/match_module.py:143-336,
+model/listener.py:10-54).
+
+What runs where: projections / 1x1 convs / LayerNorm / BatchNorm1d are plain library GEMMs and elementwise ops
+(hipBLASLt / MIOpen through torch); the attention core (scores + distance bias + key mask + softmax + PV, forward and
+backward) is the hand-written kernel `d3_attn_fwd/bwd` (csrc/attention.hip), which consumes the UN-replicated distance
+weights and (B,T) masks instead of the (B*C,4,128,128) copies the reference builds with `.repeat`
+(model/match_module.py:191-197,324-326).  The packed GRU is torch's nn.GRU (MIOpen) for now.
+"""
+import ctypes as C
+import math
+import random
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+from . import _lib
+from ._lib import check
+from .pointgroup_ops import _ptr, _stream
+
+
+# ------------------------------------------------------------------------------------ attention core
+class AttentionCoreFunction(Function):
+    """softmax(q k^T / sqrt(dk) + bias, key-masked) v on (B, n, h*d) projections."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, mask, h, bias_div):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, nq, hdk = q.shape
+        nk = k.shape[1]
+        dk, dv = hdk // h, v.shape[2] // h
+        out = torch.empty((B, nq, h * dv), dtype=torch.float32, device=q.device)
+        P = torch.empty((B, h, nq, nk), dtype=torch.float32, device=q.device)
+        if bias is not None:
+            bias = bias.contiguous()
+            assert bias.shape == (B // bias_div, h, nq, nk) and B % bias_div == 0
+        if mask is not None:
+            mask = mask.contiguous().float()
+            assert mask.shape == (B, nk)
+        with torch.cuda.device(q.device):
+            check(_lib.lib().d3_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias) if bias is not None else None,
+                                         _ptr(mask) if mask is not None else None, _ptr(out), _ptr(P), B, h, nq, nk,
+                                         dk, dv, bias_div, _stream()), "attn_fwd")
+        ctx.save_for_backward(q, k, v, P)
+        ctx.dims = (B, h, nq, nk, dk, dv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, P = ctx.saved_tensors
+        B, h, nq, nk, dk, dv = ctx.dims
+        dout = dout.contiguous()
+        dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dS = torch.empty_like(P)
+        with torch.cuda.device(q.device):
+            check(_lib.lib().d3_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(P), _ptr(dout), _ptr(dS), _ptr(dq), _ptr(dk_),
+                                         _ptr(dv_), B, h, nq, nk, dk, dv, _stream()), "attn_bwd")
+        return dq, dk_, dv_, None, None, None, None   # the distance weights are detached in the reference
+
+
+class ScaledDotProductAttention(nn.Module):
+    """(reference: model/transformer/attention.py:7-77)"""
+
+    def __init__(self, d_model, d_k, d_v, h):
+        super().__init__()
+        self.fc_q = nn.Linear(d_model, h * d_k)
+        self.fc_k = nn.Linear(d_model, h * d_k)
+        self.fc_v = nn.Linear(d_model, h * d_v)
+        self.fc_o = nn.Linear(h * d_v, d_model)
+        self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
+        for fc in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
+            nn.init.xavier_uniform_(fc.weight)
+            nn.init.constant_(fc.bias, 0)
+
+    def forward(self, queries, keys, values, key_mask=None, attention_weights=None, way="add", weights_div=1):
+        """key_mask (B, nk) with 0 = masked (the reference passes its (B,h,nq,nk) replica);
+        attention_weights (B/weights_div, h, nq, nk), added to the scaled scores (way == "add")."""
+        if attention_weights is not None and way != "add":
+            raise NotImplementedError("only the additive weights the reference uses (match_module.py:238) are implemented")
+        out = AttentionCoreFunction.apply(self.fc_q(queries), self.fc_k(keys), self.fc_v(values), attention_weights,
+                                          key_mask, self.h, weights_div)
+        return self.fc_o(out)
+
+
+class MultiHeadAttention(nn.Module):
+    """post-LN residual attention layer with dropout (reference: model/transformer/attention.py:134-176)."""
+
+    def __init__(self, d_model, d_k, d_v, h, dropout=.1):
+        super().__init__()
+        self.attention = ScaledDotProductAttention(d_model=d_model, d_k=d_k, d_v=d_v, h=h)
+        self.dropout = nn.Dropout(p=dropout)
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    def forward(self, queries, keys, values, key_mask=None, attention_weights=None, way="add", weights_div=1):
+        out = self.attention(queries, keys, values, key_mask, attention_weights, way, weights_div)
+        return self.layer_norm(queries + self.dropout(out))
+
+
+# ------------------------------------------------------------------------------------------ language
+class LangModule(nn.Module):
+    """GRU description encoder + language classifier (reference: model/lang_module.py:8-178)."""
+
+    def __init__(self, cfg, emb_size=300, hidden_size=256):
+        super().__init__()
+        self.num_text_classes = cfg.model.num_bbox_class
+        self.use_lang_classifier = cfg.model.use_lang_classifier
+        self.use_bidir = cfg.model.use_bidir
+        self.emb_size, self.hidden_size = emb_size, hidden_size
+        self.gru = nn.GRU(input_size=emb_size, hidden_size=hidden_size, batch_first=True, bidirectional=self.use_bidir)
+        if self.use_lang_classifier:
+            self.lang_cls = nn.Sequential(nn.Linear(hidden_size, self.num_text_classes), nn.Dropout())
+
+    def _encode(self, word_embs, lang_len):
+        """(B,C,T,300), (B,C) -> padded hiddens (B*C,T,H), last hidden (B*C,H), mask (B*C,T), scores"""
+        B, Cn, T, _ = word_embs.shape
+        embs = word_embs.reshape(-1, T, self.emb_size)
+        lens = lang_len.reshape(-1)
+        packed = pack_padded_sequence(embs, lens.cpu(), batch_first=True, enforce_sorted=False)
+        hiddens, last = self.gru(packed)
+        hiddens, _ = pad_packed_sequence(hiddens, batch_first=True)
+        last = last.permute(1, 0, 2).contiguous().flatten(start_dim=1)
+        if self.use_bidir:  # average the two directions (:59-61)
+            H = self.hidden_size
+            hiddens = (hiddens[:, :, :H] + hiddens[:, :, H:]) / 2
+            last = (last[:, :H] + last[:, H:]) / 2
+        pad = hiddens.new_zeros(B * Cn, T, self.hidden_size)
+        pad[:, :hiddens.shape[1]] = hiddens                                  # zero padding up to T (:67-68)
+        masks = (torch.arange(T, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)).float()
+        scores = self.lang_cls(last) if self.use_lang_classifier else None
+        return pad, last, masks, scores
+
+    def forward(self, data_dict, use_rl=False):
+        if use_rl:
+            s = self._encode(data_dict["lang_feat"]["sampled"], data_dict["lang_len"]["sampled"])
+            with torch.no_grad():
+                b = self._encode(data_dict["lang_feat"]["baseline"], data_dict["lang_len"]["baseline"])
+            for key, i in (("lang_hiddens", 0), ("lang_emb", 1), ("lang_masks", 2), ("lang_scores", 3)):
+                data_dict[key] = {"sampled": s[i], "baseline": b[i]}
+        else:
+            hid, last, masks, scores = self._encode(data_dict["lang_feat"], data_dict["lang_len"])
+            data_dict["lang_masks"], data_dict["lang_hiddens"], data_dict["lang_emb"] = masks, hid, last
+            if self.use_lang_classifier:
+                data_dict["lang_scores"] = scores
+        return data_dict
+
+
+# --------------------------------------------------------------------------------------------- match
+class TransformerMatchModule(nn.Module):
+    """(reference: model/match_module.py:143-336)"""
+
+    def __init__(self, cfg, lang_size=256, hidden_size=128, head=4, depth=2, use_dist_weight_matrix=True):
+        super().__init__()
+        self.use_dist_weight_matrix = use_dist_weight_matrix
+        self.num_proposals = cfg.model.max_num_proposal
+        self.lang_size, self.hidden_size, self.head = lang_size, hidden_size, head
+        self.depth = depth - 1
+        self.det_channel = cfg.model.m
+        self.chunk_size = cfg.data.num_des_per_scene
+        self.features_concat = nn.Sequential(
+            nn.Conv1d(self.det_channel, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(hidden_size),
+            nn.Conv1d(hidden_size, hidden_size, 1))
+        self.match = nn.Sequential(
+            nn.Conv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(),
+            nn.Conv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(),
+            nn.Conv1d(hidden_size, 1, 1))
+        self.lang_fc = nn.Sequential(nn.Linear(lang_size, hidden_size), nn.ReLU(), nn.Dropout(p=0.1), nn.LayerNorm(hidden_size))
+        self.lang_self_attn = MultiHeadAttention(d_model=hidden_size, d_k=16, d_v=16, h=head)
+        dh = hidden_size // head
+        self.self_attn = nn.ModuleList(MultiHeadAttention(hidden_size, dh, dh, head) for _ in range(depth))
+        self.cross_attn = nn.ModuleList(MultiHeadAttention(hidden_size, dh, dh, head) for _ in range(depth))
+
+    def multiplex_attention(self, v_features, l_features, l_masks, dist_weights, weights_div):
+        """v (B*C,K,128), l (B*C,T,256), l_masks (B*C,T), dist_weights (B',h,K,K) shared by weights_div items"""
+        l_features = self.lang_fc(l_features)
+        l_features = self.lang_self_attn(l_features, l_features, l_features, key_mask=l_masks)
+        v_features = self.cross_attn[0](v_features, l_features, l_features, key_mask=l_masks)
+        for i in range(self.depth):
+            v_features = self.self_attn[i + 1](v_features, v_features, v_features, attention_weights=dist_weights,
+                                               weights_div=weights_div)
+            v_features = self.cross_attn[i + 1](v_features, l_features, l_features, key_mask=l_masks)
+        return self.match(v_features.permute(0, 2, 1).contiguous()).squeeze(1)       # (B*C, K)
+
+    def _dist_weights(self, centers):
+        """row-normalised inverse centre distances, one copy per head (:220-238); detached"""
+        diff = centers[:, None, :, :] - centers[:, :, None, :]
+        dist = torch.sqrt(torch.sum(diff.pow(2), dim=-1))[:, None, :, :]
+        w = 1 / (dist + 1e-2)
+        w = w / torch.sum(w, dim=2, keepdim=True)
+        return w.expand(-1, self.head, -1, -1).contiguous().detach()
+
+    def _copy_paste(self, features, obj_masks):
+        """train-time augmentation: fill the empty proposal slots of each scene with real proposal features of the
+        batch (:266-291), same indexing as the reference."""
+        B, K = obj_masks.shape
+        out = features.clone()
+        lens = obj_masks.sum(1)
+        flat = features.reshape(B * K, -1)[obj_masks.reshape(-1)]
+        total = flat.shape[0]
+        pool = flat.repeat(2, 1)
+        j = 0
+        for i in range(B):
+            empty = torch.where(~obj_masks[i])[0]
+            n_i = int(lens[i])
+            j += n_i
+            n = empty.shape[0] if empty.shape[0] < total - n_i else total - n_i
+            out[i, empty[:n], :] = pool[j:j + n, :]
+        return out
+
+    def forward(self, data_dict, use_rl=False):
+        centers = data_dict["proposal_center_batched"]
+        dist_weights = self._dist_weights(centers) if self.use_dist_weight_matrix else None
+        feats = self.features_concat(data_dict["proposal_feats_batched"].permute(0, 2, 1)).permute(0, 2, 1)
+        B, K = feats.shape[:2]
+        masks = data_dict["proposal_batch_mask"].float()
+        feats = self.self_attn[0](feats, feats, feats, attention_weights=dist_weights)     # no proposal mask (:260)
+        data_dict["random"] = random.random()
+        feature0 = feats
+        if data_dict["istrain"][0] == 1 and data_dict["random"] < 0.5:
+            feature0 = self._copy_paste(feats, masks.bool())
+        Cn = self.chunk_size
+        if use_rl:
+            topn = data_dict["sampled_topn"]
+            v = feature0.unsqueeze(1).repeat(1, topn * Cn, 1, 1).reshape(-1, K, self.hidden_size)
+            div = topn * Cn
+            sampled = self.multiplex_attention(v, data_dict["lang_hiddens"]["sampled"], data_dict["lang_masks"]["sampled"],
+                                               dist_weights, div)
+            with torch.no_grad():
+                baseline = self.multiplex_attention(v, data_dict["lang_hiddens"]["baseline"],
+                                                    data_dict["lang_masks"]["baseline"], dist_weights, div)
+            data_dict["cluster_ref"] = {"sampled": sampled, "baseline": baseline}
+        else:
+            v = feature0[:, None].repeat(1, Cn, 1, 1).reshape(-1, K, self.hidden_size)
+            data_dict["cluster_ref"] = self.multiplex_attention(v, data_dict["lang_hiddens"], data_dict["lang_masks"],
+                                                                dist_weights, Cn)
+        return data_dict
+
+
+class ListenerNet(nn.Module):
+    """(reference: model/listener.py:10-54)"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.match_type = cfg.model.match_type
+        self.lang = LangModule(cfg)
+        if self.match_type != "Transformer":
+            raise NotImplementedError("only match_type: Transformer (the shipped default, conf/pointgroup.yaml:79)")
+        self.match = TransformerMatchModule(cfg)
+
+    def forward(self, data_dict, use_rl=False):
+        data_dict = self.lang(data_dict, use_rl)
+        return self.match(data_dict, use_rl)
+
+
+# ---------------------------------------------------------------------------------------------- loss
+def aabb_iou_to_gt(pred_corners, gt_corners):
+    """AABB IoU of every proposal box (N,K,8,3) with its sample's GT box (N,8,3) -> (N,K)
+    (lib/utils/bbox.py:247-271 get_aabb3d_iou_batch), on the device."""
+    pmin, pmax = pred_corners.min(2)[0], pred_corners.max(2)[0]
+    gmin, gmax = gt_corners.min(1)[0].unsqueeze(1), gt_corners.max(1)[0].unsqueeze(1)
+    inter = (torch.minimum(pmax, gmax) - torch.maximum(pmin, gmin)).clamp(min=0).prod(-1)
+    vol_p = (pmax - pmin).prod(-1)
+    vol_g = (gmax - gmin).prod(-1)
+    return inter / (vol_p + vol_g - inter + 1e-8)
+
+
+def softmax_ranking_loss(inputs, targets):
+    """lib/grounding/loss.py:6-25 (the 1e-8 inside and outside the softmax included)"""
+    probs = torch.softmax(inputs + 1e-8, dim=1)
+    return (-torch.sum(torch.log(probs + 1e-8) * targets, dim=1)).mean()
+
+
+def get_grounding_loss(data_dict, is_frozen=False):
+    """non-RL branch of lib/grounding/loss_helper.py:133-214: pseudo-GT = proposal with the highest IoU with the
+    referred box, softmax ranking loss, accuracy and IoU rates -- without the per-sample host loops."""
+    preds = data_dict["cluster_ref"]
+    N, K = preds.shape
+    corners = data_dict["proposal_bbox_batched"]
+    chunk = N // corners.shape[0]
+    corners = corners.unsqueeze(1).repeat(1, chunk, 1, 1, 1).reshape(N, K, 8, 3)
+    gt = data_dict["ref_box_corner_label"].reshape(N, 8, 3)
+    ious = aabb_iou_to_gt(corners, gt)
+    label_idx = ious.argmax(1)
+    labels = torch.zeros_like(preds).scatter_(1, label_idx.unsqueeze(1), 1.0)
+    loss = softmax_ranking_loss(preds, labels)
+    data_dict["cluster_labels"] = labels
+    pred_idx = preds.argmax(-1)
+    acc = (pred_idx == label_idx).sum().float() / N
+    rows = torch.arange(N, device=preds.device)
+    ref_ious, best_ious = ious[rows, pred_idx], ious[rows, label_idx]
+    data_dict["ref_loss"] = loss if not is_frozen else preds.new_zeros(())
+    data_dict["ref_acc_mean"] = acc
+    data_dict["ref_iou_mean"] = ref_ious.mean()
+    data_dict["best_ious_mean"] = best_ious.mean()
+    data_dict["ref_iou_rate_0.25"] = (ref_ious >= 0.25).float().mean()
+    data_dict["ref_iou_rate_0.5"] = (ref_ious >= 0.5).float().mean()
+    return data_dict["ref_loss"], data_dict
+
+
+def get_lobjcls_loss(data_dict, is_frozen=False):
+    """non-RL branch of lib/grounding/loss_helper.py:276-292"""
+    preds = data_dict["lang_scores"]
+    targets = data_dict.get("ref_cat_label", data_dict["object_cat"]).reshape(-1)
+    loss = nn.functional.cross_entropy(preds, targets)
+    data_dict["lang_loss"] = loss if not is_frozen else preds.new_zeros(())
+    data_dict["lang_acc"] = (preds.argmax(-1) == targets).sum().float() / targets.shape[0]
+    return data_dict["lang_loss"], data_dict

@@ -164,6 +164,20 @@ int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const flo
                    const float *beta, float *dx, float *dgamma, float *dbeta, int M, int C, float eps, int relu,
                    void *ws, size_t ws_bytes, void *stream);
 
+/* ---- proposal-level attention (listener) ------------------------------------------------ */
+/* Core of ScaledDotProductAttention.forward between the projections (model/transformer/attention.py:61-75):
+ * softmax(q k^T / sqrt(dk) + bias, masked where mask == 0) v, per (batch item, head), fp32.
+ * q (B,nq,h*dk), k (B,nk,h*dk), v (B,nk,h*dv), out (B,nq,h*dv) -- the layouts nn.Linear produces;
+ * bias (B/bias_div, h, nq, nk) or NULL: additive attention weights, shared by bias_div consecutive batch items
+ * (the reference replicates them per description chunk, model/match_module.py:324-326);
+ * mask (B, nk) or NULL: 0 = masked key (the reference replicates it to (B,h,nq,nk), match_module.py:191-197);
+ * P (B,h,nq,nk): softmax probabilities, kept for the backward.  nq,nk <= 128, dk,dv <= 32.
+ * bwd: dS (B,h,nq,nk) scratch; dq, dk, dv written. */
+int d3_attn_fwd(const float *q, const float *k, const float *v, const float *bias, const float *mask, float *out,
+                float *P, int B, int h, int nq, int nk, int dk, int dv, int bias_div, void *stream);
+int d3_attn_bwd(const float *q, const float *k, const float *v, const float *P, const float *dout, float *dS,
+                float *dq, float *dk, float *dv, int B, int h, int nq, int nk, int dkdim, int dvdim, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

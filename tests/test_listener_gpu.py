@@ -1,0 +1,81 @@
+"""GPU parity of the listener path (d3net_amd.listener, HIP attention core) against the golden vectors produced by the
+reference's own modules and against the pinned CPU oracle.  Tolerance: fp32 everywhere; differences come from the
+summation order of library GEMMs / MIOpen GRU / the attention kernel: rtol 1e-3, atol 1e-4 on outputs."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def test_attention_core_fwd_bwd_vs_torch(dev):
+    from d3net_amd.listener import AttentionCoreFunction
+    torch.manual_seed(0)
+    for (B, h, nq, nk, dk, dv, div, use_bias, use_mask) in [(8, 4, 128, 128, 32, 32, 4, True, False), (6, 4, 128, 24, 32, 32, 1, False, True),
+                                                          (6, 4, 24, 24, 16, 16, 1, False, True), (3, 2, 50, 77, 8, 24, 3, True, True)]:
+        q = torch.randn(B, nq, h * dk, device=dev, requires_grad=True)
+        k = torch.randn(B, nk, h * dk, device=dev, requires_grad=True)
+        v = torch.randn(B, nk, h * dv, device=dev, requires_grad=True)
+        bias = torch.randn(B // div, h, nq, nk, device=dev) if use_bias else None
+        mask = (torch.rand(B, nk, device=dev) > 0.3).float() if use_mask else None
+        if mask is not None:
+            mask[:, 0] = 1
+        out = AttentionCoreFunction.apply(q, k, v, bias, mask, h, div)
+        g = torch.randn_like(out)
+        out.backward(g)
+        q2, k2, v2 = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        att = torch.matmul(q2.view(B, nq, h, dk).permute(0, 2, 1, 3), k2.view(B, nk, h, dk).permute(0, 2, 3, 1)) / np.sqrt(dk)
+        if bias is not None:
+            att = att + bias.repeat_interleave(div, 0)
+        if mask is not None:
+            att = att.masked_fill(mask[:, None, None, :] == 0, -np.inf)
+        ref = torch.matmul(torch.softmax(att, -1), v2.view(B, nk, h, dv).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, nq, h * dv)
+        ref.backward(g)
+        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5)
+        for a, b in ((q.grad, q2.grad), (k.grad, k2.grad), (v.grad, v2.grad)):
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), float((a - b).abs().max())
+
+
+def _load(dev):
+    from gen_listener_golden import golden_weights, make_cfg
+    from d3net_amd.listener import ListenerNet
+    g = np.load(os.path.join(HERE, "golden", "listener_golden.npz"))
+    net = ListenerNet(make_cfg())
+    net.load_state_dict(golden_weights(net.state_dict()))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    d = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in/")}
+    return g, net.to(dev), d
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_listener_matches_reference_golden(dev, mode):
+    from d3net_amd.listener import get_grounding_loss, get_lobjcls_loss
+    g, net, d = _load(dev)
+    net.train(mode == "train")
+    d["istrain"] = torch.tensor([1 if mode == "train" else 0])
+    random.seed(3)
+    d = net(d)
+    assert abs(d["random"] - float(g[mode + "/random"])) < 1e-7
+    _, d = get_grounding_loss(d)
+    _, d = get_lobjcls_loss(d)
+    for k in ("cluster_ref", "lang_scores", "lang_emb", "lang_hiddens", "lang_masks", "cluster_labels", "ref_loss", "lang_loss",
+              "ref_acc_mean", "lang_acc", "ref_iou_mean", "best_ious_mean", "ref_iou_rate_0.25", "ref_iou_rate_0.5"):
+        ref = g["%s/%s" % (mode, k)]
+        got = d[k].detach().cpu().numpy()
+        assert np.allclose(got, ref, rtol=1e-3, atol=1e-4), (mode, k, float(np.abs(got - ref).max()))
+    if mode == "train":
+        (d["ref_loss"] + d["lang_loss"]).backward()
+        params = dict(net.named_parameters())
+        for k in g.files:
+            if k.startswith("train/grad/"):
+                ref = g[k]
+                got = params[k[len("train/grad/"):]].grad.cpu().numpy()
+                assert np.allclose(got, ref, rtol=5e-3, atol=1e-5 + 2e-3 * np.abs(ref).max()), (k, float(np.abs(got - ref).max()))
