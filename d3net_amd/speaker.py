@@ -1,0 +1,350 @@
+"""Speaker (dense captioning) head on MI355X: `GraphModule` (EdgeConv relation graph), `TopDownSceneCaptionModule`
+(top-down attention two-GRUCell captioner) and `SpeakerNet`, with the reference's constructors, `data_dict` keys and
+state-dict layout (reference: model/graph_module.py:21-324, model/caption_module.py:13-898, model/speaker.py:11-52;
+SURVEY.md rows A16, A17).
+
+Re-designed hot spots (results unchanged):
+  * `_query_locals` for ALL target proposals in one HIP launch (csrc/proposals.hip) instead of 128 sequential calls
+    with a device->host->device IoU round trip each (graph_module.py:229-238, 206-210; caption_module.py:821-824);
+  * EdgeConv without torch_geometric / scipy: edges = row-major non-zeros of the valid-node adjacency on the device,
+    message MLP as two library GEMMs, `index_add_` aggregation (graph_module.py:21-114, 273-277);
+  * decode step: embedding row lookup instead of one-hot x table matmul, and `map_feat(obj_feats)` hoisted out of the
+    time loop (caption_module.py:95-98, 108 recompute it every step);
+  * evaluation decodes all 128 target proposals of a scene as one batch instead of 128 x 31 sequential steps
+    (caption_module.py:710-749).
+Not implemented yet: the self-critical path (beam search, caption_module.py:136-349) -> `use_rl=True` raises.
+"""
+import ctypes as C
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check
+from .pointgroup_ops import _ptr, _stream
+
+
+# --------------------------------------------------------------------------------------- local context
+def query_locals_all(corners, object_masks, num_locals, include_self, overlay_threshold=0.5, query_mode="corner"):
+    """Local-context masks of every target proposal: (B,K,8,3), (B,K) -> (B,K,K); row t is what the reference's
+    `_query_locals(target_ids = t)` returns (graph_module.py:184-227 / caption_module.py:800-842)."""
+    B, K = object_masks.shape
+    corners = corners.contiguous().float()
+    masks = object_masks.contiguous().float()
+    dist = torch.empty((B, K, K), dtype=torch.float32, device=corners.device)
+    with torch.cuda.device(corners.device):
+        check(_lib.lib().d3_query_locals_dist(_ptr(corners), _ptr(masks), _ptr(dist), B, K, int(include_self),
+                                              float(overlay_threshold), int(query_mode == "center"), _stream()),
+              "query_locals_dist")
+    _, topk_ids = torch.topk(dist, num_locals, largest=False, dim=2)
+    return torch.zeros_like(dist).scatter_(2, topk_ids, 1)
+
+
+# ------------------------------------------------------------------------------------------- EdgeConv
+class EdgeConv(nn.Module):
+    """message = MLP([x_i, x_j - x_i]) summed at the target node i (graph_module.py:21-114).  With the reference's
+    edge_index = [adjacency row, adjacency column] and PyG's source->target flow, x_j = x[edge_index[0]] and
+    x_i = x[edge_index[1]], aggregation at edge_index[1].  Returns (aggregated nodes, per-edge messages)."""
+
+    def __init__(self, in_size, out_size, aggregation="add"):
+        super().__init__()
+        assert aggregation == "add"
+        self.in_size, self.out_size = in_size, out_size
+        self.map_edge = nn.Sequential(nn.Linear(2 * in_size, out_size), nn.ReLU(), nn.Linear(out_size, out_size))
+
+    def forward(self, x, edge_index):
+        x_j, x_i = x[edge_index[0]], x[edge_index[1]]
+        message = self.map_edge(torch.cat([x_i, x_j - x_i], dim=1))
+        out = torch.zeros(x.shape[0], self.out_size, dtype=x.dtype, device=x.device).index_add_(0, edge_index[1], message)
+        return out, message
+
+
+class GraphModule(nn.Module):
+    """(reference: model/graph_module.py:116-324)"""
+
+    def __init__(self, in_size, out_size, num_layers, num_proposals, feat_size, num_locals, query_mode="corner",
+                 graph_mode="edge_conv", return_edge=False, graph_aggr="add", return_orientation=False, num_bins=6,
+                 return_distance=False):
+        super().__init__()
+        if graph_mode != "edge_conv":
+            raise NotImplementedError("graph_mode edge_conv is the only one the reference instantiates (model/speaker.py:21-23)")
+        self.in_size, self.out_size = in_size, out_size
+        self.num_proposals, self.feat_size, self.num_locals, self.query_mode = num_proposals, feat_size, num_locals, query_mode
+        self.map_input = nn.Linear(in_size, out_size)
+        self.graph_mode = graph_mode
+        self.gc_layers = nn.ModuleList(EdgeConv(out_size, out_size, graph_aggr) for _ in range(num_layers))
+        self.return_edge, self.return_orientation, self.return_distance, self.num_bins = return_edge, return_orientation, return_distance, num_bins
+        if self.return_orientation:
+            self.edge_layer = EdgeConv(out_size, out_size, graph_aggr)
+            self.edge_predict = nn.Linear(out_size, num_bins + 1)
+
+    def forward(self, data_dict):
+        obj_feats = self.map_input(data_dict["proposal_feats_batched"])           # (B,K,out)
+        object_masks = data_dict["proposal_batch_mask"]
+        B, K, _ = obj_feats.shape
+        adjacent_mat = query_locals_all(data_dict["proposal_bbox_batched"], object_masks, self.num_locals,
+                                        include_self=False, query_mode=self.query_mode).type_as(object_masks)
+        new_obj_feats = obj_feats.new_zeros(B, K, self.feat_size)
+        edge_indices = obj_feats.new_zeros(B, 2, K * self.num_locals)
+        edge_feats = obj_feats.new_zeros(B, K, self.num_locals, self.out_size)
+        edge_preds = obj_feats.new_zeros(B, K * self.num_locals, self.num_bins + 1)
+        num_sources = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
+        num_targets = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
+        for b in range(B):
+            valid = object_masks[b] == 1
+            sub = adjacent_mat[b][valid][:, valid]
+            edge_index = torch.nonzero(sub, as_tuple=False).t().contiguous()        # row-major non-zeros == scipy COO order
+            x = obj_feats[b, valid]
+            node, message = x, None
+            for layer in self.gc_layers:
+                node, message = layer(node, edge_index)
+            if self.return_orientation and edge_index.shape[1] > 0:
+                n_src = int(torch.unique(edge_index[0]).numel())
+                n_tar = int(message.shape[0] / n_src)
+                n = n_src * n_tar
+                num_sources[b], num_targets[b] = n_src, n_tar
+                if n_tar <= self.num_locals and n_src <= K:
+                    edge_feats[b, :n_src, :n_tar] = message[:n].view(n_src, n_tar, self.out_size)
+                    edge_indices[b, :, :n] = edge_index[:, :n].to(edge_indices.dtype)
+                    _, last = self.edge_layer(node, edge_index)
+                    pred = self.edge_predict(last)
+                    if pred.shape[0] == n:      # the reference's assignment raises otherwise and the exception is swallowed (:291-308)
+                        edge_preds[b, :n] = pred
+            new_obj_feats[b, valid] = x + node                                      # skip connection (:311-312)
+        data_dict["bbox_feature"] = new_obj_feats
+        data_dict["adjacent_mat"] = adjacent_mat
+        data_dict["edge_index"] = edge_indices
+        data_dict["edge_feature"] = edge_feats
+        data_dict["num_edge_source"] = num_sources
+        data_dict["num_edge_target"] = num_targets
+        data_dict["edge_orientations"] = edge_preds[:, :, :-1]
+        data_dict["edge_distances"] = edge_preds[:, :, -1]
+        return data_dict
+
+
+# ------------------------------------------------------------------------------------------- captioner
+def _aabb_iou(c1, c2):
+    """lib/utils/bbox.py:247-271 on (...,8,3) tensors"""
+    mn1, mx1, mn2, mx2 = c1.min(-2)[0], c1.max(-2)[0], c2.min(-2)[0], c2.max(-2)[0]
+    inter = (torch.minimum(mx1, mx2) - torch.maximum(mn1, mn2)).clamp(min=0).prod(-1)
+    return inter / ((mx1 - mn1).prod(-1) + (mx2 - mn2).prod(-1) - inter + 1e-8)
+
+
+class TopDownSceneCaptionModule(nn.Module):
+    """(reference: model/caption_module.py:13-898)"""
+
+    def __init__(self, cfg, vocabulary, embeddings, emb_size=300, feat_size=128, hidden_size=512, num_proposals=256,
+                 num_locals=-1, query_mode="corner", use_relation=False, use_oracle=False):
+        super().__init__()
+        self.cfg, self.vocabulary = cfg, vocabulary
+        self.num_vocabs = len(vocabulary["word2idx"])
+        self.register_buffer("embeddings", torch.as_tensor(embeddings, dtype=torch.float32))
+        self.emb_size, self.feat_size, self.hidden_size = emb_size, feat_size, hidden_size
+        self.num_proposals, self.num_locals, self.query_mode = num_proposals, num_locals, query_mode
+        self.use_relation, self.use_oracle = use_relation, use_oracle
+        self.map_topdown = nn.Linear(hidden_size + feat_size + emb_size, emb_size)
+        self.recurrent_cell_1 = nn.GRUCell(input_size=emb_size, hidden_size=hidden_size)
+        self.map_feat = nn.Linear(feat_size, hidden_size, bias=False)
+        self.map_hidd = nn.Linear(hidden_size, hidden_size, bias=False)
+        self.attend = nn.Linear(hidden_size, 1, bias=False)
+        self.map_lang = nn.Linear(feat_size + hidden_size, emb_size)
+        self.recurrent_cell_2 = nn.GRUCell(input_size=emb_size, hidden_size=hidden_size)
+        self.classifier = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.ReLU(), nn.Linear(hidden_size, self.num_vocabs))
+
+    def forward(self, data_dict, use_tf=True, use_rl=False, is_eval=False, beam_opt={}):
+        if is_eval:
+            return self._forward_scene_batch(data_dict, beam_opt)
+        return self._forward_sample_batch(data_dict, use_tf, use_rl, beam_opt=beam_opt)
+
+    # ---- one decode step (:72-133); `feat_proj` = map_feat(obj_feats), hoisted by the drivers
+    def step(self, step_word_idx, hiddens, target_feat, obj_feats, object_masks, feat_proj=None):
+        hidden_1, hidden_2 = hiddens
+        step_input = self.embeddings[step_word_idx]                               # == one-hot @ embeddings (:95-98)
+        step_input = self.map_topdown(torch.cat([step_input, hidden_2, target_feat], dim=-1))
+        hidden_1 = self.recurrent_cell_1(step_input, hidden_1)
+        if feat_proj is None:
+            feat_proj = self.map_feat(obj_feats)
+        combined = torch.tanh(feat_proj + self.map_hidd(hidden_1).unsqueeze(1))
+        scores = self.attend(combined).masked_fill(object_masks == 0, 0)          # masked scores are 0, not -inf (:112-114)
+        masks = F.softmax(scores, dim=1)
+        attended = (obj_feats * masks).sum(1)
+        hidden_2 = self.recurrent_cell_2(self.map_lang(torch.cat([attended, hidden_1], dim=-1)), hidden_2)
+        step_output = self.classifier(hidden_2)
+        return step_output, step_output.clone(), (hidden_1, hidden_2), masks
+
+    @torch.no_grad()
+    def greedy_decode(self, target_feats, obj_feats, valid_masks, max_len):
+        """(:350-383) -> trimmed token / log-prob lists"""
+        N = target_feats.shape[0]
+        word = torch.full((N,), int(self.vocabulary["word2idx"]["sos"]), dtype=torch.long, device=target_feats.device)
+        hiddens = (target_feats.new_zeros(N, self.hidden_size), target_feats.new_zeros(N, self.hidden_size))
+        proj = self.map_feat(obj_feats)
+        outs, lps = [], []
+        for _ in range(max_len):
+            _, logits, hiddens, _ = self.step(word, hiddens, target_feats, obj_feats, valid_masks, proj)
+            lp, word = F.log_softmax(logits, dim=-1).max(-1)
+            outs.append(word.unsqueeze(1)); lps.append(lp.unsqueeze(1))
+        return self.trim_outputs(torch.cat(outs, 1).unsqueeze(1), torch.cat(lps, 1).unsqueeze(1))
+
+    def trim_outputs(self, raw_word_ids, raw_logprobs):
+        """cut every sequence at its first eos / pad_ (:385-414); if none occurs the LAST token is dropped, as the
+        reference's loop leaves t = max_len - 1"""
+        eos, pad = int(self.vocabulary["word2idx"]["eos"]), int(self.vocabulary["word2idx"]["pad_"])
+        ids, lps = raw_word_ids.cpu(), raw_logprobs.cpu()
+        N, topn, T = ids.shape
+        out_ids, out_lps = [], []
+        for n in range(N):
+            a, b = [], []
+            for s in range(topn):
+                stop = ((ids[n, s] == eos) | (ids[n, s] == pad)).nonzero()
+                t = int(stop[0]) if len(stop) else T - 1
+                a.append(raw_word_ids[n, s, :t]); b.append(raw_logprobs[n, s, :t])
+            out_ids.append(a); out_lps.append(b)
+        return out_ids, out_lps
+
+    def select_target(self, bbox_objness, bbox_center, bbox_corner, bbox_center_label, bbox_corner_label, ref_box_label,
+                      ref_box_corner_label, is_annotated, bbox_id_label=None):
+        """(:416-508) target proposal per description: best IoU with the referred box when annotated, else a random
+        non-empty proposal (python `random`, one draw per such sample, in sample order) assigned to its nearest GT."""
+        N, K, _ = bbox_center.shape
+        if self.use_oracle:
+            raise NotImplementedError("use_oracle (model.no_detection) is off in every shipped config")
+        ious = _aabb_iou(bbox_corner, ref_box_corner_label.unsqueeze(1))          # (N,K)
+        ann_ids = ious.argmax(1)
+        ann_ious = ious.gather(1, ann_ids.unsqueeze(1)).squeeze(1)
+        ann_lab = ref_box_label.argmax(-1)
+        target_ids, target_ious, labels = ann_ids.clone(), ann_ious.clone(), ann_lab.clone()
+        not_ann = (is_annotated != 1).nonzero().view(-1).tolist()
+        if not_ann:
+            objness = bbox_objness.cpu()
+            for n in not_ann:
+                valid = (objness[n] == 1).nonzero().view(-1)
+                pool = valid if len(valid) > 0 else torch.arange(K)
+                t = int(pool[random.randrange(len(pool))])                         # == random.choice(valid_ids)
+                d = ((bbox_center[n, t].unsqueeze(0) - bbox_center_label[n]) ** 2).sum(-1)   # nn_distance default (squared L2)
+                a = int(d.argmin())
+                target_ids[n], labels[n] = t, a
+                target_ious[n] = _aabb_iou(bbox_corner[n, t], bbox_corner_label[n, a])
+        return target_ids, target_ious, labels
+
+    def _query_locals(self, corners, target_ids, object_masks, include_self=True, overlay_threshold=0.5):
+        """(:800-842) -> (N,K) local-context mask of the given targets"""
+        allm = query_locals_all(corners, object_masks, self.num_locals, include_self, overlay_threshold, self.query_mode)
+        return allm.gather(1, target_ids.view(-1, 1, 1).expand(-1, 1, allm.shape[2])).squeeze(1)
+
+    def _add_relation_feat(self, rel_feats, adjacent_mat, obj_feats, target_ids):
+        """(:866-885) add the target's edge features onto its adjacency-row neighbours, in ascending slot order"""
+        N = rel_feats.shape[0]
+        rel = rel_feats.gather(1, target_ids.view(N, 1, 1, 1).expand(-1, 1, self.num_locals, self.feat_size)).squeeze(1)
+        rows = adjacent_mat.gather(1, target_ids.view(N, 1, 1).expand(-1, 1, self.num_proposals)).squeeze(1)
+        rel_masks = rows.unsqueeze(-1).expand(-1, -1, self.feat_size) == 1
+        return obj_feats + torch.zeros_like(obj_feats).masked_scatter(rel_masks, rel)
+
+    # ---- training driver (:510-687)
+    def _forward_sample_batch(self, data_dict, use_tf, use_rl, beam_opt={}):
+        if use_rl:
+            raise NotImplementedError("self-critical training (beam search, caption_module.py:136-349) is not built yet")
+        K, L = self.num_proposals, self.num_locals
+        word_ids = data_dict["lang_ids"].reshape(-1, self.cfg.data.max_spk_len + 2)
+        des_lens = data_dict["lang_len"].reshape(-1)
+        is_annotated = data_dict["annotated"].reshape(-1)
+        ref_labels = data_dict["ref_box_label"].reshape(-1, 128)
+        ref_corners = data_dict["ref_box_corner_label"].reshape(-1, 8, 3)
+        N = des_lens.shape[0]
+        Cn = N // data_dict["center_label"].shape[0]
+        rep = lambda t: t.unsqueeze(1).repeat(1, Cn, *([1] * (t.dim() - 1))).reshape(N, *t.shape[1:])
+        center_labels, corner_labels = rep(data_dict["center_label"]), rep(data_dict["gt_bbox"])
+        obj_feats, obj_centers = rep(data_dict["bbox_feature"]), rep(data_dict["proposal_center_batched"])
+        obj_corners, obj_masks = rep(data_dict["proposal_bbox_batched"]), rep(data_dict["proposal_batch_mask"])
+        num_words = int(des_lens.max())
+
+        target_ids, target_ious, labels = self.select_target(obj_masks, obj_centers, obj_corners, center_labels, corner_labels,
+                                                             ref_labels, ref_corners, is_annotated)
+        data_dict["assigned_bbox_id_labels"] = labels
+        target_feats = obj_feats.gather(1, target_ids.view(N, 1, 1).expand(-1, 1, self.feat_size)).squeeze(1)
+        if L == -1:
+            valid_masks = obj_masks
+        else:   # one launch for the B scenes, then pick the rows of the N targets
+            allm = query_locals_all(data_dict["proposal_bbox_batched"], data_dict["proposal_batch_mask"], L, True,
+                                    0.5, self.query_mode)
+            valid_masks = rep(allm).gather(1, target_ids.view(N, 1, 1).expand(-1, 1, K)).squeeze(1)
+        valid_masks = valid_masks.unsqueeze(-1)
+        if self.use_relation:
+            obj_feats = self._add_relation_feat(rep(data_dict["edge_feature"]), rep(data_dict["adjacent_mat"]), obj_feats, target_ids)
+
+        hiddens = (obj_feats.new_zeros(N, self.hidden_size), obj_feats.new_zeros(N, self.hidden_size))
+        proj = self.map_feat(obj_feats)
+        outputs, masks = [], []
+        word = word_ids[:, 0]
+        for step_id in range(1, max(num_words, 2)):
+            logits, _, hiddens, m = self.step(word, hiddens, target_feats, obj_feats, valid_masks, proj)
+            outputs.append(logits.unsqueeze(1)); masks.append(m)
+            word = word_ids[:, step_id] if use_tf else logits.argmax(-1)
+        data_dict["topdown_attn"] = torch.cat(masks, dim=-1)
+        good = target_ious > self.cfg.data.min_iou_threshold
+        data_dict["lang_cap"] = torch.cat(outputs, dim=1)
+        data_dict["pred_ious"] = target_ious[good].mean() if bool(good.any()) else obj_feats.new_zeros(())
+        data_dict["valid_masks"] = valid_masks
+        data_dict["good_bbox_masks"] = good
+        return data_dict
+
+    # ---- evaluation driver (:689-770): all K targets of every scene decoded as one batch of B*K
+    @torch.no_grad()
+    def _forward_scene_batch(self, data_dict, beam_opt={}):
+        K, L = self.num_proposals, self.num_locals
+        obj_feats, obj_masks = data_dict["bbox_feature"], data_dict["proposal_batch_mask"]
+        B = obj_feats.shape[0]
+        T = self.cfg.data.max_spk_len + 1
+        if L == -1:
+            valid = obj_masks.unsqueeze(1).expand(-1, K, -1)
+        else:
+            valid = query_locals_all(data_dict["proposal_bbox_batched"], obj_masks, L, True, 0.5, self.query_mode)
+        target_ids = torch.arange(K, device=obj_feats.device).repeat(B)
+        feats = obj_feats.unsqueeze(1).expand(-1, K, -1, -1).reshape(B * K, K, self.feat_size)
+        step_feats = feats
+        if self.use_relation:
+            rel = data_dict["edge_feature"].unsqueeze(1).expand(-1, K, -1, -1, -1).reshape(B * K, K, L, self.feat_size)
+            adj = data_dict["adjacent_mat"].unsqueeze(1).expand(-1, K, -1, -1).reshape(B * K, K, K)
+            step_feats = self._add_relation_feat(rel, adj, feats, target_ids)
+        # NOTE the reference builds prop_obj_feats with the relation features but then feeds the plain obj_feats to
+        # step() (caption_module.py:713,719,738): the relation features do not reach the evaluation decode.
+        del step_feats
+        target_feats = obj_feats.reshape(B * K, self.feat_size)
+        vm = valid.reshape(B * K, K, 1)
+        hiddens = (feats.new_zeros(B * K, self.hidden_size), feats.new_zeros(B * K, self.hidden_size))
+        proj = self.map_feat(obj_feats).unsqueeze(1).expand(-1, K, -1, -1).reshape(B * K, K, self.hidden_size)
+        word = torch.full((B * K,), int(self.vocabulary["word2idx"]["sos"]), dtype=torch.long, device=feats.device)
+        outs, attn = [], []
+        for _ in range(T):
+            logits, _, hiddens, m = self.step(word, hiddens, target_feats, feats, vm, proj)
+            word = logits.argmax(-1)
+            outs.append(word.unsqueeze(1)); attn.append(m)
+        data_dict["lang_cap"] = torch.cat(outs, 1).view(B, K, T)
+        data_dict["topdown_attn"] = torch.cat(attn, -1).view(B, K, K, T)
+        data_dict["valid_masks"] = valid
+        return data_dict
+
+
+class SpeakerNet(nn.Module):
+    """(reference: model/speaker.py:11-52)"""
+
+    def __init__(self, cfg, vocabulary, embeddings):
+        super().__init__()
+        self.cfg, self.vocabulary, self.embeddings = cfg, vocabulary, embeddings
+        if cfg.model.num_graph_steps > 0:
+            self.graph = GraphModule(cfg.model.m, 128, cfg.model.num_graph_steps, cfg.model.max_num_proposal, 128,
+                                     cfg.model.num_locals, return_edge=cfg.model.use_relation,
+                                     return_orientation=cfg.model.use_orientation)
+        if not cfg.model.no_captioning:
+            self.caption = TopDownSceneCaptionModule(cfg, vocabulary, embeddings, num_proposals=cfg.model.max_num_proposal,
+                                                     num_locals=cfg.model.num_locals, use_relation=cfg.model.use_relation,
+                                                     use_oracle=cfg.model.no_detection)
+
+    def forward(self, data_dict, use_tf=True, use_rl=False, is_eval=False, beam_opt={}):
+        if self.cfg.model.num_graph_steps > 0:
+            data_dict = self.graph(data_dict)
+        if not self.cfg.model.no_captioning:
+            data_dict = self.caption(data_dict, use_tf, use_rl, is_eval, beam_opt)
+        return data_dict

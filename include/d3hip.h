@@ -178,6 +178,13 @@ int d3_attn_fwd(const float *q, const float *k, const float *v, const float *bia
 int d3_attn_bwd(const float *q, const float *k, const float *v, const float *P, const float *dout, float *dS,
                 float *dq, float *dk, float *dv, int B, int h, int nq, int nk, int dkdim, int dvdim, void *stream);
 
+/* ---- proposal geometry (speaker / graph heads) ------------------------------------------ */
+/* Distance matrix of `_query_locals` (model/graph_module.py:184-227 == model/caption_module.py:800-842) for all
+ * target proposals at once: corners (B,K,8,3), masks (B,K) -> dist (B,K,K), dist[b,t,j] as the reference's pc_dist
+ * for target id t before its top-k (invalid / overlaid (IoU >= overlay_threshold) -> 1e30, self -> 0 or 1e30). */
+int d3_query_locals_dist(const float *corners, const float *masks, float *dist, int B, int K, int include_self,
+                         float overlay_threshold, int center_mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

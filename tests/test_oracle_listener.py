@@ -13,12 +13,12 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 
 def load():
-    from gen_listener_golden import golden_weights, make_cfg
+    from gen_listener_golden import golden_weights, make_cfg, listener_inputs
     from d3net_amd.listener import ListenerNet   # only for the key layout / shapes of the state dict (CPU, no kernels run)
     g = np.load(os.path.join(HERE, "golden", "listener_golden.npz"))
     net = ListenerNet(make_cfg())
     p = golden_weights(net.state_dict())
-    d = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in/")}
+    d = {k: torch.from_numpy(v) for k, v in listener_inputs().items()}
     return g, p, d, net
 
 
@@ -50,5 +50,5 @@ def test_oracle_matches_reference_golden_eval_and_train():
                 if k.startswith("train/grad/"):
                     n = k[len("train/grad/"):]
                     ref = g[k]
-                    got = pp[n].grad.numpy()
+                    got = pp[n].grad.numpy()[:32]
                     assert np.allclose(got, ref, rtol=1e-3, atol=1e-5 + 1e-3 * np.abs(ref).max()), (n, np.abs(got - ref).max())
