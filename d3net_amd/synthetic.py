@@ -144,3 +144,48 @@ def make_batch(scenes, device, mode=4):
     voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(batch["locs_scaled"].contiguous(), len(scenes), mode)
     batch["voxel_locs"], batch["p2v_map"], batch["v2p_map"] = voxel_locs, p2v_map, v2p_map
     return batch
+
+
+def make_vocabulary(size=3004):
+    """vocabulary dict in the reference's format (word2idx / idx2word with pad_, unk, sos, eos first)"""
+    words = ["pad_", "unk", "sos", "eos"] + ["w%d" % i for i in range(size - 4)]
+    return {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {i: w for i, w in enumerate(words)}}
+
+
+def add_language(batch, device, chunk=8, max_spk_len=30, max_lis_len=126, vocab=3004, seed=3):
+    """Synthetic ScanRefer-shaped language tensors for the speaker / listener heads:
+    random token ids in [4, V), caption length U[8, 30], description length U[10, 126], GloVe-like N(0,1) embeddings,
+    referred object uniform over the scene's GT boxes.  Keys as written by the reference loader
+    (lib/dataset/pipeline.py:282-318)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    B = batch["center_label"].shape[0]
+    centers, sizes = batch["center_label"].cpu().numpy(), batch["size_label"].cpu().numpy()
+    n_obj = batch["box_label_mask"].cpu().numpy().sum(1).astype(int)
+    sgn = np.array([[1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1], [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1]], np.float32)
+    gt_bbox = centers[:, :, None, :] + sgn[None, None] * sizes[:, :, None, :] / 2
+    T = max_lis_len + 2
+    lang_len = rng.integers(10, max_lis_len + 1, (B, chunk)).astype(np.int64)
+    spk_len = rng.integers(8, max_spk_len + 1, (B, chunk)).astype(np.int64)
+    lang_ids = np.zeros((B, chunk, max_spk_len + 2), np.int64)
+    ref_label = np.zeros((B, chunk, 128), np.float32)
+    ref_corner = np.zeros((B, chunk, 8, 3), np.float32)
+    cat = np.zeros((B, chunk), np.int64)
+    for b in range(B):
+        for c in range(chunk):
+            n = spk_len[b, c] + 2
+            lang_ids[b, c, 0] = 2; lang_ids[b, c, 1:n - 1] = rng.integers(4, vocab, n - 2); lang_ids[b, c, n - 1] = 3
+            o = rng.integers(0, max(n_obj[b], 1))
+            ref_label[b, c, o] = 1; ref_corner[b, c] = gt_bbox[b, o]
+            cat[b, c] = int(batch["sem_cls_label"][b, o]) % 18
+    out = dict(lang_feat=rng.standard_normal((B, chunk, T, 300)).astype(np.float32), lang_len=lang_len, lang_ids=lang_ids,
+               annotated=np.ones((B, chunk), np.int64), ref_box_label=ref_label, ref_box_corner_label=ref_corner, object_cat=cat,
+               gt_bbox=gt_bbox.astype(np.float32), istrain=np.ones(B, np.int64),
+               scene_object_rotations=np.tile(np.eye(3, dtype=np.float32), (B, 128, 1, 1)),
+               scene_object_rotation_masks=batch["box_label_mask"].cpu().numpy().astype(np.float32))
+    # the speaker's lang_len is the caption length (+2), the listener's the description length: the reference feeds
+    # two different batches; a single synthetic batch carries the caption lengths under `lang_len` for mode 1
+    for k, v in out.items():
+        batch[k] = torch.from_numpy(v).to(device)
+    batch["spk_lang_len"] = torch.from_numpy(spk_len + 2).to(device)
+    return batch

@@ -76,6 +76,20 @@ def step_inputs(seed=11):
                 obj=f(8, K, 128), mask=(rng.random((8, K, 1)) > 0.5).astype(np.float32))
 
 
+def orientation_inputs(seed=13, B=2, E=60):
+    rng = np.random.default_rng(seed)
+    def rotz(a):
+        c, s_ = np.cos(a), np.sin(a)
+        return np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    rots = np.stack([np.stack([rotz(rng.uniform(0, np.pi)) for _ in range(128)]) for _ in range(B)])
+    ei = np.zeros((B, 2, K * L), np.float32)
+    ei[:, :, :E] = rng.integers(0, K, (B, 2, E))
+    return dict(object_assignment=rng.integers(0, 128, (B, K)).astype(np.int64), edge_index=ei,
+                edge_orientations=rng.standard_normal((B, K * L, 6)).astype(np.float32),
+                num_edge_source=np.array([6, 5], np.int64), num_edge_target=np.array([10, 10], np.int64),
+                scene_object_rotations=rots, scene_object_rotation_masks=(rng.random((B, 128)) > 0.3).astype(np.float32))
+
+
 def main():
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
@@ -121,6 +135,14 @@ def main():
     out.update({"xe/lang_cap": logits.detach().numpy(), "xe/topdown_attn": dd["topdown_attn"].detach().numpy(),
                 "xe/valid_masks": dd["valid_masks"].numpy(), "xe/assigned": dd["assigned_bbox_id_labels"].numpy(),
                 "xe/pred_ious": np.float32(dd["pred_ious"].detach()), "xe/good": dd["good_bbox_masks"].numpy(), "xe/loss": np.float32(loss.detach())})
+    # the reference's own caption loss (lib/captioning/loss_helper.py:177-224) and orientation loss (:244-307)
+    from lib.captioning.loss_helper import compute_cap_loss, compute_node_orientation_loss
+    dd["lang_len"], dd["lang_ids"] = d["lang_len"], d["lang_ids"]
+    _, dd = compute_cap_loss(dd, {"use_rl": False, "max_len": MAXLEN + 2})
+    out["xe/cap_loss"], out["xe/cap_acc"] = np.float32(dd["cap_loss"].detach()), np.float32(dd["cap_acc"])
+    oi = orientation_inputs()
+    ol, oa = compute_node_orientation_loss({k: torch.from_numpy(v) for k, v in oi.items()}, 6)
+    out["ori/loss"], out["ori/acc"] = np.float32(ol), np.float32(oa)
     for n in ("map_topdown.weight", "recurrent_cell_1.weight_hh", "map_feat.weight", "attend.weight", "map_lang.bias",
               "recurrent_cell_2.weight_ih", "classifier.2.weight"):
         out["xe/grad/" + n] = dict(cap.named_parameters())[n].grad.numpy()[:32].copy()   # first 32 rows only
