@@ -35,10 +35,13 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float *__restrict_
 // running = (1-momentum)*running + momentum*stat, with the UNBIASED variance (M/(M-1))
 __global__ void bn_finalize_kernel(const double *acc, int nblocks, int M, int C, float *mean, float *var,
                                    float *running_mean, float *running_var, float momentum) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per channel: lanes stride over the workgroup partials, fp64 wave reduction (fixed order: deterministic)
+    const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double sa = 0., sb = 0.;
-    for (int b = 0; b < nblocks; b++) { sa += acc[(size_t)b * 2 * C + c]; sb += acc[(size_t)b * 2 * C + C + c]; }
+    for (int b = lane; b < nblocks; b += 64) { sa += acc[(size_t)b * 2 * C + c]; sb += acc[(size_t)b * 2 * C + C + c]; }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+    if (lane != 0) return;
     const double m = sa / (double)M;
     double v = sb / (double)M - m * m;
     if (v < 0.) v = 0.;
@@ -111,10 +114,12 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(const float *__rest
 // adds the partials: sums[0..C) = sum g, sums[C..2C) = sum g*xhat (fp64), and writes dbeta / dgamma
 __global__ void bn_bwd_params_kernel(const double *acc, int nblocks, int C, double *sums, float *dgamma,
                                      float *dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double sa = 0., sb = 0.;
-    for (int b = 0; b < nblocks; b++) { sa += acc[(size_t)b * 2 * C + c]; sb += acc[(size_t)b * 2 * C + C + c]; }
+    for (int b = lane; b < nblocks; b += 64) { sa += acc[(size_t)b * 2 * C + c]; sb += acc[(size_t)b * 2 * C + C + c]; }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+    if (lane != 0) return;
     sums[c] = sa; sums[C + c] = sb;
     dbeta[c] = (float)sa;
     dgamma[c] = (float)sb;
@@ -157,7 +162,7 @@ extern "C" int d3_bn_stats(const float *x, int M, int C, float *mean, float *var
     hipStream_t s = d3_stream(stream);
     const int nb = bn_blocks(M, C);
     bn_stats_kernel<<<nb, BN_T, 0, s>>>(x, M, C, (double *)ws);
-    bn_finalize_kernel<<<(C + 63) / 64, 64, 0, s>>>((const double *)ws, nb, M, C, mean, var, running_mean, running_var,
+    bn_finalize_kernel<<<(C + 3) / 4, 256, 0, s>>>((const double *)ws, nb, M, C, mean, var, running_mean, running_var,
                                                   momentum);
     D3_LAUNCH_CHECK();
     return 0;
@@ -189,7 +194,7 @@ extern "C" int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean
     const int nb = bn_blocks(M, C);
     double *partials = (double *)ws, *sums = partials + (size_t)BN_MAXBLK * 2 * C;
     bn_bwd_reduce_kernel<<<nb, BN_T, 0, s>>>(x, dy, mean, var, gamma, beta, M, C, eps, relu, partials);
-    bn_bwd_params_kernel<<<(C + 63) / 64, 64, 0, s>>>(partials, nb, C, sums, dgamma, dbeta);
+    bn_bwd_params_kernel<<<(C + 3) / 4, 256, 0, s>>>(partials, nb, C, sums, dgamma, dbeta);
     long long total = (long long)M * C;
     bn_bwd_apply_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, dy, mean, var, gamma, beta, sums, dx, total, M, C,
                                                                  eps, relu);

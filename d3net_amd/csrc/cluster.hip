@@ -43,7 +43,8 @@ struct ClWs {
     int *seeds;    // n  seed of cluster c
     int *par;      // n  BFS: queue position of the first discoverer
     int *queue;    // n  BFS queues (cluster c at koff[seed])
-    int *fcnt;     // n  BFS: children per frontier entry / scanned
+    int *fcnt;     // n  BFS: list start of every queued node
+    int *qln;      // n  BFS: list length of every queued node
     int *scalars;  // [0]=changed [1]=nCluster [2]=sumNPoint
     void *temp; size_t temp_bytes;
 };
@@ -54,6 +55,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
     w.parent = c.take<int>(nn); w.lab = c.take<int>(nn); w.own = c.take<int>(nn); w.sizes = c.take<int>(nn);
     w.flag = c.take<int>(nn); w.cid = c.take<int>(nn); w.ksz = c.take<int>(nn); w.koff = c.take<int>(nn);
     w.seeds = c.take<int>(nn); w.par = c.take<int>(nn); w.queue = c.take<int>(nn); w.fcnt = c.take<int>(nn);
+    w.qln = c.take<int>(nn);
     w.scalars = c.take<int>(64);
     w.temp_bytes = d3_scan_temp_bytes(n);
     w.temp = c.take<char>(w.temp_bytes);
@@ -62,7 +64,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
 extern "C" size_t d3_bfs_cluster_ws_bytes(int n) {
     D3Carver c(nullptr, 0);
     size_t nn = (size_t)(n > 0 ? n : 1);
-    for (int i = 0; i < 12; i++) c.take<int>(nn);
+    for (int i = 0; i < 13; i++) c.take<int>(nn);
     c.take<int>(64);
     c.take<char>(d3_scan_temp_bytes(n));
     return c.off + 256;
@@ -102,15 +104,15 @@ __device__ __forceinline__ void cl_union(int *parent, int a, int b) {
     }
 }
 
-// phase 1a: one wave per node, lanes over its list
+// phase 1a: one thread per node walks its (complete, hence short) list
 __global__ __launch_bounds__(256) void cl_union_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                       const int *__restrict__ start_len, int n, int *parent) {
-    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     if (ln >= CL_CAP) return;
     const int si = sem[i];
-    for (int e = d3_lane(); e < ln; e += 64) {
+    for (int e = 0; e < ln; e++) {
         const int j = idx[st + e];
         if (j == i || sem[j] != si) continue;
         if (start_len[j * 2 + 1] >= CL_CAP) continue;
@@ -158,11 +160,16 @@ __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *
     if (i >= n) return;   // tail lanes simply drop out of the ballots below
     int o = cl_chase(lab, lab[root[i]]);
     own[i] = o;
-    // neighbouring points mostly share an owner: one atomic per wave when they all agree
-    const int o0 = __shfl(o, 0);
-    const unsigned long long act = __ballot(1);
-    if (__ballot(o == o0) == act) { if ((threadIdx.x & 63) == 0) atomicAdd(&sizes[o0], (int)__popcll(act)); }
-    else atomicAdd(&sizes[o], 1);
+    // a wave holds only a few distinct owners: one atomic per distinct owner (leader = lowest lane of each group)
+    unsigned long long todo = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const int ol = __shfl(o, leader);
+        const unsigned long long grp = __ballot(o == ol) & todo;
+        if (lane == leader) atomicAdd(&sizes[ol], (int)__popcll(grp));
+        todo &= ~grp;
+    }
 }
 __global__ void cl_keep_kernel(const int *sizes, int *flag, int *ksz, int n, int threshold) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,7 +196,7 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
     cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, n, w.scalars);
-    cl_union_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
+    cl_union_kernel<<<nb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
     for (int it = 0; it < n + 2; it++) {
@@ -250,7 +257,11 @@ __device__ __forceinline__ int cl_blk_scan(int v, int *wsum, int &total) {
 // the owning frontier entry), so a level of F nodes / E edges costs ~E/1024 iterations whatever the list
 // lengths are.  Flat edge order == (parent queue position, list position) == the FIFO discovery order, so
 // pass C is a plain ordered compaction of the "first discoverer" edges.
+// The level loop is latency bound (a 4 m floor is ~200 levels deep), so dependent global round trips are cut:
+// the queue stores (node, list start, list length) records written when a node is appended; a component has a
+// single semantic label; pass A keeps its edge candidates in registers for pass C (frontiers up to 4096 edges).
 #define CL_FCH 1024
+#define CL_KEEP 4     // edge candidates kept per thread between pass A and pass C
 __global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__restrict__ sem,
                                                                const int *__restrict__ idx,
                                                                const int *__restrict__ start_len,
@@ -258,72 +269,102 @@ __global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__res
                                                                const int *__restrict__ seeds,
                                                                const int *__restrict__ koff,
                                                                const int *__restrict__ sizes, int *par, int *queue,
-                                                               int *fcnt, int *cluster_idxs) {
-    __shared__ int s_st[CL_FCH], s_sem[CL_FCH], s_off[CL_FCH + 1], s_w[24];
-    (void)fcnt;
+                                                               int *qst_all, int *qln_all, int *cluster_idxs) {
+    __shared__ int s_st[CL_FCH], s_off[CL_FCH + 1], s_w[24];
     const int c = blockIdx.x;
     const int s = seeds[c];
     const int base = koff[s];
     const int size = sizes[s];
-    int *q = queue + base;
+    (void)sem;
+    int *q = queue + base, *qst = qst_all + base, *qln = qln_all + base;
     const int tid = threadIdx.x;
-    if (tid == 0) { st_dev(&q[0], s); st_dev(&par[s], -1); }
+    if (tid == 0) { st_dev(&q[0], s); st_dev(&qst[0], start_len[s * 2]); st_dev(&qln[0], start_len[s * 2 + 1]); st_dev(&par[s], -1); }
     __syncthreads();
     int lo = 0, hi = 1;
     while (lo < hi && hi <= size) {
         const bool single = (hi - lo) <= CL_FCH;
         int E = 0;
+        int keep_j[CL_KEEP], keep_gp[CL_KEEP];
+        int2 keep_sl[CL_KEEP];
+#pragma unroll
+        for (int r = 0; r < CL_KEEP; r++) { keep_j[r] = -1; keep_gp[r] = 0; keep_sl[r] = make_int2(0, 0); }
         // ---- pass A: first discoverer of every neighbour = smallest parent queue position
         for (int fb = lo; fb < hi; fb += CL_FCH) {
             const int nf = min(CL_FCH, hi - fb);
             int ln = 0;
-            if (tid < nf) {
-                const int u = ld_dev(&q[fb + tid]);
-                s_st[tid] = start_len[u * 2]; ln = start_len[u * 2 + 1]; s_sem[tid] = sem[u];
-            }
+            if (tid < nf) { s_st[tid] = ld_dev(&qst[fb + tid]); ln = ld_dev(&qln[fb + tid]); }
             const int off = cl_blk_scan(ln, s_w, E);
             if (tid < nf) s_off[tid] = off;
             if (tid == 0) s_off[nf] = E;
             __syncthreads();
-            for (int e = tid; e < E; e += CL_BFS_THREADS) {
-                int a = 0, b = nf;  // largest f with s_off[f] <= e
+            const bool keep = single && E <= CL_KEEP * CL_BFS_THREADS;
+#pragma unroll
+            for (int r = 0; r < CL_KEEP; r++) {
+                const int e = tid + r * CL_BFS_THREADS;
+                if (e < E) {
+                    int a = 0, b = nf;  // largest f with s_off[f] <= e
+                    while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
+                    const int j = idx[s_st[a] + e - s_off[a]];
+                    if (own[j] == s) {   // owned by this seed => same semantic label (a component has one label)
+                        const int gp = fb + a;
+                        if (ld_dev(&par[j]) > gp) atomicMin(&par[j], gp);
+                        if (keep) { keep_j[r] = j; keep_gp[r] = gp; keep_sl[r] = *(const int2 *)&start_len[j * 2]; }
+                    }
+                }
+            }
+            for (int e = tid + CL_KEEP * CL_BFS_THREADS; e < E; e += CL_BFS_THREADS) {
+                int a = 0, b = nf;
                 while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
                 const int j = idx[s_st[a] + e - s_off[a]];
-                if (sem[j] == s_sem[a] && own[j] == s) { const int gp = fb + a; if (ld_dev(&par[j]) > gp) atomicMin(&par[j], gp); }
+                if (own[j] == s) { const int gp = fb + a; if (ld_dev(&par[j]) > gp) atomicMin(&par[j], gp); }
             }
             __syncthreads();
         }
         // ---- pass C: children in flat edge order
         int tail = hi;
-        for (int fb = lo; fb < hi; fb += CL_FCH) {
-            const int nf = min(CL_FCH, hi - fb);
-            if (!single) {  // several frontier chunks: rebuild this chunk's LDS tables
-                int ln = 0;
-                if (tid < nf) {
-                    const int u = ld_dev(&q[fb + tid]);
-                    s_st[tid] = start_len[u * 2]; ln = start_len[u * 2 + 1]; s_sem[tid] = sem[u];
-                }
-                const int off = cl_blk_scan(ln, s_w, E);
-                if (tid < nf) s_off[tid] = off;
-                if (tid == 0) s_off[nf] = E;
-                __syncthreads();
-            }
-            for (int e0 = 0; e0 < E; e0 += CL_BFS_THREADS) {
-                const int e = e0 + tid;
-                int child = 0, j = 0;
-                if (e < E) {
-                    int a = 0, b = nf;
-                    while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
-                    j = idx[s_st[a] + e - s_off[a]];
-                    child = (sem[j] == s_sem[a] && own[j] == s && ld_dev(&par[j]) == fb + a) ? 1 : 0;
-                }
+        if (single && E <= CL_KEEP * CL_BFS_THREADS) {
+#pragma unroll
+            for (int r = 0; r < CL_KEEP; r++) {
+                if (r * CL_BFS_THREADS >= E) break;   // uniform
+                const int j = keep_j[r];
+                int child = 0, cst = 0, cln = 0;
+                if (j >= 0 && ld_dev(&par[j]) == keep_gp[r]) { child = 1; cst = keep_sl[r].x; cln = keep_sl[r].y; }
                 if (!__syncthreads_or(child)) continue;
                 int tot;
                 const int pos = cl_blk_scan(child, s_w, tot);
-                if (child && tail + pos < size) st_dev(&q[tail + pos], j);
+                if (child && tail + pos < size) { st_dev(&q[tail + pos], j); st_dev(&qst[tail + pos], cst); st_dev(&qln[tail + pos], cln); }
                 tail += tot;
             }
             __syncthreads();
+        } else {
+            for (int fb = lo; fb < hi; fb += CL_FCH) {
+                const int nf = min(CL_FCH, hi - fb);
+                if (!single) {  // several frontier chunks: rebuild this chunk's LDS tables
+                    int ln = 0;
+                    if (tid < nf) { s_st[tid] = ld_dev(&qst[fb + tid]); ln = ld_dev(&qln[fb + tid]); }
+                    const int off = cl_blk_scan(ln, s_w, E);
+                    if (tid < nf) s_off[tid] = off;
+                    if (tid == 0) s_off[nf] = E;
+                    __syncthreads();
+                }
+                for (int e0 = 0; e0 < E; e0 += CL_BFS_THREADS) {
+                    const int e = e0 + tid;
+                    int child = 0, j = 0, cst = 0, cln = 0;
+                    if (e < E) {
+                        int a = 0, b = nf;
+                        while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
+                        j = idx[s_st[a] + e - s_off[a]];
+                        child = (own[j] == s && ld_dev(&par[j]) == fb + a) ? 1 : 0;
+                        if (child) { cst = start_len[j * 2]; cln = start_len[j * 2 + 1]; }
+                    }
+                    if (!__syncthreads_or(child)) continue;
+                    int tot;
+                    const int pos = cl_blk_scan(child, s_w, tot);
+                    if (child && tail + pos < size) { st_dev(&q[tail + pos], j); st_dev(&qst[tail + pos], cst); st_dev(&qln[tail + pos], cln); }
+                    tail += tot;
+                }
+                __syncthreads();
+            }
         }
         lo = hi; hi = tail;
     }
@@ -345,7 +386,7 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
     cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
     if (nCluster > 0)
         cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
-                                                         w.koff, w.sizes, w.par, w.queue, w.fcnt, cluster_idxs);
+                                                         w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs);
     D3_LAUNCH_CHECK();
     return 0;
 }

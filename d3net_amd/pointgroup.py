@@ -15,6 +15,7 @@ Host RNG draws the reference makes (`torch.rand(3)` x2 at :161, `torch.randperm(
 from the same CPU generator in the same order, so a seeded run is comparable with the oracle.
 """
 import functools
+import threading
 
 import numpy as np
 import torch
@@ -71,6 +72,14 @@ class PointGroup(nn.Module):
 
         # test hooks: override predictions before clustering ("teacher" switch of SURVEY.md 8(d))
         self.teacher = False
+        self.concurrent_clustering = True
+        self._streams = {}
+
+    def _side_stream(self, device):
+        key = (device.index, threading.get_ident())
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
     # ------------------------------------------------------------------------------------- helpers
     @staticmethod
@@ -207,21 +216,43 @@ class PointGroup(nn.Module):
                 pt_offsets_ = cluster_offsets[object_idxs]
                 semantic_preds_ = semantic_preds[object_idxs].int().contiguous()
 
-                # shifted coordinates (:296-299)
-                idx_shift, start_len_shift = pointgroup_ops.ballquery_batch_p(
-                    (coords_ + pt_offsets_).detach().contiguous(), batch_idxs_, batch_offsets_, self.cluster_radius,
-                    self.cluster_shift_meanActive)
-                proposals_idx_shift, proposals_offset_shift = pointgroup_ops.bfs_cluster(
-                    semantic_preds_, idx_shift, start_len_shift, self.cluster_npoint_thre)
-                proposals_idx_shift[:, 1] = object_idxs[proposals_idx_shift[:, 1].long()].int()
-                proposals_batchId_shift_all = batch_idxs[proposals_idx_shift[:, 1].long()].int()
-                # original coordinates (:304-307)
-                idx, start_len = pointgroup_ops.ballquery_batch_p(coords_, batch_idxs_, batch_offsets_,
-                                                                  self.cluster_radius, self.cluster_meanActive)
-                proposals_idx, proposals_offset = pointgroup_ops.bfs_cluster(semantic_preds_, idx, start_len,
-                                                                             self.cluster_npoint_thre)
-                proposals_idx[:, 1] = object_idxs[proposals_idx[:, 1].long()].int()
-                proposals_batchId_all = batch_idxs[proposals_idx[:, 1].long()].int()
+                def cluster_branch(xyz, mean_active):
+                    idx_, start_len_ = pointgroup_ops.ballquery_batch_p(xyz, batch_idxs_, batch_offsets_, self.cluster_radius,
+                                                                        mean_active)
+                    p_idx, p_off = pointgroup_ops.bfs_cluster(semantic_preds_, idx_, start_len_, self.cluster_npoint_thre)
+                    p_idx[:, 1] = object_idxs[p_idx[:, 1].long()].int()
+                    return p_idx, p_off, batch_idxs[p_idx[:, 1].long()].int()
+
+                # The two clusterings (shifted :296-299, original :304-307) are independent until the merge: the shifted
+                # one runs on a side stream from a helper thread (ctypes releases the GIL inside libd3hip), so its count
+                # phases, which synchronise their own stream, overlap the other branch instead of serialising with it.
+                shifted_xyz = (coords_ + pt_offsets_).detach().contiguous()
+                cur = torch.cuda.current_stream()
+                if self.concurrent_clustering:
+                    side = self._side_stream(coords_.device)
+                    side.wait_stream(cur)
+                    box = {}
+
+                    def work():
+                        try:
+                            with torch.cuda.device(coords_.device), torch.cuda.stream(side):
+                                box["out"] = cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
+                        except BaseException as e:   # re-raised on the main thread
+                            box["err"] = e
+                    th = threading.Thread(target=work)
+                    th.start()
+                    proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive)
+                    th.join()
+                    if "err" in box:
+                        raise box["err"]
+                    cur.wait_stream(side)
+                    proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = box["out"]
+                    for t in box["out"]:
+                        t.record_stream(cur)
+                else:
+                    proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = cluster_branch(
+                        shifted_xyz, self.cluster_shift_meanActive)
+                    proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive)
                 # merge (:312-316), including the reference's one-element-short batch-id concat
                 proposals_idx_shift[:, 0] += (proposals_offset.size(0) - 1)
                 proposals_offset_shift += proposals_offset[-1]

@@ -13,6 +13,7 @@ Differences from the reference, all at the edges:
 There is no CPU implementation here: without a GPU these functions raise.
 """
 import ctypes as C
+import threading
 
 import torch
 from torch.autograd import Function
@@ -33,7 +34,8 @@ def _ptr(t):
 
 def _workspace(nbytes, device, tag):
     """A cached, growing device scratch buffer per (device, tag)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    # per host thread: the two clustering branches of PointGroup.forward run concurrently on their own streams
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, threading.get_ident())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
