@@ -119,6 +119,10 @@ __global__ void spconv_wgrad_exact_kernel(const float *__restrict__ x, const int
 #define CV_LD 40      // LDS row stride in bf16 (80 B: conflict-free ds_read_b64 fragments)
 #define CV_MAXK 27
 
+// Software-pipelined main loop: the (kernel offset, 32-channel chunk) stages that the tile actually uses are walked
+// with double-buffered LDS tiles; the global loads of stage s+1 (gathered rows + weight chunk) are issued into
+// registers before the MFMAs of stage s and written to the other LDS buffer afterwards -- one barrier per stage, and
+// the gather latency hides behind the matrix work and the LDS reads of the current stage.
 template <int NT, bool TRANSW>
 __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__restrict__ x,
                                                              const int *__restrict__ tbl,
@@ -126,79 +130,115 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
                                                              int Mout, int K, int Cin, int Cout, int flipk, int kper) {
     constexpr int CoutP = NT * 16;  // Cout rounded up to the MFMA tile; columns >= Cout are zero / not stored
     __shared__ int tblS[CV_BM * CV_MAXK];
-    __shared__ __attribute__((aligned(16))) unsigned short As[CV_BM * CV_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bt[NT * 16 * CV_LD];
+    __shared__ unsigned int kmaskS;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][CV_BM * CV_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bt[2][NT * 16 * CV_LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * CV_BM;
-    // kernel-map rows of this tile, coalesced
-    for (int e = t; e < CV_BM * K; e += 256) {
-        const int r = e / K, k = e % K;
-        const int u = row0 + r;
-        tblS[e] = (u < Mout) ? (tbl ? tbl[(long long)u * K + k] : u) : -1;
+    if (t == 0) kmaskS = 0u;
+    __syncthreads();
+    // kernel-map rows of this tile, coalesced; and the set of offsets at least one row of the tile uses
+    {
+        unsigned int bits = 0u;
+        for (int e = t; e < CV_BM * K; e += 256) {
+            const int r = e / K, k = e % K;
+            const int u = row0 + r;
+            const int v = (u < Mout) ? (tbl ? tbl[(long long)u * K + k] : u) : -1;
+            tblS[e] = v;
+            if (v >= 0) bits |= 1u << k;
+        }
+        if (bits) atomicOr(&kmaskS, bits);
     }
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    const int arow = t >> 2, aq = t & 3;  // staging role: row, 8-channel group
-    const bool cin4 = (Cin & 3) == 0;
-    // gridDim.y > 1: the K offsets are split over workgroups (small Mout: the serial offset loop is pure
+    // gridDim.y > 1: the K offsets are split over workgroups (few-row levels: the serial offset loop is pure
     // latency) and the partial sums are added atomically into a zero-filled output
     const int k_begin = blockIdx.y * kper, k_end = min(K, k_begin + kper);
-    for (int k = k_begin; k < k_end; k++) {
+    unsigned int kmask = kmaskS;
+    kmask &= (k_end >= 32 ? 0xFFFFFFFFu : ((1u << k_end) - 1u)) & ~((1u << k_begin) - 1u);
+    const int arow = t >> 2, aq = t & 3;  // staging role: row, 8-channel group
+    const bool cin4 = (Cin & 3) == 0;
+
+    float va[8];          // staged A values of the next stage
+    float vb[NT][2];      // staged B values of the next stage
+    auto load_stage = [&](int k, int c0) {
         const int idx = tblS[arow * K + k];
-        if (!__syncthreads_or(idx >= 0)) continue;  // no row of the tile uses this offset
+#pragma unroll
+        for (int j = 0; j < 8; j++) va[j] = 0.f;
+        const int c = c0 + aq * 8;
+        if (idx >= 0) {
+            const float *src = x + (long long)idx * Cin + c;
+            if (cin4) {
+                if (c + 4 <= Cin) { float4 f = *(const float4 *)src; va[0] = f.x; va[1] = f.y; va[2] = f.z; va[3] = f.w; }
+                if (c + 8 <= Cin) { float4 f = *(const float4 *)(src + 4); va[4] = f.x; va[5] = f.y; va[6] = f.z; va[7] = f.w; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c + 2 * j + 2 <= Cin) { float2 f = *(const float2 *)(src + 2 * j); va[2 * j] = f.x; va[2 * j + 1] = f.y; }
+            }
+        }
         const int wk = flipk ? (K - 1 - k) : k;
         const float *Wk = W + (long long)wk * Cin * Cout;
-        for (int c0 = 0; c0 < Cin; c0 += CV_KC) {
-            // ---- stage A: 64 gathered rows x 32 channels -> bf16
-            {
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = 0.f;
-                const int c = c0 + aq * 8;
-                if (idx >= 0) {
-                    const float *src = x + (long long)idx * Cin + c;
-                    if (cin4) {
-                        if (c + 4 <= Cin) { float4 f = *(const float4 *)src; v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
-                        if (c + 8 <= Cin) { float4 f = *(const float4 *)(src + 4); v[4] = f.x; v[5] = f.y; v[6] = f.z; v[7] = f.w; }
-                    } else {
+        for (int i = 0; i < NT; i++) {
+            const int e = t + i * 256;       // 16 * CoutP == NT * 256 elements, one (n, k-pair) each
+            float w0 = 0.f, w1 = 0.f;
+            if (TRANSW) {  // W laid out (K, Cout, Cin): contiguous along the reduction index
+                const int n = e >> 4, kp = e & 15, cc = c0 + 2 * kp;
+                if (n < Cout && cc + 2 <= Cin) { float2 f = *(const float2 *)(Wk + (long long)n * Cin + cc); w0 = f.x; w1 = f.y; }
+            } else {       // W laid out (K, Cin, Cout): coalesced along n
+                const int kp = e / CoutP, n = e % CoutP, cc = c0 + 2 * kp;
+                if (n < Cout && cc < Cin) w0 = Wk[(long long)cc * Cout + n];
+                if (n < Cout && cc + 1 < Cin) w1 = Wk[(long long)(cc + 1) * Cout + n];
+            }
+            vb[i][0] = w0; vb[i][1] = w1;
+        }
+    };
+    auto store_stage = [&](int buf) {
+        uint4 pk;
+        pk.x = pack2bf(va[0], va[1]); pk.y = pack2bf(va[2], va[3]); pk.z = pack2bf(va[4], va[5]); pk.w = pack2bf(va[6], va[7]);
+        *(uint4 *)&As[buf][arow * CV_LD + aq * 8] = pk;
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (c + 2 * j + 2 <= Cin) { float2 f = *(const float2 *)(src + 2 * j); v[2 * j] = f.x; v[2 * j + 1] = f.y; }
-                    }
-                }
-                uint4 pk;
-                pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-                *(uint4 *)&As[arow * CV_LD + aq * 8] = pk;
+        for (int i = 0; i < NT; i++) {
+            const int e = t + i * 256;
+            int n, kp;
+            if (TRANSW) { n = e >> 4; kp = e & 15; } else { kp = e / CoutP; n = e % CoutP; }
+            *(unsigned int *)&Bt[buf][n * CV_LD + 2 * kp] = pack2bf(vb[i][0], vb[i][1]);
+        }
+    };
+
+    if (kmask != 0u) {
+        int k = (int)__builtin_ctz(kmask), c0 = 0;
+        unsigned int rest = kmask & (kmask - 1u);
+        load_stage(k, c0);
+        store_stage(0);
+        __syncthreads();
+        int buf = 0;
+        for (;;) {
+            // next stage
+            int nk = k, nc0 = c0 + CV_KC;
+            bool more = true;
+            if (nc0 >= Cin) {
+                nc0 = 0;
+                if (rest == 0u) more = false;
+                else { nk = (int)__builtin_ctz(rest); rest &= rest - 1u; }
             }
-            // ---- stage B: W chunk (32 x Cout) -> Bt[n][kk] bf16, two kk per 32-bit store
-            for (int e = t; e < 16 * CoutP; e += 256) {
-                int n, kp;
-                float w0 = 0.f, w1 = 0.f;
-                if (TRANSW) {  // W laid out (K, Cout, Cin): contiguous along the reduction index
-                    n = e >> 4; kp = e & 15;
-                    const int c = c0 + 2 * kp;
-                    if (n < Cout && c + 2 <= Cin) { float2 f = *(const float2 *)(Wk + (long long)n * Cin + c); w0 = f.x; w1 = f.y; }
-                } else {       // W laid out (K, Cin, Cout): coalesced along n
-                    kp = e / CoutP; n = e % CoutP;
-                    const int c = c0 + 2 * kp;
-                    if (n < Cout && c < Cin) w0 = Wk[(long long)c * Cout + n];
-                    if (n < Cout && c + 1 < Cin) w1 = Wk[(long long)(c + 1) * Cout + n];
-                }
-                *(unsigned int *)&Bt[n * CV_LD + 2 * kp] = pack2bf(w0, w1);
-            }
-            __syncthreads();
+            if (more) load_stage(nk, nc0);
             const int ksteps = (Cin - c0 > 16) ? 2 : 1;
             for (int ks = 0; ks < ksteps; ks++) {
-                const bf16x4 a = *(const bf16x4 *)&As[(wave * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
+                const bf16x4 a = *(const bf16x4 *)&As[buf][(wave * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
-                    const bf16x4 b = *(const bf16x4 *)&Bt[(n * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
+                    const bf16x4 b = *(const bf16x4 *)&Bt[buf][(n * 16 + (lane & 15)) * CV_LD + ks * 16 + (lane >> 4) * 4];
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[n], 0, 0, 0);
                 }
             }
+            if (!more) break;
+            store_stage(buf ^ 1);
             __syncthreads();
+            buf ^= 1; k = nk; c0 = nc0;
         }
     }
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -210,7 +250,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
             const int col = n * 16 + (lane & 15);
             if (u < Mout && col < Cout) {
                 if (gridDim.y == 1) out[(long long)u * Cout + col] = acc[n][r];
-                else atomicAdd(&out[(long long)u * Cout + col], acc[n][r]);
+                else if (kmask != 0u) atomicAdd(&out[(long long)u * Cout + col], acc[n][r]);
             }
         }
     }
