@@ -55,6 +55,7 @@ SIGNATURES = {
     "d3_bn_ws_bytes": (sz, [i32]),
     "d3_bn_stats": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "d3_bn_relu_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "d3_bn_relu_fwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "d3_bn_relu_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, sz, vp]),
 }
 

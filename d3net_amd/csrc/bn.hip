@@ -69,6 +69,30 @@ __global__ void bn_relu_fwd_kernel(const float *__restrict__ x, const float *__r
     }
     ((float4 *)y)[e] = make_float4(o[0], o[1], o[2], o[3]);
 }
+// same, output stored as bf16 (round-to-nearest-even): the consumer is a convolution, whose MFMA operands are bf16
+// anyway, so this is numerically identical to writing fp32 and converting in the conv -- at half the bytes
+__device__ __forceinline__ unsigned int bn_pack2bf(float lo, float hi) {
+    unsigned int a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7FFFu + ((a >> 16) & 1u); b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+__global__ void bn_relu_fwd_bf16_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                        const float *__restrict__ var, const float *__restrict__ gamma,
+                                        const float *__restrict__ beta, unsigned short *__restrict__ y, long long total4,
+                                        int C, float eps, int relu) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels per thread (C % 4 == 0)
+    if (e >= total4) return;
+    const int c = (int)((e * 4) % C);
+    const float4 v = ((const float4 *)x)[e];
+    float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float inv = rsqrtf(var[c + j] + eps);
+        float r = fmaf((in[j] - mean[c + j]) * inv, gamma[c + j], beta[c + j]);
+        o[j] = (relu && r < 0.f) ? 0.f : r;
+    }
+    ((uint2 *)y)[e] = make_uint2(bn_pack2bf(o[0], o[1]), bn_pack2bf(o[2], o[3]));
+}
 __global__ void bn_relu_fwd_scalar_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                           const float *__restrict__ var, const float *__restrict__ gamma,
                                           const float *__restrict__ beta, float *__restrict__ y, long long total,
@@ -180,6 +204,17 @@ extern "C" int d3_bn_relu_fwd(const float *x, const float *mean, const float *va
         bn_relu_fwd_scalar_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, mean, var, gamma, beta, y, total, C,
                                                                            eps, relu);
     }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_bn_relu_fwd_bf16(const float *x, const float *mean, const float *var, const float *gamma,
+                                   const float *beta, void *y_bf16, int M, int C, float eps, int relu, void *stream) {
+    D3_CLEAR();
+    if (M <= 0) return 0;
+    if ((C & 3) != 0) return D3_ERR_ARG;
+    long long t4 = (long long)M * C / 4;
+    bn_relu_fwd_bf16_kernel<<<(int)((t4 + 255) / 256), 256, 0, d3_stream(stream)>>>(x, mean, var, gamma, beta,
+                                                                                  (unsigned short *)y_bf16, t4, C, eps, relu);
     D3_LAUNCH_CHECK();
     return 0;
 }

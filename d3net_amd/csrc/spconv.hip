@@ -127,7 +127,8 @@ template <int NT, bool TRANSW>
 __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__restrict__ x,
                                                              const int *__restrict__ tbl,
                                                              const float *__restrict__ W, float *__restrict__ out,
-                                                             int Mout, int K, int Cin, int Cout, int flipk, int kper) {
+                                                             int Mout, int K, int Cin, int Cout, int flipk, int kper,
+                                                             int xbf16) {
     constexpr int CoutP = NT * 16;  // Cout rounded up to the MFMA tile; columns >= Cout are zero / not stored
     __shared__ int tblS[CV_BM * CV_MAXK];
     __shared__ unsigned int kmaskS;
@@ -161,14 +162,18 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
     const int arow = t >> 2, aq = t & 3;  // staging role: row, 8-channel group
     const bool cin4 = (Cin & 3) == 0;
 
-    float va[8];          // staged A values of the next stage
+    float va[8];          // staged A values of the next stage (fp32 input)
+    uint4 vpk = make_uint4(0u, 0u, 0u, 0u);   // ... or 8 packed bf16 when the input is stored as bf16 (D3_CONV_XBF16)
     float vb[NT][2];      // staged B values of the next stage
     auto load_stage = [&](int k, int c0) {
         const int idx = tblS[arow * K + k];
 #pragma unroll
         for (int j = 0; j < 8; j++) va[j] = 0.f;
         const int c = c0 + aq * 8;
-        if (idx >= 0) {
+        if (xbf16) {   // Cin % 8 == 0 (checked on the host): one 16-byte gather per thread, no conversion
+            vpk = make_uint4(0u, 0u, 0u, 0u);
+            if (idx >= 0 && c + 8 <= Cin) vpk = *(const uint4 *)((const unsigned short *)x + (long long)idx * Cin + c);
+        } else if (idx >= 0) {
             const float *src = x + (long long)idx * Cin + c;
             if (cin4) {
                 if (c + 4 <= Cin) { float4 f = *(const float4 *)src; va[0] = f.x; va[1] = f.y; va[2] = f.z; va[3] = f.w; }
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
         }
     };
     auto store_stage = [&](int buf) {
-        uint4 pk;
-        pk.x = pack2bf(va[0], va[1]); pk.y = pack2bf(va[2], va[3]); pk.z = pack2bf(va[4], va[5]); pk.w = pack2bf(va[6], va[7]);
+        uint4 pk = vpk;
+        if (!xbf16) { pk.x = pack2bf(va[0], va[1]); pk.y = pack2bf(va[2], va[3]); pk.z = pack2bf(va[4], va[5]); pk.w = pack2bf(va[6], va[7]); }
         *(uint4 *)&As[buf][arow * CV_LD + aq * 8] = pk;
 #pragma unroll
         for (int i = 0; i < NT; i++) {
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_mfma_kernel(const float *__res
 
 template <bool TRANSW>
 static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float *out, int Mout, int K, int Cin,
-                           int Cout, int flipk, hipStream_t s) {
+                           int Cout, int flipk, int xbf16, hipStream_t s) {
     const int tiles = (Mout + CV_BM - 1) / CV_BM;
     // enough workgroups to cover the chip: split the offsets when there are few row tiles
     int ksplit = 1;
@@ -269,7 +274,7 @@ static int launch_fwd_mfma(const float *x, const int *tbl, const float *W, float
     const dim3 grid(tiles, ksplit);
 #define CV_CASE(NTV)                                                                                              \
     case NTV:                                                                                                     \
-        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, kper); \
+        spconv_fwd_mfma_kernel<NTV, TRANSW><<<grid, 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, kper, xbf16); \
         break;
     switch ((Cout + 15) / 16) {
         CV_CASE(1) CV_CASE(2) CV_CASE(3) CV_CASE(4) CV_CASE(5) CV_CASE(6) CV_CASE(7) CV_CASE(8) CV_CASE(9)
@@ -289,6 +294,7 @@ extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, flo
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
     hipStream_t s = d3_stream(stream);
     const int flipk = (flags & D3_CONV_FLIPK) ? 1 : 0, transw = (flags & D3_CONV_TRANSW) ? 1 : 0;
+    if ((flags & D3_CONV_EXACT) && (flags & D3_CONV_XBF16)) return D3_ERR_ARG;
     if (flags & D3_CONV_EXACT) {
         long long total = (long long)Mout * Cout;
         spconv_fwd_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, W, out, Mout, K, Cin, Cout, flipk,
@@ -296,13 +302,15 @@ extern "C" int d3_spconv_fwd(const float *x, const int *tbl, const float *W, flo
         D3_LAUNCH_CHECK();
         return 0;
     }
-    if ((Cin & 1) != 0 || Cout > 224) return D3_ERR_ARG;
-    // algorithmic traffic: features in once, out once, weights once, one table entry per (row, offset)
-    const double bytes = 4.0 * ((double)Min * Cin + (double)Mout * Cout + (double)K * Cin * Cout) +
+    const int xbf16 = (flags & D3_CONV_XBF16) ? 1 : 0;
+    if ((Cin & 1) != 0 || Cout > 224 || (xbf16 && (Cin & 7) != 0)) return D3_ERR_ARG;
+    // algorithmic traffic: features in once (2 B/elem when stored as bf16), out once, weights once, one table entry
+    // per (row, offset)
+    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * ((double)Mout * Cout + (double)K * Cin * Cout) +
                          (tbl ? 4.0 * (double)Mout * K : 0.0);
     ProfRec *pr = prof_begin(0, bytes, 0.0, s);
-    int rc = transw ? launch_fwd_mfma<true>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s)
-                    : launch_fwd_mfma<false>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, s);
+    int rc = transw ? launch_fwd_mfma<true>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, xbf16, s)
+                    : launch_fwd_mfma<false>(x, tbl, W, out, Mout, K, Cin, Cout, flipk, xbf16, s);
     prof_end(pr, s);
     return rc;
 }
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__r
                                                                const int *__restrict__ tbl,
                                                                const float *__restrict__ dy, float *__restrict__ dW,
                                                                int Mout, int K, int Cin, int Cout, int rows_per_block,
-                                                               int xstat, int flipk) {
+                                                               int xstat, int flipk, int xbf16) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
@@ -356,6 +364,15 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const float *__r
             any_valid = true;
             const int xrow = xstat ? u : idx, dyrow = xstat ? idx : u;
             // stage x (gathered) and dy, transposed: element (c, row) at [c*CV_LD + row]
+            if (xbf16) {   // x stored as bf16: copy the pair as is
+                const unsigned short *xb = (const unsigned short *)x;
+                for (int c = shalf * 2; c < CinP; c += 4) {
+                    unsigned int pr = 0u;
+                    if (idx >= 0 && c + 2 <= Cin) pr = *(const unsigned int *)(xb + (long long)xrow * Cin + c);
+                    Xt[c * CV_LD + srow] = (unsigned short)(pr & 0xFFFFu);
+                    Xt[(c + 1) * CV_LD + srow] = (unsigned short)(pr >> 16);
+                }
+            } else
             for (int c = shalf * 2; c < CinP; c += 4) {
                 float a = 0.f, b = 0.f;
                 if (idx >= 0 && c + 2 <= Cin) { float2 f = *(const float2 *)(x + (long long)xrow * Cin + c); a = f.x; b = f.y; }
@@ -413,6 +430,7 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
     const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0, flipk = (flags & D3_CONV_FLIPK) ? 1 : 0;
     const int rows = xstat ? Min : Mout;   // stationary rows == rows of tbl
     if (!(flags & D3_CONV_ACCUM)) D3_CHECK(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), s));
+    if ((flags & D3_CONV_EXACT) && (flags & D3_CONV_XBF16)) return D3_ERR_ARG;
     if (flags & D3_CONV_EXACT) {
         long long total = (long long)K * Cin * Cout;
         spconv_wgrad_exact_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, tbl, dy, dW, rows, K, Cin, Cout, xstat,
@@ -420,6 +438,7 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
         D3_LAUNCH_CHECK();
         return 0;
     }
+    const int xbf16 = (flags & D3_CONV_XBF16) ? 1 : 0;
     if ((Cin & 1) != 0 || (Cout & 1) != 0) return D3_ERR_ARG;
     const int CinP = (Cin + 15) & ~15, CoutP = (Cout + 15) & ~15;
     // 64 KB of dynamic LDS per workgroup: wide layers run with fewer waves (each wave stages its own rows)
@@ -434,10 +453,10 @@ extern "C" int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, 
     if (rpb < nwaves * 2 * WG_RC) rpb = nwaves * 2 * WG_RC;
     if (rpb > WG_ROWS_MAX) rpb = WG_ROWS_MAX;
     dim3 grid((rows + rpb - 1) / rpb, K, passes);
-    const double bytes = 4.0 * ((double)Min * Cin + (double)Mout * Cout + (double)K * Cin * Cout) +
+    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * ((double)Mout * Cout + (double)K * Cin * Cout) +
                          (tbl ? 4.0 * (double)Mout * K : 0.0);
     ProfRec *pr = prof_begin(1, bytes, 0.0, s);
-    spconv_wgrad_mfma_kernel<<<grid, nwaves * 64, lds, s>>>(x, tbl, dy, dW, rows, K, Cin, Cout, rpb, xstat, flipk);
+    spconv_wgrad_mfma_kernel<<<grid, nwaves * 64, lds, s>>>(x, tbl, dy, dW, rows, K, Cin, Cout, rpb, xstat, flipk, xbf16);
     prof_end(pr, s);
     D3_LAUNCH_CHECK();
     return 0;

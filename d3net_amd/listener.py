@@ -20,7 +20,7 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from . import _lib
 from ._lib import check
-from .pointgroup_ops import _ptr, _stream
+from .pointgroup_ops import _on, _ptr, _stream
 
 
 # ------------------------------------------------------------------------------------ attention core
@@ -41,7 +41,7 @@ class AttentionCoreFunction(Function):
         if mask is not None:
             mask = mask.contiguous().float()
             assert mask.shape == (B, nk)
-        with torch.cuda.device(q.device):
+        with _on(q.device):
             check(_lib.lib().d3_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias) if bias is not None else None,
                                          _ptr(mask) if mask is not None else None, _ptr(out), _ptr(P), B, h, nq, nk,
                                          dk, dv, bias_div, _stream()), "attn_fwd")
@@ -56,7 +56,7 @@ class AttentionCoreFunction(Function):
         dout = dout.contiguous()
         dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dS = torch.empty_like(P)
-        with torch.cuda.device(q.device):
+        with _on(q.device):
             check(_lib.lib().d3_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(P), _ptr(dout), _ptr(dS), _ptr(dq), _ptr(dk_),
                                          _ptr(dv_), B, h, nq, nk, dk, dv, _stream()), "attn_bwd")
         return dq, dk_, dv_, None, None, None, None   # the distance weights are detached in the reference

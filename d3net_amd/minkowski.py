@@ -24,9 +24,9 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check
-from .pointgroup_ops import _ptr, _stream, _workspace
+from .pointgroup_ops import _on, _ptr, _stream, _workspace
 
-D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT, D3_CONV_XSTAT = 1, 2, 4, 8
+D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT, D3_CONV_XSTAT, D3_CONV_XBF16 = 1, 2, 4, 8, 32
 
 _EXACT = False  # True: fp32 FMA kernels (validation); False: bf16 MFMA with fp32 accumulate
 
@@ -61,7 +61,7 @@ class CoordinateManager:
             M = c.size(0)
             nbr = torch.empty((M, 27), dtype=torch.int32, device=self.device)
             ws = self._ws(M)
-            with torch.cuda.device(self.device):
+            with _on(self.device):
                 check(_lib.lib().d3_kmap_k3(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _stream()), "kmap_k3")
             self._k3[ts] = nbr
         return self._k3[ts]
@@ -75,7 +75,7 @@ class CoordinateManager:
             kidx = torch.empty(M, dtype=torch.int32, device=self.device)
             ws = self._ws(M)
             L = _lib.lib()
-            with torch.cuda.device(self.device):
+            with _on(self.device):
                 Mo = C.c_int(0)
                 check(L.d3_kmap_down_count(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(parent), _ptr(kidx),
                                            C.byref(Mo), _stream()), "kmap_down_count")
@@ -99,6 +99,7 @@ class SparseTensor:
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = tensor_stride
         self._relu_done = False
+        self._conv_done = None
 
     @property
     def features(self):
@@ -134,7 +135,7 @@ def cat(*tensors):
 # ------------------------------------------------------------------------------------- autograd ops
 def _conv_call(x, tbl, W3, Mout, K, Cin, Cout, flags):
     out = torch.empty((Mout, Cout), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.lib().d3_spconv_fwd(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(W3), _ptr(out),
                                        x.size(0), Mout, K, Cin, Cout, flags | _mode_flag(), _stream()), "spconv_fwd")
     return out
@@ -166,18 +167,73 @@ class SparseConvFunction(Function):
             # data gradient: the same contraction over the transposed map with W^T (Cout -> Cin)
             dx = _conv_call(dy, tbl_b, W3, x.size(0), K, Cout, Cin, bwd_flags | D3_CONV_TRANSW)
         if ctx.needs_input_grad[1]:
-            dW = torch.empty_like(W3)   # cleared inside d3_spconv_wgrad
-            # read the wider operand contiguously: x-stationary over the transposed map when Cin > Cout
-            if tbl_b is not None and Cin > Cout:
-                tbl, wflags = tbl_b, D3_CONV_XSTAT | (bwd_flags & D3_CONV_FLIPK)
-            else:
-                tbl, wflags = tbl_f, 0
-            with torch.cuda.device(x.device):
-                check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(dy),
-                                                 _ptr(dW), x.size(0), Mout, K, Cin, Cout, wflags | _mode_flag(),
-                                                 _stream()), "spconv_wgrad")
-            dW = dW.view_as(W)
+            dW = _conv_wgrad(x, tbl_f, tbl_b, dy, W3, Mout, bwd_flags).view_as(W)
         return dx, dW, None, None, None, None
+
+
+def _conv_wgrad(x, tbl_f, tbl_b, dy, W3, Mout, bwd_flags, xflag=0):
+    """dW of out = sum_k x[tbl_f[:,k]] @ W[k]; reads the wider operand contiguously (x-stationary over the transposed map)"""
+    K, Cin, Cout = W3.shape
+    dW = torch.empty_like(W3)   # cleared inside d3_spconv_wgrad
+    if tbl_b is not None and Cin > Cout:
+        tbl, wflags = tbl_b, D3_CONV_XSTAT | (bwd_flags & D3_CONV_FLIPK)
+    else:
+        tbl, wflags = tbl_f, 0
+    with _on(x.device):
+        check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(dy), _ptr(dW), x.size(0),
+                                         Mout, K, Cin, Cout, wflags | xflag | _mode_flag(), _stream()), "spconv_wgrad")
+    return dW
+
+
+class PreActConvFunction(Function):
+    """The pre-activation unit of every U-Net block as ONE autograd node: BatchNorm (batch statistics) -> ReLU -> conv.
+    The normalised activations are materialised once, as bf16 -- the convolution's MFMA operands are bf16 anyway, so
+    this is numerically identical to an fp32 intermediate -- which halves the bytes of the gather that bounds the
+    large levels and of the tensor kept for the weight gradient.  (Exact mode keeps the intermediate in fp32.)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, W, tbl_f, tbl_b, Mout, bwd_flags, eps, relu, running_mean, running_var, momentum):
+        x = x.contiguous()
+        M, Cc = x.shape
+        W3 = W if W.dim() == 3 else W.unsqueeze(0)
+        K, Cin, Cout = W3.shape
+        assert Cin == Cc
+        L = _lib.lib()
+        stats = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        ws = _workspace(L.d3_bn_ws_bytes(Cc), x.device, "bn")
+        use_bf16 = (not _EXACT) and Cc % 8 == 0
+        y = torch.empty((M, Cc), dtype=torch.bfloat16 if use_bf16 else torch.float32, device=x.device)
+        with _on(x.device):
+            check(L.d3_bn_stats(_ptr(x), M, Cc, _ptr(stats[0]), _ptr(stats[1]),
+                                _ptr(running_mean) if running_mean is not None else None,
+                                _ptr(running_var) if running_var is not None else None, float(momentum or 0.0),
+                                _ptr(ws), ws.numel(), _stream()), "bn_stats")
+            fwd = L.d3_bn_relu_fwd_bf16 if use_bf16 else L.d3_bn_relu_fwd
+            check(fwd(_ptr(x), _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta), _ptr(y), M, Cc, eps, int(relu),
+                      _stream()), "bn_relu_fwd")
+        xflag = D3_CONV_XBF16 if use_bf16 else 0
+        out = _conv_call(y, tbl_f, W3, Mout, K, Cin, Cout, xflag)
+        ctx.save_for_backward(x, gamma, beta, stats, y, W)
+        ctx.cfg = (tbl_f, tbl_b, Mout, bwd_flags, eps, relu, xflag)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, beta, stats, y, W = ctx.saved_tensors
+        tbl_f, tbl_b, Mout, bwd_flags, eps, relu, xflag = ctx.cfg
+        dout = dout.contiguous()
+        W3 = W if W.dim() == 3 else W.unsqueeze(0)
+        K, Cin, Cout = W3.shape
+        M = x.shape[0]
+        dy = _conv_call(dout, tbl_b, W3, M, K, Cout, Cin, bwd_flags | D3_CONV_TRANSW)          # grad w.r.t. the conv input
+        dW = _conv_wgrad(y, tbl_f, tbl_b, dout, W3, Mout, bwd_flags, xflag).view_as(W) if ctx.needs_input_grad[3] else None
+        dx, dgamma, dbeta = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(beta)
+        ws = _workspace(_lib.lib().d3_bn_ws_bytes(Cin), x.device, "bn")
+        with _on(x.device):
+            check(_lib.lib().d3_bn_relu_bwd(_ptr(x), _ptr(dy), _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta),
+                                            _ptr(dx), _ptr(dgamma), _ptr(dbeta), M, Cin, eps, int(relu), _ptr(ws),
+                                            ws.numel(), _stream()), "bn_relu_bwd")
+        return (dx, dgamma, dbeta, dW) + (None,) * 9
 
 
 class BatchNormReLUFunction(Function):
@@ -190,7 +246,7 @@ class BatchNormReLUFunction(Function):
         y = torch.empty_like(x)
         L = _lib.lib()
         ws = _workspace(L.d3_bn_ws_bytes(Cc), x.device, "bn")
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             check(L.d3_bn_stats(_ptr(x), M, Cc, _ptr(mean), _ptr(var),
                                 _ptr(running_mean) if running_mean is not None else None,
                                 _ptr(running_var) if running_var is not None else None, float(momentum or 0.0),
@@ -212,7 +268,7 @@ class BatchNormReLUFunction(Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         ws = _workspace(_lib.lib().d3_bn_ws_bytes(Cc), x.device, "bn")
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             check(_lib.lib().d3_bn_relu_bwd(_ptr(x), _ptr(dy), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
                                             _ptr(dx), _ptr(dgamma), _ptr(dbeta), M, Cc, eps, int(relu), _ptr(ws),
                                             ws.numel(), _stream()), "bn_relu_bwd")
@@ -226,7 +282,7 @@ class BatchNormEvalFunction(Function):
     def forward(ctx, x, gamma, beta, mean, var, eps, relu):
         x = x.contiguous()
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             check(_lib.lib().d3_bn_relu_fwd(_ptr(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), _ptr(y),
                                             x.size(0), x.size(1), eps, int(relu), _stream()), "bn_relu_fwd")
         return y
@@ -252,18 +308,23 @@ class MinkowskiConvolution(nn.Module):
         with torch.no_grad():
             self.kernel.uniform_(-stdv, stdv)
 
-    def forward(self, x):
+    def maps(self, x):
+        """-> (forward table, transposed table, output rows, backward flags, output tensor stride)"""
         cm, ts = x.coordinate_manager, x.tensor_stride
         if self.kernel_size == 3:
             nbr = cm.k3(ts)
-            f = SparseConvFunction.apply(x.F, self.kernel, nbr, nbr, nbr.size(0), D3_CONV_FLIPK)
-            return x._like(f)
+            return nbr, nbr, nbr.size(0), D3_CONV_FLIPK, ts
         if self.kernel_size == 1:
-            f = SparseConvFunction.apply(x.F, self.kernel, None, None, x.F.size(0), 0)
-            return x._like(f)
+            return None, None, x.F.size(0), 0, ts
         child, up, Mo = cm.down(ts)
-        f = SparseConvFunction.apply(x.F, self.kernel, child, up, Mo, 0)
-        return x._like(f, 2 * ts)
+        return child, up, Mo, 0, 2 * ts
+
+    def forward(self, x):
+        if x._conv_done is self:      # already applied inside the fused BN -> ReLU -> conv unit
+            x._conv_done = None
+            return x
+        tbl_f, tbl_b, Mout, bflags, ts_out = self.maps(x)
+        return x._like(SparseConvFunction.apply(x.F, self.kernel, tbl_f, tbl_b, Mout, bflags), ts_out)
 
     def extra_repr(self):
         return "in=%d, out=%d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels, self.kernel_size, self.stride)
@@ -275,13 +336,12 @@ class MinkowskiConvolutionTranspose(MinkowskiConvolution):
         super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, dimension)
         self.reset_parameters(True)
 
-    def forward(self, x):
+    def maps(self, x):
         cm, ts = x.coordinate_manager, x.tensor_stride
         assert ts % 2 == 0, "transposed conv lands on the cached finer coordinates"
         child, up, Mo = cm.down(ts // 2)
         assert Mo == x.F.size(0)
-        f = SparseConvFunction.apply(x.F, self.kernel, up, child, up.size(0), 0)
-        return x._like(f, ts // 2)
+        return up, child, up.size(0), 0, ts // 2
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -305,6 +365,17 @@ class MinkowskiBatchNorm(nn.Module):
 
     def forward(self, x):
         bn = self.bn
+        conv = self.__dict__.get("fused_conv")
+        if conv is not None and self.fused_relu and (self.training or not bn.track_running_stats):
+            track = bn.track_running_stats
+            tbl_f, tbl_b, Mout, bflags, ts_out = conv.maps(x)
+            f = PreActConvFunction.apply(x.F, bn.weight, bn.bias, conv.kernel, tbl_f, tbl_b, Mout, bflags, bn.eps, True,
+                                         bn.running_mean if track else None, bn.running_var if track else None, bn.momentum)
+            if track:
+                self._steps += 1
+            out = x._like(f, ts_out)
+            out._relu_done, out._conv_done = True, conv
+            return out
         if self.training or not bn.track_running_stats:
             track = bn.track_running_stats
             y = BatchNormReLUFunction.apply(x.F, bn.weight, bn.bias, bn.eps, self.fused_relu,
@@ -339,4 +410,9 @@ def fuse_bn_relu(module):
             for a, b in zip(kids[:-1], kids[1:]):
                 if isinstance(a, MinkowskiBatchNorm) and isinstance(b, MinkowskiReLU):
                     a.fused_relu = True
+            # [BN, ReLU, conv] triples additionally run as one fused unit (PreActConvFunction); the conv is kept out
+            # of the BN module's children (plain __dict__ entry) so the module tree and state-dict keys are unchanged
+            for a, b, c in zip(kids[:-2], kids[1:-1], kids[2:]):
+                if isinstance(a, MinkowskiBatchNorm) and isinstance(b, MinkowskiReLU) and isinstance(c, MinkowskiConvolution):
+                    a.__dict__["fused_conv"] = c
     return module

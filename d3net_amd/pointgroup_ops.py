@@ -43,6 +43,23 @@ def _workspace(nbytes, device, tag):
     return buf
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _on(device):
+    """device guard for the raw library calls: a no-op (sub-microsecond) when `device` is already current --
+    `torch.cuda.device(...)` costs ~10 us per use, which at ~600 operator calls per step is host time the GPU waits for"""
+    return _NOGUARD if device.index is None or device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 def _device_of(*tensors):
     for t in tensors:
         if t.is_cuda:
@@ -68,7 +85,7 @@ class Voxelization_Idx(Function):
         c = coords.to(dev) if on_cpu else coords
         N, ncols = c.shape
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _on(dev):
             input_map = torch.empty(N, dtype=torch.int32, device=dev)
             ws = _workspace(L.d3_voxelize_idx_ws_bytes(N), dev, "vi")
             M, mA = C.c_int(0), C.c_int(1)
@@ -107,7 +124,7 @@ class Voxelization(Function):
         maxActive = map_rule.size(1) - 1
         output_feats = torch.zeros((M, Cc), dtype=torch.float32, device=feats.device)
         ctx.for_backwards = (map_rule, mode, maxActive, N)
-        with torch.cuda.device(feats.device):
+        with _on(feats.device):
             check(_lib.lib().d3_voxelize_fp(_ptr(feats), _ptr(output_feats), _ptr(map_rule), int(mode), M, maxActive,
                                             Cc, _stream()), "voxelize_fp")
         return output_feats
@@ -118,7 +135,7 @@ class Voxelization(Function):
         M, Cc = d_output_feats.size()
         d_output_feats = d_output_feats.contiguous()
         d_feats = torch.zeros((N, Cc), dtype=torch.float32, device=d_output_feats.device)
-        with torch.cuda.device(d_feats.device):
+        with _on(d_feats.device):
             check(_lib.lib().d3_voxelize_bp(_ptr(d_output_feats), _ptr(d_feats), _ptr(map_rule), int(mode), M,
                                             maxActive, Cc, _stream()), "voxelize_bp")
         return d_feats, None, None
@@ -142,7 +159,7 @@ class PointRecover(Function):
         maxActive = map_rule.size(1) - 1
         output_feats = torch.zeros((nPoint, Cc), dtype=torch.float32, device=feats.device)
         ctx.for_backwards = (map_rule, maxActive, M)
-        with torch.cuda.device(feats.device):
+        with _on(feats.device):
             check(_lib.lib().d3_point_recover_fp(_ptr(feats), _ptr(output_feats), _ptr(map_rule), M, maxActive, Cc,
                                                  _stream()), "point_recover_fp")
         return output_feats
@@ -153,7 +170,7 @@ class PointRecover(Function):
         N, Cc = d_output_feats.size()
         d_output_feats = d_output_feats.contiguous()
         d_feats = torch.zeros((M, Cc), dtype=torch.float32, device=d_output_feats.device)
-        with torch.cuda.device(d_feats.device):
+        with _on(d_feats.device):
             check(_lib.lib().d3_point_recover_bp(_ptr(d_output_feats), _ptr(d_feats), _ptr(map_rule), M, maxActive,
                                                  Cc, _stream()), "point_recover_bp")
         return d_feats, None, None
@@ -180,7 +197,7 @@ class BallQueryBatchP(Function):
         assert batch_offsets.is_contiguous() and batch_offsets.is_cuda and batch_offsets.dtype == torch.int32
         dev = coords.device
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _on(dev):
             start_len = torch.empty((n, 2), dtype=torch.int32, device=dev)
             ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bq")
             nActive = C.c_int(0)
@@ -222,7 +239,7 @@ class BFSCluster(Function):
         if idx.numel() == 0:
             idx = torch.zeros(1, dtype=torch.int32, device=dev)
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _on(dev):
             ws = _workspace(L.d3_bfs_cluster_ws_bytes(N), dev, "cl")
             S, P = C.c_int(0), C.c_int(0)
             check(L.d3_bfs_cluster_count(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(),
@@ -258,7 +275,7 @@ class RoiPool(Function):
         assert proposals_offset.is_contiguous() and proposals_offset.is_cuda and proposals_offset.dtype == torch.int32
         output_feats = torch.empty((nProposal, Cc), dtype=torch.float32, device=feats.device)
         output_maxidx = torch.empty((nProposal, Cc), dtype=torch.int32, device=feats.device)
-        with torch.cuda.device(feats.device):
+        with _on(feats.device):
             check(_lib.lib().d3_roipool_fp(_ptr(feats), _ptr(proposals_offset), _ptr(output_feats),
                                            _ptr(output_maxidx), nProposal, Cc, _stream()), "roipool_fp")
         ctx.for_backwards = (output_maxidx, proposals_offset, sumNPoint)
@@ -270,7 +287,7 @@ class RoiPool(Function):
         output_maxidx, proposals_offset, sumNPoint = ctx.for_backwards
         d_output_feats = d_output_feats.contiguous()
         d_feats = torch.zeros((sumNPoint, Cc), dtype=torch.float32, device=d_output_feats.device)
-        with torch.cuda.device(d_feats.device):
+        with _on(d_feats.device):
             check(_lib.lib().d3_roipool_bp(_ptr(d_feats), _ptr(proposals_offset), _ptr(output_maxidx),
                                            _ptr(d_output_feats), nProposal, Cc, _stream()), "roipool_bp")
         return d_feats, None
@@ -296,7 +313,7 @@ class GetIoU(Function):
         assert instance_labels.is_contiguous() and instance_labels.is_cuda and instance_labels.dtype == torch.int64
         assert instance_pointnum.is_contiguous() and instance_pointnum.is_cuda and instance_pointnum.dtype == torch.int32
         proposals_iou = torch.empty((nProposal, nInstance), dtype=torch.float32, device=proposals_idx.device)
-        with torch.cuda.device(proposals_idx.device):
+        with _on(proposals_idx.device):
             check(_lib.lib().d3_get_iou(_ptr(proposals_idx), _ptr(proposals_offset), _ptr(instance_labels),
                                         _ptr(instance_pointnum), _ptr(proposals_iou), nInstance, nProposal,
                                         _stream()), "get_iou")
@@ -316,7 +333,7 @@ def _sec(name, inp, offsets):
     assert inp.is_contiguous() and inp.is_cuda and inp.dtype == torch.float32
     assert offsets.is_contiguous() and offsets.is_cuda and offsets.dtype == torch.int32
     out = torch.empty((nProposal, Cc), dtype=torch.float32, device=inp.device)
-    with torch.cuda.device(inp.device):
+    with _on(inp.device):
         check(getattr(_lib.lib(), name)(_ptr(inp), _ptr(offsets), _ptr(out), nProposal, Cc, _stream()), name)
     return out
 

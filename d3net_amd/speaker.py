@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check
-from .pointgroup_ops import _ptr, _stream
+from .pointgroup_ops import _on, _ptr, _stream
 
 
 # --------------------------------------------------------------------------------------- local context
@@ -34,7 +34,7 @@ def query_locals_all(corners, object_masks, num_locals, include_self, overlay_th
     corners = corners.contiguous().float()
     masks = object_masks.contiguous().float()
     dist = torch.empty((B, K, K), dtype=torch.float32, device=corners.device)
-    with torch.cuda.device(corners.device):
+    with _on(corners.device):
         check(_lib.lib().d3_query_locals_dist(_ptr(corners), _ptr(masks), _ptr(dist), B, K, int(include_self),
                                               float(overlay_threshold), int(query_mode == "center"), _stream()),
               "query_locals_dist")

@@ -133,6 +133,7 @@ int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_byte
 #define D3_CONV_EXACT 4
 #define D3_CONV_XSTAT 8
 #define D3_CONV_ACCUM 16
+#define D3_CONV_XBF16 32   /* x is stored as bf16 (ushort), Cin % 8 == 0; not with D3_CONV_EXACT */
 int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
                   int Cout, int flags, void *stream);
 /* Weight gradient  dW[k] = sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32; cleared here unless
@@ -160,6 +161,9 @@ int d3_bn_stats(const float *x, int M, int C, float *mean, float *var, float *ru
                 float momentum, void *ws, size_t ws_bytes, void *stream);
 int d3_bn_relu_fwd(const float *x, const float *mean, const float *var, const float *gamma, const float *beta,
                    float *y, int M, int C, float eps, int relu, void *stream);
+/* same as d3_bn_relu_fwd with y stored as bf16 (RNE): for outputs consumed by a convolution (D3_CONV_XBF16) */
+int d3_bn_relu_fwd_bf16(const float *x, const float *mean, const float *var, const float *gamma, const float *beta,
+                        void *y_bf16, int M, int C, float eps, int relu, void *stream);
 int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const float *var, const float *gamma,
                    const float *beta, float *dx, float *dgamma, float *dbeta, int M, int C, float eps, int relu,
                    void *ws, size_t ws_bytes, void *stream);
