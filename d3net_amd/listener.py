@@ -268,23 +268,53 @@ def aabb_iou_to_gt(pred_corners, gt_corners):
     return inter / (vol_p + vol_g - inter + 1e-8)
 
 
-def softmax_ranking_loss(inputs, targets):
+def softmax_ranking_loss(inputs, targets, reduce=True):
     """lib/grounding/loss.py:6-25 (the 1e-8 inside and outside the softmax included)"""
     probs = torch.softmax(inputs + 1e-8, dim=1)
-    return (-torch.sum(torch.log(probs + 1e-8) * targets, dim=1)).mean()
+    loss = -torch.sum(torch.log(probs + 1e-8) * targets, dim=1)
+    return loss.mean() if reduce else loss
 
 
-def get_grounding_loss(data_dict, is_frozen=False):
-    """non-RL branch of lib/grounding/loss_helper.py:133-214: pseudo-GT = proposal with the highest IoU with the
-    referred box, softmax ranking loss, accuracy and IoU rates -- without the per-sample host loops."""
-    preds = data_dict["cluster_ref"]
-    N, K = preds.shape
+def _pseudo_gt(data_dict, N, K, repeat):
+    """proposal boxes repeated to the N description rows and their IoU with the referred boxes; the pseudo-GT is the
+    proposal with the highest IoU (lib/grounding/loss_helper.py:47-58, 148-158) -- without the per-sample host loops"""
     corners = data_dict["proposal_bbox_batched"]
-    chunk = N // corners.shape[0]
-    corners = corners.unsqueeze(1).repeat(1, chunk, 1, 1, 1).reshape(N, K, 8, 3)
+    corners = corners.unsqueeze(1).repeat(1, repeat, 1, 1, 1).reshape(N, K, 8, 3)
     gt = data_dict["ref_box_corner_label"].reshape(N, 8, 3)
     ious = aabb_iou_to_gt(corners, gt)
-    label_idx = ious.argmax(1)
+    return ious, ious.argmax(1)
+
+
+def get_grounding_loss(data_dict, is_frozen=False, use_rl=False):
+    """lib/grounding/loss_helper.py:12-229 (loss="cross_entropy"): softmax ranking loss against the pseudo-GT, accuracy
+    and IoU rates.  use_rl: `cluster_ref` holds the listener's scores for the sampled and the greedy (baseline)
+    captions; both unreduced losses are kept for the speaker's reward and the sampled one is the listener's loss."""
+    if use_rl:
+        sampled, baseline = data_dict["cluster_ref"]["sampled"], data_dict["cluster_ref"]["baseline"]
+        N, K = sampled.shape
+        B = data_dict["proposal_bbox_batched"].shape[0]
+        ious, label_idx = _pseudo_gt(data_dict, N, K, N // B)     # rows: (scene, sample, chunk); boxes depend on scene only
+        labels = torch.zeros_like(sampled).scatter_(1, label_idx.unsqueeze(1), 1.0)
+        data_dict["cluster_labels"] = labels
+        s_loss = softmax_ranking_loss(sampled, labels, reduce=False)
+        b_loss = softmax_ranking_loss(baseline, labels, reduce=False)
+        s_idx, b_idx = sampled.argmax(-1), baseline.argmax(-1)
+        rows = torch.arange(N, device=sampled.device)
+        s_ious, best_ious = ious[rows, s_idx], ious[rows, label_idx]
+        data_dict["ref_loss"] = s_loss.mean()
+        data_dict["ref_sampled_loss"], data_dict["ref_baseline_loss"] = s_loss, b_loss
+        data_dict["ref_acc_mean"] = data_dict["ref_sampled_acc"] = (s_idx == label_idx).sum().float() / N
+        data_dict["ref_sampled_acc_all"] = (s_idx == label_idx).float()
+        data_dict["ref_baseline_acc"] = (b_idx == label_idx).sum().float() / N
+        data_dict["ref_baseline_acc_all"] = (b_idx == label_idx).float()
+        data_dict["ref_iou_mean"] = s_ious.mean()
+        data_dict["best_ious_mean"] = best_ious.mean()
+        data_dict["ref_iou_rate_0.25"] = (s_ious >= 0.25).float().mean()
+        data_dict["ref_iou_rate_0.5"] = (s_ious >= 0.5).float().mean()
+        return data_dict["ref_loss"], data_dict
+    preds = data_dict["cluster_ref"]
+    N, K = preds.shape
+    ious, label_idx = _pseudo_gt(data_dict, N, K, N // data_dict["proposal_bbox_batched"].shape[0])
     labels = torch.zeros_like(preds).scatter_(1, label_idx.unsqueeze(1), 1.0)
     loss = softmax_ranking_loss(preds, labels)
     data_dict["cluster_labels"] = labels
@@ -301,10 +331,20 @@ def get_grounding_loss(data_dict, is_frozen=False):
     return data_dict["ref_loss"], data_dict
 
 
-def get_lobjcls_loss(data_dict, is_frozen=False):
-    """non-RL branch of lib/grounding/loss_helper.py:276-292"""
+def get_lobjcls_loss(data_dict, is_frozen=False, use_rl=False):
+    """lib/grounding/loss_helper.py:231-302"""
+    targets = (data_dict["ref_cat_label"] if "ref_cat_label" in data_dict else data_dict["object_cat"]).reshape(-1)
+    if use_rl:
+        sampled, baseline = data_dict["lang_scores"]["sampled"], data_dict["lang_scores"]["baseline"]
+        assert targets.shape[0] == sampled.shape[0]
+        s_loss = nn.functional.cross_entropy(sampled, targets.long(), reduction="none")
+        b_loss = nn.functional.cross_entropy(baseline, targets.long(), reduction="none")
+        data_dict["lang_loss"] = s_loss.mean()
+        data_dict["sampled_lang_loss"], data_dict["baseline_lang_loss"] = s_loss, b_loss
+        data_dict["lang_acc"] = data_dict["lang_sampled_acc"] = (sampled.argmax(-1) == targets).sum().float() / targets.shape[0]
+        data_dict["lang_baseline_acc"] = (baseline.argmax(-1) == targets).sum().float() / targets.shape[0]
+        return data_dict["lang_loss"], data_dict
     preds = data_dict["lang_scores"]
-    targets = data_dict.get("ref_cat_label", data_dict["object_cat"]).reshape(-1)
     loss = nn.functional.cross_entropy(preds, targets)
     data_dict["lang_loss"] = loss if not is_frozen else preds.new_zeros(())
     data_dict["lang_acc"] = (preds.argmax(-1) == targets).sum().float() / targets.shape[0]

@@ -2,8 +2,8 @@
 (`detector`, `speaker`, `listener`), loss composition and logged keys (reference: model/pipeline.py:25-123,134-226,
 738-757).  A plain nn.Module: Lightning's `self.log` becomes `self.logged` (a dict filled per step; the reference's
 per-key `sync_dist=True` scalar all-reduces collapse into one packed all-reduce in `reduce_logged`).
-Built: modes 0 (detector), 1 (detector -> speaker, cross-entropy) and 2 (detector -> listener).  Mode 3 (joint
-self-critical training through `moderator`, model/pipeline.py:228-309,759-892) is the next row."""
+Built: modes 0 (detector), 1 (detector -> speaker), 2 (detector -> listener) and 3 (joint speaker-listener training,
+self-critical when cfg.train.use_rl, through `moderator`: model/pipeline.py:228-309,759-892)."""
 import random
 
 import numpy as np
@@ -28,8 +28,15 @@ class PipelineNet(nn.Module):
         if dataset:
             self.vocabulary = dataset["train"].vocabulary
             self.register_buffer("embeddings", torch.as_tensor(dataset["train"].glove, dtype=torch.float32))
+            self.beam_opt = {"train_beam_size": cfg.train.beam_size, "train_sample_topn": cfg.train.sample_topn,
+                             "eval_beam_size": cfg.train.beam_size}
             self.loss_opt = {"use_rl": cfg.train.use_rl, "sample_topn": cfg.train.sample_topn, "idx2word": self.vocabulary["idx2word"],
-                             "max_len": cfg.data.max_spk_len + 2, "loss_type": cfg.model.loss_type}
+                             "train_dataset_data": getattr(dataset["train"], "chunked_data", None),
+                             "organized_data": getattr(dataset["train"], "organized", None),
+                             "max_len": cfg.data.max_spk_len + 2, "loss_type": cfg.model.loss_type,
+                             "ref_reward_weight": cfg.train.ref_reward_weight, "lang_reward_weight": cfg.train.lang_reward_weight,
+                             "listener_reward_weight": cfg.train.listener_reward_weight,
+                             "caption_reward_weight": cfg.train.caption_reward_weight}
         if self.no_detection:
             raise NotImplementedError("GT-proposal modes 4-6 (no_detection) are not on the hot path")
         self.detector = PointGroup(cfg)
@@ -92,12 +99,7 @@ class PipelineNet(nn.Module):
                          "pred_ious": data_dict["pred_ious"]}.items():
                 self.log("train_{}/{}".format("loss" if "loss" in k else "score", k), v)
         elif self.mode == 2:
-            data_dict = self.listener(self._detect(data_dict))
-            _, data_dict = get_grounding_loss(data_dict)
-            if self.use_lang_classifier:
-                _, data_dict = get_lobjcls_loss(data_dict)
-            else:
-                data_dict["lang_loss"] = data_dict["ref_loss"].new_zeros(()); data_dict["lang_acc"] = data_dict["lang_loss"]
+            data_dict = self._ground(self.listener(self._detect(data_dict)), False)
             loss = data_dict["total_loss"][0] + data_dict["ref_loss"] + data_dict["lang_loss"]
             for k, v in {"loss": loss, "detect_loss": data_dict["total_loss"][0], "grounding_loss": data_dict["ref_loss"],
                          "lobjcls_loss": data_dict["lang_loss"], "ref_acc_mean": data_dict["ref_acc_mean"],
@@ -105,10 +107,94 @@ class PipelineNet(nn.Module):
                          "ref_iou_rate_0.25": data_dict["ref_iou_rate_0.25"], "ref_iou_rate_0.5": data_dict["ref_iou_rate_0.5"],
                          "lang_acc": data_dict["lang_acc"]}.items():
                 self.log("train_{}/{}".format("loss" if "loss" in k else "score", k), v)
+        elif self.mode == 3:
+            assert len(data_dict) == 2
+            use_rl = self.cfg.train.use_rl
+            assert use_rl, "mode 3 only works self-critically: `moderator` needs the sampled and greedy captions (pipeline.py:773-774)"
+            spk = self.speaker(self._detect(data_dict[0]), use_rl=use_rl, is_eval=False, beam_opt=self.beam_opt)
+            spk = self.moderator(spk, self.cfg.data.max_spk_len + 2)
+            spk = self._ground(self.listener(spk, use_rl=use_rl), use_rl)
+            _, spk = get_captioning_loss(spk, caption=not self.no_captioning, orientation=self.cfg.model.use_orientation,
+                                         num_bins=self.cfg.data.num_ori_bins, loss_opt=self.loss_opt)
+            loss = spk["total_loss"][0] + spk["cap_loss"] + 0.1 * spk["ori_loss"] + spk["ref_loss"] + spk["lang_loss"]
+            lis = self._ground(self.listener(self._detect(data_dict[1])), False)
+            loss = loss + lis["total_loss"][0] + lis["ref_loss"] + lis["lang_loss"]
+            avg = lambda k: (spk[k] + lis[k]) / 2
+            logs = {"loss": loss, "detect_loss": (spk["total_loss"][0] + lis["total_loss"][0]) / 2, "captioning_loss": spk["cap_loss"],
+                    "orientation_loss": spk["ori_loss"], "grounding_loss": avg("ref_loss"), "lobjcls_loss": avg("lang_loss"),
+                    "cap_acc": spk["cap_acc"], "ori_acc": spk["ori_acc"], "pred_ious": spk["pred_ious"], "cap_rwd": spk["cap_rwd"],
+                    "loc_rwd": spk["loc_rwd"], "ttl_rwd": spk["ttl_rwd"]}
+            for k in ("ref_acc_mean", "ref_iou_mean", "best_ious_mean", "ref_iou_rate_0.25", "ref_iou_rate_0.5", "lang_acc"):
+                logs[k] = avg(k)
+            for k, v in logs.items():
+                self.log("train_{}/{}".format("loss" if "loss" in k else "score", k), v)
+            data_dict = {"speaker": spk, "listener": lis}
         else:
-            raise NotImplementedError("mode 3 (joint speaker-listener, self-critical) is not built yet")
+            raise NotImplementedError("GT-proposal modes 4-6 (no_detection) are not on the hot path")
         self.global_step += 1
         return loss, data_dict
+
+    def _ground(self, data_dict, use_rl):
+        """lib/grounding/loss_helper.py:304-335 `get_loss`"""
+        _, data_dict = get_grounding_loss(data_dict, use_rl=use_rl)
+        if self.use_lang_classifier:
+            _, data_dict = get_lobjcls_loss(data_dict, use_rl=use_rl)
+        else:
+            data_dict["lang_loss"] = data_dict["ref_loss"].new_zeros(()); data_dict["lang_acc"] = data_dict["lang_loss"]
+        return data_dict
+
+    def moderator(self, data_dict, max_spk_len):
+        """Turn the speaker's sampled and greedy captions into listener inputs, and the speaker's targets into the
+        listener's (pseudo) ground truth (model/pipeline.py:759-892).  After it the listener batch is
+        (scene, sample, chunk): `lang_feat[...]` is (B*topn, chunk, T, 300).
+
+        One host transfer for all token lists; the one-hot x embedding products of the reference (:819-826) are row
+        lookups (a one-hot row selects exactly one embedding row; padding positions select row 0, `pad_`).
+        NOTE `lang_len[...]` keeps the (scene*chunk, sample) layout (:846-849) while the embeddings have the sample
+        axis moved out -- the two only line up for chunk == 1 or topn == 1; kept as in the reference."""
+        sampled, baseline = data_dict["lang_cap"], data_dict["baseline_cap"]
+        assert len(sampled[0]) == len(baseline[0])
+        N, topn = len(sampled), len(sampled[0])
+        feats = data_dict["bbox_feature"]
+        B, dev = feats.shape[0], feats.device
+        Cn = N // B
+        sos, eos = 2, 3                                                        # hard-coded in the reference (:786)
+
+        def to_matrix(table):
+            lens = [len(table[n][k]) for n in range(N) for k in range(topn)]
+            flat = torch.cat([table[n][k].reshape(-1) for n in range(N) for k in range(topn)]).tolist()
+            mat = np.zeros((N * topn, max_spk_len), np.int64)
+            out_len = np.zeros(N * topn, np.int64)
+            pos = 0
+            for i, l in enumerate(lens):
+                toks = [sos] + flat[pos:pos + l]
+                pos += l
+                if eos not in toks:
+                    toks.append(eos)
+                assert len(toks) <= max_spk_len
+                mat[i, :len(toks)] = toks
+                out_len[i] = len(toks)
+            return (torch.from_numpy(mat).to(dev).view(N, topn, max_spk_len), torch.from_numpy(out_len).to(dev).view(N, topn))
+
+        def embed(mat):
+            e = self.embeddings[mat]                                               # (N, topn, T, 300)
+            e = e.reshape(-1, Cn, topn, max_spk_len, e.shape[-1]).transpose(2, 1)
+            return e.reshape(-1, Cn, max_spk_len, e.shape[-1])
+
+        s_mat, s_len = to_matrix(sampled)
+        b_mat, b_len = to_matrix(baseline)
+        data_dict["sampled_topn"] = topn
+        data_dict["lang_feat"] = {"sampled": embed(s_mat), "baseline": embed(b_mat)}
+        data_dict["lang_len"] = {"sampled": s_len, "baseline": b_len}
+        # pseudo ground truth: box / class of the GT object assigned to every description's target
+        assigned = data_dict["assigned_bbox_id_labels"].reshape(-1, Cn).unsqueeze(1).repeat(1, topn, 1)   # (B, topn, Cn)
+        corners, sems = data_dict["proposal_bbox_batched"], data_dict["proposal_sem_cls_batched"]
+        scene = torch.arange(B, device=dev).view(B, 1, 1).expand_as(assigned)
+        data_dict["ref_box_corner_label"] = corners[scene, assigned].reshape(B * topn, Cn, 8, 3)
+        cat = sems[scene, assigned].reshape(B * topn, Cn) - 2                      # wall / floor are not ScanRefer classes
+        cat[cat < 0] = 17
+        data_dict["ref_cat_label"] = cat
+        return data_dict
 
     def configure_optimizers(self):
         """AdamW + StepLR(10, 0.8) over the trainable parameters (model/pipeline.py:738-757)"""

@@ -12,7 +12,8 @@ Re-designed hot spots (results unchanged):
     time loop (caption_module.py:95-98, 108 recompute it every step);
   * evaluation decodes all 128 target proposals of a scene as one batch instead of 128 x 31 sequential steps
     (caption_module.py:710-749).
-Not implemented yet: the self-critical path (beam search, caption_module.py:136-349) -> `use_rl=True` raises.
+  * self-critical training: the beam search carries only the chosen-token log-probs (not the (N,b,t,V) history),
+    keeps per-step snapshots on the device and ranks finished beams with one stable sort (caption_module.py:136-349).
 """
 import ctypes as C
 import random
@@ -188,6 +189,70 @@ class TopDownSceneCaptionModule(nn.Module):
             outs.append(word.unsqueeze(1)); lps.append(lp.unsqueeze(1))
         return self.trim_outputs(torch.cat(outs, 1).unsqueeze(1), torch.cat(lps, 1).unsqueeze(1))
 
+    def beam_decode(self, target_feats, obj_feats, valid_masks, beam_size, max_len, topn=None):
+        """Differentiable batched beam search (:136-349 with the reference's call `opt={"beam_size": b}`: one group, no
+        diversity / constraints / temperature).  Returns, per sample, its finished beams best-first as dicts
+        {"seq": (l,) tokens, "logps": (l,) log-prob of every chosen token -- on the autograd graph, "p": float}.
+
+        Same search as the reference's, restructured: the b live beams of all N samples advance as one (N*b) batch;
+        instead of carrying the full (N,b,t,V) log-prob history and gathering the chosen tokens afterwards
+        (:202-204, 609), only the chosen-token log-probs (N,b,t) are carried; finished beams are not copied out one by
+        one on the host (:285-300) -- each step keeps its (seq, logps, p, ended) snapshot on the device and the
+        per-sample ranking is one stable sort at the end (ties keep the reference's append order: step, then beam).
+        """
+        N, b, V = target_feats.shape[0], beam_size, self.num_vocabs
+        dev = target_feats.device
+        eos = int(self.vocabulary["word2idx"]["eos"])
+        word = torch.full((N,), int(self.vocabulary["word2idx"]["sos"]), dtype=torch.long, device=dev)
+        hiddens = (obj_feats.new_zeros(N, self.hidden_size), obj_feats.new_zeros(N, self.hidden_size))
+        proj = self.map_feat(obj_feats)
+        _, logits, hiddens, _ = self.step(word, hiddens, target_feats, obj_feats, valid_masks, proj)
+        logp = F.log_softmax(logits, dim=-1).view(N, 1, V)                 # t = 0: a single live beam per sample (:176-179)
+        # per-beam copies of the context for t >= 1 (== target_feat[inter_ids] etc., :305-307)
+        rep = lambda t: t.repeat_interleave(b, dim=0)
+        tf_b, of_b, vm_b, proj_b = rep(target_feats), rep(obj_feats), rep(valid_masks), rep(proj)
+        base = torch.arange(N, device=dev).unsqueeze(1)
+        sums = obj_feats.new_zeros(N, 1)
+        seq = torch.zeros(N, b, 0, dtype=torch.long, device=dev)
+        lps = obj_feats.new_zeros(N, b, 0)
+        snaps = []
+        for t in range(max_len):
+            live = logp.shape[1]
+            cand = (sums.unsqueeze(-1) + logp).reshape(N, live * V)
+            ix = torch.sort(cand, -1, True)[1][:, :b]                       # full sort as the reference (:181-182)
+            beam_ix, tok = ix // V, ix % V
+            state_ix = (beam_ix + base * live).reshape(-1)
+            if t > 0:
+                seq = seq.gather(1, beam_ix.unsqueeze(-1).expand_as(seq))
+                lps = lps.gather(1, beam_ix.unsqueeze(-1).expand_as(lps))
+            chosen = logp.reshape(N, live * V).gather(1, ix)
+            seq = torch.cat([seq, tok.unsqueeze(-1)], -1)
+            lps = torch.cat([lps, chosen.unsqueeze(-1)], -1)
+            sums = sums.gather(1, beam_ix) + chosen
+            hiddens = tuple(h[state_ix] for h in hiddens)
+            ended = (tok == eos) if t < max_len - 1 else torch.ones_like(tok, dtype=torch.bool)
+            snaps.append((seq, lps, sums.detach().clone(), ended))
+            sums = sums - 1000.0 * ended.to(sums.dtype)                     # finished beams stay, heavily penalised (:300)
+            if t == max_len - 1:
+                break                                                       # (the reference runs one more, unused, step)
+            _, logits, hiddens, _ = self.step(tok.reshape(-1), hiddens, tf_b, of_b, vm_b, proj_b)
+            logp = F.log_softmax(logits, dim=-1).view(N, b, V)
+        # rank the finished beams of every sample: p descending, stable in (step, beam) order
+        P = torch.stack([torch.where(e, p, torch.full_like(p, float("-inf"))) for (_, _, p, e) in snaps], 1).reshape(N, -1)
+        keep = b if topn is None else min(topn, b)
+        order = torch.sort(P, dim=1, descending=True, stable=True)[1][:, :b].cpu()
+        Pc = P.cpu()
+        done = []
+        for n in range(N):
+            beams = []
+            for j in order[n].tolist()[:keep]:
+                if Pc[n, j] == float("-inf"):
+                    break
+                t, v = divmod(j, b)
+                beams.append({"seq": snaps[t][0][n, v], "logps": snaps[t][1][n, v], "p": float(Pc[n, j])})
+            done.append(beams)
+        return done
+
     def trim_outputs(self, raw_word_ids, raw_logprobs):
         """cut every sequence at its first eos / pad_ (:385-414); if none occurs the LAST token is dropped, as the
         reference's loop leaves t = max_len - 1"""
@@ -244,8 +309,6 @@ class TopDownSceneCaptionModule(nn.Module):
 
     # ---- training driver (:510-687)
     def _forward_sample_batch(self, data_dict, use_tf, use_rl, beam_opt={}):
-        if use_rl:
-            raise NotImplementedError("self-critical training (beam search, caption_module.py:136-349) is not built yet")
         K, L = self.num_proposals, self.num_locals
         word_ids = data_dict["lang_ids"].reshape(-1, self.cfg.data.max_spk_len + 2)
         des_lens = data_dict["lang_len"].reshape(-1)
@@ -274,17 +337,27 @@ class TopDownSceneCaptionModule(nn.Module):
         if self.use_relation:
             obj_feats = self._add_relation_feat(rep(data_dict["edge_feature"]), rep(data_dict["adjacent_mat"]), obj_feats, target_ids)
 
-        hiddens = (obj_feats.new_zeros(N, self.hidden_size), obj_feats.new_zeros(N, self.hidden_size))
-        proj = self.map_feat(obj_feats)
-        outputs, masks = [], []
-        word = word_ids[:, 0]
-        for step_id in range(1, max(num_words, 2)):
-            logits, _, hiddens, m = self.step(word, hiddens, target_feats, obj_feats, valid_masks, proj)
-            outputs.append(logits.unsqueeze(1)); masks.append(m)
-            word = word_ids[:, step_id] if use_tf else logits.argmax(-1)
-        data_dict["topdown_attn"] = torch.cat(masks, dim=-1)
+        if use_rl:   # self-critical: sampled = best beams (with gradients), baseline = greedy (:588-633)
+            assert beam_opt
+            beam_size, topn = beam_opt.get("train_beam_size", 5), beam_opt.get("train_sample_topn", 1)
+            done = self.beam_decode(target_feats, obj_feats, valid_masks, beam_size, self.cfg.data.max_spk_len, topn)
+            lang_cap = [[done[n][k]["seq"] for k in range(topn)] for n in range(N)]
+            data_dict["lang_logprob"] = [[done[n][k]["logps"] for k in range(topn)] for n in range(N)]
+            greedy, _ = self.greedy_decode(target_feats, obj_feats, valid_masks, self.cfg.data.max_spk_len + 1)
+            data_dict["baseline_cap"] = [[greedy[n][0] for _ in range(topn)] for n in range(N)]
+        else:
+            hiddens = (obj_feats.new_zeros(N, self.hidden_size), obj_feats.new_zeros(N, self.hidden_size))
+            proj = self.map_feat(obj_feats)
+            outputs, masks = [], []
+            word = word_ids[:, 0]
+            for step_id in range(1, max(num_words, 2)):
+                logits, _, hiddens, m = self.step(word, hiddens, target_feats, obj_feats, valid_masks, proj)
+                outputs.append(logits.unsqueeze(1)); masks.append(m)
+                word = word_ids[:, step_id] if use_tf else logits.argmax(-1)
+            data_dict["topdown_attn"] = torch.cat(masks, dim=-1)
+            lang_cap = torch.cat(outputs, dim=1)
         good = target_ious > self.cfg.data.min_iou_threshold
-        data_dict["lang_cap"] = torch.cat(outputs, dim=1)
+        data_dict["lang_cap"] = lang_cap
         data_dict["pred_ious"] = target_ious[good].mean() if bool(good.any()) else obj_feats.new_zeros(())
         data_dict["valid_masks"] = valid_masks
         data_dict["good_bbox_masks"] = good

@@ -149,7 +149,7 @@ def make_batch(scenes, device, mode=4):
 def make_vocabulary(size=3004):
     """vocabulary dict in the reference's format (word2idx / idx2word with pad_, unk, sos, eos first)"""
     words = ["pad_", "unk", "sos", "eos"] + ["w%d" % i for i in range(size - 4)]
-    return {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {i: w for i, w in enumerate(words)}}
+    return {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {str(i): w for i, w in enumerate(words)}}   # str keys: the reference loads it from json
 
 
 def add_language(batch, device, chunk=8, max_spk_len=30, max_lis_len=126, vocab=3004, seed=3):
@@ -185,7 +185,24 @@ def add_language(batch, device, chunk=8, max_spk_len=30, max_lis_len=126, vocab=
                scene_object_rotation_masks=batch["box_label_mask"].cpu().numpy().astype(np.float32))
     # the speaker's lang_len is the caption length (+2), the listener's the description length: the reference feeds
     # two different batches; a single synthetic batch carries the caption lengths under `lang_len` for mode 1
+    out["id"] = np.arange(B, dtype=np.int64)                                  # scene index into `chunked_data`
+    out["chunk_ids"] = np.tile(np.arange(chunk, dtype=np.int64), (B, 1))
     for k, v in out.items():
         batch[k] = torch.from_numpy(v).to(device)
     batch["spk_lang_len"] = torch.from_numpy(spk_len + 2).to(device)
     return batch
+
+
+def make_language_corpus(B, chunk=8, vocab=3004, max_spk_len=30, objects_per_scene=8, seed=5):
+    """Synthetic ScanRefer-shaped annotation store for the self-critical reward (lib/captioning/loss_helper.py:15-96):
+    `chunked_data[scene][chunk]` -> {scene_id, object_id}; `organized[scene_id][object_id]` -> list of {token: [...]}
+    (2-5 tokenised descriptions per object, words drawn from the vocabulary)."""
+    rng = np.random.default_rng(seed)
+    words = ["w%d" % i for i in range(vocab - 4)]
+    chunked, organized = [], {}
+    for b in range(B):
+        sid = "scene%04d_00" % b
+        organized[sid] = {str(o): [{"token": [words[i] for i in rng.integers(0, len(words), int(rng.integers(6, max_spk_len)))]}
+                                   for _ in range(int(rng.integers(2, 6)))] for o in range(objects_per_scene)}
+        chunked.append([{"scene_id": sid, "object_id": str(int(rng.integers(0, objects_per_scene)))} for _ in range(chunk)])
+    return chunked, organized

@@ -1,0 +1,122 @@
+"""GPU parity of the self-critical (RL) speaker -> moderator -> listener chain against the golden vectors produced by
+the reference's own modules (tests/golden/rl_golden.npz), and PipelineNet mode 3 end to end.
+Tolerance: fp32; differences come from library GEMM / GRU summation order and the HIP attention core: rtol 1e-3,
+atol 2e-4 on outputs; token sequences (beam search / greedy argmax over well-separated scores) must be identical."""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+
+
+def test_rl_chain_matches_reference_golden(dev):
+    from test_oracle_rl import setup
+    from gen_listener_golden import make_cfg as listener_cfg
+    from d3net_amd.captioning_loss import compute_cap_loss
+    from d3net_amd.listener import ListenerNet, get_grounding_loss, get_lobjcls_loss
+    from d3net_amd.pipeline import PipelineNet
+    from d3net_amd.speaker import TopDownSceneCaptionModule, query_locals_all
+    R, S, g, cfg, vocab, p, lp, d, opt = setup()
+    cap = TopDownSceneCaptionModule(cfg, vocab, S.make_embeddings(), num_proposals=S.K, num_locals=S.L, use_relation=True)
+    cap.load_state_dict(p)
+    cap = cap.to(dev)
+    net = ListenerNet(listener_cfg())
+    net.load_state_dict(lp)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = net.to(dev).train()
+    d = {k: v.to(dev) for k, v in d.items()}
+    d["adjacent_mat"] = query_locals_all(d["proposal_bbox_batched"], d["proposal_batch_mask"], S.L, include_self=False)
+    # beam search alone
+    si = {k: torch.from_numpy(v).to(dev) for k, v in S.step_inputs().items()}
+    done = cap.beam_decode(si["target"], si["obj"], si["mask"], R.BEAM, S.MAXLEN)
+    for n in range(8):
+        for k in range(R.BEAM):
+            l = g["beam/len"][n, k]
+            assert np.array_equal(done[n][k]["seq"].cpu().numpy(), g["beam/seq"][n, k, :l]), (n, k)
+            assert np.allclose(done[n][k]["logps"].detach().cpu().numpy(), g["beam/logps"][n, k, :l], atol=2e-4)
+            assert abs(done[n][k]["p"] - g["beam/p"][n, k]) < 1e-3
+    # the training chain
+    random.seed(5)
+    dd = cap(dict(d), use_tf=True, use_rl=True, is_eval=False, beam_opt={"train_beam_size": R.BEAM, "train_sample_topn": R.TOPN})
+    for n in range(8):
+        for k in range(R.TOPN):
+            l, bl = g["rl/lang_cap_len"][n, k], g["rl/baseline_len"][n, k]
+            assert np.array_equal(dd["lang_cap"][n][k].cpu().numpy(), g["rl/lang_cap"][n, k, :l])
+            assert np.allclose(dd["lang_logprob"][n][k].detach().cpu().numpy(), g["rl/lang_logprob"][n, k, :l], atol=2e-4)
+            assert np.array_equal(dd["baseline_cap"][n][k].cpu().numpy(), g["rl/baseline_cap"][n, k, :bl])
+    assert np.array_equal(dd["assigned_bbox_id_labels"].cpu().numpy(), g["rl/assigned"]) and np.array_equal(dd["good_bbox_masks"].cpu().numpy(), g["rl/good"])
+    dd = PipelineNet.moderator(types.SimpleNamespace(embeddings=cap.embeddings), dd, S.MAXLEN + 2)
+    dd["istrain"] = torch.tensor([1])
+    random.seed(3)
+    dd = net(dd, use_rl=True)
+    for k in ("sampled", "baseline"):
+        for name in ("cluster_ref", "lang_scores"):
+            ref, got = g["lis/%s/%s" % (name, k)], dd[name][k].detach().cpu().numpy()
+            assert np.allclose(got, ref, rtol=1e-3, atol=2e-4), (name, k, float(np.abs(got - ref).max()))
+        assert not dd["cluster_ref"]["baseline"].requires_grad and dd["cluster_ref"]["sampled"].requires_grad
+    _, dd = get_grounding_loss(dd, use_rl=True)
+    _, dd = get_lobjcls_loss(dd, use_rl=True)
+    _, dd = compute_cap_loss(dd, opt)
+    assert np.array_equal(dd["cluster_labels"].cpu().numpy().argmax(-1), g["lis/cluster_labels"])
+    for k in ("ref_loss", "ref_sampled_loss", "ref_baseline_loss", "ref_acc_mean", "ref_baseline_acc", "ref_iou_mean",
+              "best_ious_mean", "lang_loss", "sampled_lang_loss", "baseline_lang_loss", "lang_acc", "lang_baseline_acc",
+              "cap_loss", "cap_acc", "cap_rwd", "loc_rwd", "ttl_rwd", "ref_iou_rate_0.25", "ref_iou_rate_0.5"):
+        ref, got = g["loss/" + k], dd[k].detach().cpu().numpy()
+        assert np.allclose(got, ref, rtol=1e-3, atol=2e-4), (k, float(np.abs(got - ref).max()))
+    (dd["cap_loss"] + dd["ref_loss"] + dd["lang_loss"]).backward()
+    cp, lpn = dict(cap.named_parameters()), dict(net.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/cap/"):
+            ref, got = g[k], cp[k[len("grad/cap/"):]].grad.cpu().numpy()[:32]
+        elif k.startswith("grad/lis/"):
+            ref, got = g[k], lpn[k[len("grad/lis/"):]].grad.cpu().numpy()[:32]
+        else:
+            continue
+        assert np.allclose(got, ref, rtol=5e-3, atol=1e-6 + 2e-3 * np.abs(ref).max()), (k, float(np.abs(got - ref).max()))
+
+
+def test_pipeline_mode3_runs_and_trains(dev):
+    from d3net_amd import synthetic as S
+    from d3net_amd.config import default_conf
+    from d3net_amd.pipeline import PipelineNet
+    Cn, V = 2, 200
+    cfg = default_conf(overrides={
+        "model": {"blocks": [1, 2, 3], "num_graph_steps": 2, "num_locals": 10, "use_relation": True, "use_orientation": True,
+                  "match_type": "Transformer", "use_lang_classifier": True, "use_bidir": False, "num_bbox_class": 18,
+                  "loss_type": "cross_entropy", "no_captioning": False, "no_grounding": False},
+        "data": {"num_des_per_scene": Cn, "max_spk_len": 30, "max_lis_len": 126, "min_iou_threshold": 0.25, "num_ori_bins": 6},
+        "train": {"use_rl": True, "sample_topn": 2, "beam_size": 2}})
+    chunked, organized = S.make_language_corpus(2, chunk=Cn, vocab=V)
+    ds = {"train": types.SimpleNamespace(vocabulary=S.make_vocabulary(V), glove=np.random.default_rng(0).standard_normal((V, 300)).astype(np.float32),
+                                         chunked_data=chunked, organized=organized)}
+    net = PipelineNet(cfg, ds).to(dev).train()
+    assert net.mode == 3
+    net.detector.teacher = True
+    scenes = [S.small_scene(dims=(40, 32, 20), n_boxes=3, seed=s) for s in (3, 4)]
+    spk = S.add_language(S.make_batch(scenes, dev), dev, chunk=Cn, vocab=V)
+    spk["lang_len"] = spk["spk_lang_len"]
+    lis = S.add_language(S.make_batch(scenes, dev), dev, chunk=Cn, vocab=V, seed=9)
+    loss, out = net.training_step([spk, lis])
+    assert torch.isfinite(loss)
+    loss.backward()
+    grads = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    assert any(n.startswith("speaker.caption") and float(g.abs().sum()) > 0 for n, g in grads.items())
+    assert any(n.startswith("listener.match") and float(g.abs().sum()) > 0 for n, g in grads.items())
+    s = out["speaker"]
+    assert len(s["lang_cap"]) == 2 * Cn and len(s["lang_cap"][0]) == 2
+    assert s["lang_feat"]["sampled"].shape == (2 * 2, Cn, 32, 300) and s["cluster_ref"]["sampled"].shape == (2 * 2 * Cn, 128)
+    for k in ("train_score/cap_rwd", "train_score/loc_rwd", "train_score/ttl_rwd", "train_loss/captioning_loss", "train_score/ref_iou_rate_0.5"):
+        assert k in net.logged
+    opt, _ = net.configure_optimizers()
+    opt[0].step()
