@@ -46,6 +46,12 @@ SIGNATURES = {
     "d3_kmap_down_fill": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, i32, vp]),
     "d3_spconv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "d3_spconv_pack_bytes": (sz, [i32, i32, i32]),
+    "d3_spconv_pack": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "d3_spconv_fwd2_nparts": (i32, [i32, i32, i32, i32]),
+    "d3_spconv_fwd2": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "d3_spconv_wgrad2_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "d3_spconv_wgrad2": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),

@@ -21,7 +21,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the indexing / segment kernels must round exactly like the reference's C
 # expressions; kernels that want FMAs ask for them explicitly (fmaf / MFMA).
 CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-            "-Wno-unused-result", "-I" + os.path.join(HERE, "..", "include")]
+            "-Wno-unused-result", "-I" + os.path.join(HERE, "..", "include")] + os.environ.get("D3_CXX_EXTRA", "").split()
 
 
 def _hipcc():

@@ -17,6 +17,7 @@
 // Roofline: HBM.  Algorithmic bytes per launch = 4*(Min*Cin + Mout*Cout) + 4*K*Cin*Cout + 4*Mout*K
 // (features once, weights once, table once); FLOPs = 2*pairs*Cin*Cout, AI 8..56 FLOP/B << 300.
 #include "common.h"
+#include "prof.h"
 
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -33,9 +34,9 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
 // ------------------------------------------------------------------------------ launch timing (bench.py)
 // When enabled, every MFMA convolution launch is bracketed by two HIP events on its own stream and tagged
 // with its algorithmic byte / flop count; d3_prof_collect() resolves them after the timed region.
-#include <vector>
+#include <deque>
 struct ProfRec { hipEvent_t a, b; int family; double bytes, flops; };
-static std::vector<ProfRec> g_prof;
+static std::deque<ProfRec> g_prof;   // stable element addresses
 static size_t g_prof_used = 0;
 static int g_prof_on = 0;
 #define PROF_MAX 200000
@@ -46,7 +47,10 @@ extern "C" int d3_prof_enable(int on) {
     g_prof_used = 0;
     return 0;
 }
+#include <mutex>
+static std::mutex g_prof_mu;
 static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof_used >= PROF_MAX) return nullptr;
     if (g_prof_used == g_prof.size()) {
         ProfRec r;
@@ -59,6 +63,8 @@ static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s
     return r;
 }
 static void prof_end(ProfRec *r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
+void *d3_prof_begin(int family, double bytes, double flops, hipStream_t s) { return prof_begin(family, bytes, flops, s); }
+void d3_prof_end(void *rec, hipStream_t s) { prof_end((ProfRec *)rec, s); }
 // family: 0 = spconv_fwd_mfma (forward + data gradient), 1 = spconv_wgrad_mfma
 extern "C" int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes,
                                double *total_flops) {

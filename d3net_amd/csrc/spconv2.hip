@@ -1,0 +1,780 @@
+// spconv2.hip -- second-generation sparse convolution kernels for gfx950: wave-autonomous gather -> MFMA.
+//
+// Same contraction as spconv.hip (MinkowskiConvolution / MinkowskiConvolutionTranspose forward and data gradient,
+// reference call sites model/common.py:32,38,41,66,90,98; model/pointgroup.py:70):
+//
+//   out[u,:] = sum_k x[tbl[u,k],:] @ W[k]   (+ res[u,:])        tbl: dense (Mout,K) kernel map (coordmap.hip)
+//
+// Design (what changed against spconv.hip, and why -- profiles/r01_h: the 64-row LDS-staged tile spends one barrier
+// and one LDS round trip per (offset, 32 channels) to feed a single 16x16x16 MFMA at C=16):
+//   * a WAVE owns a 16-row output tile.  The MFMA A operand (16 rows x 32 reduction elements, 8 bf16 per lane) is
+//     gathered straight from HBM/L2 into registers: lane (r = lane&15, g = lane>>4) loads 16 bytes (8 channels) of
+//     input row tbl[row0+r][k]; no LDS staging of activations, no workgroup barrier in the main loop.
+//   * the reduction index is the flattened list of (active offset, 8-channel group) "slots"; one
+//     v_mfma_f32_16x16x32_bf16 consumes four slots (one per lane group), so Cin=16 packs two offsets into one MFMA
+//     and offsets unused by the 16-row tile cost nothing (4x finer skipping than a 64-row tile).
+//   * weights are pre-packed once per step into bf16 MFMA-B fragment order (d3_spconv_pack); a fragment is one
+//     contiguous 16-byte read per lane, from LDS when the layer's weights fit (big levels, persistent workgroups)
+//     or from L2 (deep levels).
+//   * few-row levels: the waves of a workgroup split the slots of ONE tile and reduce through LDS -- no atomics,
+//     no zero fill, deterministic, and the complete tile is available to the epilogue.
+//   * epilogue fusions: residual add, accumulate-into, strided output (writes straight into a concatenated
+//     buffer) and per-channel sum / sum-of-squares partials for the following BatchNorm.
+// Roofline: HBM; algorithmic bytes per launch as in spconv.hip.
+#include "common.h"
+#include "prof.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short f2bf2(float f) {  // round to nearest even (finite inputs)
+    unsigned int u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack2bf2(float lo, float hi) {
+    return (unsigned int)f2bf2(lo) | ((unsigned int)f2bf2(hi) << 16);
+}
+
+#define C2_MAXK 27
+#ifndef C2_UBIG
+#define C2_UBIG 8
+#endif
+#ifndef C2_OCC_SMALL
+#define C2_OCC_SMALL 4
+#endif
+#define C2_U(NTV) ((NTV) <= 2 ? C2_UBIG : 4)   // MFMA steps whose gathers are issued together
+
+// ------------------------------------------------------------------------------ weight packing
+// Wp[((k*S + c8)*NT + n)*16 + col][8] = bf16(Weff[k][c8*8 + j][n*16 + col]),  Weff = W[flipk ? K-1-k : k] (or its
+// transpose when W is laid out (K, Cout, Cin)); columns >= Cout are zero.
+__global__ void spconv_pack_kernel(const float *__restrict__ W, uint4 *__restrict__ Wp, int K, int Cin, int Cout,
+                                   int NT, int flipk, int transw) {
+    const int S = Cin >> 3;
+    const long long total = (long long)K * S * NT * 16;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int col = (int)(e & 15);
+    const int n = (int)((e >> 4) % NT);
+    const int c8 = (int)((e / (16 * NT)) % S);
+    const int k = (int)(e / ((long long)16 * NT * S));
+    const int co = n * 16 + col, wk = flipk ? (K - 1 - k) : k;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int ci = c8 * 8 + j;
+        v[j] = 0.f;
+        if (co < Cout) v[j] = transw ? W[((long long)wk * Cout + co) * Cin + ci] : W[((long long)wk * Cin + ci) * Cout + co];
+    }
+    Wp[e] = make_uint4(pack2bf2(v[0], v[1]), pack2bf2(v[2], v[3]), pack2bf2(v[4], v[5]), pack2bf2(v[6], v[7]));
+}
+
+extern "C" size_t d3_spconv_pack_bytes(int K, int Cin, int Cout) {
+    return (size_t)K * (Cin / 8) * ((Cout + 15) / 16) * 256;
+}
+
+extern "C" int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream) {
+    D3_CLEAR();
+    if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1) return D3_ERR_ARG;
+    const int NT = (Cout + 15) / 16;
+    const long long total = (long long)K * (Cin / 8) * NT * 16;
+    spconv_pack_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(
+        W, (uint4 *)Wp, K, Cin, Cout, NT, (flags & D3_CONV_FLIPK) ? 1 : 0, (flags & D3_CONV_TRANSW) ? 1 : 0);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ forward / data gradient
+struct Conv2Args {
+    const void *x;              // (Min, ldx) fp32 or bf16
+    const int *tbl;             // (Mout, K) or NULL (identity, K = 1)
+    const unsigned short *Wp;   // packed bf16 fragments
+    float *out;                 // (Mout, ldo)
+    const float *res;           // optional residual (Mout, ldr), added before the store
+    float *part;                // optional BatchNorm partials: [nparts][2][NT*16] (sum, sum of squares per column)
+    int ldx, ldo, ldr;
+    int Mout, K, Cout, S;       // S = Cin / 8 slots per offset
+    unsigned int inv;           // ceil(65536 / S): i = (s * inv) >> 16 == s / S for s < 4096
+    int xbf16, accum, ntiles, NT;   // NT = ceil(Cout / 16)
+    unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
+};
+
+__device__ __forceinline__ bf16x8_t c2_zero() {
+    uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    return __builtin_bit_cast(bf16x8_t, z);
+}
+__device__ __forceinline__ bf16x8_t c2_load_a(const void *x, int xbf16, long long off) {
+    if (xbf16) {
+        uint4 v = *(const uint4 *)((const unsigned short *)x + off);
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+    const float4 f0 = *(const float4 *)((const float *)x + off);
+    const float4 f1 = *(const float4 *)((const float *)x + off + 4);
+    uint4 v = make_uint4(pack2bf2(f0.x, f0.y), pack2bf2(f0.z, f0.w), pack2bf2(f1.x, f1.y), pack2bf2(f1.z, f1.w));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// LDS use of the wave-per-tile kernel besides the weights
+#define C2_TBL_INTS (16 * C2_MAXK)
+#define C2_WAVE_LDS_BYTES(NTV) (4 * C2_TBL_INTS * 4 + 4 * 32 * 4 + 4 * 2 * (NTV) * 16 * 4)
+
+// Wave-per-tile kernel (big levels): 256 threads = 4 independent waves, persistent over a contiguous range of
+// 4-tile groups (XCD-contiguous: block b runs on XCD b % 8, so XCD x gets the x-th eighth of the rows and the
+// neighbour rows its tiles gather stay in that XCD's L2).
+// Every dependent global access of a wave is a full L2/HBM round trip and the MFMA work between them is tiny, so the
+// kernel is organised around round trips, not FLOPs: (1) the kernel-map rows of the NEXT tile are prefetched into
+// registers while the current tile computes; (2) all gathers of a batch are issued before the first MFMA; (3) no
+// per-tile offset mask / compaction (its shuffle + LDS chain cost more than the skipped MFMAs: a 16-row tile uses
+// nearly all offsets) -- absent neighbours simply gather nothing; (4) the MFMA is issued TRANSPOSED (A = weights,
+// B = gathered rows), so a lane ends up with 4 consecutive output channels of one row: the tile is stored (and the
+// residual read) as one contiguous float4 per lane instead of four 64-byte row fragments.
+#define C2_OCC(NTV) ((NTV) <= 4 ? C2_OCC_SMALL : (NTV) <= 9 ? 3 : 2)
+template <int NT, bool WLDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT), 8))) void spconv_fwd2_kernel(const Conv2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int U = C2_U(NT);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
+    const int K = a.K, S = a.S;
+    const size_t wbytes = WLDS ? (size_t)K * S * NT * 256 : 0;
+    int *tblS = (int *)(smem + wbytes) + wave * C2_TBL_INTS;
+    float *redS = (float *)(smem + wbytes + 4 * C2_TBL_INTS * 4);
+    const unsigned short *Wb = WLDS ? (const unsigned short *)smem : a.Wp;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int lb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const int ntg = (a.ntiles + 3) >> 2;
+    const int per = (ntg + nb - 1) / nb;
+    const int tg0 = lb * per, tg1 = min(ntg, tg0 + per);
+    int v[7];
+#define C2_LOAD_TBL(TILE)                                                                                     \
+    {                                                                                                         \
+        const int tile_ = (TILE);                                                                             \
+        const long long base_ = (long long)tile_ * 16 * K, lim_ = (long long)a.Mout * K;                      \
+        _Pragma("unroll") for (int it = 0; it < 7; it++) {                                                    \
+            const int e = lane + it * 64;                                                                     \
+            v[it] = -1;                                                                                       \
+            if (tile_ < a.ntiles && e < 16 * K && base_ + e < lim_) v[it] = a.tbl ? a.tbl[base_ + e] : (int)(base_ + e); \
+        }                                                                                                     \
+    }
+    C2_LOAD_TBL(tg0 * 4 + wave)
+    if (WLDS) {
+        const uint4 *src = (const uint4 *)a.Wp;
+        uint4 *dst = (uint4 *)smem;
+        const int n16 = (int)(wbytes >> 4);
+        for (int i0 = 0; i0 < n16; i0 += 1024) {
+            uint4 w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = i0 + q * 256 + t; w4[q] = make_uint4(0u, 0u, 0u, 0u); if (i < n16) w4[q] = src[i]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = i0 + q * 256 + t; if (i < n16) dst[i] = w4[q]; }
+        }
+        __syncthreads();
+    }
+    f32x4 ssum[NT], ssq[NT];   // per lane: its row's values, channels n*16 + g*4 + q
+#pragma unroll
+    for (int n = 0; n < NT; n++) { ssum[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int nsteps = (K * S + 3) >> 2;
+
+    for (int tg = tg0; tg < tg1; tg++) {
+        const int tile = tg * 4 + wave;
+        if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
+        const int row0 = tile * 16;
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const int e = lane + it * 64;
+            if (e < 16 * K) tblS[e] = v[it];
+        }
+        if (tg + 1 < tg1) C2_LOAD_TBL(tile + 4)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m0 = 0; m0 < nsteps; m0 += U) {
+            bf16x8_t A[U];
+            int boff[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = 4 * (m0 + u) + g;
+                const int k = (int)(((unsigned int)s * a.inv) >> 16);
+                const int c8 = s - k * S;
+                const bool ok = (m0 + u < nsteps) && (k < K);
+                const int idx = ok ? tblS[r * K + k] : -1;
+                boff[u] = ok ? (((k * S + c8) * NT) * 16 + r) * 8 : r * 8;
+                A[u] = c2_zero();
+                if (idx >= 0) A[u] = c2_load_a(a.x, a.xbf16, (long long)idx * a.ldx + c8 * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (m0 + u < nsteps) {   // wave-uniform
+#pragma unroll
+                    for (int n = 0; n < NT; n++) {
+                        const uint4 bv = *(const uint4 *)(Wb + boff[u] + n * 128);
+                        // transposed product: D[m = channel][n = row] += W^T[channel][k] * X^T[k][row]
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), A[u], acc[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // D layout: column (= output row) lane & 15, rows (= channels) (lane >> 4) * 4 + q
+        {
+            const int u = row0 + r;
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const int col = n * 16 + g * 4;
+                if (u < a.Mout && col < a.Cout) {   // Cout % 4 == 0 (checked on the host)
+                    f32x4 vv = acc[n];
+                    if (a.res) { const f32x4 rr = *(const f32x4 *)(a.res + (long long)u * a.ldr + col); vv += rr; }
+                    f32x4 *o = (f32x4 *)(a.out + (long long)u * a.ldo + col);
+                    if (a.accum) vv += *o;
+                    *o = vv;
+                    ssum[n] += vv; ssq[n] += vv * vv;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // tblS is rewritten by the next tile
+    }
+#undef C2_LOAD_TBL
+    if (a.part) {   // per-workgroup BatchNorm partials (fixed order: deterministic)
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float s1 = ssum[n][q], s2 = ssq[n][q];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (r == 0) { redS[wave * 2 * NT * 16 + n * 16 + g * 4 + q] = s1; redS[wave * 2 * NT * 16 + NT * 16 + n * 16 + g * 4 + q] = s2; }
+            }
+        }
+        __syncthreads();
+        if (t < 2 * NT * 16) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) s += redS[w * 2 * NT * 16 + t];
+            a.part[(long long)b * 2 * NT * 16 + t] = s;
+        }
+    }
+}
+
+// Workgroup-per-tile kernel (few-row levels): grid = (16-row tiles, column groups of NTW 16-wide tiles).  The
+// W = blockDim.x/64 waves split the MFMA steps of the tile, their accumulators are summed through LDS in wave order,
+// and the workgroup owns complete output columns: no atomics, no cross-workgroup reduction, deterministic.
+template <int NTW>
+__global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args a) {
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
+    const int W = blockDim.x >> 6, K = a.K, S = a.S;
+    int *tblS = (int *)smem;                         // 16*27 ints
+    int *actS = tblS + C2_TBL_INTS;                  // 32 ints
+    unsigned int *kmaskS = (unsigned int *)(actS + 32);   // 1 (+3 pad)
+    float *redS = (float *)(kmaskS + 4);             // W * NTW*256 floats
+    float *finS = redS + (size_t)W * NTW * 256;      // 16 x NTW*16
+    const int row0 = blockIdx.x * 16, n0 = blockIdx.y * NTW;
+    if (t == 0) *kmaskS = 0u;
+    __syncthreads();
+    {
+        unsigned int bits = 0u;
+        const long long base = (long long)row0 * K, lim = (long long)a.Mout * K;
+        int v[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {   // blockDim.x >= 256 and 16*K <= 432
+            const int e = t + it * blockDim.x;
+            v[it] = -1;
+            if (e < 16 * K && base + e < lim) v[it] = a.tbl ? a.tbl[base + e] : (int)(base + e);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int e = t + it * blockDim.x;
+            if (e < 16 * K) {
+                tblS[e] = v[it];
+                if (v[it] >= 0) bits |= 1u << (e - (int)(((unsigned int)e * a.invK) >> 16) * K);
+            }
+        }
+        if (bits) atomicOr(kmaskS, bits);
+    }
+    __syncthreads();
+    const unsigned int kmask = *kmaskS;
+    const int na = __popc(kmask);
+    if (t < K && ((kmask >> t) & 1u)) actS[__popc(kmask & ((1u << t) - 1u))] = t;
+    __syncthreads();
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nsteps = (na * S + 3) >> 2;
+    for (int m0 = wave; m0 < nsteps; m0 += W * U) {
+        bf16x8_t A[U];
+        int boff[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int m = m0 + u * W;
+            const int s = 4 * m + g;
+            const int i = (int)(((unsigned int)s * a.inv) >> 16);
+            const int c8 = s - i * S;
+            const bool ok = (m < nsteps) && (i < na);
+            const int k = actS[ok ? i : 0];
+            const int idx = ok ? tblS[r * K + k] : -1;
+            boff[u] = (((k * S + (ok ? c8 : 0)) * a.NT + n0) * 16 + r) * 8;
+            A[u] = c2_zero();
+            if (idx >= 0) A[u] = c2_load_a(a.x, a.xbf16, (long long)idx * a.ldx + c8 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (m0 + u * W < nsteps) {
+#pragma unroll
+                for (int n = 0; n < NTW; n++) {
+                    if (n0 + n < a.NT) {
+                        const uint4 bv = *(const uint4 *)(a.Wp + boff[u] + n * 128);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[u], __builtin_bit_cast(bf16x8_t, bv), acc[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NTW; n++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) redS[(wave * NTW * 4 + n * 4 + q) * 64 + lane] = acc[n][q];
+    __syncthreads();
+    // final tile: element e = row * CW + col (CW = NTW*16 columns of this workgroup), summed in wave order
+    constexpr int CW = NTW * 16;
+    for (int e = t; e < 16 * CW; e += blockDim.x) {
+        const int row = e / CW, cl = e - row * CW;
+        const int n = cl >> 4, ln = (row >> 2) * 16 + (cl & 15), q = row & 3;
+        float v = 0.f;
+        for (int w = 0; w < W; w++) v += redS[(w * NTW * 4 + n * 4 + q) * 64 + ln];
+        const int u = row0 + row, col = n0 * 16 + cl;
+        if (u < a.Mout && col < a.Cout) {
+            if (a.res) v += a.res[(long long)u * a.ldr + col];
+            float *o = a.out + (long long)u * a.ldo + col;
+            if (a.accum) v += *o;
+            *o = v;
+        } else v = 0.f;
+        finS[e] = v;
+    }
+    if (a.part) {
+        __syncthreads();
+        if (t < 2 * CW) {
+            const int cl = (t < CW) ? t : t - CW;
+            float s = 0.f;
+            for (int row = 0; row < 16; row++) { const float v = finS[row * CW + cl]; s += (t < CW) ? v : v * v; }
+            if (n0 * 16 + cl < a.NT * 16)
+                a.part[(long long)blockIdx.x * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl] = s;
+        }
+    }
+}
+
+struct Conv2Plan { int split, W, grid, wlds, ntw, gy; size_t lds; };
+
+static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout) {
+    Conv2Plan p;
+    const int NT = (Cout + 15) / 16, ntiles = (Mout + 15) / 16;
+    const size_t wbytes = (size_t)K * (Cin / 8) * NT * 256;
+    p.ntw = NT; p.gy = 1;
+    if (ntiles >= 1024) {
+        p.split = 0; p.W = 1;
+        const int ntg = (ntiles + 3) / 4;
+        const int per = (ntg + 2047) / 2048;
+        p.grid = (ntg + per - 1) / per;
+        p.wlds = (wbytes + C2_WAVE_LDS_BYTES(NT) <= 72 * 1024) ? 1 : 0;
+        p.lds = (p.wlds ? wbytes : 0) + C2_WAVE_LDS_BYTES(NT);
+    } else {
+        p.split = 1; p.grid = ntiles; p.wlds = 0;
+        // few tiles: one column tile per workgroup (the gather is repeated per column group, from L2)
+        if (ntiles < 256) p.ntw = 1; else if (NT > 4) p.ntw = (NT + 1) / 2;
+        if (p.ntw > 7) p.ntw = 7;
+        p.gy = (NT + p.ntw - 1) / p.ntw;
+        const int steps = K * (Cin / 8) / 4 + 1;     // upper bound of MFMA steps per tile
+        int W = ntiles * p.gy >= 512 ? 4 : 8;
+        if (ntiles * p.gy < 128) W = 16;
+        while (W > 4 && W * 2 > steps) W >>= 1;
+        p.W = W;
+        p.lds = (size_t)(C2_TBL_INTS + 32 + 4) * 4 + (size_t)W * p.ntw * 1024 + (size_t)p.ntw * 1024;
+    }
+    return p;
+}
+
+extern "C" int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout) {
+    return conv2_plan(Mout, K, Cin, Cout).grid;
+}
+
+template <int NT>
+static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {   // allow more than 64 KB of dynamic LDS
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_done = true;
+    }
+    if (p.wlds) spconv_fwd2_kernel<NT, true><<<p.grid, 256, p.lds, s>>>(a);
+    else spconv_fwd2_kernel<NT, false><<<p.grid, 256, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+template <int NTW>
+static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    spconv_fwd2_split_kernel<NTW><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo,
+                              const float *res, int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout,
+                              int flags, void *stream) {
+    D3_CLEAR();
+    if (Mout <= 0) return 0;
+    if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
+    if (tbl == nullptr && K != 1) return D3_ERR_ARG;
+    const int xbf16 = (flags & D3_CONV_XBF16) ? 1 : 0;
+    if ((xbf16 && (ldx & 7)) || (!xbf16 && (ldx & 3)) || ldx < Cin || ldo < Cout) return D3_ERR_ARG;
+    if ((Cout & 3) || (ldo & 3) || (res && (ldr & 3))) return D3_ERR_ARG;   // float4 epilogue
+    hipStream_t s = d3_stream(stream);
+    Conv2Args a;
+    a.x = x; a.tbl = tbl; a.Wp = (const unsigned short *)Wp; a.out = out; a.res = res; a.part = part;
+    a.ldx = ldx; a.ldo = ldo; a.ldr = ldr; a.Mout = Mout; a.K = K; a.Cout = Cout; a.S = Cin / 8;
+    a.inv = (65536u + a.S - 1) / a.S;
+    a.invK = (65536u + K - 1) / K;
+    a.xbf16 = xbf16; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
+    const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
+    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + 2.0 * (double)K * Cin * Cout +
+                         (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
+    void *pr = d3_prof_begin(0, bytes, 2.0 * 0.0, s);
+    int rc;
+    a.NT = (Cout + 15) / 16;
+    if (p.split) {
+        switch (p.ntw) {
+            case 1: rc = launch_fwd2_split<1>(a, p, s); break;
+            case 2: rc = launch_fwd2_split<2>(a, p, s); break;
+            case 3: rc = launch_fwd2_split<3>(a, p, s); break;
+            case 4: rc = launch_fwd2_split<4>(a, p, s); break;
+            case 5: rc = launch_fwd2_split<5>(a, p, s); break;
+            case 6: rc = launch_fwd2_split<6>(a, p, s); break;
+            default: rc = launch_fwd2_split<7>(a, p, s); break;
+        }
+        d3_prof_end(pr, s);
+        return rc;
+    }
+#define C2_CASE(NTV) case NTV: rc = launch_fwd2<NTV>(a, p, s); break;
+    switch ((Cout + 15) / 16) {
+        C2_CASE(1) C2_CASE(2) C2_CASE(3) C2_CASE(4) C2_CASE(5) C2_CASE(6) C2_CASE(7) C2_CASE(8) C2_CASE(9)
+        C2_CASE(10) C2_CASE(11) C2_CASE(12) C2_CASE(13) C2_CASE(14)
+        default: rc = D3_ERR_ARG;
+    }
+#undef C2_CASE
+    d3_prof_end(pr, s);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ weight gradient
+// dW[k] = sum_u x[tbl[u,k],:]^T dy[u,:].  One operand is read contiguously ("stationary": rows u of the table),
+// the other is gathered through the table; the host gathers the narrower one (the gather is re-done per offset).
+//   P[k] (Cg x Cs) = sum_rows G[tbl[row,k],:]^T S[row,:]       MFMA: M = gathered channel, N = stationary channel,
+//                                                               reduction = 32 rows per v_mfma_f32_16x16x32_bf16
+// Both MFMA operands need 8 consecutive ROWS per lane, i.e. columns of the row-major matrices: each wave stages its
+// 32-row chunk transposed in a private LDS region (St once per chunk, shared by all offsets of the pass -- the
+// spconv.hip kernel re-read dy once per offset: profiles/r01_h, 85 MB of traffic against 8 MB algorithmic).
+// grid = (row splits R, offset groups, tile passes).  A wave keeps 16 accumulator tiles: OPW = 16/TPO offsets x
+// TPO tiles per offset; the 4 waves of a workgroup take alternate chunks and are summed through LDS in wave order;
+// with R > 1 the workgroup writes a partial dW that wgrad2_reduce_kernel sums in split order (deterministic; no
+// atomics).
+#define WG2_LDT 40      // shorts per transposed LDS row: 32 rows + 8 pad (80 B)
+#define WG2_T 16        // accumulator tiles per wave (64 AGPRs): occupancy matters more than reuse here
+
+struct Wg2Args {
+    const void *G; const void *Sm; const int *tbl; float *dst;
+    int ldg, lds, gbf16, sbf16;
+    int Ms, K, mt, nt;          // mt / nt: 16-channel tiles of the gathered / stationary operand
+    int Cg8, Cs8;               // 8-channel units per row
+    unsigned int invg, invs;    // ceil(65536 / Cg8), ceil(65536 / Cs8)
+    int cpw;                    // chunks per workgroup
+    int gx, flipk, Cin, Cout;   // gx: the gathered operand is x (P = dW[k]); else it is dy (P = dW[k]^T)
+};
+
+__device__ __forceinline__ uint4 wg2_load8(const void *p, int bf16, long long off) {
+    if (bf16) return *(const uint4 *)((const unsigned short *)p + off);
+    const float4 f0 = *(const float4 *)((const float *)p + off);
+    const float4 f1 = *(const float4 *)((const float *)p + off + 4);
+    return make_uint4(pack2bf2(f0.x, f0.y), pack2bf2(f0.z, f0.w), pack2bf2(f1.x, f1.y), pack2bf2(f1.z, f1.w));
+}
+__device__ __forceinline__ void wg2_store_t(unsigned short *T, int c8, int row, uint4 v) {
+    unsigned short *d = T + (c8 * 8) * WG2_LDT + row;
+    d[0 * WG2_LDT] = (unsigned short)(v.x & 0xFFFFu); d[1 * WG2_LDT] = (unsigned short)(v.x >> 16);
+    d[2 * WG2_LDT] = (unsigned short)(v.y & 0xFFFFu); d[3 * WG2_LDT] = (unsigned short)(v.y >> 16);
+    d[4 * WG2_LDT] = (unsigned short)(v.z & 0xFFFFu); d[5 * WG2_LDT] = (unsigned short)(v.z >> 16);
+    d[6 * WG2_LDT] = (unsigned short)(v.w & 0xFFFFu); d[7 * WG2_LDT] = (unsigned short)(v.w >> 16);
+}
+
+template <int TPO, int NU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NU <= 2 ? 3 : NU <= 7 ? 2 : 1, 8))) void spconv_wgrad2_kernel(const Wg2Args a) {
+    constexpr int OPW = WG2_T / TPO;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
+    const int K = a.K;
+    // per-wave LDS: Gt (mt*16 x LDT), St (nt*16 x LDT) bf16, table chunk 32*K ints
+    const size_t wave_bytes = (size_t)(a.mt + a.nt) * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4;
+    unsigned short *Gt = (unsigned short *)(smem + (size_t)wave * wave_bytes);
+    unsigned short *St = Gt + (size_t)a.mt * 16 * WG2_LDT;
+    int *tblW = (int *)(St + (size_t)a.nt * 16 * WG2_LDT);
+    const int k0 = blockIdx.y * OPW;
+    const int tile0 = blockIdx.z * TPO, ntl = a.mt * a.nt;
+    const int nchunks = (a.Ms + 31) >> 5;
+    const int c_begin = blockIdx.x * a.cpw, c_end = min(nchunks, c_begin + a.cpw);
+
+    f32x4 acc[OPW][TPO];
+#pragma unroll
+    for (int j = 0; j < OPW; j++)
+#pragma unroll
+        for (int i = 0; i < TPO; i++) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+        const int u0 = c * 32;
+        // table chunk (32 rows x K, contiguous) -> LDS
+        if (a.tbl) {   // loads first, LDS stores after (a rolled loop would serialise one round trip per pass)
+            const long long base = (long long)u0 * K, lim = (long long)a.Ms * K;
+            int v[14];
+#pragma unroll
+            for (int it = 0; it < 14; it++) {
+                const int e = lane + it * 64;
+                v[it] = -1;
+                if (e < 32 * K && base + e < lim) v[it] = a.tbl[base + e];
+            }
+#pragma unroll
+            for (int it = 0; it < 14; it++) {
+                const int e = lane + it * 64;
+                if (e < 32 * K) tblW[e] = v[it];
+            }
+        }
+        // stationary rows, transposed (batches of 4 units per lane in flight)
+        for (int ub = 0; ub < 32 * a.Cs8; ub += 256) {
+            uint4 sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int unit = ub + q * 64 + lane;
+                sv[q] = make_uint4(0u, 0u, 0u, 0u);
+                if (unit < 32 * a.Cs8) {
+                    const int row = (int)(((unsigned int)unit * a.invs) >> 16), c8 = unit - row * a.Cs8;
+                    if (u0 + row < a.Ms) sv[q] = wg2_load8(a.Sm, a.sbf16, (long long)(u0 + row) * a.lds + c8 * 8);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int unit = ub + q * 64 + lane;
+                if (unit < 32 * a.Cs8) {
+                    const int row = (int)(((unsigned int)unit * a.invs) >> 16), c8 = unit - row * a.Cs8;
+                    wg2_store_t(St, c8, row, sv[q]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // offsets in groups of PF: the gathers of a group are issued together (memory-level parallelism -- every
+        // offset is one dependent LDS -> L2/HBM -> LDS -> MFMA chain, and the MFMA work per offset is tiny)
+        constexpr int PF = NU == 1 ? 4 : NU == 2 ? 2 : 1;
+        uint4 pre[PF][NU];
+        bool pre_any[PF];
+#pragma unroll
+        for (int j0 = 0; j0 < OPW; j0 += PF) {
+#pragma unroll
+            for (int pf = 0; pf < PF; pf++) {
+                const int k = k0 + j0 + pf;
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < NU; q++) {
+                    const int unit = lane + q * 64;
+                    pre[pf][q] = make_uint4(0u, 0u, 0u, 0u);
+                    if (j0 + pf < OPW && k < K && unit < 32 * a.Cg8) {
+                        const int row = (int)(((unsigned int)unit * a.invg) >> 16), c8 = unit - row * a.Cg8;
+                        int idx = -1;
+                        if (u0 + row < a.Ms) idx = a.tbl ? tblW[row * K + k] : (u0 + row);
+                        if (idx >= 0) { pre[pf][q] = wg2_load8(a.G, a.gbf16, (long long)idx * a.ldg + c8 * 8); any = true; }
+                    }
+                }
+                pre_any[pf] = __any(any) != 0;
+            }
+#pragma unroll
+            for (int pf = 0; pf < PF; pf++) {
+                const int j = j0 + pf;
+                if (j < OPW && k0 + j < K && pre_any[pf]) {   // uniform
+#pragma unroll
+                    for (int q = 0; q < NU; q++) {
+                        const int unit = lane + q * 64;
+                        if (unit < 32 * a.Cg8) {
+                            const int row = (int)(((unsigned int)unit * a.invg) >> 16), c8 = unit - row * a.Cg8;
+                            wg2_store_t(Gt, c8, row, pre[pf][q]);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int i = 0; i < TPO; i++) {
+                        const int tile = tile0 + i;
+                        if (tile < ntl) {   // uniform
+                            const int mi = tile / a.nt, ni = tile - mi * a.nt;
+                            const uint4 av = *(const uint4 *)&Gt[(mi * 16 + r) * WG2_LDT + g * 8];
+                            const uint4 bv = *(const uint4 *)&St[(ni * 16 + r) * WG2_LDT + g * 8];
+                            acc[j < OPW ? j : 0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc[j < OPW ? j : 0][i], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // St / tblW are rewritten by the next chunk
+    }
+    // sum the four waves through LDS (8 tiles per round) and store
+    __syncthreads();
+    float *red = (float *)smem;   // 4 waves x 8 tiles x 256 floats = 32 KB
+    const long long wsz = (long long)K * a.Cin * a.Cout;
+    float *dst = a.dst + (long long)blockIdx.x * wsz;
+#pragma unroll
+    for (int rd = 0; rd < WG2_T / 8; rd++) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; q8++) {
+            const int f = rd * 8 + q8, j = f / TPO, i = f % TPO;
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[((wave * 8 + q8) * 4 + q) * 64 + lane] = acc[j][i][q];
+        }
+        __syncthreads();
+        // wave w finishes tiles 2w, 2w+1 of the round
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int q8 = wave * 2 + h, f = rd * 8 + q8, j = f / TPO, i = f % TPO;
+            const int k = k0 + j, tile = tile0 + i;
+            if (k < K && tile < ntl) {
+                const int mi = tile / a.nt, ni = tile - mi * a.nt;
+                const int wk = a.flipk ? (K - 1 - k) : k;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) v += red[((w * 8 + q8) * 4 + q) * 64 + lane];
+                    const int cg = mi * 16 + g * 4 + q, cs = ni * 16 + r;
+                    const int ci = a.gx ? cg : cs, co = a.gx ? cs : cg;
+                    if (ci < a.Cin && co < a.Cout) dst[((long long)wk * a.Cin + ci) * a.Cout + co] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dW[e] = sum_r part[r][e]: 32 elements x 8 split groups per workgroup; group sums are combined in group order
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, long long n, int R, int accum) {
+    __shared__ float sh[8][32];
+    const int el = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long long e = (long long)blockIdx.x * 32 + el;
+    float v = 0.f;
+    if (e < n)
+        for (int r = rg; r < R; r += 8) v += part[(long long)r * n + e];
+    sh[rg][el] = v;
+    __syncthreads();
+    if (rg == 0 && e < n) {
+        float s = accum ? dW[e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += sh[q][el];
+        dW[e] = s;
+    }
+}
+
+struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw; size_t lds, ws_bytes; };
+
+static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
+    Wg2Plan p;
+    const int mt = (Cg + 15) / 16, nt = (Cs + 15) / 16, ntl = mt * nt;
+    p.tpo = ntl <= 1 ? 1 : ntl <= 2 ? 2 : ntl <= 4 ? 4 : ntl <= 8 ? 8 : 16;
+    p.nu = (Cg / 8 * 32 + 63) / 64;    // 16-byte units per lane per offset
+    p.opw = WG2_T / p.tpo;
+    p.kg = (K + p.opw - 1) / p.opw;
+    p.passes = (ntl + p.tpo - 1) / p.tpo;
+    const int nchunks = (Ms + 31) / 32;
+    // row splits: ~2048 waves in flight, at least 2 chunks per wave, partial buffer <= 8 MB
+    const long long wsz = (long long)K * Cin * Cout * 4;
+    int R = 512 / (p.kg * p.passes); if (R < 1) R = 1;
+    const int maxR_rows = (nchunks + 7) / 8; if (R > maxR_rows) R = maxR_rows;
+    const long long maxR_mem = (8ll << 20) / wsz; if (R > maxR_mem) R = (int)maxR_mem;
+    if (R < 1) R = 1;
+    p.cpw = (nchunks + R - 1) / R;
+    p.cpw = (p.cpw + 3) / 4 * 4;
+    p.R = (nchunks + p.cpw - 1) / p.cpw;
+    const size_t wave_bytes = (size_t)(mt + nt) * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4;
+    p.lds = 4 * wave_bytes; if (p.lds < 32 * 1024) p.lds = 32 * 1024;
+    p.ws_bytes = p.R > 1 ? (size_t)p.R * wsz : 0;
+    return p;
+}
+
+extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags) {
+    const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0;
+    return wg2_plan(xstat ? Min : Mout, K, xstat ? Cout : Cin, xstat ? Cin : Cout, Cin, Cout).ws_bytes;
+}
+
+template <int TPO, int NU>
+static int launch_wg2(const Wg2Args &a, const Wg2Plan &p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_kernel<TPO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    spconv_wgrad2_kernel<TPO, NU><<<dim3(p.R, p.kg, p.passes), 256, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// x (Min, ldx) and dy (Mout, ldy), each fp32 or bf16 (D3_CONV_XBF16 / D3_CONV_DYBF16); tbl as for d3_spconv_wgrad
+// (the forward map, or with D3_CONV_XSTAT the transposed map); dW (K,Cin,Cout) fp32, written (or accumulated into
+// with D3_CONV_ACCUM).  ws >= d3_spconv_wgrad2_ws_bytes().  Cin % 8 == 0 and Cout % 8 == 0, else D3_ERR_ARG.
+extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min,
+                                int Mout, int K, int Cin, int Cout, int flags, void *ws, size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (K < 1 || K > C2_MAXK || Cin < 8 || Cout < 8 || (Cin & 7) || (Cout & 7) || Cin > 224 || Cout > 224) return D3_ERR_ARG;
+    if (tbl == nullptr && K != 1) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0, accum = (flags & D3_CONV_ACCUM) ? 1 : 0;
+    const int xbf = (flags & D3_CONV_XBF16) ? 1 : 0, dybf = (flags & D3_CONV_DYBF16) ? 1 : 0;
+    if ((xbf ? (ldx & 7) : (ldx & 3)) || (dybf ? (ldy & 7) : (ldy & 3))) return D3_ERR_ARG;
+    const long long wn = (long long)K * Cin * Cout;
+    const int Ms = xstat ? Min : Mout;
+    if (Ms <= 0) { if (!accum) D3_CHECK(hipMemsetAsync(dW, 0, wn * 4, s)); return 0; }
+    Wg2Args a;
+    if (xstat) { a.Sm = x; a.lds = ldx; a.sbf16 = xbf; a.G = dy; a.ldg = ldy; a.gbf16 = dybf; a.gx = 0; }
+    else { a.Sm = dy; a.lds = ldy; a.sbf16 = dybf; a.G = x; a.ldg = ldx; a.gbf16 = xbf; a.gx = 1; }
+    const int Cg = xstat ? Cout : Cin, Cs = xstat ? Cin : Cout;
+    const Wg2Plan p = wg2_plan(Ms, K, Cg, Cs, Cin, Cout);
+    if (p.ws_bytes > ws_bytes) return D3_ERR_WORKSPACE;
+    const bool direct = (p.R == 1 && !accum);
+    a.tbl = tbl; a.dst = direct ? dW : (float *)ws;
+    if (!direct && p.R == 1 && ws_bytes < (size_t)wn * 4) return D3_ERR_WORKSPACE;
+    a.Ms = Ms; a.K = K; a.mt = (Cg + 15) / 16; a.nt = (Cs + 15) / 16; a.Cg8 = Cg / 8; a.Cs8 = Cs / 8;
+    a.invg = (65536u + a.Cg8 - 1) / a.Cg8; a.invs = (65536u + a.Cs8 - 1) / a.Cs8;
+    a.cpw = p.cpw; a.flipk = (flags & D3_CONV_FLIPK) ? 1 : 0; a.Cin = Cin; a.Cout = Cout;
+    const double bytes = (xbf ? 2.0 : 4.0) * (double)Min * Cin + (dybf ? 2.0 : 4.0) * (double)Mout * Cout + 4.0 * (double)wn +
+                         (tbl ? 4.0 * (double)Ms * K : 0.0);
+    void *pr = d3_prof_begin(1, bytes, 0.0, s);
+    int rc = D3_ERR_ARG;
+#define WG2_NU(TPOV)                                                                          \
+    (p.nu <= 1 ? launch_wg2<TPOV, 1>(a, p, s) : p.nu <= 2 ? launch_wg2<TPOV, 2>(a, p, s)          \
+     : p.nu <= 4 ? launch_wg2<TPOV, 4>(a, p, s) : p.nu <= 7 ? launch_wg2<TPOV, 7>(a, p, s)        \
+                                                            : launch_wg2<TPOV, 14>(a, p, s))
+    switch (p.tpo) {
+        case 1: rc = WG2_NU(1); break;
+        case 2: rc = WG2_NU(2); break;
+        case 4: rc = WG2_NU(4); break;
+        case 8: rc = WG2_NU(8); break;
+        default: rc = WG2_NU(16); break;
+    }
+#undef WG2_NU
+    if (rc == 0 && !direct) {
+        wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
+        D3_LAUNCH_CHECK();
+    }
+    d3_prof_end(pr, s);
+    return rc;
+}

@@ -26,7 +26,7 @@ from . import _lib
 from ._lib import check
 from .pointgroup_ops import _on, _ptr, _stream, _workspace
 
-D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT, D3_CONV_XSTAT, D3_CONV_XBF16 = 1, 2, 4, 8, 32
+D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT, D3_CONV_XSTAT, D3_CONV_ACCUM, D3_CONV_XBF16, D3_CONV_DYBF16 = 1, 2, 4, 8, 16, 32, 64
 
 _EXACT = False  # True: fp32 FMA kernels (validation); False: bf16 MFMA with fp32 accumulate
 
@@ -133,8 +133,21 @@ def cat(*tensors):
 
 
 # ------------------------------------------------------------------------------------- autograd ops
+_GEN2 = True   # second-generation kernels (csrc/spconv2.hip) whenever the channel counts allow
+
+
 def _conv_call(x, tbl, W3, Mout, K, Cin, Cout, flags):
     out = torch.empty((Mout, Cout), dtype=torch.float32, device=x.device)
+    if _GEN2 and not _EXACT and Cin % 8 == 0 and Cout % 4 == 0:
+        L = _lib.lib()
+        wp = _workspace(L.d3_spconv_pack_bytes(K, Cin, Cout), x.device, "wpack")
+        with _on(x.device):
+            check(L.d3_spconv_pack(_ptr(W3), _ptr(wp), K, Cin, Cout, flags & (D3_CONV_FLIPK | D3_CONV_TRANSW), _stream()),
+                  "spconv_pack")
+            check(L.d3_spconv_fwd2(_ptr(x), Cin, _ptr(tbl) if tbl is not None else None, _ptr(wp), _ptr(out), Cout,
+                                   None, 0, None, x.size(0), Mout, K, Cin, Cout, flags & D3_CONV_XBF16, _stream()),
+                  "spconv_fwd2")
+        return out
     with _on(x.device):
         check(_lib.lib().d3_spconv_fwd(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(W3), _ptr(out),
                                        x.size(0), Mout, K, Cin, Cout, flags | _mode_flag(), _stream()), "spconv_fwd")
@@ -175,10 +188,18 @@ def _conv_wgrad(x, tbl_f, tbl_b, dy, W3, Mout, bwd_flags, xflag=0):
     """dW of out = sum_k x[tbl_f[:,k]] @ W[k]; reads the wider operand contiguously (x-stationary over the transposed map)"""
     K, Cin, Cout = W3.shape
     dW = torch.empty_like(W3)   # cleared inside d3_spconv_wgrad
-    if tbl_b is not None and Cin > Cout:
+    if Cin > Cout and (tbl_b is not None or tbl_f is None):
         tbl, wflags = tbl_b, D3_CONV_XSTAT | (bwd_flags & D3_CONV_FLIPK)
     else:
         tbl, wflags = tbl_f, 0
+    if _GEN2 and not _EXACT and Cin % 8 == 0 and Cout % 8 == 0:
+        L = _lib.lib()
+        ws = _workspace(max(L.d3_spconv_wgrad2_ws_bytes(x.size(0), Mout, K, Cin, Cout, wflags), 16), x.device, "wgrad")
+        with _on(x.device):
+            check(L.d3_spconv_wgrad2(_ptr(x), Cin, _ptr(tbl) if tbl is not None else None, _ptr(dy), Cout, _ptr(dW),
+                                     x.size(0), Mout, K, Cin, Cout, wflags | xflag, _ptr(ws), ws.numel(), _stream()),
+                  "spconv_wgrad2")
+        return dW
     with _on(x.device):
         check(_lib.lib().d3_spconv_wgrad(_ptr(x), _ptr(tbl) if tbl is not None else None, _ptr(dy), _ptr(dW), x.size(0),
                                          Mout, K, Cin, Cout, wflags | xflag | _mode_flag(), _stream()), "spconv_wgrad")

@@ -134,6 +134,7 @@ int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_byte
 #define D3_CONV_XSTAT 8
 #define D3_CONV_ACCUM 16
 #define D3_CONV_XBF16 32   /* x is stored as bf16 (ushort), Cin % 8 == 0; not with D3_CONV_EXACT */
+#define D3_CONV_DYBF16 64  /* dy is stored as bf16 (d3_spconv_wgrad2 only) */
 int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
                   int Cout, int flags, void *stream);
 /* Weight gradient  dW[k] = sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32; cleared here unless
@@ -143,6 +144,25 @@ int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, in
  * wide operand (x) is read contiguously and the narrow one gathered. */
 int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, int Min, int Mout, int K, int Cin,
                     int Cout, int flags, void *stream);
+
+/* Second-generation MFMA kernels (csrc/spconv2.hip): wave-autonomous register gather, v_mfma_f32_16x16x32_bf16,
+ * weights pre-packed into bf16 MFMA fragment order.  Same contraction and flags as d3_spconv_fwd / d3_spconv_wgrad
+ * (D3_CONV_FLIPK / D3_CONV_TRANSW are applied by the pack step); Cin % 8 == 0 (wgrad2: Cout % 8 == 0 too).
+ *   pack   : W (K,Cin,Cout) f32 [(K,Cout,Cin) with TRANSW] -> Wp, d3_spconv_pack_bytes() bytes.
+ *   fwd2   : out[u, 0:Cout] (row stride ldo) = sum_k x[tbl[u,k]] @ Wk (+ res[u] (row stride ldr)) (+ out with
+ *            D3_CONV_ACCUM); x has row stride ldx (fp32, or bf16 with D3_CONV_XBF16).  part != NULL: per-workgroup
+ *            per-channel sum / sum of squares of the stored values, [d3_spconv_fwd2_nparts()][2][ceil16(Cout)] f32
+ *            -- the batch statistics of the following MinkowskiBatchNorm (consumed by d3_bn_finalize_parts).
+ *   wgrad2 : dW (K,Cin,Cout) f32 written (accumulated into with D3_CONV_ACCUM); ws >= d3_spconv_wgrad2_ws_bytes()
+ *            holds row-split partials that are summed in fixed order (deterministic, no atomics). */
+size_t d3_spconv_pack_bytes(int K, int Cin, int Cout);
+int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream);
+int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout);
+int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
+                   int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
+size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
+int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
+                     int K, int Cin, int Cout, int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* Launch timing for bench.py: with profiling on, each MFMA convolution launch is bracketed by HIP events on
  * its stream.  family 0 = forward/data-gradient kernel, 1 = weight-gradient kernel.  collect() synchronises. */
