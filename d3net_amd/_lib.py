@@ -51,7 +51,13 @@ SIGNATURES = {
     "d3_spconv_fwd2_nparts": (i32, [i32, i32, i32, i32]),
     "d3_spconv_fwd2": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_wgrad2_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
-    "d3_spconv_wgrad2": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "d3_spconv_wgrad2": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "d3_net_create": (vp, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32]),
+    "d3_net_destroy": (None, [vp]),
+    "d3_net_plan": (i32, [vp, vp, C.POINTER(sz), C.POINTER(sz)]),
+    "d3_net_tensor_offset": (i64, [vp, i32]),
+    "d3_net_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "d3_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),

@@ -729,10 +729,12 @@ static int launch_wg2(const Wg2Args &a, const Wg2Plan &p, hipStream_t s) {
 }
 
 // x (Min, ldx) and dy (Mout, ldy), each fp32 or bf16 (D3_CONV_XBF16 / D3_CONV_DYBF16); tbl as for d3_spconv_wgrad
-// (the forward map, or with D3_CONV_XSTAT the transposed map); dW (K,Cin,Cout) fp32, written (or accumulated into
+// (the forward map, or with D3_CONV_XSTAT the transposed map); dW (K,CinW,Cout) fp32 (CinW <= Cin: x may carry
+// zero-padded channels), written (or accumulated into
 // with D3_CONV_ACCUM).  ws >= d3_spconv_wgrad2_ws_bytes().  Cin % 8 == 0 and Cout % 8 == 0, else D3_ERR_ARG.
 extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min,
-                                int Mout, int K, int Cin, int Cout, int flags, void *ws, size_t ws_bytes, void *stream) {
+                                int Mout, int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes,
+                                void *stream) {
     D3_CLEAR();
     if (K < 1 || K > C2_MAXK || Cin < 8 || Cout < 8 || (Cin & 7) || (Cout & 7) || Cin > 224 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -740,7 +742,8 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0, accum = (flags & D3_CONV_ACCUM) ? 1 : 0;
     const int xbf = (flags & D3_CONV_XBF16) ? 1 : 0, dybf = (flags & D3_CONV_DYBF16) ? 1 : 0;
     if ((xbf ? (ldx & 7) : (ldx & 3)) || (dybf ? (ldy & 7) : (ldy & 3))) return D3_ERR_ARG;
-    const long long wn = (long long)K * Cin * Cout;
+    if (CinW < 1 || CinW > Cin) return D3_ERR_ARG;
+    const long long wn = (long long)K * CinW * Cout;   // dW is (K, CinW, Cout): x may carry zero-padded channels
     const int Ms = xstat ? Min : Mout;
     if (Ms <= 0) { if (!accum) D3_CHECK(hipMemsetAsync(dW, 0, wn * 4, s)); return 0; }
     Wg2Args a;
@@ -754,7 +757,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     if (!direct && p.R == 1 && ws_bytes < (size_t)wn * 4) return D3_ERR_WORKSPACE;
     a.Ms = Ms; a.K = K; a.mt = (Cg + 15) / 16; a.nt = (Cs + 15) / 16; a.Cg8 = Cg / 8; a.Cs8 = Cs / 8;
     a.invg = (65536u + a.Cg8 - 1) / a.Cg8; a.invs = (65536u + a.Cs8 - 1) / a.Cs8;
-    a.cpw = p.cpw; a.flipk = (flags & D3_CONV_FLIPK) ? 1 : 0; a.Cin = Cin; a.Cout = Cout;
+    a.cpw = p.cpw; a.flipk = (flags & D3_CONV_FLIPK) ? 1 : 0; a.Cin = CinW; a.Cout = Cout;
     const double bytes = (xbf ? 2.0 : 4.0) * (double)Min * Cin + (dybf ? 2.0 : 4.0) * (double)Mout * Cout + 4.0 * (double)wn +
                          (tbl ? 4.0 * (double)Ms * K : 0.0);
     void *pr = d3_prof_begin(1, bytes, 0.0, s);

@@ -197,7 +197,7 @@ def _conv_wgrad(x, tbl_f, tbl_b, dy, W3, Mout, bwd_flags, xflag=0):
         ws = _workspace(max(L.d3_spconv_wgrad2_ws_bytes(x.size(0), Mout, K, Cin, Cout, wflags), 16), x.device, "wgrad")
         with _on(x.device):
             check(L.d3_spconv_wgrad2(_ptr(x), Cin, _ptr(tbl) if tbl is not None else None, _ptr(dy), Cout, _ptr(dW),
-                                     x.size(0), Mout, K, Cin, Cout, wflags | xflag, _ptr(ws), ws.numel(), _stream()),
+                                     x.size(0), Mout, K, Cin, Cout, Cin, wflags | xflag, _ptr(ws), ws.numel(), _stream()),
                   "spconv_wgrad2")
         return dW
     with _on(x.device):

@@ -1,0 +1,288 @@
+"""Layer-program builder and python front end of the native sparse U-Net executor (csrc/unet.hip).
+
+The reference runs `self.backbone` / `self.score_net` (model/pointgroup.py:69-74, 88-92, 268-272, 332-333) module by
+module through MinkowskiEngine.  Here the same module tree (same state-dict keys: d3net_amd/common.py,
+d3net_amd/minkowski.py) is flattened once into a program of four op types -- CONV (with fused residual add, strided
+concat output and BatchNorm-statistics epilogue), BNACT (finalize + normalise + ReLU, bf16 output for convolution
+operands), PADCAST (stem input -> zero-padded bf16) and STATS -- and every forward / backward of the whole network is
+ONE call into libd3hip.so.  Parameter gradients are written by the executor straight into one flat buffer whose views
+are installed as `param.grad` (no autograd accumulation nodes: ~500 parameters, one kernel each otherwise).
+"""
+import ctypes as C
+import struct
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, common
+from . import minkowski as ME
+from ._lib import check
+from .pointgroup_ops import _on, _stream
+
+OP_CONV, OP_BNACT, OP_PADCAST, OP_STATS = 1, 2, 3, 4
+MAP_K1, MAP_K3, MAP_DOWN, MAP_UP = 0, 1, 2, 3
+F32, BF16 = 0, 1
+
+
+def _fbits(x):
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+class _Builder:
+    def __init__(self):
+        self.tensors, self.bufs, self.ops, self.params, self.grad_params, self.bns = [], [], [], [], [], []
+
+    def buf(self, level, width, dtype):
+        self.bufs.append((level, width, dtype))
+        return len(self.bufs) - 1
+
+    def view(self, buf, coff, Cc):
+        level, width, dtype = self.bufs[buf]
+        self.tensors.append((level, Cc, width, coff, dtype, buf))
+        return len(self.tensors) - 1
+
+    def new(self, level, Cc, dtype):
+        return self.view(self.buf(level, Cc, dtype), 0, Cc)
+
+    def external(self, Cc):
+        self.tensors.append((0, Cc, Cc, 0, F32, -1))
+        return len(self.tensors) - 1
+
+    def param(self, t, grad):
+        self.params.append(t)
+        self.grad_params.append(bool(grad))
+        return len(self.params) - 1
+
+    def C(self, t):
+        return self.tensors[t][1]
+
+    def level(self, t):
+        return self.tensors[t][0]
+
+    def op(self, *fields):
+        self.ops.append(list(fields) + [0] * (16 - len(fields)))
+
+    # ---- op emitters
+    def bnact(self, x, bn, out_dtype=BF16, relu=True):
+        """MinkowskiBatchNorm (+ fused MinkowskiReLU) on tensor x -> new tensor."""
+        b = bn.bn
+        assert b.track_running_stats and b.affine and b.num_features == self.C(x)
+        y = self.new(self.level(x), self.C(x), out_dtype)
+        self.op(OP_BNACT, x, y, -1, self.param(b.weight, True), self.param(b.bias, True), self.param(b.running_mean, False),
+                self.param(b.running_var, False), int(relu), _fbits(b.eps), _fbits(b.momentum))
+        self.bns.append(bn)
+        return y
+
+    def conv(self, x, conv, level_out, out=None, res=-1, stats=True, cin_w=None):
+        if isinstance(conv, ME.MinkowskiConvolutionTranspose):
+            kind, mlevel = MAP_UP, level_out
+        elif conv.kernel_size == 3:
+            kind, mlevel = MAP_K3, level_out
+        elif conv.kernel_size == 2:
+            kind, mlevel = MAP_DOWN, self.level(x)
+        else:
+            kind, mlevel = MAP_K1, level_out
+        if out is None:
+            out = self.new(level_out, conv.out_channels, F32)
+        assert self.C(out) == conv.out_channels
+        self.op(OP_CONV, x, out, res, self.param(conv.kernel, True), kind, mlevel, conv.kernel_volume,
+                conv.in_channels if cin_w is None else cin_w, int(stats))
+        return out
+
+    # ---- module walkers (reference: model/common.py)
+    def block(self, blk, x, out=None):
+        level = self.level(x)
+        if isinstance(blk, common.ResidualBlock):
+            skip = x if blk.downsample is None else self.conv(x, blk.downsample[0], level, stats=False)
+            cb = blk.conv_branch
+            t = self.conv(self.bnact(x, cb[0]), cb[2], level)
+            return self.conv(self.bnact(t, cb[3]), cb[5], level, out=out, res=skip)
+        cl = blk.conv_layers   # VGGBlock
+        return self.conv(self.bnact(x, cl[0]), cl[2], level, out=out)
+
+    def ublock(self, u, x, out=None):
+        level = self.level(x)
+        deeper = len(u.nPlanes) > 1
+        c = u.nPlanes[0]
+        blocks = list(u.blocks.children())
+        cat = self.buf(level, 2 * c, F32) if deeper else None
+        for i, blk in enumerate(blocks):
+            last = i == len(blocks) - 1
+            target = self.view(cat, 0, c) if (deeper and last) else (out if (last and not deeper) else None)
+            x = self.block(blk, x, out=target)
+        if not deeper:
+            return x
+        d = self.conv(self.bnact(x, u.conv[0]), u.conv[2], level + 1)
+        d = self.ublock(u.u, d)
+        self.conv(self.bnact(d, u.deconv[0]), u.deconv[2], level, out=self.view(cat, c, c))
+        x = self.view(cat, 0, 2 * c)
+        tail = list(u.blocks_tail.children())
+        for i, blk in enumerate(tail):
+            x = self.block(blk, x, out=out if i == len(tail) - 1 else None)
+        return x
+
+
+class NativeUNet:
+    """`stem` (MinkowskiConvolution or None) -> UBlock -> MinkowskiBatchNorm -> ReLU as one native program."""
+
+    def __init__(self, stem, ublock, final_bn, in_channels, input_needs_grad):
+        b = _Builder()
+        x = b.external(in_channels)
+        if stem is not None:
+            cpad = (in_channels + 7) // 8 * 8
+            xp = b.new(0, cpad, BF16)
+            b.op(OP_PADCAST, x, xp)
+            x = b.conv(xp, stem, 0, cin_w=in_channels)
+        else:
+            b.op(OP_STATS, x)
+        x = b.ublock(ublock, x)
+        out = b.bnact(x, final_bn, out_dtype=F32, relu=final_bn.fused_relu)
+        self.b = b
+        self.out_tensor, self.out_channels = out, b.C(out)
+        self.nlevels = len(ublock.nPlanes)
+        self.input_needs_grad = bool(input_needs_grad)
+        self.in_channels = in_channels
+        self.handle = None
+        self._ptr_key = None
+        self._plan_key, self._plan = None, None
+        self._flat_grad, self._grad_views = None, None
+        self.fresh_grads = False     # set by the owner's zero_grad(): the next backward writes instead of accumulating
+
+    # ------------------------------------------------------------------ lazily created native state
+    def _net(self):
+        if self.handle is None:
+            b = self.b
+            L = _lib.lib()
+            prog = (C.c_int64 * (16 * len(b.ops)))(*[v for op in b.ops for v in op])
+            tens = (C.c_int64 * (6 * len(b.tensors)))(*[v for t in b.tensors for v in t])
+            bufs = (C.c_int64 * (3 * len(b.bufs)))(*[v for t in b.bufs for v in t])
+            self.handle = C.c_void_p(L.d3_net_create(prog, len(b.ops), tens, len(b.tensors), bufs, len(b.bufs), self.nlevels,
+                                                     len(b.params), int(self.input_needs_grad), self.out_tensor))
+            assert self.handle.value
+        return self.handle
+
+    def __deepcopy__(self, memo):
+        return None     # native state is per object: the owner rebuilds its executor lazily
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.handle.value:
+                _lib.lib().d3_net_destroy(self.handle)
+        except Exception:
+            pass
+
+    def _param_ptrs(self):
+        ps = self.b.params
+        key = (ps[0].data_ptr(), ps[-1].data_ptr(), ps[len(ps) // 2].data_ptr())
+        if key != self._ptr_key:
+            assert all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+            self._pp = (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+            self._ptr_key = key
+            self._flat_grad = None
+        return self._pp
+
+    def _plan_for(self, rows):
+        key = tuple(rows)
+        if key != self._plan_key:
+            a, g = C.c_size_t(0), C.c_size_t(0)
+            check(_lib.lib().d3_net_plan(self._net(), (C.c_int * len(rows))(*rows), C.byref(a), C.byref(g)), "net_plan")
+            self._plan_key = key
+            self._plan = (a.value, g.value, _lib.lib().d3_net_tensor_offset(self._net(), self.out_tensor))
+        return self._plan
+
+    def _grads(self, device):
+        """flat gradient buffer + one view per trainable parameter"""
+        if self._flat_grad is None:
+            ps, gp = self.b.params, self.b.grad_params
+            total = sum(p.numel() for p, g in zip(ps, gp) if g)
+            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+            views, off = [], 0
+            for p, g in zip(ps, gp):
+                if g:
+                    views.append(self._flat_grad[off:off + p.numel()].view_as(p)); off += p.numel()
+                else:
+                    views.append(None)
+            self._grad_views = views
+        return self._grad_views
+
+    def maps(self, cm):
+        k3, child, up, rows, keep = [], [], [], [], []
+        ts = 1
+        for lev in range(self.nlevels):
+            nbr = cm.k3(ts)
+            keep.append(nbr); k3.append(nbr.data_ptr()); rows.append(nbr.size(0))
+            if lev + 1 < self.nlevels:
+                ch, u, _ = cm.down(ts)
+                keep += [ch, u]; child.append(ch.data_ptr()); up.append(u.data_ptr())
+            else:
+                child.append(0); up.append(0)
+            ts *= 2
+        n = self.nlevels
+        return ((C.c_void_p * n)(*k3), (C.c_void_p * n)(*child), (C.c_void_p * n)(*up), rows, keep)
+
+    def __call__(self, feats, cm, training):
+        ps = self.b.params
+        return _NetFunction.apply(feats, self, cm, bool(training), *[p for p, g in zip(ps, self.b.grad_params) if g])
+
+
+class _NetFunction(Function):
+    @staticmethod
+    def forward(ctx, feats, net, cm, training, *trainable):
+        feats = feats.contiguous()
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.size(1) == net.in_channels
+        dev = feats.device
+        L = _lib.lib()
+        k3, child, up, rows, keep = net.maps(cm)
+        assert rows[0] == feats.size(0)
+        arena_bytes, grad_bytes, out_off = net._plan_for(rows)
+        arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
+        pp = net._param_ptrs()
+        with _on(dev):
+            check(L.d3_net_forward(net._net(), pp, k3, child, up, C.c_void_p(feats.data_ptr()), C.c_void_p(arena.data_ptr()),
+                                   int(training), _stream()), "net_forward")
+        if training:
+            for bn in net.b.bns:
+                bn._steps += 1
+        M, Co = rows[0], net.out_channels
+        out = arena[out_off:out_off + M * Co * 4].view(torch.float32).view(M, Co)
+        ctx.net, ctx.maps, ctx.arena, ctx.feats, ctx.grad_bytes = net, (k3, child, up, keep), arena, feats, grad_bytes
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        assert ctx.training, "backward through the native U-Net needs a training-mode forward (batch statistics)"
+        k3, child, up, keep = ctx.maps
+        dev = gout.device
+        gout = gout.contiguous()
+        L = _lib.lib()
+        ps, gp = net.b.params, net.b.grad_params
+        views = net._grads(dev)
+        n = len(ps)
+        pg = (C.c_void_p * n)()
+        acc = (C.c_int * n)()
+        fresh = net.fresh_grads
+        for i in range(n):
+            if gp[i] and ps[i].requires_grad:
+                v = views[i]
+                pg[i] = v.data_ptr()
+                if fresh:
+                    if ps[i].grad is not v:
+                        ps[i].grad = v
+                else:
+                    g = ps[i].grad
+                    if g is None or g.data_ptr() != v.data_ptr():
+                        ps[i].grad = v
+                    else:
+                        acc[i] = 1
+        net.fresh_grads = False
+        garena = torch.empty(ctx.grad_bytes, dtype=torch.uint8, device=dev)
+        gin = torch.empty_like(ctx.feats) if net.input_needs_grad else None
+        with _on(dev):
+            check(L.d3_net_backward(net._net(), net._param_ptrs(), k3, child, up, C.c_void_p(ctx.feats.data_ptr()),
+                                    C.c_void_p(ctx.arena.data_ptr()), C.c_void_p(garena.data_ptr()), C.c_void_p(gout.data_ptr()),
+                                    pg, acc, C.c_void_p(gin.data_ptr()) if gin is not None else None, _stream()), "net_backward")
+        # garena / arena are only touched by work already enqueued on this stream and on the executor's side stream,
+        # which this stream has joined: the caching allocator may reuse them for later work on this stream
+        return (gin, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)

@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from . import common
 from . import minkowski as ME
+from . import netexec
 from . import pointgroup_ops
 
 
@@ -74,12 +75,49 @@ class PointGroup(nn.Module):
         self.teacher = False
         self.concurrent_clustering = True
         self._streams = {}
+        # native executors (csrc/unet.hip) for the two sparse U-Nets: one C-ABI call per forward / backward instead of
+        # one python call per module.  Built lazily; the module tree above stays the owner of every parameter.
+        self.native_unet = True
+        self.__dict__["_execs"] = {}
 
     def _side_stream(self, device):
         key = (device.index, threading.get_ident())
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
+
+    def _exec(self, name):
+        ex = self._execs.get(name)
+        if ex is None:
+            if name == "backbone":
+                in_channel = self.backbone[0].in_channels
+                ex = netexec.NativeUNet(self.backbone[0], self.backbone[1], self.backbone[2], in_channel, False)
+            else:
+                ex = netexec.NativeUNet(None, self.score_net[0], self.score_net[1], self.cfg.model.m, True)
+            self._execs[name] = ex
+        return ex
+
+    def _run_unet(self, name, module, x):
+        """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""
+        if self.native_unet and not ME._EXACT and x.F.size(0) > 0:
+            return self._exec(name)(x.F, x.coordinate_manager, self.training)
+        return module(x).features
+
+    def zero_grad(self, set_to_none=True):
+        """nn.Module.zero_grad; gradients owned by the native executors are marked stale instead of being detached
+        one by one (the next backward overwrites them)."""
+        native = set()
+        for ex in self._execs.values():
+            if ex is not None and ex._grad_views is not None and set_to_none:
+                ex.fresh_grads = True
+                native.update(id(p) for p, v in zip(ex.b.params, ex._grad_views) if v is not None and p.grad is v)
+        for p in self.parameters():
+            if id(p) in native or p.grad is None:
+                continue
+            if set_to_none:
+                p.grad = None
+            else:
+                p.grad.detach_(); p.grad.zero_()
 
     # ------------------------------------------------------------------------------------- helpers
     @staticmethod
@@ -190,8 +228,8 @@ class PointGroup(nn.Module):
     def forward(self, data_dict):
         batch_size = len(data_dict["batch_offsets"]) - 1
         x = ME.SparseTensor(features=data_dict["voxel_feats"], coordinates=data_dict["voxel_locs"].int())
-        out = self.backbone(x)
-        pt_feats = out.features[data_dict["p2v_map"].long()]                       # (N, m) "devoxelize"
+        out_feats = self._run_unet("backbone", self.backbone, x)
+        pt_feats = out_feats[data_dict["p2v_map"].long()]                          # (N, m) "devoxelize"
 
         semantic_scores = self.sem_seg(pt_feats)
         semantic_preds = semantic_scores.max(1)[1]
@@ -273,8 +311,8 @@ class PointGroup(nn.Module):
                 proposals_idx, proposals_offset, pt_feats, data_dict["locs"], self.score_fullscale, self.score_scale,
                 self.mode, rand=data_dict.get("cluster_rand"))
 
-            score_feats = self.score_net(proposals_voxel_feats)
-            pt_score_feats = score_feats.features[proposals_p2v_map.long()]
+            score_feats = self._run_unet("score_net", self.score_net, proposals_voxel_feats)
+            pt_score_feats = score_feats[proposals_p2v_map.long()]
             proposals_score_feats = pointgroup_ops.roipool(pt_score_feats, proposals_offset)   # (P, m)
             scores = self.score_linear(proposals_score_feats)
             data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset)

@@ -153,7 +153,7 @@ int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, 
  *            D3_CONV_ACCUM); x has row stride ldx (fp32, or bf16 with D3_CONV_XBF16).  part != NULL: per-workgroup
  *            per-channel sum / sum of squares of the stored values, [d3_spconv_fwd2_nparts()][2][ceil16(Cout)] f32
  *            -- the batch statistics of the following MinkowskiBatchNorm (consumed by d3_bn_finalize_parts).
- *   wgrad2 : dW (K,Cin,Cout) f32 written (accumulated into with D3_CONV_ACCUM); ws >= d3_spconv_wgrad2_ws_bytes()
+ *   wgrad2 : dW (K,CinW,Cout) f32 (CinW <= Cin: x may carry zero-padded channels) written (accumulated into with D3_CONV_ACCUM); ws >= d3_spconv_wgrad2_ws_bytes()
  *            holds row-split partials that are summed in fixed order (deterministic, no atomics). */
 size_t d3_spconv_pack_bytes(int K, int Cin, int Cout);
 int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream);
@@ -162,7 +162,7 @@ int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float
                    int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
 size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
-                     int K, int Cin, int Cout, int flags, void *ws, size_t ws_bytes, void *stream);
+                     int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* Launch timing for bench.py: with profiling on, each MFMA convolution launch is bracketed by HIP events on
  * its stream.  family 0 = forward/data-gradient kernel, 1 = weight-gradient kernel.  collect() synchronises. */
@@ -187,6 +187,32 @@ int d3_bn_relu_fwd_bf16(const float *x, const float *mean, const float *var, con
 int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const float *var, const float *gamma,
                    const float *beta, float *dx, float *dgamma, float *dbeta, int M, int C, float eps, int relu,
                    void *ws, size_t ws_bytes, void *stream);
+
+/* ---- native sparse U-Net executor (csrc/unet.hip) ---------------------------------------------------
+ * Runs the whole backbone / ScoreNet of the detector (model/pointgroup.py:69-74,88-92: stem conv, UBlock of
+ * ResidualBlock / VGGBlock units (model/common.py:22-118), final BN + ReLU) from a layer program: one call for the
+ * forward, one for the backward.  The program is three int64 tables built by d3net_amd/netexec.py:
+ *   tensors (ntensors x 6): level, C, ld, coff, dtype (0 f32, 1 bf16), buffer id (-1 = the external input)
+ *   bufs    (nbufs x 3)   : level, width, dtype
+ *   prog    (nops x 16)   : [0] type 1 CONV {in, out, res|-1, weight param, map 0 k1 / 1 k3 / 2 down / 3 up, map level,
+ *                           K, CinW (rows of the weight), stats 0/1}; 2 BNACT {in, out, -, gamma, beta, running_mean,
+ *                           running_var, relu, eps bits, momentum bits}; 3 PADCAST {in, out} (fp32 -> zero-padded
+ *                           bf16); 4 STATS {in} (batch statistics of the external input)
+ * plan(rows per level) fixes the arena layout; forward writes activations / BN state / packed weights into the
+ * caller's arena (kept for the backward); backward needs a gradient arena of grad_bytes.  params[i] / pgrads[i] are
+ * device pointers of parameter i and of its gradient (NULL = frozen; paccum[i] != 0: accumulate).  k3 / child / up:
+ * the kernel-map tables of d3_kmap_* per level.  Data gradients run on `stream`, weight gradients on an internal
+ * side stream that `stream` joins before the call returns. */
+void *d3_net_create(const int64_t *prog, int nops, const int64_t *tensors, int ntensors, const int64_t *bufs, int nbufs,
+                    int nlevels, int nparams, int input_needs_grad, int out_tensor);
+void d3_net_destroy(void *net);
+int d3_net_plan(void *net, const int *rows, size_t *arena_bytes, size_t *grad_bytes);
+long long d3_net_tensor_offset(void *net, int tensor);
+int d3_net_forward(void *net, const void *const *params, const int *const *k3, const int *const *child,
+                   const int *const *up, const void *input, void *arena, int training, void *stream);
+int d3_net_backward(void *net, const void *const *params, const int *const *k3, const int *const *child,
+                    const int *const *up, const void *input, void *arena, void *grad_arena, const float *gout,
+                    float *const *pgrads, const int *paccum, float *gin, void *stream);
 
 /* ---- proposal-level attention (listener) ------------------------------------------------ */
 /* Core of ScaledDotProductAttention.forward between the projections (model/transformer/attention.py:61-75):

@@ -223,6 +223,70 @@ def test_unet_forward_backward_vs_oracle(dev, exact):
         so.set_precision("fp32")
 
 
+@pytest.mark.parametrize("stem", [True, False])
+def test_native_executor_vs_oracle_and_module_path(dev, stem):
+    """csrc/unet.hip (one call per forward / backward, fused epilogues, side-stream weight gradients) against the
+    oracle's bf16 restatement and against the module-by-module HIP path on the same parameters."""
+    from d3net_amd import minkowski as ME, netexec
+    so.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(11)
+        planes, cin = [16, 32, 48, 64], (134 if stem else 16)
+        coords = rand_coords(rng, (40, 32, 20), 0.12)
+        x = torch.from_numpy(rng.standard_normal((len(coords), cin)).astype(np.float32))
+        net, params = _shared_unet(dev, planes, cin)
+        ocm = so.OracleCoords(coords)
+        xo = x.clone().requires_grad_(True)
+        h = so.conv_k3(xo, params["0.kernel"], ocm.get_k3(1)) if stem else xo
+        h = so.OracleUNet(params, planes).forward(h, ocm)
+        ref = so.bn_relu(h, params["2.bn.weight"], params["2.bn.bias"], 1e-4, True)
+        g = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        ref.backward(g)
+        cd = torch.from_numpy(coords).int().to(dev)
+        # module path
+        xm = x.to(dev).requires_grad_(True)
+        st = ME.SparseTensor(xm, coordinates=cd)
+        out_m = (net(st) if stem else net[3](net[2](net[1](st)))).F
+        out_m.backward(g.to(dev))
+        gm = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        xm_grad = xm.grad.clone()
+        rm_module = net[2].bn.running_mean.clone()
+        for p in net.parameters():
+            p.grad = None
+        # native executor (running statistics restored first: both paths update them)
+        net2, _ = _shared_unet(dev, planes, cin)
+        ex = netexec.NativeUNet(net2[0] if stem else None, net2[1], net2[2], cin, not stem)
+        xn = x.to(dev).requires_grad_(True)
+        out_n = ex(xn, ME.CoordinateManager(cd), True)
+        out_n.backward(g.to(dev))
+        torch.cuda.synchronize()
+
+        def cos(a, b):
+            a = a.detach().cpu().double().flatten(); b = b.detach().cpu().double().flatten()
+            return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert l2err(out_n, ref) < 3e-2, l2err(out_n, ref)
+        assert l2err(out_n, out_m) < 3e-2, l2err(out_n, out_m)
+        assert relerr(net2[2].bn.running_mean, rm_module) < 1e-2
+        if not stem:
+            assert cos(xn.grad, xo.grad) > 0.9 and cos(xn.grad, xm_grad) > 0.9, (cos(xn.grad, xo.grad), cos(xn.grad, xm_grad))
+        names = [n for n, _ in net2.named_parameters() if stem or not n.startswith("0.")]
+        cs = {n: cos(dict(net2.named_parameters())[n].grad, params[n].grad) for n in names}
+        cm_ = {n: cos(dict(net2.named_parameters())[n].grad, gm[n]) for n in names}
+        vals = sorted(cs.values())
+        assert vals[len(vals) // 2] > 0.9 and vals[0] > 0.5, (vals[len(vals) // 2], min(cs, key=cs.get), vals[0])
+        vals = sorted(cm_.values())
+        assert vals[len(vals) // 2] > 0.9 and vals[0] > 0.5, (vals[len(vals) // 2], min(cm_, key=cm_.get), vals[0])
+        # a second backward accumulates into the same gradient views (torch semantics)
+        g1 = net2[1].blocks.block0.conv_branch[2].kernel.grad.clone()
+        out2 = ex(x.to(dev).requires_grad_(True), ME.CoordinateManager(cd), True)
+        out2.backward(g.to(dev))
+        torch.cuda.synchronize()
+        g2 = net2[1].blocks.block0.conv_branch[2].kernel.grad
+        assert l2err(g2, 2 * g1) < 5e-2, l2err(g2, 2 * g1)
+    finally:
+        so.set_precision("fp32")
+
+
 def test_unet_bf16_forward_close_to_fp32_oracle(dev):
     """stated tolerance of the bf16-MFMA backbone against the fp32 reference arithmetic: 5e-2 relative L2"""
     from d3net_amd import minkowski as ME
