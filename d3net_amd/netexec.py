@@ -246,6 +246,7 @@ class _NetFunction(Function):
         M, Co = rows[0], net.out_channels
         out = arena[out_off:out_off + M * Co * 4].view(torch.float32).view(M, Co)
         ctx.net, ctx.maps, ctx.arena, ctx.feats, ctx.grad_bytes = net, (k3, child, up, keep), arena, feats, grad_bytes
+        ctx.rows = rows
         ctx.training = training
         return out
 
@@ -277,6 +278,7 @@ class _NetFunction(Function):
                     else:
                         acc[i] = 1
         net.fresh_grads = False
+        net._plan_for(ctx.rows)   # the arena layout belongs to the forward's level sizes (another forward may have re-planned)
         garena = torch.empty(ctx.grad_bytes, dtype=torch.uint8, device=dev)
         gin = torch.empty_like(ctx.feats) if net.input_needs_grad else None
         with _on(dev):
