@@ -58,6 +58,10 @@ SIGNATURES = {
     "d3_net_tensor_offset": (i64, [vp, i32]),
     "d3_net_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "d3_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "d3_tall_wgrad_ws_bytes": (sz, [i32, i32]),
+    "d3_tall_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "d3_cross_entropy_ws_bytes": (sz, []),
+    "d3_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),

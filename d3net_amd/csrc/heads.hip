@@ -1,0 +1,136 @@
+// heads.hip -- point-level heads of the PointGroup detector (gfx950): the pieces of `sem_seg`, `offset_net` and the
+// semantic loss (reference: model/pointgroup.py:77-85, 274-279, 387-395) whose library kernels collapse at
+// N = 165k rows x 16..20 channels:
+//   * weight gradient of a tall-skinny nn.Linear, dW (O,I) = dy^T x with a 165k-long reduction: the BLAS library
+//     picks a single-workgroup kernel (0.25-0.5 ms per layer, profiles/r01_i); here 512 workgroups reduce row ranges
+//     and a second kernel adds the partials in fixed order (deterministic), bias gradient included;
+//   * softmax cross-entropy with ignore_index over (N, 20) logits: forward loss and the gradient softmax - onehot in
+//     one pass (the library's log_softmax + nll_loss forward/backward are four passes).
+// HBM bound: bytes = 4*N*(I+O) (wgrad), 8*N*C (cross entropy: logits in, gradient out).
+#include "common.h"
+
+#define TW_ROWS 64
+#define TW_GRID 512
+// part[block][O][I+1]: columns 0..I-1 = dW, column I = bias gradient
+__global__ __launch_bounds__(256) void tall_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                        float *__restrict__ part, int N, int I, int O) {
+    __shared__ float xs[TW_ROWS * 33], ds[TW_ROWS * 33];
+    const int t = threadIdx.x;
+    const int I1 = I + 1, npair = O * I1;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // O, I <= 32: at most 32*33/256 = 4.1 pairs per thread
+    const int per = ((N + gridDim.x - 1) / gridDim.x + TW_ROWS - 1) / TW_ROWS * TW_ROWS;
+    const int r0 = blockIdx.x * per, r1 = min(N, r0 + per);
+    for (int rb = r0; rb < r1; rb += TW_ROWS) {
+        const int rows = min(TW_ROWS, r1 - rb);
+        for (int e = t; e < rows * I; e += 256) { const int r = e / I, c = e - r * I; xs[r * 33 + c] = x[(long long)rb * I + e]; }
+        for (int e = t; e < rows * O; e += 256) { const int r = e / O, c = e - r * O; ds[r * 33 + c] = dy[(long long)rb * O + e]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int pr = t + q * 256;
+            if (pr < npair) {
+                const int o = pr / I1, i = pr - o * I1;
+                float a = acc[q];
+                if (i < I) { for (int r = 0; r < rows; r++) a = fmaf(ds[r * 33 + o], xs[r * 33 + i], a); }
+                else { for (int r = 0; r < rows; r++) a += ds[r * 33 + o]; }
+                acc[q] = a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int pr = t + q * 256;
+        if (pr < npair) part[(long long)blockIdx.x * npair + pr] = acc[q];
+    }
+}
+__global__ void tall_wgrad_reduce_kernel(const float *__restrict__ part, int nblocks, int I, int O, float *dW, float *db) {
+    const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+    const int I1 = I + 1, npair = O * I1;
+    if (pr >= npair) return;
+    double s = 0.;
+    for (int b = 0; b < nblocks; b++) s += (double)part[(long long)b * npair + pr];
+    const int o = pr / I1, i = pr - o * I1;
+    if (i < I) dW[o * I + i] = (float)s;
+    else if (db) db[o] = (float)s;
+}
+
+extern "C" size_t d3_tall_wgrad_ws_bytes(int I, int O) { return (size_t)TW_GRID * O * (I + 1) * sizeof(float); }
+
+// dW (O,I) = dy (N,O)^T x (N,I), db (O) = column sums of dy (db may be NULL); I, O <= 32
+extern "C" int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *db, int N, int I, int O, void *ws,
+                             size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (I < 1 || O < 1 || I > 32 || O > 32) return D3_ERR_ARG;
+    if (ws_bytes < d3_tall_wgrad_ws_bytes(I, O)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    int grid = TW_GRID;
+    if (N < grid * TW_ROWS) grid = (N + TW_ROWS - 1) / TW_ROWS;
+    if (grid < 1) grid = 1;
+    tall_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float *)ws, N, I, O);
+    const int npair = O * (I + 1);
+    tall_wgrad_reduce_kernel<<<(npair + 255) / 256, 256, 0, s>>>((const float *)ws, grid, I, O, dW, db);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ softmax cross entropy
+// per row: loss = logsumexp(z) - z[label] (label != ignore), grad = softmax(z) - onehot (0 for ignored rows).
+// part[block][2] = (sum of losses, number of counted rows) in fp32; the reduce kernel produces loss_sum, count.
+#define CE_GRID 1024
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ z, const long long *__restrict__ label,
+                                                    float *__restrict__ grad, float *__restrict__ part, int N, int C,
+                                                    int ignore) {
+    __shared__ float s1[256], s2[256];
+    float ls = 0.f, cnt = 0.f;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (long long)gridDim.x * blockDim.x) {
+        const float *zr = z + r * C;
+        float *gr = grad + r * C;
+        const long long lb = label[r];
+        float m = -INFINITY;
+        for (int c = 0; c < C; c++) m = fmaxf(m, zr[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; c++) se += expf(zr[c] - m);
+        const float lse = m + logf(se);
+        if (lb == ignore || lb < 0 || lb >= C) {
+            for (int c = 0; c < C; c++) gr[c] = 0.f;
+        } else {
+            const float inv = 1.f / se;
+            for (int c = 0; c < C; c++) gr[c] = expf(zr[c] - m) * inv - (c == lb ? 1.f : 0.f);
+            ls += lse - zr[lb]; cnt += 1.f;
+        }
+    }
+    s1[threadIdx.x] = ls; s2[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = s1[0]; part[blockIdx.x * 2 + 1] = s2[0]; }
+}
+__global__ void ce_reduce_kernel(const float *part, int nblocks, float *out) {   // out[0] = mean loss, out[1] = count
+    const int lane = threadIdx.x;
+    double a = 0., b = 0.;
+    for (int i = lane; i < nblocks; i += 64) { a += (double)part[i * 2]; b += (double)part[i * 2 + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane == 0) { out[0] = (float)(b > 0. ? a / b : 0.); out[1] = (float)b; }
+}
+
+extern "C" size_t d3_cross_entropy_ws_bytes(void) { return (size_t)CE_GRID * 2 * sizeof(float); }
+
+// nn.functional.cross_entropy(z, label, ignore_index) with mean reduction: out[0] = loss, out[1] = counted rows;
+// grad (N,C) = d(sum of losses)/dz (the caller scales it by grad_out / count)
+extern "C" int d3_cross_entropy(const float *z, const int64_t *label, float *grad, float *out, int N, int C,
+                                int ignore_index, void *ws, size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (C < 1 || C > 64) return D3_ERR_ARG;
+    if (ws_bytes < d3_cross_entropy_ws_bytes()) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    int grid = (N + 255) / 256;
+    if (grid > CE_GRID) grid = CE_GRID;
+    if (grid < 1) grid = 1;
+    ce_fwd_kernel<<<grid, 256, 0, s>>>(z, (const long long *)label, grad, (float *)ws, N, C, ignore_index);
+    ce_reduce_kernel<<<1, 64, 0, s>>>((const float *)ws, grid, out);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

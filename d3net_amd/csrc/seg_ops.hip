@@ -83,50 +83,73 @@ __global__ __launch_bounds__(SEG_THREADS) void sec_mean_kernel(const float *__re
     }
 }
 
-// One WAVE per segment, software pipelined: the add chain (the only serial part -- one dependent fp32 add per row,
-// bit-exactness forbids reordering it) runs back to back while the same wave's loads of the NEXT chunk are in flight
-// and its divisions / LDS stores of that chunk are done between two chains.  The workgroup-per-segment kernel above
-// idles 253 of 256 lanes during the chain and the chain during the staging.
-#define MEANW_CHUNK 1024   // floats per chunk (16 per lane)
-__global__ __launch_bounds__(64) void sec_mean_wave_kernel(const float *__restrict__ inp, const int *__restrict__ offsets,
-                                                          float *__restrict__ out, int nProposal, int C) {
-    __shared__ float stage[2][MEANW_CHUNK];
-    const int lane = threadIdx.x, p = blockIdx.x;
+// Producer / consumer workgroup per segment: the add chain (the only serial part -- one dependent fp32 add per row;
+// bit-exactness forbids reordering it) runs back to back on wave 0 while waves 1-3 load, divide (IEEE division is
+// ~40 instructions per element) and stage the chunks of the NEXT round in LDS.  The workgroup-per-segment kernel
+// above idles 253 of 256 lanes during the chain and the chain during the staging.
+#define MEANW_CHUNK 1024   // floats per chunk (16 per producer lane)
+#define MEANW_PROD 3       // producer waves = chunks per round
+__global__ __launch_bounds__(256) void sec_mean_pc_kernel(const float *__restrict__ inp, const int *__restrict__ offsets,
+                                                         float *__restrict__ out, int nProposal, int C) {
+    __shared__ float stage[2][MEANW_PROD][MEANW_CHUNK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = blockIdx.x;
     const int start = offsets[p], end = offsets[p + 1];
     const float count = (float)(end - start);
     const int rpc = MEANW_CHUNK / C, cf = rpc * C;          // rows / floats per chunk
     const long long base = (long long)start * C, total = (long long)(end - start) * C;
     const int nchunk = (int)((total + cf - 1) / cf);
-    float v[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) { const long long f = j * 64 + lane; v[j] = (f < cf && f < total) ? inp[base + f] : 0.f; }
+    const int nround = (nchunk + MEANW_PROD - 1) / MEANW_PROD;
     float mean = 0.f;
-    for (int k = 0; k < nchunk; k++) {
-        float *st = stage[k & 1];
+    for (int rd = 0; rd <= nround; rd++) {
+        if (wave > 0) {   // produce chunk (rd, wave-1) of round rd into buffer rd & 1
+            const int k = rd * MEANW_PROD + wave - 1;
+            if (rd < nround && k < nchunk) {
+                float *st = stage[rd & 1][wave - 1];
+                const long long cb = (long long)k * cf;
+                float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const int f = j * 64 + lane; if (f < cf) st[f] = __fdiv_rn(v[j], count); }
-        const long long nb = (long long)(k + 1) * cf;
+                for (int j = 0; j < 16; j++) { const long long f = j * 64 + lane; v[j] = (f < cf && cb + f < total) ? inp[base + cb + f] : 0.f; }
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const long long f = j * 64 + lane; v[j] = (f < cf && nb + f < total) ? inp[base + nb + f] : 0.f; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const long long left = total - (long long)k * cf;
-        const int rows = (int)((left < cf ? left : cf) / C);
-        if (lane < C) {
-            int r = 0;
-            for (; r + 8 <= rows; r += 8) {
-                float w[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) w[j] = st[(r + j) * C + lane];
-#pragma unroll
-                for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w[j]);
+                for (int j = 0; j < 16; j++) { const int f = j * 64 + lane; if (f < cf) st[f] = __fdiv_rn(v[j], count); }
             }
-            for (; r < rows; r++) mean = __fadd_rn(mean, st[r * C + lane]);
+        } else if (rd > 0) {   // consume round rd-1
+            for (int q = 0; q < MEANW_PROD; q++) {
+                const int k = (rd - 1) * MEANW_PROD + q;
+                if (k >= nchunk) break;
+                const float *st = stage[(rd - 1) & 1][q];
+                const long long left = total - (long long)k * cf;
+                const int rows = (int)((left < cf ? left : cf) / C);
+                if (lane < C) {   // the LDS reads of the next 8 rows are in flight during the 8 dependent adds
+                    int r = 0;
+                    float w0[8], w1[8];
+                    if (rows >= 8) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) w0[j] = st[j * C + lane];
+                    }
+                    for (; r + 16 <= rows; r += 16) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) w1[j] = st[(r + 8 + j) * C + lane];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w0[j]);
+                        if (r + 24 <= rows) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) w0[j] = st[(r + 16 + j) * C + lane];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w1[j]);
+                    }
+                    if (r + 8 <= rows) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w0[j]);
+                        r += 8;
+                    }
+                    for (; r < rows; r++) mean = __fadd_rn(mean, st[r * C + lane]);
+                }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
-    if (lane < C) out[(long long)p * C + lane] = mean;
+    if (wave == 0 && lane < C) out[(long long)p * C + lane] = mean;
 }
 
 // -------------------------------------------------------------------------------- roipool
@@ -244,13 +267,37 @@ template <bool IS_MAX>
 __global__ __launch_bounds__(SEG_THREADS) void seg_minmax_flat_kernel(const float *__restrict__ inp,
                                                                      const int *__restrict__ offsets,
                                                                      float *__restrict__ out, int nProposal, int C) {
+    __shared__ float red[SEG_THREADS];
     const int active = (SEG_THREADS / C) * C, rpp = active / C, t = threadIdx.x;
-    if (t >= active) return;
     const int c = t % C;
     const int total = offsets[nProposal], first = offsets[0];
     int per = (total - first + gridDim.x - 1) / gridDim.x;
     per = (per + rpp - 1) / rpp * rpp;
     const int R0 = first + blockIdx.x * per, R1 = min(total, R0 + per);
+    if (R0 >= R1) return;                                   // uniform
+    const int p0 = seg_find(offsets, nProposal, R0);
+    if (offsets[p0 + 1] >= R1) {
+        // the whole range lies in one segment (the common case: a few clusters hold most rows): reduce in the
+        // workgroup and issue C atomics instead of one per thread -- hundreds of thousands of atomics on the same
+        // P*C addresses serialise in L2
+        float v = IS_MAX ? -INFINITY : INFINITY;
+        if (t < active)
+            for (int r = R0 + t / C; r < R1; r += rpp) {
+                const float x = inp[(long long)r * C + c];
+                if (IS_MAX ? (x > v) : (x < v)) v = x;
+            }
+        red[t] = v;
+        __syncthreads();
+        if (t < C) {
+            float b = red[t];
+            for (int k = t + C; k < active; k += C) { const float x = red[k]; if (IS_MAX ? (x > b) : (x < b)) b = x; }
+            if (IS_MAX ? (b > -INFINITY) : (b < INFINITY)) {
+                if (IS_MAX) seg_atomic_max_f32(&out[(long long)p0 * C + t], b); else seg_atomic_min_f32(&out[(long long)p0 * C + t], b);
+            }
+        }
+        return;
+    }
+    if (t >= active) return;
     int r = R0 + t / C;
     if (r >= R1) return;
     int p = seg_find(offsets, nProposal, r);
@@ -273,13 +320,32 @@ __global__ __launch_bounds__(SEG_THREADS) void roipool_arg_flat_kernel(const flo
                                                                       const int *__restrict__ offsets,
                                                                       const float *__restrict__ out_feats,
                                                                       int *__restrict__ out_maxidx, int nProposal, int C) {
+    __shared__ int redi[SEG_THREADS];
     const int active = (SEG_THREADS / C) * C, rpp = active / C, t = threadIdx.x;
-    if (t >= active) return;
     const int c = t % C;
     const int total = offsets[nProposal], first = offsets[0];
     int per = (total - first + gridDim.x - 1) / gridDim.x;
     per = (per + rpp - 1) / rpp * rpp;
     const int R0 = first + blockIdx.x * per, R1 = min(total, R0 + per);
+    if (R0 >= R1) return;
+    const int p0 = seg_find(offsets, nProposal, R0);
+    if (offsets[p0 + 1] >= R1) {   // one segment: workgroup reduction, C atomics
+        int a = 0x7FFFFFFF;
+        if (t < active) {
+            const float mx = out_feats[(long long)p0 * C + c];
+            for (int r = R0 + t / C; r < R1; r += rpp)
+                if (feats[(long long)r * C + c] == mx) { a = r; break; }
+        }
+        redi[t] = a;
+        __syncthreads();
+        if (t < C) {
+            int b = redi[t];
+            for (int k = t + C; k < active; k += C) b = min(b, redi[k]);
+            if (b != 0x7FFFFFFF) atomicMin((unsigned int *)&out_maxidx[(long long)p0 * C + t], (unsigned int)b);
+        }
+        return;
+    }
+    if (t >= active) return;
     int r = R0 + t / C;
     if (r >= R1) return;
     int p = seg_find(offsets, nProposal, r);
@@ -304,7 +370,7 @@ extern "C" int d3_sec_mean(const float *inp, const int *offsets, float *out, int
     D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
-    if (C <= 64) sec_mean_wave_kernel<<<nProposal, 64, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
+    if (C <= 64) sec_mean_pc_kernel<<<nProposal, 256, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
     else sec_mean_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
     D3_LAUNCH_CHECK();
     return 0;

@@ -525,6 +525,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NU <= 2 ? 3
     const int tile0 = blockIdx.z * TPO, ntl = a.mt * a.nt;
     const int nchunks = (a.Ms + 31) >> 5;
     const int c_begin = blockIdx.x * a.cpw, c_end = min(nchunks, c_begin + a.cpw);
+    // stationary column window of this pass (8-channel units)
+    int sc8lo = 0, sc8n = a.Cs8;
+    {
+        const int tlast = min(ntl, tile0 + TPO) - 1;
+        if (tlast >= tile0 && tile0 / a.nt == tlast / a.nt) {
+            sc8lo = (tile0 % a.nt) * 2;
+            sc8n = min(a.Cs8, (tlast % a.nt + 1) * 2) - sc8lo;
+        }
+    }
 
     f32x4 acc[OPW][TPO];
 #pragma unroll
@@ -550,23 +559,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NU <= 2 ? 3
                 if (e < 32 * K) tblW[e] = v[it];
             }
         }
-        // stationary rows, transposed (batches of 4 units per lane in flight)
-        for (int ub = 0; ub < 32 * a.Cs8; ub += 256) {
+        // stationary rows, transposed (batches of 4 units per lane in flight); only the columns this pass's tiles
+        // use (a wide stationary operand with a narrow gathered one is split into column passes by the host)
+        for (int ub = 0; ub < 32 * sc8n; ub += 256) {
             uint4 sv[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int unit = ub + q * 64 + lane;
                 sv[q] = make_uint4(0u, 0u, 0u, 0u);
-                if (unit < 32 * a.Cs8) {
-                    const int row = (int)(((unsigned int)unit * a.invs) >> 16), c8 = unit - row * a.Cs8;
+                if (unit < 32 * sc8n) {
+                    const int row = unit / sc8n, c8 = sc8lo + unit - row * sc8n;
                     if (u0 + row < a.Ms) sv[q] = wg2_load8(a.Sm, a.sbf16, (long long)(u0 + row) * a.lds + c8 * 8);
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int unit = ub + q * 64 + lane;
-                if (unit < 32 * a.Cs8) {
-                    const int row = (int)(((unsigned int)unit * a.invs) >> 16), c8 = unit - row * a.Cs8;
+                if (unit < 32 * sc8n) {
+                    const int row = unit / sc8n, c8 = sc8lo + unit - row * sc8n;
                     wg2_store_t(St, c8, row, sv[q]);
                 }
             }
@@ -691,6 +701,7 @@ static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
     Wg2Plan p;
     const int mt = (Cg + 15) / 16, nt = (Cs + 15) / 16, ntl = mt * nt;
     p.tpo = ntl <= 1 ? 1 : ntl <= 2 ? 2 : ntl <= 4 ? 4 : ntl <= 8 ? 8 : 16;
+    if (mt == 1 && nt > 4) p.tpo = 4;   // column passes of 4 tiles, 4 offsets per wave (the stem: 16 x 136 channels)
     p.nu = (Cg / 8 * 32 + 63) / 64;    // 16-byte units per lane per offset
     p.opw = WG2_T / p.tpo;
     p.kg = (K + p.opw - 1) / p.opw;

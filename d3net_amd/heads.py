@@ -1,0 +1,102 @@
+"""Point-level head operators of the detector on MI355X (csrc/heads.hip): drop-in replacements for the three library
+calls that dominate the heads at N ~ 165k points -- the weight gradient of a tall-skinny `nn.Linear`
+(reference: model/pointgroup.py:77-85 `sem_seg`, `offset_net`), `F.cross_entropy` over (N, 20) logits (:389-390) and the
+backward of the voxel -> point gather `output.features[p2v_map]` (:272).  Small inputs fall through to the library.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check
+from .pointgroup_ops import _on, _ptr, _stream, _workspace
+
+TALL_ROWS = 8192   # below this the library GEMM is fine
+
+
+class _TallLinear(Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty(W.size(0), dtype=W.dtype, device=W.device) if ctx.has_bias else None
+        L = _lib.lib()
+        O, I = W.shape
+        ws = _workspace(L.d3_tall_wgrad_ws_bytes(I, O), x.device, "tallw")
+        with _on(x.device):
+            check(L.d3_tall_wgrad(_ptr(x), _ptr(dy), _ptr(dW), _ptr(db) if db is not None else None, x.size(0), I, O,
+                                  _ptr(ws), ws.numel(), _stream()), "tall_wgrad")
+        return dx, dW, db
+
+
+def linear(module, x):
+    """module(x) for an nn.Linear; tall-skinny inputs use the HIP weight-gradient kernel in the backward"""
+    W = module.weight
+    if x.is_cuda and x.dim() == 2 and x.size(0) >= TALL_ROWS and W.size(0) <= 32 and W.size(1) <= 32 \
+            and x.dtype == torch.float32 and torch.is_grad_enabled():
+        return _TallLinear.apply(x.contiguous(), W, module.bias)
+    return module(x)
+
+
+class _CrossEntropy(Function):
+    @staticmethod
+    def forward(ctx, z, label, ignore_index):
+        z = z.contiguous()
+        N, Cc = z.shape
+        grad = torch.empty_like(z)
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        L = _lib.lib()
+        ws = _workspace(L.d3_cross_entropy_ws_bytes(), z.device, "ce")
+        with _on(z.device):
+            check(L.d3_cross_entropy(_ptr(z), _ptr(label), _ptr(grad), _ptr(out), N, Cc, int(ignore_index), _ptr(ws),
+                                     ws.numel(), _stream()), "cross_entropy")
+        ctx.save_for_backward(grad, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, out = ctx.saved_tensors
+        return grad * (g / out[1].clamp(min=1.0)), None, None
+
+
+def cross_entropy(z, label, ignore_index=-100):
+    """nn.functional.cross_entropy(z, label, ignore_index=...) (mean reduction) in one HIP pass for big (N, C<=64) logits"""
+    if z.is_cuda and z.dim() == 2 and z.size(0) >= TALL_ROWS and z.size(1) <= 64 and z.dtype == torch.float32 \
+            and label.dtype == torch.int64:
+        return _CrossEntropy.apply(z, label.contiguous(), ignore_index)
+    return torch.nn.functional.cross_entropy(z, label, ignore_index=ignore_index)
+
+
+class _Devoxelize(Function):
+    """feats[p2v] with the backward as a rule-ordered per-voxel sum over v2p (deterministic, no atomics) instead of the
+    library's sort-based index_put backward"""
+
+    @staticmethod
+    def forward(ctx, feats, p2v, v2p):
+        ctx.save_for_backward(v2p)
+        ctx.M = feats.size(0)
+        return feats.index_select(0, p2v)
+
+    @staticmethod
+    def backward(ctx, dpt):
+        (v2p,) = ctx.saved_tensors
+        dpt = dpt.contiguous()
+        M, Cc = ctx.M, dpt.size(1)
+        dv = torch.zeros((M, Cc), dtype=dpt.dtype, device=dpt.device)
+        with _on(dpt.device):
+            check(_lib.lib().d3_point_recover_bp(_ptr(dpt), _ptr(dv), _ptr(v2p), M, v2p.size(1) - 1, Cc, _stream()),
+                  "point_recover_bp")
+        return dv, None, None
+
+
+def devoxelize(feats, p2v, v2p):
+    if feats.is_cuda and v2p is not None and v2p.dtype == torch.int32 and v2p.is_contiguous() and feats.dtype == torch.float32:
+        return _Devoxelize.apply(feats, p2v.long(), v2p)
+    return feats[p2v.long()]

@@ -22,9 +22,54 @@ import torch
 import torch.nn as nn
 
 from . import common
+from . import heads
 from . import minkowski as ME
 from . import netexec
 from . import pointgroup_ops
+
+
+class _HostStage:
+    """Small host -> device transfers without draining the stream: a pageable `.to(device)` blocks the host until
+    every kernel already queued has run (the copy is stream ordered), which costs the run-ahead of the whole step for
+    a 12-byte vector.  A ring of pinned buffers + asynchronous copies keeps the host ahead; the ring is deeper than the
+    number of steps the host can run ahead (every step has blocking count phases)."""
+
+    def __init__(self, slots=64, nbytes=4096):
+        self.slots, self.nbytes, self.ring, self.i = slots, nbytes, None, 0
+
+    def put(self, t, device):
+        if self.ring is None:
+            self.ring = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
+        t = t.contiguous()
+        n = t.numel() * t.element_size()
+        if n > self.nbytes:
+            return t.to(device)
+        pin = self.ring[self.i][:n].view(t.dtype).view(t.shape)
+        self.i = (self.i + 1) % self.slots
+        pin.copy_(t)
+        return torch.empty(t.shape, dtype=t.dtype, device=device).copy_(pin, non_blocking=True)
+
+
+_STAGE = _HostStage()
+_CONST = {}
+
+
+def _const(key, device, build):
+    """device-resident constants (one upload per device instead of one per step)"""
+    k = (key, device.index)
+    if k not in _CONST:
+        _CONST[k] = build().to(device)
+    return _CONST[k]
+
+
+PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
+
+
+def _mark(name):
+    if PHASES is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        PHASES.append((name, ev))
 
 
 class PointGroup(nn.Module):
@@ -138,11 +183,14 @@ class PointGroup(nn.Module):
         clusters_feats = feats[c_idxs]
         clusters_coords = coords[c_idxs]
 
+        _mark("cv_gather")
         clusters_coords_mean = pointgroup_ops.sec_mean(clusters_coords, clusters_offset)      # (P,3)
+        _mark("cv_sec_mean")
         clusters_coords = clusters_coords - torch.index_select(clusters_coords_mean, 0, cid)
         clusters_coords_min = pointgroup_ops.sec_min(clusters_coords, clusters_offset)
         clusters_coords_max = pointgroup_ops.sec_max(clusters_coords, clusters_offset)
 
+        _mark("cv_sec_minmax")
         clusters_size = clusters_coords_max - clusters_coords_min
         clusters_center = (clusters_coords_max + clusters_coords_min) / 2 + clusters_coords_mean
 
@@ -158,16 +206,20 @@ class PointGroup(nn.Module):
             r0, r1 = torch.rand(3), torch.rand(3)   # CPU generator, same order as the reference
         else:
             r0, r1 = rand[0].cpu(), rand[1].cpu()
-        offset = - min_xyz + torch.clamp(fullscale - rng - 0.001, min=0) * r0.to(dev) + \
-            torch.clamp(fullscale - rng + 0.001, max=0) * r1.to(dev)
+        r01 = _STAGE.put(torch.stack([r0, r1]).float(), dev)
+        offset = - min_xyz + torch.clamp(fullscale - rng - 0.001, min=0) * r01[0] + \
+            torch.clamp(fullscale - rng + 0.001, max=0) * r01[1]
         clusters_coords = clusters_coords + torch.index_select(offset, 0, cid)
 
         clusters_coords = clusters_coords.long()                                               # truncation (:166)
         clusters_coords = torch.cat([cid.view(-1, 1), clusters_coords], 1).contiguous()        # (S,4) on the device
         n_clusters = int(clusters_offset.numel() - 1)
+        _mark("cv_elementwise")
         voxel_coords, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(clusters_coords, n_clusters, mode)
+        _mark("cv_voxelization_idx")
         voxel_feats = pointgroup_ops.voxelization(clusters_feats, v2p_map, mode)
         voxel_feats = ME.SparseTensor(features=voxel_feats, coordinates=voxel_coords.int())
+        voxel_feats.v2p_map = v2p_map
         return voxel_feats, p2v_map, (clusters_center, clusters_size)
 
     def get_object_assignments(self, data_dict):
@@ -181,10 +233,9 @@ class PointGroup(nn.Module):
     def _box_corners(center, size):
         """lib/utils/bbox.py:54-74 (get_3d_box_batch) for heading 0, in fp64 like the numpy original."""
         c = center.double(); s = size.double()
-        sx = torch.tensor([1, 1, -1, -1, 1, 1, -1, -1], dtype=torch.float64, device=c.device)
-        sy = torch.tensor([1, -1, -1, 1, 1, -1, -1, 1], dtype=torch.float64, device=c.device)
-        sz = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], dtype=torch.float64, device=c.device)
-        corners = torch.stack([s[:, 0:1] / 2 * sx, s[:, 1:2] / 2 * sy, s[:, 2:3] / 2 * sz], -1)  # (P,8,3)
+        sgn = _const("corner_signs", c.device, lambda: torch.tensor(
+            [[1, 1, -1, -1, 1, 1, -1, -1], [1, -1, -1, 1, 1, -1, -1, 1], [1, 1, 1, 1, -1, -1, -1, -1]], dtype=torch.float64))
+        corners = torch.stack([s[:, 0:1] / 2 * sgn[0], s[:, 1:2] / 2 * sgn[1], s[:, 2:3] / 2 * sgn[2]], -1)  # (P,8,3)
         return corners + c.unsqueeze(1)
 
     def convert_stack_to_batch(self, data_dict, perms=None):
@@ -203,22 +254,27 @@ class PointGroup(nn.Module):
             "proposal_scores_batched": pf.new_zeros(batch_size, K),
             "proposal_batch_mask": pf.new_zeros(batch_size, K),
         }
-        bids = data_dict["proposals_batchId"]
-        for b in range(batch_size):
-            idx = torch.nonzero(bids == b).squeeze(-1)[:K]
-            n = idx.numel()
-            rows = {
-                "proposal_feats_batched": pf[idx], "proposal_bbox_batched": corners[idx],
-                "proposal_center_batched": crop[idx, :3], "proposal_sem_cls_batched": crop[idx, 7],
-                "proposal_scores_batched": data_dict["proposal_objectness_scores"][idx],
-            }
-            perm = (torch.randperm(K) if perms is None else perms[b]).to(dev)   # slot shuffle (:251)
-            for k, v in rows.items():
-                buf = out[k][b].clone()
-                buf[:n] = v
-                out[k][b] = buf[perm]
-            mask = pf.new_zeros(K); mask[:n] = 1
-            out["proposal_batch_mask"][b] = mask[perm]
+        # No host round trips: rank of every proposal inside its scene by a one-hot cumulative sum, the first K per
+        # scene are scattered to slot inv_perm[rank] (out[b][j] = buf[perm[j]] with buf[:n] = rows, as in the reference).
+        bids = data_dict["proposals_batchId"].long()
+        perm = torch.stack([torch.randperm(K) if perms is None else perms[b].cpu() for b in range(batch_size)])   # (:251)
+        perm = _STAGE.put(perm, dev)
+        inv = torch.empty_like(perm).scatter_(1, perm, _const(("arange", K), dev, lambda: torch.arange(K)).expand(batch_size, K))
+        onehot = torch.nn.functional.one_hot(bids, batch_size)
+        rank = (onehot.cumsum(0) - onehot).gather(1, bids.view(-1, 1)).squeeze(1)
+        ok = rank < K
+        slot = bids * K + inv.view(-1)[bids * K + rank.clamp(max=K - 1)]
+        slot = torch.where(ok, slot, torch.full_like(slot, batch_size * K))     # overflow rows -> a dump slot
+        rows = {
+            "proposal_feats_batched": pf, "proposal_bbox_batched": corners,
+            "proposal_center_batched": crop[:, :3], "proposal_sem_cls_batched": crop[:, 7],
+            "proposal_scores_batched": data_dict["proposal_objectness_scores"],
+            "proposal_batch_mask": pf.new_ones(pf.size(0)),
+        }
+        for k, v in rows.items():
+            flat = out[k].new_zeros((batch_size * K + 1,) + tuple(out[k].shape[2:]))
+            flat.index_copy_(0, slot, v.to(flat.dtype))
+            out[k] = flat[:-1].view(out[k].shape)
         data_dict.update(out)
         if self.cfg.general.task != "test":
             data_dict = self.get_object_assignments(data_dict)
@@ -228,15 +284,19 @@ class PointGroup(nn.Module):
     def forward(self, data_dict):
         batch_size = len(data_dict["batch_offsets"]) - 1
         x = ME.SparseTensor(features=data_dict["voxel_feats"], coordinates=data_dict["voxel_locs"].int())
+        _mark("voxelize")
         out_feats = self._run_unet("backbone", self.backbone, x)
-        pt_feats = out_feats[data_dict["p2v_map"].long()]                          # (N, m) "devoxelize"
+        _mark("backbone_fwd")
+        pt_feats = heads.devoxelize(out_feats, data_dict["p2v_map"], data_dict.get("v2p_map"))   # (N, m)
 
-        semantic_scores = self.sem_seg(pt_feats)
+        semantic_scores = heads.linear(self.sem_seg, pt_feats)
         semantic_preds = semantic_scores.max(1)[1]
         data_dict["semantic_scores"] = semantic_scores
-        pt_offsets = self.offset_net(pt_feats)
+        on = self.offset_net
+        pt_offsets = heads.linear(on[3], on[2](on[1](heads.linear(on[0], pt_feats))))
         data_dict["pt_offsets"] = pt_offsets
 
+        _mark("heads")
         if data_dict["epoch"] > self.prepare_epochs or self.freeze_backbone:
             if self.teacher:   # benchmark/test switch: cluster on the labels instead of the (random-init) predictions
                 semantic_preds = data_dict["sem_labels"].clamp(min=0)
@@ -254,10 +314,14 @@ class PointGroup(nn.Module):
                 pt_offsets_ = cluster_offsets[object_idxs]
                 semantic_preds_ = semantic_preds[object_idxs].int().contiguous()
 
-                def cluster_branch(xyz, mean_active):
+                def cluster_branch(xyz, mean_active, marks=False):
                     idx_, start_len_ = pointgroup_ops.ballquery_batch_p(xyz, batch_idxs_, batch_offsets_, self.cluster_radius,
                                                                         mean_active)
+                    if marks:
+                        _mark("cl_ballquery")
                     p_idx, p_off = pointgroup_ops.bfs_cluster(semantic_preds_, idx_, start_len_, self.cluster_npoint_thre)
+                    if marks:
+                        _mark("cl_bfs")
                     p_idx[:, 1] = object_idxs[p_idx[:, 1].long()].int()
                     return p_idx, p_off, batch_idxs[p_idx[:, 1].long()].int()
 
@@ -265,6 +329,7 @@ class PointGroup(nn.Module):
                 # one runs on a side stream from a helper thread (ctypes releases the GIL inside libd3hip), so its count
                 # phases, which synchronise their own stream, overlap the other branch instead of serialising with it.
                 shifted_xyz = (coords_ + pt_offsets_).detach().contiguous()
+                _mark("cl_prepare")
                 cur = torch.cuda.current_stream()
                 if self.concurrent_clustering:
                     side = self._side_stream(coords_.device)
@@ -279,7 +344,7 @@ class PointGroup(nn.Module):
                             box["err"] = e
                     th = threading.Thread(target=work)
                     th.start()
-                    proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive)
+                    proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive, True)
                     th.join()
                     if "err" in box:
                         raise box["err"]
@@ -302,6 +367,7 @@ class PointGroup(nn.Module):
                 proposals_offset = data_dict["gt_proposals_offset"].to(pt_feats.device)
                 proposals_batchId_all = batch_idxs[proposals_idx[:, 1].long()].int()
 
+            _mark("clustering")
             num_proposals = proposals_offset.shape[0] - 1
             data_dict["num_raw_proposals"] = num_proposals
             if num_proposals == 0:
@@ -311,8 +377,10 @@ class PointGroup(nn.Module):
                 proposals_idx, proposals_offset, pt_feats, data_dict["locs"], self.score_fullscale, self.score_scale,
                 self.mode, rand=data_dict.get("cluster_rand"))
 
+            _mark("cluster_voxelization")
             score_feats = self._run_unet("score_net", self.score_net, proposals_voxel_feats)
-            pt_score_feats = score_feats[proposals_p2v_map.long()]
+            _mark("score_net_fwd")
+            pt_score_feats = heads.devoxelize(score_feats, proposals_p2v_map, getattr(proposals_voxel_feats, "v2p_map", None))
             proposals_score_feats = pointgroup_ops.roipool(pt_score_feats, proposals_offset)   # (P, m)
             scores = self.score_linear(proposals_score_feats)
             data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset)
@@ -327,10 +395,11 @@ class PointGroup(nn.Module):
             # NOTE the reference reads the one-short batch-id vector at the cluster starts (:349); cluster starts of
             # the shifted set therefore read element start+1 of that set -- same cluster, same batch id.
             starts = proposals_offset[:-1].long().clamp(max=max(proposals_batchId_all.numel() - 1, 0))
-            proposals_batchId = proposals_batchId_all[starts][thres_mask]
+            keep = torch.nonzero(thres_mask).squeeze(1)    # one host round trip for the four selections below
+            proposals_batchId = proposals_batchId_all[starts].index_select(0, keep)
             data_dict["proposals_batchId"] = proposals_batchId
-            data_dict["proposal_feats"] = proposals_score_feats[thres_mask]
-            data_dict["proposal_objectness_scores"] = sig[thres_mask]
+            data_dict["proposal_feats"] = proposals_score_feats.index_select(0, keep)
+            data_dict["proposal_objectness_scores"] = sig.index_select(0, keep)
 
             if self.cfg.model.crop_bbox:
                 crop = scores.new_zeros(num_proposals, 9)
@@ -338,7 +407,7 @@ class PointGroup(nn.Module):
                 crop[:, 3:6] = proposals_size
                 crop[:, 7] = semantic_preds[proposals_idx[proposals_offset[:-1].long(), 1].long()].to(crop.dtype)
                 crop[:, 8] = sig
-                data_dict["proposal_crop_bbox"] = crop[thres_mask]
+                data_dict["proposal_crop_bbox"] = crop.index_select(0, keep)
         return data_dict
 
     def _no_proposals(self, data_dict, pt_feats):
@@ -365,11 +434,10 @@ class PointGroup(nn.Module):
             segmented = (fg_mask > 0).float()
             k = 1 / (fg_thresh - bg_thresh)
             b = bg_thresh / (bg_thresh - fg_thresh)
-            segmented[interval_mask] = scores[interval_mask] * k + b
-            return segmented
+            return torch.where(interval_mask, scores * k + b, segmented)    # masked assignment without a host round trip
 
         semantic_scores, semantic_labels = data_dict["semantic_scores"]
-        semantic_loss = nn.functional.cross_entropy(semantic_scores, semantic_labels, ignore_index=self.cfg.data.ignore_label)
+        semantic_loss = heads.cross_entropy(semantic_scores, semantic_labels, ignore_index=self.cfg.data.ignore_label)
         data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
 
         pt_offsets, coords, instance_info, instance_ids = data_dict["pt_offsets"]
@@ -439,7 +507,10 @@ class PointGroup(nn.Module):
 
     def training_step(self, data_dict, idx=0):
         """(reference :513-528) minus the Lightning logging."""
+        _mark("begin")
         data_dict = self.feed(data_dict, self.current_epoch)
+        _mark("proposals")
         _, data_dict = self.parse_feed_ret(data_dict, self.current_epoch)
         data_dict = self.loss(data_dict, self.current_epoch)
+        _mark("loss")
         return data_dict["total_loss"][0], data_dict

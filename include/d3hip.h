@@ -214,6 +214,19 @@ int d3_net_backward(void *net, const void *const *params, const int *const *k3, 
                     const int *const *up, const void *input, void *arena, void *grad_arena, const float *gout,
                     float *const *pgrads, const int *paccum, float *gin, void *stream);
 
+/* ---- point-level heads (csrc/heads.hip) -------------------------------------------------------------
+ * sem_seg / offset_net (model/pointgroup.py:77-85,274-279) and the semantic loss (:389-390) at N ~ 165k rows:
+ *   tall_wgrad   : weight (and bias) gradient of y = x W^T + b for a tall-skinny x: dW (O,I) = dy^T x, db (O) = column
+ *                  sums of dy (NULL to skip); I, O <= 32; deterministic two-stage reduction.
+ *   cross_entropy: nn.functional.cross_entropy(z (N,C), label (N) int64, ignore_index), mean over counted rows:
+ *                  out[0] = loss, out[1] = counted rows, grad (N,C) = softmax - onehot (0 on ignored rows). */
+size_t d3_tall_wgrad_ws_bytes(int I, int O);
+int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *db, int N, int I, int O, void *ws, size_t ws_bytes,
+                  void *stream);
+size_t d3_cross_entropy_ws_bytes(void);
+int d3_cross_entropy(const float *z, const int64_t *label, float *grad, float *out, int N, int C, int ignore_index,
+                     void *ws, size_t ws_bytes, void *stream);
+
 /* ---- proposal-level attention (listener) ------------------------------------------------ */
 /* Core of ScaledDotProductAttention.forward between the projections (model/transformer/attention.py:61-75):
  * softmax(q k^T / sqrt(dk) + bias, masked where mask == 0) v, per (batch item, head), fp32.
