@@ -40,6 +40,8 @@ SIGNATURES = {
     "d3_bfs_cluster_ws_bytes": (sz, [i32]),
     "d3_bfs_cluster_count": (i32, [vp, vp, vp, i32, i32, vp, sz, pi, pi, vp]),
     "d3_bfs_cluster_fill": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, i32, i32, vp]),
+    "d3_bfs_cluster_erec_bytes": (sz, [i64]),
+    "d3_bfs_cluster_fill2": (i32, [vp, vp, vp, i32, vp, sz, vp, sz, i64, vp, vp, i32, i32, vp]),
     "d3_coordmap_ws_bytes": (sz, [i32]),
     "d3_kmap_k3": (i32, [vp, i32, i32, vp, sz, vp, vp]),
     "d3_kmap_down_count": (i32, [vp, i32, i32, vp, sz, vp, vp, pi, vp]),
@@ -50,6 +52,7 @@ SIGNATURES = {
     "d3_spconv_pack": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "d3_spconv_fwd2_nparts": (i32, [i32, i32, i32, i32]),
     "d3_spconv_fwd2": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "d3_spconv_fwd2_bnbwd": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_wgrad2_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "d3_spconv_wgrad2": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "d3_net_create": (vp, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32]),

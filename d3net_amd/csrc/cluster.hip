@@ -45,6 +45,8 @@ struct ClWs {
     int *queue;    // n  BFS queues (cluster c at koff[seed])
     int *fcnt;     // n  BFS: list start of every queued node
     int *qln;      // n  BFS: list length of every queued node
+    int *lid;      // n  BFS (record kernel): dense id of a node inside its cluster (any bijection)
+    int *lcnt;     // n  per-owner counter behind lid
     int *scalars;  // [0]=changed [1]=nCluster [2]=sumNPoint
     void *temp; size_t temp_bytes;
 };
@@ -56,6 +58,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
     w.flag = c.take<int>(nn); w.cid = c.take<int>(nn); w.ksz = c.take<int>(nn); w.koff = c.take<int>(nn);
     w.seeds = c.take<int>(nn); w.par = c.take<int>(nn); w.queue = c.take<int>(nn); w.fcnt = c.take<int>(nn);
     w.qln = c.take<int>(nn);
+    w.lid = c.take<int>(nn); w.lcnt = c.take<int>(nn);
     w.scalars = c.take<int>(64);
     w.temp_bytes = d3_scan_temp_bytes(n);
     w.temp = c.take<char>(w.temp_bytes);
@@ -64,7 +67,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
 extern "C" size_t d3_bfs_cluster_ws_bytes(int n) {
     D3Carver c(nullptr, 0);
     size_t nn = (size_t)(n > 0 ? n : 1);
-    for (int i = 0; i < 13; i++) c.take<int>(nn);
+    for (int i = 0; i < 15; i++) c.take<int>(nn);
     c.take<int>(64);
     c.take<char>(d3_scan_temp_bytes(n));
     return c.off + 256;
@@ -269,13 +272,14 @@ __global__ __launch_bounds__(CL_BFS_THREADS) void cl_bfs_kernel(const int *__res
                                                                const int *__restrict__ seeds,
                                                                const int *__restrict__ koff,
                                                                const int *__restrict__ sizes, int *par, int *queue,
-                                                               int *qst_all, int *qln_all, int *cluster_idxs) {
+                                                               int *qst_all, int *qln_all, int *cluster_idxs, int min_size) {
     __shared__ int s_st[CL_FCH], s_off[CL_FCH + 1], s_w[24];
     const int c = blockIdx.x;
     const int s = seeds[c];
     const int base = koff[s];
     const int size = sizes[s];
     (void)sem;
+    if (size <= min_size) return;   // handled by cl_bfs2_kernel
     int *q = queue + base, *qst = qst_all + base, *qln = qln_all + base;
     const int tid = threadIdx.x;
     if (tid == 0) { st_dev(&q[0], s); st_dev(&qst[0], start_len[s * 2]); st_dev(&qln[0], start_len[s * 2 + 1]); st_dev(&par[s], -1); }
@@ -386,7 +390,201 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
     cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
     if (nCluster > 0)
         cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
-                                                         w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs);
+                                                         w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, 0);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// phase 3, record form.  The level loop above pays three to four dependent L2 round trips per level (frontier
+// records, neighbour ids, owner / visited state of the neighbours, winner read-back) and a 4 m floor is ~200 levels
+// deep: 2.3 ms for the canonical scene (profiles/r01_i).  Here everything a level needs about a neighbour travels
+// WITH the edge: a fully parallel pre-pass rewrites every list entry of a kept cluster as the record
+// (node, dense id inside its cluster, list start, list length) -- or node = -1 for a neighbour of another
+// component -- and the BFS keeps its state in LDS: a visited bitmap over the dense ids, the frontier's list
+// extents, and a small hash that picks, among the edges of a batch that reach the same unvisited node, the one
+// with the smallest flat edge id (= the FIFO discoverer).  Batches are processed in flat edge order and the bitmap
+// is updated between them, so "first discoverer" is preserved exactly.  One global round trip per batch.
+#define B2_THREADS 1024
+#define B2_EPT 2
+#define B2_BATCH (B2_THREADS * B2_EPT)
+#define B2_HASH 4096
+#define B2_FMAX 1024
+#define B2_BITWORDS 16384                       // 64 KB: clusters up to 524288 points; larger ones use cl_bfs_kernel
+#define B2_MAXSIZE (B2_BITWORDS * 32)
+
+__global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, int *lcnt, int *lid, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;   // tail lanes simply drop out of the ballots below
+    const int o = own[i];
+    const bool kept = flag[o] != 0;
+    // a wave holds only a few distinct owners: one atomic per distinct owner (leader = lowest lane of each group);
+    // one atomic per NODE serialises tens of thousands of updates of the same counter in L2
+    int id = -1;
+    unsigned long long todo = __ballot(kept);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const int ol = __shfl(o, leader);
+        const unsigned long long grp = __ballot(kept && o == ol) & todo;
+        int b = 0;
+        if (lane == leader) b = atomicAdd(&lcnt[ol], (int)__popcll(grp));
+        b = __shfl(b, leader);
+        if (kept && o == ol) id = b + (int)__popcll(grp & ((1ull << lane) - 1ull));
+        todo &= ~grp;
+    }
+    lid[i] = id;
+}
+// one wave per node of a kept cluster: its list -> edge records
+__global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
+                                                     const int *__restrict__ own, const int *__restrict__ flag,
+                                                     const int *__restrict__ lid, int4 *__restrict__ erec, int n) {
+    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n) return;
+    const int oi = own[i];
+    if (!flag[oi]) return;
+    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    for (int e = d3_lane(); e < ln; e += 64) {
+        const int j = idx[st + e];
+        int4 r = make_int4(-1, 0, 0, 0);
+        if (own[j] == oi) { const int2 sl = *(const int2 *)&start_len[j * 2]; r = make_int4(j, lid[j], sl.x, sl.y); }
+        erec[st + e] = r;
+    }
+}
+
+__global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restrict__ erec, const int *__restrict__ start_len,
+                                                            const int *__restrict__ lid, const int *__restrict__ seeds,
+                                                            const int *__restrict__ koff, const int *__restrict__ sizes,
+                                                            int *qst_all, int *qln_all, int *cluster_idxs) {
+    extern __shared__ __attribute__((aligned(16))) int b2_smem[];
+    unsigned int *bitmap = (unsigned int *)b2_smem;                 // B2_BITWORDS
+    int *hkey = b2_smem + B2_BITWORDS;                              // B2_HASH
+    int *hval = hkey + B2_HASH;                                     // B2_HASH
+    int *fst = hval + B2_HASH;                                      // 2 * B2_FMAX
+    int *fln = fst + 2 * B2_FMAX;                                   // 2 * B2_FMAX
+    int *s_off = fln + 2 * B2_FMAX;                                 // B2_FMAX + 1
+    int *s_w = s_off + B2_FMAX + 8;                                 // 24
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int s = seeds[c], base = koff[s], size = sizes[s];
+    if (size > B2_MAXSIZE) return;                                  // left to cl_bfs_kernel
+    int *qst = qst_all + base, *qln = qln_all + base;
+    const int words = (size + 31) >> 5;
+    for (int w = tid; w < words; w += B2_THREADS) bitmap[w] = 0u;
+    for (int h = tid; h < B2_HASH; h += B2_THREADS) { hkey[h] = -1; hval[h] = CL_INF; }
+    __syncthreads();
+    if (tid == 0) {
+        const int ls = lid[s];
+        bitmap[ls >> 5] = 1u << (ls & 31);
+        fst[0] = start_len[s * 2]; fln[0] = start_len[s * 2 + 1];
+        cluster_idxs[(size_t)base * 2] = c; cluster_idxs[(size_t)base * 2 + 1] = s;
+    }
+    __syncthreads();
+    int lo = 0, hi = 1, cur = 0;
+    while (lo < hi && hi <= size) {
+        const bool small = (hi - lo) <= B2_FMAX;      // the frontier's list extents are already in LDS
+        int tail = hi;
+        for (int fb = lo; fb < hi; fb += B2_FMAX) {
+            const int nf = min(B2_FMAX, hi - fb);
+            int *cst = fst + cur * B2_FMAX, *cln = fln + cur * B2_FMAX;
+            if (!small) {
+                if (tid < nf) { cst[tid] = ld_dev(&qst[fb + tid]); cln[tid] = ld_dev(&qln[fb + tid]); }
+                __syncthreads();
+            }
+            int E;
+            const int off = cl_blk_scan(tid < nf ? cln[tid] : 0, s_w, E);
+            if (tid < nf) s_off[tid] = off;
+            if (tid == 0) s_off[nf] = E;
+            __syncthreads();
+            for (int e0 = 0; e0 < E; e0 += B2_BATCH) {
+                int4 rec[B2_EPT];
+                int slot[B2_EPT];
+                bool cand[B2_EPT];
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) {
+                    const int e = e0 + tid * B2_EPT + r;    // a thread's edges are consecutive in flat order
+                    cand[r] = false; slot[r] = 0; rec[r] = make_int4(-1, 0, 0, 0);
+                    if (e < E) {
+                        int a = 0, b = nf;  // largest f with s_off[f] <= e
+                        while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
+                        rec[r] = erec[cst[a] + e - s_off[a]];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) {
+                    if (rec[r].x >= 0 && !((bitmap[rec[r].y >> 5] >> (rec[r].y & 31)) & 1u)) {
+                        cand[r] = true;
+                        const int key = rec[r].y, v = tid * B2_EPT + r;
+                        int h = (int)(((unsigned int)key * 2654435761u) >> 20);
+                        for (;;) {
+                            const int old = atomicCAS(&hkey[h], -1, key);
+                            if (old == -1 || old == key) { atomicMin(&hval[h], v); break; }
+                            h = (h + 1) & (B2_HASH - 1);
+                        }
+                        slot[r] = h;
+                    }
+                }
+                __syncthreads();
+                int win[B2_EPT], nwin = 0;
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) { win[r] = (cand[r] && hval[slot[r]] == tid * B2_EPT + r) ? 1 : 0; nwin += win[r]; }
+                int tot;
+                const int pos = cl_blk_scan(nwin, s_w, tot);     // (barriers inside: every hval read is done)
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) {
+                    if (win[r]) {
+                        const int p = tail + pos + k; k++;
+                        if (p < size) {
+                            cluster_idxs[(size_t)(base + p) * 2] = c; cluster_idxs[(size_t)(base + p) * 2 + 1] = rec[r].x;
+                            const int nx = p - hi;            // position inside the next frontier
+                            if (nx < B2_FMAX) { fst[(cur ^ 1) * B2_FMAX + nx] = rec[r].z; fln[(cur ^ 1) * B2_FMAX + nx] = rec[r].w; }
+                            st_dev(&qst[p], rec[r].z); st_dev(&qln[p], rec[r].w);
+                            atomicOr(&bitmap[rec[r].y >> 5], 1u << (rec[r].y & 31));
+                        }
+                    }
+                    if (cand[r]) { hkey[slot[r]] = -1; hval[slot[r]] = CL_INF; }   // every occupied slot has >= 1 candidate
+                }
+                tail += tot;
+                __syncthreads();
+                if (tail >= size) return;   // every node of the component is queued: the remaining edges (a dense
+                                            // component has ~size^2 of them) cannot discover anything
+            }
+        }
+        lo = hi; hi = tail; cur ^= 1;
+    }
+}
+
+extern "C" size_t d3_bfs_cluster_erec_bytes(long long nActive) { return (size_t)(nActive > 0 ? nActive : 1) * sizeof(int4); }
+
+// d3_bfs_cluster_fill with the record-form level loop; erec: d3_bfs_cluster_erec_bytes(nActive) bytes of scratch
+// (nActive = length of ball_query_idxs).  Same outputs, bit for bit.
+extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
+                                    int n, void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive,
+                                    int *cluster_idxs, int *cluster_offsets, int sumNPoint, int nCluster, void *stream) {
+    D3_CLEAR();
+    if (n <= 0) return 0;
+    ClWs w;
+    if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    if (erec == nullptr || erec_bytes < d3_bfs_cluster_erec_bytes(nActive)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
+    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
+    if (nCluster > 0) {
+        static bool attr_done = false;
+        const size_t lds = (size_t)(B2_BITWORDS + 2 * B2_HASH + 4 * B2_FMAX + B2_FMAX + 8 + 32) * sizeof(int);
+        if (!attr_done) {
+            D3_CHECK(hipFuncSetAttribute((const void *)cl_bfs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
+        cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, w.lcnt, w.lid, n);
+        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.lid, (int4 *)erec, n);
+        cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.lid, w.seeds, w.koff, w.sizes,
+                                                        w.fcnt, w.qln, cluster_idxs);
+        // clusters beyond the LDS bitmap (> 524288 points): the generic level loop (exits at once otherwise)
+        cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
+                                                         w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, B2_MAXSIZE);
+    }
     D3_LAUNCH_CHECK();
     return 0;
 }

@@ -44,12 +44,15 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float *__restrict
         if (pr < npair) part[(long long)blockIdx.x * npair + pr] = acc[q];
     }
 }
+// one wave per (o, i) pair; lanes stride over the workgroup partials, fp64 wave reduction in fixed order
 __global__ void tall_wgrad_reduce_kernel(const float *__restrict__ part, int nblocks, int I, int O, float *dW, float *db) {
-    const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pr = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     const int I1 = I + 1, npair = O * I1;
     if (pr >= npair) return;
     double s = 0.;
-    for (int b = 0; b < nblocks; b++) s += (double)part[(long long)b * npair + pr];
+    for (int b = lane; b < nblocks; b += 64) s += (double)part[(long long)b * npair + pr];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane != 0) return;
     const int o = pr / I1, i = pr - o * I1;
     if (i < I) dW[o * I + i] = (float)s;
     else if (db) db[o] = (float)s;
@@ -69,7 +72,7 @@ extern "C" int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *
     if (grid < 1) grid = 1;
     tall_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float *)ws, N, I, O);
     const int npair = O * (I + 1);
-    tall_wgrad_reduce_kernel<<<(npair + 255) / 256, 256, 0, s>>>((const float *)ws, grid, I, O, dW, db);
+    tall_wgrad_reduce_kernel<<<(npair + 3) / 4, 256, 0, s>>>((const float *)ws, grid, I, O, dW, db);
     D3_LAUNCH_CHECK();
     return 0;
 }

@@ -97,6 +97,10 @@ struct Conv2Args {
     unsigned int inv;           // ceil(65536 / S): i = (s * inv) >> 16 == s / S for s < 4096
     int xbf16, accum, ntiles, NT;   // NT = ceil(Cout / 16)
     unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
+    // BatchNorm-backward epilogue (data gradient of a BN -> ReLU -> conv unit): the stored value is g = dy * relu'(bn(x))
+    // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
+    const float *bnx; const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
+    int ldbx, bn_relu; float bn_eps;
 };
 
 __device__ __forceinline__ bf16x8_t c2_zero() {
@@ -228,8 +232,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
                     if (a.res) { const f32x4 rr = *(const f32x4 *)(a.res + (long long)u * a.ldr + col); vv += rr; }
                     f32x4 *o = (f32x4 *)(a.out + (long long)u * a.ldo + col);
                     if (a.accum) vv += *o;
-                    *o = vv;
-                    ssum[n] += vv; ssq[n] += vv * vv;
+                    if (a.bnx) {
+                        const f32x4 xv = *(const f32x4 *)(a.bnx + (long long)u * a.ldbx + col);
+                        f32x4 xh;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float inv = rsqrtf(a.bn_var[col + q] + a.bn_eps);
+                            xh[q] = (xv[q] - a.bn_mean[col + q]) * inv;
+                            if (a.bn_relu && fmaf(xh[q], a.bn_gamma[col + q], a.bn_beta[col + q]) <= 0.f) vv[q] = 0.f;
+                        }
+                        *o = vv;
+                        ssum[n] += vv; ssq[n] += vv * xh;
+                    } else {
+                        *o = vv;
+                        ssum[n] += vv; ssq[n] += vv * vv;
+                    }
                 }
             }
         }
@@ -270,7 +287,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
     int *actS = tblS + C2_TBL_INTS;                  // 32 ints
     unsigned int *kmaskS = (unsigned int *)(actS + 32);   // 1 (+3 pad)
     float *redS = (float *)(kmaskS + 4);             // W * NTW*256 floats
-    float *finS = redS + (size_t)W * NTW * 256;      // 16 x NTW*16
+    float *finS = redS + (size_t)W * NTW * 256;      // 16 x NTW*16: stored values
+    float *fin2S = finS + 16 * NTW * 16;             // 16 x NTW*16: second statistic (v*v, or g*xhat)
     const int row0 = blockIdx.x * 16, n0 = blockIdx.y * NTW;
     if (t == 0) *kmaskS = 0u;
     __syncthreads();
@@ -342,23 +360,28 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
     for (int e = t; e < 16 * CW; e += blockDim.x) {
         const int row = e / CW, cl = e - row * CW;
         const int n = cl >> 4, ln = (row >> 2) * 16 + (cl & 15), q = row & 3;
-        float v = 0.f;
+        float v = 0.f, w2 = 0.f;
         for (int w = 0; w < W; w++) v += redS[(w * NTW * 4 + n * 4 + q) * 64 + ln];
         const int u = row0 + row, col = n0 * 16 + cl;
         if (u < a.Mout && col < a.Cout) {
             if (a.res) v += a.res[(long long)u * a.ldr + col];
             float *o = a.out + (long long)u * a.ldo + col;
             if (a.accum) v += *o;
+            if (a.bnx) {
+                const float xh = (a.bnx[(long long)u * a.ldbx + col] - a.bn_mean[col]) * rsqrtf(a.bn_var[col] + a.bn_eps);
+                if (a.bn_relu && fmaf(xh, a.bn_gamma[col], a.bn_beta[col]) <= 0.f) v = 0.f;
+                w2 = v * xh;
+            } else w2 = v * v;
             *o = v;
-        } else v = 0.f;
-        finS[e] = v;
+        } else { v = 0.f; w2 = 0.f; }
+        finS[e] = v; fin2S[e] = w2;
     }
     if (a.part) {
         __syncthreads();
         if (t < 2 * CW) {
             const int cl = (t < CW) ? t : t - CW;
             float s = 0.f;
-            for (int row = 0; row < 16; row++) { const float v = finS[row * CW + cl]; s += (t < CW) ? v : v * v; }
+            for (int row = 0; row < 16; row++) s += (t < CW) ? finS[row * CW + cl] : fin2S[row * CW + cl];
             if (n0 * 16 + cl < a.NT * 16)
                 a.part[(long long)blockIdx.x * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl] = s;
         }
@@ -390,7 +413,7 @@ static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout) {
         if (ntiles * p.gy < 128) W = 16;
         while (W > 4 && W * 2 > steps) W >>= 1;
         p.W = W;
-        p.lds = (size_t)(C2_TBL_INTS + 32 + 4) * 4 + (size_t)W * p.ntw * 1024 + (size_t)p.ntw * 1024;
+        p.lds = (size_t)(C2_TBL_INTS + 32 + 4) * 4 + (size_t)W * p.ntw * 1024 + (size_t)p.ntw * 2048;
     }
     return p;
 }
@@ -424,9 +447,10 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
     return 0;
 }
 
-extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo,
-                              const float *res, int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout,
-                              int flags, void *stream) {
+struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; };
+
+static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res, int ldr,
+                     float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, void *stream) {
     D3_CLEAR();
     if (Mout <= 0) return 0;
     if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
@@ -441,6 +465,12 @@ extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void
     a.inv = (65536u + a.S - 1) / a.S;
     a.invK = (65536u + K - 1) / K;
     a.xbf16 = xbf16; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
+    a.bnx = nullptr; a.bn_mean = a.bn_var = a.bn_gamma = a.bn_beta = nullptr; a.ldbx = 0; a.bn_relu = 0; a.bn_eps = 0.f;
+    if (bn) {
+        if (bn->ldx & 3) return D3_ERR_ARG;
+        a.bnx = bn->x; a.bn_mean = bn->mean; a.bn_var = bn->var; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
+        a.ldbx = bn->ldx; a.bn_relu = bn->relu; a.bn_eps = bn->eps;
+    }
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
     const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + 2.0 * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
@@ -469,6 +499,24 @@ extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void
 #undef C2_CASE
     d3_prof_end(pr, s);
     return rc;
+}
+
+extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo,
+                              const float *res, int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout,
+                              int flags, void *stream) {
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, stream);
+}
+
+// Data gradient of a BatchNorm -> ReLU -> convolution unit with the BatchNorm backward reductions fused in: the stored
+// value is g = (sum_k dy[tbl[u,k]] @ Wk) * relu'(bn(bnx[u])) and part receives (sum g, sum g * xhat) per channel, where
+// xhat = (bnx - mean) * rsqrt(var + eps): exactly what d3_bn_relu_bwd's reduction pass computes from a second read of
+// x and dy.  bnx (Mout, ldbx) fp32 is the BatchNorm INPUT.
+extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
+                                    const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
+                                    const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
+                                    int flags, void *stream) {
+    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps};
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, stream);
 }
 
 // ------------------------------------------------------------------------------ weight gradient

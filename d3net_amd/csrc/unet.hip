@@ -247,6 +247,9 @@ struct OpD {
     int in_grad_mode;                 // backward: 0 = input needs no gradient, 1 = write, 2 = accumulate
     int res_mode;                     // backward: 0 none, 1 alias (no work), 2 add, 3 copy (first contribution)
     int needs_dgrad_pack;
+    int bn_of_in;                     // CONV: index of the BNACT op that produced `in` (-1: none) -> fused BN-backward dgrad
+    int fused_by;                     // BNACT: index of the CONV whose dgrad epilogue already did this op's reductions
+    size_t bpart_off; int bparts;     // BNACT: gradient-arena offset / count of those partials
 };
 struct Net {
     std::vector<TensorD> T;
@@ -276,6 +279,10 @@ static int esize(int dtype) { return dtype == 1 ? 2 : 4; }
 extern "C" int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout);
 extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
                               int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
+extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
+                                    const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
+                                    const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
+                                    int flags, void *stream);
 extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
                                 int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);
@@ -300,6 +307,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -356,6 +364,15 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     }
     for (auto &o : n->ops)
         if (o.type == OP_PADCAST) n->B[n->T[o.out].buf].need_grad = 0;
+    // BN -> ReLU -> conv units: the conv's data gradient does the BatchNorm-backward reductions in its epilogue
+    for (size_t i = 0; i < n->ops.size(); i++) {
+        OpD &o = n->ops[i];
+        if (o.type != OP_CONV || o.in_grad_mode != 1) continue;
+        for (size_t j = 0; j < n->ops.size(); j++) {
+            OpD &b = n->ops[j];
+            if (b.type == OP_BNACT && b.out == o.in && b.fused_by < 0 && n->T[b.out].dtype == 1) { o.bn_of_in = (int)j; b.fused_by = (int)i; break; }
+        }
+    }
     hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
     return n;
 }
@@ -415,6 +432,13 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
             const size_t s = (size_t)bn_blocks2(n->rows[t.level], t.C) * 2 * t.C * 4;
             if (s > bnscr) bnscr = s;
         }
+    }
+    for (auto &o : n->ops) {
+        if (o.type != OP_BNACT || o.fused_by < 0) continue;
+        const OpD &cv = n->ops[o.fused_by];
+        int Min, Mout; conv_dims(n, cv, Min, Mout);
+        o.bparts = d3_spconv_fwd2_nparts(Min, cv.K, cv.Cout, cv.CinW);
+        o.bpart_off = goff; goff += d3_align((size_t)o.bparts * 2 * ((cv.CinW + 15) / 16 * 16) * 4);
     }
     n->arena_bytes = off;
     n->bnscr_off = goff; goff += d3_align(bnscr); n->bnscr_bytes = bnscr;
@@ -621,8 +645,18 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             if (o.in_grad_mode) {
                 int ldgi, root_i; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i);
                 if (root_i >= 0) wait_pending(root_i);
-                int rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
+                int rc;
+                if (o.bn_of_in >= 0) {
+                    const OpD &b = n->ops[o.bn_of_in];
+                    const TensorD &tx = n->T[b.in];
+                    float *mean = (float *)(arena + b.state_off), *var = mean + tx.C;
+                    rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
+                                              (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
+                                              (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, 0, stream);
+                } else {
+                    rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
                                         (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0), stream);
+                }
                 if (rc) return rc;
             }
             if (o.res_mode >= 2) {
@@ -640,15 +674,22 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             const float *gamma = (const float *)params[o.gamma], *beta = (const float *)params[o.beta];
             int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
             const float *x = (const float *)tptr(n, arena, input, o.in);
-            const int nb = bn_blocks2(M, C);
-            un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr);
-            un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>(bnscr, nb, C, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
+            int relu = o.relu;
+            if (o.fused_by >= 0) {   // reductions done (and the ReLU mask applied) by the consumer conv's data gradient
+                un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
+                                                               pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
+                relu = 0;
+            } else {
+                const int nb = bn_blocks2(M, C);
+                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr);
+                un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>(bnscr, nb, C, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
+            }
             if (o.in_grad_mode) {
                 int ldgi, root_i; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i);
                 if (root_i >= 0) wait_pending(root_i);
                 const long long total = (long long)M * (C / 4);
                 un_bn_bwd_apply_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
-                                                                               o.eps, o.relu, o.in_grad_mode == 2 ? 1 : 0);
+                                                                               o.eps, relu, o.in_grad_mode == 2 ? 1 : 0);
             }
         }
     }

@@ -247,8 +247,10 @@ class BFSCluster(Function):
             S, P = S.value, P.value
             cluster_idxs = torch.empty((S, 2), dtype=torch.int32, device=dev)
             cluster_offsets = torch.empty(P + 1, dtype=torch.int32, device=dev)
-            check(L.d3_bfs_cluster_fill(_ptr(sem), _ptr(idx), _ptr(sl), N, _ptr(ws), ws.numel(), _ptr(cluster_idxs),
-                                        _ptr(cluster_offsets), S, P, _stream()), "bfs_cluster_fill")
+            nact = int(idx.numel())
+            rec = _workspace(L.d3_bfs_cluster_erec_bytes(nact), dev, "clrec")
+            check(L.d3_bfs_cluster_fill2(_ptr(sem), _ptr(idx), _ptr(sl), N, _ptr(ws), ws.numel(), _ptr(rec), rec.numel(), nact,
+                                         _ptr(cluster_idxs), _ptr(cluster_offsets), S, P, _stream()), "bfs_cluster_fill2")
         if on_cpu:
             return cluster_idxs.cpu(), cluster_offsets.cpu()
         return cluster_idxs, cluster_offsets

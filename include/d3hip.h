@@ -103,6 +103,16 @@ int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, c
                         void *ws, size_t ws_bytes, int *cluster_idxs, int *cluster_offsets, int sumNPoint,
                         int nCluster, void *stream);
 
+/* d3_bfs_cluster_fill with the level loop in "record form" (csrc/cluster.hip): a parallel pre-pass rewrites the lists of
+ * the kept clusters as (node, dense id, list start, list length) records and the BFS keeps visited bits, frontier and
+ * first-discoverer arbitration in LDS -- one global round trip per batch of 2048 edges instead of four per level.
+ * erec: d3_bfs_cluster_erec_bytes(nActive) bytes of scratch, nActive = length of ball_query_idxs.  Outputs are
+ * bit-identical to d3_bfs_cluster_fill. */
+size_t d3_bfs_cluster_erec_bytes(long long nActive);
+int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, void *ws,
+                         size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int *cluster_idxs,
+                         int *cluster_offsets, int sumNPoint, int nCluster, void *stream);
+
 /* ---- sparse 3-D convolution (MinkowskiEngine subset) ---------------------------------- */
 /* Coordinates are (M,4) int32 rows [batch, x, y, z] (ME.SparseTensor(coordinates=...),
  * reference: model/pointgroup.py:176,268).  Key range as for voxelize_idx.
@@ -160,6 +170,12 @@ int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags
 int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout);
 int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
                    int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
+/* fwd2 as the data gradient of a BatchNorm -> ReLU -> conv unit, with the BatchNorm-backward reductions in the epilogue:
+ * out = (sum_k x[tbl[u,k]] @ Wk) * relu'(bn(bnx[u])), part = per-workgroup (sum out, sum out * xhat) per channel. */
+int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
+                         const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
+                         const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                         void *stream);
 size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
                      int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);

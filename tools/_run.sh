@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/ph; export TMPDIR=/tmp
-timeout 300 python tools/phase_times.py 10 > gpurun_out/ph/phase.txt 2>&1; cat gpurun_out/ph/phase.txt | tail -16
-timeout 300 python tools/hostprof.py > gpurun_out/ph/hostprof.txt 2>&1; head -45 gpurun_out/ph/hostprof.txt
-timeout 300 python -m pytest tests/test_pg_ops_gpu.py -x -q 2>&1 | tail -3
+export TMPDIR=/tmp; mkdir -p gpurun_out/ph
+rm -rf /tmp/pp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o p -- python3 tools/phase_times.py 4 > /dev/null 2>&1
+f=$(find /tmp/pp -name "*kernel_trace.csv"); head -2 $f | cut -c1-600
+python tools/backward_timeline.py $f
