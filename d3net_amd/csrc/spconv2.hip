@@ -101,7 +101,55 @@ struct Conv2Args {
     // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
     const float *bnx; const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
     int ldbx, bn_relu; float bn_eps;
+    // last-workgroup finalize of the partials (no separate reduction launch): fin_mode 1 = forward batch statistics
+    // (mean, biased var, running update), 2 = BatchNorm-backward sums (+ dgamma / dbeta)
+    int *fin_counter; int fin_mode, fin_M, fin_accum;
+    float *fin_a, *fin_b, *fin_c, *fin_d; float fin_momentum;
 };
+
+// Called by every workgroup after its partial row is written.  The last one to arrive (device-scope ticket) reduces all
+// rows: one wave per channel, lanes stride over the rows, fp64, fixed order -- the same arithmetic as the stand-alone
+// finalize kernels.  The per-XCD L2s are not coherent inside a kernel and an agent-scope release fence writes back the
+// whole L2 (measured: 2.3x slower convolutions with a __threadfence() per workgroup), so the partial rows and the
+// ticket travel as agent-scope (write-through / L2-bypassing) accesses instead and only completion order is enforced.
+__device__ __forceinline__ void c2_part_store(float *p, float v) {
+    __hip_atomic_store((int *)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float c2_part_load(const float *p) {
+    return __int_as_float(__hip_atomic_load((const int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void c2_last_block_finalize(const Conv2Args &a, int total_blocks, int nparts, int *flagS) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) *flagS = (atomicAdd(a.fin_counter, 1) == total_blocks - 1) ? 1 : 0;
+    __syncthreads();
+    if (!*flagS) return;
+    const int Wd = a.NT * 16, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int c = threadIdx.x >> 6; c < a.Cout; c += nw) {
+        double sa = 0., sb = 0.;
+        for (int b = lane; b < nparts; b += 64) {
+            sa += (double)c2_part_load(&a.part[(size_t)b * 2 * Wd + c]);
+            sb += (double)c2_part_load(&a.part[(size_t)b * 2 * Wd + Wd + c]);
+        }
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+        if (lane != 0) continue;
+        if (a.fin_mode == 1) {
+            const double M = (double)a.fin_M, m = sa / M;
+            double v = sb / M - m * m;
+            if (v < 0.) v = 0.;
+            a.fin_a[c] = (float)m; a.fin_b[c] = (float)v;
+            if (a.fin_c) {
+                a.fin_c[c] = (1.f - a.fin_momentum) * a.fin_c[c] + a.fin_momentum * (float)m;
+                a.fin_d[c] = (1.f - a.fin_momentum) * a.fin_d[c] + a.fin_momentum * (float)(v * (M / (a.fin_M > 1 ? M - 1. : 1.)));
+            }
+        } else {
+            a.fin_a[c] = (float)sa; a.fin_a[a.Cout + c] = (float)sb;
+            if (a.fin_c) a.fin_c[c] = (a.fin_accum ? a.fin_c[c] : 0.f) + (float)sa;   // dbeta
+            if (a.fin_b) a.fin_b[c] = (a.fin_accum ? a.fin_b[c] : 0.f) + (float)sb;   // dgamma
+        }
+    }
+    if (threadIdx.x == 0) *a.fin_counter = 0;
+}
 
 __device__ __forceinline__ bf16x8_t c2_zero() {
     uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -269,8 +317,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; w++) s += redS[w * 2 * NT * 16 + t];
-            a.part[(long long)b * 2 * NT * 16 + t] = s;
+            if (a.fin_counter) c2_part_store(&a.part[(long long)b * 2 * NT * 16 + t], s);
+            else a.part[(long long)b * 2 * NT * 16 + t] = s;
         }
+        if (a.fin_counter)   // (flag word: the spare LDS behind the statistics rows; no static LDS in front of the dynamic region)
+            c2_last_block_finalize(a, (int)gridDim.x, (int)gridDim.x, (int *)(redS + 4 * 2 * NT * 16));
     }
 }
 
@@ -382,9 +433,12 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             const int cl = (t < CW) ? t : t - CW;
             float s = 0.f;
             for (int row = 0; row < 16; row++) s += (t < CW) ? finS[row * CW + cl] : fin2S[row * CW + cl];
-            if (n0 * 16 + cl < a.NT * 16)
-                a.part[(long long)blockIdx.x * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl] = s;
+            if (n0 * 16 + cl < a.NT * 16) {
+                float *pp = &a.part[(long long)blockIdx.x * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl];
+                if (a.fin_counter) c2_part_store(pp, s); else *pp = s;
+            }
         }
+        if (a.fin_counter) c2_last_block_finalize(a, (int)(gridDim.x * gridDim.y), (int)gridDim.x, (int *)(kmaskS + 1));
     }
 }
 
@@ -448,9 +502,11 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
 }
 
 struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; };
+struct Conv2Fin { int *counter; int mode, M, accum; float *a, *b, *c, *d; float momentum; };
 
 static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res, int ldr,
-                     float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, void *stream) {
+                     float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, const Conv2Fin *fin,
+                     void *stream) {
     D3_CLEAR();
     if (Mout <= 0) return 0;
     if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
@@ -470,6 +526,11 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         if (bn->ldx & 3) return D3_ERR_ARG;
         a.bnx = bn->x; a.bn_mean = bn->mean; a.bn_var = bn->var; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
         a.ldbx = bn->ldx; a.bn_relu = bn->relu; a.bn_eps = bn->eps;
+    }
+    a.fin_counter = nullptr; a.fin_mode = 0; a.fin_M = 0; a.fin_accum = 0; a.fin_a = a.fin_b = a.fin_c = a.fin_d = nullptr; a.fin_momentum = 0.f;
+    if (fin && part) {
+        a.fin_counter = fin->counter; a.fin_mode = fin->mode; a.fin_M = fin->M; a.fin_accum = fin->accum;
+        a.fin_a = fin->a; a.fin_b = fin->b; a.fin_c = fin->c; a.fin_d = fin->d; a.fin_momentum = fin->momentum;
     }
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
     const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + 2.0 * (double)K * Cin * Cout +
@@ -504,7 +565,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
 extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo,
                               const float *res, int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout,
                               int flags, void *stream) {
-    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, stream);
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, nullptr, stream);
 }
 
 // Data gradient of a BatchNorm -> ReLU -> convolution unit with the BatchNorm backward reductions fused in: the stored
@@ -516,7 +577,28 @@ extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, cons
                                     const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
                                     int flags, void *stream) {
     Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps};
-    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, stream);
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, nullptr, stream);
+}
+
+// fwd2 / fwd2_bnbwd with the reduction of the partials done by the last workgroup to finish (no finalize launch).
+// counter: one zero-initialised int, left at zero.  mode 1: mean / var (C each) <- batch statistics of the stored
+// values over M rows; running_mean / running_var updated with `momentum` when non-NULL (d3_bn_stats semantics).
+// mode 2 (with the bnbwd arguments): sums (2C) = (sum g, sum g*xhat); dgamma / dbeta written (accumulated with accum).
+extern "C" int d3_spconv_fwd2_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
+                                  int ldr, float *part, int *counter, float *mean, float *var, float *running_mean,
+                                  float *running_var, float momentum, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                                  void *stream) {
+    Conv2Fin fin{counter, 1, Mout, 0, mean, var, running_mean, running_var, momentum};
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, &fin, stream);
+}
+extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
+                                        const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
+                                        const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma,
+                                        float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                                        void *stream) {
+    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps};
+    Conv2Fin fin{counter, 2, Mout, accum, sums, dgamma, dbeta, nullptr, 0.f};
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, &fin, stream);
 }
 
 // ------------------------------------------------------------------------------ weight gradient

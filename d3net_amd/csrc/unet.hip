@@ -21,6 +21,7 @@
 #include <vector>
 #include <map>
 #include <string.h>
+#include <stdlib.h>
 
 extern "C" size_t d3_spconv_pack_bytes(int K, int Cin, int Cout);
 
@@ -250,6 +251,9 @@ struct OpD {
     int bn_of_in;                     // CONV: index of the BNACT op that produced `in` (-1: none) -> fused BN-backward dgrad
     int fused_by;                     // BNACT: index of the CONV whose dgrad epilogue already did this op's reductions
     size_t bpart_off; int bparts;     // BNACT: gradient-arena offset / count of those partials
+    int fin_bn;                       // CONV: BNACT whose batch statistics this conv's last workgroup finalizes (-1: none)
+    int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
+    size_t cnt_off, bcnt_off;         // ticket counters (arena / gradient arena)
 };
 struct Net {
     std::vector<TensorD> T;
@@ -259,7 +263,8 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
-    bool planned = false;
+    bool planned = false, lastblock = false;
+    size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
     // packing jobs (device copy refreshed when a parameter pointer or the arena moves)
     std::vector<PackJob> jobs;
     PackJob *jobs_dev = nullptr;
@@ -283,6 +288,15 @@ extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, cons
                                     const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                                     const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
                                     int flags, void *stream);
+extern "C" int d3_spconv_fwd2_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
+                                  int ldr, float *part, int *counter, float *mean, float *var, float *running_mean,
+                                  float *running_var, float momentum, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                                  void *stream);
+extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
+                                        const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
+                                        const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma,
+                                        float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                                        void *stream);
 extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
                                 int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);
@@ -307,7 +321,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -364,6 +378,19 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     }
     for (auto &o : n->ops)
         if (o.type == OP_PADCAST) n->B[n->T[o.out].buf].need_grad = 0;
+    // a BatchNorm whose statistics come from exactly one convolution covering exactly its channels: that convolution's
+    // last workgroup CAN finalize them (no finalize launch).  Measured on MI355X (canonical scene): forward 2.4 -> 3.4 ms,
+    // backward 5.4 -> 5.7 ms -- every workgroup has to wait for its write-through partial row and take a memory-side
+    // ticket before it retires, which costs more than the 160 tiny finalize launches it saves.  Off unless
+    // D3_LASTBLOCK_FINALIZE=1 (kept for hardware with a coherent L2).
+    const char *lb = getenv("D3_LASTBLOCK_FINALIZE");
+    n->lastblock = lb && lb[0] == '1';
+    for (size_t j = 0; n->lastblock && j < n->ops.size(); j++) {
+        OpD &b = n->ops[j];
+        if (b.type != OP_BNACT || b.srcs.size() != 1) continue;
+        OpD &p = n->ops[b.srcs[0].op];
+        if (p.type == OP_CONV && p.fin_bn < 0 && b.srcs[0].c0 == 0 && b.srcs[0].cn == n->T[b.in].C) { p.fin_bn = (int)j; b.fin_by = b.srcs[0].op; }
+    }
     // BN -> ReLU -> conv units: the conv's data gradient does the BatchNorm-backward reductions in its epilogue
     for (size_t i = 0; i < n->ops.size(); i++) {
         OpD &o = n->ops[i];
@@ -440,6 +467,12 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
         o.bparts = d3_spconv_fwd2_nparts(Min, cv.K, cv.Cout, cv.CinW);
         o.bpart_off = goff; goff += d3_align((size_t)o.bparts * 2 * ((cv.CinW + 15) / 16 * 16) * 4);
     }
+    n->cnt_off0 = off;
+    for (auto &o : n->ops) if (o.type == OP_CONV) { o.cnt_off = off; off += 4; }
+    off = d3_align(off); n->cnt_bytes = off - n->cnt_off0;
+    n->bcnt_off0 = goff;
+    for (auto &o : n->ops) if (o.type == OP_BNACT) { o.bcnt_off = goff; goff += 4; }
+    goff = d3_align(goff); n->bcnt_bytes = goff - n->bcnt_off0;
     n->arena_bytes = off;
     n->bnscr_off = goff; goff += d3_align(bnscr); n->bnscr_bytes = bnscr;
     n->wgws_off = goff; goff += d3_align(wgws); n->wgws_bytes = wgws;
@@ -479,6 +512,7 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
     hipStream_t s = d3_stream(stream);
     char *arena = (char *)arena_;
     Maps maps{k3, child, up};
+    if (training && n->cnt_bytes) D3_CHECK(hipMemsetAsync(arena + n->cnt_off0, 0, n->cnt_bytes, s));
     // ---- all weights -> bf16 fragment order, one launch
     {
         std::vector<PackJob> jobs;
@@ -539,8 +573,18 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
             const float *res = nullptr; int ldr = 0;
             if (o.res >= 0) { res = (const float *)tptr(n, arena, input, o.res); ldr = n->T[o.res].ld; }
             float *part = (o.stats && training) ? (float *)(arena + o.part_off) : nullptr;
-            int rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
+            int rc;
+            if (part && o.fin_bn >= 0) {
+                const OpD &b = n->ops[o.fin_bn];
+                float *mean = (float *)(arena + b.state_off), *var = mean + o.Cout;
+                rc = d3_spconv_fwd2_fin(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
+                                        res, ldr, part, (int *)(arena + o.cnt_off), mean, var,
+                                        b.rmean >= 0 ? (float *)params[b.rmean] : nullptr, b.rvar >= 0 ? (float *)params[b.rvar] : nullptr,
+                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, ti.dtype == 1 ? D3_CONV_XBF16 : 0, stream);
+            } else {
+                rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
                                     res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, ti.dtype == 1 ? D3_CONV_XBF16 : 0, stream);
+            }
             if (rc) return rc;
         } else if (o.type == OP_BNACT) {
             const TensorD &ti = n->T[o.in], &to = n->T[o.out];
@@ -556,7 +600,7 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                     const OpD &p = n->ops[r.op];
                     ss[q] = StatSrc{(const float *)(arena + p.part_off), p.nparts, p.partw, r.c0, r.cn};
                 }
-                if (M > 0)
+                if (M > 0 && o.fin_by < 0)
                     un_bn_finalize_kernel<<<(C + 3) / 4, 256, 0, s>>>(ss[0], ss[1], M, C, mean, var,
                                                                    o.rmean >= 0 ? (float *)params[o.rmean] : nullptr,
                                                                    o.rvar >= 0 ? (float *)params[o.rvar] : nullptr, o.momentum);
@@ -614,6 +658,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
         auto it = pending.find(root);
         if (it != pending.end()) { hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
     };
+    if (n->bcnt_bytes) D3_CHECK(hipMemsetAsync(garena + n->bcnt_off0, 0, n->bcnt_bytes, s));
     float *bnscr = (float *)(garena + n->bnscr_off);
     char *wgws = garena + n->wgws_off;
     for (int i = (int)n->ops.size() - 1; i >= 0; i--) {
@@ -650,9 +695,15 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     const OpD &b = n->ops[o.bn_of_in];
                     const TensorD &tx = n->T[b.in];
                     float *mean = (float *)(arena + b.state_off), *var = mean + tx.C;
-                    rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
-                                              (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                              (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, 0, stream);
+                    if (!n->lastblock)
+                        rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
+                                                  (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
+                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, 0, stream);
+                    else
+                    rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
+                                                  (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
+                                                  (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
+                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, 0, stream);
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
                                         (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0), stream);
@@ -675,9 +726,10 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
-            if (o.fused_by >= 0) {   // reductions done (and the ReLU mask applied) by the consumer conv's data gradient
-                un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
-                                                               pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
+            if (o.fused_by >= 0) {   // reductions (and the ReLU mask) done by the consumer conv's data gradient
+                if (!n->lastblock)
+                    un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
+                                                                   pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
                 relu = 0;
             } else {
                 const int nb = bn_blocks2(M, C);
