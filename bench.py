@@ -115,10 +115,11 @@ def main():
     model.teacher = not args.no_teacher
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay, fused=True)
-    from d3net_amd.distributed import FlatGradAllReduce, broadcast_module
+    from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
     if world > 1:  # identical replicas
         broadcast_module(model)
-    grad_sync = FlatGradAllReduce(params, dev) if world > 1 else None
+    # the executors' flat gradient buffers are all-reduced in place (RCCL, sum -> mean); heads share one packed collective
+    grad_sync = BucketGradAllReduce(params, model.gradient_buckets) if world > 1 else None
 
     if args.small:
         occ, sem, inst, _ = S.occupancy_grid((100, 75, 50), 4, (8, 30), (8, 25), 0)
@@ -131,7 +132,7 @@ def main():
 
     def step():
         d = dict(batch)
-        opt.zero_grad(set_to_none=True)
+        model.zero_grad(set_to_none=True)
         loss, d = model.training_step(d)
         loss.backward()
         if grad_sync is not None:   # one fused gradient all-reduce over RCCL (sum -> mean), gradients only
@@ -145,7 +146,8 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    L.d3_prof_enable(1)
+    PROF_STRIDE = 7   # every 7th convolution launch is bracketed by HIP events (coprime with the launches per step)
+    L.d3_prof_enable(PROF_STRIDE)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -162,10 +164,10 @@ def main():
 
     # per-kernel launch durations measured with HIP events on the launch stream during the timed region
     prof = {}
-    for fam, name in ((0, "spconv_fwd_mfma_kernel"), (1, "spconv_wgrad_mfma_kernel")):
+    for fam, name in ((0, "spconv_fwd2_kernel"), (2, "spconv_fwd2_split_kernel"), (1, "spconv_wgrad2_kernel")):
         n, ms, by, fl = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0)
         L.d3_prof_collect(fam, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
-        prof[name] = dict(launches=n.value, total_ms=ms.value, bytes=by.value)
+        prof[name] = dict(launches=n.value, total_ms=ms.value, bytes=by.value)   # the sampled launches
     L.d3_prof_enable(0)
 
     if rank == 0:
@@ -192,14 +194,17 @@ def main():
                                    "U-Net, teacher clustering, AdamW" % (n_voxels, n_points),
                        "scenes_per_gpu": 1, "points": n_points, "voxels": n_voxels,
                        "raw_proposals": int(d.get("num_raw_proposals", 0)), "parallelism": "scene-parallel dp%d" % world,
-                       "precision": "fp32 storage, bf16 MFMA operands, fp32 accumulate"},
+                       "precision": "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate"},
             "final_loss": float(loss),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": pd["bytes"] / max(pd["launches"], 1),
-                         "launches_per_step": pd["launches"] / args.steps, "avg_launch_us": avg_ms * 1e3,
-                         "share_of_step": pd["total_ms"] / (1e3 * elapsed),
-                         "other": {k: {"launches_per_step": v["launches"] / args.steps,
+                         "launches_per_step": pd["launches"] * PROF_STRIDE / args.steps, "avg_launch_us": avg_ms * 1e3,
+                         "launches_sampled": pd["launches"],
+                         "timing": "HIP events on the launch stream around every %d-th convolution launch of the timed "
+                                   "region, minus the elapsed time of an empty event pair" % PROF_STRIDE,
+                         "share_of_step": pd["total_ms"] * PROF_STRIDE / (1e3 * elapsed),
+                         "other": {k: {"launches_per_step": v["launches"] * PROF_STRIDE / args.steps,
                                        "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1),
                                        "achieved": (v["bytes"] / max(v["total_ms"], 1e-9)) / 1e6}
                                    for k, v in prof.items() if k != dom}},

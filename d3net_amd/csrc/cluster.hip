@@ -26,6 +26,8 @@
 //      written in (parent position, list order) -- which is the FIFO order.
 // All passes stream the neighbour lists: bytes = 4*nActive per pass + 12*n, HBM/L2 bound.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 #define CL_CAP 1000
 #define CL_BFS_THREADS 1024
@@ -406,11 +408,11 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
 // with the smallest flat edge id (= the FIFO discoverer).  Batches are processed in flat edge order and the bitmap
 // is updated between them, so "first discoverer" is preserved exactly.  One global round trip per batch.
 #define B2_THREADS 1024
-#define B2_EPT 2
+#define B2_EPT 4
 #define B2_BATCH (B2_THREADS * B2_EPT)
-#define B2_HASH 4096
+#define B2_HASH 8192
 #define B2_FMAX 1024
-#define B2_BITWORDS 16384                       // 64 KB: clusters up to 524288 points; larger ones use cl_bfs_kernel
+#define B2_BITWORDS 8192                        // 32 KB: clusters up to 262144 points; larger ones use cl_bfs_kernel
 #define B2_MAXSIZE (B2_BITWORDS * 32)
 
 __global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, int *lcnt, int *lid, int n) {
@@ -452,11 +454,38 @@ __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ id
     }
 }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave
+// (s_waitcnt vmcnt(0)), and each level issues write-through stores (cluster_idxs, queue records) whose completion
+// nobody in the level loop depends on: ~2 us per barrier, several barriers per level, ~200 levels.  All cross-wave
+// traffic of the level loop goes through LDS, so only lgkmcnt has to drain.
+__device__ __forceinline__ void b2_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ int b2_blk_scan(int v, int *wsum, int &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wv] = x;
+    b2_barrier();
+    if (wv == 0) {
+        int w = (lane < nw) ? wsum[lane] : 0, ws = w;
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(ws, o); if (lane >= o) ws += y; }
+        if (lane < nw) wsum[lane] = ws - w;
+        if (lane == 63) wsum[nw] = ws;
+    }
+    b2_barrier();
+    const int r = wsum[wv] + x - v;
+    total = wsum[nw];
+    b2_barrier();
+    return r;
+}
+
 __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restrict__ erec, const int *__restrict__ start_len,
                                                             const int *__restrict__ lid, const int *__restrict__ seeds,
                                                             const int *__restrict__ koff, const int *__restrict__ sizes,
-                                                            int *qst_all, int *qln_all, int *cluster_idxs) {
+                                                            int *qst_all, int *qln_all, int *cluster_idxs, int *dbg) {
     extern __shared__ __attribute__((aligned(16))) int b2_smem[];
+    int n_levels = 0, n_batches = 0;
     unsigned int *bitmap = (unsigned int *)b2_smem;                 // B2_BITWORDS
     int *hkey = b2_smem + B2_BITWORDS;                              // B2_HASH
     int *hval = hkey + B2_HASH;                                     // B2_HASH
@@ -487,48 +516,68 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
             const int nf = min(B2_FMAX, hi - fb);
             int *cst = fst + cur * B2_FMAX, *cln = fln + cur * B2_FMAX;
             if (!small) {
+                __syncthreads();   // (global queue records written by other waves: full barrier)
                 if (tid < nf) { cst[tid] = ld_dev(&qst[fb + tid]); cln[tid] = ld_dev(&qln[fb + tid]); }
-                __syncthreads();
+                b2_barrier();
             }
             int E;
-            const int off = cl_blk_scan(tid < nf ? cln[tid] : 0, s_w, E);
+            const int off = b2_blk_scan(tid < nf ? cln[tid] : 0, s_w, E);
             if (tid < nf) s_off[tid] = off;
             if (tid == 0) s_off[nf] = E;
-            __syncthreads();
+            b2_barrier();
             for (int e0 = 0; e0 < E; e0 += B2_BATCH) {
+                // A level is a chain of dependent LDS / L2 latencies, so the per-thread work is written for
+                // instruction-level parallelism: one binary search per thread (its edges are consecutive, the owners of the
+                // following edges are found by stepping), all record loads, then all bitmap tests, then all first hash
+                // probes are issued before any of their results is used.
                 int4 rec[B2_EPT];
-                int slot[B2_EPT];
+                int slot[B2_EPT], key[B2_EPT], oldk[B2_EPT];
                 bool cand[B2_EPT];
+                const int ef = e0 + tid * B2_EPT;               // first edge of this thread
+                int a = 0;
+                if (ef < E) {
+                    int b = nf;                                  // largest f with s_off[f] <= ef
+                    while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= ef) a = m; else b = m; }
+                }
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
-                    const int e = e0 + tid * B2_EPT + r;    // a thread's edges are consecutive in flat order
+                    const int e = ef + r;
                     cand[r] = false; slot[r] = 0; rec[r] = make_int4(-1, 0, 0, 0);
                     if (e < E) {
-                        int a = 0, b = nf;  // largest f with s_off[f] <= e
-                        while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= e) a = m; else b = m; }
+                        while (s_off[a + 1] <= e) a++;          // s_off[nf] = E > e terminates
                         rec[r] = erec[cst[a] + e - s_off[a]];
                     }
                 }
+                unsigned int bw[B2_EPT];
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) bw[r] = (rec[r].x >= 0) ? bitmap[rec[r].y >> 5] : 0xFFFFFFFFu;
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
-                    if (rec[r].x >= 0 && !((bitmap[rec[r].y >> 5] >> (rec[r].y & 31)) & 1u)) {
-                        cand[r] = true;
-                        const int key = rec[r].y, v = tid * B2_EPT + r;
-                        int h = (int)(((unsigned int)key * 2654435761u) >> 20);
-                        for (;;) {
-                            const int old = atomicCAS(&hkey[h], -1, key);
-                            if (old == -1 || old == key) { atomicMin(&hval[h], v); break; }
+                    cand[r] = rec[r].x >= 0 && !((bw[r] >> (rec[r].y & 31)) & 1u);
+                    key[r] = rec[r].y;
+                    slot[r] = (int)(((unsigned int)key[r] * 2654435761u) >> 19);
+                    oldk[r] = 0;
+                }
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) if (cand[r]) oldk[r] = atomicCAS(&hkey[slot[r]], -1, key[r]);
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) {
+                    if (cand[r]) {
+                        int h = slot[r], old = oldk[r];
+                        while (old != -1 && old != key[r]) {     // occupied by another node: linear probing
                             h = (h + 1) & (B2_HASH - 1);
+                            old = atomicCAS(&hkey[h], -1, key[r]);
                         }
                         slot[r] = h;
+                        atomicMin(&hval[h], tid * B2_EPT + r);
                     }
                 }
-                __syncthreads();
+                b2_barrier();
                 int win[B2_EPT], nwin = 0;
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) { win[r] = (cand[r] && hval[slot[r]] == tid * B2_EPT + r) ? 1 : 0; nwin += win[r]; }
                 int tot;
-                const int pos = cl_blk_scan(nwin, s_w, tot);     // (barriers inside: every hval read is done)
+                const int pos = b2_blk_scan(nwin, s_w, tot);     // (barriers inside: every hval read is done)
                 int k = 0;
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
@@ -545,13 +594,15 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                     if (cand[r]) { hkey[slot[r]] = -1; hval[slot[r]] = CL_INF; }   // every occupied slot has >= 1 candidate
                 }
                 tail += tot;
-                __syncthreads();
-                if (tail >= size) return;   // every node of the component is queued: the remaining edges (a dense
+                b2_barrier();
+                n_batches++;
+                if (tail >= size) { if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; } return; }   // every node of the component is queued: the remaining edges (a dense
                                             // component has ~size^2 of them) cannot discover anything
             }
         }
-        lo = hi; hi = tail; cur ^= 1;
+        lo = hi; hi = tail; cur ^= 1; n_levels++;
     }
+    if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; }
 }
 
 extern "C" size_t d3_bfs_cluster_erec_bytes(long long nActive) { return (size_t)(nActive > 0 ? nActive : 1) * sizeof(int4); }
@@ -579,8 +630,14 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
         cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, w.lcnt, w.lid, n);
         cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.lid, (int4 *)erec, n);
+        const bool debug = getenv("D3_BFS_DEBUG") != nullptr;
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.lid, w.seeds, w.koff, w.sizes,
-                                                        w.fcnt, w.qln, cluster_idxs);
+                                                        w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
+        if (debug) {
+            int h[60];
+            hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);
+            for (int c = 0; c < nCluster && c < 20; c++) fprintf(stderr, "bfs2 cluster %d size %d levels %d batches %d\n", c, h[c * 3], h[c * 3 + 1], h[c * 3 + 2]);
+        }
         // clusters beyond the LDS bitmap (> 524288 points): the generic level loop (exits at once otherwise)
         cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
                                                          w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, B2_MAXSIZE);

@@ -41,17 +41,25 @@ static size_t g_prof_used = 0;
 static int g_prof_on = 0;
 #define PROF_MAX 200000
 
+static int g_prof_stride = 1;
+static unsigned long long g_prof_seq = 0;
+// on = 0: off; on = n >= 1: bracket every n-th convolution launch (an event pair is a queue barrier plus a timestamp
+// write: bracketing all ~260 launches of a step costs the step ~2 ms; a stride coprime with the launches per step
+// rotates through the layers, so over the timed region every layer is sampled)
 extern "C" int d3_prof_enable(int on) {
     D3_CLEAR();
-    g_prof_on = on;
+    g_prof_on = on > 0 ? 1 : 0;
+    g_prof_stride = on > 1 ? on : 1;
     g_prof_used = 0;
+    g_prof_seq = 0;
     return 0;
 }
 #include <mutex>
 static std::mutex g_prof_mu;
 static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s) {
+    if (!g_prof_on) return nullptr;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_on || g_prof_used >= PROF_MAX) return nullptr;
+    if ((g_prof_seq++ % (unsigned long long)g_prof_stride) != 0 || g_prof_used >= PROF_MAX) return nullptr;
     if (g_prof_used == g_prof.size()) {
         ProfRec r;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
@@ -65,18 +73,36 @@ static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s
 static void prof_end(ProfRec *r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 void *d3_prof_begin(int family, double bytes, double flops, hipStream_t s) { return prof_begin(family, bytes, flops, s); }
 void d3_prof_end(void *rec, hipStream_t s) { prof_end((ProfRec *)rec, s); }
-// family: 0 = spconv_fwd_mfma (forward + data gradient), 1 = spconv_wgrad_mfma
+// family: 0 = spconv_fwd2 / spconv_fwd_mfma (forward + data gradient), 1 = weight gradient, 2 = spconv_fwd2_split.
+// The elapsed time of an EMPTY event pair on the same stream (median of 32) is subtracted from every sample: it is the
+// cost of the bracket itself, not of the kernel (rocprofv3's kernel durations carry no such term).
 extern "C" int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes,
                                double *total_flops) {
     D3_CLEAR();
     *launches = 0; *total_ms = 0; *total_bytes = 0; *total_flops = 0;
+    static double empty_ms = -1.0;
+    if (empty_ms < 0.0) {
+        hipEvent_t a, b;
+        D3_CHECK(hipEventCreate(&a)); D3_CHECK(hipEventCreate(&b));
+        float v[32];
+        for (int i = 0; i < 32; i++) {
+            hipEventRecord(a, 0); hipEventRecord(b, 0);
+            D3_CHECK(hipEventSynchronize(b));
+            v[i] = 0.f; hipEventElapsedTime(&v[i], a, b);
+        }
+        for (int i = 0; i < 32; i++) for (int j = i + 1; j < 32; j++) if (v[j] < v[i]) { float t = v[i]; v[i] = v[j]; v[j] = t; }
+        empty_ms = v[16];
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
     for (size_t i = 0; i < g_prof_used; i++) {
         ProfRec &r = g_prof[i];
         if (r.family != family) continue;
         D3_CHECK(hipEventSynchronize(r.b));
         float ms = 0.f;
         D3_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
-        *launches += 1; *total_ms += ms; *total_bytes += r.bytes; *total_flops += r.flops;
+        double d = (double)ms - empty_ms;
+        if (d < 0.0005) d = 0.0005;
+        *launches += 1; *total_ms += d; *total_bytes += r.bytes; *total_flops += r.flops;
     }
     return 0;
 }

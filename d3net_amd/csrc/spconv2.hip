@@ -43,6 +43,9 @@ __device__ __forceinline__ unsigned int pack2bf2(float lo, float hi) {
 #ifndef C2_OCC_SMALL
 #define C2_OCC_SMALL 4
 #endif
+#ifndef C2_PREFETCH
+#define C2_PREFETCH 1   // prefetch the next tile's kernel-map rows into registers (7 VGPRs)
+#endif
 #define C2_U(NTV) ((NTV) <= 2 ? C2_UBIG : 4)   // MFMA steps whose gathers are issued together
 
 // ------------------------------------------------------------------------------ weight packing
@@ -181,7 +184,7 @@ __device__ __forceinline__ bf16x8_t c2_load_a(const void *x, int xbf16, long lon
 // B = gathered rows), so a lane ends up with 4 consecutive output channels of one row: the tile is stored (and the
 // residual read) as one contiguous float4 per lane instead of four 64-byte row fragments.
 #define C2_OCC(NTV) ((NTV) <= 4 ? C2_OCC_SMALL : (NTV) <= 9 ? 3 : 2)
-template <int NT, bool WLDS>
+template <int NT, bool WLDS, bool XBF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT), 8))) void spconv_fwd2_kernel(const Conv2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int U = C2_U(NT);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
             if (tile_ < a.ntiles && e < 16 * K && base_ + e < lim_) v[it] = a.tbl ? a.tbl[base_ + e] : (int)(base_ + e); \
         }                                                                                                     \
     }
-    C2_LOAD_TBL(tg0 * 4 + wave)
+    if (C2_PREFETCH) C2_LOAD_TBL(tg0 * 4 + wave)
     if (WLDS) {
         const uint4 *src = (const uint4 *)a.Wp;
         uint4 *dst = (uint4 *)smem;
@@ -230,12 +233,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
         const int tile = tg * 4 + wave;
         if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
         const int row0 = tile * 16;
+        if (!C2_PREFETCH) C2_LOAD_TBL(tile)
 #pragma unroll
         for (int it = 0; it < 7; it++) {
             const int e = lane + it * 64;
             if (e < 16 * K) tblS[e] = v[it];
         }
-        if (tg + 1 < tg1) C2_LOAD_TBL(tile + 4)
+        if (C2_PREFETCH && tg + 1 < tg1) C2_LOAD_TBL(tile + 4)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
                 const int idx = ok ? tblS[r * K + k] : -1;
                 boff[u] = ok ? (((k * S + c8) * NT) * 16 + r) * 8 : r * 8;
                 A[u] = c2_zero();
-                if (idx >= 0) A[u] = c2_load_a(a.x, a.xbf16, (long long)idx * a.ldx + c8 * 8);
+                if (idx >= 0) A[u] = c2_load_a(a.x, XBF ? 1 : 0, (long long)idx * a.ldx + c8 * 8);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -480,12 +484,19 @@ template <int NT>
 static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {   // allow more than 64 KB of dynamic LDS
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;
     }
-    if (p.wlds) spconv_fwd2_kernel<NT, true><<<p.grid, 256, p.lds, s>>>(a);
-    else spconv_fwd2_kernel<NT, false><<<p.grid, 256, p.lds, s>>>(a);
+    if (a.xbf16) {
+        if (p.wlds) spconv_fwd2_kernel<NT, true, true><<<p.grid, 256, p.lds, s>>>(a);
+        else spconv_fwd2_kernel<NT, false, true><<<p.grid, 256, p.lds, s>>>(a);
+    } else {
+        if (p.wlds) spconv_fwd2_kernel<NT, true, false><<<p.grid, 256, p.lds, s>>>(a);
+        else spconv_fwd2_kernel<NT, false, false><<<p.grid, 256, p.lds, s>>>(a);
+    }
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -535,7 +546,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
     const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + 2.0 * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
-    void *pr = d3_prof_begin(0, bytes, 2.0 * 0.0, s);
+    void *pr = d3_prof_begin(p.split ? 2 : 0, bytes, 0.0, s);
     int rc;
     a.NT = (Cout + 15) / 16;
     if (p.split) {

@@ -38,6 +38,36 @@ class FlatGradAllReduce:
                 p.grad.copy_(v)
 
 
+class BucketGradAllReduce:
+    """Gradient averaging for models whose sub-networks already keep their gradients in flat buffers (the native U-Net
+    executors, d3net_amd/netexec.py): those buffers are all-reduced in place -- one collective each, no packing -- and the
+    remaining parameters (the point-level heads: a dozen small tensors) share one packed collective.
+    `buckets()` -> (list of flat gradient tensors, list of the parameters they cover); called every step because the
+    executors create their buffers lazily."""
+
+    def __init__(self, params, buckets):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = buckets
+
+    def __call__(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        flats, covered = self.buckets()
+        cov = {id(p) for p in covered}
+        works = [dist.all_reduce(f, async_op=True) for f in flats]
+        rest = [p for p in self.params if id(p) not in cov and p.grad is not None]
+        if rest:
+            grads = [p.grad for p in rest]
+            packed = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(packed)
+            packed.div_(world)
+            torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(packed.split([g.numel() for g in grads]), grads)])
+        for w, f in zip(works, flats):
+            w.wait()
+            f.div_(world)
+
+
 def broadcast_module(module, src=0):
     """identical replicas at start (what DDP does at construction)"""
     if not (dist.is_available() and dist.is_initialized()):

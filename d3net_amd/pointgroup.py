@@ -148,6 +148,18 @@ class PointGroup(nn.Module):
             return self._exec(name)(x.F, x.coordinate_manager, self.training)
         return module(x).features
 
+    def gradient_buckets(self):
+        """(flat gradient buffers of the native executors, the parameters whose .grad lives in them) -- for
+        d3net_amd.distributed.BucketGradAllReduce.  A parameter whose .grad is not the executor's view is left out."""
+        flats, covered = [], []
+        for ex in self._execs.values():
+            if ex is None or ex._flat_grad is None:
+                continue
+            ok = [p for p, v in zip(ex.b.params, ex._grad_views) if v is not None and p.grad is v]
+            if len(ok) == sum(1 for v in ex._grad_views if v is not None):
+                flats.append(ex._flat_grad); covered += ok
+        return flats, covered
+
     def zero_grad(self, set_to_none=True):
         """nn.Module.zero_grad; gradients owned by the native executors are marked stale instead of being detached
         one by one (the next backward overwrites them)."""

@@ -105,7 +105,7 @@ int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, c
 
 /* d3_bfs_cluster_fill with the level loop in "record form" (csrc/cluster.hip): a parallel pre-pass rewrites the lists of
  * the kept clusters as (node, dense id, list start, list length) records and the BFS keeps visited bits, frontier and
- * first-discoverer arbitration in LDS -- one global round trip per batch of 2048 edges instead of four per level.
+ * first-discoverer arbitration in LDS -- one global round trip per batch of 4096 edges instead of four per level.
  * erec: d3_bfs_cluster_erec_bytes(nActive) bytes of scratch, nActive = length of ball_query_idxs.  Outputs are
  * bit-identical to d3_bfs_cluster_fill. */
 size_t d3_bfs_cluster_erec_bytes(long long nActive);
@@ -192,7 +192,9 @@ int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int
                      int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* Launch timing for bench.py: with profiling on, each MFMA convolution launch is bracketed by HIP events on
- * its stream.  family 0 = forward/data-gradient kernel, 1 = weight-gradient kernel.  collect() synchronises. */
+ * its stream.  family 0 = forward/data-gradient kernel (spconv_fwd2_kernel, or spconv_fwd_mfma_kernel for the first-
+ * generation entry points), 1 = weight-gradient kernels, 2 = spconv_fwd2_split_kernel (few-row levels).
+ * collect() synchronises. */
 int d3_prof_enable(int on);
 int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes, double *total_flops);
 

@@ -46,3 +46,41 @@ def test_flat_grad_allreduce_world2():
         assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6)     # which is the mean of the local ones
     assert r0["shard"] == [0, 2, 4, 6] and r1["shard"] == [1, 3, 5]
     assert not torch.allclose(r0["rm"], r1["rm"])               # BN statistics stay per rank (no SyncBN)
+
+
+def _bucket_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 7), torch.nn.Linear(7, 3))
+    broadcast_module(net)
+    # the first two layers keep their gradients as views of one flat buffer (what the native executors do)
+    owned = list(net[0].parameters()) + list(net[1].parameters())
+    flat = torch.zeros(sum(p.numel() for p in owned))
+    off = 0
+    for p in owned:
+        p.grad = flat[off:off + p.numel()].view_as(p); off += p.numel()
+    torch.manual_seed(100 + rank)
+    net(torch.randn(16, 5)).pow(2).sum().backward()          # accumulates into the views / creates the head grads
+    local = [p.grad.clone() for p in net.parameters()]
+    BucketGradAllReduce(net.parameters(), lambda: ([flat], owned))()
+    ret[rank] = dict(local=local, avg=[p.grad.clone() for p in net.parameters()],
+                     still_views=all(p.grad.data_ptr() >= flat.data_ptr() and
+                                     p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4 for p in owned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_grad_allreduce_world2():
+    """executor-owned flat gradient buffers are all-reduced in place, the remaining parameters in one packed collective"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["still_views"] and r1["still_views"]
+    for a0, a1, l0, l1 in zip(r0["avg"], r1["avg"], r0["local"], r1["local"]):
+        assert torch.allclose(a0, a1)
+        assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6)
