@@ -193,7 +193,7 @@ __global__ void cm_down_fill_kernel(const int *__restrict__ coords, int M, int t
     const int p = parent[i], k = kidx[i];
     child[p * 8 + k] = i;
     up[i * 8 + k] = p;
-    if (flag[i]) {  // first row of its parent cell: defines the output coordinate
+    if (flag && flag[i]) {  // first row of its parent cell: defines the output coordinate
         const int s2 = 2 * ts;
         out_coords[p * 4 + 0] = coords[i * 4];
         out_coords[p * 4 + 1] = floor_div(coords[i * 4 + 1], s2) * s2;
@@ -214,6 +214,117 @@ extern "C" int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, siz
     cm_fill_neg_kernel<<<(int)((nc + T - 1) / T), T, 0, s>>>(child, nc);
     cm_fill_neg_kernel<<<(int)((nu + T - 1) / T), T, 0, s>>>(up, nu);
     cm_down_fill_kernel<<<(M + T - 1) / T, T, 0, s>>>(coords, M, ts, parent, kidx, w.flag, out_coords, child, up);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// All stride-2 levels of a U-Net with ONE host round trip.  d3_kmap_down_count synchronises once per level to return
+// the row count the caller allocates with (6 round trips for the 7-level backbone, each draining the stream).  Here
+// the row counts stay on the device while the whole coordinate pyramid is built -- every kernel takes its row count
+// from device memory and is launched over the level-0 bound -- and one copy returns all of them; the kernel-map
+// tables are then filled with exact sizes (d3_kmap_k3, d3_kmap_down_fill2), which needs no further synchronisation.
+__global__ void cmp_insert_kernel(const int *__restrict__ coords, const int *Mdev, int q, unsigned long long *keys,
+                                  int *first, size_t cap, int *slot_of, int *scalars) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *Mdev) return;
+    int b = coords[i * 4], x = coords[i * 4 + 1], y = coords[i * 4 + 2], z = coords[i * 4 + 3];
+    x = floor_div(x, q) * q; y = floor_div(y, q) * q; z = floor_div(z, q) * q;
+    unsigned long long key;
+    if (!cm_pack(b, x, y, z, key)) { scalars[2] = 1; key &= ~(1ull << 63); }
+    size_t slot = cm_hash(key) & (cap - 1);
+    for (size_t probe = 0; probe < cap; probe++) {
+        unsigned long long prev = atomicCAS(&keys[slot], CM_EMPTY, key);
+        if (prev == CM_EMPTY || prev == key) { atomicMin(&first[slot], i); slot_of[i] = (int)slot; return; }
+        slot = (slot + 1) & (cap - 1);
+    }
+    scalars[2] = 2;
+    slot_of[i] = 0;
+}
+__global__ void cmp_flag_kernel(const int *first, const int *slot_of, int *flag, const int *Mdev, int bound) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bound) flag[i] = (i < *Mdev && first[slot_of[i]] == i) ? 1 : 0;
+}
+// parent / kernel index of every row, the coarse coordinates, and the coarse row count
+__global__ void cmp_level_kernel(const int *__restrict__ coords, const int *Mdev, int ts, const int *flag, const int *scan,
+                                 const int *slot_of, int *slot_vid_unused, int *parent, int *kidx, int *out_coords,
+                                 int *Mnext) {
+    const int M = *Mdev;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *Mnext = (M > 0) ? scan[M - 1] + flag[M - 1] : 0;
+    if (i >= M) return;
+    (void)slot_vid_unused; (void)slot_of;
+    const int s2 = 2 * ts;
+    const int x = coords[i * 4 + 1], y = coords[i * 4 + 2], z = coords[i * 4 + 3];
+    kidx[i] = (x - floor_div(x, s2) * s2) / ts + 2 * ((y - floor_div(y, s2) * s2) / ts) + 4 * ((z - floor_div(z, s2) * s2) / ts);
+    if (flag[i]) {
+        const int p = scan[i];
+        out_coords[p * 4 + 0] = coords[i * 4];
+        out_coords[p * 4 + 1] = floor_div(x, s2) * s2;
+        out_coords[p * 4 + 2] = floor_div(y, s2) * s2;
+        out_coords[p * 4 + 3] = floor_div(z, s2) * s2;
+    }
+}
+// parent[i] = id of the first row of i's cell (two passes: the ids are the scan values of the flagged rows)
+__global__ void cmp_vid_kernel(const int *flag, const int *scan, const int *slot_of, int *slot_vid, const int *Mdev) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *Mdev && flag[i]) slot_vid[slot_of[i]] = scan[i];
+}
+__global__ void cmp_parent_kernel(const int *slot_of, const int *slot_vid, int *parent, const int *Mdev) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *Mdev) parent[i] = slot_vid[slot_of[i]];
+}
+
+__global__ void cmp_set_kernel(int *p, int v) { *p = v; }
+
+// coords0 (M0,4); levels 1..nlevels-1 are written to coords_out[(l-1)*M0*4 ...], parent / kidx / flag of level l
+// (rows of level l) to [l*M0 ...]; rows_host[l] = row count of level l.  ws >= d3_coordmap_ws_bytes(M0).
+extern "C" int d3_kmap_pyramid(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out,
+                               int *parent, int *kidx, int *flag, int *rows_dev, int *rows_host, void *stream) {
+    D3_CLEAR();
+    for (int l = 0; l < nlevels; l++) rows_host[l] = 0;
+    if (M0 <= 0 || nlevels < 1) return 0;
+    CmWs w;
+    if (ws == nullptr || cm_layout(ws, ws_bytes, M0, w) > ws_bytes) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256, nb = (M0 + T - 1) / T;
+    D3_CHECK(hipMemsetAsync(w.scalars, 0, 8 * sizeof(int), s));
+    cmp_set_kernel<<<1, 1, 0, s>>>(rows_dev, M0);
+    const int *cur = coords0;
+    int ts = 1;
+    for (int l = 0; l + 1 < nlevels; l++) {
+        int *pl = parent + (size_t)l * M0, *kl = kidx + (size_t)l * M0, *fl = flag + (size_t)l * M0;
+        int *nxt = coords_out + (size_t)l * M0 * 4;
+        cm_init_kernel<<<(int)((w.cap + T - 1) / T), T, 0, s>>>(w.keys, w.first, w.cap, w.scalars + 8);   // scalars[2] (error flag) is kept
+        cmp_insert_kernel<<<nb, T, 0, s>>>(cur, rows_dev + l, 2 * ts, w.keys, w.first, w.cap, w.slot_of, w.scalars);
+        cmp_flag_kernel<<<nb, T, 0, s>>>(w.first, w.slot_of, fl, rows_dev + l, M0);
+        int rc = d3_exclusive_scan_i32(fl, w.scan, M0, w.temp, w.temp_bytes, s);
+        if (rc) return rc;
+        cmp_vid_kernel<<<nb, T, 0, s>>>(fl, w.scan, w.slot_of, w.slot_vid, rows_dev + l);
+        cmp_parent_kernel<<<nb, T, 0, s>>>(w.slot_of, w.slot_vid, pl, rows_dev + l);
+        cmp_level_kernel<<<nb, T, 0, s>>>(cur, rows_dev + l, ts, fl, w.scan, w.slot_of, w.slot_vid, pl, kl, nxt, rows_dev + l + 1);
+        cur = nxt; ts *= 2;
+    }
+    D3_LAUNCH_CHECK();
+    int h[3] = {0, 0, 0};
+    D3_CHECK(hipMemcpyAsync(rows_host, rows_dev, sizeof(int) * nlevels, hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipStreamSynchronize(s));
+    if (h[2] == 1) return D3_ERR_RANGE;
+    if (h[2] == 2) return D3_ERR_OVERFLOW;
+    return 0;
+}
+
+// d3_kmap_down_fill with the first-row flags passed in (the pyramid keeps them per level)
+extern "C" int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int *child, int *up, void *stream) {
+    D3_CLEAR();
+    if (M <= 0 || Mout <= 0) return 0;
+    hipStream_t s = d3_stream(stream);
+    const int T = 256;
+    long long nc = (long long)Mout * 8, nu = (long long)M * 8;
+    cm_fill_neg_kernel<<<(int)((nc + T - 1) / T), T, 0, s>>>(child, nc);
+    cm_fill_neg_kernel<<<(int)((nu + T - 1) / T), T, 0, s>>>(up, nu);
+    cm_down_fill_kernel<<<(M + T - 1) / T, T, 0, s>>>(nullptr, M, 1, parent, kidx, nullptr, nullptr, child, up);
     D3_LAUNCH_CHECK();
     return 0;
 }

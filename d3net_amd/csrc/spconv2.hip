@@ -625,6 +625,12 @@ extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, 
 // with R > 1 the workgroup writes a partial dW that wgrad2_reduce_kernel sums in split order (deterministic; no
 // atomics).
 #define WG2_LDT 40      // shorts per transposed LDS row: 32 rows + 8 pad (80 B)
+#ifndef WG2_TARGET_WGS
+#define WG2_TARGET_WGS 512   // workgroups per launch the row split aims at
+#endif
+#ifndef WG2_PART_MB
+#define WG2_PART_MB 8         // cap of the partial-dW buffer
+#endif
 #define WG2_T 16        // accumulator tiles per wave (64 AGPRs): occupancy matters more than reuse here
 
 struct Wg2Args {
@@ -850,9 +856,9 @@ static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
     const int nchunks = (Ms + 31) / 32;
     // row splits: ~2048 waves in flight, at least 2 chunks per wave, partial buffer <= 8 MB
     const long long wsz = (long long)K * Cin * Cout * 4;
-    int R = 512 / (p.kg * p.passes); if (R < 1) R = 1;
+    int R = WG2_TARGET_WGS / (p.kg * p.passes); if (R < 1) R = 1;
     const int maxR_rows = (nchunks + 7) / 8; if (R > maxR_rows) R = maxR_rows;
-    const long long maxR_mem = (8ll << 20) / wsz; if (R > maxR_mem) R = (int)maxR_mem;
+    const long long maxR_mem = ((long long)WG2_PART_MB << 20) / wsz; if (R > maxR_mem) R = (int)maxR_mem;
     if (R < 1) R = 1;
     p.cpw = (nchunks + R - 1) / R;
     p.cpw = (p.cpw + 3) / 4 * 4;

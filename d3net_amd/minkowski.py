@@ -66,6 +66,38 @@ class CoordinateManager:
             self._k3[ts] = nbr
         return self._k3[ts]
 
+    def build_pyramid(self, nlevels):
+        """Coordinates and stride-2 maps of levels 1..nlevels-1 with one host round trip (d3_kmap_pyramid) instead of
+        one per level; afterwards `down(ts)` / `coords[ts]` are cache hits."""
+        if all((1 << l) in self._down for l in range(nlevels - 1)) or 1 in self._down:
+            return
+        c0 = self.coords[1]
+        M0 = c0.size(0)
+        if M0 == 0 or nlevels < 2:
+            return
+        dev = self.device
+        L = _lib.lib()
+        n1 = nlevels - 1
+        cout = torch.empty((n1, M0, 4), dtype=torch.int32, device=dev)
+        par = torch.empty((n1, M0), dtype=torch.int32, device=dev)
+        kid = torch.empty((n1, M0), dtype=torch.int32, device=dev)
+        flg = torch.empty((n1, M0), dtype=torch.int32, device=dev)
+        rdev = torch.empty(nlevels, dtype=torch.int32, device=dev)
+        rows = (C.c_int * nlevels)()
+        ws = self._ws(M0)
+        with _on(dev):
+            check(L.d3_kmap_pyramid(_ptr(c0), M0, nlevels, _ptr(ws), ws.numel(), _ptr(cout), _ptr(par), _ptr(kid), _ptr(flg),
+                                    _ptr(rdev), rows, _stream()), "kmap_pyramid")
+            ts = 1
+            for l in range(n1):
+                M, Mo = rows[l], rows[l + 1]
+                child = torch.empty((Mo, 8), dtype=torch.int32, device=dev)
+                up = torch.empty((M, 8), dtype=torch.int32, device=dev)
+                check(L.d3_kmap_down_fill2(M, Mo, _ptr(par[l]), _ptr(kid[l]), _ptr(child), _ptr(up), _stream()), "kmap_down_fill2")
+                self.coords[2 * ts] = cout[l, :Mo]
+                self._down[ts] = (child, up, Mo, par[l, :M], kid[l, :M])
+                ts *= 2
+
     def down(self, ts):
         """-> (child (Mout,8), up (M,8), Mout); registers the coordinates of stride 2*ts."""
         if ts not in self._down:

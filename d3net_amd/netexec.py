@@ -207,6 +207,7 @@ class NativeUNet:
 
     def maps(self, cm):
         k3, child, up, rows, keep = [], [], [], [], []
+        cm.build_pyramid(self.nlevels)
         ts = 1
         for lev in range(self.nlevels):
             nbr = cm.k3(ts)

@@ -132,6 +132,14 @@ int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_byt
 int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,
                       const int *kidx, int *out_coords, int *child, int *up, int Mout, void *stream);
 
+/* All stride-2 levels with ONE host round trip (d3_kmap_down_count costs one per level): the coordinate pyramid is
+ * built with device-side row counts, rows_host[l] returns them all, and the tables are then filled with exact sizes by
+ * d3_kmap_k3 / d3_kmap_down_fill2 without further synchronisation.  coords_out: (nlevels-1, M0, 4); parent / kidx / flag:
+ * (nlevels-1, M0) (level l at [l*M0], rows of level l); rows_dev: nlevels ints.  ws >= d3_coordmap_ws_bytes(M0). */
+int d3_kmap_pyramid(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out, int *parent,
+                    int *kidx, int *flag, int *rows_dev, int *rows_host, void *stream);
+int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int *child, int *up, void *stream);
+
 /* Gather-GEMM convolution  out[u,:] = sum_k x[tbl[u,k],:] @ Wk   (tbl == NULL: identity map, K = 1).
  * flags: D3_CONV_FLIPK  -> Wk = W[K-1-k]      (data gradient of a kernel-3 conv)
  *        D3_CONV_TRANSW -> W is laid out (K, Cout, Cin) and used transposed (data gradients)

@@ -323,3 +323,69 @@ def test_canonical_scene_maps(dev):
         cm.down(ts); ts *= 2
     assert Ms == [142920, 35127, 8282, 1945, 460, 104, 22]
     assert Ps == [1332424, 355069, 88232, 22779, 5710, 1236, 212]
+
+
+def test_native_executor_eval_mode_vgg_and_frozen_parameters(dev):
+    """the executor in the configurations the training step does not exercise: eval mode (running statistics), VGG
+    blocks (cfg.model.block_residual = False, model/common.py:56-70), frozen parameters (scripts/train.py:312-325
+    freeze_*: no gradient may be produced for them), num_batches_tracked bookkeeping"""
+    from d3net_amd import minkowski as ME, common, netexec
+    rng = np.random.default_rng(21)
+    planes, cin = [16, 32, 48], 16
+    coords = rand_coords(rng, (32, 28, 16), 0.15)
+    cd = torch.from_numpy(coords).int().to(dev)
+    x = torch.from_numpy(rng.standard_normal((len(coords), cin)).astype(np.float32)).to(dev)
+    norm = functools.partial(ME.MinkowskiBatchNorm, eps=1e-4, momentum=0.1)
+    for block in (common.ResidualBlock, common.VGGBlock):
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(common.UBlock(planes, norm, 2, block), norm(planes[0]), ME.MinkowskiReLU(inplace=True)).to(dev)
+        ME.fuse_bn_relu(net)
+        ex = netexec.NativeUNet(None, net[0], net[1], cin, True)
+        # training forward: same as the module path on a twin (running statistics included)
+        twin = torch.nn.Sequential(common.UBlock(planes, norm, 2, block), norm(planes[0]), ME.MinkowskiReLU(inplace=True)).to(dev)
+        twin.load_state_dict(net.state_dict())
+        ME.fuse_bn_relu(twin)
+        net.train(); twin.train()
+        out_n = ex(x.clone().requires_grad_(True), ME.CoordinateManager(cd), True)
+        out_m = twin(ME.SparseTensor(x.clone(), coordinates=cd)).F
+        assert l2err(out_n, out_m) < 3e-2
+        sd_n, sd_m = net.state_dict(), twin.state_dict()
+        for k in sd_n:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                assert relerr(sd_n[k], sd_m[k]) < 2e-2, k
+            if k.endswith("num_batches_tracked"):
+                assert int(sd_n[k]) == int(sd_m[k]) == 1, k
+        # eval forward uses the running statistics and needs no batch reduction
+        net.eval(); twin.eval()
+        with torch.no_grad():
+            e_n = ex(x, ME.CoordinateManager(cd), False)
+            e_m = twin(ME.SparseTensor(x, coordinates=cd)).F
+        assert l2err(e_n, e_m) < 3e-2
+        # frozen parameters get no gradient, the others do
+        net.train()
+        frozen = [p for n, p in net.named_parameters() if n.startswith("0.blocks.")]
+        for p in frozen:
+            p.requires_grad_(False)
+        xin = x.clone().requires_grad_(True)
+        ex(xin, ME.CoordinateManager(cd), True).sum().backward()
+        torch.cuda.synchronize()
+        assert all(p.grad is None for p in frozen)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters() if p.requires_grad)
+        assert xin.grad is not None and torch.isfinite(xin.grad).all()
+
+
+def test_coordinate_pyramid_one_round_trip_matches_per_level_build(dev):
+    """d3_kmap_pyramid (all stride-2 levels, one host round trip) == d3_kmap_down_count/_fill level by level, bit for bit"""
+    from d3net_amd import minkowski as ME
+    rng = np.random.default_rng(3)
+    coords = torch.from_numpy(rand_coords(rng, (48, 40, 24), 0.1)).int().to(dev)
+    a, b = ME.CoordinateManager(coords), ME.CoordinateManager(coords)
+    b.build_pyramid(5)
+    ts = 1
+    for _ in range(4):
+        ca, ua, Ma = a.down(ts)
+        cb, ub, Mb = b.down(ts)
+        assert Ma == Mb and torch.equal(ca, cb) and torch.equal(ua, ub)
+        assert torch.equal(a.coords[2 * ts], b.coords[2 * ts])
+        assert torch.equal(a.k3(2 * ts), b.k3(2 * ts))
+        ts *= 2
