@@ -68,6 +68,8 @@ SIGNATURES = {
     "d3_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_tall_wgrad_ws_bytes": (sz, [i32, i32]),
     "d3_tall_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "d3_offset_loss_ws_bytes": (sz, []),
+    "d3_offset_loss": (i32, [vp, vp, vp, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),
     "d3_cross_entropy_ws_bytes": (sz, []),
     "d3_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -137,3 +137,72 @@ extern "C" int d3_cross_entropy(const float *z, const int64_t *label, float *gra
     D3_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------ offset losses
+// PointGroup.loss, offset part (reference: model/pointgroup.py:397-420): L1 offset loss and direction loss over the
+// points that belong to an instance, ~15 elementwise library kernels forward and as many backward over N = 165k rows.
+// One pass: per point the two loss terms and the two UNSCALED gradients w.r.t. pt_offsets,
+//   g1 = sign(pt - gt) * valid,   g2 = -valid * d/dpt [ gt/(|gt|+1e-8) . pt/(|pt|+1e-8) ],
+// and per-workgroup partial sums (sum dist*valid, sum dir*valid, sum valid) reduced in fixed order.
+#define OL_GRID 1024
+__global__ __launch_bounds__(256) void offset_loss_kernel(const float *__restrict__ pt, const float *__restrict__ coords,
+                                                         const float *__restrict__ info, int ldi,
+                                                         const long long *__restrict__ ids, long long ignore,
+                                                         float *__restrict__ g1, float *__restrict__ g2,
+                                                         float *__restrict__ part, int N) {
+    __shared__ float s[3][256];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const float valid = (ids[i] != ignore) ? 1.f : 0.f;
+        float p[3], g[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { p[k] = pt[i * 3 + k]; g[k] = info[i * ldi + k] - coords[i * 3 + k]; }
+        float dist = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float d = p[k] - g[k];
+            dist += fabsf(d);
+            g1[i * 3 + k] = valid * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), pn = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        const float ig = 1.f / (gn + 1e-8f), ip = 1.f / (pn + 1e-8f);
+        const float dot = (g[0] * p[0] + g[1] * p[1] + g[2] * p[2]) * ig;      // gt_ . pt
+        const float dir = -dot * ip;
+        // d/dpt_k [ (gt_ . pt) / (|pt| + eps) ] = gt_k / (|pt|+eps) - (gt_ . pt) * pt_k / (|pt| (|pt|+eps)^2); |pt| = 0 -> first term only
+        const float q = (pn > 0.f) ? dot * ip * ip / pn : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) g2[i * 3 + k] = -valid * (g[k] * ig * ip - q * p[k]);
+        a += dist * valid; b += dir * valid; c += valid;
+    }
+    s[0][threadIdx.x] = a; s[1][threadIdx.x] = b; s[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; s[2][threadIdx.x] += s[2][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = s[threadIdx.x][0];
+}
+__global__ void offset_loss_reduce_kernel(const float *part, int nblocks, float *out) {   // out: norm loss, dir loss, sum valid
+    const int lane = threadIdx.x;
+    double a = 0., b = 0., c = 0.;
+    for (int i = lane; i < nblocks; i += 64) { a += (double)part[i * 3]; b += (double)part[i * 3 + 1]; c += (double)part[i * 3 + 2]; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    if (lane == 0) { const double den = c + 1e-6; out[0] = (float)(a / den); out[1] = (float)(b / den); out[2] = (float)c; }
+}
+extern "C" size_t d3_offset_loss_ws_bytes(void) { return (size_t)OL_GRID * 3 * sizeof(float); }
+// pt (N,3), coords (N,3), info (N, ldi) with the instance centre in columns 0..2, ids (N) int64.  out[0] = offset_norm_loss,
+// out[1] = offset_dir_loss (both divided by sum(valid) + 1e-6), out[2] = sum(valid); g1 / g2 (N,3): unscaled gradients.
+extern "C" int d3_offset_loss(const float *pt, const float *coords, const float *info, int ldi, const int64_t *ids,
+                              long long ignore, float *g1, float *g2, float *out, int N, void *ws, size_t ws_bytes,
+                              void *stream) {
+    D3_CLEAR();
+    if (ws_bytes < d3_offset_loss_ws_bytes()) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    int grid = (N + 255) / 256;
+    if (grid > OL_GRID) grid = OL_GRID;
+    if (grid < 1) grid = 1;
+    offset_loss_kernel<<<grid, 256, 0, s>>>(pt, coords, info, ldi, (const long long *)ids, ignore, g1, g2, (float *)ws, N);
+    offset_loss_reduce_kernel<<<1, 64, 0, s>>>((const float *)ws, grid, out);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

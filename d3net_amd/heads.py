@@ -100,3 +100,43 @@ def devoxelize(feats, p2v, v2p):
     if feats.is_cuda and v2p is not None and v2p.dtype == torch.int32 and v2p.is_contiguous() and feats.dtype == torch.float32:
         return _Devoxelize.apply(feats, p2v.long(), v2p)
     return feats[p2v.long()]
+
+
+class _OffsetLoss(Function):
+    @staticmethod
+    def forward(ctx, pt_offsets, coords, instance_info, instance_ids, ignore_label):
+        pt = pt_offsets.contiguous()
+        N = pt.size(0)
+        g1, g2 = torch.empty_like(pt), torch.empty_like(pt)
+        out = torch.empty(3, dtype=torch.float32, device=pt.device)
+        L = _lib.lib()
+        ws = _workspace(L.d3_offset_loss_ws_bytes(), pt.device, "ol")
+        with _on(pt.device):
+            check(L.d3_offset_loss(_ptr(pt), _ptr(coords), _ptr(instance_info), instance_info.size(1), _ptr(instance_ids),
+                                   int(ignore_label), _ptr(g1), _ptr(g2), _ptr(out), N, _ptr(ws), ws.numel(), _stream()),
+                  "offset_loss")
+        ctx.save_for_backward(g1, g2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g1, g2, out = ctx.saved_tensors
+        den = out[2] + 1e-6
+        return torch.addcmul(g1 * (g[0] / den), g2, g[1] / den), None, None, None, None
+
+
+def offset_losses(pt_offsets, coords, instance_info, instance_ids, ignore_label):
+    """(offset_norm_loss, offset_dir_loss, sum(valid)) of PointGroup.loss (reference: model/pointgroup.py:397-420)"""
+    if pt_offsets.is_cuda and pt_offsets.size(0) >= TALL_ROWS and pt_offsets.dtype == torch.float32 \
+            and coords.is_contiguous() and instance_info.is_contiguous() and instance_ids.dtype == torch.int64 \
+            and coords.dtype == torch.float32 and instance_info.dtype == torch.float32:
+        o = _OffsetLoss.apply(pt_offsets, coords, instance_info, instance_ids.contiguous(), ignore_label)
+        return o[0], o[1], o[2].detach()
+    gt_offsets = instance_info[:, 0:3] - coords
+    pt_dist = torch.sum(torch.abs(pt_offsets - gt_offsets), dim=-1)
+    valid = (instance_ids != ignore_label).float()
+    norm_loss = torch.sum(pt_dist * valid) / (torch.sum(valid) + 1e-6)
+    gt_ = gt_offsets / (torch.norm(gt_offsets, p=2, dim=1).unsqueeze(-1) + 1e-8)
+    pt_ = pt_offsets / (torch.norm(pt_offsets, p=2, dim=1).unsqueeze(-1) + 1e-8)
+    dir_loss = torch.sum(-(gt_ * pt_).sum(-1) * valid) / (torch.sum(valid) + 1e-6)
+    return norm_loss, dir_loss, valid.sum()

@@ -453,19 +453,10 @@ class PointGroup(nn.Module):
         data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
 
         pt_offsets, coords, instance_info, instance_ids = data_dict["pt_offsets"]
-        gt_offsets = instance_info[:, 0:3] - coords
-        pt_diff = pt_offsets - gt_offsets
-        pt_dist = torch.sum(torch.abs(pt_diff), dim=-1)
-        valid = (instance_ids != self.cfg.data.ignore_label).float()
-        offset_norm_loss = torch.sum(pt_dist * valid) / (torch.sum(valid) + 1e-6)
-        gt_offsets_norm = torch.norm(gt_offsets, p=2, dim=1)
-        gt_offsets_ = gt_offsets / (gt_offsets_norm.unsqueeze(-1) + 1e-8)
-        pt_offsets_norm = torch.norm(pt_offsets, p=2, dim=1)
-        pt_offsets_ = pt_offsets / (pt_offsets_norm.unsqueeze(-1) + 1e-8)
-        direction_diff = - (gt_offsets_ * pt_offsets_).sum(-1)
-        offset_dir_loss = torch.sum(direction_diff * valid) / (torch.sum(valid) + 1e-6)
-        data_dict["offset_norm_loss"] = (offset_norm_loss, valid.sum())
-        data_dict["offset_dir_loss"] = (offset_dir_loss, valid.sum())
+        offset_norm_loss, offset_dir_loss, n_valid = heads.offset_losses(pt_offsets, coords, instance_info, instance_ids,
+                                                                         self.cfg.data.ignore_label)
+        data_dict["offset_norm_loss"] = (offset_norm_loss, n_valid)
+        data_dict["offset_dir_loss"] = (offset_dir_loss, n_valid)
 
         w = self.cfg.train.loss_weight
         loss = w[0] * semantic_loss + w[1] * offset_norm_loss + w[2] * offset_dir_loss

@@ -260,6 +260,12 @@ int d3_net_backward(void *net, const void *const *params, const int *const *k3, 
 size_t d3_tall_wgrad_ws_bytes(int I, int O);
 int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *db, int N, int I, int O, void *ws, size_t ws_bytes,
                   void *stream);
+/*   offset_loss  : the offset L1 and direction losses of PointGroup.loss (model/pointgroup.py:397-420) and their unscaled
+ *                  gradients w.r.t. pt_offsets in one pass: out[0] = offset_norm_loss, out[1] = offset_dir_loss, out[2] =
+ *                  sum(valid); d loss / d pt = (w_norm*g1 + w_dir*g2) / (out[2] + 1e-6). */
+size_t d3_offset_loss_ws_bytes(void);
+int d3_offset_loss(const float *pt, const float *coords, const float *info, int ldi, const int64_t *ids, long long ignore,
+                   float *g1, float *g2, float *out, int N, void *ws, size_t ws_bytes, void *stream);
 size_t d3_cross_entropy_ws_bytes(void);
 int d3_cross_entropy(const float *z, const int64_t *label, float *grad, float *out, int N, int C, int ignore_index,
                      void *ws, size_t ws_bytes, void *stream);
