@@ -53,6 +53,18 @@ static bool bq_carve(void *ws, size_t ws_bytes, int n, BqWs &w) {
     return ws != nullptr && c.ok();
 }
 
+// the optional hit stash (n * BQ_CAP ints, 400 MB at n = 100k: HBM is 288 GB) sits behind the base workspace; both phases
+// use it iff the caller's workspace is big enough (d3_ballquery_ws_bytes_single_pass)
+extern "C" size_t d3_ballquery_ws_bytes(int n);
+static int *bq_stash(void *ws, size_t ws_bytes, int n) {
+    const size_t base = d3_align(d3_ballquery_ws_bytes(n), 4096);
+    const size_t need = base + (size_t)(n > 0 ? n : 1) * BQ_CAP * sizeof(int);
+    return (ws != nullptr && ws_bytes >= need) ? (int *)((char *)ws + base) : nullptr;
+}
+extern "C" size_t d3_ballquery_ws_bytes_single_pass(int n) {
+    return d3_align(d3_ballquery_ws_bytes(n), 4096) + (size_t)(n > 0 ? n : 1) * BQ_CAP * sizeof(int);
+}
+
 extern "C" size_t d3_ballquery_ws_bytes(int n) {
     BqWs w;
     D3Carver c(nullptr, 0);
@@ -123,7 +135,9 @@ __device__ __forceinline__ bool bq_box_near(float ox, float oy, float oz, const 
            bq_axis_near(oz, lo[i * 3 + 2], hi[i * 3 + 2], rc);
 }
 
-template <bool FILL>
+// MODE 0: count; 1: fill idx at the scanned starts; 2: count AND stash the hits at stash[q*BQ_CAP + pos] (single pass:
+// the fill then only compacts the stash instead of repeating the search)
+template <int MODE>
 __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ xyz,
                                                      const int *__restrict__ batch_idxs,
                                                      const int *__restrict__ batch_offsets, int n, float radius,
@@ -142,7 +156,8 @@ __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ 
     const int b = batch_idxs[q];
     const int start = batch_offsets[b], end = batch_offsets[b + 1];
     long long base = 0;
-    if (FILL) base = start_in[q];
+    if (MODE == 1) base = start_in[q];
+    if (MODE == 2) base = (long long)q * BQ_CAP;
     int cnt = 0;
     if (end > start) {
         const int c_first = start / BQ_CHUNK, c_last = (end - 1) / BQ_CHUNK;
@@ -165,17 +180,29 @@ __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ 
                     hit = d2 < radius2;
                 }
                 const unsigned long long hm = __ballot(hit);
-                if (FILL && hit) {
+                if (MODE != 0 && hit) {
                     const int pos = cnt + (int)__popcll(hm & lt);
                     // cap (bfs_cluster.cu:38-44) and buffer truncation (bfs_cluster.cu:51-59)
-                    if (pos < BQ_CAP && base + pos < idx_capacity) idx[base + pos] = k;
+                    if (pos < BQ_CAP && (MODE == 2 || base + pos < idx_capacity)) idx[base + pos] = k;
                 }
                 cnt += (int)__popcll(hm);
             }
         }
     }
     if (cnt > BQ_CAP) cnt = BQ_CAP;
-    if (!FILL && lane == 0) len_out[q] = cnt;
+    if (MODE != 1 && lane == 0) len_out[q] = cnt;
+}
+
+// stash -> idx at the scanned starts (one wave per point; ascending order is preserved)
+__global__ __launch_bounds__(256) void bq_compact_kernel(const int *__restrict__ stash, const int *__restrict__ len,
+                                                        const int *__restrict__ start, int n, int *__restrict__ idx,
+                                                        long long idx_capacity) {
+    const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (q >= n) return;
+    const int ln = len[q];
+    const long long st = start[q];
+    for (int e = d3_lane(); e < ln; e += 64)
+        if (st + e < idx_capacity) idx[st + e] = stash[(long long)q * BQ_CAP + e];
 }
 
 __global__ void bq_pack_kernel(const int *len, const int *start, int *start_len, int n, int *total) {
@@ -204,7 +231,12 @@ extern "C" int d3_ballquery_count(const float *xyz, const int *batch_idxs, const
     hipStream_t s = d3_stream(stream);
     int rc = bq_boxes(xyz, n, w, s);
     if (rc) return rc;
-    bq_scan_kernel<false><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo,
+    int *stash = bq_stash(ws, ws_bytes, n);
+    if (stash)
+        bq_scan_kernel<2><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo,
+                                                     w.shi, w.nchunks, w.len, nullptr, stash, 0);
+    else
+        bq_scan_kernel<0><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo,
                                                      w.shi, w.nchunks, w.len, nullptr, nullptr, 0);
     rc = d3_exclusive_scan_i32(w.len, w.start, n, w.temp, w.temp_bytes, s);
     if (rc) return rc;
@@ -224,8 +256,14 @@ extern "C" int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const 
     BqWs w;
     if (!bq_carve((void *)ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
-    // boxes and starts are still in the workspace from the count phase
-    bq_scan_kernel<true><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo,
+    // boxes and starts are still in the workspace from the count phase; with the big workspace so are the hits
+    int *stash = bq_stash((void *)ws, ws_bytes, n);
+    if (stash) {
+        bq_compact_kernel<<<(n + 3) / 4, 256, 0, s>>>(stash, w.len, w.start, n, idx, idx_capacity);
+        D3_LAUNCH_CHECK();
+        return 0;
+    }
+    bq_scan_kernel<1><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo,
                                                     w.shi, w.nchunks, nullptr, w.start, idx, idx_capacity);
     D3_LAUNCH_CHECK();
     return 0;

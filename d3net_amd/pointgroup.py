@@ -168,8 +168,13 @@ class PointGroup(nn.Module):
             if ex is not None and ex._grad_views is not None and set_to_none:
                 ex.fresh_grads = True
                 native.update(id(p) for p, v in zip(ex.b.params, ex._grad_views) if v is not None and p.grad is v)
-        for p in self.parameters():
-            if id(p) in native or p.grad is None:
+        key = (len(native), set_to_none)
+        cache = self.__dict__.get("_zg_cache")
+        if cache is None or cache[0] != key:   # walking ~500 parameters through nn.Module.parameters() costs ~1 ms per step
+            cache = (key, [p for p in self.parameters() if id(p) not in native])
+            self.__dict__["_zg_cache"] = cache
+        for p in cache[1]:
+            if p.grad is None:
                 continue
             if set_to_none:
                 p.grad = None

@@ -199,7 +199,9 @@ class BallQueryBatchP(Function):
         L = _lib.lib()
         with _on(dev):
             start_len = torch.empty((n, 2), dtype=torch.int32, device=dev)
-            ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bq")
+            # single-pass ball query (hits stashed by the count phase) when the stash fits 2 GB, else count + second search
+            big = L.d3_ballquery_ws_bytes_single_pass(n)
+            ws = _workspace(big if big <= (2 << 30) else L.d3_ballquery_ws_bytes(n), dev, "bq")
             nActive = C.c_int(0)
             check(L.d3_ballquery_count(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius),
                                        _ptr(start_len), _ptr(ws), ws.numel(), C.byref(nActive), _stream()),

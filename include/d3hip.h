@@ -84,6 +84,9 @@ int d3_voxelize_idx_fill(const int64_t *coords, int n, int ncols, int mode, cons
  * fill : neighbour indices in ascending order; entries at positions >= idx_capacity are
  *        dropped exactly as the reference truncates at n*meanActive (bfs_cluster.cu:51-59). */
 size_t d3_ballquery_ws_bytes(int n);
+/* with a workspace of this size (adds n*1000 ints) the count phase also stashes the hits and the fill phase only
+ * compacts them: one neighbour search instead of two */
+size_t d3_ballquery_ws_bytes_single_pass(int n);
 int d3_ballquery_count(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
                        int *start_len, void *ws, size_t ws_bytes, int *nActive_host, void *stream);
 int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,

@@ -10,7 +10,7 @@ opt = torch.optim.AdamW(model.parameters(), lr=0.002, fused=True)
 occ, sem, inst, _ = S.occupancy_grid(); scene = S.scene_from_grid(occ, sem, inst)
 batch = S.make_batch([scene], dev)
 def step():
-    d = dict(batch); opt.zero_grad(set_to_none=True)
+    d = dict(batch); model.zero_grad(set_to_none=True)
     loss, d = model.training_step(d); loss.backward(); opt.step()
 for _ in range(4): step()
 torch.cuda.synchronize()
