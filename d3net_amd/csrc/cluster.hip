@@ -407,11 +407,15 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
 // extents, and a small hash that picks, among the edges of a batch that reach the same unvisited node, the one
 // with the smallest flat edge id (= the FIFO discoverer).  Batches are processed in flat edge order and the bitmap
 // is updated between them, so "first discoverer" is preserved exactly.  One global round trip per batch.
+#ifndef B2_THREADS
 #define B2_THREADS 1024
+#endif
+#ifndef B2_EPT
 #define B2_EPT 4
+#endif
 #define B2_BATCH (B2_THREADS * B2_EPT)
 #define B2_HASH 8192
-#define B2_FMAX 1024
+#define B2_FMAX B2_THREADS
 #define B2_BITWORDS 8192                        // 32 KB: clusters up to 262144 points; larger ones use cl_bfs_kernel
 #define B2_MAXSIZE (B2_BITWORDS * 32)
 

@@ -1,7 +1,11 @@
-mkdir -p gpurun_out/cb; export TMPDIR=/tmp; export CONV_BENCH_GROUPS=/tmp/groups.json
-for v in "512 8" "1024 16" "2048 32"; do set -- $v
-  rm -f d3net_amd/build/spconv2.o*
-  D3_CXX_EXTRA="-DWG2_TARGET_WGS=$1 -DWG2_PART_MB=$2" python -m d3net_amd.build > /dev/null 2>&1
-  rm -rf /tmp/cbp; timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/cbp -o cb -- python3 tools/conv_bench.py 4 5 > /tmp/cb.txt 2>&1
-  echo "=== TARGET=$1 MB=$2"; python tools/conv_trace.py $(find /tmp/cbp -name "*kernel_trace.csv") /tmp/groups.json | awk -F'|' '{print $1 "|" $4}'
+export TMPDIR=/tmp
+for v in "1024 4" "512 8" "256 16"; do set -- $v
+  rm -f d3net_amd/build/cluster.o*
+  D3_CXX_EXTRA="-DB2_THREADS=$1 -DB2_EPT=$2" python -m d3net_amd.build > /dev/null 2>&1
+  rm -rf /tmp/pp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python3 tools/phase_times.py 4 > /dev/null 2>&1
+  echo "=== THREADS=$1 EPT=$2"; python -c "
+import csv,glob
+for r in csv.DictReader(open(glob.glob('/tmp/pp/**/*kernel_stats.csv',recursive=True)[0])):
+    if r['Name'].startswith('cl_bfs2'): print(r['Calls'], r['AverageNs'])
+"
 done
