@@ -874,6 +874,12 @@ extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, i
     return wg2_plan(xstat ? Min : Mout, K, xstat ? Cout : Cin, xstat ? Cin : Cout, Cin, Cout).ws_bytes;
 }
 
+// number of row splits d3_spconv_wgrad2 uses for this shape (its partials: splits x K*CinW*Cout floats in ws)
+extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags) {
+    const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0;
+    return wg2_plan(xstat ? Min : Mout, K, xstat ? Cout : Cin, xstat ? Cin : Cout, Cin, Cout).R;
+}
+
 template <int TPO, int NU>
 static int launch_wg2(const Wg2Args &a, const Wg2Plan &p, hipStream_t s) {
     static bool attr_done = false;
@@ -911,6 +917,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     const Wg2Plan p = wg2_plan(Ms, K, Cg, Cs, Cin, Cout);
     if (p.ws_bytes > ws_bytes) return D3_ERR_WORKSPACE;
     const bool direct = (p.R == 1 && !accum);
+    const bool noreduce = (flags & D3_CONV_NOREDUCE) != 0;   // the caller sums the partials (batched over its layers)
     a.tbl = tbl; a.dst = direct ? dW : (float *)ws;
     if (!direct && p.R == 1 && ws_bytes < (size_t)wn * 4) return D3_ERR_WORKSPACE;
     a.Ms = Ms; a.K = K; a.mt = (Cg + 15) / 16; a.nt = (Cs + 15) / 16; a.Cg8 = Cg / 8; a.Cs8 = Cs / 8;
@@ -932,7 +939,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         default: rc = WG2_NU(16); break;
     }
 #undef WG2_NU
-    if (rc == 0 && !direct) {
+    if (rc == 0 && !direct && !noreduce) {
         wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
         D3_LAUNCH_CHECK();
     }

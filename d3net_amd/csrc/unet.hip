@@ -230,6 +230,30 @@ __global__ void un_add_kernel(float *__restrict__ dst, int ldd, const float *__r
     *(float4 *)(dst + row * ldd + c) = a;
 }
 
+// Row-split partials of ALL weight gradients of a backward -> dW, one launch (one 6 us reduction per layer otherwise, 69
+// of them on the side stream).  Same arithmetic as spconv2.hip's wgrad2_reduce_kernel: 32 elements x 8 split groups per
+// workgroup, group sums combined in group order.
+struct RedJob { const float *part; float *dW; long long n; int R, accum; long long start; };   // start: first workgroup
+__global__ __launch_bounds__(256) void un_wgrad_reduce_batched_kernel(const RedJob *__restrict__ jobs, int njobs) {
+    __shared__ float sh[8][32];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].start <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const RedJob j = jobs[lo];
+    const int el = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long long e = ((long long)blockIdx.x - j.start) * 32 + el;
+    float v = 0.f;
+    if (e < j.n)
+        for (int r = rg; r < j.R; r += 8) v += j.part[(long long)r * j.n + e];
+    sh[rg][el] = v;
+    __syncthreads();
+    if (rg == 0 && e < j.n) {
+        float s = j.accum ? j.dW[e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += sh[q][el];
+        j.dW[e] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------ the network object
 enum { OP_CONV = 1, OP_BNACT = 2, OP_PADCAST = 3, OP_STATS = 4 };
 enum { MAP_K1 = 0, MAP_K3 = 1, MAP_DOWN = 2, MAP_UP = 3 };
@@ -254,6 +278,7 @@ struct OpD {
     int fin_bn;                       // CONV: BNACT whose batch statistics this conv's last workgroup finalizes (-1: none)
     int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
     size_t cnt_off, bcnt_off;         // ticket counters (arena / gradient arena)
+    size_t wpart_off, wpart_bytes; int wsplits;   // CONV: weight-gradient partials in the gradient arena
 };
 struct Net {
     std::vector<TensorD> T;
@@ -273,6 +298,8 @@ struct Net {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;       // pool
     size_t ev_used = 0;
+    RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (double buffered) + device copy of the reduce jobs
+    size_t red_cap = 0; int red_flip = 0;
     hipEvent_t next_event() {
         if (ev_used == ev.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; ev.push_back(e); }
         return ev[ev_used++];
@@ -298,6 +325,7 @@ extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, 
                                         float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
                                         void *stream);
 extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
+extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
                                 int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);
 
@@ -321,7 +349,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -408,6 +436,8 @@ extern "C" void d3_net_destroy(void *h) {
     Net *n = (Net *)h;
     if (!n) return;
     if (n->jobs_dev) hipFree(n->jobs_dev);
+    if (n->red_host) hipHostFree(n->red_host);
+    if (n->red_dev) hipFree(n->red_dev);
     for (auto e : n->ev) hipEventDestroy(e);
     if (n->side) hipStreamDestroy(n->side);
     delete n;
@@ -447,8 +477,8 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
                 o.part_off = off; off += d3_align((size_t)o.nparts * 2 * o.partw * 4);
             }
             const int xstat = (o.Cin > o.Cout) ? D3_CONV_XSTAT : 0;
-            const size_t w = d3_spconv_wgrad2_ws_bytes(Min, Mout, o.K, o.Cin, o.Cout, xstat) + (size_t)o.K * o.Cin * o.Cout * 4;
-            if (w > wgws) wgws = w;
+            o.wsplits = d3_spconv_wgrad2_splits(Min, Mout, o.K, o.Cin, o.Cout, xstat);
+            o.wpart_bytes = d3_align((size_t)o.wsplits * o.K * o.Cin * o.Cout * 4 + 256);
         } else if (o.type == OP_STATS) {
             const TensorD &t = n->T[o.in];
             o.nparts = bn_blocks2(n->rows[t.level], t.C); o.partw = t.C;
@@ -467,6 +497,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
         o.bparts = d3_spconv_fwd2_nparts(Min, cv.K, cv.Cout, cv.CinW);
         o.bpart_off = goff; goff += d3_align((size_t)o.bparts * 2 * ((cv.CinW + 15) / 16 * 16) * 4);
     }
+    for (auto &o : n->ops) if (o.type == OP_CONV) { o.wpart_off = goff; goff += o.wpart_bytes; }
     n->cnt_off0 = off;
     for (auto &o : n->ops) if (o.type == OP_CONV) { o.cnt_off = off; off += 4; }
     off = d3_align(off); n->cnt_bytes = off - n->cnt_off0;
@@ -660,7 +691,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     };
     if (n->bcnt_bytes) D3_CHECK(hipMemsetAsync(garena + n->bcnt_off0, 0, n->bcnt_bytes, s));
     float *bnscr = (float *)(garena + n->bnscr_off);
-    char *wgws = garena + n->wgws_off;
+    std::vector<RedJob> red;
+    long long red_blocks = 0;
     for (int i = (int)n->ops.size() - 1; i >= 0; i--) {
         OpD &o = n->ops[i];
         if (o.type == OP_CONV) {
@@ -680,8 +712,17 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 if (xstat) { flags |= D3_CONV_XSTAT | (flip ? D3_CONV_FLIPK : 0); tw = tb; }
                 float *dW = pgrads[o.w];
                 // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
+                char *wpart = garena + o.wpart_off;
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
-                                          flags, wgws, n->wgws_bytes, (void *)n->side);
+                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)n->side);
+                if (o.wsplits > 1 || paccum[o.w]) {   // (a single split without accumulation was written to dW directly)
+                    RedJob j;
+                    memset(&j, 0, sizeof(j));
+                    j.part = (const float *)wpart; j.dW = dW; j.n = (long long)o.K * o.CinW * o.Cout; j.R = o.wsplits;
+                    j.accum = paccum[o.w] ? 1 : 0; j.start = red_blocks;
+                    red_blocks += (j.n + 31) / 32;
+                    red.push_back(j);
+                }
                 if (rc) return rc;
                 D3_CHECK(hipEventRecord(e2, n->side));
                 if (root_o >= 0) pending[root_o] = e2;
@@ -744,6 +785,21 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                                                                                o.eps, relu, o.in_grad_mode == 2 ? 1 : 0);
             }
         }
+    }
+    // all row-split partials -> dW, one launch at the end of the side stream
+    if (!red.empty()) {
+        if (red.size() > n->red_cap) {
+            if (n->red_host) hipHostFree(n->red_host);
+            if (n->red_dev) hipFree(n->red_dev);
+            n->red_cap = red.size() + 16;
+            D3_CHECK(hipHostMalloc((void **)&n->red_host, 2 * n->red_cap * sizeof(RedJob)));
+            D3_CHECK(hipMalloc((void **)&n->red_dev, 2 * n->red_cap * sizeof(RedJob)));
+        }
+        n->red_flip ^= 1;
+        RedJob *hj = n->red_host + (size_t)n->red_flip * n->red_cap, *dj = n->red_dev + (size_t)n->red_flip * n->red_cap;
+        memcpy(hj, red.data(), red.size() * sizeof(RedJob));
+        D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, n->side));
+        un_wgrad_reduce_batched_kernel<<<(int)red_blocks, 256, 0, n->side>>>(dj, (int)red.size());
     }
     // join: the caller's stream waits for the last weight gradient
     if (n->ev_used > 0) {

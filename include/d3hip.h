@@ -156,6 +156,8 @@ int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int 
 #define D3_CONV_ACCUM 16
 #define D3_CONV_XBF16 32   /* x is stored as bf16 (ushort), Cin % 8 == 0; not with D3_CONV_EXACT */
 #define D3_CONV_DYBF16 64  /* dy is stored as bf16 (d3_spconv_wgrad2 only) */
+#define D3_CONV_NOREDUCE 128 /* d3_spconv_wgrad2: leave the row-split partials in ws (d3_spconv_wgrad2_splits() of them, or one
+                              * when accumulating); the caller sums them (the executor does it for all layers in one launch) */
 int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
                   int Cout, int flags, void *stream);
 /* Weight gradient  dW[k] = sum_u x[tbl[u,k],:]^T dy[u,:]   (dW (K,Cin,Cout) f32; cleared here unless
@@ -199,6 +201,7 @@ int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void 
                              const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma, float *dbeta,
                              int accum, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
 size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
+int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags);
 int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
                      int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes, void *stream);
 
