@@ -206,3 +206,26 @@ extern "C" int d3_offset_loss(const float *pt, const float *coords, const float 
     D3_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------ row scatter-add
+// Backward of the cluster feature gather `pt_feats[proposals_idx[:,1]]` (reference: model/pointgroup.py:130
+// clusters_feats = feats[c_idxs]): out[idx[s], :] += g[s, :].  The library's index backward sorts the indices (a dozen
+// launches).  A point is in at most one cluster of each of the two cluster sets, i.e. every output row receives at most
+// two addends, and fp32 addition of two values onto zero is order independent ((0+a)+b == (0+b)+a): the atomics below
+// are deterministic for this operator.
+__global__ void scatter_add_rows_kernel(const float *__restrict__ g, const long long *__restrict__ idx, float *__restrict__ out,
+                                        long long total, int C) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long long s = e / C;
+    const int c = (int)(e - s * C);
+    atomicAdd(&out[idx[s] * C + c], g[e]);
+}
+extern "C" int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream) {
+    D3_CLEAR();
+    const long long total = S * C;
+    if (total <= 0) return 0;
+    scatter_add_rows_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(g, (const long long *)idx, out, total, C);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

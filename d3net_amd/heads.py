@@ -140,3 +140,30 @@ def offset_losses(pt_offsets, coords, instance_info, instance_ids, ignore_label)
     pt_ = pt_offsets / (torch.norm(pt_offsets, p=2, dim=1).unsqueeze(-1) + 1e-8)
     dir_loss = torch.sum(-(gt_ * pt_).sum(-1) * valid) / (torch.sum(valid) + 1e-6)
     return norm_loss, dir_loss, valid.sum()
+
+
+class _GatherRows(Function):
+    """feats[idx] whose backward is one atomic scatter-add launch (deterministic for <= 2 addends per row: the cluster
+    feature gather, where a point is in at most one cluster of each of the two cluster sets)"""
+
+    @staticmethod
+    def forward(ctx, feats, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = feats.size(0)
+        return feats.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.zeros((ctx.rows, g.size(1)), dtype=g.dtype, device=g.device)
+        with _on(g.device):
+            check(_lib.lib().d3_scatter_add_rows(_ptr(g), _ptr(idx), _ptr(out), g.size(0), g.size(1), _stream()), "scatter_add_rows")
+        return out, None
+
+
+def gather_cluster_rows(feats, idx):
+    """feats[idx] for the cluster feature gather (idx int64, every row index at most twice)"""
+    if feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and feats.requires_grad:
+        return _GatherRows.apply(feats, idx.contiguous())
+    return feats[idx]

@@ -197,7 +197,7 @@ class PointGroup(nn.Module):
         dev = feats.device
         c_idxs = clusters_idx[:, 1].long()
         cid = clusters_idx[:, 0].long()
-        clusters_feats = feats[c_idxs]
+        clusters_feats = heads.gather_cluster_rows(feats, c_idxs)
         clusters_coords = coords[c_idxs]
 
         _mark("cv_gather")

@@ -272,6 +272,9 @@ int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *db, int N, 
 size_t d3_offset_loss_ws_bytes(void);
 int d3_offset_loss(const float *pt, const float *coords, const float *info, int ldi, const int64_t *ids, long long ignore,
                    float *g1, float *g2, float *out, int N, void *ws, size_t ws_bytes, void *stream);
+/* out[idx[s], :] += g[s, :] (out zero-filled by the caller): backward of the cluster feature gather
+ * (model/pointgroup.py:130); deterministic when every output row receives at most two addends, as it does there */
+int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream);
 size_t d3_cross_entropy_ws_bytes(void);
 int d3_cross_entropy(const float *z, const int64_t *label, float *grad, float *out, int N, int C, int ignore_index,
                      void *ws, size_t ws_bytes, void *stream);

@@ -98,3 +98,15 @@ def test_offset_losses_match_library(dev):
     assert abs(float(na) - float(nb)) < 1e-5 * abs(float(nb)) and abs(float(da) - float(db)) < 1e-5 * abs(float(db))
     assert float(va) == float(vb)
     assert rel(a.grad, b.grad) < 1e-5
+
+
+def test_gather_cluster_rows_backward(dev):
+    from d3net_amd import heads
+    torch.manual_seed(1)
+    f = torch.randn(5000, 16, device=dev)
+    idx = torch.cat([torch.randperm(5000, device=dev)[:3000], torch.randperm(5000, device=dev)[:2500]])   # <= 2 per row
+    g = torch.randn(idx.numel(), 16, device=dev)
+    a = f.clone().requires_grad_(True); b = f.clone().requires_grad_(True)
+    heads.gather_cluster_rows(a, idx).backward(g)
+    b[idx].backward(g)
+    assert torch.equal(a.grad, b.grad)     # two addends per row at most: order independent, bit-exact
