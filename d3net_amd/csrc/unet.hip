@@ -275,6 +275,7 @@ struct OpD {
     int bn_of_in;                     // CONV: index of the BNACT op that produced `in` (-1: none) -> fused BN-backward dgrad
     int fused_by;                     // BNACT: index of the CONV whose dgrad epilogue already did this op's reductions
     size_t bpart_off; int bparts;     // BNACT: gradient-arena offset / count of those partials
+    int wg_hazard;                    // CONV: its output gradient buffer is accumulated into in place later in the backward
     int fin_bn;                       // CONV: BNACT whose batch statistics this conv's last workgroup finalizes (-1: none)
     int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
     size_t cnt_off, bcnt_off;         // ticket counters (arena / gradient arena)
@@ -349,7 +350,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -406,6 +407,28 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     }
     for (auto &o : n->ops)
         if (o.type == OP_PADCAST) n->B[n->T[o.out].buf].need_grad = 0;
+    // which convolutions' output gradients are written in place after their weight gradient was issued?
+    auto groot = [&](int tensor) {
+        for (int guard = 0; guard < 1000; guard++) {
+            const TensorD &t = n->T[tensor];
+            if (t.buf < 0) return -1;
+            if (tensor == n->out_tensor) return -2;
+            if (n->galias[t.buf] < 0) return t.buf;
+            tensor = n->galias[t.buf];
+        }
+        return -3;
+    };
+    for (int i = 0; i < (int)n->ops.size(); i++) {
+        OpD &o = n->ops[i];
+        if (o.type != OP_CONV) continue;
+        const int r = groot(o.out);
+        if (r < 0) continue;
+        for (int j = i - 1; j >= 0 && !o.wg_hazard; j--) {   // ops processed after op i in the backward
+            const OpD &q = n->ops[j];
+            if ((q.type == OP_CONV || q.type == OP_BNACT) && q.in_grad_mode == 2 && groot(q.in) == r) o.wg_hazard = 1;
+            if (q.type == OP_CONV && q.res_mode == 2 && groot(q.res) == r) o.wg_hazard = 1;
+        }
+    }
     // a BatchNorm whose statistics come from exactly one convolution covering exactly its channels: that convolution's
     // last workgroup CAN finalize them (no finalize launch).  Measured on MI355X (canonical scene): forward 2.4 -> 3.4 ms,
     // backward 5.4 -> 5.7 ms -- every workgroup has to wait for its write-through partial row and take a memory-side
@@ -684,8 +707,16 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     char *arena = (char *)arena_, *garena = (char *)garena_;
     Maps maps{k3, child, up};
     n->ev_used = 0;
-    std::map<int, hipEvent_t> pending;   // gradient buffer root -> last side-stream read
+    // Small networks (ScoreNet: a few thousand rows, every kernel ~5 us) are bound by host API calls: their weight
+    // gradients stay on the caller's stream (no events).  Big ones use the side stream; the "a side-stream kernel still
+    // reads this gradient buffer" hazard gets an event only for the convolutions whose output gradient is later
+    // accumulated into in place (residual aliases: known from the program, OpD::wg_hazard).
+    const bool use_side = n->rows[0] >= 32768;
+    hipStream_t ws_stream = use_side ? n->side : s;
+    std::map<int, hipEvent_t> pending;   // gradient buffer root -> event after its last side-stream reader
+    bool side_used = false;
     auto wait_pending = [&](int root) {
+        if (!use_side) return;
         auto it = pending.find(root);
         if (it != pending.end()) { hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
     };
@@ -702,10 +733,13 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
             // weight gradient on the side stream
             if (pgrads[o.w] != nullptr) {
-                hipEvent_t e1 = n->next_event(), e2 = n->next_event();
-                if (!e1 || !e2) return D3_ERR_OVERFLOW;
-                D3_CHECK(hipEventRecord(e1, s));
-                D3_CHECK(hipStreamWaitEvent(n->side, e1, 0));
+                if (use_side) {
+                    hipEvent_t e1 = n->next_event();
+                    if (!e1) return D3_ERR_OVERFLOW;
+                    D3_CHECK(hipEventRecord(e1, s));
+                    D3_CHECK(hipStreamWaitEvent(n->side, e1, 0));
+                    side_used = true;
+                }
                 const bool xstat = o.Cin > o.Cout;
                 int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0);
                 const int *tw = tf;
@@ -714,7 +748,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
                 char *wpart = garena + o.wpart_off;
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
-                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)n->side);
+                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)ws_stream);
                 if (o.wsplits > 1 || paccum[o.w]) {   // (a single split without accumulation was written to dW directly)
                     RedJob j;
                     memset(&j, 0, sizeof(j));
@@ -724,8 +758,12 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     red.push_back(j);
                 }
                 if (rc) return rc;
-                D3_CHECK(hipEventRecord(e2, n->side));
-                if (root_o >= 0) pending[root_o] = e2;
+                if (use_side && root_o >= 0 && o.wg_hazard) {
+                    hipEvent_t e2 = n->next_event();
+                    if (!e2) return D3_ERR_OVERFLOW;
+                    D3_CHECK(hipEventRecord(e2, n->side));
+                    pending[root_o] = e2;
+                }
             }
             // data gradient
             if (o.in_grad_mode) {
@@ -798,11 +836,11 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
         n->red_flip ^= 1;
         RedJob *hj = n->red_host + (size_t)n->red_flip * n->red_cap, *dj = n->red_dev + (size_t)n->red_flip * n->red_cap;
         memcpy(hj, red.data(), red.size() * sizeof(RedJob));
-        D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, n->side));
-        un_wgrad_reduce_batched_kernel<<<(int)red_blocks, 256, 0, n->side>>>(dj, (int)red.size());
+        D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, ws_stream));
+        un_wgrad_reduce_batched_kernel<<<(int)red_blocks, 256, 0, ws_stream>>>(dj, (int)red.size());
     }
     // join: the caller's stream waits for the last weight gradient
-    if (n->ev_used > 0) {
+    if (side_used) {
         hipEvent_t e = n->next_event();
         if (!e) return D3_ERR_OVERFLOW;
         D3_CHECK(hipEventRecord(e, n->side));
