@@ -150,12 +150,20 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
     const int li = cl_chase(lab, ld_dev(&lab[ri]));
     if (li < ld_dev(&lab[ri])) atomicMin(&lab[ri], li);
     bool changed = false;
-    for (int e = d3_lane(); e < ln; e += 64) {
-        const int j = idx[st + e];
-        if (sem[j] != si) continue;
-        const int rj = root[j];
-        if (rj == ri) continue;
-        if (ld_dev(&lab[rj]) > li) { if (atomicMin(&lab[rj], li) > li) changed = true; }
+    // four edges per lane in flight: every edge is a chain of three dependent gathers (neighbour id -> its root ->
+    // the root's label) and a capped list is 16 passes long
+    for (int e0 = d3_lane(); e0 < ln; e0 += 256) {
+        int j[4], rj[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int e = e0 + q * 64; ok[q] = e < ln; j[q] = ok[q] ? idx[st + e] : 0; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ok[q] = ok[q] && sem[j[q]] == si; rj[q] = ok[q] ? root[j[q]] : ri; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!ok[q] || rj[q] == ri) continue;
+            if (ld_dev(&lab[rj[q]]) > li) { if (atomicMin(&lab[rj[q]], li) > li) changed = true; }
+        }
     }
     if (__any(changed) && d3_lane() == 0) scalars[0] = 1;
 }
