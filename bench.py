@@ -100,8 +100,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL over xGMI ("nccl" on ROCm); D3_DIST_BACKEND=gloo + D3_SHARE_DEVICE=1 is a plumbing test of the N>1 path on a
+        # one-GPU box (all ranks on cuda:0), not a benchmark configuration
+        dist.init_process_group(os.environ.get("D3_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if os.environ.get("D3_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -195,7 +199,7 @@ def main():
                        "scenes_per_gpu": 1, "points": n_points, "voxels": n_voxels,
                        "raw_proposals": int(d.get("num_raw_proposals", 0)), "parallelism": "scene-parallel dp%d" % world,
                        "precision": "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate"},
-            "final_loss": float(loss),
+            "final_loss": float(loss.detach()),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": pd["bytes"] / max(pd["launches"], 1),
