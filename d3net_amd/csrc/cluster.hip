@@ -596,10 +596,15 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                     if (win[r]) {
                         const int p = tail + pos + k; k++;
                         if (p < size) {
-                            cluster_idxs[(size_t)(base + p) * 2] = c; cluster_idxs[(size_t)(base + p) * 2 + 1] = rec[r].x;
+#ifndef B2_EXP_NOSTORE
+                            *(int2 *)&cluster_idxs[(size_t)(base + p) * 2] = make_int2(c, rec[r].x);
+#endif
                             const int nx = p - hi;            // position inside the next frontier
                             if (nx < B2_FMAX) { fst[(cur ^ 1) * B2_FMAX + nx] = rec[r].z; fln[(cur ^ 1) * B2_FMAX + nx] = rec[r].w; }
-                            st_dev(&qst[p], rec[r].z); st_dev(&qln[p], rec[r].w);
+#ifndef B2_EXP_NOSTORE
+                            // plain stores: the only reader is this workgroup (same XCD, L2-coherent) through ld_dev
+                            qst[p] = rec[r].z; qln[p] = rec[r].w;
+#endif
                             atomicOr(&bitmap[rec[r].y >> 5], 1u << (rec[r].y & 31));
                         }
                     }

@@ -1,9 +1,9 @@
 export TMPDIR=/tmp
-for v in "1024 4" "512 8" "256 16"; do set -- $v
+for v in "" "-DB2_EXP_NOSTORE"; do
   rm -f d3net_amd/build/cluster.o*
-  D3_CXX_EXTRA="-DB2_THREADS=$1 -DB2_EPT=$2" python -m d3net_amd.build > /dev/null 2>&1
+  D3_CXX_EXTRA="$v" python -m d3net_amd.build > /dev/null 2>&1
   rm -rf /tmp/pp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python3 tools/phase_times.py 4 > /dev/null 2>&1
-  echo "=== THREADS=$1 EPT=$2"; python -c "
+  echo "=== variant [$v]"; python -c "
 import csv,glob
 for r in csv.DictReader(open(glob.glob('/tmp/pp/**/*kernel_stats.csv',recursive=True)[0])):
     if r['Name'].startswith('cl_bfs2'): print(r['Calls'], r['AverageNs'])
