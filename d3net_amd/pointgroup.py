@@ -62,6 +62,20 @@ def _const(key, device, build):
     return _CONST[k]
 
 
+_WORKER = None
+
+
+def _cluster_worker():
+    """ONE persistent helper thread per process for the concurrent clustering branch.  A fresh thread per step would
+    give the per-thread operator workspaces (pointgroup_ops._workspace, up to 0.5 GB for the ball-query stash) a new
+    key whenever the OS hands out a new thread id, i.e. leak them."""
+    global _WORKER
+    if _WORKER is None:
+        import concurrent.futures
+        _WORKER = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="d3-cluster")
+    return _WORKER
+
+
 PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
 
 
@@ -351,23 +365,18 @@ class PointGroup(nn.Module):
                 if self.concurrent_clustering:
                     side = self._side_stream(coords_.device)
                     side.wait_stream(cur)
-                    box = {}
 
                     def work():
-                        try:
-                            with torch.cuda.device(coords_.device), torch.cuda.stream(side):
-                                box["out"] = cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
-                        except BaseException as e:   # re-raised on the main thread
-                            box["err"] = e
-                    th = threading.Thread(target=work)
-                    th.start()
-                    proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive, True)
-                    th.join()
-                    if "err" in box:
-                        raise box["err"]
+                        with torch.cuda.device(coords_.device), torch.cuda.stream(side):
+                            return cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
+                    fut = _cluster_worker().submit(work)
+                    try:
+                        proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive, True)
+                    finally:
+                        shifted = fut.result()      # (an exception of the helper is re-raised here)
                     cur.wait_stream(side)
-                    proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = box["out"]
-                    for t in box["out"]:
+                    proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = shifted
+                    for t in shifted:
                         t.record_stream(cur)
                 else:
                     proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = cluster_branch(
