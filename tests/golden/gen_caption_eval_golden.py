@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/caption_eval_golden.npz by RUNNING THE REFERENCE's own lib/captioning/eval_helper.py
-(assign_dense_caption, prepare_corpus, filter / check / organize candidates) and lib/capeval/cider on CPU.
+(assign_dense_caption, prepare_corpus, filter / check / organize candidates) and lib/capeval/{cider,bleu,rouge} on CPU.
 Run in the build container only (needs /root/reference).  Inputs are rebuilt by `caption_inputs()`."""
 import json
 import os
@@ -55,6 +55,8 @@ def main():
     sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
     import lib.captioning.eval_helper as eh
     import lib.capeval.cider.cider as capcider
+    import lib.capeval.bleu.bleu as capbleu
+    import lib.capeval.rouge.rouge as caprouge
     from lib.utils.bbox import generalized_box3d_iou
     inp = caption_inputs()
     t = {k: torch.from_numpy(v) for k, v in inp.items() if isinstance(v, np.ndarray)}
@@ -72,6 +74,12 @@ def main():
         score, scores = capcider.Cider().compute_score(corpus, c)
         out["cider_%s" % thr] = np.float64(score)
         out["cider_scores_%s" % thr] = np.asarray(scores, np.float64)
+        bleu, bleu_list = capbleu.Bleu(4).compute_score(corpus, c)
+        out["bleu_%s" % thr] = np.asarray(bleu, np.float64)
+        out["bleu_list_%s" % thr] = np.asarray(bleu_list, np.float64)
+        rouge, rouges = caprouge.Rouge().compute_score(corpus, c)
+        out["rouge_%s" % thr] = np.float64(rouge)
+        out["rouge_scores_%s" % thr] = np.asarray(rouges, np.float64)
         out["corpus_keys"] = np.array(list(corpus.keys()))
     np.savez_compressed(os.path.join(HERE, "caption_eval_golden.npz"), **out)
     print({k: np.asarray(v).shape for k, v in out.items()}, float(out["cider_0.5"]), float(out["cider_0.25"]))

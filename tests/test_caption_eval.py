@@ -29,4 +29,12 @@ def test_assignment_and_cider_match_reference_golden():
         assert ckeys == g["corpus_keys"].tolist()
         assert abs(mean - float(g["cider_%s" % thr])) <= 5e-3 * abs(float(g["cider_%s" % thr]))   # the north-star bound: 0.5 %
         assert np.allclose(scores, g["cider_scores_%s" % thr], rtol=1e-9, atol=1e-12)            # and in fact to rounding
+        from d3net_amd import caption_metrics as cm
+        corpus = ce.prepare_corpus(inp["raw"], cands, 30)
+        kept = {k: v["caption"] for k, v in cands.items() if v["iou"] >= thr}
+        refs, hyps = [corpus[k] for k in ckeys], [kept.get(k, "sos eos") for k in ckeys]
+        bleu, bleu_list = cm.bleu_scores(refs, hyps)
+        assert np.allclose(bleu, g["bleu_%s" % thr], rtol=1e-12) and np.allclose(bleu_list, g["bleu_list_%s" % thr], rtol=1e-12)
+        rouge, rouges = cm.rouge_l_scores(refs, hyps)
+        assert abs(rouge - float(g["rouge_%s" % thr])) < 1e-12 and np.allclose(rouges, g["rouge_scores_%s" % thr], rtol=1e-12)
     assert float(g["cider_0.25"]) > float(g["cider_0.5"]) > 0   # the fixture has matches on both sides of the thresholds
