@@ -108,7 +108,7 @@ int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, c
 
 /* d3_bfs_cluster_fill with the level loop in "record form" (csrc/cluster.hip): a parallel pre-pass rewrites the lists of
  * the kept clusters as (node, dense id, list start, list length) records and the BFS keeps visited bits, frontier and
- * first-discoverer arbitration in LDS -- one global round trip per batch of 4096 edges instead of four per level.
+ * first-discoverer arbitration in LDS -- one global round trip per batch of 3072 edges instead of four per level.
  * erec: d3_bfs_cluster_erec_bytes(nActive) bytes of scratch, nActive = length of ball_query_idxs.  Outputs are
  * bit-identical to d3_bfs_cluster_fill. */
 size_t d3_bfs_cluster_erec_bytes(long long nActive);
