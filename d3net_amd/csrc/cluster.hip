@@ -551,15 +551,22 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                     int b = nf;                                  // largest f with s_off[f] <= ef
                     while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= ef) a = m; else b = m; }
                 }
+                // owners first (LDS-only loops), THEN all record loads back to back: a loop between two global loads makes
+                // the compiler drain vmcnt before it, i.e. one full memory round trip per edge slot
+                long long addr[B2_EPT];
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
                     const int e = ef + r;
-                    cand[r] = false; slot[r] = 0; rec[r] = make_int4(-1, 0, 0, 0);
+                    cand[r] = false; slot[r] = 0; addr[r] = -1;
                     if (e < E) {
                         while (s_off[a + 1] <= e) a++;          // s_off[nf] = E > e terminates
-                        rec[r] = erec[cst[a] + e - s_off[a]];
+                        addr[r] = (long long)cst[a] + e - s_off[a];
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) rec[r] = erec[addr[r] >= 0 ? addr[r] : 0];   // branch-free: one wait for all
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) if (addr[r] < 0) rec[r] = make_int4(-1, 0, 0, 0);
                 unsigned int bw[B2_EPT];
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) bw[r] = (rec[r].x >= 0) ? bitmap[rec[r].y >> 5] : 0xFFFFFFFFu;
