@@ -419,13 +419,19 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
 #define B2_THREADS 1024
 #endif
 #ifndef B2_EPT
-#define B2_EPT 3       // measured: 2 -> 1.24 ms, 3 -> 1.14 ms, 4 -> 1.23 ms for the canonical floor (a level has 2-3.5k edges)
+#define B2_EPT 3       // edges per thread per batch (a level of the canonical floor has 2-3.5k edges)
 #endif
 #define B2_BATCH (B2_THREADS * B2_EPT)
 #define B2_HASH 8192
-#define B2_FMAX B2_THREADS
+#define B2_FMAX 1024                            // frontier nodes whose list extents are kept in LDS
+#define B2_IPT (B2_FMAX / B2_THREADS)
+#ifndef B2_HGRID
+#define B2_HGRID 16                             // owner hints: one per B2_HGRID edges of the next level
+#endif
+#define B2_HINTS 8192
 #define B2_BITWORDS 8192                        // 32 KB: clusters up to 262144 points; larger ones use cl_bfs_kernel
 #define B2_MAXSIZE (B2_BITWORDS * 32)
+#define B2_LDS_INTS (B2_BITWORDS + 2 * B2_HASH + 2 * B2_FMAX + 2 * (B2_FMAX + 8) + B2_HINTS + 160)
 
 __global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, int *lcnt, int *lid, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -473,38 +479,64 @@ __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ id
 __device__ __forceinline__ void b2_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-__device__ __forceinline__ int b2_blk_scan(int v, int *wsum, int &total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int x = v;
-    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) wsum[wv] = x;
-    b2_barrier();
-    if (wv == 0) {
-        int w = (lane < nw) ? wsum[lane] : 0, ws = w;
-        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(ws, o); if (lane >= o) ws += y; }
-        if (lane < nw) wsum[lane] = ws - w;
-        if (lane == 63) wsum[nw] = ws;
+// Workgroup exclusive scan of a pair of ints with ONE barrier: every wave reads all wave totals and scans them itself;
+// the totals live in two alternating LDS buffers, so the next call needs no barrier before overwriting them.
+__device__ __forceinline__ void b2_scan2(int v0, int v1, int *wsum, int &phase, int &p0, int &p1, int &t0, int &t1) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int nw = B2_THREADS / 64;
+    int x0 = v0, x1 = v1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y0 = __shfl_up(x0, o), y1 = __shfl_up(x1, o);
+        if (lane >= o) { x0 += y0; x1 += y1; }
     }
+    int *buf = wsum + (phase & 1) * 64;
+    phase++;
+    if (lane == 63) { buf[wv] = x0; buf[32 + wv] = x1; }
     b2_barrier();
-    const int r = wsum[wv] + x - v;
-    total = wsum[nw];
-    b2_barrier();
-    return r;
+    int w0 = (lane < nw) ? buf[lane] : 0, w1 = (lane < nw) ? buf[32 + lane] : 0;
+    int s0 = w0, s1 = w1;
+#pragma unroll
+    for (int o = 1; o < nw; o <<= 1) {
+        const int y0 = __shfl_up(s0, o), y1 = __shfl_up(s1, o);
+        if (lane >= o) { s0 += y0; s1 += y1; }
+    }
+    t0 = __shfl(s0, nw - 1); t1 = __shfl(s1, nw - 1);
+    p0 = __shfl(s0 - w0, wv) + x0 - v0;
+    p1 = __shfl(s1 - w1, wv) + x1 - v1;
 }
 
+#ifdef B2_TIMING
+#define B2_TICK(k) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; }
+#define B2_TDUMP if (dbg && tid == 0 && c < 20) for (int k = 0; k < 8; k++) dbg[60 + c * 8 + k] = (int)(tacc[k] >> 4);
+#else
+#define B2_TICK(k)
+#define B2_TDUMP
+#endif
+// One workgroup per kept cluster.  Profiled per level (cycle counters, profiles/r01_n): the global round trip for the
+// edge records is only ~15 % of a level; the rest is workgroup barriers and dependent LDS chains.  So the level loop
+// is organised to need few of both:
+//   * the winners of a batch are ranked by ONE scan that carries (count, list length): the list offsets of the next
+//     frontier come out of the enqueue step and the next level starts without a scan of its own;
+//   * a winner also writes an owner hint for every B2_HGRID-th edge of its list, so a thread of the next level finds
+//     the frontier node of its first edge with one LDS read and a step or two instead of a binary search;
+//   * the scan needs one barrier (b2_scan2), a batch three in total.
 __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restrict__ erec, const int *__restrict__ start_len,
                                                             const int *__restrict__ lid, const int *__restrict__ seeds,
                                                             const int *__restrict__ koff, const int *__restrict__ sizes,
                                                             int *qst_all, int *qln_all, int *cluster_idxs, int *dbg) {
     extern __shared__ __attribute__((aligned(16))) int b2_smem[];
     int n_levels = 0, n_batches = 0;
+#ifdef B2_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_readcyclecounter();
+#endif
     unsigned int *bitmap = (unsigned int *)b2_smem;                 // B2_BITWORDS
     int *hkey = b2_smem + B2_BITWORDS;                              // B2_HASH
     int *hval = hkey + B2_HASH;                                     // B2_HASH
-    int *fst = hval + B2_HASH;                                      // 2 * B2_FMAX
-    int *fln = fst + 2 * B2_FMAX;                                   // 2 * B2_FMAX
-    int *s_off = fln + 2 * B2_FMAX;                                 // B2_FMAX + 1
-    int *s_w = s_off + B2_FMAX + 8;                                 // 24
+    int *fst = hval + B2_HASH;                                      // 2 * B2_FMAX: list starts of the frontier nodes
+    int *foff = fst + 2 * B2_FMAX;                                  // 2 * (B2_FMAX + 8): exclusive prefix of their lengths
+    unsigned short *hint = (unsigned short *)(foff + 2 * (B2_FMAX + 8));   // 2 * B2_HINTS
+    int *s_w = (int *)(hint + 2 * B2_HINTS);                        // 128
     const int c = blockIdx.x, tid = threadIdx.x;
     const int s = seeds[c], base = koff[s], size = sizes[s];
     if (size > B2_MAXSIZE) return;                                  // left to cl_bfs_kernel
@@ -516,117 +548,158 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     if (tid == 0) {
         const int ls = lid[s];
         bitmap[ls >> 5] = 1u << (ls & 31);
-        fst[0] = start_len[s * 2]; fln[0] = start_len[s * 2 + 1];
+        fst[0] = start_len[s * 2]; foff[0] = 0; foff[1] = start_len[s * 2 + 1];
         cluster_idxs[(size_t)base * 2] = c; cluster_idxs[(size_t)base * 2 + 1] = s;
     }
     __syncthreads();
-    int lo = 0, hi = 1, cur = 0;
+    int lo = 0, hi = 1, cur = 0, phase = 0;
+    bool hints_ok = false;                             // hint[cur] covers every B2_EPT-th edge of this level
     while (lo < hi && hi <= size) {
         const bool small = (hi - lo) <= B2_FMAX;      // the frontier's list extents are already in LDS
-        int tail = hi;
+        int tail = hi, ltail = 0;                     // next frontier: nodes queued / list entries so far
+        int *nst = fst + (cur ^ 1) * B2_FMAX, *noff = foff + (cur ^ 1) * (B2_FMAX + 8);
+        unsigned short *nhint = hint + (cur ^ 1) * B2_HINTS;
+        const unsigned short *chint = hint + cur * B2_HINTS;
         for (int fb = lo; fb < hi; fb += B2_FMAX) {
             const int nf = min(B2_FMAX, hi - fb);
-            int *cst = fst + cur * B2_FMAX, *cln = fln + cur * B2_FMAX;
+            int *cst = fst + cur * B2_FMAX, *coff = foff + cur * (B2_FMAX + 8);
             if (!small) {
+                // frontier beyond the LDS window: its records come back from the global queue, B2_FMAX at a time
                 __syncthreads();   // (global queue records written by other waves: full barrier)
-                if (tid < nf) { cst[tid] = ld_dev(&qst[fb + tid]); cln[tid] = ld_dev(&qln[fb + tid]); }
+                int ln[B2_IPT], sum = 0;
+#pragma unroll
+                for (int i = 0; i < B2_IPT; i++) {
+                    const int f = tid * B2_IPT + i;
+                    ln[i] = 0;
+                    if (f < nf) { cst[f] = ld_dev(&qst[fb + f]); ln[i] = ld_dev(&qln[fb + f]); }
+                    sum += ln[i];
+                }
+                int p0, p1, t0, t1;
+                b2_scan2(sum, 0, s_w, phase, p0, p1, t0, t1);
+#pragma unroll
+                for (int i = 0; i < B2_IPT; i++) {
+                    const int f = tid * B2_IPT + i;
+                    if (f < nf) coff[f] = p0;
+                    p0 += ln[i];
+                }
+                if (tid == 0) coff[nf] = t0;
                 b2_barrier();
             }
-            int E;
-            const int off = b2_blk_scan(tid < nf ? cln[tid] : 0, s_w, E);
-            if (tid < nf) s_off[tid] = off;
-            if (tid == 0) s_off[nf] = E;
-            b2_barrier();
+            B2_TICK(0)
+            const int E = coff[nf];
             for (int e0 = 0; e0 < E; e0 += B2_BATCH) {
                 // A level is a chain of dependent LDS / L2 latencies, so the per-thread work is written for
-                // instruction-level parallelism: one binary search per thread (its edges are consecutive, the owners of the
-                // following edges are found by stepping), all record loads, then all bitmap tests, then all first hash
-                // probes are issued before any of their results is used.
+                // instruction-level parallelism: the owner of the thread's first edge (hint or binary search; its edges are
+                // consecutive, the owners of the following edges are found by stepping), all record loads, then all bitmap
+                // tests, then all first hash probes are issued before any of their results is used.
                 int4 rec[B2_EPT];
-                int slot[B2_EPT], key[B2_EPT], oldk[B2_EPT];
+                int slot[B2_EPT], oldk[B2_EPT];
                 bool cand[B2_EPT];
                 const int ef = e0 + tid * B2_EPT;               // first edge of this thread
-                int a = 0;
-                if (ef < E) {
-                    int b = nf;                                  // largest f with s_off[f] <= ef
-                    while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= ef) a = m; else b = m; }
-                }
-                // owners first (LDS-only loops), THEN all record loads back to back: a loop between two global loads makes
-                // the compiler drain vmcnt before it, i.e. one full memory round trip per edge slot
                 long long addr[B2_EPT];
 #pragma unroll
-                for (int r = 0; r < B2_EPT; r++) {
-                    const int e = ef + r;
-                    cand[r] = false; slot[r] = 0; addr[r] = -1;
-                    if (e < E) {
-                        while (s_off[a + 1] <= e) a++;          // s_off[nf] = E > e terminates
-                        addr[r] = (long long)cst[a] + e - s_off[a];
+                for (int r = 0; r < B2_EPT; r++) addr[r] = -1;
+                if (ef < E) {
+                    int a = 0;
+                    if (hints_ok) a = chint[ef / B2_HGRID];     // owner of edge (ef / B2_HGRID) * B2_HGRID: a lower bound
+                    else {
+                        int b = nf;                              // largest f with coff[f] <= ef
+                        while (b - a > 1) { const int m = (a + b) >> 1; if (coff[m] <= ef) a = m; else b = m; }
+                    }
+                    // owners first (LDS-only loops), THEN all record loads back to back: a loop between two global loads makes
+                    // the compiler drain vmcnt before it, i.e. one full memory round trip per edge slot
+                    int o0 = coff[a], o1 = coff[a + 1], st = cst[a];
+#pragma unroll
+                    for (int r = 0; r < B2_EPT; r++) {
+                        const int e = ef + r;
+                        if (e < E) {
+                            while (o1 <= e) { a++; o0 = o1; o1 = coff[a + 1]; st = cst[a]; }   // coff[nf] = E > e terminates
+                            addr[r] = (long long)st + e - o0;
+                        }
                     }
                 }
+                B2_TICK(2)
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) rec[r] = erec[addr[r] >= 0 ? addr[r] : 0];   // branch-free: one wait for all
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the first use, and its wait, behind the last load)
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) if (addr[r] < 0) rec[r] = make_int4(-1, 0, 0, 0);
+#ifdef B2_TIMING
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                B2_TICK(3)
                 unsigned int bw[B2_EPT];
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) bw[r] = (rec[r].x >= 0) ? bitmap[rec[r].y >> 5] : 0xFFFFFFFFu;
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
                     cand[r] = rec[r].x >= 0 && !((bw[r] >> (rec[r].y & 31)) & 1u);
-                    key[r] = rec[r].y;
-                    slot[r] = (int)(((unsigned int)key[r] * 2654435761u) >> 19);
+                    slot[r] = (int)(((unsigned int)rec[r].y * 2654435761u) >> 19);
                     oldk[r] = 0;
                 }
 #pragma unroll
-                for (int r = 0; r < B2_EPT; r++) if (cand[r]) oldk[r] = atomicCAS(&hkey[slot[r]], -1, key[r]);
+                for (int r = 0; r < B2_EPT; r++) if (cand[r]) oldk[r] = atomicCAS(&hkey[slot[r]], -1, rec[r].y);
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
                     if (cand[r]) {
                         int h = slot[r], old = oldk[r];
-                        while (old != -1 && old != key[r]) {     // occupied by another node: linear probing
+                        while (old != -1 && old != rec[r].y) {   // occupied by another node: linear probing
                             h = (h + 1) & (B2_HASH - 1);
-                            old = atomicCAS(&hkey[h], -1, key[r]);
+                            old = atomicCAS(&hkey[h], -1, rec[r].y);
                         }
                         slot[r] = h;
                         atomicMin(&hval[h], tid * B2_EPT + r);
                     }
                 }
                 b2_barrier();
-                int win[B2_EPT], nwin = 0;
-#pragma unroll
-                for (int r = 0; r < B2_EPT; r++) { win[r] = (cand[r] && hval[slot[r]] == tid * B2_EPT + r) ? 1 : 0; nwin += win[r]; }
-                int tot;
-                const int pos = b2_blk_scan(nwin, s_w, tot);     // (barriers inside: every hval read is done)
-                int k = 0;
+                B2_TICK(4)
+                unsigned int win = 0u;
+                int nwin = 0, lwin = 0;
 #pragma unroll
                 for (int r = 0; r < B2_EPT; r++) {
-                    if (win[r]) {
-                        const int p = tail + pos + k; k++;
+                    if (cand[r] && hval[slot[r]] == tid * B2_EPT + r) { win |= 1u << r; nwin++; lwin += rec[r].w; }
+                }
+                int pos, lpos, tot, ltot;
+                b2_scan2(nwin, lwin, s_w, phase, pos, lpos, tot, ltot);   // (its barrier: every hval read is done)
+                B2_TICK(5)
+                int p = tail + pos, lp = ltail + lpos;
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) {
+                    if ((win >> r) & 1u) {
                         if (p < size) {
-#ifndef B2_EXP_NOSTORE
                             *(int2 *)&cluster_idxs[(size_t)(base + p) * 2] = make_int2(c, rec[r].x);
-#endif
                             const int nx = p - hi;            // position inside the next frontier
-                            if (nx < B2_FMAX) { fst[(cur ^ 1) * B2_FMAX + nx] = rec[r].z; fln[(cur ^ 1) * B2_FMAX + nx] = rec[r].w; }
-#ifndef B2_EXP_NOSTORE
+                            if (nx < B2_FMAX) {
+                                nst[nx] = rec[r].z; noff[nx] = lp;
+                                for (int g = (lp + B2_HGRID - 1) / B2_HGRID; g * B2_HGRID < lp + rec[r].w && g < B2_HINTS; g++)
+                                    nhint[g] = (unsigned short)nx;
+                            }
                             // plain stores: the only reader is this workgroup (same XCD, L2-coherent) through ld_dev
                             qst[p] = rec[r].z; qln[p] = rec[r].w;
-#endif
                             atomicOr(&bitmap[rec[r].y >> 5], 1u << (rec[r].y & 31));
                         }
+                        p++; lp += rec[r].w;
                     }
                     if (cand[r]) { hkey[slot[r]] = -1; hval[slot[r]] = CL_INF; }   // every occupied slot has >= 1 candidate
                 }
-                tail += tot;
+                tail += tot; ltail += ltot;
+                if (tid == 0 && tail - hi <= B2_FMAX) noff[tail - hi] = ltail;   // closes the prefix (rewritten per batch)
                 b2_barrier();
+                B2_TICK(6)
                 n_batches++;
-                if (tail >= size) { if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; } return; }   // every node of the component is queued: the remaining edges (a dense
-                                            // component has ~size^2 of them) cannot discover anything
+                if (tail >= size) {   // every node of the component is queued: the remaining edges (a dense component has
+                                      // ~size^2 of them) cannot discover anything
+                    if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; }
+                    B2_TDUMP
+                    return;
+                }
             }
         }
+        hints_ok = (tail - hi) <= B2_FMAX && ltail <= B2_HINTS * B2_HGRID;
         lo = hi; hi = tail; cur ^= 1; n_levels++;
     }
     if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; }
+    B2_TDUMP
 }
 
 extern "C" size_t d3_bfs_cluster_erec_bytes(long long nActive) { return (size_t)(nActive > 0 ? nActive : 1) * sizeof(int4); }
@@ -646,7 +719,7 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
     cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
     if (nCluster > 0) {
         static bool attr_done = false;
-        const size_t lds = (size_t)(B2_BITWORDS + 2 * B2_HASH + 4 * B2_FMAX + B2_FMAX + 8 + 32) * sizeof(int);
+        const size_t lds = (size_t)B2_LDS_INTS * sizeof(int);
         if (!attr_done) {
             D3_CHECK(hipFuncSetAttribute((const void *)cl_bfs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_done = true;
@@ -658,9 +731,15 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.lid, w.seeds, w.koff, w.sizes,
                                                         w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
         if (debug) {
-            int h[60];
+            int h[60 + 160];
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);
-            for (int c = 0; c < nCluster && c < 20; c++) fprintf(stderr, "bfs2 cluster %d size %d levels %d batches %d\n", c, h[c * 3], h[c * 3 + 1], h[c * 3 + 2]);
+            for (int c = 0; c < nCluster && c < 20; c++) {
+                fprintf(stderr, "bfs2 cluster %d size %d levels %d batches %d", c, h[c * 3], h[c * 3 + 1], h[c * 3 + 2]);
+#ifdef B2_TIMING
+                for (int k = 0; k < 7; k++) fprintf(stderr, " t%d=%d", k, h[60 + c * 8 + k] * 16);
+#endif
+                fprintf(stderr, "\n");
+            }
         }
         // clusters beyond the LDS bitmap (> 524288 points): the generic level loop (exits at once otherwise)
         cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,

@@ -23,6 +23,7 @@
 // Roofline: HBM; algorithmic bytes per launch as in spconv.hip.
 #include "common.h"
 #include "prof.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -169,9 +170,25 @@ __device__ __forceinline__ bf16x8_t c2_load_a(const void *x, int xbf16, long lon
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// Gathers are issued RAW (no conversion next to the load): a use right behind a load makes the compiler wait for it
+// before the next load is issued, i.e. one memory round trip per gathered row instead of one per batch.
+template <bool XBF>
+__device__ __forceinline__ void c2_load_raw(const void *x, long long off, uint4 &lo, uint4 &hi) {
+    if (XBF) lo = *(const uint4 *)((const unsigned short *)x + off);
+    else { lo = *(const uint4 *)((const float *)x + off); hi = *(const uint4 *)((const float *)x + off + 4); }
+}
+template <bool XBF>
+__device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
+    if (XBF) return __builtin_bit_cast(bf16x8_t, lo);
+    const uint4 v = make_uint4(pack2bf2(__uint_as_float(lo.x), __uint_as_float(lo.y)), pack2bf2(__uint_as_float(lo.z), __uint_as_float(lo.w)),
+                               pack2bf2(__uint_as_float(hi.x), __uint_as_float(hi.y)), pack2bf2(__uint_as_float(hi.z), __uint_as_float(hi.w)));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // LDS use of the wave-per-tile kernel besides the weights
 #define C2_TBL_INTS (16 * C2_MAXK)
-#define C2_WAVE_LDS_BYTES(NTV) (4 * C2_TBL_INTS * 4 + 4 * 32 * 4 + 4 * 2 * (NTV) * 16 * 4)
+#define C2_WAVE_LDS_BASE(NTV) (4 * C2_TBL_INTS * 4 + 4 * 32 * 4 + 4 * 2 * (NTV) * 16 * 4)
+#define C2_WAVE_LDS_BYTES(NTV) (C2_WAVE_LDS_BASE(NTV) + (NTV) * 16 * 16)   // + BatchNorm parameters, float4 per channel
 
 // Wave-per-tile kernel (big levels): 256 threads = 4 independent waves, persistent over a contiguous range of
 // 4-tile groups (XCD-contiguous: block b runs on XCD b % 8, so XCD x gets the x-th eighth of the rows and the
@@ -183,9 +200,10 @@ __device__ __forceinline__ bf16x8_t c2_load_a(const void *x, int xbf16, long lon
 // nearly all offsets) -- absent neighbours simply gather nothing; (4) the MFMA is issued TRANSPOSED (A = weights,
 // B = gathered rows), so a lane ends up with 4 consecutive output channels of one row: the tile is stored (and the
 // residual read) as one contiguous float4 per lane instead of four 64-byte row fragments.
-#define C2_OCC(NTV) ((NTV) <= 4 ? C2_OCC_SMALL : (NTV) <= 9 ? 3 : 2)
+// (fp32 gathers hold twice the registers of bf16 ones until they are converted: one occupancy step less)
+#define C2_OCC(NTV, XB) ((NTV) <= 4 ? ((XB) ? C2_OCC_SMALL : C2_OCC_SMALL - 1) : (NTV) <= 9 ? ((XB) ? 3 : 2) : 2)
 template <int NT, bool WLDS, bool XBF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT), 8))) void spconv_fwd2_kernel(const Conv2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, XBF), 8))) void spconv_fwd2_kernel(const Conv2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int U = C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
@@ -211,6 +229,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
         }                                                                                                     \
     }
     if (C2_PREFETCH) C2_LOAD_TBL(tg0 * 4 + wave)
+    float4 *bnS = (float4 *)(smem + wbytes + C2_WAVE_LDS_BASE(NT));   // (mean, 1/std, gamma, beta) per channel
+    if (a.bnx && t < NT * 16) {
+        float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < a.Cout) {
+            bp.x = a.bn_mean[t]; bp.y = rsqrtf(a.bn_var[t] + a.bn_eps);
+            if (a.bn_relu) { bp.z = a.bn_gamma[t]; bp.w = a.bn_beta[t]; }
+        }
+        bnS[t] = bp;
+    }
     if (WLDS) {
         const uint4 *src = (const uint4 *)a.Wp;
         uint4 *dst = (uint4 *)smem;
@@ -222,8 +249,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int i = i0 + q * 256 + t; if (i < n16) dst[i] = w4[q]; }
         }
-        __syncthreads();
     }
+    if (WLDS || a.bnx) __syncthreads();
     f32x4 ssum[NT], ssq[NT];   // per lane: its row's values, channels n*16 + g*4 + q
 #pragma unroll
     for (int n = 0; n < NT; n++) { ssum[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -247,8 +274,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Epilogue operands (residual, accumulate target, BatchNorm input) do not depend on the gathers: for narrow
+        // outputs they are requested BEFORE the gathers and arrive with them; wider outputs request them in chunks of
+        // NB column tiles at the epilogue (one round trip per chunk, not one per operand).
+        constexpr int NB = NT <= 4 ? NT : 4;
+        constexpr bool HOIST = NT == 1 || (NT == 2 && !XBF);   // (register budget of the bf16 variants: 128)
+        f32x4 e_res[NB], e_out[NB], e_bnx[NB];
+        const int urow = row0 + r;
+#define C2_EPI_LOAD(N0)                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < NB; j++) {                                                      \
+            const int col = ((N0) + j) * 16 + g * 4;                                                          \
+            e_res[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; e_out[j] = e_res[j]; e_bnx[j] = e_res[j];                   \
+            if ((N0) + j < NT && urow < a.Mout && col < a.Cout) {                                             \
+                if (a.res) e_res[j] = *(const f32x4 *)(a.res + (long long)urow * a.ldr + col);                \
+                if (a.accum) e_out[j] = *(const f32x4 *)(a.out + (long long)urow * a.ldo + col);              \
+                if (a.bnx) e_bnx[j] = *(const f32x4 *)(a.bnx + (long long)urow * a.ldbx + col);               \
+            }                                                                                                 \
+        }
+        if (HOIST) { C2_EPI_LOAD(0) }
         for (int m0 = 0; m0 < nsteps; m0 += U) {
-            bf16x8_t A[U];
+            uint4 rlo[U], rhi[U];
             int boff[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -258,40 +303,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
                 const bool ok = (m0 + u < nsteps) && (k < K);
                 const int idx = ok ? tblS[r * K + k] : -1;
                 boff[u] = ok ? (((k * S + c8) * NT) * 16 + r) * 8 : r * 8;
-                A[u] = c2_zero();
-                if (idx >= 0) A[u] = c2_load_a(a.x, XBF ? 1 : 0, (long long)idx * a.ldx + c8 * 8);
+                rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u];
+                if (idx >= 0) c2_load_raw<XBF>(a.x, (long long)idx * a.ldx + c8 * 8, rlo[u], rhi[u]);
             }
+            if (WLDS) {
+                __builtin_amdgcn_sched_barrier(0);   // every gather is in flight before the first conversion
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (m0 + u < nsteps) {   // wave-uniform
+                for (int u = 0; u < U; u++) {
+                    if (m0 + u < nsteps) {   // wave-uniform
+                        const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
 #pragma unroll
-                    for (int n = 0; n < NT; n++) {
-                        const uint4 bv = *(const uint4 *)(Wb + boff[u] + n * 128);
-                        // transposed product: D[m = channel][n = row] += W^T[channel][k] * X^T[k][row]
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), A[u], acc[n], 0, 0, 0);
+                        for (int n = 0; n < NT; n++) {
+                            const uint4 bv = *(const uint4 *)(Wb + boff[u] + n * 128);
+                            // transposed product: D[m = channel][n = row] += W^T[channel][k] * X^T[k][row]
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), A, acc[n], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                // weights from global memory (L2)
+                if (NT <= 4) {   // the fragments of step u + 1 are requested before the MFMAs of step u
+                    uint4 wnext[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; n++) wnext[n] = *(const uint4 *)(Wb + boff[0] + n * 128);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (m0 + u < nsteps) {   // wave-uniform
+                            uint4 wcur[NT];
+#pragma unroll
+                            for (int n = 0; n < NT; n++) wcur[n] = wnext[n];
+                            if (u + 1 < U && m0 + u + 1 < nsteps) {
+#pragma unroll
+                                for (int n = 0; n < NT; n++) wnext[n] = *(const uint4 *)(Wb + boff[u + 1] + n * 128);
+                            }
+                            const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
+#pragma unroll
+                            for (int n = 0; n < NT; n++)
+                                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wcur[n]), A, acc[n], 0, 0, 0);
+                        }
+                    }
+                } else {         // (registers) the fragments of a step in batches of 4: one round trip per batch
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (m0 + u < nsteps) {   // wave-uniform
+                            const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
+#pragma unroll
+                            for (int nb = 0; nb < NT; nb += 4) {
+                                uint4 wv[4];
+#pragma unroll
+                                for (int j = 0; j < 4; j++) if (nb + j < NT) wv[j] = *(const uint4 *)(Wb + boff[u] + (nb + j) * 128);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                    if (nb + j < NT) acc[nb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[j]), A, acc[nb + j], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
         }
         // D layout: column (= output row) lane & 15, rows (= channels) (lane >> 4) * 4 + q
-        {
-            const int u = row0 + r;
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
+        for (int n0 = 0; n0 < NT; n0 += NB) {
+            if (!HOIST) { C2_EPI_LOAD(n0) __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int n = n0 + j;
+                if (n >= NT) continue;
                 const int col = n * 16 + g * 4;
-                if (u < a.Mout && col < a.Cout) {   // Cout % 4 == 0 (checked on the host)
+                if (urow < a.Mout && col < a.Cout) {   // Cout % 4 == 0 (checked on the host)
                     f32x4 vv = acc[n];
-                    if (a.res) { const f32x4 rr = *(const f32x4 *)(a.res + (long long)u * a.ldr + col); vv += rr; }
-                    f32x4 *o = (f32x4 *)(a.out + (long long)u * a.ldo + col);
-                    if (a.accum) vv += *o;
+                    if (a.res) vv += e_res[j];
+                    f32x4 *o = (f32x4 *)(a.out + (long long)urow * a.ldo + col);
+                    if (a.accum) vv += e_out[j];
                     if (a.bnx) {
-                        const f32x4 xv = *(const f32x4 *)(a.bnx + (long long)u * a.ldbx + col);
                         f32x4 xh;
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const float inv = rsqrtf(a.bn_var[col + q] + a.bn_eps);
-                            xh[q] = (xv[q] - a.bn_mean[col + q]) * inv;
-                            if (a.bn_relu && fmaf(xh[q], a.bn_gamma[col + q], a.bn_beta[col + q]) <= 0.f) vv[q] = 0.f;
+                            const float4 bp = bnS[col + q];
+                            xh[q] = (e_bnx[j][q] - bp.x) * bp.y;
+                            if (a.bn_relu && fmaf(xh[q], bp.z, bp.w) <= 0.f) vv[q] = 0.f;
                         }
                         *o = vv;
                         ssum[n] += vv; ssq[n] += vv * xh;
@@ -302,6 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
                 }
             }
         }
+#undef C2_EPI_LOAD
         __builtin_amdgcn_wave_barrier();   // tblS is rewritten by the next tile
     }
 #undef C2_LOAD_TBL
@@ -332,9 +426,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT),
 // Workgroup-per-tile kernel (few-row levels): grid = (16-row tiles, column groups of NTW 16-wide tiles).  The
 // W = blockDim.x/64 waves split the MFMA steps of the tile, their accumulators are summed through LDS in wave order,
 // and the workgroup owns complete output columns: no atomics, no cross-workgroup reduction, deterministic.
-template <int NTW>
+template <int NTW, bool XBF>
 __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args a) {
     constexpr int U = 4;
+    constexpr int CW = NTW * 16;                     // output columns of this workgroup
+    constexpr bool SMALL = NTW <= (XBF ? 3 : 2);     // register budget: 128 VGPRs at 1024 threads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int W = blockDim.x >> 6, K = a.K, S = a.S;
@@ -345,18 +441,39 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
     float *finS = redS + (size_t)W * NTW * 256;      // 16 x NTW*16: stored values
     float *fin2S = finS + 16 * NTW * 16;             // 16 x NTW*16: second statistic (v*v, or g*xhat)
     const int row0 = blockIdx.x * 16, n0 = blockIdx.y * NTW;
+    // The kernel is a short chain of dependent memory round trips (kernel-map rows -> gathers -> epilogue operands), so
+    // everything whose address is known up front is requested up front: the kernel-map rows and, for narrow column
+    // groups, the epilogue operands of this thread's output elements e = t + i * blockDim.x (blockDim.x >= 256: at most
+    // NTW of them).  Wide groups request the epilogue operands in one batch at the epilogue instead (registers).
+    float e_res[NTW], e_out[NTW], e_bnx[NTW], e_mean[NTW], e_var[NTW], e_gam[NTW], e_bet[NTW];
+#define C2S_EPI_LOAD                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NTW; i++) {                                                         \
+        const int e = t + i * (int)blockDim.x;                                                                \
+        const int row = e / CW, cl = e - row * CW;                                                            \
+        const int u = row0 + row, col = n0 * 16 + cl;                                                         \
+        e_res[i] = 0.f; e_out[i] = 0.f; e_bnx[i] = 0.f; e_mean[i] = 0.f; e_var[i] = 1.f; e_gam[i] = 0.f; e_bet[i] = 0.f; \
+        if (e < 16 * CW && u < a.Mout && col < a.Cout) {                                                      \
+            if (a.res) e_res[i] = a.res[(long long)u * a.ldr + col];                                          \
+            if (a.accum) e_out[i] = a.out[(long long)u * a.ldo + col];                                        \
+            if (a.bnx) {                                                                                      \
+                e_bnx[i] = a.bnx[(long long)u * a.ldbx + col]; e_mean[i] = a.bn_mean[col]; e_var[i] = a.bn_var[col]; \
+                if (a.bn_relu) { e_gam[i] = a.bn_gamma[col]; e_bet[i] = a.bn_beta[col]; }                     \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    int v[2];
+    const long long base = (long long)row0 * K, lim = (long long)a.Mout * K;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {   // blockDim.x >= 256 and 16*K <= 432
+        const int e = t + it * blockDim.x;
+        v[it] = -1;
+        if (e < 16 * K && base + e < lim) v[it] = a.tbl ? a.tbl[base + e] : (int)(base + e);
+    }
+    if (SMALL) { C2S_EPI_LOAD }
     if (t == 0) *kmaskS = 0u;
     __syncthreads();
     {
         unsigned int bits = 0u;
-        const long long base = (long long)row0 * K, lim = (long long)a.Mout * K;
-        int v[2];
-#pragma unroll
-        for (int it = 0; it < 2; it++) {   // blockDim.x >= 256 and 16*K <= 432
-            const int e = t + it * blockDim.x;
-            v[it] = -1;
-            if (e < 16 * K && base + e < lim) v[it] = a.tbl ? a.tbl[base + e] : (int)(base + e);
-        }
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int e = t + it * blockDim.x;
@@ -377,7 +494,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
     for (int n = 0; n < NTW; n++) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nsteps = (na * S + 3) >> 2;
     for (int m0 = wave; m0 < nsteps; m0 += W * U) {
-        bf16x8_t A[U];
+        uint4 rlo[U], rhi[U];
         int boff[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -389,18 +506,45 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             const int k = actS[ok ? i : 0];
             const int idx = ok ? tblS[r * K + k] : -1;
             boff[u] = (((k * S + (ok ? c8 : 0)) * a.NT + n0) * 16 + r) * 8;
-            A[u] = c2_zero();
-            if (idx >= 0) A[u] = c2_load_a(a.x, a.xbf16, (long long)idx * a.ldx + c8 * 8);
+            rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u];
+            if (idx >= 0) c2_load_raw<XBF>(a.x, (long long)idx * a.ldx + c8 * 8, rlo[u], rhi[u]);
         }
+        if (SMALL) {
+            // gathers and all weight fragments of the batch in flight together: one round trip per batch
+            uint4 wv[U][NTW];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (m0 + u * W < nsteps) {
+            for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int n = 0; n < NTW; n++) {
-                    if (n0 + n < a.NT) {
-                        const uint4 bv = *(const uint4 *)(a.Wp + boff[u] + n * 128);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[u], __builtin_bit_cast(bf16x8_t, bv), acc[n], 0, 0, 0);
+                    wv[u][n] = make_uint4(0u, 0u, 0u, 0u);
+                    if (m0 + u * W < nsteps && n0 + n < a.NT) wv[u][n] = *(const uint4 *)(a.Wp + boff[u] + n * 128);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (m0 + u * W < nsteps) {
+                    const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
+#pragma unroll
+                    for (int n = 0; n < NTW; n++)
+                        if (n0 + n < a.NT) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, wv[u][n]), acc[n], 0, 0, 0);
+                }
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (m0 + u * W < nsteps) {
+                    uint4 wv[NTW];
+#pragma unroll
+                    for (int n = 0; n < NTW; n++) {
+                        wv[n] = make_uint4(0u, 0u, 0u, 0u);
+                        if (n0 + n < a.NT) wv[n] = *(const uint4 *)(a.Wp + boff[u] + n * 128);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
+#pragma unroll
+                    for (int n = 0; n < NTW; n++)
+                        if (n0 + n < a.NT) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, wv[n]), acc[n], 0, 0, 0);
                 }
             }
         }
@@ -409,28 +553,31 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
     for (int n = 0; n < NTW; n++)
 #pragma unroll
         for (int q = 0; q < 4; q++) redS[(wave * NTW * 4 + n * 4 + q) * 64 + lane] = acc[n][q];
+    if (!SMALL) { C2S_EPI_LOAD }
     __syncthreads();
-    // final tile: element e = row * CW + col (CW = NTW*16 columns of this workgroup), summed in wave order
-    constexpr int CW = NTW * 16;
-    for (int e = t; e < 16 * CW; e += blockDim.x) {
+    // final tile: element e = row * CW + col, summed in wave order
+#pragma unroll
+    for (int i = 0; i < NTW; i++) {
+        const int e = t + i * (int)blockDim.x;
+        if (e >= 16 * CW) continue;
         const int row = e / CW, cl = e - row * CW;
         const int n = cl >> 4, ln = (row >> 2) * 16 + (cl & 15), q = row & 3;
         float v = 0.f, w2 = 0.f;
         for (int w = 0; w < W; w++) v += redS[(w * NTW * 4 + n * 4 + q) * 64 + ln];
         const int u = row0 + row, col = n0 * 16 + cl;
         if (u < a.Mout && col < a.Cout) {
-            if (a.res) v += a.res[(long long)u * a.ldr + col];
-            float *o = a.out + (long long)u * a.ldo + col;
-            if (a.accum) v += *o;
+            if (a.res) v += e_res[i];
+            if (a.accum) v += e_out[i];
             if (a.bnx) {
-                const float xh = (a.bnx[(long long)u * a.ldbx + col] - a.bn_mean[col]) * rsqrtf(a.bn_var[col] + a.bn_eps);
-                if (a.bn_relu && fmaf(xh, a.bn_gamma[col], a.bn_beta[col]) <= 0.f) v = 0.f;
+                const float xh = (e_bnx[i] - e_mean[i]) * rsqrtf(e_var[i] + a.bn_eps);
+                if (a.bn_relu && fmaf(xh, e_gam[i], e_bet[i]) <= 0.f) v = 0.f;
                 w2 = v * xh;
             } else w2 = v * v;
-            *o = v;
+            a.out[(long long)u * a.ldo + col] = v;
         } else { v = 0.f; w2 = 0.f; }
         finS[e] = v; fin2S[e] = w2;
     }
+#undef C2S_EPI_LOAD
     if (a.part) {
         __syncthreads();
         if (t < 2 * CW) {
@@ -456,7 +603,8 @@ static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout) {
     if (ntiles >= 1024) {
         p.split = 0; p.W = 1;
         const int ntg = (ntiles + 3) / 4;
-        const int per = (ntg + 2047) / 2048;
+        static const int cap = getenv("D3_C2_GRIDCAP") ? atoi(getenv("D3_C2_GRIDCAP")) : 1024;   // (experiments)
+        const int per = (ntg + cap - 1) / cap;
         p.grid = (ntg + per - 1) / per;
         p.wlds = (wbytes + C2_WAVE_LDS_BYTES(NT) <= 72 * 1024) ? 1 : 0;
         p.lds = (p.wlds ? wbytes : 0) + C2_WAVE_LDS_BYTES(NT);
@@ -504,10 +652,12 @@ template <int NTW>
 static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done = true;
     }
-    spconv_fwd2_split_kernel<NTW><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
+    if (a.xbf16) spconv_fwd2_split_kernel<NTW, true><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
+    else spconv_fwd2_split_kernel<NTW, false><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
 }
