@@ -89,16 +89,21 @@ __global__ __launch_bounds__(SEG_THREADS) void sec_mean_kernel(const float *__re
 // above idles 253 of 256 lanes during the chain and the chain during the staging.
 #define MEANW_CHUNK 1024   // floats per chunk (16 per producer lane)
 #define MEANW_PROD 3       // producer waves = chunks per round
+// The chunk is staged TRANSPOSED (channel-major, rows padded to a multiple of 4), so the chain lane of a channel reads
+// four consecutive rows with one ds_read_b128 and keeps 32 rows in flight behind the 32 dependent adds: the chain runs
+// at the issue rate of v_add_f32 instead of waiting for LDS.
 __global__ __launch_bounds__(256) void sec_mean_pc_kernel(const float *__restrict__ inp, const int *__restrict__ offsets,
                                                          float *__restrict__ out, int nProposal, int C) {
-    __shared__ float stage[2][MEANW_PROD][MEANW_CHUNK];
+    __shared__ __attribute__((aligned(16))) float stage[2][MEANW_PROD][MEANW_CHUNK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = blockIdx.x;
     const int start = offsets[p], end = offsets[p + 1];
     const float count = (float)(end - start);
-    const int rpc = MEANW_CHUNK / C, cf = rpc * C;          // rows / floats per chunk
+    const int rpc = (MEANW_CHUNK / C) & ~3, cf = rpc * C;   // rows / floats per chunk (rows: a multiple of 4, or 0)
+    if (rpc == 0) return;                                    // (C <= 64 on this path: rpc >= 16)
     const long long base = (long long)start * C, total = (long long)(end - start) * C;
     const int nchunk = (int)((total + cf - 1) / cf);
     const int nround = (nchunk + MEANW_PROD - 1) / MEANW_PROD;
+    const unsigned int invC = (65536u + C - 1) / C;          // f / C for f < 1024 (exact: f * invC < 2^26, C <= 64)
     float mean = 0.f;
     for (int rd = 0; rd <= nround; rd++) {
         if (wave > 0) {   // produce chunk (rd, wave-1) of round rd into buffer rd & 1
@@ -110,40 +115,43 @@ __global__ __launch_bounds__(256) void sec_mean_pc_kernel(const float *__restric
 #pragma unroll
                 for (int j = 0; j < 16; j++) { const long long f = j * 64 + lane; v[j] = (f < cf && cb + f < total) ? inp[base + cb + f] : 0.f; }
 #pragma unroll
-                for (int j = 0; j < 16; j++) { const int f = j * 64 + lane; if (f < cf) st[f] = __fdiv_rn(v[j], count); }
+                for (int j = 0; j < 16; j++) {
+                    const int f = j * 64 + lane;
+                    if (f < cf) { const int row = (int)(((unsigned int)f * invC) >> 16), c = f - row * C; st[c * rpc + row] = __fdiv_rn(v[j], count); }
+                }
             }
         } else if (rd > 0) {   // consume round rd-1
             for (int q = 0; q < MEANW_PROD; q++) {
                 const int k = (rd - 1) * MEANW_PROD + q;
                 if (k >= nchunk) break;
-                const float *st = stage[(rd - 1) & 1][q];
+                const float *st = stage[(rd - 1) & 1][q] + lane * rpc;
                 const long long left = total - (long long)k * cf;
                 const int rows = (int)((left < cf ? left : cf) / C);
-                if (lane < C) {   // the LDS reads of the next 8 rows are in flight during the 8 dependent adds
+                if (lane < C) {
                     int r = 0;
-                    float w0[8], w1[8];
-                    if (rows >= 8) {
+                    float4 w0[8], w1[8];
+                    if (rows >= 32) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) w0[j] = st[j * C + lane];
+                        for (int j = 0; j < 8; j++) w0[j] = *(const float4 *)(st + j * 4);
                     }
-                    for (; r + 16 <= rows; r += 16) {
+                    for (; r + 64 <= rows; r += 64) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) w1[j] = st[(r + 8 + j) * C + lane];
+                        for (int j = 0; j < 8; j++) w1[j] = *(const float4 *)(st + r + 32 + j * 4);
 #pragma unroll
-                        for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w0[j]);
-                        if (r + 24 <= rows) {
+                        for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, w0[j].x); mean = __fadd_rn(mean, w0[j].y); mean = __fadd_rn(mean, w0[j].z); mean = __fadd_rn(mean, w0[j].w); }
+                        if (r + 96 <= rows) {
 #pragma unroll
-                            for (int j = 0; j < 8; j++) w0[j] = st[(r + 16 + j) * C + lane];
+                            for (int j = 0; j < 8; j++) w0[j] = *(const float4 *)(st + r + 64 + j * 4);
                         }
 #pragma unroll
-                        for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w1[j]);
+                        for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, w1[j].x); mean = __fadd_rn(mean, w1[j].y); mean = __fadd_rn(mean, w1[j].z); mean = __fadd_rn(mean, w1[j].w); }
                     }
-                    if (r + 8 <= rows) {
+                    if (r + 32 <= rows) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) mean = __fadd_rn(mean, w0[j]);
-                        r += 8;
+                        for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, w0[j].x); mean = __fadd_rn(mean, w0[j].y); mean = __fadd_rn(mean, w0[j].z); mean = __fadd_rn(mean, w0[j].w); }
+                        r += 32;
                     }
-                    for (; r < rows; r++) mean = __fadd_rn(mean, st[r * C + lane]);
+                    for (; r < rows; r++) mean = __fadd_rn(mean, st[r]);
                 }
             }
         }
