@@ -109,20 +109,31 @@ __device__ __forceinline__ void cl_union(int *parent, int a, int b) {
     }
 }
 
-// phase 1a: one thread per node walks its (complete, hence short) list
+// phase 1a: eight lanes per node walk its (complete, hence short) list, four edges per lane in flight: every edge is a
+// chain of dependent gathers (neighbour id -> its label / list length -> the two finds), and a thread per node walked
+// that chain once per edge.  scalars[3] is raised when any list is capped: only then does phase 1b have work.
+#define CL_UG 8
 __global__ __launch_bounds__(256) void cl_union_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
-                                                      const int *__restrict__ start_len, int n, int *parent) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
-    if (ln >= CL_CAP) return;
+                                                      const int *__restrict__ start_len, int n, int *parent, int *scalars) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid / CL_UG, sub = gid % CL_UG;
+    const bool live = i < n;
+    const int st = live ? start_len[i * 2] : 0, ln = live ? start_len[i * 2 + 1] : 0;
+    if (__any(ln >= CL_CAP) && d3_lane() == 0) scalars[3] = 1;
+    if (!live || ln >= CL_CAP) return;
     const int si = sem[i];
-    for (int e = 0; e < ln; e++) {
-        const int j = idx[st + e];
-        if (j == i || sem[j] != si) continue;
-        if (start_len[j * 2 + 1] >= CL_CAP) continue;
-        if (j < i) continue;  // the edge is mutual (both lists complete): handle it once, from its smaller endpoint
-        cl_union(parent, i, j);
+    for (int e0 = sub; e0 < ln; e0 += 4 * CL_UG) {
+        int j[4], sj[4], lj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int e = e0 + q * CL_UG; j[q] = e < ln ? idx[st + e] : i; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { sj[q] = sem[j[q]]; lj[q] = start_len[j[q] * 2 + 1]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // the edge is mutual (both lists complete): handle it once, from its smaller endpoint
+            if (j[q] <= i || sj[q] != si || lj[q] >= CL_CAP) continue;
+            cl_union(parent, i, j[q]);
+        }
     }
 }
 __global__ void cl_flatten_kernel(int *parent, int n) {
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
                                                      const int *__restrict__ root, int *lab, int *scalars) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
+    if (scalars[3] == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     const int si = sem[i];
     const int ri = root[i];
@@ -209,7 +221,7 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
     cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, n, w.scalars);
-    cl_union_kernel<<<nb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
+    cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
     for (int it = 0; it < n + 2; it++) {
