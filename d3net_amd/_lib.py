@@ -38,6 +38,8 @@ SIGNATURES = {
     "d3_ballquery_ws_bytes_single_pass": (sz, [i32]),
     "d3_ballquery_count": (i32, [vp, vp, vp, i32, f32, vp, vp, sz, pi, vp]),
     "d3_ballquery_fill": (i32, [vp, vp, vp, i32, f32, vp, vp, sz, vp, i64, vp]),
+    "d3_ballquery_cap": (i32, []),
+    "d3_ballquery_padded": (i32, [vp, vp, vp, i32, f32, vp, vp, sz, vp, vp]),
     "d3_bfs_cluster_ws_bytes": (sz, [i32]),
     "d3_bfs_cluster_count": (i32, [vp, vp, vp, i32, i32, vp, sz, pi, pi, vp]),
     "d3_bfs_cluster_fill": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, i32, i32, vp]),

@@ -131,8 +131,11 @@ __device__ __forceinline__ bool bq_axis_near(float o, float lo, float hi, float 
 }
 __device__ __forceinline__ bool bq_box_near(float ox, float oy, float oz, const float *lo, const float *hi, int i,
                                             float rc) {
-    return bq_axis_near(ox, lo[i * 3 + 0], hi[i * 3 + 0], rc) && bq_axis_near(oy, lo[i * 3 + 1], hi[i * 3 + 1], rc) &&
-           bq_axis_near(oz, lo[i * 3 + 2], hi[i * 3 + 2], rc);
+    // all six loads first (a short-circuit && would wait for each axis before requesting the next)
+    const float l0 = lo[i * 3 + 0], l1 = lo[i * 3 + 1], l2 = lo[i * 3 + 2];
+    const float h0 = hi[i * 3 + 0], h1 = hi[i * 3 + 1], h2 = hi[i * 3 + 2];
+    const bool a = bq_axis_near(ox, l0, h0, rc), b = bq_axis_near(oy, l1, h1, rc), c = bq_axis_near(oz, l2, h2, rc);
+    return a & b & c;
 }
 
 // MODE 0: count; 1: fill idx at the scanned starts; 2: count AND stash the hits at stash[q*BQ_CAP + pos] (single pass:
@@ -162,31 +165,53 @@ __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ 
     if (end > start) {
         const int c_first = start / BQ_CHUNK, c_last = (end - 1) / BQ_CHUNK;
         const int s_first = c_first / BQ_SUPER, s_last = c_last / BQ_SUPER;
-        for (int sc = s_first; sc <= s_last && cnt < BQ_CAP; sc++) {
-            if (!bq_box_near(ox, oy, oz, slo, shi, sc, rc)) continue;  // wave-uniform
+        // the super boxes are tested 64 at a time, one per lane (a serial walk paid one round trip per super box)
+        for (int sb = s_first; sb <= s_last && cnt < BQ_CAP; sb += 64) {
+          const int sl = min(sb + lane, s_last);
+          unsigned long long sm = __ballot(sb + lane <= s_last && bq_box_near(ox, oy, oz, slo, shi, sl, rc));
+          while (sm != 0ull && cnt < BQ_CAP) {
+            const int sc = sb + (int)__builtin_ctzll(sm);
+            sm &= sm - 1ull;
             const int c = sc * BQ_SUPER + lane;
-            bool pass = (c >= c_first) && (c <= c_last) && bq_box_near(ox, oy, oz, clo, chi, c, rc);
+            const bool crange = (c >= c_first) && (c <= c_last);
+            const bool pass = bq_box_near(ox, oy, oz, clo, chi, crange ? c : c_first, rc) && crange;
             unsigned long long cm = __ballot(pass);
+            // four candidate chunks per round trip: their points are requested together (branch-free addresses: a
+            // branch between the loads would make each one wait for the previous), then tested in chunk order
             while (cm != 0ull && cnt < BQ_CAP) {
-                const int cc = sc * BQ_SUPER + (int)__builtin_ctzll(cm);
-                cm &= cm - 1ull;
-                const int k = cc * BQ_CHUNK + lane;
-                bool hit = false;
-                if (k >= start && k < end) {
-                    const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-                    const float dx = __fsub_rn(ox, x), dy = __fsub_rn(oy, y), dz = __fsub_rn(oz, z);
+                int kk[4];
+                bool in[4], valid[4];
+                float x[4], y[4], z[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    valid[j] = cm != 0ull;
+                    const int cc = sc * BQ_SUPER + (valid[j] ? (int)__builtin_ctzll(cm) : 0);
+                    if (valid[j]) cm &= cm - 1ull;
+                    kk[j] = cc * BQ_CHUNK + lane;
+                    in[j] = valid[j] && kk[j] >= start && kk[j] < end;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ka = in[j] ? kk[j] : q;
+                    x[j] = xyz[ka * 3 + 0]; y[j] = xyz[ka * 3 + 1]; z[j] = xyz[ka * 3 + 2];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!valid[j] || cnt >= BQ_CAP) continue;   // wave-uniform
+                    const float dx = __fsub_rn(ox, x[j]), dy = __fsub_rn(oy, y[j]), dz = __fsub_rn(oz, z[j]);
                     // ((dx*dx + dy*dy) + dz*dz), every operation rounded separately (bfs_cluster.cu:36)
                     const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                    hit = d2 < radius2;
+                    const bool hit = in[j] && d2 < radius2;
+                    const unsigned long long hm = __ballot(hit);
+                    if (MODE != 0 && hit) {
+                        const int pos = cnt + (int)__popcll(hm & lt);
+                        // cap (bfs_cluster.cu:38-44) and buffer truncation (bfs_cluster.cu:51-59)
+                        if (pos < BQ_CAP && (MODE == 2 || base + pos < idx_capacity)) idx[base + pos] = kk[j];
+                    }
+                    cnt += (int)__popcll(hm);
                 }
-                const unsigned long long hm = __ballot(hit);
-                if (MODE != 0 && hit) {
-                    const int pos = cnt + (int)__popcll(hm & lt);
-                    // cap (bfs_cluster.cu:38-44) and buffer truncation (bfs_cluster.cu:51-59)
-                    if (pos < BQ_CAP && (MODE == 2 || base + pos < idx_capacity)) idx[base + pos] = k;
-                }
-                cnt += (int)__popcll(hm);
             }
+          }
         }
     }
     if (cnt > BQ_CAP) cnt = BQ_CAP;
@@ -268,3 +293,31 @@ extern "C" int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const 
     D3_LAUNCH_CHECK();
     return 0;
 }
+
+// Padded (sync-free) form: every point owns a fixed slot of d3_ballquery_cap() entries, start_len[q] = (q * cap, len).
+// No scan, no compaction, no host round trip for nActive: the consumers (d3_bfs_cluster_*) only ever index
+// idx[start + e], e < len, so the padded layout is a valid (idx, start_len) pair for them.  idx_padded: n * cap ints.
+__global__ void bq_pack_padded_kernel(const int *len, int *start_len, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    start_len[i * 2 + 0] = i * BQ_CAP;
+    start_len[i * 2 + 1] = len[i];
+}
+extern "C" int d3_ballquery_cap(void) { return BQ_CAP; }
+extern "C" int d3_ballquery_padded(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
+                                   int *start_len, void *ws, size_t ws_bytes, int *idx_padded, void *stream) {
+    D3_CLEAR();
+    if (n <= 0) return 0;
+    if ((long long)n * BQ_CAP > 0x7FFFFFFFLL) return D3_ERR_ARG;
+    BqWs w;
+    if (!bq_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    int rc = bq_boxes(xyz, n, w, s);
+    if (rc) return rc;
+    bq_scan_kernel<2><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo, w.shi,
+                                                 w.nchunks, w.len, nullptr, idx_padded, 0);
+    bq_pack_padded_kernel<<<(n + 255) / 256, 256, 0, s>>>(w.len, start_len, n);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -346,8 +346,10 @@ class PointGroup(nn.Module):
                 semantic_preds_ = semantic_preds[object_idxs].int().contiguous()
 
                 def cluster_branch(xyz, mean_active, marks=False):
-                    idx_, start_len_ = pointgroup_ops.ballquery_batch_p(xyz, batch_idxs_, batch_offsets_, self.cluster_radius,
-                                                                        mean_active)
+                    # (padded lists: same neighbours, no host round trip for nActive; bfs_cluster reads either form)
+                    padded = pointgroup_ops.ballquery_batch_p_padded(xyz, batch_idxs_, batch_offsets_, self.cluster_radius)
+                    idx_, start_len_ = padded if padded is not None else pointgroup_ops.ballquery_batch_p(
+                        xyz, batch_idxs_, batch_offsets_, self.cluster_radius, mean_active)
                     if marks:
                         _mark("cl_ballquery")
                     p_idx, p_off = pointgroup_ops.bfs_cluster(semantic_preds_, idx_, start_len_, self.cluster_npoint_thre)

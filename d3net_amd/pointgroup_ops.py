@@ -221,6 +221,29 @@ class BallQueryBatchP(Function):
 ballquery_batch_p = BallQueryBatchP.apply
 
 
+def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=2 << 30):
+    """Sync-free ball query for callers that hand the result straight to `bfs_cluster`: every point owns a fixed slot
+    of `cap` entries (start_len[q] = (q * cap, len)), so there is no nActive to fetch, no scan and no compaction.  Same
+    neighbours in the same order as `ballquery_batch_p` (lib/pointgroup_ops/functions/pointgroup_ops.py:143-180);
+    returns None when the padded buffer would exceed `max_bytes` (the caller then uses `ballquery_batch_p`)."""
+    n = coords.size(0)
+    L = _lib.lib()
+    cap = L.d3_ballquery_cap()
+    if n == 0 or n * cap * 4 > max_bytes:
+        return None
+    assert coords.is_contiguous() and coords.is_cuda and coords.dtype == torch.float32
+    assert batch_idxs.is_contiguous() and batch_idxs.is_cuda and batch_idxs.dtype == torch.int32
+    assert batch_offsets.is_contiguous() and batch_offsets.is_cuda and batch_offsets.dtype == torch.int32
+    dev = coords.device
+    with _on(dev):
+        start_len = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        idx = torch.empty(n * cap, dtype=torch.int32, device=dev)
+        ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bqp")
+        check(L.d3_ballquery_padded(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius), _ptr(start_len),
+                                    _ptr(ws), ws.numel(), _ptr(idx), _stream()), "ballquery_padded")
+    return idx, start_len
+
+
 class BFSCluster(Function):
     @staticmethod
     def forward(ctx, semantic_label, ball_query_idxs, start_len, threshold):

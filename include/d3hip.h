@@ -92,6 +92,13 @@ int d3_ballquery_count(const float *xyz, const int *batch_idxs, const int *batch
 int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
                       const int *start_len, const void *ws, size_t ws_bytes, int *idx, long long idx_capacity,
                       void *stream);
+/* Padded, sync-free ball query: point q owns idx_padded[q * d3_ballquery_cap() ...], start_len[q] = (q * cap, len).
+ * Same neighbours in the same order as d3_ballquery_count/fill; no nActive, no host round trip.  Valid input of
+ * d3_bfs_cluster_count / d3_bfs_cluster_fill2 (which only read idx[start + e], e < len).  idx_padded: n * cap ints;
+ * ws: d3_ballquery_ws_bytes(n).  Replaces the same reference call as d3_ballquery_count (bfs_cluster.cu:13-63). */
+int d3_ballquery_cap(void);
+int d3_ballquery_padded(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
+                        int *start_len, void *ws, size_t ws_bytes, int *idx_padded, void *stream);
 
 /* PG_OP.bfs_cluster  (src/bfs_cluster/bfs_cluster.cpp:28-112), on the device, two-phase.
  * count: connected components (same semantic label, directed ball-query lists, seeds in

@@ -159,6 +159,31 @@ def test_ballquery_random_order_and_cap(dev):
     assert np.array_equal(N(sl), rsl) and np.array_equal(N(idx), ridx)
 
 
+def test_ballquery_padded_matches_compact_and_feeds_bfs(dev):
+    """The sync-free padded form: same lists in the same order as the compact one (incl. capped lists), and
+    bfs_cluster on it returns the oracle's clusters bit for bit."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(72)
+    n = 7000
+    xyz = rng.random((n, 3)).astype(np.float32) * np.array([1.2, 1, 0.2], np.float32)
+    xyz[rng.permutation(n)[:2200]] = np.array([0.5, 0.5, 0.1], np.float32) + rng.normal(0, 0.004, (2200, 3)).astype(np.float32)
+    n1 = 4000
+    bi = np.concatenate([np.zeros(n1, np.int32), np.ones(n - n1, np.int32)]); bo = np.array([0, n1, n], np.int32)
+    sem = (1 + (xyz[:, 0] * 3).astype(np.int32) % 2).astype(np.int32)
+    ridx, rsl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
+    assert rsl[:, 1].max() == 1000
+    pidx, psl = P.ballquery_batch_p_padded(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03)
+    pidx, psl_h = N(pidx), N(psl)
+    cap = pidx.size // n
+    assert np.array_equal(psl_h[:, 1], rsl[:, 1]) and np.array_equal(psl_h[:, 0], np.arange(n, dtype=np.int64) * cap)
+    for q in rng.permutation(n)[:400]:
+        assert np.array_equal(pidx[q * cap:q * cap + rsl[q, 1]], ridx[rsl[q, 0]:rsl[q, 0] + rsl[q, 1]])
+    rci, rco = o.bfs_cluster(sem, ridx, rsl, 20)
+    ci, co = P.bfs_cluster(T(sem, dev), T(pidx, dev), psl, 20)
+    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+    assert P.ballquery_batch_p_padded(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, max_bytes=1024) is None
+
+
 def test_ballquery_empty_batch_item_and_tiny(dev):
     from d3net_amd import pointgroup_ops as P
     xyz = np.array([[0, 0, 0], [0.01, 0, 0], [1, 1, 1]], np.float32)
