@@ -229,3 +229,45 @@ extern "C" int d3_scatter_add_rows(const float *g, const int64_t *idx, float *ou
     D3_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ score loss
+// PointGroup's proposal score loss (reference model/pointgroup.py:436-452) in one launch instead of ~30 elementwise
+// launches over a few dozen proposals:  gt_iou = max_j ious[p, j];  gt_score = 1 above fg, 0 below bg, linear between;
+// loss = mean_p BCEWithLogits(score_p, gt_score_p) with torch's stable form (1 - z) x + m + log(exp(-m) + exp(-x - m)),
+// m = max(-x, 0).  out[0] = loss; dscore[p] = (sigmoid(x) - z) / P (scaled by the upstream gradient on the host side).
+__global__ __launch_bounds__(256) void score_loss_kernel(const float *__restrict__ scores, const float *__restrict__ ious, int P,
+                                                        int nInst, float fg, float bg, float *__restrict__ gt_iou,
+                                                        float *__restrict__ dscore, float *__restrict__ out) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    float part = 0.f;
+    const float k = 1.f / (fg - bg), b = bg / (bg - fg);
+    for (int p0 = 0; p0 < P; p0 += 256) {     // fixed order: deterministic
+        const int p = p0 + t;
+        float l = 0.f;
+        if (p < P) {
+            float m = -INFINITY;
+            for (int j = 0; j < nInst; j++) m = fmaxf(m, ious[(long long)p * nInst + j]);
+            gt_iou[p] = m;
+            const float z = (m > fg) ? 1.f : (m < bg) ? 0.f : m * k + b;
+            const float x = scores[p];
+            const float mv = fmaxf(-x, 0.f);
+            l = (1.f - z) * x + mv + logf(expf(-mv) + expf(-x - mv));
+            dscore[p] = (1.f / (1.f + expf(-x)) - z) / (float)P;
+        }
+        red[t] = l;
+        __syncthreads();
+        if (t == 0) { for (int i = 0; i < 256 && p0 + i < P; i++) part += red[i]; }
+        __syncthreads();
+    }
+    if (t == 0) out[0] = part / (float)P;
+}
+extern "C" int d3_score_loss(const float *scores, const float *ious, int P, int nInst, float fg, float bg, float *gt_iou,
+                             float *dscore, float *out, void *stream) {
+    D3_CLEAR();
+    if (P <= 0 || nInst <= 0) return D3_ERR_ARG;
+    score_loss_kernel<<<1, 256, 0, d3_stream(stream)>>>(scores, ious, P, nInst, fg, bg, gt_iou, dscore, out);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -21,10 +21,22 @@ __global__ void voxelize_fp_kernel(const float *__restrict__ feats, float *__res
     if (e >= total) return;
     const int row = (int)(e / nPlanes), plane = (int)(e % nPlanes);
     const int *r = rules + (long long)row * (maxActive + 1);
+    // A voxel holds one to a few points.  The count, the first four point ids and the accumulator are requested together,
+    // then the four gathers together (branch-free: selects instead of a loop whose every step waits for two dependent
+    // loads); the adds keep the reference's serial order.
     const int nActive = r[0];
-    const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
+    int id[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) id[j] = r[j < maxActive ? 1 + j : 0];
     float acc = out[e];
-    for (int i = 1; i <= nActive; i++)
+    const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = feats[(long long)(j < nActive ? id[j] : 0) * nPlanes + plane];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < nActive) acc = __fadd_rn(acc, __fmul_rn(multiplier, v[j]));
+    for (int i = 5; i <= nActive; i++)
         acc = __fadd_rn(acc, __fmul_rn(multiplier, feats[(long long)r[i] * nPlanes + plane]));
     out[e] = acc;
 }

@@ -142,6 +142,42 @@ def offset_losses(pt_offsets, coords, instance_info, instance_ids, ignore_label)
     return norm_loss, dir_loss, valid.sum()
 
 
+class _ScoreLoss(Function):
+    @staticmethod
+    def forward(ctx, scores, ious, fg, bg):
+        x = scores.reshape(-1).contiguous()
+        P = x.numel()
+        gt_iou, ds = torch.empty_like(x), torch.empty_like(x)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        with _on(x.device):
+            check(_lib.lib().d3_score_loss(_ptr(x), _ptr(ious), P, ious.size(1), float(fg), float(bg), _ptr(gt_iou), _ptr(ds),
+                                           _ptr(out), _stream()), "score_loss")
+        ctx.save_for_backward(ds)
+        ctx.shape = scores.shape
+        ctx.mark_non_differentiable(gt_iou)
+        return out[0], gt_iou
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (ds,) = ctx.saved_tensors
+        return (ds * g).view(ctx.shape), None, None, None
+
+
+def score_loss(scores, ious, fg_thresh, bg_thresh):
+    """(score_loss, gt_ious) of PointGroup.loss (reference: model/pointgroup.py:436-452): row maxima of the IoU matrix,
+    soft labels between the two thresholds, mean BCE-with-logits."""
+    if scores.is_cuda and scores.dtype == torch.float32 and ious.dtype == torch.float32 and ious.dim() == 2 \
+            and ious.size(1) > 0 and scores.numel() > 0 and ious.is_contiguous():
+        return _ScoreLoss.apply(scores, ious, fg_thresh, bg_thresh)
+    gt_ious, _ = ious.max(1)
+    fg_mask = gt_ious > fg_thresh
+    bg_mask = gt_ious < bg_thresh
+    k = 1 / (fg_thresh - bg_thresh)
+    b = bg_thresh / (bg_thresh - fg_thresh)
+    gt_scores = torch.where(~fg_mask & ~bg_mask, gt_ious * k + b, fg_mask.float())
+    return torch.nn.functional.binary_cross_entropy_with_logits(scores.view(-1), gt_scores, reduction="none").mean(), gt_ious
+
+
 class _GatherRows(Function):
     """feats[idx] whose backward is one atomic scatter-add launch (deterministic for <= 2 addends per row: the cluster
     feature gather, where a point is in at most one cluster of each of the two cluster sets)"""

@@ -455,15 +455,6 @@ class PointGroup(nn.Module):
     # ---------------------------------------------------------------------------------------- loss
     def loss(self, data_dict, epoch):
         """semantic CE + offset L1 / direction + soft-IoU score BCE (reference :387-463)."""
-        def get_segmented_scores(scores, fg_thresh=1.0, bg_thresh=0.0):
-            fg_mask = scores > fg_thresh
-            bg_mask = scores < bg_thresh
-            interval_mask = (fg_mask == 0) & (bg_mask == 0)
-            segmented = (fg_mask > 0).float()
-            k = 1 / (fg_thresh - bg_thresh)
-            b = bg_thresh / (bg_thresh - fg_thresh)
-            return torch.where(interval_mask, scores * k + b, segmented)    # masked assignment without a host round trip
-
         semantic_scores, semantic_labels = data_dict["semantic_scores"]
         semantic_loss = heads.cross_entropy(semantic_scores, semantic_labels, ignore_index=self.cfg.data.ignore_label)
         data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
@@ -481,9 +472,7 @@ class PointGroup(nn.Module):
             if scores.shape[0] > 0:
                 ious = pointgroup_ops.get_iou(proposals_idx[:, 1].contiguous(), proposals_offset, instance_ids,
                                               instance_pointnum)
-                gt_ious, _ = ious.max(1)
-                gt_scores = get_segmented_scores(gt_ious, self.cfg.train.fg_thresh, self.cfg.train.bg_thresh)
-                score_loss = nn.functional.binary_cross_entropy_with_logits(scores.view(-1), gt_scores, reduction="none").mean()
+                score_loss, gt_ious = heads.score_loss(scores, ious, self.cfg.train.fg_thresh, self.cfg.train.bg_thresh)
             else:  # the reference would produce NaN (mean of an empty tensor); keep the step finite
                 gt_ious = scores.new_zeros(0)
                 score_loss = scores.sum() * 0

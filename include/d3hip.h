@@ -279,6 +279,11 @@ int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *db, int N, 
 size_t d3_offset_loss_ws_bytes(void);
 int d3_offset_loss(const float *pt, const float *coords, const float *info, int ldi, const int64_t *ids, long long ignore,
                    float *g1, float *g2, float *out, int N, void *ws, size_t ws_bytes, void *stream);
+/* Proposal score loss of PointGroup.loss (reference model/pointgroup.py:436-452: ious.max(1), get_segmented_scores,
+ * binary_cross_entropy_with_logits(...).mean()) in one launch.  ious: (P, nInst) row-major.  gt_iou: (P) row maxima;
+ * dscore: (P) d loss / d score; out[0] = loss. */
+int d3_score_loss(const float *scores, const float *ious, int P, int nInst, float fg, float bg, float *gt_iou,
+                  float *dscore, float *out, void *stream);
 /* out[idx[s], :] += g[s, :] (out zero-filled by the caller): backward of the cluster feature gather
  * (model/pointgroup.py:130); deterministic when every output row receives at most two addends, as it does there */
 int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream);
