@@ -72,6 +72,7 @@ SIGNATURES = {
     "d3_net_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_tall_wgrad_ws_bytes": (sz, [i32, i32]),
     "d3_tall_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "d3_stack_to_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_score_loss": (i32, [vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
     "d3_offset_loss_ws_bytes": (sz, []),
     "d3_offset_loss": (i32, [vp, vp, vp, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),

@@ -271,3 +271,77 @@ extern "C" int d3_score_loss(const float *scores, const float *ious, int P, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- stack -> batch
+// PointGroup.convert_stack_to_batch + get_object_assignments (reference model/pointgroup.py:216-263) in three launches
+// instead of ~45 library launches over a few dozen proposals.  Proposal p of scene b with rank r among the kept
+// proposals of b (stacking order) lands in slot b*K + inv_perm[b][r] when r < K (out[b][j] = buf[perm[b][j]] with
+// buf[:n] = rows, as the reference's padded-then-shuffled copy); box corners are centre +- size/2 in fp64 like the
+// numpy original (lib/utils/bbox.py:54-74, heading 0).
+#define STB_MAXP 4096
+#define STB_MAXBK 8192
+__global__ __launch_bounds__(1024) void stb_slot_kernel(const int *__restrict__ bids, const long long *__restrict__ perm, int P,
+                                                       int B, int K, long long *__restrict__ slot) {
+    __shared__ int bS[STB_MAXP];
+    __shared__ int invS[STB_MAXBK];
+    const int t = threadIdx.x;
+    for (int p = t; p < P; p += blockDim.x) bS[p] = bids[p];
+    for (int i = t; i < B * K; i += blockDim.x) { const int b = i / K; invS[b * K + (int)perm[i]] = i - b * K; }
+    __syncthreads();
+    for (int p = t; p < P; p += blockDim.x) {
+        const int b = bS[p];
+        int rank = 0;
+        for (int q = 0; q < p; q++) rank += (bS[q] == b) ? 1 : 0;
+        slot[p] = (b >= 0 && b < B && rank < K) ? (long long)b * K + invS[b * K + rank] : -1;
+    }
+}
+__global__ __launch_bounds__(64) void stb_scatter_kernel(const float *__restrict__ feats, const float *__restrict__ crop,
+                                                        const float *__restrict__ scores, const long long *__restrict__ slot,
+                                                        int m, float *__restrict__ feats_b, float *__restrict__ bbox_b,
+                                                        float *__restrict__ center_b, float *__restrict__ sem_b,
+                                                        float *__restrict__ scores_b, float *__restrict__ mask_b) {
+    const int p = blockIdx.x, t = threadIdx.x;
+    const long long s = slot[p];
+    if (s < 0) return;
+    for (int c = t; c < m; c += 64) feats_b[s * m + c] = feats[(long long)p * m + c];
+    const float *cr = crop + (long long)p * 9;
+    if (t < 24) {
+        const int corner = t / 3, ax = t - corner * 3;
+        // corner signs of get_3d_box_batch: x (+,+,-,-,+,+,-,-), y (+,-,-,+,+,-,-,+), z (+,+,+,+,-,-,-,-)
+        const int sx = (corner & 2) ? -1 : 1, sy = ((corner + 1) & 2) ? -1 : 1, sz = (corner & 4) ? -1 : 1;
+        const double sg = ax == 0 ? sx : ax == 1 ? sy : sz;
+        bbox_b[s * 24 + t] = (float)((double)cr[3 + ax] / 2.0 * sg + (double)cr[ax]);
+    }
+    if (t >= 32 && t < 35) center_b[s * 3 + (t - 32)] = cr[t - 32];
+    if (t == 40) { sem_b[s] = cr[7]; scores_b[s] = scores[p]; mask_b[s] = 1.f; }
+}
+// nearest GT centre in L1 for every slot (lib/utils/nn_distance.py:32-59 as used at :216-221): smallest index on ties
+__global__ void stb_assign_kernel(const float *__restrict__ center_b, const float *__restrict__ gt, int B, int K, int G,
+                                  long long *__restrict__ assign) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K;
+    const float x = center_b[i * 3], y = center_b[i * 3 + 1], z = center_b[i * 3 + 2];
+    float best = INFINITY; int bi = 0;
+    for (int g = 0; g < G; g++) {
+        const float *c = gt + ((long long)b * G + g) * 3;
+        const float d = __fadd_rn(__fadd_rn(fabsf(__fsub_rn(x, c[0])), fabsf(__fsub_rn(y, c[1]))), fabsf(__fsub_rn(z, c[2])));
+        if (d < best) { best = d; bi = g; }
+    }
+    assign[i] = bi;
+}
+extern "C" int d3_stack_to_batch(const float *feats, const float *crop, const float *scores, const int *bids,
+                                 const long long *perm, const float *center_label, int G, int P, int m, int B, int K,
+                                 float *feats_b, float *bbox_b, float *center_b, float *sem_b, float *scores_b, float *mask_b,
+                                 long long *slot, long long *assign, void *stream) {
+    D3_CLEAR();
+    if (P < 0 || P > STB_MAXP || B < 1 || K < 1 || B * K > STB_MAXBK || m < 1) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    if (P > 0) {
+        stb_slot_kernel<<<1, 1024, 0, s>>>(bids, perm, P, B, K, slot);
+        stb_scatter_kernel<<<P, 64, 0, s>>>(feats, crop, scores, slot, m, feats_b, bbox_b, center_b, sem_b, scores_b, mask_b);
+    }
+    if (assign && center_label && G > 0) stb_assign_kernel<<<(B * K + 255) / 256, 256, 0, s>>>(center_b, center_label, B, K, G, assign);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+

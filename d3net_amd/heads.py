@@ -178,6 +178,56 @@ def score_loss(scores, ious, fg_thresh, bg_thresh):
     return torch.nn.functional.binary_cross_entropy_with_logits(scores.view(-1), gt_scores, reduction="none").mean(), gt_ious
 
 
+class _StackToBatch(Function):
+    @staticmethod
+    def forward(ctx, pf, scores, crop, bids, perm, center_label, B, K):
+        P, m = pf.shape
+        dev = pf.device
+        pf_c, sc_c = pf.contiguous(), scores.contiguous()
+        flat = torch.zeros(B * K * (m + 24 + 3 + 3), dtype=torch.float32, device=dev)   # one fill for the six outputs
+        o = 0
+        outs = []
+        for w in (m, 24, 3, 1, 1, 1):
+            outs.append(flat[o:o + B * K * w]); o += B * K * w
+        slot = torch.empty(max(P, 1), dtype=torch.int64, device=dev)
+        G = 0 if center_label is None else center_label.size(1)
+        assign = torch.empty((B, K), dtype=torch.int64, device=dev) if G > 0 else None
+        with _on(dev):
+            check(_lib.lib().d3_stack_to_batch(_ptr(pf_c), _ptr(crop), _ptr(sc_c), _ptr(bids), _ptr(perm),
+                                               _ptr(center_label) if G > 0 else None, G, P, m, B, K, *[_ptr(t) for t in outs],
+                                               _ptr(slot), _ptr(assign) if G > 0 else None, _stream()), "stack_to_batch")
+        ctx.save_for_backward(slot[:P])
+        ctx.dims = (P, m)
+        res = (outs[0].view(B, K, m), outs[1].view(B, K, 8, 3), outs[2].view(B, K, 3), outs[3].view(B, K), outs[4].view(B, K),
+               outs[5].view(B, K), assign if assign is not None else torch.empty(0, dtype=torch.int64, device=dev))
+        ctx.mark_non_differentiable(res[1], res[2], res[3], res[5], res[6])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_feats, g_bbox, g_center, g_sem, g_scores, g_mask, g_assign):
+        (slot,) = ctx.saved_tensors
+        P, m = ctx.dims
+        ok = slot >= 0
+        idx = slot.clamp(min=0)
+        gp = g_feats.reshape(-1, m).index_select(0, idx) * ok.unsqueeze(1).to(g_feats.dtype) if g_feats is not None else None
+        gs = g_scores.reshape(-1).index_select(0, idx) * ok.to(g_scores.dtype) if g_scores is not None else None
+        return gp, gs, None, None, None, None, None, None
+
+
+def stack_to_batch(pf, scores, crop, bids, perm, center_label, B, K):
+    """Fused PointGroup.convert_stack_to_batch + get_object_assignments (reference model/pointgroup.py:216-263); returns
+    None when the shapes are outside the kernel's limits (the caller then uses the library-op path).
+    -> (feats (B,K,m), corners (B,K,8,3), centres (B,K,3), sem_cls, scores, mask (B,K), object_assignment (B,K) or empty)"""
+    if not (pf.is_cuda and pf.dtype == torch.float32 and crop.dtype == torch.float32 and crop.is_contiguous() and crop.size(1) == 9
+            and scores.dtype == torch.float32 and bids.dtype == torch.int32 and bids.is_contiguous()
+            and perm.dtype == torch.int64 and perm.is_contiguous() and pf.size(0) <= 4096 and B * K <= 8192):
+        return None
+    if center_label is not None and not (center_label.is_cuda and center_label.dtype == torch.float32
+                                         and center_label.is_contiguous() and center_label.dim() == 3 and center_label.size(0) == B):
+        return None
+    return _StackToBatch.apply(pf, scores, crop, bids, perm, center_label, B, K)
+
+
 class _GatherRows(Function):
     """feats[idx] whose backward is one atomic scatter-add launch (deterministic for <= 2 addends per row: the cluster
     feature gather, where a point is in at most one cluster of each of the two cluster sets)"""

@@ -276,6 +276,19 @@ class PointGroup(nn.Module):
         pf = data_dict["proposal_feats"]
         dev = pf.device
         crop = data_dict["proposal_crop_bbox"]
+        keys = ("proposal_feats_batched", "proposal_bbox_batched", "proposal_center_batched", "proposal_sem_cls_batched",
+                "proposal_scores_batched", "proposal_batch_mask")
+        perm = torch.stack([torch.randperm(K) if perms is None else perms[b].cpu() for b in range(batch_size)])   # (:251)
+        perm = _STAGE.put(perm, dev)
+        # one fill + three launches (csrc/heads.hip) when the shapes allow; the library-op form below otherwise
+        want_assign = self.cfg.general.task != "test"
+        fused = heads.stack_to_batch(pf, data_dict["proposal_objectness_scores"], crop.detach(), data_dict["proposals_batchId"],
+                                     perm, data_dict["center_label"] if want_assign else None, batch_size, K)
+        if fused is not None:
+            data_dict.update(zip(keys, fused[:6]))
+            if want_assign:
+                data_dict["object_assignment"] = fused[6]
+            return data_dict
         corners = self._box_corners(crop[:, :3].detach(), crop[:, 3:6].detach()).to(pf.dtype)
         out = {
             "proposal_feats_batched": pf.new_zeros(batch_size, K, self.cfg.model.m),
@@ -288,8 +301,6 @@ class PointGroup(nn.Module):
         # No host round trips: rank of every proposal inside its scene by a one-hot cumulative sum, the first K per
         # scene are scattered to slot inv_perm[rank] (out[b][j] = buf[perm[j]] with buf[:n] = rows, as in the reference).
         bids = data_dict["proposals_batchId"].long()
-        perm = torch.stack([torch.randperm(K) if perms is None else perms[b].cpu() for b in range(batch_size)])   # (:251)
-        perm = _STAGE.put(perm, dev)
         inv = torch.empty_like(perm).scatter_(1, perm, _const(("arange", K), dev, lambda: torch.arange(K)).expand(batch_size, K))
         onehot = torch.nn.functional.one_hot(bids, batch_size)
         rank = (onehot.cumsum(0) - onehot).gather(1, bids.view(-1, 1)).squeeze(1)
@@ -413,6 +424,7 @@ class PointGroup(nn.Module):
             scores = self.score_linear(proposals_score_feats)
             data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset)
 
+            _mark("pr_roipool_score")
             proposals_npoint = (proposals_offset[1:] - proposals_offset[:-1]).float()           # == the loop at :342-344
             sig = torch.sigmoid(scores.view(-1))
             thres_mask = torch.logical_and(sig > self.cfg.test.TEST_SCORE_THRESH,
@@ -436,6 +448,7 @@ class PointGroup(nn.Module):
                 crop[:, 7] = semantic_preds[proposals_idx[proposals_offset[:-1].long(), 1].long()].to(crop.dtype)
                 crop[:, 8] = sig
                 data_dict["proposal_crop_bbox"] = crop.index_select(0, keep)
+            _mark("pr_select")
         return data_dict
 
     def _no_proposals(self, data_dict, pt_feats):

@@ -284,6 +284,15 @@ int d3_offset_loss(const float *pt, const float *coords, const float *info, int 
  * dscore: (P) d loss / d score; out[0] = loss. */
 int d3_score_loss(const float *scores, const float *ious, int P, int nInst, float fg, float bg, float *gt_iou,
                   float *dscore, float *out, void *stream);
+/* PointGroup.convert_stack_to_batch + get_object_assignments (reference model/pointgroup.py:216-263).  Kept proposals
+ * (feats (P,m), crop (P,9): centre, size, -, semantic class, -; scores (P); bids (P) scene of each) are scattered to the
+ * padded, per-scene shuffled (B,K,.) tensors, which the caller has zeroed: slot = b*K + inv_perm[b][rank of p in b]
+ * for rank < K.  perm: (B,K) int64 permutations of 0..K-1.  slot: (P) out (-1: dropped).  assign (B,K) (optional):
+ * index of the L1-nearest row of center_label (B,G,3) for every slot.  P <= 4096, B*K <= 8192. */
+int d3_stack_to_batch(const float *feats, const float *crop, const float *scores, const int *bids, const long long *perm,
+                      const float *center_label, int G, int P, int m, int B, int K, float *feats_b, float *bbox_b,
+                      float *center_b, float *sem_b, float *scores_b, float *mask_b, long long *slot, long long *assign,
+                      void *stream);
 /* out[idx[s], :] += g[s, :] (out zero-filled by the caller): backward of the cluster feature gather
  * (model/pointgroup.py:130); deterministic when every output row receives at most two addends, as it does there */
 int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream);

@@ -135,3 +135,41 @@ def test_score_loss_matches_library(dev, P, nInst):
     assert torch.equal(gt, gt_ref)
     assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
     assert rel(ga, s2.grad) < 1e-5
+
+
+def test_stack_to_batch_matches_library_path(dev, monkeypatch):
+    """Fused convert_stack_to_batch + object assignment vs the library-op form of the same function (reference
+    model/pointgroup.py:216-263): identical tensors (pure data movement; corners in fp64 then cast), incl. scenes with
+    more than K kept proposals (the overflow is dropped) and an empty scene; gradients of the two differentiable inputs."""
+    from types import SimpleNamespace as NS
+    from d3net_amd import heads
+    from d3net_amd.pointgroup import PointGroup
+    torch.manual_seed(5)
+    B, K, m, P, G = 3, 16, 16, 41, 7
+    bids = torch.cat([torch.zeros(22), torch.full((9,), 2.0), torch.zeros(4), torch.full((6,), 2.0)]).int().to(dev)   # scene 1 empty
+    crop = torch.randn(P, 9, device=dev); crop[:, 3:6] = crop[:, 3:6].abs()
+    perms = [torch.randperm(K) for _ in range(B)]
+    fake = NS(cfg=NS(model=NS(max_num_proposal=K, m=m), general=NS(task="train")),
+              _box_corners=PointGroup._box_corners, get_object_assignments=lambda d: PointGroup.get_object_assignments(fake, d))
+
+    def run(fused):
+        pf = torch.randn(P, m, device=dev, generator=torch.Generator(dev).manual_seed(1)).requires_grad_(True)
+        sc = torch.rand(P, device=dev, generator=torch.Generator(dev).manual_seed(2)).requires_grad_(True)
+        d = {"batch_offsets": list(range(B + 1)), "proposal_feats": pf * 1.0, "proposal_crop_bbox": crop,
+             "proposals_batchId": bids, "proposal_objectness_scores": sc * 1.0,
+             "center_label": torch.randn(B, G, 3, device=dev, generator=torch.Generator(dev).manual_seed(3))}
+        if not fused:
+            monkeypatch.setattr(heads, "stack_to_batch", lambda *a, **k: None)
+        out = PointGroup.convert_stack_to_batch(fake, d, perms=perms)
+        monkeypatch.undo()
+        w1 = torch.randn(B, K, m, device=dev, generator=torch.Generator(dev).manual_seed(4))
+        w2 = torch.randn(B, K, device=dev, generator=torch.Generator(dev).manual_seed(5))
+        ((out["proposal_feats_batched"] * w1).sum() + (out["proposal_scores_batched"] * w2).sum()).backward()
+        return out, pf.grad, sc.grad
+
+    a, gpa, gsa = run(True)
+    b, gpb, gsb = run(False)
+    for k in ("proposal_feats_batched", "proposal_bbox_batched", "proposal_center_batched", "proposal_sem_cls_batched",
+              "proposal_scores_batched", "proposal_batch_mask", "object_assignment"):
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    assert a["proposal_batch_mask"].sum() == K + 15 and torch.equal(gpa, gpb) and torch.equal(gsa, gsb)

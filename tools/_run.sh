@@ -1,5 +1,3 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-python -m pytest tests/test_heads_gpu.py tests/test_pg_ops_gpu.py tests/test_pipeline_gpu.py tests/test_sparse_gpu.py -x -q -m gpu 2>&1 | tail -3
-python bench.py --steps 30 --warmup 8 2>&1 | tail -1 | cut -c1-200
-python bench.py --steps 30 --warmup 8 2>&1 | tail -1 | cut -c1-200
+python -m pytest tests/test_heads_gpu.py tests/test_map_parity_gpu.py tests/test_pipeline_gpu.py -x -q -m gpu 2>&1 | tail -15
+python3 tools/phase_times.py 12 2>&1 | grep -E "wall|pr_|proposals|loss" | tr '\n' ';'; echo
