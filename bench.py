@@ -118,7 +118,8 @@ def main():
     model = PointGroup(cfg).to(dev).train()
     model.teacher = not args.no_teacher
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay, fused=True)
+    from d3net_amd.optim import FusedAdamW
+    opt = FusedAdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)
     from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
     if world > 1:  # identical replicas
         broadcast_module(model)

@@ -15,6 +15,7 @@ class D3Error(RuntimeError):
 
 _lib = None
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+f64 = C.c_double
 pi = C.POINTER(C.c_int)
 
 # name -> (restype, argtypes); every symbol include/d3hip.h declares
@@ -73,6 +74,8 @@ SIGNATURES = {
     "d3_tall_wgrad_ws_bytes": (sz, [i32, i32]),
     "d3_tall_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "d3_stack_to_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "d3_adamw_chunk": (i32, []),
+    "d3_adamw": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, f64, vp]),
     "d3_score_loss": (i32, [vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
     "d3_offset_loss_ws_bytes": (sz, []),
     "d3_offset_loss": (i32, [vp, vp, vp, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),

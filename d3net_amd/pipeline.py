@@ -199,5 +199,9 @@ class PipelineNet(nn.Module):
     def configure_optimizers(self):
         """AdamW + StepLR(10, 0.8) over the trainable parameters (model/pipeline.py:738-757)"""
         params = [p for p in self.parameters() if p.requires_grad]
-        opt = torch.optim.AdamW(params, lr=self.cfg.train.optim.lr, weight_decay=self.cfg.train.optim.weight_decay, fused=params[0].is_cuda)
+        if params[0].is_cuda:   # one launch for all tensors (csrc/heads.hip); same update rule
+            from .optim import FusedAdamW
+            opt = FusedAdamW(params, lr=self.cfg.train.optim.lr, weight_decay=self.cfg.train.optim.weight_decay)
+        else:
+            opt = torch.optim.AdamW(params, lr=self.cfg.train.optim.lr, weight_decay=self.cfg.train.optim.weight_decay)
         return [opt], [torch.optim.lr_scheduler.StepLR(opt, step_size=10, gamma=0.8)]

@@ -293,6 +293,13 @@ int d3_stack_to_batch(const float *feats, const float *crop, const float *scores
                       const float *center_label, int G, int P, int m, int B, int K, float *feats_b, float *bbox_b,
                       float *center_b, float *sem_b, float *scores_b, float *mask_b, long long *slot, long long *assign,
                       void *stream);
+/* AdamW step (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments, no amsgrad) over a list of
+ * fp32 tensors in one launch.  ptrs: device table, 4 pointers per tensor (param, grad, exp_avg, exp_avg_sq); numel:
+ * elements per tensor; blocks: (tensor, chunk) int pairs, one per workgroup, chunk = d3_adamw_chunk() elements.
+ * The reference trains with torch.optim.Adam/AdamW through Lightning (model/pipeline.py:738-757). */
+int d3_adamw_chunk(void);
+int d3_adamw(const long long *ptrs, const int *numel, const void *blocks, int nblocks, double lr, double beta1, double beta2,
+             double eps, double weight_decay, double bias_correction1, double bias_correction2_sqrt, void *stream);
 /* out[idx[s], :] += g[s, :] (out zero-filled by the caller): backward of the cluster feature gather
  * (model/pointgroup.py:130); deterministic when every output row receives at most two addends, as it does there */
 int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream);

@@ -173,3 +173,28 @@ def test_stack_to_batch_matches_library_path(dev, monkeypatch):
               "proposal_scores_batched", "proposal_batch_mask", "object_assignment"):
         assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
     assert a["proposal_batch_mask"].sum() == K + 15 and torch.equal(gpa, gpb) and torch.equal(gsa, gsb)
+
+
+def test_fused_adamw_matches_torch(dev):
+    """Single-launch AdamW vs torch.optim.AdamW over 5 steps on tensors of assorted sizes (one spanning several chunks, one
+    of a single element, one whose gradient tensor is replaced mid-run): parameters and moments within 1e-6 relative."""
+    from d3net_amd.optim import FusedAdamW
+    torch.manual_seed(11)
+    shapes = [(27, 16, 32), (1,), (5000, 3), (112,), (3, 3, 3, 48, 48)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdamW(pa, lr=2e-3, weight_decay=0.05)
+    ob = torch.optim.AdamW(pb, lr=2e-3, weight_decay=0.05)
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a)
+            if a.grad is None or (it == 3 and a.numel() == 112):
+                a.grad = g.clone()          # (a replaced gradient tensor: the pointer table is rebuilt)
+            else:
+                a.grad.copy_(g)
+            b.grad = g.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert rel(a.detach(), b.detach()) < 1e-6
+        assert rel(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-6
+        assert rel(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6

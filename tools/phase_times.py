@@ -19,7 +19,8 @@ cfg = default_conf()
 torch.manual_seed(123)
 model = PG.PointGroup(cfg).to(dev).train()
 model.teacher = True
-opt = torch.optim.AdamW(model.parameters(), lr=0.002, fused=True)
+from d3net_amd.optim import FusedAdamW
+opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=0.002)
 occ, sem, inst, _ = S.occupancy_grid()
 batch = S.make_batch([S.scene_from_grid(occ, sem, inst)], dev)
 
