@@ -152,10 +152,11 @@ __device__ __forceinline__ int cl_chase(const int *lab, int l) {
 // phase 1b: push labels over all edges; root[] == parent[] after flatten
 __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                      const int *__restrict__ start_len, int n,
-                                                     const int *__restrict__ root, int *lab, int *scalars) {
+                                                     const int *__restrict__ root, int *lab, int *changed_flag,
+                                                     const int *__restrict__ capped_flag) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
-    if (scalars[3] == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
+    if (*capped_flag == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     const int si = sem[i];
     const int ri = root[i];
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
             if (ld_dev(&lab[rj[q]]) > li) { if (atomicMin(&lab[rj[q]], li) > li) changed = true; }
         }
     }
-    if (__any(changed) && d3_lane() == 0) scalars[0] = 1;
+    if (__any(changed) && d3_lane() == 0) *changed_flag = 1;
 }
 
 __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *sizes, int n) {
@@ -224,13 +225,17 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
-    for (int it = 0; it < n + 2; it++) {
+    // label pushes in pairs per host round trip: the usual case is one productive sweep plus the sweep that finds nothing
+    // left to do, and the second one reports through its own flag (scalars[4]) so both are read back together
+    for (int it = 0; it < n + 2; it += 2) {
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars);
-        int changed = 0;
-        D3_CHECK(hipMemcpyAsync(&changed, w.scalars, sizeof(int), hipMemcpyDeviceToHost, s));
+        D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars, w.scalars + 3);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars + 4, w.scalars + 3);
+        int changed[5] = {0, 0, 0, 0, 0};
+        D3_CHECK(hipMemcpyAsync(changed, w.scalars, sizeof(changed), hipMemcpyDeviceToHost, s));
         D3_CHECK(hipStreamSynchronize(s));
-        if (!changed) break;
+        if (!changed[0] || !changed[4]) break;
     }
     cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
     cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);

@@ -1,1 +1,5 @@
-python -m pytest tests/test_heads_gpu.py -x -q -m gpu -k "adamw" 2>&1 | tail -2
+python3 tools/step_jitter.py 80
+python3 tools/step_jitter.py 80 0.005 off
+python3 tools/step_jitter.py 80 0.0002
+python3 tools/step_jitter.py 80 0.0002 off
+python3 tools/step_jitter.py 80
