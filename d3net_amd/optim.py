@@ -3,9 +3,12 @@
 Same update as `torch.optim.AdamW` (decoupled weight decay, bias-corrected moments, no amsgrad / maximize), which the
 reference configures through Lightning (model/pipeline.py:738-757); `torch.optim.AdamW(fused=True)` issues one
 multi-tensor launch per ~30 tensors (8 launches, 0.27 ms for the detector's ~300 tensors), this one issues one.
-A device table of (param, grad, exp_avg, exp_avg_sq) pointers is kept per group and rebuilt only when a gradient tensor
-was replaced (the native U-Net executor keeps its flat gradient buffer, so in steady state it never is)."""
+A device table of (param, grad, exp_avg, exp_avg_sq) pointers is kept per group.  Per step the host only collects the
+gradient addresses (the native U-Net executor keeps its flat gradient buffer, the few head gradients are re-allocated by
+`zero_grad(set_to_none=True)`); when any of them moved, the address column is refreshed through a pinned staging buffer
+(one asynchronous 10 KB copy, no synchronisation)."""
 import math
+import operator
 
 import numpy as np
 import torch
@@ -14,22 +17,25 @@ from . import _lib
 from ._lib import check
 
 
+_DATA_PTR = operator.methodcaller("data_ptr")
+_GRAD = operator.attrgetter("grad")
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
 
-    def _table(self, gi, group):
-        plist = [p for p in group["params"] if p.grad is not None]
-        grads = [p.grad for p in plist]
-        tb = self._tables.get(gi)
-        if tb is not None and len(tb["grads"]) == len(grads) and all(a is b for a, b in zip(tb["grads"], grads)) \
-                and all(a is b for a, b in zip(tb["params"], plist)):
-            return tb
+    @staticmethod
+    def _validate(p):
+        g = p.grad
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
+                and g.dtype == torch.float32 and not g.is_sparse and g.device == p.device):
+            raise RuntimeError("FusedAdamW: contiguous fp32 device parameters and gradients only")
+
+    def _build(self, gi, plist):
         for p in plist:
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
-                    and p.grad.dtype == torch.float32 and not p.grad.is_sparse):
-                raise RuntimeError("FusedAdamW: contiguous fp32 device parameters and gradients only")
+            self._validate(p)
         dev = plist[0].device
         fresh = [p for p in plist if "exp_avg" not in self.state[p]]
         if fresh:   # moments of the tensors seen for the first time: one flat buffer
@@ -41,14 +47,45 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.state[p]["exp_avg_sq"] = flat[o + n:o + 2 * n].view_as(p)
                 o += 2 * n
         chunk = _lib.lib().d3_adamw_chunk()
-        ptrs = np.array([[p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
-                          self.state[p]["exp_avg_sq"].data_ptr()] for p in plist], dtype=np.int64)
+        host = torch.empty((len(plist), 4), dtype=torch.int64).pin_memory()
+        hv = host.numpy()
+        hv[:, 0] = [p.data_ptr() for p in plist]
+        hv[:, 1] = [p.grad.data_ptr() for p in plist]
+        hv[:, 2] = [self.state[p]["exp_avg"].data_ptr() for p in plist]
+        hv[:, 3] = [self.state[p]["exp_avg_sq"].data_ptr() for p in plist]
         numel = np.array([p.numel() for p in plist], dtype=np.int32)
         blocks = np.array([(t, c) for t, n in enumerate(numel) for c in range((int(n) + chunk - 1) // chunk)], dtype=np.int32)
-        tb = {"grads": grads, "params": plist, "nblocks": int(blocks.shape[0]),
-              "ptrs": torch.from_numpy(ptrs).to(dev), "numel": torch.from_numpy(numel).to(dev),
+        tb = {"pptr": [p.data_ptr() for p in plist], "gptr": hv[:, 1].tolist(), "host": host,
+              "nblocks": int(blocks.shape[0]), "ptrs": host.to(dev), "numel": torch.from_numpy(numel).to(dev),
               "blocks": torch.from_numpy(blocks.reshape(-1)).to(dev), "device": dev}
         self._tables[gi] = tb
+        return tb
+
+    def _table(self, gi, group):
+        tb = self._tables.get(gi)
+        params = group["params"]
+        if tb is not None and len(tb["plist"]) <= len(params):
+            plist = tb["plist"]
+            try:
+                gptr = list(map(_DATA_PTR, map(_GRAD, plist)))
+            except AttributeError:          # a gradient went missing: rebuild over the tensors that have one
+                gptr = None
+            if gptr is not None and tb["ngrad"] == sum(1 for p in params if p.grad is not None) \
+                    and tb["pptr"] == list(map(_DATA_PTR, plist)):
+                if gptr != tb["gptr"]:   # some gradients were re-allocated: refresh their addresses (asynchronous, stream ordered)
+                    for i, (a, b) in enumerate(zip(gptr, tb["gptr"])):
+                        if a != b:
+                            self._validate(plist[i])
+                    tb["host"].numpy()[:, 1] = gptr
+                    tb["ptrs"].copy_(tb["host"], non_blocking=True)
+                    tb["gptr"] = gptr
+                return tb
+        plist = [p for p in params if p.grad is not None]
+        if not plist:
+            return {"nblocks": 0, "plist": [], "ngrad": -1}
+        tb = self._build(gi, plist)
+        tb["plist"] = plist
+        tb["ngrad"] = len(plist)
         return tb
 
     @torch.no_grad()
@@ -59,14 +96,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         L = _lib.lib()
         for gi, group in enumerate(self.param_groups):
-            if not any(p.grad is not None for p in group["params"]):
-                continue
             tb = self._table(gi, group)
+            if tb["nblocks"] == 0:
+                continue
             group["step"] = t = int(group.get("step", 0)) + 1
             b1, b2 = group["betas"]
             with torch.cuda.device(tb["device"]):
                 check(L.d3_adamw(tb["ptrs"].data_ptr(), tb["numel"].data_ptr(), tb["blocks"].data_ptr(), tb["nblocks"],
                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t),
-                                 torch.cuda.current_stream().cuda_stream), "adamw")
+                                 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), torch.cuda.current_stream().cuda_stream), "adamw")
         return loss
