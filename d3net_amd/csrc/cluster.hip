@@ -225,29 +225,28 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
-    // label pushes in pairs per host round trip: the usual case is one productive sweep plus the sweep that finds nothing
-    // left to do, and the second one reports through its own flag (scalars[4]) so both are read back together
-    for (int it = 0; it < n + 2; it += 2) {
+    // Label pushes in pairs, and the sizes / ids / offsets computed right behind them, all read back with ONE host round
+    // trip: the usual case is one productive sweep plus the sweep that finds nothing left to do (the second one reports
+    // through its own flag, scalars[4]); only when both sweeps still changed labels is the tail recomputed after more.
+    int h[5] = {0, 0, 0, 0, 0};
+    for (int it = 0;; it += 2) {
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
         cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars, w.scalars + 3);
         cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars + 4, w.scalars + 3);
-        int changed[5] = {0, 0, 0, 0, 0};
-        D3_CHECK(hipMemcpyAsync(changed, w.scalars, sizeof(changed), hipMemcpyDeviceToHost, s));
+        if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
+        cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
+        cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);
+        int rc = d3_exclusive_scan_i32(w.flag, w.cid, n, w.temp, w.temp_bytes, s);
+        if (rc) return rc;
+        rc = d3_exclusive_scan_i32(w.ksz, w.koff, n, w.temp, w.temp_bytes, s);
+        if (rc) return rc;
+        cl_totals_kernel<<<1, 64, 0, s>>>(w.flag, w.cid, w.ksz, w.koff, n, w.scalars);
+        D3_LAUNCH_CHECK();
+        D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
         D3_CHECK(hipStreamSynchronize(s));
-        if (!changed[0] || !changed[4]) break;
+        if (!h[0] || !h[4] || it >= n + 2) break;
     }
-    cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
-    cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);
-    int rc = d3_exclusive_scan_i32(w.flag, w.cid, n, w.temp, w.temp_bytes, s);
-    if (rc) return rc;
-    rc = d3_exclusive_scan_i32(w.ksz, w.koff, n, w.temp, w.temp_bytes, s);
-    if (rc) return rc;
-    cl_totals_kernel<<<1, 64, 0, s>>>(w.flag, w.cid, w.ksz, w.koff, n, w.scalars);
-    D3_LAUNCH_CHECK();
-    int h[3];
-    D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
-    D3_CHECK(hipStreamSynchronize(s));
     *nCluster_host = h[1];
     *sumNPoint_host = h[2];
     return 0;
