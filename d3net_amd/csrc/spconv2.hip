@@ -781,7 +781,9 @@ extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, 
 #ifndef WG2_PART_MB
 #define WG2_PART_MB 8         // cap of the partial-dW buffer
 #endif
+#ifndef WG2_T
 #define WG2_T 16        // accumulator tiles per wave (64 AGPRs): occupancy matters more than reuse here
+#endif
 
 struct Wg2Args {
     const void *G; const void *Sm; const int *tbl; float *dst;
@@ -808,7 +810,7 @@ __device__ __forceinline__ void wg2_store_t(unsigned short *T, int c8, int row, 
 }
 
 template <int TPO, int NU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NU <= 2 ? 3 : NU <= 7 ? 2 : 1, 8))) void spconv_wgrad2_kernel(const Wg2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 ? (NU <= 7 ? 2 : 1) : (NU <= 2 ? 3 : NU <= 7 ? 2 : 1), 8))) void spconv_wgrad2_kernel(const Wg2Args a) {
     constexpr int OPW = WG2_T / TPO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;

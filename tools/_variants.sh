@@ -1,18 +1,18 @@
 export TMPDIR=/tmp
-for v in "-DB2_TIMING" "-DB2_HGRID=16" "-DB2_HGRID=32" "-DB2_HGRID=16 -DB2_EPT=2" "-DB2_HGRID=16 -DB2_EPT=4"; do
-  rm -f d3net_amd/build/cluster.o*
+for v in "-DWG2_T=16" "-DWG2_T=32"; do
+  rm -f d3net_amd/build/spconv2.o*
   D3_CXX_EXTRA="$v" python -m d3net_amd.build > /dev/null 2>&1
   echo "=== variant [$v]"
-  if [ "$v" = "-DB2_TIMING" ]; then
-    D3_BFS_DEBUG=1 timeout 300 python3 tools/phase_times.py 2 2>&1 | grep "bfs2 cluster" | sort -k7 -n -r | head -3
-    continue
-  fi
+  timeout 300 python -m pytest tests/test_sparse_gpu.py -x -q -m gpu -k "wgrad or executor or native" 2>&1 | tail -1
   rm -rf /tmp/pp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python3 tools/phase_times.py 4 > /dev/null 2>&1
-  python -c "
+  python3 - <<PY
 import csv,glob
+t=0
 for r in csv.DictReader(open(glob.glob('/tmp/pp/**/*kernel_stats.csv',recursive=True)[0])):
-    if r['Name'].startswith('cl_bfs2'): print(r['Calls'], r['AverageNs'])
-"
-  timeout 200 python -m pytest tests/test_pg_ops_gpu.py -x -q -k "bfs or cluster" 2>&1 | tail -1
+    if 'wgrad2_kernel' in r['Name']:
+        t+=float(r['TotalDurationNs']); print('  ',r['Name'][5:36], r['Calls'], '%.1f'%(float(r['AverageNs'])/1e3))
+print('  wgrad total ms/8 steps', t/1e6)
+PY
+  python3 tools/phase_times.py 12 2>&1 | grep -E "wall|backward" | tr '\n' ';'; echo
 done
-rm -f d3net_amd/build/cluster.o*
+rm -f d3net_amd/build/spconv2.o*
