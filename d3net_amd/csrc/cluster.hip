@@ -569,6 +569,9 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     }
     __syncthreads();
     int lo = 0, hi = 1, cur = 0, phase = 0;
+    // Prefetch of the next level's records: a winner touches the first lines of its own list as soon as it knows it has
+    // won, so that the lines travel to this XCD's L2 while the level finishes (rank scan, enqueue, barriers) and the
+    // next level's record loads hit near.  (The loaded values are never used.)
     bool hints_ok = false;                             // hint[cur] covers every B2_EPT-th edge of this level
     while (lo < hi && hi <= size) {
         const bool small = (hi - lo) <= B2_FMAX;      // the frontier's list extents are already in LDS
@@ -675,6 +678,19 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                 for (int r = 0; r < B2_EPT; r++) {
                     if (cand[r] && hval[slot[r]] == tid * B2_EPT + r) { win |= 1u << r; nwin++; lwin += rec[r].w; }
                 }
+#ifndef B2_NO_PREFETCH
+                // (inline asm: written as C++ loads the compiler merges the non-winner addresses and waits on each value)
+                int pf0[B2_EPT], pf1[B2_EPT], pf2[B2_EPT];
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) {                // a non-winner touches the first record (always valid)
+                    const bool wn = (win >> r) & 1u;
+                    const int *q0 = (const int *)(erec + (wn ? rec[r].z : 0));   // 8 records per 128-byte line
+                    const int *q1 = q0 + ((wn && rec[r].w > 8) ? 32 : 0), *q2 = q0 + ((wn && rec[r].w > 16) ? 64 : 0);
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf0[r]) : "v"(q0) : "memory");
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf1[r]) : "v"(q1) : "memory");
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf2[r]) : "v"(q2) : "memory");
+                }
+#endif
                 int pos, lpos, tot, ltot;
                 b2_scan2(nwin, lwin, s_w, phase, pos, lpos, tot, ltot);   // (its barrier: every hval read is done)
                 B2_TICK(5)
@@ -700,6 +716,11 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                 }
                 tail += tot; ltail += ltot;
                 if (tid == 0 && tail - hi <= B2_FMAX) noff[tail - hi] = ltail;   // closes the prefix (rewritten per batch)
+#ifndef B2_NO_PREFETCH
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetch registers are free again only now
+#pragma unroll
+                for (int r = 0; r < B2_EPT; r++) asm volatile("" :: "v"(pf0[r]), "v"(pf1[r]), "v"(pf2[r]));
+#endif
                 b2_barrier();
                 B2_TICK(6)
                 n_batches++;
