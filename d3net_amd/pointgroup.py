@@ -435,12 +435,15 @@ class PointGroup(nn.Module):
             # NOTE the reference reads the one-short batch-id vector at the cluster starts (:349); cluster starts of
             # the shifted set therefore read element start+1 of that set -- same cluster, same batch id.
             starts = proposals_offset[:-1].long().clamp(max=max(proposals_batchId_all.numel() - 1, 0))
+            _mark("pr_mask")
             keep = torch.nonzero(thres_mask).squeeze(1)    # one host round trip for the four selections below
+            _mark("pr_nonzero")
             proposals_batchId = proposals_batchId_all[starts].index_select(0, keep)
             data_dict["proposals_batchId"] = proposals_batchId
             data_dict["proposal_feats"] = proposals_score_feats.index_select(0, keep)
             data_dict["proposal_objectness_scores"] = sig.index_select(0, keep)
 
+            _mark("pr_index")
             if self.cfg.model.crop_bbox:
                 crop = scores.new_zeros(num_proposals, 9)
                 crop[:, :3] = proposals_center

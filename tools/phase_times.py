@@ -18,7 +18,7 @@ torch.cuda.set_device(0)
 cfg = default_conf()
 torch.manual_seed(123)
 model = PG.PointGroup(cfg).to(dev).train()
-model.teacher = True
+model.teacher = os.environ.get("D3_TEACHER", "1") != "0"
 from d3net_amd.optim import FusedAdamW
 opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=0.002)
 occ, sem, inst, _ = S.occupancy_grid()
