@@ -1,1 +1,2 @@
-D3_DBG=1 D3_TEACHER=0 python3 tools/phase_times.py 4 2>&1 | grep DBG | tail -5
+python -m pytest tests/test_sparse_gpu.py -x -q -m gpu 2>&1 | tail -2
+for v in 0 1 0 1; do echo "fuse_small=$v"; D3_FUSE_SMALL_BN=$v python3 tools/step_jitter.py 80; done
