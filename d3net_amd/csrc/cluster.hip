@@ -46,6 +46,8 @@ struct ClWs {
     int *par;      // n  BFS: queue position of the first discoverer
     int *queue;    // n  BFS queues (cluster c at koff[seed])
     int *fcnt;     // n  BFS: list start of every queued node
+    int *klen;     // n  list length of a node of a kept cluster, else 0
+    int *estart;   // n  exclusive scan of klen: the node's list start in the (compact) record array
     int *qln;      // n  BFS: list length of every queued node
     int *lid;      // n  BFS (record kernel): dense id of a node inside its cluster (any bijection)
     int *lcnt;     // n  per-owner counter behind lid
@@ -61,6 +63,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
     w.seeds = c.take<int>(nn); w.par = c.take<int>(nn); w.queue = c.take<int>(nn); w.fcnt = c.take<int>(nn);
     w.qln = c.take<int>(nn);
     w.lid = c.take<int>(nn); w.lcnt = c.take<int>(nn);
+    w.klen = c.take<int>(nn); w.estart = c.take<int>(nn);
     w.scalars = c.take<int>(64);
     w.temp_bytes = d3_scan_temp_bytes(n);
     w.temp = c.take<char>(w.temp_bytes);
@@ -69,7 +72,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
 extern "C" size_t d3_bfs_cluster_ws_bytes(int n) {
     D3Carver c(nullptr, 0);
     size_t nn = (size_t)(n > 0 ? n : 1);
-    for (int i = 0; i < 15; i++) c.take<int>(nn);
+    for (int i = 0; i < 17; i++) c.take<int>(nn);
     c.take<int>(64);
     c.take<char>(d3_scan_temp_bytes(n));
     return c.off + 256;
@@ -89,10 +92,13 @@ __global__ void cl_init_kernel(int *parent, int *lab, int *sizes, int *par, int 
     if (i < 8) scalars[i] = 0;
 }
 
+// Reads go through the cache: parent pointers only ever move to smaller ancestors, so a stale value is still an
+// ancestor (the walk just takes an older path), and a stale "root" is caught by the atomicMin in cl_union, which
+// returns the current parent.  L2-bypassing loads here made the walk a chain of memory-side round trips.
 __device__ __forceinline__ int cl_find(int *parent, int x) {
-    int p = ld_dev(&parent[x]);
+    int p = parent[x];
     while (p != x) {
-        int gp = ld_dev(&parent[p]);
+        int gp = parent[p];
         if (gp != p) atomicMin(&parent[x], gp);  // path halving; only ever lowers towards an ancestor
         x = p; p = gp;
     }
@@ -175,7 +181,10 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (!ok[q] || rj[q] == ri) continue;
-            if (ld_dev(&lab[rj[q]]) > li) { if (atomicMin(&lab[rj[q]], li) > li) changed = true; }
+            // The filter reads through the cache: labels only ever decrease, so a stale (larger) value can at worst let an
+            // atomicMin through that changes nothing -- it can never hide a needed update.  (An L2-bypassing load here,
+            // once per edge of a capped list, was most of this kernel's time.)
+            if (lab[rj[q]] > li) { if (atomicMin(&lab[rj[q]], li) > li) changed = true; }
         }
     }
     if (__any(changed) && d3_lane() == 0) *changed_flag = 1;
@@ -449,11 +458,13 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
 #define B2_MAXSIZE (B2_BITWORDS * 32)
 #define B2_LDS_INTS (B2_BITWORDS + 2 * B2_HASH + 2 * B2_FMAX + 2 * (B2_FMAX + 8) + B2_HINTS + 160)
 
-__global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, int *lcnt, int *lid, int n) {
+__global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, const int *__restrict__ start_len,
+                              int *lcnt, int *lid, int *klen, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;   // tail lanes simply drop out of the ballots below
     const int o = own[i];
     const bool kept = flag[o] != 0;
+    klen[i] = kept ? start_len[i * 2 + 1] : 0;
     // a wave holds only a few distinct owners: one atomic per distinct owner (leader = lowest lane of each group);
     // one atomic per NODE serialises tens of thousands of updates of the same counter in L2
     int id = -1;
@@ -472,19 +483,24 @@ __global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict
     lid[i] = id;
 }
 // one wave per node of a kept cluster: its list -> edge records
+// The records are COMPACT whatever the layout of idx (the padded ball query gives every node a 1000-entry slot: records at
+// the same sparse positions cost 4x the write time and scatter the BFS's loads over 16 KB strides): node i's records
+// start at estart[i], the exclusive scan of the kept nodes' list lengths, and a record carries its target's estart.
 __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
                                                      const int *__restrict__ own, const int *__restrict__ flag,
-                                                     const int *__restrict__ lid, int4 *__restrict__ erec, int n) {
+                                                     const int *__restrict__ lid, const int *__restrict__ estart,
+                                                     int4 *__restrict__ erec, int n) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
     const int oi = own[i];
     if (!flag[oi]) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    const long long es = estart[i];
     for (int e = d3_lane(); e < ln; e += 64) {
         const int j = idx[st + e];
         int4 r = make_int4(-1, 0, 0, 0);
-        if (own[j] == oi) { const int2 sl = *(const int2 *)&start_len[j * 2]; r = make_int4(j, lid[j], sl.x, sl.y); }
-        erec[st + e] = r;
+        if (own[j] == oi) r = make_int4(j, lid[j], estart[j], start_len[j * 2 + 1]);
+        erec[es + e] = r;
     }
 }
 
@@ -538,6 +554,7 @@ __device__ __forceinline__ void b2_scan2(int v0, int v1, int *wsum, int &phase, 
 //     the frontier node of its first edge with one LDS read and a step or two instead of a binary search;
 //   * the scan needs one barrier (b2_scan2), a batch three in total.
 __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restrict__ erec, const int *__restrict__ start_len,
+                                                            const int *__restrict__ estart,
                                                             const int *__restrict__ lid, const int *__restrict__ seeds,
                                                             const int *__restrict__ koff, const int *__restrict__ sizes,
                                                             int *qst_all, int *qln_all, int *cluster_idxs, int *dbg) {
@@ -564,7 +581,7 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     if (tid == 0) {
         const int ls = lid[s];
         bitmap[ls >> 5] = 1u << (ls & 31);
-        fst[0] = start_len[s * 2]; foff[0] = 0; foff[1] = start_len[s * 2 + 1];
+        fst[0] = estart[s]; foff[0] = 0; foff[1] = start_len[s * 2 + 1];
         cluster_idxs[(size_t)base * 2] = c; cluster_idxs[(size_t)base * 2 + 1] = s;
     }
     __syncthreads();
@@ -762,10 +779,12 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
             attr_done = true;
         }
         D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
-        cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, w.lcnt, w.lid, n);
-        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.lid, (int4 *)erec, n);
+        cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, start_len, w.lcnt, w.lid, w.klen, n);
+        int rc = d3_exclusive_scan_i32(w.klen, w.estart, n, w.temp, w.temp_bytes, s);
+        if (rc) return rc;
+        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.lid, w.estart, (int4 *)erec, n);
         const bool debug = getenv("D3_BFS_DEBUG") != nullptr;
-        cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.lid, w.seeds, w.koff, w.sizes,
+        cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
                                                         w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
         if (debug) {
             int h[60 + 160];
