@@ -86,9 +86,9 @@ __device__ __forceinline__ void st_dev(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void cl_init_kernel(int *parent, int *lab, int *sizes, int *par, int n, int *scalars) {
+__global__ void cl_init_kernel(int *parent, int *lab, int *sizes, int *par, int *pushed, int n, int *scalars) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { parent[i] = i; lab[i] = i; sizes[i] = 0; par[i] = CL_INF; }
+    if (i < n) { parent[i] = i; lab[i] = i; sizes[i] = 0; par[i] = CL_INF; pushed[i] = CL_INF; }
     if (i < 8) scalars[i] = 0;
 }
 
@@ -99,7 +99,8 @@ __device__ __forceinline__ int cl_find(int *parent, int x) {
     int p = parent[x];
     while (p != x) {
         int gp = parent[p];
-        if (gp != p) atomicMin(&parent[x], gp);  // path halving; only ever lowers towards an ancestor
+        if (gp != p) parent[x] = gp;  // path halving: any value ever stored in parent[x] is an ancestor of x, and x is not a
+                                      // root here, so a plain (racy) store can only trade one valid ancestor for another
         x = p; p = gp;
     }
     return x;
@@ -158,8 +159,8 @@ __device__ __forceinline__ int cl_chase(const int *lab, int l) {
 // phase 1b: push labels over all edges; root[] == parent[] after flatten
 __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                      const int *__restrict__ start_len, int n,
-                                                     const int *__restrict__ root, int *lab, int *changed_flag,
-                                                     const int *__restrict__ capped_flag) {
+                                                     const int *__restrict__ root, int *lab, int *pushed,
+                                                     int *changed_flag, const int *__restrict__ capped_flag) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
     if (*capped_flag == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
@@ -168,6 +169,11 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
     const int ri = root[i];
     const int li = cl_chase(lab, ld_dev(&lab[ri]));
     if (li < ld_dev(&lab[ri])) atomicMin(&lab[ri], li);
+    // Worklist: a node pushes again only when its own label got smaller since its last push -- every neighbour's label
+    // was <= that value then and labels only decrease.  The verification sweep therefore walks only the lists of the
+    // nodes the previous sweep changed (the first 1000 points of a collapsed instance, not all of them).
+    if (pushed[i] == li) return;          // (one wave per node: uniform)
+    if (d3_lane() == 0) pushed[i] = li;
     bool changed = false;
     // four edges per lane in flight: every edge is a chain of three dependent gathers (neighbour id -> its root ->
     // the root's label) and a capped list is 16 passes long
@@ -230,7 +236,7 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
-    cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, n, w.scalars);
+    cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, n, w.scalars);   // (klen: scratch until the fill)
     cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
@@ -241,8 +247,8 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     for (int it = 0;; it += 2) {
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars, w.scalars + 3);
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.scalars + 4, w.scalars + 3);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars + 4, w.scalars + 3);
         if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
         cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
         cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);

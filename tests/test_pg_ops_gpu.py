@@ -228,6 +228,28 @@ def test_bfs_cluster_truncated_lists(dev):
     assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
 
 
+@pytest.mark.parametrize("order", ["forward", "reverse", "shuffled"])
+def test_bfs_cluster_capped_chain(dev, order):
+    """A chain of dense blobs, every list capped at 1000: the labels travel blob to blob, so the label push needs
+    several sweeps (worklist, paired sweeps per host round trip) -- in three index orders."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(83)
+    nb, per = 7, 1300
+    xyz = np.concatenate([rng.normal(0, 0.004, (per, 3)).astype(np.float32) + np.array([0.02 * k, 0, 0], np.float32) for k in range(nb)])
+    n = xyz.shape[0]
+    if order == "reverse":
+        xyz = xyz[::-1].copy()
+    elif order == "shuffled":
+        xyz = xyz[rng.permutation(n)]
+    sem = np.ones(n, np.int32)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
+    assert (sl[:, 1] >= 1000).sum() > n // 2
+    rci, rco = o.bfs_cluster(sem, idx, sl, 10)
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 10)
+    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+
+
 def test_bfs_cluster_no_clusters(dev):
     from d3net_amd import pointgroup_ops as P
     sem = np.array([1, 2, 3], np.int32); idx = np.array([0, 1, 2], np.int32)
