@@ -149,9 +149,14 @@ def main():
     for _ in range(args.warmup):
         loss, d = step()
     torch.cuda.synchronize()
+    # the interpreter's cyclic collector: a full (generation-2) pass every ~26 steps walks the whole module / tensor heap
+    # (2-7 ms each, tools/step_jitter.py); freezing the long-lived objects after warm-up keeps those passes short
+    import gc
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
-    PROF_STRIDE = 7   # every 7th convolution launch is bracketed by HIP events (coprime with the launches per step)
+    PROF_STRIDE = 13   # every 13th convolution launch is bracketed by HIP events (coprime with the 257 launches per step)
     L.d3_prof_enable(PROF_STRIDE)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -1,7 +1,6 @@
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-python3 tools/phase_times.py 12 2>&1 | grep " ms" | tr '\n' ';'; echo
-rm -rf /tmp/pp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python3 tools/phase_times.py 4 > gpurun_out/phase.log 2>&1
-cp $(find /tmp/pp -name "*kernel_stats.csv") gpurun_out/stats.csv
-python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-200
-python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-200
+python bench.py --steps 60 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-200
+python bench.py --steps 60 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-200
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read()); r = d['roofline']
+print(d['ms_per_step'], r['kernel'], r['launches_sampled'], round(r['achieved'], 1), round(r['avg_launch_us'], 1), {k: (v['launches_per_step'], round(v['avg_launch_us'], 1)) for k, v in r['other'].items()})"
