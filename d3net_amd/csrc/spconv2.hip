@@ -885,7 +885,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // offsets in groups of PF: the gathers of a group are issued together (memory-level parallelism -- every
         // offset is one dependent LDS -> L2/HBM -> LDS -> MFMA chain, and the MFMA work per offset is tiny)
-        constexpr int PF = NU == 1 ? 4 : NU == 2 ? 2 : 1;
+#ifndef WG2_PF1
+#define WG2_PF1 4
+#endif
+#ifndef WG2_PF2
+#define WG2_PF2 2
+#endif
+        constexpr int PF = NU == 1 ? WG2_PF1 : NU == 2 ? WG2_PF2 : 1;
         uint4 pre[PF][NU];
         bool pre_any[PF];
 #pragma unroll
