@@ -1,6 +1,5 @@
-python bench.py --steps 60 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-200
-python bench.py --steps 60 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-200
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read()); r = d['roofline']
-print(d['ms_per_step'], r['kernel'], r['launches_sampled'], round(r['achieved'], 1), round(r['avg_launch_us'], 1), {k: (v['launches_per_step'], round(v['avg_launch_us'], 1)) for k, v in r['other'].items()})"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -rf /tmp/pq; timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d /tmp/pq -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_sq.log 2>&1
+python tools/pmc_summary.py $(find /tmp/pq -name "*counter_collection.csv") > gpurun_out/pmc_sq.csv
+wc -l gpurun_out/pmc_sq.csv; tail -3 gpurun_out/pmc_sq.log
