@@ -201,11 +201,17 @@ __device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
 // B = gathered rows), so a lane ends up with 4 consecutive output channels of one row: the tile is stored (and the
 // residual read) as one contiguous float4 per lane instead of four 64-byte row fragments.
 // (fp32 gathers hold twice the registers of bf16 ones until they are converted: one occupancy step less)
-#define C2_OCC(NTV, XB) ((NTV) <= 4 ? ((XB) ? C2_OCC_SMALL : C2_OCC_SMALL - 1) : (NTV) <= 9 ? ((XB) ? 3 : 2) : 2)
+#ifndef C2_F32_U
+#define C2_F32_U 8          // gathers per batch of the fp32-input variants with <= 2 column tiles (experiments: 4 with C2_F32_OCCDROP 0)
+#endif
+#ifndef C2_F32_OCCDROP
+#define C2_F32_OCCDROP 1
+#endif
+#define C2_OCC(NTV, XB) ((NTV) <= 4 ? ((XB) ? C2_OCC_SMALL : C2_OCC_SMALL - C2_F32_OCCDROP) : (NTV) <= 9 ? ((XB) ? 3 : 2) : 2)
 template <int NT, bool WLDS, bool XBF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, XBF), 8))) void spconv_fwd2_kernel(const Conv2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int U = C2_U(NT);
+    constexpr int U = (!XBF && NT <= 2) ? C2_F32_U : C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int K = a.K, S = a.S;
     const size_t wbytes = WLDS ? (size_t)K * S * NT * 256 : 0;
