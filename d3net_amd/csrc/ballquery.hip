@@ -140,6 +140,9 @@ __device__ __forceinline__ bool bq_box_near(float ox, float oy, float oz, const 
 
 // MODE 0: count; 1: fill idx at the scanned starts; 2: count AND stash the hits at stash[q*BQ_CAP + pos] (single pass:
 // the fill then only compacts the stash instead of repeating the search)
+#ifndef BQ_NB
+#define BQ_NB 4     // candidate chunks whose points are requested together
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ xyz,
                                                      const int *__restrict__ batch_idxs,
@@ -176,14 +179,14 @@ __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ 
             const bool crange = (c >= c_first) && (c <= c_last);
             const bool pass = bq_box_near(ox, oy, oz, clo, chi, crange ? c : c_first, rc) && crange;
             unsigned long long cm = __ballot(pass);
-            // four candidate chunks per round trip: their points are requested together (branch-free addresses: a
+            // BQ_NB candidate chunks per round trip: their points are requested together (branch-free addresses: a
             // branch between the loads would make each one wait for the previous), then tested in chunk order
             while (cm != 0ull && cnt < BQ_CAP) {
-                int kk[4];
-                bool in[4], valid[4];
-                float x[4], y[4], z[4];
+                int kk[BQ_NB];
+                bool in[BQ_NB], valid[BQ_NB];
+                float x[BQ_NB], y[BQ_NB], z[BQ_NB];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < BQ_NB; j++) {
                     valid[j] = cm != 0ull;
                     const int cc = sc * BQ_SUPER + (valid[j] ? (int)__builtin_ctzll(cm) : 0);
                     if (valid[j]) cm &= cm - 1ull;
@@ -191,12 +194,12 @@ __global__ __launch_bounds__(256) void bq_scan_kernel(const float *__restrict__ 
                     in[j] = valid[j] && kk[j] >= start && kk[j] < end;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < BQ_NB; j++) {
                     const int ka = in[j] ? kk[j] : q;
                     x[j] = xyz[ka * 3 + 0]; y[j] = xyz[ka * 3 + 1]; z[j] = xyz[ka * 3 + 2];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < BQ_NB; j++) {
                     if (!valid[j] || cnt >= BQ_CAP) continue;   // wave-uniform
                     const float dx = __fsub_rn(ox, x[j]), dy = __fsub_rn(oy, y[j]), dz = __fsub_rn(oz, z[j]);
                     // ((dx*dx + dy*dy) + dz*dz), every operation rounded separately (bfs_cluster.cu:36)
