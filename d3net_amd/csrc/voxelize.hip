@@ -36,8 +36,18 @@ __global__ void voxelize_fp_kernel(const float *__restrict__ feats, float *__res
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (j < nActive) acc = __fadd_rn(acc, __fmul_rn(multiplier, v[j]));
-    for (int i = 5; i <= nActive; i++)
-        acc = __fadd_rn(acc, __fmul_rn(multiplier, feats[(long long)r[i] * nPlanes + plane]));
+    // crowded voxels (cluster grids hold tens of points per voxel): eight ids, then their eight rows, per round trip
+    for (int i0 = 5; i0 <= nActive; i0 += 8) {
+        int idn[8];
+        float vn[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) idn[j] = r[i0 + j <= nActive ? i0 + j : 0];
+#pragma unroll
+        for (int j = 0; j < 8; j++) vn[j] = feats[(long long)(i0 + j <= nActive ? idn[j] : 0) * nPlanes + plane];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (i0 + j <= nActive) acc = __fadd_rn(acc, __fmul_rn(multiplier, vn[j]));
+    }
     out[e] = acc;
 }
 
@@ -52,7 +62,14 @@ __global__ void voxelize_bp_kernel(const float *__restrict__ d_out, float *__res
     const int nActive = r[0];
     const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
     const float g = __fmul_rn(multiplier, d_out[e]);
-    for (int i = 1; i <= nActive; i++) atomicAdd(&d_feats[(long long)r[i] * nPlanes + plane], g);
+    for (int i0 = 1; i0 <= nActive; i0 += 8) {   // eight point ids per round trip (crowded cluster voxels), then the atomics
+        int idn[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) idn[j] = r[i0 + j <= nActive ? i0 + j : 0];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (i0 + j <= nActive) atomicAdd(&d_feats[(long long)idn[j] * nPlanes + plane], g);
+    }
 }
 
 static int launch_fp(const float *feats, float *out, const int *rules, int nActive, int maxActive, int nPlane,
