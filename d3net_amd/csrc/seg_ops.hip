@@ -227,9 +227,20 @@ __global__ __launch_bounds__(SEG_THREADS) void get_iou_kernel(const int *__restr
             const int wn = min(IOU_BINS, nInstance - w0);
             for (int b = t; b < wn; b += SEG_THREADS) hist[b] = 0;
             __syncthreads();
-            for (int i = start + t; i < end; i += SEG_THREADS) {
-                int lab = (int)instance_labels[proposals_idx[i]] - w0;  // (int) cast as in the reference
-                if (lab >= 0 && lab < wn) atomicAdd(&hist[lab], 1);
+            // eight points per thread per round trip (point ids, then their labels): a big proposal is ~130 steps of two
+            // dependent loads otherwise
+            for (int i0 = start + t; i0 < end; i0 += 8 * SEG_THREADS) {
+                int pi[8];
+                int64_t lb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const int i = i0 + j * SEG_THREADS; pi[j] = proposals_idx[i < end ? i : start]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) lb[j] = instance_labels[pi[j]];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int lab = (int)lb[j] - w0;  // (int) cast as in the reference
+                    if (i0 + j * SEG_THREADS < end && lab >= 0 && lab < wn) atomicAdd(&hist[lab], 1);
+                }
             }
             __syncthreads();
             for (int b = t; b < wn; b += SEG_THREADS) {
