@@ -502,11 +502,19 @@ __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ id
     if (!flag[oi]) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     const long long es = estart[i];
-    for (int e = d3_lane(); e < ln; e += 64) {
-        const int j = idx[st + e];
-        int4 r = make_int4(-1, 0, 0, 0);
-        if (own[j] == oi) r = make_int4(j, lid[j], estart[j], start_len[j * 2 + 1]);
-        erec[es + e] = r;
+    // four entries per lane per round trip pair (ids; then owner / dense id / record start / length of all four together,
+    // unconditionally): a capped list is 16 passes of three dependent gathers otherwise
+    for (int e0 = d3_lane(); e0 < ln; e0 += 256) {
+        int j[4], oj[4], lj[4], ej[4], nj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int e = e0 + q * 64; j[q] = idx[st + (e < ln ? e : 0)]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { oj[q] = own[j[q]]; lj[q] = lid[j[q]]; ej[q] = estart[j[q]]; nj[q] = start_len[j[q] * 2 + 1]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = e0 + q * 64;
+            if (e < ln) erec[es + e] = (oj[q] == oi) ? make_int4(j[q], lj[q], ej[q], nj[q]) : make_int4(-1, 0, 0, 0);
+        }
     }
 }
 

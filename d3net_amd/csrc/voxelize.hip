@@ -233,12 +233,24 @@ __global__ void vi_assign_kernel(const int *flag, const int *scan, const int *sl
 }
 __global__ void vi_p2v_kernel(const int *slot_of, const int *slot_vid, int *input_map, int *cnt, int n,
                               int *scalars) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int v = slot_vid[slot_of[i]];
-    input_map[i] = v;
-    int c = atomicAdd(&cnt[v], 1) + 1;
-    atomicMax(&scalars[1], c);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = i < n;
+    int v = -1;
+    if (live) { v = slot_vid[slot_of[i]]; input_map[i] = v; }
+    // Neighbouring points share voxels (a cluster grid holds ~100 points per voxel): one atomicAdd per distinct voxel of the
+    // wave (leader = lowest lane of each group) and one atomicMax per wave -- a returning atomic per point serialised
+    // hundreds deep on the crowded voxels, and every point hammered the maximum.
+    int c = 0;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const int vl = __shfl(v, leader);
+        const unsigned long long grp = __ballot(live && v == vl) & todo;
+        if (lane == leader) c = max(c, atomicAdd(&cnt[vl], (int)__popcll(grp)) + (int)__popcll(grp));
+        todo &= ~grp;
+    }
+    for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
+    if (lane == 0 && c > 0) atomicMax(&scalars[1], c);
 }
 __global__ void vi_total_kernel(const int *flag, const int *scan, int n, int *scalars) {
     if (threadIdx.x == 0 && blockIdx.x == 0) scalars[0] = n > 0 ? scan[n - 1] + flag[n - 1] : 0;
