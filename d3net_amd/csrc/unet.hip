@@ -105,9 +105,17 @@ __global__ void un_bn_finalize_kernel(StatSrc s0, StatSrc s1, int M, int C, floa
     const StatSrc s = (c >= s0.c0 && c < s0.c0 + s0.cn) ? s0 : s1;
     const int cc = c - s.c0;
     double sa = 0., sb = 0.;
-    for (int b = lane; b < s.nparts; b += 64) {
-        sa += (double)s.part[(size_t)b * 2 * s.width + cc];
-        sb += (double)s.part[(size_t)b * 2 * s.width + s.width + cc];
+    for (int b0 = lane; b0 < s.nparts; b0 += 256) {   // four partial rows per lane per round trip; same summation order
+        float pa[4], pb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int b = b0 + q * 64;
+            const size_t o = (size_t)(b < s.nparts ? b : 0) * 2 * s.width + cc;
+            pa[q] = s.part[o]; pb[q] = s.part[o + s.width];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (b0 + q * 64 < s.nparts) { sa += (double)pa[q]; sb += (double)pb[q]; }
     }
     for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
     if (lane != 0) return;
@@ -179,7 +187,18 @@ __global__ void un_bn_bwd_final_kernel(const float *part, int nparts, int C, flo
     const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double sa = 0., sb = 0.;
-    for (int b = lane; b < nparts; b += 64) { sa += (double)part[(size_t)b * 2 * C + c]; sb += (double)part[(size_t)b * 2 * C + C + c]; }
+    for (int b0 = lane; b0 < nparts; b0 += 256) {   // four partial rows per lane per round trip; same summation order
+        float pa[4], pb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int b = b0 + q * 64;
+            const size_t o = (size_t)(b < nparts ? b : 0) * 2 * C + c;
+            pa[q] = part[o]; pb[q] = part[o + C];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (b0 + q * 64 < nparts) { sa += (double)pa[q]; sb += (double)pb[q]; }
+    }
     for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
     if (lane != 0) return;
     sums[c] = (float)sa; sums[C + c] = (float)sb;
