@@ -811,8 +811,9 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
                 fprintf(stderr, "\n");
             }
         }
-        // clusters beyond the LDS bitmap (> 524288 points): the generic level loop (exits at once otherwise)
-        cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
+        // clusters beyond the LDS bitmap: the generic level loop (none can exist when all kept points together fit)
+        if (sumNPoint > B2_MAXSIZE)
+            cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
                                                          w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, B2_MAXSIZE);
     }
     D3_LAUNCH_CHECK();
