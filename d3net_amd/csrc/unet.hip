@@ -730,7 +730,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     // gradients stay on the caller's stream (no events).  Big ones use the side stream; the "a side-stream kernel still
     // reads this gradient buffer" hazard gets an event only for the convolutions whose output gradient is later
     // accumulated into in place (residual aliases: known from the program, OpD::wg_hazard).
-    const bool use_side = n->rows[0] >= 32768;
+    static const int side_min_rows = getenv("D3_SIDE_MIN_ROWS") ? atoi(getenv("D3_SIDE_MIN_ROWS")) : 32768;   // (experiments)
+    const bool use_side = n->rows[0] >= side_min_rows;
     hipStream_t ws_stream = use_side ? n->side : s;
     std::map<int, hipEvent_t> pending;   // gradient buffer root -> event after its last side-stream reader
     bool side_used = false;

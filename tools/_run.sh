@@ -1,1 +1,1 @@
-python -m pytest tests/test_pg_ops_gpu.py -x -q -m gpu 2>&1 | tail -2
+for v in 32768 2048 32768 2048; do echo "side_min_rows=$v"; D3_SIDE_MIN_ROWS=$v python3 tools/step_jitter.py 80; done
