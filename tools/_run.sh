@@ -1,1 +1,2 @@
-for v in 32768 2048 32768 2048; do echo "side_min_rows=$v"; D3_SIDE_MIN_ROWS=$v python3 tools/step_jitter.py 80; done
+python bench.py --steps 30 --warmup 12 --no-cpu-baseline --no-teacher 2>&1 | tail -1 | cut -c1-200
+python bench.py --steps 10 --warmup 4 --no-cpu-baseline --small 2>&1 | tail -1 | cut -c1-200
