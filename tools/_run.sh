@@ -1,2 +1,5 @@
-python bench.py --steps 30 --warmup 12 --no-cpu-baseline --no-teacher 2>&1 | tail -1 | cut -c1-200
-python bench.py --steps 10 --warmup 4 --no-cpu-baseline --small 2>&1 | tail -1 | cut -c1-200
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -rf /tmp/pp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o p -- python3 tools/phase_times.py 4 > gpurun_out/phase.log 2>&1
+python3 tools/backward_timeline.py $(find /tmp/pp -name "*kernel_trace.csv") | tail -19 > gpurun_out/bwd_timeline.txt
+python3 tools/prebackward.py $(find /tmp/pp -name "*kernel_trace.csv") > gpurun_out/prebackward.txt 2>&1

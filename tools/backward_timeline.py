@@ -15,7 +15,7 @@ def short(n):
 
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows]
 # step boundaries: AdamW kernels
-adam = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2]]
+adam = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2] or e[2].startswith("adamw_kernel")]
 ce = [i for i, e in enumerate(ev) if e[2].startswith("ce_fwd_kernel")]
 steps = []
 for c in ce:
