@@ -38,6 +38,24 @@ class FlatGradAllReduce:
                 p.grad.copy_(v)
 
 
+_AVG_OK = None
+
+
+def _avg_supported(like):
+    """ReduceOp.AVG on this backend?  Probed once with a one-element collective (every rank takes the same branch)."""
+    global _AVG_OK
+    if _AVG_OK is None:
+        _AVG_OK = False
+        if dist.get_backend() == "nccl" and like is not None:
+            try:
+                t = torch.ones(1, device=like.device)
+                dist.all_reduce(t, op=dist.ReduceOp.AVG)
+                _AVG_OK = bool(abs(float(t) - 1.0) < 1e-6)
+            except Exception:
+                _AVG_OK = False
+    return _AVG_OK
+
+
 class BucketGradAllReduce:
     """Gradient averaging for models whose sub-networks already keep their gradients in flat buffers (the native U-Net
     executors, d3net_amd/netexec.py): those buffers are all-reduced in place -- one collective each, no packing -- and the
@@ -55,17 +73,22 @@ class BucketGradAllReduce:
         world = dist.get_world_size()
         flats, covered = self.buckets()
         cov = {id(p) for p in covered}
-        works = [dist.all_reduce(f, async_op=True) for f in flats]
+        # RCCL averages inside the collective (no extra pass over the 31 MB buffer); gloo (the CPU tests) has no AVG
+        avg = _avg_supported(flats[0] if flats else None)
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        works = [dist.all_reduce(f, op=op, async_op=True) for f in flats]
         rest = [p for p in self.params if id(p) not in cov and p.grad is not None]
         if rest:
             grads = [p.grad for p in rest]
             packed = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(packed)
-            packed.div_(world)
+            dist.all_reduce(packed, op=op)
+            if not avg:
+                packed.div_(world)
             torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(packed.split([g.numel() for g in grads]), grads)])
         for w, f in zip(works, flats):
             w.wait()
-            f.div_(world)
+            if not avg:
+                f.div_(world)
 
 
 def broadcast_module(module, src=0):

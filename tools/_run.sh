@@ -1,2 +1,1 @@
-python bench.py --steps 20 --warmup 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c60-210
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c60-210
+timeout 120 python3 tools/_nccl_probe.py 2>&1 | grep -E "avg supported|value|Error|error" | head
