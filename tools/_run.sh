@@ -1,1 +1,1 @@
-timeout 120 python3 tools/_nccl_probe.py 2>&1 | grep -E "avg supported|value|Error|error" | head
+python3 tools/h2d_rate.py 2>&1 | tail -6
