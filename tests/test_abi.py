@@ -32,6 +32,17 @@ def test_binding_table_matches_header(built_lib):
     assert l.d3_version() >= 100
 
 
+def test_host_side_constants(built_lib):
+    """Pure host entry points (no GPU): the padded ball query's slot size is the reference's 1000-neighbour cap
+    (src/bfs_cluster/bfs_cluster.cu:38-44) and the AdamW chunk matches the block map d3net_amd.optim builds."""
+    from d3net_amd import _lib
+    l = _lib.lib()
+    assert l.d3_ballquery_cap() == 1000
+    assert l.d3_adamw_chunk() == 4096
+    assert l.d3_bfs_cluster_erec_bytes(10) == 160
+    assert l.d3_bfs_cluster_ws_bytes(1000) > 17 * 4 * 1000
+
+
 def test_product_never_imports_oracle():
     """d3net_amd/ must not reference oracle/ (no CPU fallback through the checker)."""
     bad = []
