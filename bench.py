@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- scenes/sec of the PointGroup detector training step on MI355X (BASELINE.json metric).
+"""bench.py -- scenes/sec of D3Net's training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1 default)
+    python bench.py [--config speaker|detector|listener|joint] --gpus N --steps K --warmup W       (N=1 default)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): PointGroup detector only, the canonical synthetic ScanNet-shaped scene of
-SURVEY.md section 8(d) (200x150x100 grid @ 2 cm, 142,920 voxels = 4.8 % occupancy, ~164k points, 134 input channels), one
-scene per GPU per step (weak scaling), random-init weights (seed 123), "teacher" clustering inputs (labels and GT
-offsets drive the ball query / BFS so that the clustering stage carries a realistic load with untrained weights).
-A step = feed (voxelise -> sparse U-Net -> heads -> 2x ball query + BFS clustering -> cluster re-voxelisation ->
-ScoreNet -> proposals) + loss + backward + gradient all-reduce (N>1) + AdamW step, inputs resident in HBM.
-One JSON line on stdout (rank 0).
+Default workload = the configuration BASELINE.json's metric is quoted on ("scenes/sec fwd+bwd (PointGroup+speaker)",
+configs[2]): `PipelineNet` mode 1 (reference step: model/pipeline.py:152-185) with conf/pointgroup_captioning.yaml --
+batch_size 4 scenes per GPU per step, 8 descriptions per scene, vocabulary 3004, cross-entropy captioning -- on the 40-box
+synthetic ScanNet-shaped scenes of SURVEY.md 8(d) "Config 3" (200x150x100 grid @ 2 cm, 40 hollow boxes of 8..30 cells per
+side, ~160 k voxels / ~185 k points per scene, 134 input channels), random-init weights (seed 123), "teacher" clustering
+inputs (labels and GT offsets drive the ball query / BFS so that the clustering stage carries a realistic load with
+untrained weights: ~40 instances per scene).  A step = detector feed (voxelise -> sparse U-Net -> heads -> 2x ball query +
+BFS -> cluster re-voxelisation -> ScoreNet -> batched proposals) + relation graph + top-down captioner (teacher forcing)
++ losses + backward + gradient all-reduce (N>1) + AdamW, inputs resident in HBM.  Weak scaling: every rank runs its own
+4 scenes.  `--config detector` is BASELINE configs[1] (one canonical 142,920-voxel scene per step), `listener` configs[3]
+(mode 2), `joint` configs[4] (mode 3, self-critical).  One JSON line on stdout (rank 0).
 """
 import argparse
 import ctypes as C
@@ -18,12 +22,18 @@ import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+VOCAB = 3004
+CONF = {"speaker": "pointgroup_captioning.yaml", "detector": "pointgroup.yaml", "listener": "pointgroup_grounding.yaml",
+        "joint": "pointgroup_joint.yaml"}
+METRIC = {"speaker": "scenes/sec fwd+bwd (PointGroup+speaker)", "detector": "scenes/sec fwd+bwd (PointGroup detector)",
+          "listener": "scenes/sec fwd+bwd (PointGroup+listener)", "joint": "scenes/sec fwd+bwd (PointGroup+speaker+listener, self-critical)"}
 
 
 def parse():
@@ -31,55 +41,115 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONF), default="speaker")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the untimed exact-fp32 (reference precision) steps")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-teacher", action="store_true", help="cluster on the network's own predictions")
-    ap.add_argument("--small", action="store_true", help="quarter-size scene (debug)")
+    ap.add_argument("--small", action="store_true", help="quarter-size scenes (debug)")
     return ap.parse_args()
 
 
 CPU_THREADS = 8   # torch-CPU sparse conv is fastest at ~8 threads (256 threads on the GPU box: 1000x slower)
 
 
-def cpu_baseline_child():
-    """`bench.py --cpu-baseline-only`: the oracle (CPU restatement of the reference step) timed on this host:
-    one forward+loss+backward of the SAME canonical scene.  Never touches the GPU.  Prints one JSON object."""
+# ------------------------------------------------------------------------------------------ workloads
+def make_scenes(config, rank, small=False):
+    """the synthetic scenes of one rank's step (numpy, host side)"""
+    from d3net_amd import synthetic as S
+    if config == "detector":
+        if small:
+            occ, sem, inst, _ = S.occupancy_grid((100, 75, 50), 4, (8, 30), (8, 25), 0)
+        else:
+            occ, sem, inst, _ = S.occupancy_grid()
+        return [S.scene_from_grid(occ, sem, inst, feat_seed=2 + rank)]   # same geometry, per-rank features
+    scenes = []
+    for b in range(4):   # data.batch_size 4 (conf/pointgroup_captioning.yaml); 40-box variant of SURVEY.md 8(d)
+        dims, nb, side = ((100, 75, 50), 10, (6, 16)) if small else ((200, 150, 100), 40, (8, 30))
+        occ, sem, inst, _ = S.occupancy_grid(dims, nb, side, side, seed=4 * rank + b)
+        scenes.append(S.scene_from_grid(occ, sem, inst, seed=1 + b, feat_seed=2 + 4 * rank + b))
+    return scenes
+
+
+def make_dataset(n_scenes, chunk, joint):
+    """the `dataset["train"]` object PipelineNet reads: vocabulary, GloVe table (N(0,1), seed 3), RL annotation store"""
+    import numpy as np
+    from d3net_amd import synthetic as S
+    ds = types.SimpleNamespace(vocabulary=S.make_vocabulary(VOCAB),
+                               glove=np.random.default_rng(3).standard_normal((VOCAB, 300)).astype(np.float32))
+    if joint:
+        ds.chunked_data, ds.organized = S.make_language_corpus(n_scenes, chunk=chunk, vocab=VOCAB)
+    return {"train": ds}
+
+
+def cpu_baseline_child(config):
+    """`bench.py --cpu-baseline-only`: the oracle (CPU restatement of the reference step) timed on this host, on a bounded
+    sample of the same workload.  Never touches the GPU.  Prints one JSON object."""
     import numpy as np
     import torch
     from d3net_amd import synthetic as S
     from d3net_amd.config import default_conf
-    from d3net_amd.pointgroup import PointGroup
     from oracle import pg_oracle as pg
     from oracle.pointgroup_oracle import PointGroupOracle
     cores = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(cores)
-    cfg = default_conf()
+    cfg = default_conf(CONF[config])
     torch.manual_seed(cfg.general.manual_seed)
-    state_dict = PointGroup(cfg).state_dict()          # same random init as the GPU run (CPU tensors)
-    occ, sem, inst, _ = S.occupancy_grid()
-    scene = S.scene_from_grid(occ, sem, inst)
-    b = S.collate([scene])
+    scenes = make_scenes(config, 0)[:1]          # ONE scene of the step's batch (the bounded sample)
+    b = S.collate(scenes)
     vl, p2v, v2p = pg.voxelization_idx(b["locs_scaled"], 1, 4)   # loader-side work, not timed (as on the GPU)
     b["voxel_locs"], b["p2v_map"], b["v2p_map"] = vl, p2v, v2p
     cpu = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()}
-    orc = PointGroupOracle(cfg, state_dict)
+    if config == "detector":
+        from d3net_amd.pointgroup import PointGroup
+        state = PointGroup(cfg).state_dict()          # same random init as the GPU run (CPU tensors)
+        spk = None
+    else:
+        from d3net_amd.pipeline import PipelineNet
+        net = PipelineNet(cfg, make_dataset(1, cfg.data.num_des_per_scene, False))
+        state = net.detector.state_dict()
+        spk = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and k != "caption.embeddings")
+               for k, v in net.speaker.state_dict().items()} if config in ("speaker", "joint") else None
+        lang = S.add_language({k: v for k, v in cpu.items()}, torch.device("cpu"), chunk=cfg.data.num_des_per_scene, vocab=VOCAB)
+        lang["lang_len"] = lang["spk_lang_len"]
+    orc = PointGroupOracle(cfg, state)
     orc.teacher = True
     t0 = time.time()
     d = orc.loss(orc.feed(cpu, 0))
-    d["total_loss"].backward()
+    loss = d["total_loss"]
+    what = "detector"
+    if spk is not None:   # relation graph + top-down captioner (teacher forcing) + cross-entropy, oracle/speaker_oracle.py
+        import torch.nn.functional as F
+        from oracle import speaker_oracle as spo
+        d.update({k: v for k, v in lang.items() if k not in d})
+        d["lang_len"] = lang["lang_len"]
+        g = spo.graph_module({k[len("graph."):]: v for k, v in spk.items() if k.startswith("graph.")}, d, cfg.model.num_graph_steps,
+                             cfg.model.num_locals)
+        d.update(g)
+        cp = {k[len("caption."):]: v for k, v in spk.items() if k.startswith("caption.")}
+        out = spo.forward_sample_batch(cp, d, cfg, cfg.model.max_num_proposal, cfg.model.num_locals)
+        logits = out["lang_cap"]
+        tgt = d["lang_ids"].reshape(-1, cfg.data.max_spk_len + 2)[:, 1:logits.shape[1] + 1]
+        good = out["good"]
+        if bool(good.any()):
+            loss = loss + F.cross_entropy(logits[good].reshape(-1, logits.shape[-1]), tgt[good].reshape(-1), ignore_index=0)
+        what = "detector + relation graph + captioner (XE)"
+    loss.backward()
     dt = time.time() - t0
     print(json.dumps({"value": 1.0 / dt, "unit": "scenes/sec", "cores": cores, "kind": "port",
-                      "sample": "1 step (forward+loss+backward, no optimizer) of the same %d-point canonical scene "
-                                "through oracle/ (torch-CPU gather-mm sparse conv, %d threads; C ball query / BFS / "
-                                "segment ops single-threaded): %.1f s" % (cpu["locs"].shape[0], cores, dt)}), flush=True)
+                      "sample": "1 scene (of the step's %d; %d points) x 1 step, forward+loss+backward, no optimizer: %s "
+                                "through oracle/ (torch-CPU gather-mm sparse conv and the reference's brute-force ball query on %d "
+                                "threads; BFS / segment ops single-threaded): %.1f s" % (1 if config == "detector" else 4,
+                                                                                         cpu["locs"].shape[0], what, cores, dt)}), flush=True)
 
 
-def cpu_baseline(limit_s=420):
+def cpu_baseline(config, limit_s=420):
     """run the baseline in a child process (bounded; it must never take the GPU number down with it)"""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
-                           text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(CPU_THREADS)))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", config],
+                           capture_output=True, text=True, timeout=limit_s,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(CPU_THREADS)))
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -91,7 +161,7 @@ def cpu_baseline(limit_s=420):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        return cpu_baseline_child()
+        return cpu_baseline_child(args.config)
     import torch
     import torch.distributed as dist
 
@@ -109,45 +179,60 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from d3net_amd import _lib, synthetic as S
+    from d3net_amd import _lib, minkowski as ME, synthetic as S
     from d3net_amd.config import default_conf
-    from d3net_amd.pointgroup import PointGroup
-
-    cfg = default_conf()
-    torch.manual_seed(cfg.general.manual_seed)
-    model = PointGroup(cfg).to(dev).train()
-    model.teacher = not args.no_teacher
-    params = [p for p in model.parameters() if p.requires_grad]
-    from d3net_amd.optim import FusedAdamW
-    opt = FusedAdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)
     from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
+    from d3net_amd.optim import FusedAdamW
+
+    config = args.config
+    cfg = default_conf(CONF[config])
+    torch.manual_seed(cfg.general.manual_seed)
+    scenes = make_scenes(config, rank, args.small)
+    n_scenes = len(scenes)
+    chunk = cfg.data.num_des_per_scene
+    if config == "detector":
+        from d3net_amd.pointgroup import PointGroup
+        model = PointGroup(cfg).to(dev).train()
+        detector = model
+    else:
+        from d3net_amd.pipeline import PipelineNet
+        model = PipelineNet(cfg, make_dataset(n_scenes, chunk, config == "joint")).to(dev).train()
+        detector = model.detector
+    detector.teacher = not args.no_teacher
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)
+    opt.register_step_pre_hook(lambda *a: detector.drop_stale_grads())
     if world > 1:  # identical replicas
         broadcast_module(model)
-    # the executors' flat gradient buffers are all-reduced in place (RCCL, sum -> mean); heads share one packed collective
-    grad_sync = BucketGradAllReduce(params, model.gradient_buckets) if world > 1 else None
+    # the executors' flat gradient buffers are all-reduced in place (RCCL, sum -> mean); the other parameters share one
+    # packed collective; the bucket layout is static (identical on every rank whatever its scenes produce)
+    grad_sync = BucketGradAllReduce(params, detector) if world > 1 else None
 
-    if args.small:
-        occ, sem, inst, _ = S.occupancy_grid((100, 75, 50), 4, (8, 30), (8, 25), 0)
-        scene = S.scene_from_grid(occ, sem, inst, feat_seed=2 + rank)
-    else:
-        occ, sem, inst, _ = S.occupancy_grid()
-        scene = S.scene_from_grid(occ, sem, inst, feat_seed=2 + rank)   # same geometry, per-rank features
-    batch = S.make_batch([scene], dev)
+    batch = S.make_batch(scenes, dev)
+    if config != "detector":
+        batch = S.add_language(batch, dev, chunk=chunk, vocab=VOCAB)
+        if config in ("speaker", "joint"):
+            batch["lang_len"] = batch["spk_lang_len"]     # the speaker's lang_len is the caption length (+2)
+        if config == "joint":                               # second (listener) batch of the joint step (pipeline.py:229-274)
+            lis = S.add_language(S.make_batch(scenes, dev), dev, chunk=chunk, vocab=VOCAB, seed=9)
     n_points, n_voxels = int(batch["locs"].shape[0]), int(batch["voxel_locs"].shape[0])
 
     def step():
-        d = dict(batch)
         model.zero_grad(set_to_none=True)
-        loss, d = model.training_step(d)
+        if config == "joint":
+            loss, d = model.training_step([dict(batch), dict(lis)])
+            d = d["speaker"]
+        else:
+            loss, d = model.training_step(dict(batch))
         loss.backward()
-        if grad_sync is not None:   # one fused gradient all-reduce over RCCL (sum -> mean), gradients only
+        if grad_sync is not None:   # gradient all-reduce over RCCL (sum -> mean), gradients only
             grad_sync()
         opt.step()
         return loss, d
 
     L = _lib.lib()
-    # set-up, not a step of the run: one dry pass sizes the cached workspaces (the clustering scratch is ~3 GB) and loads
-    # the code objects, so that a run with a very small --warmup does not time one-off allocations (reported as "setup")
+    # set-up, not a step of the run: one dry pass sizes the cached workspaces (the clustering scratch is several GB) and
+    # loads the code objects, so that a run with a very small --warmup does not time one-off allocations ("setup")
     loss, d = step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -160,7 +245,7 @@ def main():
     gc.freeze()
     if world > 1:
         dist.barrier()
-    PROF_STRIDE = 13   # every 13th convolution launch is bracketed by HIP events (coprime with the 257 launches per step)
+    PROF_STRIDE = 13   # every 13th convolution launch is bracketed by HIP events (coprime with the launches per step)
     L.d3_prof_enable(PROF_STRIDE)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -183,6 +268,25 @@ def main():
         L.d3_prof_collect(fam, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
         prof[name] = dict(launches=n.value, total_ms=ms.value, bytes=by.value)   # the sampled launches
     L.d3_prof_enable(0)
+    final_loss = float(loss.detach())
+
+    # reference precision beside the bf16 number: a few untimed-for-`value` steps with the exact-fp32 kernels
+    fp32 = None
+    if world == 1 and not args.no_fp32:
+        ME.set_exact(True)
+        try:
+            step(); torch.cuda.synchronize()
+            k = 3
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            fp32 = {"value": n_scenes * k / dt, "unit": "scenes/sec", "ms_per_step": 1e3 * dt / k, "steps": k,
+                    "note": "same step with minkowski.set_exact(True): fp32 storage and fp32 FMA convolutions (the "
+                            "reference's precision; validation kernels, not tuned), module-by-module path"}
+        finally:
+            ME.set_exact(False)
 
     if rank == 0:
         dom = max(prof, key=lambda k: prof[k]["total_ms"])
@@ -194,23 +298,34 @@ def main():
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc = pmc.get(config, pmc)
             traffic = pmc[dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2*FETCH+WRITE)*1024)"
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command; (2*FETCH+WRITE)*1024)"
         except Exception:
             pass
+        workload = {
+            "speaker": "BASELINE configs[2]: PipelineNet mode 1 (PointGroup detector -> relation graph -> top-down captioner, "
+                       "XE), conf/pointgroup_captioning.yaml: %d scenes/GPU/step (40-box synthetic ScanNet scenes, 200x150x100 "
+                       "@ 2 cm), %d descriptions/scene, V=%d, teacher clustering, AdamW" % (n_scenes, chunk, VOCAB),
+            "detector": "BASELINE configs[1]: PointGroup detector only, canonical synthetic ScanNet scene (200x150x100 @ 2 cm), "
+                        "1 scene/GPU/step, m=16, 7-level U-Net, teacher clustering, AdamW",
+            "listener": "BASELINE configs[3]: PipelineNet mode 2 (detector -> GRU language encoder -> transformer match), "
+                        "conf/pointgroup_grounding.yaml: %d scenes/GPU/step, %d descriptions/scene (T=128)" % (n_scenes, chunk),
+            "joint": "BASELINE configs[4]: PipelineNet mode 3 (self-critical speaker-listener, beam 3 / top-3, CIDEr reward), "
+                     "conf/pointgroup_joint.yaml: 2 x %d scenes/GPU/step" % n_scenes}[config]
         out = {
-            "metric": "scenes/sec fwd+bwd (PointGroup detector)", "value": world * args.steps / elapsed,
+            "metric": METRIC[config], "value": world * n_scenes * args.steps / elapsed,
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: PointGroup detector only, canonical synthetic ScanNet scene "
-                                   "(200x150x100 @ 2 cm, %d voxels, %d points, 134 ch), 1 scene/GPU/step, m=16, 7-level "
-                                   "U-Net, teacher clustering, AdamW" % (n_voxels, n_points),
-                       "scenes_per_gpu": 1, "points": n_points, "voxels": n_voxels,
-                       "raw_proposals": int(d.get("num_raw_proposals", 0)), "parallelism": "scene-parallel dp%d" % world,
-                       "precision": "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate",
+            "config": {"workload": workload + " (%d voxels, %d points, 134 ch per step)" % (n_voxels, n_points),
+                       "scenes_per_gpu": n_scenes, "global_batch": world * n_scenes, "points": n_points, "voxels": n_voxels,
+                       "raw_proposals": int(d.get("num_raw_proposals", 0)),
+                       "proposals_per_scene": float(d["proposal_batch_mask"].sum() / n_scenes) if "proposal_batch_mask" in d else None,
+                       "parallelism": "scene-parallel dp%d" % world,
+                       "precision": "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate; heads fp32",
                        "setup": "1 untimed dry-run step before the warm-up (workspace allocation, code-object loads)"},
-            "final_loss": float(loss.detach()),
+            "final_loss": final_loss, "fp32_exact": fp32,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": pd["bytes"] / max(pd["launches"], 1),
@@ -225,7 +340,7 @@ def main():
                                    for k, v in prof.items() if k != dom}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

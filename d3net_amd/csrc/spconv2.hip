@@ -634,6 +634,15 @@ extern "C" int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout) {
     return conv2_plan(Mout, K, Cin, Cout).grid;
 }
 
+// which kernel d3_spconv_fwd2* runs for this shape: out[6] = {split (1: spconv_fwd2_split_kernel), waves per workgroup,
+// grid.x, weights resident in LDS, column tiles per workgroup, grid.y}
+extern "C" int d3_spconv_fwd2_plan(int Mout, int K, int Cin, int Cout, int *out) {
+    if (!out || K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
+    const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
+    out[0] = p.split; out[1] = p.W; out[2] = p.grid; out[3] = p.wlds; out[4] = p.ntw; out[5] = p.gy;
+    return 0;
+}
+
 template <int NT>
 static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
     static bool attr_done = false;

@@ -41,14 +41,15 @@ class FlatGradAllReduce:
 _AVG_OK = None
 
 
-def _avg_supported(like):
-    """ReduceOp.AVG on this backend?  Probed once with a one-element collective (every rank takes the same branch)."""
+def _avg_supported(device):
+    """ReduceOp.AVG on this backend?  Probed once with a one-element collective (every rank takes the same branch: the
+    decision depends on the backend only)."""
     global _AVG_OK
     if _AVG_OK is None:
         _AVG_OK = False
-        if dist.get_backend() == "nccl" and like is not None:
+        if dist.get_backend() == "nccl":
             try:
-                t = torch.ones(1, device=like.device)
+                t = torch.ones(1, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.AVG)
                 _AVG_OK = bool(abs(float(t) - 1.0) < 1e-6)
             except Exception:
@@ -57,38 +58,75 @@ def _avg_supported(like):
 
 
 class BucketGradAllReduce:
-    """Gradient averaging for models whose sub-networks already keep their gradients in flat buffers (the native U-Net
-    executors, d3net_amd/netexec.py): those buffers are all-reduced in place -- one collective each, no packing -- and the
-    remaining parameters (the point-level heads: a dozen small tensors) share one packed collective.
-    `buckets()` -> (list of flat gradient tensors, list of the parameters they cover); called every step because the
-    executors create their buffers lazily."""
+    """Gradient averaging for models whose sub-networks keep their gradients in flat buffers (the native U-Net executors,
+    d3net_amd/netexec.py): those buffers are all-reduced in place -- one collective each, no packing -- and the remaining
+    parameters (point-level heads, speaker / listener) share one packed collective.
 
-    def __init__(self, params, buckets):
+    The collective schedule is STATIC: it is derived from the `requires_grad` parameter list and the owner's executor
+    set, never from which gradients happen to exist on this rank.  A rank whose step produced no proposals (its ScoreNet
+    backward never ran) contributes zeros and receives the other ranks' average, exactly what DDP does for a zero
+    gradient; every rank therefore issues the same collectives with the same sizes, in the same order, every step.  The
+    layout signature is compared across ranks once, at the first call.
+
+    `owner`: an object with `static_gradient_buckets()` -> [(flat tensor, [parameters], executor)] (PointGroup), or --
+    legacy form used by the CPU tests -- a callable returning ([flat tensors], [covered parameters])."""
+
+    def __init__(self, params, owner):
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = buckets
+        self.owner = owner
+        self._checked = False
+        self._rest = None
+
+    def _buckets(self):
+        if hasattr(self.owner, "static_gradient_buckets"):
+            return self.owner.static_gradient_buckets()
+        flats, covered = self.owner()
+        return [(f, covered if i == 0 else [], None) for i, f in enumerate(flats)]
+
+    def _check_signature(self, sizes, device):
+        """every rank must run the same schedule: compare (count, sizes) once"""
+        sig = torch.tensor([float(len(sizes))] + [float(n) for n in sizes], dtype=torch.float64, device=device)
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("BucketGradAllReduce: ranks disagree on the gradient bucket layout %s" % (sizes,))
+        self._checked = True
 
     def __call__(self):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()
-        flats, covered = self.buckets()
-        cov = {id(p) for p in covered}
+        buckets = self._buckets()
+        if self._rest is None:
+            cov = {id(p) for _, ps, _ in buckets for p in ps}
+            self._rest = [p for p in self.params if id(p) not in cov]
+        rest = self._rest
+        dev = buckets[0][0].device if buckets else rest[0].device
+        if not self._checked:
+            self._check_signature([f.numel() for f, _, _ in buckets] + [sum(p.numel() for p in rest)], dev)
         # RCCL averages inside the collective (no extra pass over the 31 MB buffer); gloo (the CPU tests) has no AVG
-        avg = _avg_supported(flats[0] if flats else None)
+        avg = _avg_supported(dev)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        works = [dist.all_reduce(f, op=op, async_op=True) for f in flats]
-        rest = [p for p in self.params if id(p) not in cov and p.grad is not None]
+        works = []
+        for flat, ps, ex in buckets:
+            if ex is not None:
+                ex.prepare_for_allreduce()     # zero-fill if no backward wrote it this step; install the views as .grad
+            works.append(dist.all_reduce(flat, op=op, async_op=True))
         if rest:
-            grads = [p.grad for p in rest]
-            packed = torch.cat([g.reshape(-1) for g in grads])
+            packed = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in rest])
             dist.all_reduce(packed, op=op)
             if not avg:
                 packed.div_(world)
-            torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(packed.split([g.numel() for g in grads]), grads)])
-        for w, f in zip(works, flats):
+            for p, v in zip(rest, packed.split([p.numel() for p in rest])):
+                if p.grad is None:
+                    p.grad = v.view_as(p).clone()
+                else:
+                    p.grad.copy_(v.view_as(p))
+        for w, (flat, _, _) in zip(works, buckets):
             w.wait()
             if not avg:
-                f.div_(world)
+                flat.div_(world)
 
 
 def broadcast_module(module, src=0):

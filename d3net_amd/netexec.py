@@ -205,6 +205,32 @@ class NativeUNet:
             self._grad_views = views
         return self._grad_views
 
+    def owned_params(self):
+        """trainable parameters whose gradient lives in this executor's flat buffer"""
+        return [p for p, g in zip(self.b.params, self.b.grad_params) if g and p.requires_grad]
+
+    def drop_stale_grads(self):
+        """torch semantics for a step in which this executor's backward never ran (no proposals -> no ScoreNet pass): the
+        owner's zero_grad(set_to_none=True) only marked the flat buffer stale, so the parameters still point at LAST
+        step's gradients -- detach them (grad None: the optimizer skips the tensor, like torch after zero_grad)."""
+        if self.fresh_grads and self._grad_views is not None:
+            for p, v in zip(self.b.params, self._grad_views):
+                if v is not None and p.grad is v:
+                    p.grad = None
+
+    def prepare_for_allreduce(self):
+        """before the in-place all-reduce of the flat buffer: a rank whose backward did not run this step contributes
+        zeros (and then holds the other ranks' average like everybody else)"""
+        views = self._grads(self.b.params[0].device)
+        if self.fresh_grads:
+            self._flat_grad.zero_()
+            self.fresh_grads = False
+        for p, v, g in zip(self.b.params, views, self.b.grad_params):
+            if g and p.requires_grad and p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
     def maps(self, cm):
         k3, child, up, rows, keep = [], [], [], [], []
         cm.build_pyramid(self.nlevels)

@@ -61,6 +61,21 @@ class PipelineNet(nn.Module):
             if torch.cuda.is_available():
                 torch.cuda.manual_seed_all(s)
 
+    def zero_grad(self, set_to_none=True):
+        """the detector's executors own their gradients (PointGroup.zero_grad marks them stale instead of detaching
+        ~500 views); everything else is plain nn.Module.zero_grad"""
+        self.detector.zero_grad(set_to_none)
+        rest = self.__dict__.get("_zg_rest")
+        if rest is None:
+            det = {id(p) for p in self.detector.parameters()}
+            rest = self.__dict__["_zg_rest"] = [p for p in self.parameters() if id(p) not in det]
+        for p in rest:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_(); p.grad.zero_()
+
     def log(self, name, value, **kw):
         self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
@@ -202,6 +217,7 @@ class PipelineNet(nn.Module):
         if params[0].is_cuda:   # one launch for all tensors (csrc/heads.hip); same update rule
             from .optim import FusedAdamW
             opt = FusedAdamW(params, lr=self.cfg.train.optim.lr, weight_decay=self.cfg.train.optim.weight_decay)
+            opt.register_step_pre_hook(lambda *a: self.detector.drop_stale_grads())
         else:
             opt = torch.optim.AdamW(params, lr=self.cfg.train.optim.lr, weight_decay=self.cfg.train.optim.weight_decay)
         return [opt], [torch.optim.lr_scheduler.StepLR(opt, step_size=10, gamma=0.8)]

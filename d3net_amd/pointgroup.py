@@ -162,17 +162,24 @@ class PointGroup(nn.Module):
             return self._exec(name)(x.F, x.coordinate_manager, self.training)
         return module(x).features
 
-    def gradient_buckets(self):
-        """(flat gradient buffers of the native executors, the parameters whose .grad lives in them) -- for
-        d3net_amd.distributed.BucketGradAllReduce.  A parameter whose .grad is not the executor's view is left out."""
-        flats, covered = [], []
+    def static_gradient_buckets(self):
+        """[(flat gradient buffer, its parameters, executor)] for BOTH executors, created eagerly so that every rank of
+        a data-parallel job has the same bucket layout whatever its scenes produce (d3net_amd.distributed)."""
+        out = []
+        dev = self.score_linear.weight.device
+        for name in ("score_net", "backbone"):      # backward order: ScoreNet's gradients are complete first
+            ex = self._exec(name)
+            ex._param_ptrs()
+            ex._grads(dev)
+            out.append((ex._flat_grad, ex.owned_params(), ex))
+        return out
+
+    def drop_stale_grads(self):
+        """call before optimizer.step(): executors whose backward did not run since zero_grad() must not re-apply the
+        previous step's gradient (FusedAdamW / torch.optim skip tensors whose grad is None)"""
         for ex in self._execs.values():
-            if ex is None or ex._flat_grad is None:
-                continue
-            ok = [p for p, v in zip(ex.b.params, ex._grad_views) if v is not None and p.grad is v]
-            if len(ok) == sum(1 for v in ex._grad_views if v is not None):
-                flats.append(ex._flat_grad); covered += ok
-        return flats, covered
+            if ex is not None:
+                ex.drop_stale_grads()
 
     def zero_grad(self, set_to_none=True):
         """nn.Module.zero_grad; gradients owned by the native executors are marked stale instead of being detached

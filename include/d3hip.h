@@ -188,6 +188,10 @@ int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, 
 size_t d3_spconv_pack_bytes(int K, int Cin, int Cout);
 int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream);
 int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout);
+/* which kernel fwd2 runs for a shape (tests assert the variant they mean to cover): out[6] = {split (1 = the few-row
+ * spconv_fwd2_split_kernel, 0 = the persistent wave-per-tile spconv_fwd2_kernel), waves per workgroup, grid.x,
+ * weights resident in LDS, column tiles per workgroup, grid.y} */
+int d3_spconv_fwd2_plan(int Mout, int K, int Cin, int Cout, int *out6);
 int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
                    int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
 /* fwd2 as the data gradient of a BatchNorm -> ReLU -> conv unit, with the BatchNorm-backward reductions in the epilogue:

@@ -143,33 +143,57 @@ void orc_voxelize_bp(const float *d_out, float *d_feats, const Int *rules, int n
  * Distance expression evaluated exactly as written (no FMA contraction; nvcc's default
  * -fmad=true may contract it on the reference's GPU -- unverifiable here).
  * Returns cumsum (total hits, may exceed n*meanActive => caller must retry). */
+/* one point's scan: the reference thread body (bfs_cluster.cu:27-47) */
+static int orc_bq_point(int pt, float radius2, const float *xyz, const int *batch_idxs, const int *batch_offsets,
+                        int *idx_temp) {
+    float o_x = xyz[pt * 3 + 0], o_y = xyz[pt * 3 + 1], o_z = xyz[pt * 3 + 2];
+    int b = batch_idxs[pt];
+    int start = batch_offsets[b], end = batch_offsets[b + 1];
+    int cnt = 0;
+    for (int k = start; k < end; k++) {
+        float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+        float d2 = (o_x - x) * (o_x - x) + (o_y - y) * (o_y - y) + (o_z - z) * (o_z - z);
+        if (d2 < radius2) {
+            if (cnt < 1000) idx_temp[cnt] = k; else break;
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
+/* Points are independent (one CUDA thread each in the reference), so the host restatement may spread them over the
+ * cores (OpenMP; bench.py's cpu_baseline states the thread count): count pass, serial exclusive scan, fill pass.  The
+ * result is identical to the single-threaded loop for any thread count. */
 int orc_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
                           const int *batch_idxs, const int *batch_offsets, int *idx, int *start_len) {
-    long long cumsum = 0;
     float radius2 = radius * radius;
-    int *idx_temp = (int *)malloc(sizeof(int) * 1000);
     long long thre = (long long)n * meanActive;
-    for (int pt = 0; pt < n; pt++) {
-        float o_x = xyz[pt * 3 + 0], o_y = xyz[pt * 3 + 1], o_z = xyz[pt * 3 + 2];
-        int b = batch_idxs[pt];
-        int start = batch_offsets[b], end = batch_offsets[b + 1];
-        int cnt = 0;
-        for (int k = start; k < end; k++) {
-            float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-            float d2 = (o_x - x) * (o_x - x) + (o_y - y) * (o_y - y) + (o_z - z) * (o_z - z);
-            if (d2 < radius2) {
-                if (cnt < 1000) idx_temp[cnt] = k; else break;
-                ++cnt;
-            }
-        }
-        long long s = cumsum; cumsum += cnt;
-        start_len[pt * 2 + 0] = (int)s;
-        start_len[pt * 2 + 1] = cnt;
-        if (s >= thre) continue;
-        if (s + cnt >= thre) cnt = (int)(thre - s);
-        for (int k = 0; k < cnt; k++) idx[s + k] = idx_temp[k];
+#pragma omp parallel
+    {
+        int *idx_temp = (int *)malloc(sizeof(int) * 1000);
+#pragma omp for schedule(dynamic, 128)
+        for (int pt = 0; pt < n; pt++)
+            start_len[pt * 2 + 1] = orc_bq_point(pt, radius2, xyz, batch_idxs, batch_offsets, idx_temp);
+        free(idx_temp);
     }
-    free(idx_temp);
+    long long cumsum = 0;
+    for (int pt = 0; pt < n; pt++) {
+        start_len[pt * 2 + 0] = (int)cumsum;
+        cumsum += start_len[pt * 2 + 1];
+    }
+#pragma omp parallel
+    {
+        int *idx_temp = (int *)malloc(sizeof(int) * 1000);
+#pragma omp for schedule(dynamic, 128)
+        for (int pt = 0; pt < n; pt++) {
+            long long s = start_len[pt * 2 + 0];
+            if (s >= thre) continue;
+            int cnt = orc_bq_point(pt, radius2, xyz, batch_idxs, batch_offsets, idx_temp);
+            if (s + cnt >= thre) cnt = (int)(thre - s);
+            for (int k = 0; k < cnt; k++) idx[s + k] = idx_temp[k];
+        }
+        free(idx_temp);
+    }
     return (int)cumsum;
 }
 

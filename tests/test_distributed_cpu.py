@@ -84,3 +84,72 @@ def test_bucket_grad_allreduce_world2():
     for a0, a1, l0, l1 in zip(r0["avg"], r1["avg"], r0["local"], r1["local"]):
         assert torch.allclose(a0, a1)
         assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6)
+
+
+class _FakeExecutor:
+    """host-side stand-in for netexec.NativeUNet's gradient bookkeeping (same three members the reducer uses)"""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.flat = torch.zeros(sum(p.numel() for p in self.params))
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p)); off += p.numel()
+        self.fresh_grads = True
+
+    def prepare_for_allreduce(self):
+        if self.fresh_grads:
+            self.flat.zero_(); self.fresh_grads = False
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
+
+class _Owner:
+    def __init__(self, ex):
+        self.ex = ex
+
+    def static_gradient_buckets(self):
+        return [(self.ex.flat, self.ex.params, self.ex)]
+
+
+def _ragged_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 7), torch.nn.Linear(7, 3))
+    broadcast_module(net)
+    ex = _FakeExecutor(net[1].parameters())          # "ScoreNet": its backward only runs on rank 0 this step
+    sync = BucketGradAllReduce(net.parameters(), _Owner(ex))
+    torch.manual_seed(100 + rank)
+    x = torch.randn(16, 5)
+    if rank == 0:
+        for p, v in zip(ex.params, ex.views):
+            p.grad = v
+        ex.fresh_grads = False
+        net(x).pow(2).sum().backward()
+    else:                                            # no proposals: the middle layer and the last one get no gradient
+        net[0](x).pow(2).sum().backward()
+    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    sync()
+    ret[rank] = dict(local=local, avg=[p.grad.clone() for p in net.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_layout_is_static_when_a_rank_has_no_gradients():
+    """a rank whose executor backward never ran (no proposals) still issues the same collectives: it contributes zeros and
+    ends up with the average, like DDP -- no hang, no shorter packed tensor (rank-local bucket schedules)"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ragged_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    for a0, a1, l0, l1 in zip(r0["avg"], r1["avg"], r0["local"], r1["local"]):
+        assert torch.allclose(a0, a1)
+        want = (l0 + (l1 if l1 is not None else torch.zeros_like(l0))) / 2
+        assert torch.allclose(a0, want, atol=1e-6)

@@ -1,20 +1,24 @@
 #!/bin/bash
-# One GPU session: full -m gpu suite, smoke, bench (with CPU baseline), rocprofv3 kernel stats and PMC traffic.
-# usage: tools/gpu_round.sh <tag> [skip-tests]    -> everything lands under gpurun_out/<tag>/ ; every step is bounded.
+# One GPU session: full -m gpu suite, smoke, bench (default = BASELINE's PointGroup+speaker config, with CPU baseline),
+# rocprofv3 kernel stats and PMC traffic of the same command.
+# usage: tools/gpu_round.sh <tag> [skip-tests] [bench args...]  -> everything lands under gpurun_out/<tag>/ ; every step is bounded.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+SKIP=${2:-}
+shift; shift
+BARGS="$@"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-if [ "${2:-}" != "skip-tests" ]; then
-  timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+if [ "$SKIP" != "skip-tests" ]; then
+  timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 2>&1 | tail -40 > $OUT/pytest_gpu.log
   timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -2 > $OUT/smoke.log
 fi
-timeout 700 python bench.py 2>&1 | grep '^{' > $OUT/bench.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+timeout 900 python bench.py $BARGS 2> $OUT/bench.err | grep '^{' > $OUT/bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fp32 $BARGS > $OUT/bench_under_rocprof.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv") $OUT/kernel_stats.csv
 for CTR in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $CTR --output-format csv -d /tmp/pmc_${TAG}_$CTR -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$CTR.log 2>&1
+  timeout 600 rocprofv3 --pmc $CTR --output-format csv -d /tmp/pmc_${TAG}_$CTR -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 $BARGS > $OUT/pmc_$CTR.log 2>&1
   python tools/pmc_summary.py $(find /tmp/pmc_${TAG}_$CTR -name "*counter_collection.csv") > $OUT/pmc_$CTR.csv
 done
-cat $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; cut -c1-300 $OUT/bench.json; head -6 $OUT/pmc_FETCH_SIZE.csv; head -4 $OUT/pmc_WRITE_SIZE.csv
+cat $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; tail -3 $OUT/bench.err; cut -c1-400 $OUT/bench.json; head -12 $OUT/kernel_stats.csv | cut -c1-150; head -6 $OUT/pmc_FETCH_SIZE.csv; head -4 $OUT/pmc_WRITE_SIZE.csv
