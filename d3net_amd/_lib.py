@@ -85,6 +85,8 @@ SIGNATURES = {
     "d3_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "d3_hgemm": (i32, [vp, i32, vp]),
+    "d3_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "d3_prof_enable": (i32, [i32]),
     "d3_prof_collect": (i32, [i32, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -95,6 +97,17 @@ SIGNATURES = {
     "d3_bn_relu_fwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "d3_bn_relu_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, sz, vp]),
 }
+
+
+class GemmSeg(C.Structure):
+    """d3_gemm_seg (include/d3hip.h)"""
+    _fields_ = [("A", vp), ("ia", vp), ("lda", i64), ("a_kmajor", i32), ("B", vp), ("ldb", i64), ("b_kmajor", i32), ("K", i32)]
+
+
+class GemmProb(C.Structure):
+    """d3_gemm_prob (include/d3hip.h)"""
+    _fields_ = [("seg", GemmSeg * 3), ("nseg", i32), ("M", i32), ("N", i32), ("C", vp), ("ldc", i64), ("bias", vp), ("add", vp),
+                ("ldadd", i64), ("relu", i32), ("accum", i32), ("perm_nb", i32), ("perm_s", i32)]
 
 
 def lib():

@@ -1,0 +1,211 @@
+// hgemm.hip -- small-batch fp32 GEMMs on the matrix cores for the proposal-level heads (gfx950).
+//
+// The speaker / listener heads of D3Net (model/caption_module.py:72-133 the top-down captioner step,
+// model/graph_module.py:101-108 the EdgeConv message MLP, model/lang_module.py:51-55 the GRU language encoder) are chains
+// of nn.Linear / nn.GRUCell calls on a few dozen rows (batch 32 = 4 scenes x 8 descriptions; 128 proposals per scene).
+// The reference issues them through cuBLAS one by one -- ~25 launches per decode step, ~4,000 per training step; the BLAS
+// library's kernels for M = 32 take 5-25 us each.  Here ONE kernel family covers every one of them:
+//
+//     C (M,N) [+]= act( sum_seg A_seg (M,K_seg) . B_seg (N,K_seg)^T + bias[N] + add (M,N) )
+//
+//   * fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_16x16x4_f32 is EXACT fp32 (an fmaf chain) at the fp32
+//     vector rate (155 TFLOP/s measured, MI355X_MICROARCH.md) -- the heads keep the reference's precision;
+//   * up to three K-segments per problem with their own operand pointers: torch.cat([a, b, c], -1) @ W^T never
+//     materialises the concatenation (map_topdown: [embedding, hidden_2, target], map_lang: [attended, hidden_1]); a
+//     segment's A rows may be gathered through an index vector (the embedding lookup: one-hot x table in the reference,
+//     caption_module.py:95-98);
+//   * either operand may be "k-major" (element (r,k) at base[k*ld + r]): the same kernel does y = x W^T (forward),
+//     dx = dy W (data gradient, B k-major) and dW = dy^T x (weight gradient, both k-major, K = rows) without transposes;
+//   * skinny problems (M <= 64: a decode step) give one 16-column tile to a workgroup whose 4 waves split the K loop and
+//     are summed through LDS (a 32 x 512 x 512 step has only 32 column tiles: without the split 32 waves would each walk
+//     a 128-deep dependent chain); tall problems give every wave its own tile;
+//   * up to four independent problems per launch (blockIdx.z): the two GEMMs of a GRU backward share one launch.
+// Every lane loads 16 bytes of a row per 16-wide k block (64-byte segments per row across the 4 lane groups) and four
+// k blocks are requested before the first MFMA of the batch (the loads are L2 / Infinity-Cache hits: weights of a step
+// total ~20 MB and are re-read every step).
+// Roofline: these GEMMs are latency / launch bound at M = 32 (0.3 GFLOP per decode step); the batched ones (classifier
+// over all time steps: 992 x 512 x 3004) are bound by the fp32 matrix rate.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HG_MAXP 4
+struct HgBatch { d3_gemm_prob p[HG_MAXP]; };
+
+// 4 consecutive-k values of one operand row for this lane: k = k0 .. k0+3
+__device__ __forceinline__ f32x4 hg_load4(const float *base, long long ld, int kmajor, int vec, int k0, int K, bool valid) {
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!valid || k0 >= K) return v;
+    if (!kmajor) {
+        if (vec && k0 + 3 < K) return *(const f32x4 *)(base + k0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) if (k0 + s < K) v[s] = base[k0 + s];
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) if (k0 + s < K) v[s] = base[(long long)(k0 + s) * ld];
+    }
+    return v;
+}
+
+template <int RT, bool KSPLIT>
+__global__ __launch_bounds__(256) void hg_gemm_kernel(const HgBatch batch) {
+    __shared__ float red[KSPLIT ? 4 * RT * 256 : 1];
+    const d3_gemm_prob &p = batch.p[blockIdx.z];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int ctiles = (p.N + 15) >> 4, rgroups = (p.M + RT * 16 - 1) / (RT * 16);
+    const int ct = KSPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int rg = blockIdx.y;
+    if (rg >= rgroups || (KSPLIT ? ct >= ctiles : (int)blockIdx.x * 4 >= ctiles)) return;
+    const bool tile_ok = ct < ctiles;
+    f32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int col = ct * 16 + i;
+    const bool cvalid = tile_ok && col < p.N;
+    int gkb = 0;   // k-block counter over the concatenated segments (K-split assignment)
+    for (int s = 0; s < p.nseg; s++) {
+        const d3_gemm_seg &sg = p.seg[s];
+        const int K = sg.K, nkb = (K + 15) >> 4;
+        const int avec = (!sg.a_kmajor && (sg.lda & 3) == 0 && (((size_t)sg.A) & 15) == 0) ? 1 : 0;
+        const int bvec = (!sg.b_kmajor && (sg.ldb & 3) == 0 && (((size_t)sg.B) & 15) == 0) ? 1 : 0;
+        const float *ab[RT];
+        bool av[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int row = (rg * RT + r) * 16 + i;
+            av[r] = tile_ok && row < p.M;
+            long long ar = av[r] ? (sg.ia ? (long long)sg.ia[row] : (long long)row) : 0;
+            ab[r] = sg.a_kmajor ? sg.A + ar : sg.A + ar * sg.lda;
+        }
+        const float *bb = sg.b_kmajor ? sg.B + (cvalid ? col : 0) : sg.B + (long long)(cvalid ? col : 0) * sg.ldb;
+        // this wave's k blocks of the segment: kb = first, first + step, ...
+        const int step = KSPLIT ? 4 : 1;
+        int first = KSPLIT ? ((wave - gkb) & 3) : 0;
+        gkb += nkb;
+        constexpr int U = RT <= 2 ? 4 : 2;
+        for (int kb0 = first; kb0 < nkb; kb0 += step * U) {
+            f32x4 a[U][RT], b[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k0 = (kb0 + u * step) * 16 + g * 4;
+                const bool in = kb0 + u * step < nkb;
+                b[u] = hg_load4(bb, sg.ldb, sg.b_kmajor, bvec, k0, K, in && cvalid);
+#pragma unroll
+                for (int r = 0; r < RT; r++) a[u][r] = hg_load4(ab[r], sg.lda, sg.a_kmajor, avec, k0, K, in && av[r]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (kb0 + u * step < nkb) {   // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int r = 0; r < RT; r++)
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][r][q], b[u][q], acc[r], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: D layout col = lane & 15, row = (lane >> 4) * 4 + q
+    auto finish = [&](int r, int q, int ln, float v) {
+        const int row = (rg * RT + r) * 16 + (ln >> 4) * 4 + q, c = ct * 16 + (ln & 15);
+        if (row >= p.M || c >= p.N) return;
+        if (p.bias) v += p.bias[c];
+        if (p.add) v += p.add[(long long)row * p.ldadd + c];
+        if (p.relu && v < 0.f) v = 0.f;
+        const long long orow = p.perm_nb > 0 ? (long long)(row % p.perm_nb) * p.perm_s + row / p.perm_nb : (long long)row;
+        float *o = p.C + orow * p.ldc + c;
+        *o = p.accum ? *o + v : v;
+    };
+    if (KSPLIT) {
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[((wave * RT + r) * 4 + q) * 64 + lane] = acc[r][q];
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < RT; n++) {
+            const int e = t + n * 256, r = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) v += red[((w * RT + r) * 4 + q) * 64 + ln];
+            finish(r, q, ln, v);
+        }
+    } else if (tile_ok) {
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) finish(r, q, lane, acc[r][q]);
+    }
+}
+
+static int hg_check(const d3_gemm_prob &p) {
+    if (p.nseg < 1 || p.nseg > 3 || p.M < 0 || p.N < 1 || !p.C) return D3_ERR_ARG;
+    for (int s = 0; s < p.nseg; s++)
+        if (!p.seg[s].A || !p.seg[s].B || p.seg[s].K < 1) return D3_ERR_ARG;
+    return 0;
+}
+
+// host-side launcher shared with topdown.hip / edgeconv.hip (C++ linkage; the C entry point is d3_hgemm)
+int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
+    if (nprobs < 1 || nprobs > HG_MAXP) return D3_ERR_ARG;
+    HgBatch b;
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < nprobs; i++) {
+        int rc = hg_check(probs[i]);
+        if (rc) return rc;
+        b.p[i] = probs[i];
+        if (probs[i].M > maxM) maxM = probs[i].M;
+        if (probs[i].N > maxN) maxN = probs[i].N;
+    }
+    for (int i = nprobs; i < HG_MAXP; i++) b.p[i] = probs[0];
+    if (maxM == 0) return 0;
+    const int ctiles = (maxN + 15) / 16;
+    if (maxM <= 64) {            // a decode step: K split over the waves of a workgroup
+        if (maxM <= 16) hg_gemm_kernel<1, true><<<dim3(ctiles, 1, nprobs), 256, 0, s>>>(b);
+        else if (maxM <= 32) hg_gemm_kernel<2, true><<<dim3(ctiles, 1, nprobs), 256, 0, s>>>(b);
+        else hg_gemm_kernel<4, true><<<dim3(ctiles, 1, nprobs), 256, 0, s>>>(b);
+    } else {
+        const long long tiles16 = (long long)ctiles * ((maxM + 15) / 16);
+        if (tiles16 < 2048) {    // few tiles: still split K so that the chip is covered
+            hg_gemm_kernel<2, true><<<dim3(ctiles, (maxM + 31) / 32, nprobs), 256, 0, s>>>(b);
+        } else {
+            hg_gemm_kernel<4, false><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
+        }
+    }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_hgemm(const d3_gemm_prob *probs, int nprobs, void *stream) {
+    D3_CLEAR();
+    return hg_launch(probs, nprobs, d3_stream(stream));
+}
+
+// out[c] (+)= sum_r x[r, c]  (bias gradients): one wave per 64 columns slice x row range, fixed order
+__global__ __launch_bounds__(256) void hg_colsum_kernel(const float *__restrict__ x, long long ld, int R, int C, float *__restrict__ out,
+                                                        int accum) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int r = wave; r < R; r += 4) s += x[(long long)r * ld + c];
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const float v = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
+        out[c] = accum ? out[c] + v : v;
+    }
+}
+
+int hg_colsum(const float *x, long long ld, int R, int C, float *out, int accum, hipStream_t s) {
+    if (C <= 0) return 0;
+    hg_colsum_kernel<<<(C + 63) / 64, 256, 0, s>>>(x, ld, R, C, out, accum);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *stream) {
+    D3_CLEAR();
+    return hg_colsum(x, ld, R, C, out, accum, d3_stream(stream));
+}

@@ -325,6 +325,31 @@ int d3_attn_fwd(const float *q, const float *k, const float *v, const float *bia
 int d3_attn_bwd(const float *q, const float *k, const float *v, const float *P, const float *dout, float *dS,
                 float *dq, float *dk, float *dv, int B, int h, int nq, int nk, int dkdim, int dvdim, void *stream);
 
+/* ---- small-batch fp32 GEMMs of the proposal-level heads (csrc/hgemm.hip) ---------------------------
+ * Every nn.Linear / nn.GRUCell product of the speaker and listener heads (model/caption_module.py:72-133,
+ * model/graph_module.py:101-108, model/lang_module.py:51-55):
+ *     C (M,N) [+]= act( sum_seg A_seg (M,K_seg) . B_seg (N,K_seg)^T + bias[N] + add (M,N) )
+ * fp32 operands, exact fp32 products and accumulation on the matrix cores (v_mfma_f32_16x16x4_f32).  Up to three K
+ * segments (torch.cat of inputs against one weight matrix is never materialised); A rows of a segment may be gathered
+ * through `ia` (embedding lookup); an operand is row-major (element (r,k) at base[r*ld + k]) or k-major (base[k*ld + r]):
+ * y = x W^T, dx = dy W (B k-major) and dW = dy^T x (both k-major) are the same kernel.  perm_nb > 0 stores row r at row
+ * (r % perm_nb) * perm_s + r / perm_nb (time-major rows -> batch-major logits).  Up to 4 problems per call share a launch. */
+typedef struct {
+    const float *A; const int *ia; long long lda; int a_kmajor;
+    const float *B; long long ldb; int b_kmajor;
+    int K;
+} d3_gemm_seg;
+typedef struct {
+    d3_gemm_seg seg[3]; int nseg;
+    int M, N;
+    float *C; long long ldc;
+    const float *bias; const float *add; long long ldadd;
+    int relu, accum, perm_nb, perm_s;
+} d3_gemm_prob;
+int d3_hgemm(const d3_gemm_prob *probs, int nprobs, void *stream);
+/* out[c] (+)= sum_r x[r*ld + c], r < R, c < C (bias gradients; fixed summation order) */
+int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *stream);
+
 /* ---- proposal geometry (speaker / graph heads) ------------------------------------------ */
 /* Distance matrix of `_query_locals` (model/graph_module.py:184-227 == model/caption_module.py:800-842) for all
  * target proposals at once: corners (B,K,8,3), masks (B,K) -> dist (B,K,K), dist[b,t,j] as the reference's pc_dist

@@ -188,8 +188,9 @@ def test_fwd2_big_kernel_data_gradient_and_bn_backward_epilogue(dev, canon, leve
     pw = (cin + 15) // 16 * 16
     part = torch.full((nparts, 2, pw), float("nan"), device=dev)
     out2 = torch.full((Min, cin), float("nan"), device=dev)
+    bnxd, meand, vard, gammad, betad = (t.to(dev) for t in (bnx, mean, var, gamma, beta))   # (kept alive across the call)
     rc = L.d3_spconv_fwd2_bnbwd(_ptr(dyd), cout, _ptr(tbl_b) if tbl_b is not None else None, _ptr(wp), _ptr(out2), cin, _ptr(part),
-                                _ptr(bnx.to(dev)), cin, _ptr(mean.to(dev)), _ptr(var.to(dev)), _ptr(gamma.to(dev)), _ptr(beta.to(dev)),
+                                _ptr(bnxd), cin, _ptr(meand), _ptr(vard), _ptr(gammad), _ptr(betad),
                                 eps, 1, Mout, Min, K, cout, cin, 0, _stream())
     assert rc == 0
     o2 = out2.cpu().double()

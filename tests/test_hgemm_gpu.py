@@ -1,0 +1,118 @@
+"""d3_hgemm (csrc/hgemm.hip): the fp32 matrix-core GEMM family behind the speaker / listener heads, against torch fp64 on the
+host.  v_mfma_f32_16x16x4_f32 is exact fp32 with fp32 accumulation: tolerance 2e-6 * sqrt(K) relative to the output scale
+(summation order only).  Shapes are those of model/caption_module.py:72-133 (batch 32, hidden 512, emb 300, feat 128,
+vocabulary 3004), model/graph_module.py:101-108 and their gradients."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _seg(A, B, K, ia=None, a_km=False, b_km=False):
+    from d3net_amd._lib import GemmSeg
+    s = GemmSeg()
+    s.A, s.lda, s.a_kmajor = A.data_ptr(), A.stride(0), int(a_km)
+    s.B, s.ldb, s.b_kmajor = B.data_ptr(), B.stride(0), int(b_km)
+    s.ia = ia.data_ptr() if ia is not None else None
+    s.K = K
+    return s
+
+
+def _prob(segs, M, N, Cmat, bias=None, add=None, relu=False, accum=False, perm=(0, 0)):
+    from d3net_amd._lib import GemmProb
+    p = GemmProb()
+    for i, s in enumerate(segs):
+        p.seg[i] = s
+    p.nseg, p.M, p.N = len(segs), M, N
+    p.C, p.ldc = Cmat.data_ptr(), Cmat.stride(0)
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.add = add.data_ptr() if add is not None else None
+    p.ldadd = add.stride(0) if add is not None else 0
+    p.relu, p.accum, p.perm_nb, p.perm_s = int(relu), int(accum), perm[0], perm[1]
+    return p
+
+
+def _run(probs):
+    from d3net_amd import _lib
+    from d3net_amd._lib import GemmProb
+    arr = (GemmProb * len(probs))(*probs)
+    rc = _lib.lib().d3_hgemm(arr, len(probs), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+
+
+def _close(got, ref, K):
+    ref = ref.double(); got = got.double().cpu()
+    err = float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+    assert err < 2e-6 * np.sqrt(K) + 1e-6, err
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 300, 512), (32, 512, 512), (16, 1536, 300), (8, 3004, 512), (64, 300, 640),
+                                   (992, 3004, 512), (4096, 512, 128), (512, 512, 512), (130, 77, 52)])
+def test_nt_bias_relu_add(dev, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / np.sqrt(K)
+    b, add = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xd, Wd, bd, addd = x.to(dev), W.to(dev), b.to(dev), add.to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    _run([_prob([_seg(xd, Wd, K)], M, N, out, bias=bd, add=addd, relu=True)])
+    _close(out, torch.relu(x.double() @ W.double().t() + b.double() + add.double()), K)
+    out2 = addd.clone()
+    _run([_prob([_seg(xd, Wd, K)], M, N, out2, accum=True)])
+    _close(out2, x.double() @ W.double().t() + add.double(), K)
+
+
+def test_three_segments_with_gather_and_row_permutation(dev):
+    """map_topdown over cat([embedding[word], hidden_2, target]) for all time steps (model/caption_module.py:95-102) with
+    time-major rows stored batch-major"""
+    g = torch.Generator().manual_seed(3)
+    V, N, S = 3004, 32, 31
+    emb = torch.randn(V, 300, generator=g)
+    words = torch.randint(0, V, (S * N,), generator=g, dtype=torch.int32)
+    h2, tgt = torch.randn(S * N, 512, generator=g), torch.randn(N, 128, generator=g)
+    tidx = (torch.arange(S * N) % N).int()
+    W = torch.randn(300, 940, generator=g) / 30
+    b = torch.randn(300, generator=g)
+    d = lambda t: t.to(dev)
+    embd, wd, h2d, tgtd, tidxd, Wd, bd = map(d, (emb, words, h2, tgt, tidx, W, b))
+    out = torch.full((N * S, 300), float("nan"), device=dev)
+    segs = [_seg(embd, Wd, 300, ia=wd), _seg(h2d, Wd[:, 300:], 512), _seg(tgtd, Wd[:, 812:], 128, ia=tidxd)]
+    _run([_prob(segs, S * N, 300, out, bias=bd, perm=(N, S))])
+    x = torch.cat([emb[words.long()], h2, tgt[tidx.long()]], 1).double()
+    ref = (x @ W.double().t() + b.double()).view(S, N, 300).transpose(0, 1).reshape(N * S, 300)
+    _close(out, ref, 940)
+
+
+def test_kmajor_operands_and_batched_problems(dev):
+    """dx = dy W (B k-major) and dW = dy^T x (both k-major) in ONE launch, as the GRU backward issues them"""
+    g = torch.Generator().manual_seed(5)
+    N, H, I = 32, 512, 300
+    dy, W, x = torch.randn(N, 3 * H, generator=g), torch.randn(3 * H, I, generator=g) / 20, torch.randn(N, I, generator=g)
+    dyd, Wd, xd = dy.to(dev), W.to(dev), x.to(dev)
+    dx = torch.full((N, I), float("nan"), device=dev)
+    dW = torch.full((3 * H, I), float("nan"), device=dev)
+    _run([_prob([_seg(dyd, Wd, 3 * H, b_km=True)], N, I, dx),
+          _prob([_seg(dyd, xd, N, a_km=True, b_km=True)], 3 * H, I, dW)])
+    _close(dx, dy.double() @ W.double(), 3 * H)
+    _close(dW, dy.double().t() @ x.double(), N)
+    # unaligned leading dimensions / K not a multiple of 4 (a vocabulary of 3001 words): scalar-load path
+    V = 3001
+    a, Bm = torch.randn(40, V, generator=g), torch.randn(24, V, generator=g)
+    ad, Bd = a.to(dev), Bm.to(dev)
+    out = torch.full((40, 24), float("nan"), device=dev)
+    _run([_prob([_seg(ad, Bd, V)], 40, 24, out)])
+    _close(out, a.double() @ Bm.double().t(), V)
+
+
+def test_colsum(dev):
+    from d3net_amd import _lib
+    x = torch.randn(992, 1536)
+    xd = x.to(dev)
+    out = torch.ones(1536, device=dev)
+    rc = _lib.lib().d3_colsum(C.c_void_p(xd.data_ptr()), 1536, 992, 1536, C.c_void_p(out.data_ptr()), 1,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    _close(out, x.double().sum(0) + 1, 992)
