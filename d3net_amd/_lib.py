@@ -87,6 +87,10 @@ SIGNATURES = {
     "d3_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_hgemm": (i32, [vp, i32, vp]),
     "d3_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "d3_topdown_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "d3_topdown_bwd_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
+    "d3_topdown_xe_forward": (i32, [vp, vp]),
+    "d3_topdown_xe_backward": (i32, [vp, vp, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "d3_prof_enable": (i32, [i32]),
     "d3_prof_collect": (i32, [i32, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -108,6 +112,23 @@ class GemmProb(C.Structure):
     """d3_gemm_prob (include/d3hip.h)"""
     _fields_ = [("seg", GemmSeg * 3), ("nseg", i32), ("M", i32), ("N", i32), ("C", vp), ("ldc", i64), ("bias", vp), ("add", vp),
                 ("ldadd", i64), ("relu", i32), ("accum", i32), ("perm_nb", i32), ("perm_s", i32)]
+
+
+TOPDOWN_PARAMS = ("W_td", "b_td", "Wih1", "Whh1", "bih1", "bhh1", "W_feat", "W_hidd", "w_att", "W_lang", "b_lang",
+                  "Wih2", "Whh2", "bih2", "bhh2", "Wc0", "bc0", "Wc2", "bc2")
+
+
+class TopdownArgs(C.Structure):
+    """d3_topdown_args (include/d3hip.h)"""
+    _fields_ = ([(k, i32) for k in ("N", "K", "S", "V", "H", "E", "F", "Tw")] +
+                [(k, vp) for k in ("word_ids", "emb", "target", "obj", "mask")] + [(k, vp) for k in TOPDOWN_PARAMS] +
+                [("logits", vp), ("attn", vp), ("ws", vp), ("ws_bytes", sz)])
+
+
+class TopdownGrads(C.Structure):
+    """d3_topdown_grads (include/d3hip.h)"""
+    _fields_ = ([("dlogits", vp)] + [("d" + k, vp) for k in TOPDOWN_PARAMS] +
+                [("dobj", vp), ("dtarget", vp), ("ws", vp), ("ws_bytes", sz)])
 
 
 def lib():

@@ -1,0 +1,610 @@
+// topdown.hip -- the top-down attention captioner of the speaker head as native gfx950 code: teacher-forced training
+// pass (forward + backward through time) and the step used by the greedy / evaluation decodes.
+//
+// Reference: model/caption_module.py:72-133 (`TopDownSceneCaptionModule.step`), :510-687 (`_forward_sample_batch`, the XE
+// driver).  One decode step there is
+//     x1 = map_topdown([emb[word], h2, target]);  h1 = GRUCell1(x1, h1)
+//     a  = softmax_k( attend . tanh(map_feat(obj)[k] + map_hidd(h1)) , masked scores := 0 );  att = sum_k a[k] obj[k]
+//     x2 = map_lang([att, h1]);  h2 = GRUCell2(x2, h2);  logits = classifier(h2)
+// issued as ~25 library kernels per step (31 steps, then ~2x that in the backward: ~4,000 launches per training step at
+// batch 32 -- 24 ms of the 74 ms PointGroup+speaker step, profiles/r02_a).  Restructured here without changing a result:
+//   * everything that does not depend on the recurrence is batched over the S time steps: the embedding + target part
+//     of map_topdown (a 3-segment GEMM with gathered rows), map_feat(obj), and the whole classifier (two GEMMs over
+//     S*N = 992 rows instead of 62 over 32 rows) -- teacher forcing makes every input word known up front;
+//   * a step is 6 launches: x1 GEMM (h2 segment + static addend), fused GRUCell (both gate GEMMs + gate math in one
+//     kernel), map_hidd GEMM, fused attention (tanh scores of the <= num_locals unmasked proposals only, softmax,
+//     weighted sum), map_lang GEMM (two segments, no concat), fused GRUCell;
+//   * backward through time: per step 8 launches (GRU gate backward, two data-gradient GEMMs sharing a launch, ...);
+//     all weight gradients are batched over time afterwards (k-major GEMMs with K = S*N rows), bias gradients are column
+//     sums; activations are kept (45 MB -- 288 GB of HBM: nothing is recomputed except the attention tanh);
+//   * the host loop is native: one C-ABI call for the forward, one for the backward.
+// Arithmetic: fp32 throughout (v_mfma_f32_16x16x4_f32 for the products: exact fp32), expf / tanhf from the device
+// library.  Results match the reference's own module to summation order (tests/test_speaker_gpu.py, golden vectors).
+// Roofline: launch / latency bound (0.3 GFLOP and ~20 MB of L2-resident weights per step); the measure is launches and
+// microseconds per step, reported by bench.py's profile.
+#include "common.h"
+#include <string.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s);
+int hg_colsum(const float *x, long long ld, int R, int C, float *out, int accum, hipStream_t s);
+
+// ------------------------------------------------------------------------------ fused GRUCell forward
+// h' = GRUCell(x, h) (torch.nn.GRUCell semantics: r, z, n gate order; n = tanh(W_in x + b_in + r * (W_hn h + b_hn))).
+// A workgroup owns 16 hidden units (the three gate rows j, H+j, 2H+j of both weight matrices) x RT*16 batch rows; its 4
+// waves split the K loop over [x | h] and are summed through LDS; the gate math runs on the reduced tile.
+struct GruArgs {
+    const float *x; long long ldx; int I;
+    const float *h; long long ldh;
+    const float *Wih, *Whh, *bih, *bhh;
+    float *hout; long long ldo;
+    float *r, *z, *n, *ghn;      // (N,H) each, kept for the backward (NULL: inference)
+    int N, H;
+};
+
+__device__ __forceinline__ f32x4 td_load4(const float *row, int k0, int K, bool valid) {
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!valid || k0 >= K) return v;
+    if (k0 + 3 < K) return *(const f32x4 *)(row + k0);
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (k0 + s < K) v[s] = row[k0 + s];
+    return v;
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void td_gru_fwd_kernel(const GruArgs a) {
+    __shared__ float red[4 * 4 * RT * 256];   // [wave][acc][rt][q][lane]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int ct = blockIdx.x, rg = blockIdx.y, H = a.H;
+    f32x4 accR[RT], accZ[RT], accNI[RT], accNH[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) { accR[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; accZ[r] = accR[r]; accNI[r] = accR[r]; accNH[r] = accR[r]; }
+    const int col = ct * 16 + i;           // hidden unit of this lane's B rows (H % 16 == 0: host check)
+    int gkb = 0;
+#pragma unroll
+    for (int seg = 0; seg < 2; seg++) {
+        const int K = seg == 0 ? a.I : H;
+        const float *X = seg == 0 ? a.x : a.h;
+        const long long ldx = seg == 0 ? a.ldx : a.ldh;
+        const float *W = seg == 0 ? a.Wih : a.Whh;
+        const int nkb = (K + 15) >> 4;
+        const float *xr[RT];
+        bool xv[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int row = (rg * RT + r) * 16 + i;
+            xv[r] = row < a.N;
+            xr[r] = X + (long long)(xv[r] ? row : 0) * ldx;
+        }
+        const float *w0 = W + (long long)col * K, *w1 = W + (long long)(H + col) * K, *w2 = W + (long long)(2 * H + col) * K;
+        const int first = (wave - gkb) & 3;
+        gkb += nkb;
+        constexpr int U = 2;
+        for (int kb0 = first; kb0 < nkb; kb0 += 4 * U) {
+            f32x4 xa[U][RT], b0[U], b1[U], b2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k0 = (kb0 + 4 * u) * 16 + g * 4;
+                const bool in = kb0 + 4 * u < nkb;
+                b0[u] = td_load4(w0, k0, K, in); b1[u] = td_load4(w1, k0, K, in); b2[u] = td_load4(w2, k0, K, in);
+#pragma unroll
+                for (int r = 0; r < RT; r++) xa[u][r] = td_load4(xr[r], k0, K, in && xv[r]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (kb0 + 4 * u < nkb) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int r = 0; r < RT; r++) {
+                            accR[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b0[u][q], accR[r], 0, 0, 0);
+                            accZ[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b1[u][q], accZ[r], 0, 0, 0);
+                            if (seg == 0) accNI[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b2[u][q], accNI[r], 0, 0, 0);
+                            else accNH[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b2[u][q], accNH[r], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            red[(((wave * 4 + 0) * RT + r) * 4 + q) * 64 + lane] = accR[r][q];
+            red[(((wave * 4 + 1) * RT + r) * 4 + q) * 64 + lane] = accZ[r][q];
+            red[(((wave * 4 + 2) * RT + r) * 4 + q) * 64 + lane] = accNI[r][q];
+            red[(((wave * 4 + 3) * RT + r) * 4 + q) * 64 + lane] = accNH[r][q];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < RT; nn++) {
+        const int e = t + nn * 256, r = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+        const int row = (rg * RT + r) * 16 + (ln >> 4) * 4 + q, c = ct * 16 + (ln & 15);
+        float s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) v += red[(((w * 4 + k) * RT + r) * 4 + q) * 64 + ln];
+            s[k] = v;
+        }
+        if (row >= a.N) continue;
+        const float rr = 1.f / (1.f + expf(-(s[0] + a.bih[c] + a.bhh[c])));
+        const float zz = 1.f / (1.f + expf(-(s[1] + a.bih[H + c] + a.bhh[H + c])));
+        const float gh = s[3] + a.bhh[2 * H + c];
+        const float nv = tanhf(s[2] + a.bih[2 * H + c] + rr * gh);
+        const float hp = a.h[(long long)row * a.ldh + c];
+        a.hout[(long long)row * a.ldo + c] = (1.f - zz) * nv + zz * hp;
+        if (a.r) {
+            const long long o = (long long)row * H + c;
+            a.r[o] = rr; a.z[o] = zz; a.n[o] = nv; a.ghn[o] = gh;
+        }
+    }
+}
+
+static int td_gru_fwd(const GruArgs &a, hipStream_t s) {
+    if (a.H & 15) return D3_ERR_ARG;
+    if (a.N <= 0) return 0;
+    if (a.N <= 16) td_gru_fwd_kernel<1><<<dim3(a.H / 16, 1), 256, 0, s>>>(a);
+    else td_gru_fwd_kernel<2><<<dim3(a.H / 16, (a.N + 31) / 32), 256, 0, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// GRUCell backward, gate part: dh' = d0 + d1 + d2 (up to three contributions, NULL = none) ->
+//   dgi (N,3H) = [dr_pre, dz_pre, dn_pre], dgh (N,3H) = [dr_pre, dz_pre, dn_pre * r], dhp (N,H) = dh' * z
+__global__ void td_gru_bwd_gates_kernel(const float *d0, long long ld0, const float *d1, long long ld1, const float *d2, long long ld2,
+                                        const float *__restrict__ r, const float *__restrict__ z, const float *__restrict__ n,
+                                        const float *__restrict__ ghn, const float *__restrict__ hp, long long ldh,
+                                        float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dhp, int N, int H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * H) return;
+    const int row = e / H, c = e - row * H;
+    float dh = 0.f;
+    if (d0) dh += d0[(long long)row * ld0 + c];
+    if (d1) dh += d1[(long long)row * ld1 + c];
+    if (d2) dh += d2[(long long)row * ld2 + c];
+    const float rr = r[e], zz = z[e], nv = n[e];
+    const float dn = dh * (1.f - zz), dz = dh * (hp[(long long)row * ldh + c] - nv);
+    const float dnp = dn * (1.f - nv * nv);
+    const float drp = dnp * ghn[e] * rr * (1.f - rr);
+    const float dzp = dz * zz * (1.f - zz);
+    const long long o = (long long)row * 3 * H + c;
+    dgi[o] = drp; dgi[o + H] = dzp; dgi[o + 2 * H] = dnp;
+    dgh[o] = drp; dgh[o + H] = dzp; dgh[o + 2 * H] = dnp * rr;
+    dhp[e] = dh * zz;
+}
+
+// ------------------------------------------------------------------------------ top-down attention
+// One workgroup per sample: scores of the unmasked proposals (masked scores are 0 -- `masked_fill_(mask == 0, 0)`, not
+// -inf: caption_module.py:112-114 -- so only the <= num_locals unmasked ones need the 512-wide tanh), softmax over all K,
+// attended feature.  attn_out: (N, K, S) slice t of `topdown_attn` (NULL: not wanted).
+__global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
+                                                          const float *__restrict__ watt, const float *__restrict__ obj,
+                                                          const float *__restrict__ mask, float *__restrict__ a_out,
+                                                          float *__restrict__ att, long long ldatt, float *__restrict__ attn_out,
+                                                          int t_step, int S, int K, int H, int F) {
+    extern __shared__ float sm[];
+    float *qs = sm, *ws = qs + H, *sc = ws + H, *part = sc + K;   // part: 2*F
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int c = t; c < H; c += 256) { qs[c] = q[(long long)n * ldq + c]; ws[c] = watt[c]; }
+    __syncthreads();
+    for (int k = wave; k < K; k += 4) {
+        float s = 0.f;
+        if (mask[(long long)n * K + k] != 0.f) {    // wave-uniform
+            const float *row = fp + ((long long)n * K + k) * H;
+            for (int c = lane * 4; c < H; c += 256) {
+                const f32x4 v = *(const f32x4 *)(row + c);
+#pragma unroll
+                for (int j = 0; j < 4; j++) s += ws[c + j] * tanhf(v[j] + qs[c + j]);
+            }
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        }
+        if (lane == 0) sc[k] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {   // softmax over the K proposals
+        float mx = -3.0e38f;
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, sc[k]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int k = lane; k < K; k += 64) { const float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int k = lane; k < K; k += 64) {
+            const float p = sc[k] * inv;
+            sc[k] = p;
+            a_out[(long long)n * K + k] = p;
+            if (attn_out) attn_out[((long long)n * K + k) * S + t_step] = p;
+        }
+    }
+    __syncthreads();
+    // attended[c] = sum_k a[k] obj[n,k,c]: two halves of k per column, fixed order
+    const int half = t / F, c = t - half * F;
+    float s = 0.f;
+    if (half < 2) {
+        const int k0 = half * ((K + 1) / 2), k1 = min(K, k0 + (K + 1) / 2);
+        for (int k = k0; k < k1; k++) s += sc[k] * obj[((long long)n * K + k) * F + c];
+        part[half * F + c] = s;
+    }
+    __syncthreads();
+    if (t < F) att[(long long)n * ldatt + t] = part[t] + part[F + t];
+}
+
+// backward of the above for one step: datt (N,F) -> dq (N,H), dfp (N,K,H) +=, dobj (N,K,F) +=, dwpart row (H)
+__global__ __launch_bounds__(256) void td_attn_bwd_kernel(const float *__restrict__ datt, long long lddatt, const float *__restrict__ a_in,
+                                                          const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
+                                                          const float *__restrict__ watt, const float *__restrict__ obj,
+                                                          const float *__restrict__ mask, float *__restrict__ dq, long long lddq,
+                                                          float *__restrict__ dfp, float *__restrict__ dobj, float *__restrict__ dwpart,
+                                                          int K, int H, int F) {
+    extern __shared__ float sm[];
+    float *das = sm, *dss = das + K, *as = dss + K, *dat = as + K, *red = dat + F;   // red: 4
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int c = t; c < F; c += 256) dat[c] = datt[(long long)n * lddatt + c];
+    for (int k = t; k < K; k += 256) as[k] = a_in[(long long)n * K + k];
+    __syncthreads();
+    for (int k = wave; k < K; k += 4) {     // da[k] = datt . obj[k];  dobj[k] += a[k] * datt
+        const float ak = as[k];
+        float s = 0.f;
+        for (int c = lane; c < F; c += 64) {
+            const long long o = ((long long)n * K + k) * F + c;
+            s += dat[c] * obj[o];
+            dobj[o] += ak * dat[c];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) das[k] = s;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int k = t; k < K; k += 256) dot += as[k] * das[k];
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    for (int k = t; k < K; k += 256) dss[k] = mask[(long long)n * K + k] != 0.f ? as[k] * (das[k] - dot) : 0.f;
+    __syncthreads();
+    for (int c = t; c < H; c += 256) {
+        const float qc = q[(long long)n * ldq + c], wc = watt[c];
+        float dqa = 0.f, dwa = 0.f;
+        for (int k = 0; k < K; k++) {
+            const float ds = dss[k];
+            if (ds == 0.f) continue;        // masked proposals (and exact zeros) contribute nothing
+            const long long o = ((long long)n * K + k) * H + c;
+            const float th = tanhf(fp[o] + qc);
+            const float dp = ds * wc * (1.f - th * th);
+            dfp[o] += dp;
+            dqa += dp; dwa += ds * th;
+        }
+        dq[(long long)n * lddq + c] = dqa;
+        dwpart[(long long)n * H + c] = dwa;
+    }
+}
+
+// ------------------------------------------------------------------------------ small helpers
+__global__ void td_rows_kernel(const long long *__restrict__ word_ids, int Tw, int N, int S, int *__restrict__ widx, int *__restrict__ nidx,
+                               int *__restrict__ bidx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;   // time-major row r = t * N + n
+    if (r >= S * N) return;
+    const int tt = r / N, n = r - tt * N;
+    widx[r] = (int)word_ids[(long long)n * Tw + tt];
+    nidx[r] = n;
+    bidx[r] = n * S + tt;                                  // the same row in batch-major order
+}
+// dst[r, :] = src[idx[r], :]  (time-major copies of batch-major / vocabulary-indexed rows)
+__global__ void td_gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ idx, float *__restrict__ dst, long long R, int C) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * C) return;
+    const long long r = e / C;
+    const int c = (int)(e - r * C);
+    dst[e] = src[(long long)idx[r] * C + c];
+}
+// dst = relu'(c0) * src (in place allowed)
+__global__ void td_relu_mask_kernel(float *__restrict__ d, const float *__restrict__ c0, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && c0[e] <= 0.f) d[e] = 0.f;
+}
+// out[n, c] = sum_t x[(t*N + n), c]
+__global__ void td_sum_time_kernel(const float *__restrict__ x, float *__restrict__ out, int S, int N, int C) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * C) return;
+    float s = 0.f;
+    for (int tt = 0; tt < S; tt++) s += x[(long long)tt * N * C + e];
+    out[e] = s;
+}
+
+static d3_gemm_seg td_seg(const float *A, long long lda, const float *B, long long ldb, int K, const int *ia = nullptr, int akm = 0, int bkm = 0) {
+    d3_gemm_seg s;
+    s.A = A; s.ia = ia; s.lda = lda; s.a_kmajor = akm; s.B = B; s.ldb = ldb; s.b_kmajor = bkm; s.K = K;
+    return s;
+}
+static d3_gemm_prob td_prob(int M, int N, float *C, long long ldc) {
+    d3_gemm_prob p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.N = N; p.C = C; p.ldc = ldc;
+    return p;
+}
+
+// ------------------------------------------------------------------------------ workspace layout
+struct TdLayout {
+    size_t widx, nidx, bidx, fp, TD, x1, x2, H1, H2, g1, g2, q, a, att, c0, total;   // byte offsets; g1/g2: r,z,n,ghn blocks
+};
+static TdLayout td_layout(int N, int K, int S, int H, int E, int F) {
+    TdLayout L;
+    size_t o = 0;
+    const size_t R = (size_t)S * N;
+    auto take = [&](size_t bytes) { size_t at = o; o += d3_align(bytes); return at; };
+    L.widx = take(R * 4); L.nidx = take(R * 4); L.bidx = take(R * 4);
+    L.fp = take((size_t)N * K * H * 4);
+    L.TD = take(R * E * 4); L.x1 = take(R * E * 4); L.x2 = take(R * E * 4);
+    L.H1 = take((R + N) * H * 4); L.H2 = take((R + N) * H * 4);
+    L.g1 = take(4 * R * H * 4); L.g2 = take(4 * R * H * 4);
+    L.q = take(R * H * 4); L.a = take(R * K * 4); L.att = take(R * F * 4); L.c0 = take(R * H * 4);
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t d3_topdown_ws_bytes(int N, int K, int S, int H, int E, int F) {
+    return td_layout(N, K, S, H, E, F).total;
+}
+
+static int td_check(const d3_topdown_args *a) {
+    if (!a || a->N < 1 || a->K < 1 || a->S < 1 || a->V < 1) return D3_ERR_ARG;
+    if ((a->H & 15) || (a->E & 3) || (a->F & 3) || a->F > 128 || a->K > 1024) return D3_ERR_ARG;
+    if (a->ws_bytes < td_layout(a->N, a->K, a->S, a->H, a->E, a->F).total) return D3_ERR_WORKSPACE;
+    return 0;
+}
+
+// Teacher-forced forward over S steps (model/caption_module.py:636-668): logits (N,S,V), attn (N,K,S).
+extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
+    D3_CLEAR();
+    int rc = td_check(a);
+    if (rc) return rc;
+    hipStream_t s = d3_stream(stream);
+    const int N = a->N, K = a->K, S = a->S, V = a->V, H = a->H, E = a->E, F = a->F, R = S * N;
+    const TdLayout L = td_layout(N, K, S, H, E, F);
+    char *ws = (char *)a->ws;
+    int *widx = (int *)(ws + L.widx), *nidx = (int *)(ws + L.nidx), *bidx = (int *)(ws + L.bidx);
+    float *fp = (float *)(ws + L.fp), *TD = (float *)(ws + L.TD), *x1 = (float *)(ws + L.x1), *x2 = (float *)(ws + L.x2);
+    float *H1 = (float *)(ws + L.H1), *H2 = (float *)(ws + L.H2), *g1 = (float *)(ws + L.g1), *g2 = (float *)(ws + L.g2);
+    float *q = (float *)(ws + L.q), *av = (float *)(ws + L.a), *att = (float *)(ws + L.att), *c0 = (float *)(ws + L.c0);
+    const long long ldtd = H + F + E;          // map_topdown weight: (E, E + H + F) over [emb | h2 | target]
+    const long long ldlang = F + H;            // map_lang weight: (E, F + H) over [attended | h1]
+    td_rows_kernel<<<(R + 255) / 256, 256, 0, s>>>(a->word_ids, a->Tw, N, S, widx, nidx, bidx);
+    D3_CHECK(hipMemsetAsync(H1, 0, (size_t)N * H * 4, s));
+    D3_CHECK(hipMemsetAsync(H2, 0, (size_t)N * H * 4, s));
+    {   // batched, recurrence-free parts: map_feat(obj) and the [embedding | target] part of map_topdown (+ bias)
+        d3_gemm_prob p[2];
+        p[0] = td_prob(N * K, H, fp, H);
+        p[0].nseg = 1; p[0].seg[0] = td_seg(a->obj, F, a->W_feat, F, F);
+        p[1] = td_prob(R, E, TD, E);
+        p[1].nseg = 2;
+        p[1].seg[0] = td_seg(a->emb, E, a->W_td, ldtd, E, widx);
+        p[1].seg[1] = td_seg(a->target, F, a->W_td + E + H, ldtd, F, nidx);
+        p[1].bias = a->b_td;
+        if ((rc = hg_launch(&p[0], 1, s))) return rc;
+        if ((rc = hg_launch(&p[1], 1, s))) return rc;
+    }
+    const size_t RH = (size_t)R * H;
+    for (int t = 0; t < S; t++) {
+        const size_t rN = (size_t)t * N;
+        float *h1p = H1 + rN * H, *h1n = H1 + (rN + N) * H, *h2p = H2 + rN * H, *h2n = H2 + (rN + N) * H;
+        {   // x1 = TD[t] + h2 W_td[:, E:E+H]^T
+            d3_gemm_prob p = td_prob(N, E, x1 + rN * E, E);
+            p.nseg = 1; p.seg[0] = td_seg(h2p, H, a->W_td + E, ldtd, H);
+            p.add = TD + rN * E; p.ldadd = E;
+            if ((rc = hg_launch(&p, 1, s))) return rc;
+        }
+        {
+            GruArgs g{x1 + rN * E, E, E, h1p, H, a->Wih1, a->Whh1, a->bih1, a->bhh1, h1n, H,
+                      g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H, g1 + 3 * RH + rN * H, N, H};
+            if ((rc = td_gru_fwd(g, s))) return rc;
+        }
+        {   // q = map_hidd(h1)
+            d3_gemm_prob p = td_prob(N, H, q + rN * H, H);
+            p.nseg = 1; p.seg[0] = td_seg(h1n, H, a->W_hidd, H, H);
+            if ((rc = hg_launch(&p, 1, s))) return rc;
+        }
+        td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, a->mask, av + rN * K,
+                                                                         att + rN * F, F, a->attn, t, S, K, H, F);
+        {   // x2 = map_lang([attended | h1])
+            d3_gemm_prob p = td_prob(N, E, x2 + rN * E, E);
+            p.nseg = 2;
+            p.seg[0] = td_seg(att + rN * F, F, a->W_lang, ldlang, F);
+            p.seg[1] = td_seg(h1n, H, a->W_lang + F, ldlang, H);
+            p.bias = a->b_lang;
+            if ((rc = hg_launch(&p, 1, s))) return rc;
+        }
+        {
+            GruArgs g{x2 + rN * E, E, E, h2p, H, a->Wih2, a->Whh2, a->bih2, a->bhh2, h2n, H,
+                      g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H, g2 + 3 * RH + rN * H, N, H};
+            if ((rc = td_gru_fwd(g, s))) return rc;
+        }
+    }
+    {   // classifier over all steps: c0 = relu(h2 Wc0^T + b), logits (batch-major rows) = c0 Wc2^T + b
+        d3_gemm_prob p = td_prob(R, H, c0, H);
+        p.nseg = 1; p.seg[0] = td_seg(H2 + (size_t)N * H, H, a->Wc0, H, H);
+        p.bias = a->bc0; p.relu = 1;
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+        d3_gemm_prob p2 = td_prob(R, V, a->logits, V);
+        p2.nseg = 1; p2.seg[0] = td_seg(c0, H, a->Wc2, H, H);
+        p2.bias = a->bc2; p2.perm_nb = N; p2.perm_s = S;
+        if ((rc = hg_launch(&p2, 1, s))) return rc;
+    }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ backward through time
+struct TdBwdLayout { size_t dlog, dc0, dH2, dgi1, dgh1, dgi2, dgh2, dx1, dx2, dq, tmpL, dh1q, dh1c, dh2c, dfp, dwp, dx1s, total; };
+static TdBwdLayout td_bwd_layout(int N, int K, int S, int V, int H, int E, int F) {
+    TdBwdLayout L;
+    size_t o = 0;
+    const size_t R = (size_t)S * N;
+    auto take = [&](size_t bytes) { size_t at = o; o += d3_align(bytes); return at; };
+    L.dlog = take(R * V * 4); L.dc0 = take(R * H * 4); L.dH2 = take(R * H * 4);
+    L.dgi1 = take(R * 3 * H * 4); L.dgh1 = take(R * 3 * H * 4); L.dgi2 = take(R * 3 * H * 4); L.dgh2 = take(R * 3 * H * 4);
+    L.dx1 = take(R * E * 4); L.dx2 = take(R * E * 4); L.dq = take(R * H * 4);
+    L.tmpL = take((size_t)N * (F + H) * 4); L.dh1q = take((size_t)N * H * 4); L.dh1c = take((size_t)N * H * 4); L.dh2c = take((size_t)N * H * 4);
+    L.dfp = take((size_t)N * K * H * 4); L.dwp = take(R * H * 4); L.dx1s = take((size_t)N * E * 4);
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t d3_topdown_bwd_ws_bytes(int N, int K, int S, int V, int H, int E, int F) {
+    return td_bwd_layout(N, K, S, V, H, E, F).total;
+}
+
+// dlogits (N,S,V) -> every parameter gradient (written), dobj (N,K,F) and dtarget (N,F) (written).
+extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown_grads *gd, void *stream) {
+    D3_CLEAR();
+    int rc = td_check(a);
+    if (rc) return rc;
+    if (!gd || !gd->dlogits || !gd->ws) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    const int N = a->N, K = a->K, S = a->S, V = a->V, H = a->H, E = a->E, F = a->F, R = S * N;
+    const TdLayout L = td_layout(N, K, S, H, E, F);
+    const TdBwdLayout B = td_bwd_layout(N, K, S, V, H, E, F);
+    if (gd->ws_bytes < B.total) return D3_ERR_WORKSPACE;
+    char *ws = (char *)a->ws, *bw = (char *)gd->ws;
+    int *widx = (int *)(ws + L.widx), *bidx = (int *)(ws + L.bidx);
+    float *fp = (float *)(ws + L.fp), *x1 = (float *)(ws + L.x1), *x2 = (float *)(ws + L.x2);
+    float *H1 = (float *)(ws + L.H1), *H2 = (float *)(ws + L.H2), *g1 = (float *)(ws + L.g1), *g2 = (float *)(ws + L.g2);
+    float *q = (float *)(ws + L.q), *av = (float *)(ws + L.a), *att = (float *)(ws + L.att), *c0 = (float *)(ws + L.c0);
+    float *dlog = (float *)(bw + B.dlog), *dc0 = (float *)(bw + B.dc0), *dH2 = (float *)(bw + B.dH2);
+    float *dgi1 = (float *)(bw + B.dgi1), *dgh1 = (float *)(bw + B.dgh1), *dgi2 = (float *)(bw + B.dgi2), *dgh2 = (float *)(bw + B.dgh2);
+    float *dx1 = (float *)(bw + B.dx1), *dx2 = (float *)(bw + B.dx2), *dq = (float *)(bw + B.dq), *tmpL = (float *)(bw + B.tmpL);
+    float *dh1q = (float *)(bw + B.dh1q), *dh1c = (float *)(bw + B.dh1c), *dh2c = (float *)(bw + B.dh2c);
+    float *dfp = (float *)(bw + B.dfp), *dwp = (float *)(bw + B.dwp), *dx1s = (float *)(bw + B.dx1s);
+    const long long ldtd = H + F + E, ldlang = F + H;
+    const size_t RH = (size_t)R * H;
+    // ---- classifier (batched over time).  dlog: time-major copy of dlogits (gathered rows), then
+    //      dWc2 = dlog^T c0, dc0 = dlog Wc2 (relu-masked), dWc0 = dc0^T h2, dH2 = dc0 Wc0
+    {
+        d3_gemm_prob p = td_prob(R, H, dc0, H);
+        p.nseg = 1; p.seg[0] = td_seg(gd->dlogits, V, a->Wc2, H, V, bidx, 0, 1);
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+        td_relu_mask_kernel<<<(int)((RH + 255) / 256), 256, 0, s>>>(dc0, c0, (long long)RH);
+    }
+    {
+        // time-major copy of dlogits for the k-major weight gradient (both operands must walk the rows in the same order)
+        const long long tot = (long long)R * V;
+        td_gather_rows_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(gd->dlogits, bidx, dlog, R, V);
+        d3_gemm_prob p[3];
+        p[0] = td_prob(V, H, gd->dWc2, H);
+        p[0].nseg = 1; p[0].seg[0] = td_seg(dlog, V, c0, H, R, nullptr, 1, 1);
+        p[1] = td_prob(H, H, gd->dWc0, H);
+        p[1].nseg = 1; p[1].seg[0] = td_seg(dc0, H, H2 + (size_t)N * H, H, R, nullptr, 1, 1);
+        p[2] = td_prob(R, H, dH2, H);
+        p[2].nseg = 1; p[2].seg[0] = td_seg(dc0, H, a->Wc0, H, H, nullptr, 0, 1);
+        if ((rc = hg_launch(&p[0], 1, s))) return rc;
+        if ((rc = hg_launch(&p[1], 1, s))) return rc;
+        if ((rc = hg_launch(&p[2], 1, s))) return rc;
+        if ((rc = hg_colsum(dlog, V, R, V, gd->dbc2, 0, s))) return rc;
+        if ((rc = hg_colsum(dc0, H, R, H, gd->dbc0, 0, s))) return rc;
+    }
+    D3_CHECK(hipMemsetAsync(dh1c, 0, (size_t)N * H * 4, s));
+    D3_CHECK(hipMemsetAsync(dh2c, 0, (size_t)N * H * 4, s));
+    D3_CHECK(hipMemsetAsync(dfp, 0, (size_t)N * K * H * 4, s));
+    D3_CHECK(hipMemsetAsync(gd->dobj, 0, (size_t)N * K * F * 4, s));
+    const int nh = (N * H + 255) / 256;
+    for (int t = S - 1; t >= 0; t--) {
+        const size_t rN = (size_t)t * N;
+        float *h1p = H1 + rN * H, *h1n = H1 + (rN + N) * H, *h2p = H2 + rN * H;
+        // GRU2 gates: dh2[t+1] = classifier part + carry from step t+1
+        td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dH2 + rN * H, H, dh2c, H, nullptr, 0, g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H,
+                                                   g2 + 3 * RH + rN * H, h2p, H, dgi2 + rN * 3 * H, dgh2 + rN * 3 * H, dh2c, N, H);
+        {   // dh2c += dgh2 Whh2 ; dx2 = dgi2 Wih2   (one launch)
+            d3_gemm_prob p[2];
+            p[0] = td_prob(N, H, dh2c, H);
+            p[0].nseg = 1; p[0].seg[0] = td_seg(dgh2 + rN * 3 * H, 3 * H, a->Whh2, H, 3 * H, nullptr, 0, 1); p[0].accum = 1;
+            p[1] = td_prob(N, E, dx2 + rN * E, E);
+            p[1].nseg = 1; p[1].seg[0] = td_seg(dgi2 + rN * 3 * H, 3 * H, a->Wih2, E, 3 * H, nullptr, 0, 1);
+            if ((rc = hg_launch(p, 2, s))) return rc;
+        }
+        {   // [datt | dh1 part] = dx2 W_lang
+            d3_gemm_prob p = td_prob(N, F + H, tmpL, F + H);
+            p.nseg = 1; p.seg[0] = td_seg(dx2 + rN * E, E, a->W_lang, ldlang, E, nullptr, 0, 1);
+            if ((rc = hg_launch(&p, 1, s))) return rc;
+        }
+        td_attn_bwd_kernel<<<N, 256, (size_t)(3 * K + F + 4) * 4, s>>>(tmpL, F + H, av + rN * K, fp, q + rN * H, H, a->w_att, a->obj, a->mask,
+                                                                     dq + rN * H, H, dfp, gd->dobj, dwp + rN * H, K, H, F);
+        {   // dh1 (through map_hidd) = dq W_hidd
+            d3_gemm_prob p = td_prob(N, H, dh1q, H);
+            p.nseg = 1; p.seg[0] = td_seg(dq + rN * H, H, a->W_hidd, H, H, nullptr, 0, 1);
+            if ((rc = hg_launch(&p, 1, s))) return rc;
+        }
+        td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dh1c, H, tmpL + F, F + H, dh1q, H, g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H,
+                                                   g1 + 3 * RH + rN * H, h1p, H, dgi1 + rN * 3 * H, dgh1 + rN * 3 * H, dh1c, N, H);
+        {   // dh1c += dgh1 Whh1 ; dx1 = dgi1 Wih1
+            d3_gemm_prob p[2];
+            p[0] = td_prob(N, H, dh1c, H);
+            p[0].nseg = 1; p[0].seg[0] = td_seg(dgh1 + rN * 3 * H, 3 * H, a->Whh1, H, 3 * H, nullptr, 0, 1); p[0].accum = 1;
+            p[1] = td_prob(N, E, dx1 + rN * E, E);
+            p[1].nseg = 1; p[1].seg[0] = td_seg(dgi1 + rN * 3 * H, 3 * H, a->Wih1, E, 3 * H, nullptr, 0, 1);
+            if ((rc = hg_launch(p, 2, s))) return rc;
+        }
+        {   // dh2c += dx1 W_td[:, E:E+H]
+            d3_gemm_prob p = td_prob(N, H, dh2c, H);
+            p.nseg = 1; p.seg[0] = td_seg(dx1 + rN * E, E, a->W_td + E, ldtd, E, nullptr, 0, 1); p.accum = 1;
+            if ((rc = hg_launch(&p, 1, s))) return rc;
+        }
+        (void)h1n;
+    }
+    // ---- weight gradients, batched over time (k-major operands, K = R rows)
+    {
+        d3_gemm_prob p[4];
+        // GRU cells
+        p[0] = td_prob(3 * H, E, gd->dWih2, E); p[0].nseg = 1; p[0].seg[0] = td_seg(dgi2, 3 * H, x2, E, R, nullptr, 1, 1);
+        p[1] = td_prob(3 * H, H, gd->dWhh2, H); p[1].nseg = 1; p[1].seg[0] = td_seg(dgh2, 3 * H, H2, H, R, nullptr, 1, 1);
+        p[2] = td_prob(3 * H, E, gd->dWih1, E); p[2].nseg = 1; p[2].seg[0] = td_seg(dgi1, 3 * H, x1, E, R, nullptr, 1, 1);
+        p[3] = td_prob(3 * H, H, gd->dWhh1, H); p[3].nseg = 1; p[3].seg[0] = td_seg(dgh1, 3 * H, H1, H, R, nullptr, 1, 1);
+        if ((rc = hg_launch(p, 4, s))) return rc;
+        if ((rc = hg_colsum(dgi2, 3 * H, R, 3 * H, gd->dbih2, 0, s))) return rc;
+        if ((rc = hg_colsum(dgh2, 3 * H, R, 3 * H, gd->dbhh2, 0, s))) return rc;
+        if ((rc = hg_colsum(dgi1, 3 * H, R, 3 * H, gd->dbih1, 0, s))) return rc;
+        if ((rc = hg_colsum(dgh1, 3 * H, R, 3 * H, gd->dbhh1, 0, s))) return rc;
+    }
+    {
+        // map_lang: dW (E, F+H) = dx2^T [att | h1[1:]] ; map_hidd: dW = dq^T h1[1:] ; map_topdown: dW (E, E+H+F) = dx1^T [emb[w] | h2[:-1] | target]
+        d3_gemm_prob p[4];
+        p[0] = td_prob(E, F, gd->dW_lang, ldlang); p[0].nseg = 1; p[0].seg[0] = td_seg(dx2, E, att, F, R, nullptr, 1, 1);
+        p[1] = td_prob(E, H, gd->dW_lang + F, ldlang); p[1].nseg = 1; p[1].seg[0] = td_seg(dx2, E, H1 + (size_t)N * H, H, R, nullptr, 1, 1);
+        p[2] = td_prob(H, H, gd->dW_hidd, H); p[2].nseg = 1; p[2].seg[0] = td_seg(dq, H, H1 + (size_t)N * H, H, R, nullptr, 1, 1);
+        p[3] = td_prob(E, H, gd->dW_td + E, ldtd); p[3].nseg = 1; p[3].seg[0] = td_seg(dx1, E, H2, H, R, nullptr, 1, 1);
+        if ((rc = hg_launch(p, 4, s))) return rc;
+        if ((rc = hg_colsum(dx2, E, R, E, gd->db_lang, 0, s))) return rc;
+        if ((rc = hg_colsum(dx1, E, R, E, gd->db_td, 0, s))) return rc;
+        if ((rc = hg_colsum(dwp, H, R, H, gd->dw_att, 0, s))) return rc;
+    }
+    {
+        // embedding / target parts of map_topdown need gathered k-major rows: materialise the two gathered matrices once
+        // (R x E and the time-sum trick for the target: sum_t dx1[t] is enough because the target feature is constant in t)
+        td_sum_time_kernel<<<(N * E + 255) / 256, 256, 0, s>>>(dx1, dx1s, S, N, E);
+        d3_gemm_prob p[3];
+        // dW_td[:, E+H:] = dx1s^T target  (K = N rows)
+        p[0] = td_prob(E, F, gd->dW_td + E + H, ldtd); p[0].nseg = 1; p[0].seg[0] = td_seg(dx1s, E, a->target, F, N, nullptr, 1, 1);
+        // dtarget = dx1s W_td[:, E+H:]
+        p[1] = td_prob(N, F, gd->dtarget, F); p[1].nseg = 1; p[1].seg[0] = td_seg(dx1s, E, a->W_td + E + H, ldtd, E, nullptr, 0, 1);
+        // map_feat: dW_feat (H, F) = dfp^T obj (K = N*K rows)
+        p[2] = td_prob(H, F, gd->dW_feat, F); p[2].nseg = 1; p[2].seg[0] = td_seg(dfp, H, a->obj, F, N * K, nullptr, 1, 1);
+        if ((rc = hg_launch(p, 3, s))) return rc;
+        // dobj += dfp W_feat
+        d3_gemm_prob po = td_prob(N * K, F, gd->dobj, F);
+        po.nseg = 1; po.seg[0] = td_seg(dfp, H, a->W_feat, F, H, nullptr, 0, 1); po.accum = 1;
+        if ((rc = hg_launch(&po, 1, s))) return rc;
+    }
+    {
+        // dW_td[:, :E] = dx1^T emb[words]: k-major B with gathered rows is not a GEMM operand form; the embedding rows of the
+        // R tokens are gathered into x-space first (R x E floats, reusing the dlog buffer which is dead by now)
+        float *embg = dlog;
+        const long long tot = (long long)R * E;
+        td_gather_rows_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(a->emb, widx, embg, R, E);
+        d3_gemm_prob p = td_prob(E, E, gd->dW_td, ldtd);
+        p.nseg = 1; p.seg[0] = td_seg(dx1, E, embg, E, R, nullptr, 1, 1);
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    D3_LAUNCH_CHECK();
+    return 0;
+}

@@ -126,6 +126,66 @@ class GraphModule(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------- captioner
+_TD_KEYS = {"W_td": "map_topdown.weight", "b_td": "map_topdown.bias", "Wih1": "recurrent_cell_1.weight_ih",
+            "Whh1": "recurrent_cell_1.weight_hh", "bih1": "recurrent_cell_1.bias_ih", "bhh1": "recurrent_cell_1.bias_hh",
+            "W_feat": "map_feat.weight", "W_hidd": "map_hidd.weight", "w_att": "attend.weight", "W_lang": "map_lang.weight",
+            "b_lang": "map_lang.bias", "Wih2": "recurrent_cell_2.weight_ih", "Whh2": "recurrent_cell_2.weight_hh",
+            "bih2": "recurrent_cell_2.bias_ih", "bhh2": "recurrent_cell_2.bias_hh", "Wc0": "classifier.0.weight",
+            "bc0": "classifier.0.bias", "Wc2": "classifier.2.weight", "bc2": "classifier.2.bias"}
+
+
+class TopDownXEFunction(torch.autograd.Function):
+    """The teacher-forced captioner pass (caption_module.py:636-668: S x `step`) as ONE native call each way
+    (csrc/topdown.hip: d3_topdown_xe_forward / _backward).  Inputs: obj_feats (N,K,F), target_feats (N,F), then the 19
+    parameters in `_lib.TOPDOWN_PARAMS` order; non-differentiable: embeddings (V,E), word_ids (N,Tw) int64, masks (N,K), S.
+    Returns logits (N,S,V) and the attention maps (N,K,S) (`topdown_attn`, not differentiated -- no loss reads it)."""
+
+    @staticmethod
+    def forward(ctx, emb, word_ids, masks, S, obj_feats, target_feats, *params):
+        L = _lib.lib()
+        obj_feats, target_feats, masks = obj_feats.contiguous(), target_feats.contiguous(), masks.contiguous().float()
+        word_ids = word_ids.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        N, K, F_ = obj_feats.shape
+        V, E = emb.shape
+        H = params[_lib.TOPDOWN_PARAMS.index("W_hidd")].shape[0]
+        dev = obj_feats.device
+        a = _lib.TopdownArgs()
+        a.N, a.K, a.S, a.V, a.H, a.E, a.F, a.Tw = N, K, S, V, H, E, F_, word_ids.shape[1]
+        a.word_ids, a.emb, a.target, a.obj, a.mask = (t.data_ptr() for t in (word_ids, emb, target_feats, obj_feats, masks))
+        for k, p in zip(_lib.TOPDOWN_PARAMS, params):
+            setattr(a, k, p.data_ptr())
+        logits = torch.empty((N, S, V), dtype=torch.float32, device=dev)
+        attn = torch.empty((N, K, S), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.d3_topdown_ws_bytes(N, K, S, H, E, F_), dtype=torch.uint8, device=dev)
+        a.logits, a.attn, a.ws, a.ws_bytes = logits.data_ptr(), attn.data_ptr(), ws.data_ptr(), ws.numel()
+        with _on(dev):
+            check(L.d3_topdown_xe_forward(C.byref(a), _stream()), "topdown_xe_forward")
+        ctx.args = a
+        ctx.keep = (emb, word_ids, masks, obj_feats, target_feats, params, ws)
+        ctx.mark_non_differentiable(attn)
+        return logits, attn
+
+    @staticmethod
+    def backward(ctx, dlogits, _dattn):
+        L = _lib.lib()
+        a = ctx.args
+        emb, word_ids, masks, obj_feats, target_feats, params, ws = ctx.keep
+        dev = obj_feats.device
+        dlogits = dlogits.contiguous()
+        g = _lib.TopdownGrads()
+        g.dlogits = dlogits.data_ptr()
+        grads = [torch.empty_like(p) for p in params]
+        for k, t in zip(_lib.TOPDOWN_PARAMS, grads):
+            setattr(g, "d" + k, t.data_ptr())
+        dobj, dtarget = torch.empty_like(obj_feats), torch.empty_like(target_feats)
+        ws2 = torch.empty(L.d3_topdown_bwd_ws_bytes(a.N, a.K, a.S, a.V, a.H, a.E, a.F), dtype=torch.uint8, device=dev)
+        g.dobj, g.dtarget, g.ws, g.ws_bytes = dobj.data_ptr(), dtarget.data_ptr(), ws2.data_ptr(), ws2.numel()
+        with _on(dev):
+            check(L.d3_topdown_xe_backward(C.byref(a), C.byref(g), _stream()), "topdown_xe_backward")
+        return (None, None, None, None, dobj, dtarget) + tuple(grads)
+
+
 def _aabb_iou(c1, c2):
     """lib/utils/bbox.py:247-271 on (...,8,3) tensors"""
     mn1, mx1, mn2, mx2 = c1.min(-2)[0], c1.max(-2)[0], c2.min(-2)[0], c2.max(-2)[0]
@@ -153,6 +213,7 @@ class TopDownSceneCaptionModule(nn.Module):
         self.map_lang = nn.Linear(feat_size + hidden_size, emb_size)
         self.recurrent_cell_2 = nn.GRUCell(input_size=emb_size, hidden_size=hidden_size)
         self.classifier = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.ReLU(), nn.Linear(hidden_size, self.num_vocabs))
+        self.native = True   # csrc/topdown.hip for the teacher-forced pass; False: the step-by-step library-op form (tests)
 
     def forward(self, data_dict, use_tf=True, use_rl=False, is_eval=False, beam_opt={}):
         if is_eval:
@@ -345,6 +406,12 @@ class TopDownSceneCaptionModule(nn.Module):
             data_dict["lang_logprob"] = [[done[n][k]["logps"] for k in range(topn)] for n in range(N)]
             greedy, _ = self.greedy_decode(target_feats, obj_feats, valid_masks, self.cfg.data.max_spk_len + 1)
             data_dict["baseline_cap"] = [[greedy[n][0] for _ in range(topn)] for n in range(N)]
+        elif use_tf and self.native and obj_feats.is_cuda:
+            # teacher forcing: every input word is known up front -> the whole S-step pass is one native call (csrc/topdown.hip)
+            sd = dict(self.named_parameters())
+            lang_cap, data_dict["topdown_attn"] = TopDownXEFunction.apply(
+                self.embeddings, word_ids, valid_masks.squeeze(-1), max(num_words, 2) - 1, obj_feats, target_feats,
+                *[sd[_TD_KEYS[k]] for k in _lib.TOPDOWN_PARAMS])
         else:
             hiddens = (obj_feats.new_zeros(N, self.hidden_size), obj_feats.new_zeros(N, self.hidden_size))
             proj = self.map_feat(obj_feats)

@@ -350,6 +350,43 @@ int d3_hgemm(const d3_gemm_prob *probs, int nprobs, void *stream);
 /* out[c] (+)= sum_r x[r*ld + c], r < R, c < C (bias gradients; fixed summation order) */
 int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *stream);
 
+/* ---- top-down captioner, native (csrc/topdown.hip) -------------------------------------------------------
+ * TopDownSceneCaptionModule (model/caption_module.py:13-62 parameters, :72-133 step, :510-687 teacher-forced driver):
+ * x1 = map_topdown([emb[word] | h2 | target]); h1 = GRUCell1(x1, h1); a = softmax_k(attend . tanh(map_feat(obj)[k] +
+ * map_hidd(h1)), masked scores := 0); att = sum_k a[k] obj[k]; x2 = map_lang([att | h1]); h2 = GRUCell2(x2, h2);
+ * logits = classifier(h2), for S steps with teacher forcing (step t reads word_ids[n, t]).  N samples, K proposals,
+ * H hidden (512), E embedding (300), F feature (128), V vocabulary.  All matrices row-major fp32, nn.Linear layout
+ * (out, in); GRU weights (3H, in) in torch's r, z, n gate order.  ws: d3_topdown_ws_bytes() bytes, filled by the forward
+ * and read by the backward (saved activations).  H % 16 == 0, E % 4 == 0, F % 4 == 0, F <= 128. */
+typedef struct {
+    int N, K, S, V, H, E, F, Tw;          /* Tw: row stride of word_ids */
+    const long long *word_ids;            /* (N, Tw) */
+    const float *emb;                     /* (V, E) */
+    const float *target;                  /* (N, F) */
+    const float *obj;                     /* (N, K, F) */
+    const float *mask;                    /* (N, K): 0 = masked proposal */
+    const float *W_td, *b_td;             /* map_topdown (E, E+H+F), (E) */
+    const float *Wih1, *Whh1, *bih1, *bhh1;   /* recurrent_cell_1 */
+    const float *W_feat, *W_hidd, *w_att;     /* map_feat (H,F), map_hidd (H,H), attend (1,H) */
+    const float *W_lang, *b_lang;         /* map_lang (E, F+H), (E) */
+    const float *Wih2, *Whh2, *bih2, *bhh2;   /* recurrent_cell_2 */
+    const float *Wc0, *bc0, *Wc2, *bc2;   /* classifier.0 (H,H), classifier.2 (V,H) */
+    float *logits;                        /* out (N, S, V) */
+    float *attn;                          /* out (N, K, S) = topdown_attn, or NULL */
+    void *ws; size_t ws_bytes;
+} d3_topdown_args;
+typedef struct {
+    const float *dlogits;                 /* (N, S, V) */
+    float *dW_td, *db_td, *dWih1, *dWhh1, *dbih1, *dbhh1, *dW_feat, *dW_hidd, *dw_att, *dW_lang, *db_lang;
+    float *dWih2, *dWhh2, *dbih2, *dbhh2, *dWc0, *dbc0, *dWc2, *dbc2;   /* written (same shapes as the parameters) */
+    float *dobj, *dtarget;                /* (N,K,F), (N,F): written */
+    void *ws; size_t ws_bytes;            /* d3_topdown_bwd_ws_bytes() of scratch */
+} d3_topdown_grads;
+size_t d3_topdown_ws_bytes(int N, int K, int S, int H, int E, int F);
+size_t d3_topdown_bwd_ws_bytes(int N, int K, int S, int V, int H, int E, int F);
+int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream);
+int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown_grads *g, void *stream);
+
 /* ---- proposal geometry (speaker / graph heads) ------------------------------------------ */
 /* Distance matrix of `_query_locals` (model/graph_module.py:184-227 == model/caption_module.py:800-842) for all
  * target proposals at once: corners (B,K,8,3), masks (B,K) -> dist (B,K,K), dist[b,t,j] as the reference's pc_dist

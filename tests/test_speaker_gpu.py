@@ -90,3 +90,63 @@ def test_graph_module_vs_oracle(dev):
     for k in ("bbox_feature", "edge_feature", "edge_orientations", "edge_distances"):
         assert np.allclose(out[k].detach().cpu().numpy(), ref[k].numpy(), rtol=1e-3, atol=1e-4), k
     assert int(ref["num_edge_source"][0]) == 37 and int(ref["num_edge_target"][0]) == G.L
+
+
+def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev):
+    """csrc/topdown.hip (one native call for the S-step teacher-forced pass, one for its backward) against the same module
+    run step by step through library ops, at the shape of conf/pointgroup_captioning.yaml: batch 4 x 8 descriptions,
+    K = 128 proposals, V = 3004, up to 31 steps.  fp32 both ways: logits / attention 1e-4, every parameter gradient and
+    the gradients w.r.t. the object and target features 2e-3 of their scale (summation order over 31 steps)."""
+    import types
+    from d3net_amd.speaker import TopDownSceneCaptionModule, TopDownXEFunction, _TD_KEYS
+    from d3net_amd import _lib, synthetic as S
+    torch.manual_seed(11)
+    V, N, K, L = 3004, 32, 128, 10
+    cfg = types.SimpleNamespace(data=types.SimpleNamespace(max_spk_len=30, min_iou_threshold=0.25))
+    emb = np.random.default_rng(3).standard_normal((V, 300)).astype(np.float32)
+    cap = TopDownSceneCaptionModule(cfg, S.make_vocabulary(V), emb, num_proposals=K, num_locals=L, use_relation=True).to(dev)
+    g = torch.Generator().manual_seed(2)
+    obj = torch.randn(N, K, 128, generator=g).to(dev).requires_grad_(True)
+    tgt = torch.randn(N, 128, generator=g).to(dev).requires_grad_(True)
+    masks = torch.zeros(N, K)
+    for n in range(N):
+        masks[n, torch.randperm(K, generator=g)[:L]] = 1
+    masks = masks.to(dev)
+    lens = torch.randint(10, 33, (N,), generator=g)
+    lens[0] = 32
+    words = torch.zeros(N, 32, dtype=torch.long)
+    for n in range(N):
+        words[n, 0] = 2; words[n, 1:lens[n] - 1] = torch.randint(4, V, (int(lens[n]) - 2,), generator=g); words[n, lens[n] - 1] = 3
+    words = words.to(dev)
+    Ssteps = int(lens.max()) - 1
+    tgt_ids = words[:, 1:Ssteps + 1]
+
+    def loss_of(logits):
+        return torch.nn.functional.cross_entropy(logits.reshape(-1, V), tgt_ids.reshape(-1), ignore_index=0)
+
+    # step by step (library ops)
+    h = (obj.new_zeros(N, 512), obj.new_zeros(N, 512))
+    proj = cap.map_feat(obj)
+    outs, att = [], []
+    for s in range(Ssteps):
+        lo, _, h, m = cap.step(words[:, s], h, tgt, obj, masks.unsqueeze(-1), proj)
+        outs.append(lo.unsqueeze(1)); att.append(m)
+    ref_logits, ref_attn = torch.cat(outs, 1), torch.cat(att, -1)
+    loss_of(ref_logits).backward()
+    ref = {k: p.grad.clone() for k, p in cap.named_parameters()}
+    ref_dobj, ref_dtgt = obj.grad.clone(), tgt.grad.clone()
+    cap.zero_grad(); obj.grad = None; tgt.grad = None
+    # native
+    sd = dict(cap.named_parameters())
+    logits, attn = TopDownXEFunction.apply(cap.embeddings, words, masks, Ssteps, obj, tgt, *[sd[_TD_KEYS[k]] for k in _lib.TOPDOWN_PARAMS])
+    assert logits.shape == (N, Ssteps, V) and attn.shape == (N, K, Ssteps)
+    scale = float(ref_logits.abs().max())
+    assert float((logits - ref_logits).abs().max()) < 1e-4 * scale, float((logits - ref_logits).abs().max())
+    assert float((attn - ref_attn).abs().max()) < 1e-5
+    loss_of(logits).backward()
+    torch.cuda.synchronize()
+    for k, p in cap.named_parameters():
+        err = float((p.grad - ref[k]).abs().max()) / (float(ref[k].abs().max()) + 1e-12)
+        assert err < 2e-3, (k, err)
+    assert float((obj.grad - ref_dobj).abs().max()) < 2e-3 * float(ref_dobj.abs().max())
+    assert float((tgt.grad - ref_dtgt).abs().max()) < 2e-3 * float(ref_dtgt.abs().max())
