@@ -147,6 +147,8 @@ class NativeUNet:
         self._plan_key, self._plan = None, None
         self._flat_grad, self._grad_views = None, None
         self.fresh_grads = False     # set by the owner's zero_grad(): the next backward writes instead of accumulating
+        self.debug_keep = False      # tests: keep the last forward's activation arena + level rows in `debug_last`
+        self.debug_last = None
 
     # ------------------------------------------------------------------ lazily created native state
     def _net(self):
@@ -277,6 +279,8 @@ class _NetFunction(Function):
                 bn._steps += 1
         M, Co = rows[0], net.out_channels
         out = arena[out_off:out_off + M * Co * 4].view(torch.float32).view(M, Co)
+        if net.debug_keep:
+            net.debug_last = (arena, list(rows))
         ctx.net, ctx.maps, ctx.arena, ctx.feats, ctx.grad_bytes = net, (k3, child, up, keep), arena, feats, grad_bytes
         ctx.rows = rows
         ctx.training = training
