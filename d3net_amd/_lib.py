@@ -91,6 +91,14 @@ SIGNATURES = {
     "d3_topdown_bwd_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "d3_topdown_xe_forward": (i32, [vp, vp]),
     "d3_topdown_xe_backward": (i32, [vp, vp, vp]),
+    "d3_topdown_step_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "d3_topdown_feat_proj": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "d3_topdown_step": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "d3_graph_edges": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "d3_edgeconv_ws_bytes": (sz, [i32, i32, i32]),
+    "d3_edgeconv_bwd_ws_bytes": (sz, [i32, i32, i32]),
+    "d3_edgeconv_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "d3_edgeconv_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "d3_prof_enable": (i32, [i32]),
     "d3_prof_collect": (i32, [i32, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -184,16 +184,17 @@ __global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restric
                                                           const float *__restrict__ watt, const float *__restrict__ obj,
                                                           const float *__restrict__ mask, float *__restrict__ a_out,
                                                           float *__restrict__ att, long long ldatt, float *__restrict__ attn_out,
-                                                          int t_step, int S, int K, int H, int F) {
+                                                          int t_step, int S, int K, int H, int F, int obj_div) {
     extern __shared__ float sm[];
     float *qs = sm, *ws = qs + H, *sc = ws + H, *part = sc + K;   // part: 2*F
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long ns = n / obj_div;      // obj / fp row block of this sample (evaluation: the K targets of a scene share it)
     for (int c = t; c < H; c += 256) { qs[c] = q[(long long)n * ldq + c]; ws[c] = watt[c]; }
     __syncthreads();
     for (int k = wave; k < K; k += 4) {
         float s = 0.f;
         if (mask[(long long)n * K + k] != 0.f) {    // wave-uniform
-            const float *row = fp + ((long long)n * K + k) * H;
+            const float *row = fp + (ns * K + k) * H;
             for (int c = lane * 4; c < H; c += 256) {
                 const f32x4 v = *(const f32x4 *)(row + c);
 #pragma unroll
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restric
     float s = 0.f;
     if (half < 2) {
         const int k0 = half * ((K + 1) / 2), k1 = min(K, k0 + (K + 1) / 2);
-        for (int k = k0; k < k1; k++) s += sc[k] * obj[((long long)n * K + k) * F + c];
+        for (int k = k0; k < k1; k++) s += sc[k] * obj[(ns * K + k) * F + c];
         part[half * F + c] = s;
     }
     __syncthreads();
@@ -407,7 +408,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
             if ((rc = hg_launch(&p, 1, s))) return rc;
         }
         td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, a->mask, av + rN * K,
-                                                                         att + rN * F, F, a->attn, t, S, K, H, F);
+                                                                         att + rN * F, F, a->attn, t, S, K, H, F, 1);
         {   // x2 = map_lang([attended | h1])
             d3_gemm_prob p = td_prob(N, E, x2 + rN * E, E);
             p.nseg = 2;
@@ -604,6 +605,87 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         d3_gemm_prob p = td_prob(E, E, gd->dW_td, ldtd);
         p.nseg = 1; p.seg[0] = td_seg(dx1, E, embg, E, R, nullptr, 1, 1);
         if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ one decode step (inference)
+// The same step for the greedy / evaluation decodes (model/caption_module.py:350-383, 689-770), where the next word depends
+// on the classifier output and nothing can be batched over time: 8 launches (x1, GRU1, map_hidd, attention, map_lang, GRU2,
+// classifier.0, classifier.2).  fp = map_feat(obj) is computed once per decode by d3_topdown_feat_proj.  obj_div: consecutive
+// samples sharing one (K,F) object block (the evaluation decode runs the K targets of a scene as K samples).
+extern "C" size_t d3_topdown_step_ws_bytes(int N, int K, int H, int E, int F) {
+    return d3_align((size_t)N * 4) + 2 * d3_align((size_t)N * E * 4) + 2 * d3_align((size_t)N * H * 4) + d3_align((size_t)N * F * 4) + 256;
+}
+
+extern "C" int d3_topdown_feat_proj(const float *obj, const float *W_feat, float *fp, int rows, int H, int F, void *stream) {
+    D3_CLEAR();
+    d3_gemm_prob p = td_prob(rows, H, fp, H);
+    p.nseg = 1; p.seg[0] = td_seg(obj, F, W_feat, F, F);
+    return hg_launch(&p, 1, d3_stream(stream));
+}
+
+__global__ void td_word_idx_kernel(const long long *__restrict__ word, int *__restrict__ widx, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) widx[n] = (int)word[n];
+}
+
+extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, const float *fp, int obj_div, const float *h1_in,
+                               const float *h2_in, float *h1_out, float *h2_out, float *logits, float *attn, void *ws_, size_t ws_bytes,
+                               void *stream) {
+    D3_CLEAR();
+    if (!a || a->N < 1 || (a->H & 15) || (a->E & 3) || (a->F & 3) || a->F > 128 || obj_div < 1) return D3_ERR_ARG;
+    const int N = a->N, K = a->K, V = a->V, H = a->H, E = a->E, F = a->F;
+    if (ws_bytes < d3_topdown_step_ws_bytes(N, K, H, E, F)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    D3Carver cv(ws_, ws_bytes);
+    int *widx = cv.take<int>(N);
+    float *x1 = cv.take<float>((size_t)N * E), *x2 = cv.take<float>((size_t)N * E), *q = cv.take<float>((size_t)N * H);
+    float *c0 = cv.take<float>((size_t)N * H), *att = cv.take<float>((size_t)N * F);
+    const long long ldtd = H + F + E, ldlang = F + H;
+    int rc;
+    td_word_idx_kernel<<<(N + 255) / 256, 256, 0, s>>>(word, widx, N);
+    {
+        d3_gemm_prob p = td_prob(N, E, x1, E);
+        p.nseg = 3;
+        p.seg[0] = td_seg(a->emb, E, a->W_td, ldtd, E, widx);
+        p.seg[1] = td_seg(h2_in, H, a->W_td + E, ldtd, H);
+        p.seg[2] = td_seg(a->target, F, a->W_td + E + H, ldtd, F);
+        p.bias = a->b_td;
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    {
+        GruArgs g{x1, E, E, h1_in, H, a->Wih1, a->Whh1, a->bih1, a->bhh1, h1_out, H, nullptr, nullptr, nullptr, nullptr, N, H};
+        if ((rc = td_gru_fwd(g, s))) return rc;
+    }
+    {
+        d3_gemm_prob p = td_prob(N, H, q, H);
+        p.nseg = 1; p.seg[0] = td_seg(h1_out, H, a->W_hidd, H, H);
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + K + 2 * F) * 4, s>>>(fp, q, H, a->w_att, a->obj, a->mask, attn, att, F, nullptr, 0, 1, K, H, F, obj_div);
+    {
+        d3_gemm_prob p = td_prob(N, E, x2, E);
+        p.nseg = 2;
+        p.seg[0] = td_seg(att, F, a->W_lang, ldlang, F);
+        p.seg[1] = td_seg(h1_out, H, a->W_lang + F, ldlang, H);
+        p.bias = a->b_lang;
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    {
+        GruArgs g{x2, E, E, h2_in, H, a->Wih2, a->Whh2, a->bih2, a->bhh2, h2_out, H, nullptr, nullptr, nullptr, nullptr, N, H};
+        if ((rc = td_gru_fwd(g, s))) return rc;
+    }
+    {
+        d3_gemm_prob p = td_prob(N, H, c0, H);
+        p.nseg = 1; p.seg[0] = td_seg(h2_out, H, a->Wc0, H, H);
+        p.bias = a->bc0; p.relu = 1;
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+        d3_gemm_prob p2 = td_prob(N, V, logits, V);
+        p2.nseg = 1; p2.seg[0] = td_seg(c0, H, a->Wc2, H, H);
+        p2.bias = a->bc2;
+        if ((rc = hg_launch(&p2, 1, s))) return rc;
     }
     D3_LAUNCH_CHECK();
     return 0;

@@ -62,6 +62,68 @@ class EdgeConv(nn.Module):
         return out, message
 
 
+def graph_edges(adjacent_mat, object_masks, num_locals):
+    """Edge structures of all scenes in one launch (csrc/edgeconv.hip: d3_graph_edges), fixed-size device tensors."""
+    B, K, _ = adjacent_mat.shape
+    dev, KL = adjacent_mat.device, K * num_locals
+    i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+    e = dict(B=B, K=K, L=num_locals, src=i32(B, KL), dst=i32(B, KL), edge_index=torch.empty((B, 2, KL), dtype=torch.float32, device=dev),
+             cnt=i32(B, 4), in_ptr=i32(B, K + 1), in_list=i32(B, KL), out_start=i32(B, K), out_cnt=i32(B, K),
+             feat_src=torch.empty((B, KL), dtype=torch.int64, device=dev), pred_src=torch.empty((B, KL), dtype=torch.int64, device=dev))
+    adj, masks = adjacent_mat.contiguous().float(), object_masks.contiguous().float()
+    with _on(dev):
+        check(_lib.lib().d3_graph_edges(_ptr(adj), _ptr(masks), B, K, num_locals, _ptr(e["src"]), _ptr(e["dst"]), _ptr(e["edge_index"]),
+                                        _ptr(e["cnt"]), _ptr(e["in_ptr"]), _ptr(e["in_list"]), _ptr(e["out_start"]), _ptr(e["out_cnt"]),
+                                        _ptr(e["feat_src"]), _ptr(e["pred_src"]), _stream()), "graph_edges")
+    return e
+
+
+class EdgeConvFunction(torch.autograd.Function):
+    """EdgeConv over the padded edge matrix of all scenes (csrc/edgeconv.hip): x (B*K, Cin) -> node (B*K, Cout), per-edge
+    messages (B*K*L, Cout; padded rows zero).  One native call each way."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, W2, b2, e):
+        L_ = _lib.lib()
+        x, W0, b0, W2, b2 = (t.contiguous() for t in (x, W0, b0, W2, b2))
+        B, K, L = e["B"], e["K"], e["L"]
+        Cin, Cout = x.shape[1], W2.shape[0]
+        Emax = B * K * L
+        node = torch.empty((B * K, Cout), dtype=torch.float32, device=x.device)
+        msg = torch.empty((Emax, Cout), dtype=torch.float32, device=x.device)
+        ws = torch.empty(L_.d3_edgeconv_ws_bytes(Emax, Cin, Cout), dtype=torch.uint8, device=x.device)
+        with _on(x.device):
+            check(L_.d3_edgeconv_fwd(_ptr(x), _ptr(W0), _ptr(b0), _ptr(W2), _ptr(b2), _ptr(e["src"]), _ptr(e["dst"]), _ptr(e["in_ptr"]),
+                                     _ptr(e["in_list"]), B, K, L, Cin, Cout, _ptr(node), _ptr(msg), _ptr(ws), ws.numel(), _stream()),
+                  "edgeconv_fwd")
+        ctx.e, ctx.dims = e, (Cin, Cout)
+        ctx.save_for_backward(W0, W2, ws)
+        return node, msg
+
+    @staticmethod
+    def backward(ctx, d_node, d_msg):
+        L_ = _lib.lib()
+        W0, W2, ws = ctx.saved_tensors
+        e = ctx.e
+        Cin, Cout = ctx.dims
+        B, K, L = e["B"], e["K"], e["L"]
+        Emax = B * K * L
+        dev = W0.device
+        d_node = d_node.contiguous() if d_node is not None else None
+        d_msg = d_msg.contiguous() if d_msg is not None else None
+        dx = torch.empty((B * K, Cin), dtype=torch.float32, device=dev)
+        dW0, db0 = torch.empty_like(W0), torch.empty(Cout, dtype=torch.float32, device=dev)
+        dW2, db2 = torch.empty_like(W2), torch.empty(Cout, dtype=torch.float32, device=dev)
+        ws2 = torch.empty(L_.d3_edgeconv_bwd_ws_bytes(Emax, Cin, Cout), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            check(L_.d3_edgeconv_bwd(_ptr(W0), _ptr(W2), _ptr(e["src"]), _ptr(e["dst"]), _ptr(e["in_ptr"]), _ptr(e["in_list"]),
+                                     _ptr(e["out_start"]), _ptr(e["out_cnt"]), B, K, L, Cin, Cout,
+                                     _ptr(d_node) if d_node is not None else None, _ptr(d_msg) if d_msg is not None else None,
+                                     _ptr(ws), _ptr(dx), _ptr(dW0), _ptr(db0), _ptr(dW2), _ptr(db2), _ptr(ws2), ws2.numel(), _stream()),
+                  "edgeconv_bwd")
+        return dx, dW0, db0, dW2, db2, None
+
+
 class GraphModule(nn.Module):
     """(reference: model/graph_module.py:116-324)"""
 
@@ -81,12 +143,50 @@ class GraphModule(nn.Module):
             self.edge_layer = EdgeConv(out_size, out_size, graph_aggr)
             self.edge_predict = nn.Linear(out_size, num_bins + 1)
 
+    native = True    # csrc/edgeconv.hip for all scenes at once; False: the per-scene library-op form (tests compare the two)
+
+    def _forward_native(self, data_dict, obj_feats, object_masks, adjacent_mat):
+        """all scenes as one padded edge matrix: no python loop over scenes, no host round trip (see csrc/edgeconv.hip)"""
+        B, K, Cc = obj_feats.shape
+        L = self.num_locals
+        e = graph_edges(adjacent_mat, object_masks, L)
+        node, msg = obj_feats.reshape(B * K, Cc), None
+        for layer in self.gc_layers:
+            m = layer.map_edge
+            node, msg = EdgeConvFunction.apply(node, m[0].weight, m[0].bias, m[2].weight, m[2].bias, e)
+        valid = (object_masks == 1).unsqueeze(-1)
+        data_dict["bbox_feature"] = torch.where(valid, obj_feats + node.view(B, K, -1), torch.zeros_like(obj_feats))   # (:311-312)
+        edge_feats = obj_feats.new_zeros(B, K, L, self.out_size)
+        edge_preds = obj_feats.new_zeros(B, K * L, self.num_bins + 1)
+        edge_indices = torch.zeros_like(e["edge_index"])
+        num_sources = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
+        num_targets = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
+        if self.return_orientation and msg is not None:
+            zrow = lambda t: torch.cat([t, t.new_zeros(1, t.shape[1])], 0)
+            edge_feats = zrow(msg).index_select(0, e["feat_src"].view(-1)).view(B, K, L, self.out_size)
+            m = self.edge_layer.map_edge
+            _, last = EdgeConvFunction.apply(node, m[0].weight, m[0].bias, m[2].weight, m[2].bias, e)
+            pred = self.edge_predict(last)
+            edge_preds = zrow(pred).index_select(0, e["pred_src"].view(-1)).view(B, K * L, self.num_bins + 1)
+            edge_indices = e["edge_index"]
+            num_sources, num_targets = e["cnt"][:, 1].long(), e["cnt"][:, 2].long()
+        data_dict["adjacent_mat"] = adjacent_mat
+        data_dict["edge_index"] = edge_indices
+        data_dict["edge_feature"] = edge_feats
+        data_dict["num_edge_source"] = num_sources
+        data_dict["num_edge_target"] = num_targets
+        data_dict["edge_orientations"] = edge_preds[:, :, :-1]
+        data_dict["edge_distances"] = edge_preds[:, :, -1]
+        return data_dict
+
     def forward(self, data_dict):
         obj_feats = self.map_input(data_dict["proposal_feats_batched"])           # (B,K,out)
         object_masks = data_dict["proposal_batch_mask"]
         B, K, _ = obj_feats.shape
         adjacent_mat = query_locals_all(data_dict["proposal_bbox_batched"], object_masks, self.num_locals,
                                         include_self=False, query_mode=self.query_mode).type_as(object_masks)
+        if self.native and obj_feats.is_cuda and self.out_size == self.feat_size:
+            return self._forward_native(data_dict, obj_feats, object_masks, adjacent_mat)
         new_obj_feats = obj_feats.new_zeros(B, K, self.feat_size)
         edge_indices = obj_feats.new_zeros(B, 2, K * self.num_locals)
         edge_feats = obj_feats.new_zeros(B, K, self.num_locals, self.out_size)
@@ -186,6 +286,51 @@ class TopDownXEFunction(torch.autograd.Function):
         return (None, None, None, None, dobj, dtarget) + tuple(grads)
 
 
+class _NativeDecoder:
+    """Inference-time decode loop state for csrc/topdown.hip's d3_topdown_step: map_feat(obj) computed once, hidden states
+    double-buffered on the device, 8 launches per step.  obj_feats: (N / obj_div, K, F) -- `obj_div` consecutive samples share
+    an object block (the evaluation decode runs the K targets of a scene as K samples: caption_module.py:710-749)."""
+
+    def __init__(self, cap, target_feats, obj_feats, masks, obj_div=1):
+        L = _lib.lib()
+        self.dev = dev = target_feats.device
+        self.target, self.obj, self.mask = target_feats.contiguous().float(), obj_feats.contiguous().float(), masks.contiguous().float()
+        N, F_ = self.target.shape
+        nblk, K, _ = self.obj.shape
+        assert nblk * obj_div == N and self.mask.shape == (N, K)
+        sd = dict(cap.named_parameters())
+        self.params = [sd[_TD_KEYS[k]].detach().contiguous() for k in _lib.TOPDOWN_PARAMS]
+        self.emb = cap.embeddings
+        V, E = self.emb.shape
+        H = cap.hidden_size
+        a = self.args = _lib.TopdownArgs()
+        a.N, a.K, a.S, a.V, a.H, a.E, a.F, a.Tw = N, K, 1, V, H, E, F_, 1
+        a.emb, a.target, a.obj, a.mask = self.emb.data_ptr(), self.target.data_ptr(), self.obj.data_ptr(), self.mask.data_ptr()
+        for k, p in zip(_lib.TOPDOWN_PARAMS, self.params):
+            setattr(a, k, p.data_ptr())
+        self.obj_div = obj_div
+        self.fp = torch.empty((nblk * K, H), dtype=torch.float32, device=dev)
+        with _on(dev):
+            check(L.d3_topdown_feat_proj(_ptr(self.obj), _ptr(self.params[_lib.TOPDOWN_PARAMS.index("W_feat")]), _ptr(self.fp),
+                                         nblk * K, H, F_, _stream()), "topdown_feat_proj")
+        self.h1 = [torch.zeros((N, H), device=dev), torch.empty((N, H), device=dev)]
+        self.h2 = [torch.zeros((N, H), device=dev), torch.empty((N, H), device=dev)]
+        self.ws = torch.empty(L.d3_topdown_step_ws_bytes(N, K, H, E, F_), dtype=torch.uint8, device=dev)
+        self.N, self.K, self.V = N, K, V
+
+    def step(self, word):
+        """word (N) int64 -> logits (N,V), attention (N,K); advances the hidden states"""
+        word = word.contiguous()
+        logits = torch.empty((self.N, self.V), dtype=torch.float32, device=self.dev)
+        attn = torch.empty((self.N, self.K), dtype=torch.float32, device=self.dev)
+        with _on(self.dev):
+            check(_lib.lib().d3_topdown_step(C.byref(self.args), _ptr(word), _ptr(self.fp), self.obj_div, _ptr(self.h1[0]), _ptr(self.h2[0]),
+                                             _ptr(self.h1[1]), _ptr(self.h2[1]), _ptr(logits), _ptr(attn), _ptr(self.ws), self.ws.numel(),
+                                             _stream()), "topdown_step")
+        self.h1.reverse(); self.h2.reverse()
+        return logits, attn
+
+
 def _aabb_iou(c1, c2):
     """lib/utils/bbox.py:247-271 on (...,8,3) tensors"""
     mn1, mx1, mn2, mx2 = c1.min(-2)[0], c1.max(-2)[0], c2.min(-2)[0], c2.max(-2)[0]
@@ -241,9 +386,16 @@ class TopDownSceneCaptionModule(nn.Module):
         """(:350-383) -> trimmed token / log-prob lists"""
         N = target_feats.shape[0]
         word = torch.full((N,), int(self.vocabulary["word2idx"]["sos"]), dtype=torch.long, device=target_feats.device)
+        outs, lps = [], []
+        if self.native and target_feats.is_cuda:
+            dec = _NativeDecoder(self, target_feats, obj_feats, valid_masks.reshape(N, -1))
+            for _ in range(max_len):
+                logits, _ = dec.step(word)
+                lp, word = F.log_softmax(logits, dim=-1).max(-1)
+                outs.append(word.unsqueeze(1)); lps.append(lp.unsqueeze(1))
+            return self.trim_outputs(torch.cat(outs, 1).unsqueeze(1), torch.cat(lps, 1).unsqueeze(1))
         hiddens = (target_feats.new_zeros(N, self.hidden_size), target_feats.new_zeros(N, self.hidden_size))
         proj = self.map_feat(obj_feats)
-        outs, lps = [], []
         for _ in range(max_len):
             _, logits, hiddens, _ = self.step(word, hiddens, target_feats, obj_feats, valid_masks, proj)
             lp, word = F.log_softmax(logits, dim=-1).max(-1)
@@ -453,14 +605,21 @@ class TopDownSceneCaptionModule(nn.Module):
         del step_feats
         target_feats = obj_feats.reshape(B * K, self.feat_size)
         vm = valid.reshape(B * K, K, 1)
-        hiddens = (feats.new_zeros(B * K, self.hidden_size), feats.new_zeros(B * K, self.hidden_size))
-        proj = self.map_feat(obj_feats).unsqueeze(1).expand(-1, K, -1, -1).reshape(B * K, K, self.hidden_size)
         word = torch.full((B * K,), int(self.vocabulary["word2idx"]["sos"]), dtype=torch.long, device=feats.device)
         outs, attn = [], []
-        for _ in range(T):
-            logits, _, hiddens, m = self.step(word, hiddens, target_feats, feats, vm, proj)
-            word = logits.argmax(-1)
-            outs.append(word.unsqueeze(1)); attn.append(m)
+        if self.native and obj_feats.is_cuda:   # B*K samples, the K targets of a scene share its object block (no expand)
+            dec = _NativeDecoder(self, target_feats, obj_feats, valid.reshape(B * K, K), obj_div=K)
+            for _ in range(T):
+                logits, m = dec.step(word)
+                word = logits.argmax(-1)
+                outs.append(word.unsqueeze(1)); attn.append(m.unsqueeze(-1))
+        else:
+            hiddens = (feats.new_zeros(B * K, self.hidden_size), feats.new_zeros(B * K, self.hidden_size))
+            proj = self.map_feat(obj_feats).unsqueeze(1).expand(-1, K, -1, -1).reshape(B * K, K, self.hidden_size)
+            for _ in range(T):
+                logits, _, hiddens, m = self.step(word, hiddens, target_feats, feats, vm, proj)
+                word = logits.argmax(-1)
+                outs.append(word.unsqueeze(1)); attn.append(m)
         data_dict["lang_cap"] = torch.cat(outs, 1).view(B, K, T)
         data_dict["topdown_attn"] = torch.cat(attn, -1).view(B, K, K, T)
         data_dict["valid_masks"] = valid

@@ -386,6 +386,42 @@ size_t d3_topdown_ws_bytes(int N, int K, int S, int H, int E, int F);
 size_t d3_topdown_bwd_ws_bytes(int N, int K, int S, int V, int H, int E, int F);
 int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream);
 int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown_grads *g, void *stream);
+/* One decode step for the greedy / evaluation decodes (model/caption_module.py:350-383, 689-770), inference only: uses N, K,
+ * V, H, E, F, emb, target, obj, mask and the parameters of `a`.  word (N) int64 -> logits (N,V), attn (N,K); hidden states
+ * h1_in / h2_in (N,H) -> h1_out / h2_out (distinct buffers).  fp = map_feat(obj) from d3_topdown_feat_proj (rows = number of
+ * (K,F) object blocks * K).  obj_div: consecutive samples sharing one object block (1: one block per sample). */
+size_t d3_topdown_step_ws_bytes(int N, int K, int H, int E, int F);
+int d3_topdown_feat_proj(const float *obj, const float *W_feat, float *fp, int rows, int H, int F, void *stream);
+int d3_topdown_step(const d3_topdown_args *a, const long long *word, const float *fp, int obj_div, const float *h1_in,
+                    const float *h2_in, float *h1_out, float *h2_out, float *logits, float *attn, void *ws, size_t ws_bytes,
+                    void *stream);
+
+/* ---- relation graph (csrc/edgeconv.hip) -----------------------------------------------------------------
+ * GraphModule / EdgeConv (model/graph_module.py:21-114, 252-324) for all B scenes at once, fixed-size outputs, no host
+ * round trip.  adj (B,K,K) 0/1 adjacency (rows = _query_locals of every proposal, L ones each), mask (B,K) valid proposals.
+ * Edges = row-major non-zeros of adj restricted to valid x valid (the reference's scipy COO order), stored per scene in a
+ * padded block of K*L slots:
+ *   src / dst (B,K*L) int32   global node ids b*K + slot of the adjacency row (x_j) / column (x_i, aggregation target), -1 pad
+ *   edge_index (B,2,K*L) f32  the reference's `edge_index` output: compacted (valid-only) node ids of the first n edges
+ *   cnt (B,4) int32           E, n_source (rows with an edge), n_target = E / n_source, number of valid nodes
+ *   in_ptr (B,K+1), in_list (B,K*L): incoming edges (scene-local edge ids) of every node in edge order
+ *   out_start / out_cnt (B,K): the contiguous outgoing range of every node
+ *   feat_src / pred_src (B,K*L) int64: row of the (B*K*L [+1 zero row], C) message / prediction matrix that lands in slot
+ *       (r, k) of `edge_feature` (message r*n_target + k) resp. row j of `edge_orientations` (only when E == n); B*K*L = none
+ * edgeconv_fwd: message = W2 relu(W0 [x_i | x_j - x_i] + b0) + b2 per edge (fp32 matrix cores), node = sum of incoming
+ * messages in edge order.  ws (d3_edgeconv_ws_bytes) keeps [edge inputs | hidden] for the backward. */
+int d3_graph_edges(const float *adj, const float *mask, int B, int K, int L, int *src, int *dst, float *edge_index, int *cnt,
+                   int *in_ptr, int *in_list, int *out_start, int *out_cnt, long long *feat_src, long long *pred_src,
+                   void *stream);
+size_t d3_edgeconv_ws_bytes(int Emax, int Cin, int Cout);
+size_t d3_edgeconv_bwd_ws_bytes(int Emax, int Cin, int Cout);
+int d3_edgeconv_fwd(const float *x, const float *W0, const float *b0, const float *W2, const float *b2, const int *src,
+                    const int *dst, const int *in_ptr, const int *in_list, int B, int K, int L, int Cin, int Cout, float *node,
+                    float *msg, void *ws, size_t ws_bytes, void *stream);
+int d3_edgeconv_bwd(const float *W0, const float *W2, const int *src, const int *dst, const int *in_ptr, const int *in_list,
+                    const int *out_start, const int *out_cnt, int B, int K, int L, int Cin, int Cout, const float *d_node,
+                    const float *d_msg, const void *ws, float *dx, float *dW0, float *db0, float *dW2, float *db2, void *ws2,
+                    size_t ws2_bytes, void *stream);
 
 /* ---- proposal geometry (speaker / graph heads) ------------------------------------------ */
 /* Distance matrix of `_query_locals` (model/graph_module.py:184-227 == model/caption_module.py:800-842) for all
