@@ -86,7 +86,8 @@ SIGNATURES = {
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_hgemm": (i32, [vp, i32, vp]),
-    "d3_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "d3_colsum_ws_bytes": (sz, [i32]),
+    "d3_colsum": (i32, [vp, i64, i32, i32, vp, i32, vp, sz, vp]),
     "d3_topdown_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "d3_topdown_bwd_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "d3_topdown_xe_forward": (i32, [vp, vp]),

@@ -19,7 +19,9 @@
 #include <string.h>
 
 int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s);
-int hg_colsum(const float *x, long long ld, int R, int C, float *out, int accum, hipStream_t s);
+size_t hg_colsum_ws_bytes(int njobs, int cmax);
+int hg_colsum_multi(const float *const *x, const long long *ld, const int *R, const int *C, float *const *out, const int *accum, int n,
+                    void *ws, size_t ws_bytes, hipStream_t s);
 
 #define GM_MAXK 256
 
@@ -164,7 +166,7 @@ extern "C" size_t d3_edgeconv_ws_bytes(int Emax, int Cin, int Cout) {
     return d3_align((size_t)Emax * 2 * Cin * 4) + d3_align((size_t)Emax * Cout * 4);
 }
 extern "C" size_t d3_edgeconv_bwd_ws_bytes(int Emax, int Cin, int Cout) {
-    return d3_align((size_t)Emax * Cout * 4) * 2 + d3_align((size_t)Emax * 2 * Cin * 4);
+    return d3_align((size_t)Emax * Cout * 4) * 2 + d3_align((size_t)Emax * 2 * Cin * 4) + d3_align(hg_colsum_ws_bytes(2, Cout));
 }
 
 // x (B*K, Cin); W0 (Cout, 2 Cin), b0; W2 (Cout, Cout), b2 -> node (B*K, Cout), msg (B*K*L, Cout).  ws keeps [Ein | hid].
@@ -245,7 +247,6 @@ extern "C" int d3_edgeconv_bwd(const float *W0, const float *W2, const int *src,
         p[1] = ec_prob(Cout, Cout, dW2, Cout); p[1].seg[0] = ec_seg(dm, Cout, hid, Cout, (int)Emax, 1, 1);
         if ((rc = hg_launch(&p[0], 1, s))) return rc;
         if ((rc = hg_launch(&p[1], 1, s))) return rc;
-        if ((rc = hg_colsum(dm, Cout, (int)Emax, Cout, db2, 0, s))) return rc;
         ec_relu_mask_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(dh, hid, tot);
     }
     {   // dE = dh W0; dW0 = dh^T Ein; db0 = colsum(dh)
@@ -254,7 +255,11 @@ extern "C" int d3_edgeconv_bwd(const float *W0, const float *W2, const int *src,
         p[1] = ec_prob(Cout, 2 * Cin, dW0, 2 * Cin); p[1].seg[0] = ec_seg(dh, Cout, Ein, 2 * Cin, (int)Emax, 1, 1);
         if ((rc = hg_launch(&p[0], 1, s))) return rc;
         if ((rc = hg_launch(&p[1], 1, s))) return rc;
-        if ((rc = hg_colsum(dh, Cout, (int)Emax, Cout, db0, 0, s))) return rc;
+        // both bias gradients in one two-stage column sum (dm is not modified after the first block)
+        const float *cx[2] = {dm, dh}; const long long cl[2] = {Cout, Cout}; const int cr[2] = {(int)Emax, (int)Emax}, cc[2] = {Cout, Cout};
+        float *co[2] = {db2, db0};
+        char *cs = (char *)ws2 + 2 * d3_align((size_t)Emax * Cout * 4) + d3_align((size_t)Emax * 2 * Cin * 4);
+        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 2, cs, hg_colsum_ws_bytes(2, Cout), s))) return rc;
     }
     ec_bwd_dx_kernel<<<B * K, ((Cin + 63) / 64) * 64, 0, s>>>(dE, in_ptr, in_list, out_start, out_cnt, dx, K, K * L, Cin);
     D3_LAUNCH_CHECK();

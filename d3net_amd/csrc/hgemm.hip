@@ -47,9 +47,11 @@ __device__ __forceinline__ f32x4 hg_load4(const float *base, long long ld, int k
     return v;
 }
 
-template <int RT, bool KSPLIT>
-__global__ __launch_bounds__(256) void hg_gemm_kernel(const HgBatch batch) {
-    __shared__ float red[KSPLIT ? 4 * RT * 256 : 1];
+// NW: waves per workgroup.  KSPLIT: the NW waves split the k blocks of ONE 16-column tile (skinny problems: the deeper the
+// reduction, the more waves -- each wave should need a single batch of loads); otherwise (NW = 4) every wave owns a tile.
+template <int RT, bool KSPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void hg_gemm_kernel(const HgBatch batch) {
+    __shared__ float red[KSPLIT ? NW * RT * 256 : 1];
     const d3_gemm_prob &p = batch.p[blockIdx.z];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
     const int ctiles = (p.N + 15) >> 4, rgroups = (p.M + RT * 16 - 1) / (RT * 16);
@@ -79,10 +81,10 @@ __global__ __launch_bounds__(256) void hg_gemm_kernel(const HgBatch batch) {
         }
         const float *bb = sg.b_kmajor ? sg.B + (cvalid ? col : 0) : sg.B + (long long)(cvalid ? col : 0) * sg.ldb;
         // this wave's k blocks of the segment: kb = first, first + step, ...
-        const int step = KSPLIT ? 4 : 1;
-        int first = KSPLIT ? ((wave - gkb) & 3) : 0;
+        const int step = KSPLIT ? NW : 1;
+        int first = KSPLIT ? ((wave - gkb) & (NW - 1)) : 0;
         gkb += nkb;
-        constexpr int U = RT <= 2 ? 4 : 2;
+        constexpr int U = (NW == 16 || RT > 2) ? 2 : 4;   // (1024-thread workgroups: 128 VGPRs per lane)
         for (int kb0 = first; kb0 < nkb; kb0 += step * U) {
             f32x4 a[U][RT], b[U];
 #pragma unroll
@@ -122,12 +124,11 @@ __global__ __launch_bounds__(256) void hg_gemm_kernel(const HgBatch batch) {
 #pragma unroll
             for (int q = 0; q < 4; q++) red[((wave * RT + r) * 4 + q) * 64 + lane] = acc[r][q];
         __syncthreads();
-#pragma unroll
-        for (int n = 0; n < RT; n++) {
-            const int e = t + n * 256, r = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+        for (int e = t; e < RT * 256; e += NW * 64) {
+            const int r = e >> 8, q = (e >> 6) & 3, ln = e & 63;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) v += red[((w * RT + r) * 4 + q) * 64 + ln];
+            for (int w = 0; w < NW; w++) v += red[((w * RT + r) * 4 + q) * 64 + ln];
             finish(r, q, ln, v);
         }
     } else if (tile_ok) {
@@ -160,18 +161,29 @@ int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
     for (int i = nprobs; i < HG_MAXP; i++) b.p[i] = probs[0];
     if (maxM == 0) return 0;
     const int ctiles = (maxN + 15) / 16;
-    if (maxM <= 64) {            // a decode step: K split over the waves of a workgroup
-        if (maxM <= 16) hg_gemm_kernel<1, true><<<dim3(ctiles, 1, nprobs), 256, 0, s>>>(b);
-        else if (maxM <= 32) hg_gemm_kernel<2, true><<<dim3(ctiles, 1, nprobs), 256, 0, s>>>(b);
-        else hg_gemm_kernel<4, true><<<dim3(ctiles, 1, nprobs), 256, 0, s>>>(b);
+    int kblocks = 0;             // deepest reduction of the batch, in 16-wide k blocks
+    for (int i = 0; i < nprobs; i++) {
+        int kb = 0;
+        for (int q = 0; q < probs[i].nseg; q++) kb += (probs[i].seg[q].K + 15) / 16;
+        if (kb > kblocks) kblocks = kb;
+    }
+#define HG_SPLIT(RTV, GY)                                                                                  \
+    do {                                                                                                   \
+        if (kblocks >= 40) hg_gemm_kernel<RTV, true, 16><<<dim3(ctiles, GY, nprobs), 1024, 0, s>>>(b);      \
+        else if (kblocks >= 20) hg_gemm_kernel<RTV, true, 8><<<dim3(ctiles, GY, nprobs), 512, 0, s>>>(b);   \
+        else hg_gemm_kernel<RTV, true, 4><<<dim3(ctiles, GY, nprobs), 256, 0, s>>>(b);                      \
+    } while (0)
+    if (maxM <= 32) {            // a decode step: K split over the waves of a workgroup
+        if (maxM <= 16) HG_SPLIT(1, 1); else HG_SPLIT(2, 1);
     } else {
         const long long tiles16 = (long long)ctiles * ((maxM + 15) / 16);
         if (tiles16 < 2048) {    // few tiles: still split K so that the chip is covered
-            hg_gemm_kernel<2, true><<<dim3(ctiles, (maxM + 31) / 32, nprobs), 256, 0, s>>>(b);
+            HG_SPLIT(2, (maxM + 31) / 32);
         } else {
-            hg_gemm_kernel<4, false><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
+            hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
         }
     }
+#undef HG_SPLIT
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -181,31 +193,67 @@ extern "C" int d3_hgemm(const d3_gemm_prob *probs, int nprobs, void *stream) {
     return hg_launch(probs, nprobs, d3_stream(stream));
 }
 
-// out[c] (+)= sum_r x[r, c]  (bias gradients): one wave per 64 columns slice x row range, fixed order
-__global__ __launch_bounds__(256) void hg_colsum_kernel(const float *__restrict__ x, long long ld, int R, int C, float *__restrict__ out,
-                                                        int accum) {
+// out[c] (+)= sum_r x[r, c]  (bias gradients), up to HG_MAXCS matrices per call: stage 1 sums HG_RS row slices per
+// 64-column block (coalesced 256-byte rows, 4 waves on interleaved rows), stage 2 adds the slices in fixed order.
+#define HG_MAXCS 12
+#define HG_RS 16
+struct HgColsumJobs { const float *x[HG_MAXCS]; float *out[HG_MAXCS]; long long ld[HG_MAXCS]; int R[HG_MAXCS], C[HG_MAXCS], accum[HG_MAXCS]; int cmax; };
+
+__global__ __launch_bounds__(256) void hg_colsum1_kernel(const HgColsumJobs j, float *__restrict__ part) {
     __shared__ float sh[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int job = blockIdx.z, rs = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, R = j.R[job], C = j.C[job];
+    if (blockIdx.x * 64 >= C) return;
+    const int per = (R + HG_RS - 1) / HG_RS, r0 = rs * per, r1 = min(R, r0 + per);
+    const float *x = j.x[job];
+    const long long ld = j.ld[job];
     float s = 0.f;
-    if (c < C)
-        for (int r = wave; r < R; r += 4) s += x[(long long)r * ld + c];
+    if (c < C) {
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {   // four rows in flight per lane
+            const float a0 = x[(long long)r * ld + c], a1 = x[(long long)(r + 4) * ld + c], a2 = x[(long long)(r + 8) * ld + c],
+                        a3 = x[(long long)(r + 12) * ld + c];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; r < r1; r += 4) s += x[(long long)r * ld + c];
+    }
     sh[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && c < C) {
-        const float v = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
-        out[c] = accum ? out[c] + v : v;
-    }
+    if (wave == 0 && c < C) part[((long long)job * HG_RS + rs) * j.cmax + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+__global__ void hg_colsum2_kernel(const HgColsumJobs j, const float *__restrict__ part) {
+    const int job = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= j.C[job]) return;
+    float s = 0.f;
+#pragma unroll
+    for (int rs = 0; rs < HG_RS; rs++) s += part[((long long)job * HG_RS + rs) * j.cmax + c];
+    float *o = j.out[job];
+    o[c] = j.accum[job] ? o[c] + s : s;
 }
 
-int hg_colsum(const float *x, long long ld, int R, int C, float *out, int accum, hipStream_t s) {
-    if (C <= 0) return 0;
-    hg_colsum_kernel<<<(C + 63) / 64, 256, 0, s>>>(x, ld, R, C, out, accum);
+size_t hg_colsum_ws_bytes(int njobs, int cmax) { return (size_t)njobs * HG_RS * cmax * 4; }
+
+// n <= HG_MAXCS column sums in two launches; ws >= hg_colsum_ws_bytes(n, max C)
+int hg_colsum_multi(const float *const *x, const long long *ld, const int *R, const int *C, float *const *out, const int *accum, int n,
+                    void *ws, size_t ws_bytes, hipStream_t s) {
+    if (n < 1 || n > HG_MAXCS) return D3_ERR_ARG;
+    HgColsumJobs j;
+    j.cmax = 0;
+    for (int i = 0; i < HG_MAXCS; i++) {
+        const int q = i < n ? i : 0;
+        j.x[i] = x[q]; j.out[i] = out[q]; j.ld[i] = ld[q]; j.R[i] = R[q]; j.C[i] = C[q]; j.accum[i] = accum ? accum[q] : 0;
+        if (i < n && C[i] > j.cmax) j.cmax = C[i];
+    }
+    if (j.cmax <= 0) return 0;
+    if (ws_bytes < hg_colsum_ws_bytes(n, j.cmax)) return D3_ERR_WORKSPACE;
+    hg_colsum1_kernel<<<dim3((j.cmax + 63) / 64, HG_RS, n), 256, 0, s>>>(j, (float *)ws);
+    hg_colsum2_kernel<<<dim3((j.cmax + 255) / 256, n), 256, 0, s>>>(j, (const float *)ws);
     D3_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *stream) {
+extern "C" size_t d3_colsum_ws_bytes(int C) { return hg_colsum_ws_bytes(1, C); }
+extern "C" int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *ws, size_t ws_bytes, void *stream) {
     D3_CLEAR();
-    return hg_colsum(x, ld, R, C, out, accum, d3_stream(stream));
+    return hg_colsum_multi(&x, &ld, &R, &C, &out, &accum, 1, ws, ws_bytes, d3_stream(stream));
 }

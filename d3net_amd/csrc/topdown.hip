@@ -28,7 +28,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s);
-int hg_colsum(const float *x, long long ld, int R, int C, float *out, int accum, hipStream_t s);
+size_t hg_colsum_ws_bytes(int njobs, int cmax);
+int hg_colsum_multi(const float *const *x, const long long *ld, const int *R, const int *C, float *const *out, const int *accum, int n,
+                    void *ws, size_t ws_bytes, hipStream_t s);
 
 // ------------------------------------------------------------------------------ fused GRUCell forward
 // h' = GRUCell(x, h) (torch.nn.GRUCell semantics: r, z, n gate order; n = tanh(W_in x + b_in + r * (W_hn h + b_hn))).
@@ -52,9 +54,10 @@ __device__ __forceinline__ f32x4 td_load4(const float *row, int k0, int K, bool 
     return v;
 }
 
+#define GRU_NW 8     // waves per workgroup: [x | h] is 51 k blocks at (300, 512): two batches of loads per wave
 template <int RT>
-__global__ __launch_bounds__(256) void td_gru_fwd_kernel(const GruArgs a) {
-    __shared__ float red[4 * 4 * RT * 256];   // [wave][acc][rt][q][lane]
+__global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a) {
+    __shared__ float red[GRU_NW * 4 * RT * 256];   // [wave][acc][rt][q][lane]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
     const int ct = blockIdx.x, rg = blockIdx.y, H = a.H;
     f32x4 accR[RT], accZ[RT], accNI[RT], accNH[RT];
@@ -78,22 +81,22 @@ __global__ __launch_bounds__(256) void td_gru_fwd_kernel(const GruArgs a) {
             xr[r] = X + (long long)(xv[r] ? row : 0) * ldx;
         }
         const float *w0 = W + (long long)col * K, *w1 = W + (long long)(H + col) * K, *w2 = W + (long long)(2 * H + col) * K;
-        const int first = (wave - gkb) & 3;
+        const int first = (wave - gkb) & (GRU_NW - 1);
         gkb += nkb;
         constexpr int U = 2;
-        for (int kb0 = first; kb0 < nkb; kb0 += 4 * U) {
+        for (int kb0 = first; kb0 < nkb; kb0 += GRU_NW * U) {
             f32x4 xa[U][RT], b0[U], b1[U], b2[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int k0 = (kb0 + 4 * u) * 16 + g * 4;
-                const bool in = kb0 + 4 * u < nkb;
+                const int k0 = (kb0 + GRU_NW * u) * 16 + g * 4;
+                const bool in = kb0 + GRU_NW * u < nkb;
                 b0[u] = td_load4(w0, k0, K, in); b1[u] = td_load4(w1, k0, K, in); b2[u] = td_load4(w2, k0, K, in);
 #pragma unroll
                 for (int r = 0; r < RT; r++) xa[u][r] = td_load4(xr[r], k0, K, in && xv[r]);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (kb0 + 4 * u < nkb) {
+                if (kb0 + GRU_NW * u < nkb) {
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -117,16 +120,15 @@ __global__ __launch_bounds__(256) void td_gru_fwd_kernel(const GruArgs a) {
             red[(((wave * 4 + 3) * RT + r) * 4 + q) * 64 + lane] = accNH[r][q];
         }
     __syncthreads();
-#pragma unroll
-    for (int nn = 0; nn < RT; nn++) {
-        const int e = t + nn * 256, r = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+    for (int e = t; e < RT * 256; e += GRU_NW * 64) {
+        const int r = e >> 8, q = (e >> 6) & 3, ln = e & 63;
         const int row = (rg * RT + r) * 16 + (ln >> 4) * 4 + q, c = ct * 16 + (ln & 15);
         float s[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) v += red[(((w * 4 + k) * RT + r) * 4 + q) * 64 + ln];
+            for (int w = 0; w < GRU_NW; w++) v += red[(((w * 4 + k) * RT + r) * 4 + q) * 64 + ln];
             s[k] = v;
         }
         if (row >= a.N) continue;
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256) void td_gru_fwd_kernel(const GruArgs a) {
 static int td_gru_fwd(const GruArgs &a, hipStream_t s) {
     if (a.H & 15) return D3_ERR_ARG;
     if (a.N <= 0) return 0;
-    if (a.N <= 16) td_gru_fwd_kernel<1><<<dim3(a.H / 16, 1), 256, 0, s>>>(a);
-    else td_gru_fwd_kernel<2><<<dim3(a.H / 16, (a.N + 31) / 32), 256, 0, s>>>(a);
+    if (a.N <= 16) td_gru_fwd_kernel<1><<<dim3(a.H / 16, 1), GRU_NW * 64, 0, s>>>(a);
+    else td_gru_fwd_kernel<2><<<dim3(a.H / 16, (a.N + 31) / 32), GRU_NW * 64, 0, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -177,109 +179,186 @@ __global__ void td_gru_bwd_gates_kernel(const float *d0, long long ld0, const fl
 }
 
 // ------------------------------------------------------------------------------ top-down attention
-// One workgroup per sample: scores of the unmasked proposals (masked scores are 0 -- `masked_fill_(mask == 0, 0)`, not
-// -inf: caption_module.py:112-114 -- so only the <= num_locals unmasked ones need the 512-wide tanh), softmax over all K,
-// attended feature.  attn_out: (N, K, S) slice t of `topdown_attn` (NULL: not wanted).
-__global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
-                                                          const float *__restrict__ watt, const float *__restrict__ obj,
-                                                          const float *__restrict__ mask, float *__restrict__ a_out,
-                                                          float *__restrict__ att, long long ldatt, float *__restrict__ attn_out,
-                                                          int t_step, int S, int K, int H, int F, int obj_div) {
-    extern __shared__ float sm[];
-    float *qs = sm, *ws = qs + H, *sc = ws + H, *part = sc + K;   // part: 2*F
-    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long long ns = n / obj_div;      // obj / fp row block of this sample (evaluation: the K targets of a scene share it)
-    for (int c = t; c < H; c += 256) { qs[c] = q[(long long)n * ldq + c]; ws[c] = watt[c]; }
-    __syncthreads();
-    for (int k = wave; k < K; k += 4) {
-        float s = 0.f;
-        if (mask[(long long)n * K + k] != 0.f) {    // wave-uniform
-            const float *row = fp + (ns * K + k) * H;
-            for (int c = lane * 4; c < H; c += 256) {
-                const f32x4 v = *(const f32x4 *)(row + c);
-#pragma unroll
-                for (int j = 0; j < 4; j++) s += ws[c + j] * tanhf(v[j] + qs[c + j]);
-            }
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+// scores[k] = attend . tanh(map_feat(obj)[k] + map_hidd(h1)); masked proposals get score 0 -- `masked_fill_(mask == 0, 0)`, not
+// -inf: caption_module.py:112-114 -- and still take part in the softmax.  With num_locals = 10 only ~10 of the K = 128
+// proposals are unmasked, so the kernels work on the ACTIVE list only and treat the masked ones in closed form:
+//   every masked k has the same probability a_m = exp(0 - max) / sum;  attended = a_m * (sum of the masked objects'
+//   features, constant over the time steps: `msum`) + sum_active a[k] obj[k];
+//   backward: sum_k a[k] da[k] = datt . attended (no K x F product), ds[k] != 0 only for active k; the gradient w.r.t. the
+//   object features, dobj[k] = sum_t a_t[k] datt_t, is accumulated after the time loop from the saved a / datt.
+__global__ __launch_bounds__(256) void td_attn_prep_kernel(const float *__restrict__ mask, const float *__restrict__ obj,
+                                                           int *__restrict__ act, int *__restrict__ nact, float *__restrict__ msum,
+                                                           int K, int F, int obj_div) {
+    __shared__ int cnt;
+    extern __shared__ float sm[];          // 2*F partial sums
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const long long ns = n / obj_div;
+    if (t < 64) {                          // wave 0: active list in ascending k (ballot + prefix popcount)
+        int base = 0;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            const bool on = k < K && mask[(long long)n * K + k] != 0.f;
+            const unsigned long long bal = __ballot(on);
+            if (on) act[(long long)n * K + base + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+            base += __popcll(bal);
         }
-        if (lane == 0) sc[k] = s;
+        if (lane == 0) { cnt = base; nact[n] = base; }
     }
     __syncthreads();
-    if (wave == 0) {   // softmax over the K proposals
-        float mx = -3.0e38f;
-        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, sc[k]);
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
-        for (int k = lane; k < K; k += 64) { const float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.f / sum;
-        for (int k = lane; k < K; k += 64) {
-            const float p = sc[k] * inv;
-            sc[k] = p;
-            a_out[(long long)n * K + k] = p;
-            if (attn_out) attn_out[((long long)n * K + k) * S + t_step] = p;
-        }
-    }
-    __syncthreads();
-    // attended[c] = sum_k a[k] obj[n,k,c]: two halves of k per column, fixed order
     const int half = t / F, c = t - half * F;
     float s = 0.f;
     if (half < 2) {
         const int k0 = half * ((K + 1) / 2), k1 = min(K, k0 + (K + 1) / 2);
-        for (int k = k0; k < k1; k++) s += sc[k] * obj[(ns * K + k) * F + c];
+        for (int k = k0; k < k1; k++)
+            if (mask[(long long)n * K + k] == 0.f) s += obj[(ns * K + k) * F + c];
+        sm[half * F + c] = s;
+    }
+    __syncthreads();
+    if (t < F) msum[(long long)n * F + t] = sm[t] + sm[F + t];
+}
+
+// one workgroup per sample; attn_out: (N, K, S) slice t of `topdown_attn` (NULL: not wanted)
+__global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
+                                                          const float *__restrict__ watt, const float *__restrict__ obj,
+                                                          const int *__restrict__ act, const int *__restrict__ nact,
+                                                          const float *__restrict__ msum, float *__restrict__ a_out,
+                                                          float *__restrict__ att, long long ldatt, float *__restrict__ attn_out,
+                                                          int t_step, int S, int K, int H, int F, int obj_div) {
+    extern __shared__ float sm[];
+    float *qs = sm, *ws = qs + H, *sc = ws + H, *ak = sc + K, *part = ak + K;   // part: 2*F
+    __shared__ float am_s;
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long ns = n / obj_div;      // obj / fp row block of this sample (evaluation: the K targets of a scene share it)
+    const int na = nact[n], nm = K - na;
+    const int *al = act + (long long)n * K;
+    for (int c = t; c < H; c += 256) { qs[c] = q[(long long)n * ldq + c]; ws[c] = watt[c]; }
+    __syncthreads();
+    for (int j = wave; j < na; j += 4) {
+        const float *row = fp + (ns * K + al[j]) * H;
+        float s = 0.f;
+        for (int c = lane * 4; c < H; c += 256) {
+            const f32x4 v = *(const f32x4 *)(row + c);
+#pragma unroll
+            for (int u = 0; u < 4; u++) s += ws[c + u] * tanhf(v[u] + qs[c + u]);
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) sc[j] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {   // softmax over all K proposals: nm of them at score 0
+        float mx = nm > 0 ? 0.f : -3.0e38f;
+        for (int j = lane; j < na; j += 64) mx = fmaxf(mx, sc[j]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = lane; j < na; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float e0 = expf(-mx);
+        sum += (float)nm * e0;
+        const float inv = 1.f / sum;
+        for (int j = lane; j < na; j += 64) sc[j] *= inv;
+        if (lane == 0) am_s = e0 * inv;
+    }
+    __syncthreads();
+    const float am = am_s;
+    for (int k = t; k < K; k += 256) ak[k] = am;
+    __syncthreads();
+    for (int j = t; j < na; j += 256) ak[al[j]] = sc[j];
+    __syncthreads();
+    for (int k = t; k < K; k += 256) {
+        a_out[(long long)n * K + k] = ak[k];
+        if (attn_out) attn_out[((long long)n * K + k) * S + t_step] = ak[k];
+    }
+    // attended[c] = a_m * msum[c] + sum_active a[k] obj[k, c]: two halves of the active list per column, fixed order
+    const int half = t / F, c = t - half * F;
+    if (half < 2) {
+        const int j0 = half * ((na + 1) / 2), j1 = min(na, j0 + (na + 1) / 2);
+        float s = 0.f;
+        for (int j = j0; j < j1; j++) s += sc[j] * obj[(ns * K + al[j]) * F + c];
         part[half * F + c] = s;
     }
     __syncthreads();
-    if (t < F) att[(long long)n * ldatt + t] = part[t] + part[F + t];
+    if (t < F) att[(long long)n * ldatt + t] = am * msum[(long long)n * F + t] + (part[t] + part[F + t]);
 }
 
-// backward of the above for one step: datt (N,F) -> dq (N,H), dfp (N,K,H) +=, dobj (N,K,F) +=, dwpart row (H)
+// backward of one step: datt (N,F) -> dq (N,H), dfp rows of the active proposals +=, dwpart row (H); datt is also copied to
+// dattS (N,F) for the accumulation of dobj after the time loop
 __global__ __launch_bounds__(256) void td_attn_bwd_kernel(const float *__restrict__ datt, long long lddatt, const float *__restrict__ a_in,
-                                                          const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
-                                                          const float *__restrict__ watt, const float *__restrict__ obj,
-                                                          const float *__restrict__ mask, float *__restrict__ dq, long long lddq,
-                                                          float *__restrict__ dfp, float *__restrict__ dobj, float *__restrict__ dwpart,
+                                                          const float *__restrict__ att, long long ldatt, const float *__restrict__ fp,
+                                                          const float *__restrict__ q, long long ldq, const float *__restrict__ watt,
+                                                          const float *__restrict__ obj, const int *__restrict__ act,
+                                                          const int *__restrict__ nact, float *__restrict__ dq, long long lddq,
+                                                          float *__restrict__ dfp, float *__restrict__ dwpart, float *__restrict__ dattS,
                                                           int K, int H, int F) {
     extern __shared__ float sm[];
-    float *das = sm, *dss = das + K, *as = dss + K, *dat = as + K, *red = dat + F;   // red: 4
+    float *dat = sm, *dss = dat + F, *red = dss + K;   // red: 4
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int c = t; c < F; c += 256) dat[c] = datt[(long long)n * lddatt + c];
-    for (int k = t; k < K; k += 256) as[k] = a_in[(long long)n * K + k];
-    __syncthreads();
-    for (int k = wave; k < K; k += 4) {     // da[k] = datt . obj[k];  dobj[k] += a[k] * datt
-        const float ak = as[k];
-        float s = 0.f;
-        for (int c = lane; c < F; c += 64) {
-            const long long o = ((long long)n * K + k) * F + c;
-            s += dat[c] * obj[o];
-            dobj[o] += ak * dat[c];
-        }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) das[k] = s;
+    const int na = nact[n];
+    const int *al = act + (long long)n * K;
+    float pd = 0.f;
+    for (int c = t; c < F; c += 256) {
+        const float v = datt[(long long)n * lddatt + c];
+        dat[c] = v; dattS[(long long)n * F + c] = v;
+        pd += v * att[(long long)n * ldatt + c];
     }
+    for (int o = 32; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
+    if (lane == 0) red[wave] = pd;
     __syncthreads();
-    float dot = 0.f;
-    for (int k = t; k < K; k += 256) dot += as[k] * das[k];
-    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-    if (lane == 0) red[wave] = dot;
-    __syncthreads();
-    dot = red[0] + red[1] + red[2] + red[3];
-    for (int k = t; k < K; k += 256) dss[k] = mask[(long long)n * K + k] != 0.f ? as[k] * (das[k] - dot) : 0.f;
+    const float dot = (red[0] + red[1]) + (red[2] + red[3]);      // sum_k a[k] da[k] = datt . attended
+    for (int j = wave; j < na; j += 4) {
+        const int k = al[j];
+        float s = 0.f;
+        for (int c = lane; c < F; c += 64) s += dat[c] * obj[((long long)n * K + k) * F + c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) dss[j] = a_in[(long long)n * K + k] * (s - dot);
+    }
     __syncthreads();
     for (int c = t; c < H; c += 256) {
         const float qc = q[(long long)n * ldq + c], wc = watt[c];
         float dqa = 0.f, dwa = 0.f;
-        for (int k = 0; k < K; k++) {
-            const float ds = dss[k];
-            if (ds == 0.f) continue;        // masked proposals (and exact zeros) contribute nothing
-            const long long o = ((long long)n * K + k) * H + c;
-            const float th = tanhf(fp[o] + qc);
-            const float dp = ds * wc * (1.f - th * th);
-            dfp[o] += dp;
-            dqa += dp; dwa += ds * th;
+        for (int j0 = 0; j0 < na; j0 += 4) {          // four rows' loads in flight
+            float fv[4], dv[4];
+            long long o[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u < na ? j0 + u : j0;
+                o[u] = ((long long)n * K + al[j]) * H + c;
+                fv[u] = fp[o[u]]; dv[u] = dfp[o[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (j0 + u < na) {
+                    const float ds = dss[j0 + u];
+                    const float th = tanhf(fv[u] + qc);
+                    const float dp = ds * wc * (1.f - th * th);
+                    dfp[o[u]] = dv[u] + dp;
+                    dqa += dp; dwa += ds * th;
+                }
+            }
         }
         dq[(long long)n * lddq + c] = dqa;
         dwpart[(long long)n * H + c] = dwa;
+    }
+}
+
+// dobj[n, k, c] = sum_t a[t, n, k] * datt[t, n, c]  (after the time loop; S*(K+F) floats staged per sample)
+__global__ __launch_bounds__(256) void td_dobj_kernel(const float *__restrict__ a, const float *__restrict__ dattS, float *__restrict__ dobj,
+                                                      int S, int N, int K, int F, int SC) {
+    extern __shared__ float sm[];
+    float *aS = sm, *dS = aS + (size_t)SC * K;
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int c = t % F, kb = t / F, kst = 256 / F;       // F divides 256 (host check)
+    for (int s0 = 0; s0 < S; s0 += SC) {
+        const int sc = min(SC, S - s0);
+        __syncthreads();
+        for (int e = t; e < sc * K; e += 256) { const int tt = e / K, k = e - tt * K; aS[e] = a[((long long)(s0 + tt) * N + n) * K + k]; }
+        for (int e = t; e < sc * F; e += 256) { const int tt = e / F, cc = e - tt * F; dS[e] = dattS[((long long)(s0 + tt) * N + n) * F + cc]; }
+        __syncthreads();
+        for (int k = kb; k < K; k += kst) {
+            float v = 0.f;
+            for (int tt = 0; tt < sc; tt++) v += aS[tt * K + k] * dS[tt * F + c];
+            float *o = dobj + ((long long)n * K + k) * F + c;
+            *o = s0 == 0 ? v : *o + v;
+        }
     }
 }
 
@@ -329,7 +408,7 @@ static d3_gemm_prob td_prob(int M, int N, float *C, long long ldc) {
 
 // ------------------------------------------------------------------------------ workspace layout
 struct TdLayout {
-    size_t widx, nidx, bidx, fp, TD, x1, x2, H1, H2, g1, g2, q, a, att, c0, total;   // byte offsets; g1/g2: r,z,n,ghn blocks
+    size_t widx, nidx, bidx, act, nact, msum, fp, TD, x1, x2, H1, H2, g1, g2, q, a, att, c0, total;   // byte offsets; g1/g2: r,z,n,ghn blocks
 };
 static TdLayout td_layout(int N, int K, int S, int H, int E, int F) {
     TdLayout L;
@@ -337,6 +416,7 @@ static TdLayout td_layout(int N, int K, int S, int H, int E, int F) {
     const size_t R = (size_t)S * N;
     auto take = [&](size_t bytes) { size_t at = o; o += d3_align(bytes); return at; };
     L.widx = take(R * 4); L.nidx = take(R * 4); L.bidx = take(R * 4);
+    L.act = take((size_t)N * K * 4); L.nact = take((size_t)N * 4); L.msum = take((size_t)N * F * 4);
     L.fp = take((size_t)N * K * H * 4);
     L.TD = take(R * E * 4); L.x1 = take(R * E * 4); L.x2 = take(R * E * 4);
     L.H1 = take((R + N) * H * 4); L.H2 = take((R + N) * H * 4);
@@ -352,7 +432,7 @@ extern "C" size_t d3_topdown_ws_bytes(int N, int K, int S, int H, int E, int F) 
 
 static int td_check(const d3_topdown_args *a) {
     if (!a || a->N < 1 || a->K < 1 || a->S < 1 || a->V < 1) return D3_ERR_ARG;
-    if ((a->H & 15) || (a->E & 3) || (a->F & 3) || a->F > 128 || a->K > 1024) return D3_ERR_ARG;
+    if ((a->H & 15) || (a->E & 3) || (a->F & 3) || a->F > 128 || (256 % a->F) || a->K > 1024) return D3_ERR_ARG;
     if (a->ws_bytes < td_layout(a->N, a->K, a->S, a->H, a->E, a->F).total) return D3_ERR_WORKSPACE;
     return 0;
 }
@@ -370,9 +450,12 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
     float *fp = (float *)(ws + L.fp), *TD = (float *)(ws + L.TD), *x1 = (float *)(ws + L.x1), *x2 = (float *)(ws + L.x2);
     float *H1 = (float *)(ws + L.H1), *H2 = (float *)(ws + L.H2), *g1 = (float *)(ws + L.g1), *g2 = (float *)(ws + L.g2);
     float *q = (float *)(ws + L.q), *av = (float *)(ws + L.a), *att = (float *)(ws + L.att), *c0 = (float *)(ws + L.c0);
+    int *act = (int *)(ws + L.act), *nact = (int *)(ws + L.nact);
+    float *msum = (float *)(ws + L.msum);
     const long long ldtd = H + F + E;          // map_topdown weight: (E, E + H + F) over [emb | h2 | target]
     const long long ldlang = F + H;            // map_lang weight: (E, F + H) over [attended | h1]
     td_rows_kernel<<<(R + 255) / 256, 256, 0, s>>>(a->word_ids, a->Tw, N, S, widx, nidx, bidx);
+    td_attn_prep_kernel<<<N, 256, (size_t)2 * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, 1);
     D3_CHECK(hipMemsetAsync(H1, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(H2, 0, (size_t)N * H * 4, s));
     {   // batched, recurrence-free parts: map_feat(obj) and the [embedding | target] part of map_topdown (+ bias)
@@ -407,8 +490,8 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
             p.nseg = 1; p.seg[0] = td_seg(h1n, H, a->W_hidd, H, H);
             if ((rc = hg_launch(&p, 1, s))) return rc;
         }
-        td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, a->mask, av + rN * K,
-                                                                         att + rN * F, F, a->attn, t, S, K, H, F, 1);
+        td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, act, nact, msum, av + rN * K,
+                                                                             att + rN * F, F, a->attn, t, S, K, H, F, 1);
         {   // x2 = map_lang([attended | h1])
             d3_gemm_prob p = td_prob(N, E, x2 + rN * E, E);
             p.nseg = 2;
@@ -438,7 +521,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
 }
 
 // ------------------------------------------------------------------------------ backward through time
-struct TdBwdLayout { size_t dlog, dc0, dH2, dgi1, dgh1, dgi2, dgh2, dx1, dx2, dq, tmpL, dh1q, dh1c, dh2c, dfp, dwp, dx1s, total; };
+struct TdBwdLayout { size_t dlog, dc0, dH2, dgi1, dgh1, dgi2, dgh2, dx1, dx2, dq, tmpL, dh1q, dh1c, dh2c, dfp, dwp, dx1s, dattS, cs, cs_bytes, total; };
 static TdBwdLayout td_bwd_layout(int N, int K, int S, int V, int H, int E, int F) {
     TdBwdLayout L;
     size_t o = 0;
@@ -449,6 +532,8 @@ static TdBwdLayout td_bwd_layout(int N, int K, int S, int V, int H, int E, int F
     L.dx1 = take(R * E * 4); L.dx2 = take(R * E * 4); L.dq = take(R * H * 4);
     L.tmpL = take((size_t)N * (F + H) * 4); L.dh1q = take((size_t)N * H * 4); L.dh1c = take((size_t)N * H * 4); L.dh2c = take((size_t)N * H * 4);
     L.dfp = take((size_t)N * K * H * 4); L.dwp = take(R * H * 4); L.dx1s = take((size_t)N * E * 4);
+    L.dattS = take(R * F * 4);
+    L.cs_bytes = hg_colsum_ws_bytes(8, V > 3 * H ? V : 3 * H); L.cs = take(L.cs_bytes);
     L.total = o;
     return L;
 }
@@ -477,7 +562,8 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
     float *dgi1 = (float *)(bw + B.dgi1), *dgh1 = (float *)(bw + B.dgh1), *dgi2 = (float *)(bw + B.dgi2), *dgh2 = (float *)(bw + B.dgh2);
     float *dx1 = (float *)(bw + B.dx1), *dx2 = (float *)(bw + B.dx2), *dq = (float *)(bw + B.dq), *tmpL = (float *)(bw + B.tmpL);
     float *dh1q = (float *)(bw + B.dh1q), *dh1c = (float *)(bw + B.dh1c), *dh2c = (float *)(bw + B.dh2c);
-    float *dfp = (float *)(bw + B.dfp), *dwp = (float *)(bw + B.dwp), *dx1s = (float *)(bw + B.dx1s);
+    float *dfp = (float *)(bw + B.dfp), *dwp = (float *)(bw + B.dwp), *dx1s = (float *)(bw + B.dx1s), *dattS = (float *)(bw + B.dattS);
+    const int *act = (const int *)(ws + L.act), *nact = (const int *)(ws + L.nact);
     const long long ldtd = H + F + E, ldlang = F + H;
     const size_t RH = (size_t)R * H;
     // ---- classifier (batched over time).  dlog: time-major copy of dlogits (gathered rows), then
@@ -502,13 +588,13 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         if ((rc = hg_launch(&p[0], 1, s))) return rc;
         if ((rc = hg_launch(&p[1], 1, s))) return rc;
         if ((rc = hg_launch(&p[2], 1, s))) return rc;
-        if ((rc = hg_colsum(dlog, V, R, V, gd->dbc2, 0, s))) return rc;
-        if ((rc = hg_colsum(dc0, H, R, H, gd->dbc0, 0, s))) return rc;
+        const float *cx[2] = {dlog, dc0}; const long long cl[2] = {V, H}; const int cr[2] = {R, R}, cc[2] = {V, H};
+        float *co[2] = {gd->dbc2, gd->dbc0};
+        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 2, bw + B.cs, B.cs_bytes, s))) return rc;
     }
     D3_CHECK(hipMemsetAsync(dh1c, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(dh2c, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(dfp, 0, (size_t)N * K * H * 4, s));
-    D3_CHECK(hipMemsetAsync(gd->dobj, 0, (size_t)N * K * F * 4, s));
     const int nh = (N * H + 255) / 256;
     for (int t = S - 1; t >= 0; t--) {
         const size_t rN = (size_t)t * N;
@@ -529,8 +615,8 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
             p.nseg = 1; p.seg[0] = td_seg(dx2 + rN * E, E, a->W_lang, ldlang, E, nullptr, 0, 1);
             if ((rc = hg_launch(&p, 1, s))) return rc;
         }
-        td_attn_bwd_kernel<<<N, 256, (size_t)(3 * K + F + 4) * 4, s>>>(tmpL, F + H, av + rN * K, fp, q + rN * H, H, a->w_att, a->obj, a->mask,
-                                                                     dq + rN * H, H, dfp, gd->dobj, dwp + rN * H, K, H, F);
+        td_attn_bwd_kernel<<<N, 256, (size_t)(F + K + 4) * 4, s>>>(tmpL, F + H, av + rN * K, att + rN * F, F, fp, q + rN * H, H, a->w_att,
+                                                                 a->obj, act, nact, dq + rN * H, H, dfp, dwp + rN * H, dattS + rN * F, K, H, F);
         {   // dh1 (through map_hidd) = dq W_hidd
             d3_gemm_prob p = td_prob(N, H, dh1q, H);
             p.nseg = 1; p.seg[0] = td_seg(dq + rN * H, H, a->W_hidd, H, H, nullptr, 0, 1);
@@ -562,10 +648,12 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         p[2] = td_prob(3 * H, E, gd->dWih1, E); p[2].nseg = 1; p[2].seg[0] = td_seg(dgi1, 3 * H, x1, E, R, nullptr, 1, 1);
         p[3] = td_prob(3 * H, H, gd->dWhh1, H); p[3].nseg = 1; p[3].seg[0] = td_seg(dgh1, 3 * H, H1, H, R, nullptr, 1, 1);
         if ((rc = hg_launch(p, 4, s))) return rc;
-        if ((rc = hg_colsum(dgi2, 3 * H, R, 3 * H, gd->dbih2, 0, s))) return rc;
-        if ((rc = hg_colsum(dgh2, 3 * H, R, 3 * H, gd->dbhh2, 0, s))) return rc;
-        if ((rc = hg_colsum(dgi1, 3 * H, R, 3 * H, gd->dbih1, 0, s))) return rc;
-        if ((rc = hg_colsum(dgh1, 3 * H, R, 3 * H, gd->dbhh1, 0, s))) return rc;
+        // all remaining bias gradients (and the attention vector's) in one two-stage column sum
+        const float *cx[7] = {dgi2, dgh2, dgi1, dgh1, dx2, dx1, dwp};
+        const long long cl[7] = {3 * H, 3 * H, 3 * H, 3 * H, E, E, H};
+        const int cr[7] = {R, R, R, R, R, R, R}, cc[7] = {3 * H, 3 * H, 3 * H, 3 * H, E, E, H};
+        float *co[7] = {gd->dbih2, gd->dbhh2, gd->dbih1, gd->dbhh1, gd->db_lang, gd->db_td, gd->dw_att};
+        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 7, bw + B.cs, B.cs_bytes, s))) return rc;
     }
     {
         // map_lang: dW (E, F+H) = dx2^T [att | h1[1:]] ; map_hidd: dW = dq^T h1[1:] ; map_topdown: dW (E, E+H+F) = dx1^T [emb[w] | h2[:-1] | target]
@@ -575,9 +663,6 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         p[2] = td_prob(H, H, gd->dW_hidd, H); p[2].nseg = 1; p[2].seg[0] = td_seg(dq, H, H1 + (size_t)N * H, H, R, nullptr, 1, 1);
         p[3] = td_prob(E, H, gd->dW_td + E, ldtd); p[3].nseg = 1; p[3].seg[0] = td_seg(dx1, E, H2, H, R, nullptr, 1, 1);
         if ((rc = hg_launch(p, 4, s))) return rc;
-        if ((rc = hg_colsum(dx2, E, R, E, gd->db_lang, 0, s))) return rc;
-        if ((rc = hg_colsum(dx1, E, R, E, gd->db_td, 0, s))) return rc;
-        if ((rc = hg_colsum(dwp, H, R, H, gd->dw_att, 0, s))) return rc;
     }
     {
         // embedding / target parts of map_topdown need gathered k-major rows: materialise the two gathered matrices once
@@ -591,7 +676,9 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         // map_feat: dW_feat (H, F) = dfp^T obj (K = N*K rows)
         p[2] = td_prob(H, F, gd->dW_feat, F); p[2].nseg = 1; p[2].seg[0] = td_seg(dfp, H, a->obj, F, N * K, nullptr, 1, 1);
         if ((rc = hg_launch(p, 3, s))) return rc;
-        // dobj += dfp W_feat
+        // dobj = sum_t a_t (x) datt_t (the attention's weighted sum), then += dfp W_feat (through map_feat)
+        const int SC = S < 32 ? S : 32;
+        td_dobj_kernel<<<N, 256, (size_t)SC * (K + F) * 4, s>>>(av, dattS, gd->dobj, S, N, K, F, SC);
         d3_gemm_prob po = td_prob(N * K, F, gd->dobj, F);
         po.nseg = 1; po.seg[0] = td_seg(dfp, H, a->W_feat, F, H, nullptr, 0, 1); po.accum = 1;
         if ((rc = hg_launch(&po, 1, s))) return rc;
@@ -616,7 +703,8 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
 // classifier.0, classifier.2).  fp = map_feat(obj) is computed once per decode by d3_topdown_feat_proj.  obj_div: consecutive
 // samples sharing one (K,F) object block (the evaluation decode runs the K targets of a scene as K samples).
 extern "C" size_t d3_topdown_step_ws_bytes(int N, int K, int H, int E, int F) {
-    return d3_align((size_t)N * 4) + 2 * d3_align((size_t)N * E * 4) + 2 * d3_align((size_t)N * H * 4) + d3_align((size_t)N * F * 4) + 256;
+    return 2 * d3_align((size_t)N * 4) + 2 * d3_align((size_t)N * E * 4) + 2 * d3_align((size_t)N * H * 4) + 2 * d3_align((size_t)N * F * 4) +
+           d3_align((size_t)N * K * 4) + 256;
 }
 
 extern "C" int d3_topdown_feat_proj(const float *obj, const float *W_feat, float *fp, int rows, int H, int F, void *stream) {
@@ -642,10 +730,13 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
     D3Carver cv(ws_, ws_bytes);
     int *widx = cv.take<int>(N);
     float *x1 = cv.take<float>((size_t)N * E), *x2 = cv.take<float>((size_t)N * E), *q = cv.take<float>((size_t)N * H);
-    float *c0 = cv.take<float>((size_t)N * H), *att = cv.take<float>((size_t)N * F);
+    float *c0 = cv.take<float>((size_t)N * H), *att = cv.take<float>((size_t)N * F), *msum = cv.take<float>((size_t)N * F);
+    int *act = cv.take<int>((size_t)N * K), *nact = cv.take<int>(N);
     const long long ldtd = H + F + E, ldlang = F + H;
     int rc;
+    if (256 % F) return D3_ERR_ARG;
     td_word_idx_kernel<<<(N + 255) / 256, 256, 0, s>>>(word, widx, N);
+    td_attn_prep_kernel<<<N, 256, (size_t)2 * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, obj_div);
     {
         d3_gemm_prob p = td_prob(N, E, x1, E);
         p.nseg = 3;
@@ -664,7 +755,8 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
         p.nseg = 1; p.seg[0] = td_seg(h1_out, H, a->W_hidd, H, H);
         if ((rc = hg_launch(&p, 1, s))) return rc;
     }
-    td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + K + 2 * F) * 4, s>>>(fp, q, H, a->w_att, a->obj, a->mask, attn, att, F, nullptr, 0, 1, K, H, F, obj_div);
+    td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q, H, a->w_att, a->obj, act, nact, msum, attn, att, F, nullptr, 0, 1, K, H,
+                                                                         F, obj_div);
     {
         d3_gemm_prob p = td_prob(N, E, x2, E);
         p.nseg = 2;

@@ -347,8 +347,9 @@ typedef struct {
     int relu, accum, perm_nb, perm_s;
 } d3_gemm_prob;
 int d3_hgemm(const d3_gemm_prob *probs, int nprobs, void *stream);
-/* out[c] (+)= sum_r x[r*ld + c], r < R, c < C (bias gradients; fixed summation order) */
-int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *stream);
+/* out[c] (+)= sum_r x[r*ld + c], r < R, c < C (bias gradients; two-stage, fixed summation order); ws >= d3_colsum_ws_bytes(C) */
+size_t d3_colsum_ws_bytes(int C);
+int d3_colsum(const float *x, long long ld, int R, int C, float *out, int accum, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- top-down captioner, native (csrc/topdown.hip) -------------------------------------------------------
  * TopDownSceneCaptionModule (model/caption_module.py:13-62 parameters, :72-133 step, :510-687 teacher-forced driver):

@@ -112,7 +112,8 @@ def test_colsum(dev):
     x = torch.randn(992, 1536)
     xd = x.to(dev)
     out = torch.ones(1536, device=dev)
-    rc = _lib.lib().d3_colsum(C.c_void_p(xd.data_ptr()), 1536, 992, 1536, C.c_void_p(out.data_ptr()), 1,
-                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ws = torch.empty(_lib.lib().d3_colsum_ws_bytes(1536), dtype=torch.uint8, device=dev)
+    rc = _lib.lib().d3_colsum(C.c_void_p(xd.data_ptr()), 1536, 992, 1536, C.c_void_p(out.data_ptr()), 1, C.c_void_p(ws.data_ptr()),
+                              ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     _close(out, x.double().sum(0) + 1, 992)
