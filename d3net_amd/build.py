@@ -70,7 +70,8 @@ def build(force=False, verbose=False):
         objs = list(ex.map(_compile, srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < newest:
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs
+        # -z defs: an undefined host symbol (a helper renamed in one translation unit only) fails the build, not the first call
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-z,defs", "-o", SO] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from .captioning_loss import get_captioning_loss
 from .listener import ListenerNet, get_grounding_loss, get_lobjcls_loss
-from .pointgroup import PointGroup
+from .pointgroup import PointGroup, _mark
 from .speaker import SpeakerNet
 
 
@@ -106,9 +106,11 @@ class PipelineNet(nn.Module):
                     self.log("train/{}".format(k), v[0])
         elif self.mode == 1:
             data_dict = self.speaker(self._detect(data_dict))
+            _mark("speaker")
             _, data_dict = get_captioning_loss(data_dict, caption=not self.no_captioning, orientation=self.cfg.model.use_orientation,
                                                num_bins=self.cfg.data.num_ori_bins, loss_opt=self.loss_opt)
             loss = data_dict["total_loss"][0] + data_dict["cap_loss"] + 0.1 * data_dict["ori_loss"]
+            _mark("caption_losses")
             for k, v in {"loss": loss, "detect_loss": data_dict["total_loss"][0], "captioning_loss": data_dict["cap_loss"],
                          "orientation_loss": data_dict["ori_loss"], "cap_acc": data_dict["cap_acc"], "ori_acc": data_dict["ori_acc"],
                          "pred_ious": data_dict["pred_ious"]}.items():

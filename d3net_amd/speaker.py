@@ -644,6 +644,8 @@ class SpeakerNet(nn.Module):
     def forward(self, data_dict, use_tf=True, use_rl=False, is_eval=False, beam_opt={}):
         if self.cfg.model.num_graph_steps > 0:
             data_dict = self.graph(data_dict)
+            from .pointgroup import _mark
+            _mark("graph")
         if not self.cfg.model.no_captioning:
             data_dict = self.caption(data_dict, use_tf, use_rl, is_eval, beam_opt)
         return data_dict
