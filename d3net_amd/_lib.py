@@ -43,6 +43,7 @@ SIGNATURES = {
     "d3_ballquery_padded": (i32, [vp, vp, vp, i32, f32, vp, vp, sz, vp, vp]),
     "d3_bfs_cluster_ws_bytes": (sz, [i32]),
     "d3_bfs_cluster_count": (i32, [vp, vp, vp, i32, i32, vp, sz, pi, pi, vp]),
+    "d3_bfs_cluster_count_ex": (i32, [vp, vp, vp, i32, i32, vp, sz, pi, pi, i32, vp]),
     "d3_bfs_cluster_fill": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, i32, i32, vp]),
     "d3_bfs_cluster_erec_bytes": (sz, [i64]),
     "d3_bfs_cluster_fill2": (i32, [vp, vp, vp, i32, vp, sz, vp, sz, i64, vp, vp, i32, i32, vp]),

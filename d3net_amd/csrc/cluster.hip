@@ -51,6 +51,7 @@ struct ClWs {
     int *qln;      // n  BFS: list length of every queued node
     int *lid;      // n  BFS (record kernel): dense id of a node inside its cluster (any bijection)
     int *lcnt;     // n  per-owner counter behind lid
+    int *star;     // n  star[o] = 1: the kept cluster of owner o is the seed's own list (no level loop needed)
     int *scalars;  // [0]=changed [1]=nCluster [2]=sumNPoint
     void *temp; size_t temp_bytes;
 };
@@ -62,7 +63,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
     w.flag = c.take<int>(nn); w.cid = c.take<int>(nn); w.ksz = c.take<int>(nn); w.koff = c.take<int>(nn);
     w.seeds = c.take<int>(nn); w.par = c.take<int>(nn); w.queue = c.take<int>(nn); w.fcnt = c.take<int>(nn);
     w.qln = c.take<int>(nn);
-    w.lid = c.take<int>(nn); w.lcnt = c.take<int>(nn);
+    w.lid = c.take<int>(nn); w.lcnt = c.take<int>(nn); w.star = c.take<int>(nn);
     w.klen = c.take<int>(nn); w.estart = c.take<int>(nn);
     w.scalars = c.take<int>(64);
     w.temp_bytes = d3_scan_temp_bytes(n);
@@ -72,7 +73,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
 extern "C" size_t d3_bfs_cluster_ws_bytes(int n) {
     D3Carver c(nullptr, 0);
     size_t nn = (size_t)(n > 0 ? n : 1);
-    for (int i = 0; i < 17; i++) c.take<int>(nn);
+    for (int i = 0; i < 18; i++) c.take<int>(nn);
     c.take<int>(64);
     c.take<char>(d3_scan_temp_bytes(n));
     return c.off + 256;
@@ -160,7 +161,7 @@ __device__ __forceinline__ int cl_chase(const int *lab, int l) {
 __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                      const int *__restrict__ start_len, int n,
                                                      const int *__restrict__ root, int *lab, int *pushed,
-                                                     int *changed_flag, const int *__restrict__ capped_flag) {
+                                                     int *changed_flag, const int *__restrict__ capped_flag, int ascending) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
     if (*capped_flag == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
@@ -175,9 +176,33 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
     if (pushed[i] == li) return;          // (one wave per node: uniform)
     if (d3_lane() == 0) pushed[i] = li;
     bool changed = false;
+    // A push can only lower the label of a target j > li: lab[root(j)] <= root(j) <= j at all times (a label starts as the
+    // node's own index, a root is the smallest index of its tree, labels only decrease).  The lists are ascending
+    // (ball query order), so the useless targets j <= li are a PREFIX: found with two 64-way probes instead of walked --
+    // in a collapsed instance of m points whose lists all are its first 1000 members, a member's own rank of them.
+    int e_first = 0;
+    if (ascending && ln > 0) {      // (the caller vouches for ascending lists: D3_BFS_ASCENDING)
+        const int lane = d3_lane();
+        const int p = (int)(((long long)lane * ln) >> 6);               // 64 probes, probe 0 = entry 0
+        const unsigned long long gt = __ballot(idx[st + p] > li);
+        if (gt == 0ull) {                                               // every probe <= li: only the tail behind the last probe is left
+            const int p63 = (int)((63ll * ln) >> 6);
+            const int q = p63 + lane;
+            const unsigned long long g2 = __ballot(q < ln && idx[st + (q < ln ? q : 0)] > li);
+            // (the last segment is at most ln/64 + 1 <= 17 entries long)
+            e_first = g2 ? p63 + (int)__builtin_ctzll(g2) : ln;
+        } else {
+            const int f = (int)__builtin_ctzll(gt);                     // first probe > li; the boundary lies in (probe f-1, probe f]
+            const int lo = f == 0 ? 0 : (int)(((long long)(f - 1) * ln) >> 6);
+            const int hi = (int)(((long long)f * ln) >> 6);
+            const int q = lo + lane;
+            const unsigned long long g2 = __ballot(q <= hi && idx[st + (q <= hi ? q : lo)] > li);
+            e_first = g2 ? lo + (int)__builtin_ctzll(g2) : hi;
+        }
+    }
     // four edges per lane in flight: every edge is a chain of three dependent gathers (neighbour id -> its root ->
     // the root's label) and a capped list is 16 passes long
-    for (int e0 = d3_lane(); e0 < ln; e0 += 256) {
+    for (int e0 = e_first + d3_lane(); e0 < ln; e0 += 256) {
         int j[4], rj[4];
         bool ok[4];
 #pragma unroll
@@ -226,10 +251,26 @@ __global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz
     }
 }
 
+static int cl_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold, void *ws,
+                    size_t ws_bytes, int *sumNPoint_host, int *nCluster_host, int flags, void *stream);
+
 extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
                                     int n, int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host,
                                     int *nCluster_host, void *stream) {
+    return cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, sumNPoint_host, nCluster_host, 0, stream);
+}
+// flags: D3_BFS_ASCENDING -- every list is in ascending index order (what ballquery_batch_p produces): the label push then
+// skips, per node, the prefix of targets that cannot change
+extern "C" int d3_bfs_cluster_count_ex(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
+                                       int n, int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host,
+                                       int *nCluster_host, int flags, void *stream) {
+    return cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, sumNPoint_host, nCluster_host, flags, stream);
+}
+
+static int cl_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold, void *ws,
+                    size_t ws_bytes, int *sumNPoint_host, int *nCluster_host, int flags, void *stream) {
     D3_CLEAR();
+    const int asc = (flags & D3_BFS_ASCENDING) ? 1 : 0;
     *sumNPoint_host = 0; *nCluster_host = 0;
     if (n <= 0) return 0;
     ClWs w;
@@ -247,8 +288,8 @@ extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_q
     for (int it = 0;; it += 2) {
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3);
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars + 4, w.scalars + 3);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3, asc);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars + 4, w.scalars + 3, asc);
         if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
         cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
         cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);
@@ -464,12 +505,50 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
 #define B2_MAXSIZE (B2_BITWORDS * 32)
 #define B2_LDS_INTS (B2_BITWORDS + 2 * B2_HASH + 2 * B2_FMAX + 2 * (B2_FMAX + 8) + B2_HINTS + 160)
 
-__global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, const int *__restrict__ start_len,
-                              int *lcnt, int *lid, int *klen, int n) {
+// Star clusters: when every member of a kept cluster is in its seed's own list, the reference's FIFO BFS is the seed
+// followed by those members in list order and ends after the first level (every later pop finds only visited nodes).  That is
+// what the shifted coordinates produce -- an instance collapses onto its centre, every list is the instance's first 1000
+// members -- and it needs neither edge records (16 B per list entry of every member: 4 GB for 4 x 40 collapsed instances)
+// nor the level loop.  One wave per kept cluster: count the seed's same-owner entries, and if they are the whole cluster
+// write it out in list order (ballot compaction).
+__global__ __launch_bounds__(256) void cl_star_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
+                                                     const int *__restrict__ own, const int *__restrict__ seeds,
+                                                     const int *__restrict__ koff, const int *__restrict__ sizes, int nCluster,
+                                                     int *__restrict__ star, int *__restrict__ cluster_idxs) {
+    const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = d3_lane();
+    if (c >= nCluster) return;
+    const int s = seeds[c], st = start_len[s * 2], ln = start_len[s * 2 + 1], size = sizes[s];
+    int cnt = 0;
+    for (int e0 = 0; e0 < ln; e0 += 64) {
+        const int e = e0 + lane;
+        const int j = e < ln ? idx[st + e] : -1;
+        cnt += (int)__popcll(__ballot(j >= 0 && j != s && own[j] == s));
+    }
+    const bool is_star = cnt + 1 == size;
+    if (lane == 0) star[s] = is_star ? 1 : 0;
+    if (!is_star) return;
+    const size_t base = (size_t)koff[s];
+    if (lane == 0) { cluster_idxs[base * 2] = c; cluster_idxs[base * 2 + 1] = s; }
+    int pos = 1;
+    for (int e0 = 0; e0 < ln; e0 += 64) {
+        const int e = e0 + lane;
+        const int j = e < ln ? idx[st + e] : -1;
+        const bool m = j >= 0 && j != s && own[j] == s;
+        const unsigned long long bal = __ballot(m);
+        if (m) {
+            const size_t o = base + pos + __popcll(bal & d3_lanemask_lt());
+            cluster_idxs[o * 2] = c; cluster_idxs[o * 2 + 1] = j;
+        }
+        pos += (int)__popcll(bal);
+    }
+}
+
+__global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict__ flag, const int *__restrict__ star,
+                              const int *__restrict__ start_len, int *lcnt, int *lid, int *klen, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;   // tail lanes simply drop out of the ballots below
     const int o = own[i];
-    const bool kept = flag[o] != 0;
+    const bool kept = flag[o] != 0 && star[o] == 0;
     klen[i] = kept ? start_len[i * 2 + 1] : 0;
     // a wave holds only a few distinct owners: one atomic per distinct owner (leader = lowest lane of each group);
     // one atomic per NODE serialises tens of thousands of updates of the same counter in L2
@@ -494,12 +573,12 @@ __global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict
 // start at estart[i], the exclusive scan of the kept nodes' list lengths, and a record carries its target's estart.
 __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
                                                      const int *__restrict__ own, const int *__restrict__ flag,
-                                                     const int *__restrict__ lid, const int *__restrict__ estart,
-                                                     int4 *__restrict__ erec, int n) {
+                                                     const int *__restrict__ star, const int *__restrict__ lid,
+                                                     const int *__restrict__ estart, int4 *__restrict__ erec, int n) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
     const int oi = own[i];
-    if (!flag[oi]) return;
+    if (!flag[oi] || star[oi]) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     const long long es = estart[i];
     // four entries per lane per round trip pair (ids; then owner / dense id / record start / length of all four together,
@@ -571,7 +650,8 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                                                             const int *__restrict__ estart,
                                                             const int *__restrict__ lid, const int *__restrict__ seeds,
                                                             const int *__restrict__ koff, const int *__restrict__ sizes,
-                                                            int *qst_all, int *qln_all, int *cluster_idxs, int *dbg) {
+                                                            const int *__restrict__ star, int *qst_all, int *qln_all,
+                                                            int *cluster_idxs, int *dbg) {
     extern __shared__ __attribute__((aligned(16))) int b2_smem[];
     int n_levels = 0, n_batches = 0;
 #ifdef B2_TIMING
@@ -587,6 +667,7 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     const int c = blockIdx.x, tid = threadIdx.x;
     const int s = seeds[c], base = koff[s], size = sizes[s];
     if (size > B2_MAXSIZE) return;                                  // left to cl_bfs_kernel
+    if (star[s]) return;                                            // written by cl_star_kernel
     int *qst = qst_all + base, *qln = qln_all + base;
     const int words = (size + 31) >> 5;
     for (int w = tid; w < words; w += B2_THREADS) bitmap[w] = 0u;
@@ -793,13 +874,18 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
             attr_done = true;
         }
         D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
-        cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, start_len, w.lcnt, w.lid, w.klen, n);
+        D3_CHECK(hipMemsetAsync(w.star, 0, (size_t)n * sizeof(int), s));
+        const bool no_star = getenv("D3_BFS_NO_STAR") != nullptr;   // (tests: force the level loop for every cluster)
+        if (!no_star)
+            cl_star_kernel<<<(nCluster + 3) / 4, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.seeds, w.koff, w.sizes, nCluster, w.star,
+                                                           cluster_idxs);
+        cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, w.star, start_len, w.lcnt, w.lid, w.klen, n);
         int rc = d3_exclusive_scan_i32(w.klen, w.estart, n, w.temp, w.temp_bytes, s);
         if (rc) return rc;
-        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.lid, w.estart, (int4 *)erec, n);
+        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.lid, w.estart, (int4 *)erec, n);
         const bool debug = getenv("D3_BFS_DEBUG") != nullptr;
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
-                                                        w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
+                                                        w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
         if (debug) {
             int h[60 + 160];
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);

@@ -370,7 +370,7 @@ class PointGroup(nn.Module):
                         xyz, batch_idxs_, batch_offsets_, self.cluster_radius, mean_active)
                     if marks:
                         _mark("cl_ballquery")
-                    p_idx, p_off = pointgroup_ops.bfs_cluster(semantic_preds_, idx_, start_len_, self.cluster_npoint_thre)
+                    p_idx, p_off = pointgroup_ops.bfs_cluster(semantic_preds_, idx_, start_len_, self.cluster_npoint_thre, True)   # (ascending lists)
                     if marks:
                         _mark("cl_bfs")
                     p_idx[:, 1] = object_idxs[p_idx[:, 1].long()].int()

@@ -246,11 +246,13 @@ def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_byte
 
 class BFSCluster(Function):
     @staticmethod
-    def forward(ctx, semantic_label, ball_query_idxs, start_len, threshold):
+    def forward(ctx, semantic_label, ball_query_idxs, start_len, threshold, ascending=False):
         """
         :param semantic_label: (N), int
         :param ball_query_idxs: (nActive), int
         :param start_len: (N, 2), int
+        :param ascending: (not in the reference) the caller guarantees ascending neighbour lists -- ballquery_batch_p's order;
+            lets the label propagation skip the useless prefix of every list.  Same results.
         :return: cluster_idxs:  int (sumNPoint, 2), dim 0 for cluster_id, dim 1 for corresponding point idxs in N
         :return: cluster_offsets: int (nCluster + 1)
         """
@@ -267,8 +269,8 @@ class BFSCluster(Function):
         with _on(dev):
             ws = _workspace(L.d3_bfs_cluster_ws_bytes(N), dev, "cl")
             S, P = C.c_int(0), C.c_int(0)
-            check(L.d3_bfs_cluster_count(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(),
-                                         C.byref(S), C.byref(P), _stream()), "bfs_cluster_count")
+            check(L.d3_bfs_cluster_count_ex(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(),
+                                            C.byref(S), C.byref(P), 1 if ascending else 0, _stream()), "bfs_cluster_count")
             S, P = S.value, P.value
             cluster_idxs = torch.empty((S, 2), dtype=torch.int32, device=dev)
             cluster_offsets = torch.empty(P + 1, dtype=torch.int32, device=dev)
@@ -281,8 +283,8 @@ class BFSCluster(Function):
         return cluster_idxs, cluster_offsets
 
     @staticmethod
-    def backward(ctx, a=None):
-        return None
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None
 
 
 bfs_cluster = BFSCluster.apply

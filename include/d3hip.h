@@ -109,6 +109,12 @@ size_t d3_bfs_cluster_ws_bytes(int n);
 int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n,
                          int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host, int *nCluster_host,
                          void *stream);
+/* d3_bfs_cluster_count with flags.  D3_BFS_ASCENDING: the caller guarantees that every neighbour list is in ascending index
+ * order (ballquery_batch_p's order, src/bfs_cluster/bfs_cluster.cu:27-47): the label propagation then skips, per node, the
+ * prefix of neighbours whose label cannot change (two 64-way probes).  Same results. */
+#define D3_BFS_ASCENDING 1
+int d3_bfs_cluster_count_ex(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
+                            void *ws, size_t ws_bytes, int *sumNPoint_host, int *nCluster_host, int flags, void *stream);
 int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n,
                         void *ws, size_t ws_bytes, int *cluster_idxs, int *cluster_offsets, int sumNPoint,
                         int nCluster, void *stream);

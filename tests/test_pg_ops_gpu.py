@@ -226,6 +226,39 @@ def test_bfs_cluster_truncated_lists(dev):
     rci, rco = o.bfs_cluster(sem, idx, sl, 10)
     ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 10)
     assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 10, True)     # ascending-list hint (prefix-skipping label push)
+    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+
+
+@pytest.mark.parametrize("star", [True, False])
+def test_bfs_cluster_collapsed_instances_star_shortcut(dev, star, monkeypatch):
+    """The shifted-coordinate regime with exact offsets: every point of an instance sits on the instance centre, lists are
+    the instance's first 1000 members.  Clusters whose members all sit in the seed's list are written by cl_star_kernel
+    (no edge records, no level loop); instances of 999 / 1000 / 1001 / 1500 points straddle the 1000-entry cap (beyond it
+    the late members are reached by nobody and drop out as singletons -- the reference's behaviour).  Both code paths
+    (D3_BFS_NO_STAR forces the level loop) must equal the sequential oracle, in shuffled point order."""
+    from d3net_amd import pointgroup_ops as P
+    if not star:
+        monkeypatch.setenv("D3_BFS_NO_STAR", "1")
+    rng = np.random.default_rng(84)
+    sizes = [60, 999, 1000, 1001, 1500, 40, 300]
+    centres = rng.random((len(sizes), 3)).astype(np.float32) * 3
+    xyz = np.concatenate([np.repeat(c[None], m, 0) for c, m in zip(centres, sizes)])
+    # a sparse sheet as well: a cluster that needs many BFS levels next to the stars
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(30), indexing="ij"), -1).reshape(-1, 2).astype(np.float32) * 0.02
+    sheet = np.concatenate([g, np.full((len(g), 1), 5.0, np.float32)], 1)
+    xyz = np.concatenate([xyz, sheet])
+    sem = np.concatenate([np.full(m, 1 + k % 3, np.int32) for k, m in enumerate(sizes)] + [np.full(len(sheet), 2, np.int32)])
+    perm = rng.permutation(len(xyz))
+    xyz, sem = xyz[perm], sem[perm]
+    n = len(xyz)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
+    rci, rco = o.bfs_cluster(sem, idx, sl, 50)
+    assert sorted(np.diff(rco).tolist()) == [60, 300, 999, 1000, 1000, 1000, 1200]
+    for asc in (False, True):
+        ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, asc)
+        assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), (star, asc)
 
 
 @pytest.mark.parametrize("order", ["forward", "reverse", "shuffled"])
@@ -246,8 +279,9 @@ def test_bfs_cluster_capped_chain(dev, order):
     idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
     assert (sl[:, 1] >= 1000).sum() > n // 2
     rci, rco = o.bfs_cluster(sem, idx, sl, 10)
-    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 10)
-    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+    for asc in (False, True):
+        ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 10, asc)
+        assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), asc
 
 
 def test_bfs_cluster_no_clusters(dev):
@@ -284,7 +318,7 @@ def test_full_size_ballquery_and_cluster_properties(dev):
         d = xyz[i] - xyz
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         assert np.array_equal(idx[sl[i, 0]:sl[i, 0] + sl[i, 1]], np.nonzero(d2 < np.float32(0.03) * np.float32(0.03))[0])
-    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50)
+    ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, True)
     ci, co = N(ci), N(co)
     # clusters partition a subset of the points, are label-pure, sized >= 50, seeds ascending
     assert len(np.unique(ci[:, 1])) == len(ci)
