@@ -77,22 +77,24 @@ def _rl_cap_loss(data_dict, loss_opt):
 
 
 def compute_cap_loss(data_dict, loss_opt={}):
-    """(loss_helper.py:177-224) XE over the descriptions whose target box is good (IoU > min_iou_threshold)"""
+    """(loss_helper.py:177-224) XE over the descriptions whose target box is good (IoU > min_iou_threshold).
+    Same value as the reference's `pred[good]` selection, without its host round trip: the targets of the other
+    descriptions are set to the ignored index 0, and an all-bad batch gives 0 (the reference's else branch)."""
     if loss_opt.get("use_rl", False):
         return _rl_cap_loss(data_dict, loss_opt)
     max_len = loss_opt.get("max_len", 30)
     pred = data_dict["lang_cap"]
-    num_words = int(data_dict["lang_len"].reshape(-1).max())
+    num_words = pred.shape[1] + 1                                   # == int(lang_len.max()) (the captioner ran num_words - 1 steps)
     target = data_dict["lang_ids"].reshape(-1, max_len)[:, 1:num_words]
     good = data_dict["good_bbox_masks"]
-    if bool(good.sum() > 0):
-        V = pred.shape[2]
-        p, t = pred[good].reshape(-1, V), target[good].reshape(-1)
-        cap_loss = F.cross_entropy(p, t, ignore_index=0)
-        m = t != 0
-        cap_acc = (p.argmax(-1)[m] == t[m]).sum().float() / m.sum().float()
-    else:
-        cap_loss, cap_acc = pred.new_zeros(()), pred.new_zeros(())
+    V = pred.shape[2]
+    t = torch.where(good.unsqueeze(1), target, torch.zeros_like(target)).reshape(-1)
+    m = t != 0
+    cnt = m.sum()
+    denom = cnt.clamp(min=1).to(pred.dtype)
+    p = pred.reshape(-1, V)
+    cap_loss = F.cross_entropy(p, t, ignore_index=0, reduction="sum") / denom
+    cap_acc = ((p.argmax(-1) == t) & m).sum().to(pred.dtype) / denom
     z = data_dict["bbox_feature"].new_zeros(())
     data_dict["cap_rwd"], data_dict["loc_rwd"], data_dict["ttl_rwd"] = z, z, z
     data_dict["cap_loss"], data_dict["cap_acc"] = cap_loss, cap_acc
@@ -106,24 +108,28 @@ def radian_to_label(radians, num_bins=6):
 
 
 def compute_node_orientation_loss(data_dict, num_bins=6):
-    """(loss_helper.py:244-307) relative rotation of the GT objects assigned to the two ends of every graph edge"""
+    """(loss_helper.py:244-307) relative rotation of the GT objects assigned to the two ends of every graph edge.
+    All scenes at once on the padded (B, K*L) edge tensors: the reference loops over the scenes and slices the first
+    n = n_source * n_target edges of each (a host round trip per scene); here edges >= n get weight 0."""
     assign = data_dict["object_assignment"]
     edge_indices, edge_preds = data_dict["edge_index"], data_dict["edge_orientations"]
     nsrc, ntar = data_dict["num_edge_source"], data_dict["num_edge_target"]
     B, K = assign.shape
+    E = edge_indices.shape[2]
     rots = torch.gather(data_dict["scene_object_rotations"], 1, assign.view(B, K, 1, 1).repeat(1, 1, 3, 3))
     rot_masks = torch.gather(data_dict["scene_object_rotation_masks"], 1, assign)
-    preds, labels, masks = [], [], []
-    for b in range(B):
-        n = int(nsrc[b]) * int(ntar[b])
-        src, tar = edge_indices[b, 0, :n].long(), edge_indices[b, 1, :n].long()
-        rel = torch.matmul(rots[b][src], rots[b][tar].transpose(2, 1))
-        rel = torch.acos(torch.clamp(0.5 * (torch.diagonal(rel, dim1=-2, dim2=-1).sum(-1) - 1), -1, 1))
-        preds.append(edge_preds[b, :n]); labels.append(radian_to_label(rel, num_bins)); masks.append(rot_masks[b][src] * rot_masks[b][tar])
-    preds, labels, masks = torch.cat(preds), torch.cat(labels), torch.cat(masks)
+    n = (nsrc * ntar).view(B, 1)
+    live = (torch.arange(E, device=assign.device).view(1, E) < n).to(rot_masks.dtype)
+    src, tar = edge_indices[:, 0].long(), edge_indices[:, 1].long()                      # (B,E); padded entries are 0
+    rs = torch.gather(rots, 1, src.view(B, E, 1, 1).expand(-1, -1, 3, 3))
+    rt = torch.gather(rots, 1, tar.view(B, E, 1, 1).expand(-1, -1, 3, 3))
+    rel = torch.matmul(rs, rt.transpose(3, 2))
+    rel = torch.acos(torch.clamp(0.5 * (torch.diagonal(rel, dim1=-2, dim2=-1).sum(-1) - 1), -1, 1))
+    labels = radian_to_label(rel, num_bins).reshape(-1)
+    masks = (torch.gather(rot_masks, 1, src) * torch.gather(rot_masks, 1, tar) * live).reshape(-1)
+    preds = edge_preds.reshape(B * E, -1)
     loss = (F.cross_entropy(preds, labels, reduction="none") * masks).sum() / (masks.sum() + 1e-8)
-    hit = preds.argmax(-1)
-    acc = (hit[masks == 1] == labels[masks == 1]).sum().float() / (masks.sum().float() + 1e-8)
+    acc = ((preds.argmax(-1) == labels).to(masks.dtype) * (masks == 1).to(masks.dtype)).sum() / (masks.sum().float() + 1e-8)
     return loss, acc
 
 

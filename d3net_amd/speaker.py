@@ -577,7 +577,8 @@ class TopDownSceneCaptionModule(nn.Module):
             lang_cap = torch.cat(outputs, dim=1)
         good = target_ious > self.cfg.data.min_iou_threshold
         data_dict["lang_cap"] = lang_cap
-        data_dict["pred_ious"] = target_ious[good].mean() if bool(good.any()) else obj_feats.new_zeros(())
+        gf = good.to(target_ious.dtype)          # == target_ious[good].mean() (0 when no box is good), without the host round trip
+        data_dict["pred_ious"] = (target_ious * gf).sum() / gf.sum().clamp(min=1)
         data_dict["valid_masks"] = valid_masks
         data_dict["good_bbox_masks"] = good
         return data_dict
