@@ -43,6 +43,12 @@ struct GruArgs {
     float *hout; long long ldo;
     float *r, *z, *n, *ghn;      // (N,H) each, kept for the backward (NULL: inference)
     int N, H;
+    // packed-sequence form (LangModule): the input-side gates x W_ih^T + b_ih are precomputed for all steps (gi_pre (N, 3H)
+    // rows at stride ldgi; x / Wih / bih unused), rows with t_step >= lens[row] keep their state (and report an identity
+    // step to the backward), hid_out (row stride ldhid) receives the step's output, zero for finished rows
+    const float *gi_pre; long long ldgi;
+    const int *lens; int t_step;
+    float *hid_out; long long ldhid;
 };
 
 __device__ __forceinline__ f32x4 td_load4(const float *row, int k0, int K, bool valid) {
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
     int gkb = 0;
 #pragma unroll
     for (int seg = 0; seg < 2; seg++) {
+        if (seg == 0 && a.gi_pre) continue;
         const int K = seg == 0 ? a.I : H;
         const float *X = seg == 0 ? a.x : a.h;
         const long long ldx = seg == 0 ? a.ldx : a.ldh;
@@ -132,16 +139,28 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
             s[k] = v;
         }
         if (row >= a.N) continue;
-        const float rr = 1.f / (1.f + expf(-(s[0] + a.bih[c] + a.bhh[c])));
-        const float zz = 1.f / (1.f + expf(-(s[1] + a.bih[H + c] + a.bhh[H + c])));
-        const float gh = s[3] + a.bhh[2 * H + c];
-        const float nv = tanhf(s[2] + a.bih[2 * H + c] + rr * gh);
         const float hp = a.h[(long long)row * a.ldh + c];
-        a.hout[(long long)row * a.ldo + c] = (1.f - zz) * nv + zz * hp;
-        if (a.r) {
-            const long long o = (long long)row * H + c;
-            a.r[o] = rr; a.z[o] = zz; a.n[o] = nv; a.ghn[o] = gh;
+        const long long o = (long long)row * H + c;
+        if (a.lens && a.t_step >= a.lens[row]) {     // finished sequence: carry the state, emit zeros (pad_packed_sequence)
+            a.hout[(long long)row * a.ldo + c] = hp;
+            if (a.hid_out) a.hid_out[(long long)row * a.ldhid + c] = 0.f;
+            if (a.r) { a.r[o] = 0.f; a.z[o] = 1.f; a.n[o] = 0.f; a.ghn[o] = 0.f; }   // identity step for the backward
+            continue;
         }
+        float gr, gz, gn;
+        if (a.gi_pre) {
+            const float *gi = a.gi_pre + (long long)row * a.ldgi;
+            gr = gi[c]; gz = gi[H + c]; gn = gi[2 * H + c];
+        } else { gr = s[0] + a.bih[c]; gz = s[1] + a.bih[H + c]; gn = s[2] + a.bih[2 * H + c]; }
+        if (a.gi_pre) { gr += s[0]; gz += s[1]; }
+        const float rr = 1.f / (1.f + expf(-(gr + a.bhh[c])));
+        const float zz = 1.f / (1.f + expf(-(gz + a.bhh[H + c])));
+        const float gh = s[3] + a.bhh[2 * H + c];
+        const float nv = tanhf(gn + rr * gh);
+        const float hn = (1.f - zz) * nv + zz * hp;
+        a.hout[(long long)row * a.ldo + c] = hn;
+        if (a.hid_out) a.hid_out[(long long)row * a.ldhid + c] = hn;
+        if (a.r) { a.r[o] = rr; a.z[o] = zz; a.n[o] = nv; a.ghn[o] = gh; }
     }
 }
 
@@ -159,21 +178,22 @@ static int td_gru_fwd(const GruArgs &a, hipStream_t s) {
 __global__ void td_gru_bwd_gates_kernel(const float *d0, long long ld0, const float *d1, long long ld1, const float *d2, long long ld2,
                                         const float *__restrict__ r, const float *__restrict__ z, const float *__restrict__ n,
                                         const float *__restrict__ ghn, const float *__restrict__ hp, long long ldh,
-                                        float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dhp, int N, int H) {
+                                        float *__restrict__ dgi, long long lddgi, float *__restrict__ dgh, float *__restrict__ dhp,
+                                        int N, int H, const int *__restrict__ lens, int t_step) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N * H) return;
     const int row = e / H, c = e - row * H;
     float dh = 0.f;
     if (d0) dh += d0[(long long)row * ld0 + c];
-    if (d1) dh += d1[(long long)row * ld1 + c];
+    if (d1 && !(lens && t_step >= lens[row])) dh += d1[(long long)row * ld1 + c];   // (a finished row's output is the constant 0)
     if (d2) dh += d2[(long long)row * ld2 + c];
     const float rr = r[e], zz = z[e], nv = n[e];
     const float dn = dh * (1.f - zz), dz = dh * (hp[(long long)row * ldh + c] - nv);
     const float dnp = dn * (1.f - nv * nv);
     const float drp = dnp * ghn[e] * rr * (1.f - rr);
     const float dzp = dz * zz * (1.f - zz);
-    const long long o = (long long)row * 3 * H + c;
-    dgi[o] = drp; dgi[o + H] = dzp; dgi[o + 2 * H] = dnp;
+    const long long o = (long long)row * 3 * H + c, oi = (long long)row * lddgi + c;
+    dgi[oi] = drp; dgi[oi + H] = dzp; dgi[oi + 2 * H] = dnp;
     dgh[o] = drp; dgh[o + H] = dzp; dgh[o + 2 * H] = dnp * rr;
     dhp[e] = dh * zz;
 }
@@ -482,7 +502,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
         }
         {
             GruArgs g{x1 + rN * E, E, E, h1p, H, a->Wih1, a->Whh1, a->bih1, a->bhh1, h1n, H,
-                      g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H, g1 + 3 * RH + rN * H, N, H};
+                      g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H, g1 + 3 * RH + rN * H, N, H, nullptr, 0, nullptr, 0, nullptr, 0};
             if ((rc = td_gru_fwd(g, s))) return rc;
         }
         {   // q = map_hidd(h1)
@@ -502,7 +522,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
         }
         {
             GruArgs g{x2 + rN * E, E, E, h2p, H, a->Wih2, a->Whh2, a->bih2, a->bhh2, h2n, H,
-                      g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H, g2 + 3 * RH + rN * H, N, H};
+                      g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H, g2 + 3 * RH + rN * H, N, H, nullptr, 0, nullptr, 0, nullptr, 0};
             if ((rc = td_gru_fwd(g, s))) return rc;
         }
     }
@@ -601,7 +621,7 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         float *h1p = H1 + rN * H, *h1n = H1 + (rN + N) * H, *h2p = H2 + rN * H;
         // GRU2 gates: dh2[t+1] = classifier part + carry from step t+1
         td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dH2 + rN * H, H, dh2c, H, nullptr, 0, g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H,
-                                                   g2 + 3 * RH + rN * H, h2p, H, dgi2 + rN * 3 * H, dgh2 + rN * 3 * H, dh2c, N, H);
+                                                   g2 + 3 * RH + rN * H, h2p, H, dgi2 + rN * 3 * H, 3 * H, dgh2 + rN * 3 * H, dh2c, N, H, nullptr, 0);
         {   // dh2c += dgh2 Whh2 ; dx2 = dgi2 Wih2   (one launch)
             d3_gemm_prob p[2];
             p[0] = td_prob(N, H, dh2c, H);
@@ -623,7 +643,7 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
             if ((rc = hg_launch(&p, 1, s))) return rc;
         }
         td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dh1c, H, tmpL + F, F + H, dh1q, H, g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H,
-                                                   g1 + 3 * RH + rN * H, h1p, H, dgi1 + rN * 3 * H, dgh1 + rN * 3 * H, dh1c, N, H);
+                                                   g1 + 3 * RH + rN * H, h1p, H, dgi1 + rN * 3 * H, 3 * H, dgh1 + rN * 3 * H, dh1c, N, H, nullptr, 0);
         {   // dh1c += dgh1 Whh1 ; dx1 = dgi1 Wih1
             d3_gemm_prob p[2];
             p[0] = td_prob(N, H, dh1c, H);
@@ -747,7 +767,7 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
         if ((rc = hg_launch(&p, 1, s))) return rc;
     }
     {
-        GruArgs g{x1, E, E, h1_in, H, a->Wih1, a->Whh1, a->bih1, a->bhh1, h1_out, H, nullptr, nullptr, nullptr, nullptr, N, H};
+        GruArgs g{x1, E, E, h1_in, H, a->Wih1, a->Whh1, a->bih1, a->bhh1, h1_out, H, nullptr, nullptr, nullptr, nullptr, N, H, nullptr, 0, nullptr, 0, nullptr, 0};
         if ((rc = td_gru_fwd(g, s))) return rc;
     }
     {
@@ -766,7 +786,7 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
         if ((rc = hg_launch(&p, 1, s))) return rc;
     }
     {
-        GruArgs g{x2, E, E, h2_in, H, a->Wih2, a->Whh2, a->bih2, a->bhh2, h2_out, H, nullptr, nullptr, nullptr, nullptr, N, H};
+        GruArgs g{x2, E, E, h2_in, H, a->Wih2, a->Whh2, a->bih2, a->bhh2, h2_out, H, nullptr, nullptr, nullptr, nullptr, N, H, nullptr, 0, nullptr, 0, nullptr, 0};
         if ((rc = td_gru_fwd(g, s))) return rc;
     }
     {
@@ -778,6 +798,103 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
         p2.nseg = 1; p2.seg[0] = td_seg(c0, H, a->Wc2, H, H);
         p2.bias = a->bc2;
         if ((rc = hg_launch(&p2, 1, s))) return rc;
+    }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ packed-sequence GRU (LangModule)
+// nn.GRU(I -> H, batch_first) over pack_padded_sequence(x, lens) (model/lang_module.py:51-55, 146-150): per sample the
+// recurrence runs for lens[n] steps; `hiddens` (N,T,H) is zero beyond a sample's length (pad_packed_sequence), `last` (N,H)
+// its final state.  The input-side gates of ALL steps are one GEMM (N*T x I x 3H); a step is then ONE launch: h W_hh^T
+// and the gate math fused (td_gru_fwd_kernel, precomputed-input form).  Backward through time: gate kernel + one
+// k-major GEMM per step; dW_ih, dW_hh and the bias gradients batched over all steps afterwards.
+struct GsLayout { size_t GI, Hs, g, total; };
+static GsLayout gs_layout(int N, int T, int H) {
+    GsLayout L; size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += d3_align(b); return at; };
+    L.GI = take((size_t)N * T * 3 * H * 4); L.Hs = take((size_t)(T + 1) * N * H * 4); L.g = take((size_t)4 * T * N * H * 4);
+    L.total = o;
+    return L;
+}
+extern "C" size_t d3_gru_seq_ws_bytes(int N, int T, int I, int H) { (void)I; return gs_layout(N, T, H).total; }
+extern "C" size_t d3_gru_seq_bwd_ws_bytes(int N, int T, int I, int H) {
+    (void)I;
+    return d3_align((size_t)N * T * 3 * H * 4) * 2 + d3_align((size_t)N * H * 4) + d3_align(hg_colsum_ws_bytes(2, 3 * H)) + 256;
+}
+
+extern "C" int d3_gru_seq_forward(const float *x, const int *lens, const float *Wih, const float *Whh, const float *bih, const float *bhh,
+                                  int N, int T, int I, int H, float *hiddens, float *last, void *ws_, size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (N < 1 || T < 1 || (H & 15) || (I & 3)) return D3_ERR_ARG;
+    const GsLayout L = gs_layout(N, T, H);
+    if (ws_bytes < L.total) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    char *ws = (char *)ws_;
+    float *GI = (float *)(ws + L.GI), *Hs = (float *)(ws + L.Hs), *g = (float *)(ws + L.g);
+    int rc;
+    {
+        d3_gemm_prob p = td_prob(N * T, 3 * H, GI, 3 * H);
+        p.nseg = 1; p.seg[0] = td_seg(x, I, Wih, I, I);
+        p.bias = bih;
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    D3_CHECK(hipMemsetAsync(Hs, 0, (size_t)N * H * 4, s));
+    const size_t NH = (size_t)N * H, TNH = (size_t)T * NH;
+    for (int t = 0; t < T; t++) {
+        GruArgs a{nullptr, 0, I, Hs + t * NH, H, nullptr, Whh, nullptr, bhh, Hs + (t + 1) * NH, H,
+                  g + t * NH, g + TNH + t * NH, g + 2 * TNH + t * NH, g + 3 * TNH + t * NH, N, H,
+                  GI + (size_t)t * 3 * H, (long long)T * 3 * H, lens, t, hiddens + (size_t)t * H, (long long)T * H};
+        if ((rc = td_gru_fwd(a, s))) return rc;
+    }
+    D3_CHECK(hipMemcpyAsync(last, Hs + (size_t)T * NH, NH * 4, hipMemcpyDeviceToDevice, s));
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// d_hiddens (N,T,H) and d_last (N,H) (either may be NULL) -> dWih, dWhh, dbih, dbhh (written); dx (N,T,I) when non-NULL
+extern "C" int d3_gru_seq_backward(const float *x, const int *lens, const float *Wih, const float *Whh, int N, int T, int I, int H,
+                                   const float *d_hiddens, const float *d_last, const void *ws_, float *dWih, float *dWhh, float *dbih,
+                                   float *dbhh, float *dx, void *ws2_, size_t ws2_bytes, void *stream) {
+    D3_CLEAR();
+    if (N < 1 || T < 1 || (H & 15) || (I & 3)) return D3_ERR_ARG;
+    if (ws2_bytes < d3_gru_seq_bwd_ws_bytes(N, T, I, H)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const GsLayout L = gs_layout(N, T, H);
+    const char *ws = (const char *)ws_;
+    const float *Hs = (const float *)(ws + L.Hs), *g = (const float *)(ws + L.g);
+    char *w2 = (char *)ws2_;
+    const size_t gsz = d3_align((size_t)N * T * 3 * H * 4);
+    float *DGI = (float *)w2, *DGH = (float *)(w2 + gsz), *carry = (float *)(w2 + 2 * gsz);
+    char *cs = w2 + 2 * gsz + d3_align((size_t)N * H * 4);
+    const size_t NH = (size_t)N * H, TNH = (size_t)T * NH;
+    int rc;
+    if (d_last) D3_CHECK(hipMemcpyAsync(carry, d_last, NH * 4, hipMemcpyDeviceToDevice, s));
+    else D3_CHECK(hipMemsetAsync(carry, 0, NH * 4, s));
+    const int nh = (int)((NH + 255) / 256);
+    for (int t = T - 1; t >= 0; t--) {
+        // DGI rows batch-major (n*T + t) like x; DGH rows time-major (t*N + n) like the saved states
+        td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(carry, H, d_hiddens ? d_hiddens + (size_t)t * H : nullptr, (long long)T * H, nullptr, 0,
+                                                   g + t * NH, g + TNH + t * NH, g + 2 * TNH + t * NH, g + 3 * TNH + t * NH, Hs + t * NH, H,
+                                                   DGI + (size_t)t * 3 * H, (long long)T * 3 * H, DGH + (size_t)t * N * 3 * H, carry, N, H, lens, t);
+        d3_gemm_prob p = td_prob(N, H, carry, H);
+        p.nseg = 1; p.seg[0] = td_seg(DGH + (size_t)t * N * 3 * H, 3 * H, Whh, H, 3 * H, nullptr, 0, 1); p.accum = 1;
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+    }
+    {
+        d3_gemm_prob p[2];
+        p[0] = td_prob(3 * H, I, dWih, I); p[0].nseg = 1; p[0].seg[0] = td_seg(DGI, 3 * H, x, I, N * T, nullptr, 1, 1);
+        p[1] = td_prob(3 * H, H, dWhh, H); p[1].nseg = 1; p[1].seg[0] = td_seg(DGH, 3 * H, Hs, H, N * T, nullptr, 1, 1);
+        if ((rc = hg_launch(&p[0], 1, s))) return rc;
+        if ((rc = hg_launch(&p[1], 1, s))) return rc;
+        const float *cx[2] = {DGI, DGH}; const long long cl[2] = {3 * H, 3 * H}; const int cr[2] = {N * T, N * T}, cc[2] = {3 * H, 3 * H};
+        float *co[2] = {dbih, dbhh};
+        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 2, cs, hg_colsum_ws_bytes(2, 3 * H), s))) return rc;
+        if (dx) {
+            d3_gemm_prob q = td_prob(N * T, I, dx, I);
+            q.nseg = 1; q.seg[0] = td_seg(DGI, 3 * H, Wih, I, 3 * H, nullptr, 0, 1);
+            if ((rc = hg_launch(&q, 1, s))) return rc;
+        }
     }
     D3_LAUNCH_CHECK();
     return 0;

@@ -101,6 +101,47 @@ class MultiHeadAttention(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ language
+class GRUSeqFunction(torch.autograd.Function):
+    """nn.GRU over a packed batch (model/lang_module.py:51-55) as one native call each way (csrc/topdown.hip:
+    d3_gru_seq_forward / _backward): x (N,T,I), lens (N) -> hiddens (N,T,H) zero-padded, last (N,H)."""
+
+    @staticmethod
+    def forward(ctx, x, lens, Wih, Whh, bih, bhh):
+        L = _lib.lib()
+        x, Wih, Whh, bih, bhh = (t.contiguous() for t in (x, Wih, Whh, bih, bhh))
+        lens32 = lens.to(device=x.device, dtype=torch.int32).contiguous()
+        N, T, I = x.shape
+        H = Whh.shape[1]
+        hiddens = torch.empty((N, T, H), dtype=torch.float32, device=x.device)
+        last = torch.empty((N, H), dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.d3_gru_seq_ws_bytes(N, T, I, H), dtype=torch.uint8, device=x.device)
+        with _on(x.device):
+            check(L.d3_gru_seq_forward(_ptr(x), _ptr(lens32), _ptr(Wih), _ptr(Whh), _ptr(bih), _ptr(bhh), N, T, I, H, _ptr(hiddens),
+                                       _ptr(last), _ptr(ws), ws.numel(), _stream()), "gru_seq_forward")
+        ctx.save_for_backward(x, lens32, Wih, Whh, ws)
+        ctx.dims = (N, T, I, H)
+        return hiddens, last
+
+    @staticmethod
+    def backward(ctx, d_hiddens, d_last):
+        L = _lib.lib()
+        x, lens32, Wih, Whh, ws = ctx.saved_tensors
+        N, T, I, H = ctx.dims
+        dev = x.device
+        d_hiddens = d_hiddens.contiguous() if d_hiddens is not None else None
+        d_last = d_last.contiguous() if d_last is not None else None
+        dWih, dWhh = torch.empty_like(Wih), torch.empty_like(Whh)
+        dbih, dbhh = torch.empty(3 * H, dtype=torch.float32, device=dev), torch.empty(3 * H, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws2 = torch.empty(L.d3_gru_seq_bwd_ws_bytes(N, T, I, H), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            check(L.d3_gru_seq_backward(_ptr(x), _ptr(lens32), _ptr(Wih), _ptr(Whh), N, T, I, H,
+                                        _ptr(d_hiddens) if d_hiddens is not None else None, _ptr(d_last) if d_last is not None else None,
+                                        _ptr(ws), _ptr(dWih), _ptr(dWhh), _ptr(dbih), _ptr(dbhh), _ptr(dx) if dx is not None else None,
+                                        _ptr(ws2), ws2.numel(), _stream()), "gru_seq_backward")
+        return dx, None, dWih, dWhh, dbih, dbhh
+
+
 class LangModule(nn.Module):
     """GRU description encoder + language classifier (reference: model/lang_module.py:8-178)."""
 
@@ -111,6 +152,7 @@ class LangModule(nn.Module):
         self.use_bidir = cfg.model.use_bidir
         self.emb_size, self.hidden_size = emb_size, hidden_size
         self.gru = nn.GRU(input_size=emb_size, hidden_size=hidden_size, batch_first=True, bidirectional=self.use_bidir)
+        self.native = True    # csrc/topdown.hip packed-sequence GRU; False: nn.GRU through the BLAS / MIOpen libraries (tests)
         if self.use_lang_classifier:
             self.lang_cls = nn.Sequential(nn.Linear(hidden_size, self.num_text_classes), nn.Dropout())
 
@@ -119,6 +161,13 @@ class LangModule(nn.Module):
         B, Cn, T, _ = word_embs.shape
         embs = word_embs.reshape(-1, T, self.emb_size)
         lens = lang_len.reshape(-1)
+        if self.native and embs.is_cuda and not self.use_bidir:
+            # one native call: no host copy of the lengths, no packing / unpacking, hiddens already zero-padded to T (:67-68)
+            g = self.gru
+            pad, last = GRUSeqFunction.apply(embs.float(), lens, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
+            masks = (torch.arange(T, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)).float()
+            scores = self.lang_cls(last) if self.use_lang_classifier else None
+            return pad, last, masks, scores
         packed = pack_padded_sequence(embs, lens.cpu(), batch_first=True, enforce_sorted=False)
         hiddens, last = self.gru(packed)
         hiddens, _ = pad_packed_sequence(hiddens, batch_first=True)

@@ -403,6 +403,20 @@ int d3_topdown_step(const d3_topdown_args *a, const long long *word, const float
                     const float *h2_in, float *h1_out, float *h2_out, float *logits, float *attn, void *ws, size_t ws_bytes,
                     void *stream);
 
+/* ---- packed-sequence GRU of the language encoder (csrc/topdown.hip) ---------------------------------------
+ * nn.GRU(I -> H, batch_first=True) over pack_padded_sequence(x (N,T,I), lens (N)) as LangModule runs it
+ * (model/lang_module.py:51-55, 146-150; torch gate order r, z, n): hiddens (N,T,H) zero beyond a sample's length, last (N,H)
+ * the final state of every sample.  ws (d3_gru_seq_ws_bytes) keeps the input-side gates, states and gate values for the
+ * backward.  backward: d_hiddens / d_last (either NULL) -> dWih (3H,I), dWhh (3H,H), dbih, dbhh (3H) written; dx (N,T,I)
+ * written when non-NULL.  H % 16 == 0, I % 4 == 0. */
+size_t d3_gru_seq_ws_bytes(int N, int T, int I, int H);
+size_t d3_gru_seq_bwd_ws_bytes(int N, int T, int I, int H);
+int d3_gru_seq_forward(const float *x, const int *lens, const float *Wih, const float *Whh, const float *bih, const float *bhh, int N,
+                       int T, int I, int H, float *hiddens, float *last, void *ws, size_t ws_bytes, void *stream);
+int d3_gru_seq_backward(const float *x, const int *lens, const float *Wih, const float *Whh, int N, int T, int I, int H,
+                        const float *d_hiddens, const float *d_last, const void *ws, float *dWih, float *dWhh, float *dbih, float *dbhh,
+                        float *dx, void *ws2, size_t ws2_bytes, void *stream);
+
 /* ---- relation graph (csrc/edgeconv.hip) -----------------------------------------------------------------
  * GraphModule / EdgeConv (model/graph_module.py:21-114, 252-324) for all B scenes at once, fixed-size outputs, no host
  * round trip.  adj (B,K,K) 0/1 adjacency (rows = _query_locals of every proposal, L ones each), mask (B,K) valid proposals.

@@ -79,3 +79,39 @@ def test_listener_matches_reference_golden(dev, mode):
                 ref = g[k]
                 got = params[k[len("train/grad/"):]].grad.cpu().numpy()[:32]
                 assert np.allclose(got, ref, rtol=5e-3, atol=1e-5 + 2e-3 * np.abs(ref).max()), (k, float(np.abs(got - ref).max()))
+
+
+def test_native_packed_gru_matches_library_gru_at_config_shape(dev):
+    """csrc/topdown.hip's packed-sequence GRU (one GEMM for all input gates + one fused launch per step) against nn.GRU over
+    pack_padded_sequence on the same parameters: batch 32, T = 128, lengths 1..128 (conf/pointgroup_grounding.yaml shape).
+    Outputs 1e-5, parameter gradients 1e-3 of their scale (128 sequential steps, summation order)."""
+    import types
+    from d3net_amd.listener import LangModule
+    torch.manual_seed(3)
+    cfg = types.SimpleNamespace(model=types.SimpleNamespace(num_bbox_class=18, use_lang_classifier=True, use_bidir=False))
+    lm = LangModule(cfg).to(dev)
+    for m in lm.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B, Cn, T = 4, 8, 128
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(B, Cn, T, 300, generator=g).to(dev)
+    lens = torch.randint(1, T + 1, (B, Cn), generator=g)
+    lens[0, 0], lens[0, 1] = 1, T
+    lens = lens.to(dev)
+    w_h, w_l, w_s = torch.randn(B * Cn, T, 256, device=dev), torch.randn(B * Cn, 256, device=dev), torch.randn(B * Cn, 18, device=dev)
+    res = {}
+    for native in (False, True):
+        lm.native = native
+        lm.zero_grad()
+        d = lm({"lang_feat": feat, "lang_len": lens})
+        loss = (d["lang_hiddens"] * w_h).sum() + (d["lang_emb"] * w_l).sum() + (d["lang_scores"] * w_s).sum()
+        loss.backward()
+        res[native] = (d, {k: p.grad.clone() for k, p in lm.named_parameters()})
+    a, b = res[False], res[True]
+    for k in ("lang_hiddens", "lang_emb", "lang_scores"):
+        assert float((a[0][k] - b[0][k]).abs().max()) < 1e-5 * (1 + float(a[0][k].abs().max())), k
+    assert torch.equal(a[0]["lang_masks"], b[0]["lang_masks"])
+    for k in a[1]:
+        err = float((a[1][k] - b[1][k]).abs().max()) / (float(a[1][k].abs().max()) + 1e-12)
+        assert err < 1e-3, (k, err)
