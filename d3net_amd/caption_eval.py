@@ -135,3 +135,22 @@ def score_captions(candidates, raw_data, max_len=30, min_iou=0.5):
     keys = list(corpus.keys())
     mean, scores = cider_scores([corpus[k] for k in keys], [kept.get(k, "sos eos") for k in keys])
     return mean, scores, keys
+
+
+def eval_caption_epoch(candidates, raw_data, max_len=30, min_iou=0.5):
+    """Corpus scores of one validation epoch in the reference's return format (eval_helper.py:264-340):
+    (bleu, cider, rouge, meteor) with bleu = ([BLEU-1..4], [per-entry lists]) and the others (mean, per-entry scores).
+    Captions whose matched box has IoU < min_iou, and undetected objects, count as the empty caption "sos eos".  METEOR is a
+    Java subprocess in the reference (lib/capeval/meteor) and no Java runtime exists here: it is reported as (0.0, zeros)."""
+    from .caption_metrics import bleu_scores, rouge_l_scores
+    corpus = prepare_corpus(raw_data, candidates, max_len)
+    kept = {k: v["caption"] for k, v in candidates.items() if v["iou"] >= min_iou}
+    keys = list(corpus.keys())
+    refs, cands = [corpus[k] for k in keys], [kept.get(k, "sos eos") for k in keys]
+    if not keys:
+        z = (0.0, np.zeros(0))
+        return ([0.0] * 4, [[] for _ in range(4)]), z, z, z
+    bleu = bleu_scores(refs, cands, 4)
+    cider = cider_scores(refs, cands)
+    rouge = rouge_l_scores(refs, cands)
+    return bleu, cider, rouge, (0.0, np.zeros(len(keys)))

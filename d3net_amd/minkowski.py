@@ -12,8 +12,9 @@ Same constructor signatures, attribute names and state-dict keys as the calls in
 
 All arithmetic runs in libd3hip.so (csrc/coordmap.hip, spconv.hip, bn.hip).  MinkowskiEngine is an
 unpinned third-party dependency of the reference; the semantics implemented here are those of
-oracle/sparse_oracle.py (pinned against dense conv3d).  Kernel offset k = ox + Kd*oy + Kd^2*oz; a real
-ME checkpoint may need `kernel_permutation` (unverifiable offline).
+oracle/sparse_oracle.py (pinned against dense conv3d).  Kernel offset k = ox + Kd*oy + Kd^2*oz (x fastest).  Which
+order a real MinkowskiEngine checkpoint uses cannot be verified offline (third party, unpinned, absent): `set_kernel_order`
+installs a load-time permutation of the `kernel` tensors for checkpoints written in another offset order.
 """
 import ctypes as C
 import math
@@ -342,6 +343,41 @@ class BatchNormEvalFunction(Function):
 
 
 # ------------------------------------------------------------------------------------------ modules
+_KERNEL_PERM = {}   # kernel volume -> index tensor: kernel_here[k] = kernel_checkpoint[perm[k]]
+
+
+def kernel_permutation(kernel_size, order):
+    """Permutation that converts a (K^3, Cin, Cout) kernel stored with offset order `order` into this module's x-fastest
+    order.  order: "xyz" (identity: x fastest) or "zyx" (z fastest, x slowest -- a row-major (x, y, z) region iterator)."""
+    K = kernel_size
+    if order == "xyz":
+        return torch.arange(K ** 3)
+    if order != "zyx":
+        raise ValueError("order must be 'xyz' or 'zyx'")
+    perm = torch.empty(K ** 3, dtype=torch.long)
+    for oz in range(K):
+        for oy in range(K):
+            for ox in range(K):
+                perm[ox + K * oy + K * K * oz] = oz + K * oy + K * K * ox
+    return perm
+
+
+def set_kernel_order(order="xyz"):
+    """Checkpoints whose convolution kernels are in `order` are permuted to x-fastest while they are loaded
+    (`load_state_dict` of any module containing MinkowskiConvolution[Transpose]); "xyz" removes the hook's effect."""
+    _KERNEL_PERM.clear()
+    if order != "xyz":
+        for ks in (2, 3):
+            _KERNEL_PERM[ks ** 3] = kernel_permutation(ks, order)
+
+
+def _permute_kernel_on_load(module, state_dict, prefix, *args):
+    key = prefix + "kernel"
+    perm = _KERNEL_PERM.get(module.kernel_volume)
+    if perm is not None and key in state_dict and state_dict[key].dim() == 3:
+        state_dict[key] = state_dict[key].index_select(0, perm.to(state_dict[key].device))
+
+
 class MinkowskiConvolution(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
         super().__init__()
@@ -354,6 +390,7 @@ class MinkowskiConvolution(nn.Module):
         self.kernel = nn.Parameter(torch.empty(shape))
         self.bias = None
         self.reset_parameters()
+        self._register_load_state_dict_pre_hook(_permute_kernel_on_load, with_module=True)
 
     def reset_parameters(self, is_transpose=False):
         n = (self.out_channels if is_transpose else self.in_channels) * self.kernel_volume

@@ -26,6 +26,10 @@ class PipelineNet(nn.Module):
         self.current_epoch, self.global_step = 0, 0
         self.logged = {}
         if dataset:
+            # validation: the description store of the validation split (model/pipeline.py:41; lib/captioning/eval_helper.py:35-62)
+            val = dataset.get("val", dataset["train"]) if isinstance(dataset, dict) else dataset["train"]
+            self.dataset_chunk_data = getattr(val, "chunked_data", None)
+            self.val_raw_data = getattr(val, "raw_data", None)
             self.vocabulary = dataset["train"].vocabulary
             self.register_buffer("embeddings", torch.as_tensor(dataset["train"].glove, dtype=torch.float32))
             self.beam_opt = {"train_beam_size": cfg.train.beam_size, "train_sample_topn": cfg.train.sample_topn,
@@ -150,6 +154,74 @@ class PipelineNet(nn.Module):
             raise NotImplementedError("GT-proposal modes 4-6 (no_detection) are not on the hot path")
         self.global_step += 1
         return loss, data_dict
+
+    # --------------------------------------------------------------------------------------------- validation
+    def _log_val(self, d, keys):
+        for k in keys:
+            self.log("val_{}/{}".format("loss" if "loss" in k else "score", k), d[k])
+        return {k: d[k] for k in keys}
+
+    _GROUND_KEYS = ("ref_acc_mean", "ref_iou_mean", "best_ious_mean", "ref_iou_rate_0.25", "ref_iou_rate_0.5", "lang_acc")
+
+    @torch.no_grad()
+    def validation_step(self, data_dict, idx=0, dataloader_idx=0):
+        """(model/pipeline.py:457-643) detector losses (mode 0), dense-caption candidates of the batch (modes 1 / 3 loader 0:
+        evaluation decode of all proposals + Hungarian assignment to the GT boxes), grounding scores (modes 2 / 3 loader 1)"""
+        from .caption_eval import eval_caption_step
+        if self.mode not in (0, 1, 2, 3):
+            raise NotImplementedError("GT-proposal modes 4-6 (no_detection) are not on the hot path")
+        data_dict = self._detect(data_dict)
+        if self.mode == 0:
+            for k, v in data_dict.items():
+                if "loss" in k:
+                    self.log("val_loss/{}".format(k), v[0])
+            return None
+        if self.mode == 1 or (self.mode == 3 and dataloader_idx == 0):
+            data_dict = self.speaker(data_dict, use_tf=False, use_rl=False, is_eval=True, beam_opt=self.beam_opt)
+            return eval_caption_step(data_dict, self.vocabulary)
+        if self.mode == 2 or (self.mode == 3 and dataloader_idx == 1):
+            data_dict = self._ground(self.listener(data_dict), False)
+            out = self._log_val(data_dict, self._GROUND_KEYS) if self.mode == 2 else {k: data_dict[k] for k in self._GROUND_KEYS}
+            return out if self.mode == 3 else None
+        raise NotImplementedError("dataloader_idx %d" % dataloader_idx)
+
+    def validation_epoch_end(self, outputs):
+        """(model/pipeline.py:645-735) corpus scores over the epoch's candidates; mode 3 adds the mean grounding scores and
+        `combined` = CIDEr + Acc@0.5IoU, the monitor of the joint training"""
+        from .caption_eval import eval_caption_epoch
+        log = {}
+        if self.mode in (0, 2):
+            return log
+        cap_outs = outputs if self.mode == 1 else outputs[0]
+        candidates = {}
+        for outs in cap_outs:
+            for k, v in (outs or {}).items():
+                candidates.setdefault(k, v)
+        bleu, cider, rouge, meteor = eval_caption_epoch(candidates, self.val_raw_data or [], max_len=self.cfg.eval.max_des_len + 2,
+                                                        min_iou=self.cfg.eval.min_iou_threshold)
+        log = {"bleu-1": bleu[0][0], "bleu-2": bleu[0][1], "bleu-3": bleu[0][2], "bleu-4": bleu[0][3], "cider": cider[0],
+               "meteor": meteor[0], "rouge": rouge[0]}
+        if self.mode == 3:
+            metrics = {}
+            for outs in outputs[1]:
+                for k, v in (outs or {}).items():
+                    metrics.setdefault(k, []).append(float(v))
+            for k, v in metrics.items():
+                log[k] = float(np.mean(v))
+            log["combined"] = log["cider"] + log.get("ref_iou_rate_0.5", 0.0)
+        for k, v in log.items():
+            self.log("val_score/{}".format(k), v)
+        return log
+
+    def forward(self, data_dict):
+        """inference entry point (model/pipeline.py:894-925): detector -> speaker -> listener, whichever exist"""
+        if not self.no_detection:
+            data_dict = self.detector.feed(data_dict, self.current_epoch)
+        if not self.no_captioning:
+            data_dict = self.speaker(data_dict)
+        if not self.no_grounding:
+            data_dict = self.listener(data_dict)
+        return data_dict
 
     def _ground(self, data_dict, use_rl):
         """lib/grounding/loss_helper.py:304-335 `get_loss`"""

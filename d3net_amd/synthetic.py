@@ -149,7 +149,8 @@ def make_batch(scenes, device, mode=4):
 def make_vocabulary(size=3004):
     """vocabulary dict in the reference's format (word2idx / idx2word with pad_, unk, sos, eos first)"""
     words = ["pad_", "unk", "sos", "eos"] + ["w%d" % i for i in range(size - 4)]
-    return {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {str(i): w for i, w in enumerate(words)}}   # str keys: the reference loads it from json
+    return {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {str(i): w for i, w in enumerate(words)},   # str keys: the reference loads it from json
+            "special_tokens": {"bos_token": "sos", "eos_token": "eos", "unk_token": "unk", "pad_token": "pad_"}}   # lib/dataset/pipeline.py:440-447
 
 
 def add_language(batch, device, chunk=8, max_spk_len=30, max_lis_len=126, vocab=3004, seed=3):
@@ -185,6 +186,9 @@ def add_language(batch, device, chunk=8, max_spk_len=30, max_lis_len=126, vocab=
                scene_object_rotation_masks=batch["box_label_mask"].cpu().numpy().astype(np.float32))
     # the speaker's lang_len is the caption length (+2), the listener's the description length: the reference feeds
     # two different batches; a single synthetic batch carries the caption lengths under `lang_len` for mode 1
+    out["gt_bbox_label"] = batch["box_label_mask"].cpu().numpy().astype(np.float32)      # valid GT boxes (lib/dataset/pipeline.py:300)
+    out["gt_bbox_object_id"] = np.tile(np.arange(gt_bbox.shape[1], dtype=np.int64), (B, 1))
+    batch["scene_id"] = ["scene%04d_00" % b for b in range(B)]
     out["id"] = np.arange(B, dtype=np.int64)                                  # scene index into `chunked_data`
     out["chunk_ids"] = np.tile(np.arange(chunk, dtype=np.int64), (B, 1))
     for k, v in out.items():
@@ -206,3 +210,8 @@ def make_language_corpus(B, chunk=8, vocab=3004, max_spk_len=30, objects_per_sce
                                    for _ in range(int(rng.integers(2, 6)))] for o in range(objects_per_scene)}
         chunked.append([{"scene_id": sid, "object_id": str(int(rng.integers(0, objects_per_scene)))} for _ in range(chunk)])
     return chunked, organized
+
+
+def corpus_raw_data(organized):
+    """the flat description list the evaluation corpus is built from (`dataset.raw_data`: scene_id, object_id, token)"""
+    return [{"scene_id": sid, "object_id": oid, "token": d["token"]} for sid, objs in organized.items() for oid, ds in objs.items() for d in ds]

@@ -46,3 +46,38 @@ def test_pipeline_modes_run_and_train(dev, mode):
         assert d["cluster_ref"].shape == (8, 128) and 0 <= float(d["ref_acc_mean"]) <= 1 and "train_score/ref_iou_rate_0.5" in net.logged
     opt, _ = net.configure_optimizers()
     opt[0].step()
+
+
+def test_validation_hooks_and_inference_forward(dev):
+    """PipelineNet.validation_step / validation_epoch_end / forward with the reference's call pattern
+    (scripts/train.py:338-365 through Lightning; scripts/eval.py:154,205-209): mode 1 returns the dense-caption candidates
+    of a batch and scores them over the epoch (CIDEr / BLEU / ROUGE keys), mode 2 logs the grounding scores, mode 0 the
+    detector losses; forward() is the inference chain."""
+    from d3net_amd import synthetic as S
+    from d3net_amd.pipeline import PipelineNet
+    V = 200
+    scenes = [S.small_scene(dims=(40, 32, 20), n_boxes=3, seed=s) for s in (3, 4)]
+    chunked, organized = S.make_language_corpus(2, chunk=4, vocab=V, objects_per_scene=3)
+    for mode, flags in ((0, dict(no_captioning=True, no_grounding=True)), (1, dict(no_captioning=False, no_grounding=True)),
+                        (2, dict(no_captioning=True, no_grounding=False))):
+        cfg = _cfg(**flags)
+        tr = types.SimpleNamespace(vocabulary=S.make_vocabulary(V), glove=np.random.default_rng(0).standard_normal((V, 300)).astype(np.float32),
+                                   chunked_data=chunked, organized=organized, raw_data=S.corpus_raw_data(organized))
+        net = PipelineNet(cfg, {"train": tr, "val": tr}).to(dev).eval()
+        net.detector.teacher = True
+        batch = S.add_language(S.make_batch(scenes, dev), dev, chunk=4, vocab=V)
+        out = net.validation_step(dict(batch), 0)
+        if mode == 0:
+            assert out is None and "val_loss/total_loss" in net.logged
+        elif mode == 1:
+            assert isinstance(out, dict) and len(out) > 0
+            k, v = next(iter(out.items()))
+            assert k.startswith("scene000") and v["caption"].startswith("sos") and 0.0 <= v["iou"] <= 1.0 and len(v["box"]) == 8
+            log = net.validation_epoch_end([out])
+            assert set(log) == {"bleu-1", "bleu-2", "bleu-3", "bleu-4", "cider", "meteor", "rouge"} and "val_score/cider" in net.logged
+            assert all(np.isfinite(float(x)) for x in log.values())
+        else:
+            assert out is None and 0.0 <= float(net.logged["val_score/ref_iou_rate_0.5"]) <= 1.0 and "val_score/lang_acc" in net.logged
+        with torch.no_grad():
+            d = net(dict(batch))
+        assert "proposal_bbox_batched" in d and (mode != 1 or "lang_cap" in d) and (mode != 2 or d["cluster_ref"].shape == (8, 128))
