@@ -30,8 +30,30 @@ def nms_3d_faster_samecls(boxes, overlap_threshold, old_type=False):
     return pick
 
 
-def parse_predictions(data_dict, config_dict=POST_DICT, num_class=18):
-    """-> per scene list of (class, corners (8,3), score) after class-aware 3D NMS and the confidence threshold"""
+def nms_pred_mask_device(data_dict, nms_iou=0.25, old_type=False):
+    """the class-aware 3D NMS of all scenes in one launch on the device (csrc/nms.hip) -> pred_mask (B,K) float tensor;
+    same picks as the host loop below (float64 arithmetic; exactly tied scores excepted)"""
+    import ctypes as C
+    import torch
+    from . import _lib
+    boxes = data_dict["proposal_bbox_batched"].detach().float()
+    B, K = boxes.shape[:2]
+    cls = data_dict["proposal_sem_cls_batched"].detach().float() - 2
+    cls = torch.where(cls < 0, torch.full_like(cls, 17.0), cls)
+    b8 = torch.cat([boxes.min(2).values, boxes.max(2).values, data_dict["proposal_scores_batched"].detach().float().unsqueeze(-1),
+                    cls.unsqueeze(-1)], -1).contiguous()
+    valid = (data_dict["proposal_batch_mask"].detach() == 1).float().contiguous()
+    pick = torch.empty((B, K), dtype=torch.float32, device=boxes.device)
+    with torch.cuda.device(boxes.device):
+        _lib.check(_lib.lib().d3_nms3d_samecls(C.c_void_p(b8.data_ptr()), C.c_void_p(valid.data_ptr()), B, K, float(nms_iou), int(old_type),
+                                               C.c_void_p(pick.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nms3d_samecls")
+    return pick
+
+
+def parse_predictions(data_dict, config_dict=POST_DICT, num_class=18, device_nms=None):
+    """-> per scene list of (class, corners (8,3), score) after class-aware 3D NMS and the confidence threshold.
+    device_nms (default: when the proposals live on the GPU): the NMS of all scenes runs as one kernel; the per-scene numpy
+    loop is the host form the reference has."""
     cfg = dict(POST_DICT); cfg.update(config_dict or {})
     assert cfg["use_3d_nms"] and cfg["cls_nms"] and not cfg["remove_empty_box"], "only the configuration the reference uses"
     g = lambda k: data_dict[k].detach().cpu().numpy()
@@ -41,7 +63,11 @@ def parse_predictions(data_dict, config_dict=POST_DICT, num_class=18):
     nonempty, prob = g("proposal_batch_mask"), g("proposal_scores_batched")
     B, K = prob.shape
     pred_mask = np.zeros((B, K))
-    for i in range(B):
+    if device_nms is None:
+        device_nms = bool(getattr(data_dict["proposal_bbox_batched"], "is_cuda", False)) and K <= 256
+    if device_nms:
+        pred_mask = nms_pred_mask_device(data_dict, cfg["nms_iou"], cfg["use_old_type_nms"]).cpu().numpy().astype(np.float64)
+    for i in range(B if not device_nms else 0):
         b = np.zeros((K, 8))
         b[:, 0:3], b[:, 3:6] = boxes[i].min(1), boxes[i].max(1)
         b[:, 6], b[:, 7] = prob[i], cls[i]

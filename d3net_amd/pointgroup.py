@@ -536,6 +536,44 @@ class PointGroup(nn.Module):
                     data_dict["proposal_crop_bboxes"] = data_dict["proposal_crop_bbox"]
         return preds, data_dict
 
+    @torch.no_grad()
+    def predict_instances(self, data_dict):
+        """The instance predictions `PointGroup.test` writes out (reference :561-601), without the files: proposals above the
+        score / size thresholds, point-mask NMS (lib/utils/eval.py:75-97).  Device-side: the pairwise mask IoUs come from the
+        (cluster, point) lists (csrc/nms.hip) instead of a dense (nProposal, N) mask product and a host copy.
+        -> dict(pick (n,) indices into the proposals, scores (n,), proposals_idx, proposals_offset, semantic_pred (N,))"""
+        import ctypes as C
+        from . import _lib
+        data_dict = self.feed(data_dict, self.current_epoch)
+        scores, proposals_idx, proposals_offset = data_dict["proposal_scores"][:3]
+        sem_pred = data_dict["semantic_scores"].max(1)[1]
+        dev = scores.device
+        P, N = proposals_offset.numel() - 1, sem_pred.numel()
+        empty = dict(pick=torch.zeros(0, dtype=torch.long, device=dev), scores=scores.new_zeros(0), proposals_idx=proposals_idx,
+                     proposals_offset=proposals_offset, semantic_pred=sem_pred)
+        if P == 0:
+            return empty
+        sig = torch.sigmoid(scores.view(-1)).contiguous()
+        keep = data_dict["proposal_thres_mask"].to(torch.uint8).contiguous()
+        ious = torch.empty((P, P), dtype=torch.float32, device=dev)
+        member = torch.empty(2 * N, dtype=torch.int32, device=dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        order = torch.empty(P, dtype=torch.int32, device=dev)
+        picked = torch.empty(P, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        cidx, off = proposals_idx.contiguous(), proposals_offset.contiguous()
+        p_, st = (lambda t: C.c_void_p(t.data_ptr())), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(L.d3_instance_cross_iou(p_(cidx), p_(off), cidx.shape[0], P, N, p_(ious), p_(member), p_(flags), st), "instance_cross_iou")
+            _lib.check(L.d3_nms_matrix(p_(ious), p_(sig), p_(keep), P, float(self.cfg.test.TEST_NMS_THRESH), p_(order), p_(picked),
+                                       p_(flags[1:]), st), "nms_matrix")
+        over, n = flags.tolist()
+        if over:
+            raise _lib.D3Error("predict_instances: a point belongs to more than two proposals")
+        pick = picked[:n].long()
+        empty.update(pick=pick, scores=sig[pick], cross_ious=ious)
+        return empty
+
     def training_step(self, data_dict, idx=0):
         """(reference :513-528) minus the Lightning logging."""
         _mark("begin")
