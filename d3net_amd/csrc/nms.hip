@@ -18,8 +18,12 @@
 #define NMS_MAXK 256
 
 // boxes (B,K,8) double-convertible floats: [x1,y1,z1,x2,y2,z2,score,cls]; valid (B,K) != 0 -> pick (B,K) float 0/1
-__global__ __launch_bounds__(256) void det_nms3d_kernel(const float *__restrict__ boxes, const float *__restrict__ valid, int K,
-                                                        double thr, int old_type, float *__restrict__ pick) {
+// visit: optional (B,K) int32 visiting order (candidate indices, best first, -1 padded) -- numpy's argsort leaves the order of
+// exactly tied scores to its sort implementation; a caller that must reproduce it passes the order, otherwise ties go to the
+// later index first
+__global__ __launch_bounds__(256) void det_nms3d_kernel(const float *__restrict__ boxes, const float *__restrict__ valid,
+                                                        const int *__restrict__ visit, int K, double thr, int old_type,
+                                                        float *__restrict__ pick) {
     __shared__ double bx[NMS_MAXK][7];    // x1 y1 z1 x2 y2 z2 area
     __shared__ float sc[NMS_MAXK], cl[NMS_MAXK];
     __shared__ int order[NMS_MAXK], alive[NMS_MAXK], nv_s;
@@ -35,8 +39,14 @@ __global__ __launch_bounds__(256) void det_nms3d_kernel(const float *__restrict_
         pick[(long long)b * K + t] = 0.f;
     }
     __syncthreads();
-    if (t < K && alive[t]) {
-        // rank in descending score; exact ties: the later index first (np.argsort ascending, then taken from the end)
+    if (visit) {
+        if (t < K) {
+            const int v = visit[(long long)b * K + t];
+            order[t] = v;
+            if (v >= 0) atomicAdd(&nv_s, 1);
+        }
+    } else if (t < K && alive[t]) {
+        // rank in descending score; exact ties: the later index first (an ascending stable sort read from its end)
         int rk = 0;
         for (int j = 0; j < K; j++)
             if (alive[j] && (sc[j] > sc[t] || (sc[j] == sc[t] && j > t))) rk++;
@@ -70,11 +80,11 @@ __global__ __launch_bounds__(256) void det_nms3d_kernel(const float *__restrict_
     }
 }
 
-extern "C" int d3_nms3d_samecls(const float *boxes, const float *valid, int B, int K, double iou_thr, int old_type, float *pick,
-                                void *stream) {
+extern "C" int d3_nms3d_samecls(const float *boxes, const float *valid, const int *visit, int B, int K, double iou_thr, int old_type,
+                                float *pick, void *stream) {
     D3_CLEAR();
     if (B < 1 || K < 1 || K > NMS_MAXK) return D3_ERR_ARG;
-    det_nms3d_kernel<<<B, 256, 0, d3_stream(stream)>>>(boxes, valid, K, iou_thr, old_type, pick);
+    det_nms3d_kernel<<<B, 256, 0, d3_stream(stream)>>>(boxes, valid, visit, K, iou_thr, old_type, pick);
     D3_LAUNCH_CHECK();
     return 0;
 }

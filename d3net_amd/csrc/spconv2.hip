@@ -643,15 +643,23 @@ extern "C" int d3_spconv_fwd2_plan(int Mout, int K, int Cin, int Cout, int *out)
     return 0;
 }
 
+// (the dynamic-LDS attribute is per device: one flag per device ordinal)
+static bool c2_attr_needed(bool *done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 template <int NT>
 static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {   // allow more than 64 KB of dynamic LDS
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev)) {   // allow more than 64 KB of dynamic LDS
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_done = true;
     }
     if (a.xbf16) {
         if (p.wlds) spconv_fwd2_kernel<NT, true, true><<<p.grid, 256, p.lds, s>>>(a);
@@ -665,11 +673,10 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
 }
 template <int NTW>
 static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev)) {
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done = true;
     }
     if (a.xbf16) spconv_fwd2_split_kernel<NTW, true><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
     else spconv_fwd2_split_kernel<NTW, false><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
@@ -1055,10 +1062,9 @@ extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Co
 
 template <int TPO, int NU>
 static int launch_wg2(const Wg2Args &a, const Wg2Plan &p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev)) {
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_kernel<TPO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done = true;
     }
     spconv_wgrad2_kernel<TPO, NU><<<dim3(p.R, p.kg, p.passes), 256, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();

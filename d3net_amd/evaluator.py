@@ -30,9 +30,11 @@ def nms_3d_faster_samecls(boxes, overlap_threshold, old_type=False):
     return pick
 
 
-def nms_pred_mask_device(data_dict, nms_iou=0.25, old_type=False):
+def nms_pred_mask_device(data_dict, nms_iou=0.25, old_type=False, numpy_tie_order=False):
     """the class-aware 3D NMS of all scenes in one launch on the device (csrc/nms.hip) -> pred_mask (B,K) float tensor;
-    same picks as the host loop below (float64 arithmetic; exactly tied scores excepted)"""
+    same picks as the host loop below (float64 arithmetic).  Exactly tied scores: numpy's argsort (the reference's visiting
+    order) leaves their order to its sort implementation; `numpy_tie_order` computes that order on the host and hands it to
+    the kernel, otherwise ties go to the later proposal first."""
     import ctypes as C
     import torch
     from . import _lib
@@ -44,13 +46,23 @@ def nms_pred_mask_device(data_dict, nms_iou=0.25, old_type=False):
                     cls.unsqueeze(-1)], -1).contiguous()
     valid = (data_dict["proposal_batch_mask"].detach() == 1).float().contiguous()
     pick = torch.empty((B, K), dtype=torch.float32, device=boxes.device)
+    visit = None
+    if numpy_tie_order:
+        sc, va = b8[:, :, 6].cpu().numpy().astype(np.float64), valid.cpu().numpy() == 1
+        vis = np.full((B, K), -1, np.int32)
+        for i in range(B):
+            inds = np.where(va[i])[0]
+            o = inds[np.argsort(sc[i][va[i]])[::-1]]          # nms.py:122: I = np.argsort(score), visited from the end
+            vis[i, :len(o)] = o
+        visit = torch.from_numpy(vis).to(boxes.device)
     with torch.cuda.device(boxes.device):
-        _lib.check(_lib.lib().d3_nms3d_samecls(C.c_void_p(b8.data_ptr()), C.c_void_p(valid.data_ptr()), B, K, float(nms_iou), int(old_type),
+        _lib.check(_lib.lib().d3_nms3d_samecls(C.c_void_p(b8.data_ptr()), C.c_void_p(valid.data_ptr()),
+                                               C.c_void_p(visit.data_ptr()) if visit is not None else None, B, K, float(nms_iou), int(old_type),
                                                C.c_void_p(pick.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nms3d_samecls")
     return pick
 
 
-def parse_predictions(data_dict, config_dict=POST_DICT, num_class=18, device_nms=None):
+def parse_predictions(data_dict, config_dict=POST_DICT, num_class=18, device_nms=None, numpy_tie_order=False):
     """-> per scene list of (class, corners (8,3), score) after class-aware 3D NMS and the confidence threshold.
     device_nms (default: when the proposals live on the GPU): the NMS of all scenes runs as one kernel; the per-scene numpy
     loop is the host form the reference has."""
@@ -66,7 +78,7 @@ def parse_predictions(data_dict, config_dict=POST_DICT, num_class=18, device_nms
     if device_nms is None:
         device_nms = bool(getattr(data_dict["proposal_bbox_batched"], "is_cuda", False)) and K <= 256
     if device_nms:
-        pred_mask = nms_pred_mask_device(data_dict, cfg["nms_iou"], cfg["use_old_type_nms"]).cpu().numpy().astype(np.float64)
+        pred_mask = nms_pred_mask_device(data_dict, cfg["nms_iou"], cfg["use_old_type_nms"], numpy_tie_order).cpu().numpy().astype(np.float64)
     for i in range(B if not device_nms else 0):
         b = np.zeros((K, 8))
         b[:, 0:3], b[:, 3:6] = boxes[i].min(1), boxes[i].max(1)

@@ -26,6 +26,23 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
 
+    RING = 4   # pinned staging slots per group: an address refresh never rewrites a buffer whose copy may still be queued
+
+    def load_state_dict(self, state_dict):
+        """moments are replaced: the cached device tables (which hold their addresses) are dropped; the step count comes from
+        the checkpoint (per-group `step`, or torch.optim.AdamW's per-parameter `state[p]["step"]`)"""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+        for group in self.param_groups:
+            if "step" not in group:
+                steps = [int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
+                if steps:
+                    group["step"] = max(steps)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+
     @staticmethod
     def _validate(p):
         g = p.grad
@@ -47,7 +64,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.state[p]["exp_avg_sq"] = flat[o + n:o + 2 * n].view_as(p)
                 o += 2 * n
         chunk = _lib.lib().d3_adamw_chunk()
-        host = torch.empty((len(plist), 4), dtype=torch.int64).pin_memory()
+        ring = [torch.empty((len(plist), 4), dtype=torch.int64).pin_memory() for _ in range(self.RING)]
+        host = ring[0]
         hv = host.numpy()
         hv[:, 0] = [p.data_ptr() for p in plist]
         hv[:, 1] = [p.grad.data_ptr() for p in plist]
@@ -55,7 +73,8 @@ class FusedAdamW(torch.optim.Optimizer):
         hv[:, 3] = [self.state[p]["exp_avg_sq"].data_ptr() for p in plist]
         numel = np.array([p.numel() for p in plist], dtype=np.int32)
         blocks = np.array([(t, c) for t, n in enumerate(numel) for c in range((int(n) + chunk - 1) // chunk)], dtype=np.int32)
-        tb = {"pptr": [p.data_ptr() for p in plist], "gptr": hv[:, 1].tolist(), "host": host,
+        tb = {"pptr": [p.data_ptr() for p in plist], "gptr": hv[:, 1].tolist(), "host": host, "ring": ring, "slot": 0,
+              "mptr": [self.state[p]["exp_avg"].data_ptr() for p in plist],
               "nblocks": int(blocks.shape[0]), "ptrs": host.to(dev), "numel": torch.from_numpy(numel).to(dev),
               "blocks": torch.from_numpy(blocks.reshape(-1)).to(dev), "device": dev}
         self._tables[gi] = tb
@@ -76,6 +95,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     for i, (a, b) in enumerate(zip(gptr, tb["gptr"])):
                         if a != b:
                             self._validate(plist[i])
+                    # next pinned slot of the ring: the previous refresh's host->device copy may still be in flight
+                    tb["slot"] = (tb["slot"] + 1) % self.RING
+                    nxt = tb["ring"][tb["slot"]]
+                    nxt.copy_(tb["host"]); tb["host"] = nxt
                     tb["host"].numpy()[:, 1] = gptr
                     tb["ptrs"].copy_(tb["host"], non_blocking=True)
                     tb["gptr"] = gptr

@@ -447,13 +447,16 @@ int d3_edgeconv_bwd(const float *W0, const float *W2, const int *src, const int 
 /* ---- evaluation-path non-maximum suppressions (csrc/nms.hip) ------------------------------------------------
  * nms3d_samecls: class-aware greedy 3D box NMS of parse_predictions (lib/det/ap_helper.py:80-108, lib/det/nms.py:110-150),
  *   all scenes in one launch.  boxes (B,K,8) = [x1,y1,z1,x2,y2,z2,score,class], valid (B,K) != 0 -> pick (B,K) 0/1;
- *   float64 arithmetic like the numpy original; K <= 256.
+ *   float64 arithmetic like the numpy original; K <= 256.  visit: NULL (descending score, exact ties: later index first) or
+ *   (B,K) int32 candidate indices in visiting order, -1 padded (numpy's argsort leaves the order of tied scores to its sort
+ *   implementation; pass its order to reproduce it).
  * instance_cross_iou: point-mask IoU between all pairs of clusters (model/pointgroup.py:577-589) from the (cluster, point)
  *   lists instead of a dense (P,N) mask product; ious (P,P) f32; member: 2*N ints scratch; *overflow_dev = 1 when a point is
  *   in more than two clusters (then the result is invalid).
  * nms_matrix: get_nms_instances (lib/utils/eval.py:75-97) over a dense IoU matrix: candidates keep[i] != 0 in descending
  *   score; picked[0..*npicked) in pick order.  order_scratch / picked: n ints each.  n <= 12288. */
-int d3_nms3d_samecls(const float *boxes, const float *valid, int B, int K, double iou_thr, int old_type, float *pick, void *stream);
+int d3_nms3d_samecls(const float *boxes, const float *valid, const int *visit, int B, int K, double iou_thr, int old_type, float *pick,
+                     void *stream);
 int d3_instance_cross_iou(const int *cluster_idxs, const int *offsets, long long S, int P, int N, float *ious, int *member,
                           int *overflow_dev, void *stream);
 int d3_nms_matrix(const float *ious, const float *scores, const unsigned char *keep, int n, float thr, int *order_scratch, int *picked,
