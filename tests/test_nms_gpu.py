@@ -61,9 +61,9 @@ def _nms_instances(cross_ious, scores, thr):
 def test_instance_mask_iou_and_nms_match_dense_reference(dev):
     from d3net_amd import _lib
     rng = np.random.default_rng(1)
-    N, P1, P2 = 20000, 40, 35
+    N, P1, P2 = 20000, 40, 40
     # two clusterings of the same points (a point is in at most one cluster of each), overlapping heavily
-    lab1 = rng.integers(-1, P1, N); lab2 = np.where(rng.random(N) < 0.7, (lab1 * 7 + 3) % P2, rng.integers(-1, P2, N)); lab2[lab1 < 0] = -1
+    lab1 = rng.integers(-1, P1, N); lab2 = np.where(rng.random(N) < 0.7, (lab1 + 3) % P2, rng.integers(-1, P2, N)); lab2[lab1 < 0] = -1
     idx, off = [], [0]
     for c in range(P1):
         pts = np.nonzero(lab1 == c)[0]; idx += [(c, p) for p in pts]; off.append(off[-1] + len(pts))
