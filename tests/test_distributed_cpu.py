@@ -153,3 +153,27 @@ def test_bucket_layout_is_static_when_a_rank_has_no_gradients():
         assert torch.allclose(a0, a1)
         want = (l0 + (l1 if l1 is not None else torch.zeros_like(l0))) / 2
         assert torch.allclose(a0, want, atol=1e-6)
+
+
+def _logged_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from d3net_amd.pipeline import PipelineNet
+    net = types.SimpleNamespace(logged={"train_loss/loss": torch.tensor(1.0 + rank), "train_score/cap_acc": 0.25 * (rank + 1)},
+                                parameters=lambda: iter([torch.zeros(1)]))
+    out = PipelineNet.reduce_logged(net)
+    ret[rank] = {k: float(v) for k, v in out.items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_logged_scalars_one_packed_allreduce_world2():
+    """the reference syncs every logged scalar separately (`sync_dist=True`, model/pipeline.py:149,182,...); here one packed
+    all-reduce averages them all"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_logged_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert abs(ret[r]["train_loss/loss"] - 1.5) < 1e-6 and abs(ret[r]["train_score/cap_acc"] - 0.375) < 1e-6

@@ -198,3 +198,76 @@ def test_fused_adamw_matches_torch(dev):
         assert rel(a.detach(), b.detach()) < 1e-6
         assert rel(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-6
         assert rel(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6
+
+
+def test_no_stale_executor_gradients_when_a_step_has_no_proposals(dev):
+    """zero_grad() only marks the executors' flat gradient buffers stale; a following step whose ScoreNet backward
+    never runs (no proposals) must not re-apply the previous step's ScoreNet gradient.  torch semantics: those parameters
+    have grad None, the optimizer leaves them and their moments untouched."""
+    from d3net_amd import synthetic as S
+    from d3net_amd.config import default_conf
+    from d3net_amd.optim import FusedAdamW
+    from d3net_amd.pointgroup import PointGroup
+    cfg = default_conf(overrides={"model": {"blocks": [1, 2, 3]}})
+    torch.manual_seed(0)
+    model = PointGroup(cfg).to(dev).train()
+    model.teacher = True
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-2, weight_decay=1e-2)
+    opt.register_step_pre_hook(lambda *a: model.drop_stale_grads())
+    scene = S.small_scene(dims=(40, 32, 20), n_boxes=2, seed=3)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, d = model.training_step(S.make_batch([scene], dev))
+        loss.backward()
+        opt.step()
+        return d
+
+    d = step()
+    assert d["proposal_scores"][2].numel() - 1 > 0
+    sn = {k: p.detach().clone() for k, p in model.score_net.named_parameters()}
+    m1 = {k: opt.state[p]["exp_avg"].clone() for k, p in model.score_net.named_parameters()}
+    bb = model.backbone[1].blocks.block0.conv_branch[2].kernel.detach().clone()
+    assert any(float(v.abs().sum()) > 0 for v in m1.values())          # the ScoreNet did train in step 1
+    model.cluster_npoint_thre = 10 ** 9                                  # no cluster survives: the _no_proposals path
+    d = step()
+    assert d["proposal_scores"][2].numel() - 1 == 0
+    torch.cuda.synchronize()
+    for k, p in model.score_net.named_parameters():
+        assert torch.equal(p.detach(), sn[k]), k                         # untouched: no gradient, no weight decay, no moment update
+        assert torch.equal(opt.state[p]["exp_avg"], m1[k]), k
+        assert p.grad is None, k
+    assert not torch.equal(model.backbone[1].blocks.block0.conv_branch[2].kernel.detach(), bb)   # the backbone still trains
+    model.cluster_npoint_thre = cfg.cluster.cluster_npoint_thre
+    d = step()                                                           # and the ScoreNet resumes afterwards
+    assert d["proposal_scores"][2].numel() - 1 > 0
+    assert any(not torch.equal(p.detach(), sn[k]) for k, p in model.score_net.named_parameters())
+
+
+def test_fused_adamw_follows_load_state_dict(dev):
+    """load_state_dict() replaces the moment tensors -- the cached device pointer table must be rebuilt, and the
+    step count must come from the checkpoint (torch.optim.AdamW stores it per parameter)"""
+    from d3net_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(33, 7, device=dev)), torch.nn.Parameter(torch.randn(5, device=dev))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a, b = FusedAdamW(ps, lr=1e-2, weight_decay=1e-2), torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2)
+    for it in range(3):
+        for p, q in zip(ps, ref):
+            g = torch.randn_like(p); p.grad = g.clone(); q.grad = g.clone()
+        a.step(); b.step()
+    # restart the fused optimizer from the library optimizer's checkpoint
+    a2 = FusedAdamW(ps, lr=1e-2, weight_decay=1e-2)
+    for p, q in zip(ps, ref):
+        p.grad = torch.zeros_like(p)
+    a2.step()                                                            # builds a table over fresh (zero) moments
+    with torch.no_grad():
+        for p, q in zip(ps, ref):
+            p.copy_(q)
+    a2.load_state_dict(b.state_dict())
+    for it in range(2):
+        for p, q in zip(ps, ref):
+            g = torch.randn_like(p); p.grad = g.clone(); q.grad = g.clone()
+        a2.step(); b.step()
+    for p, q in zip(ps, ref):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
