@@ -264,7 +264,8 @@ def test_fused_adamw_follows_load_state_dict(dev):
     with torch.no_grad():
         for p, q in zip(ps, ref):
             p.copy_(q)
-    a2.load_state_dict(b.state_dict())
+    import copy
+    a2.load_state_dict(copy.deepcopy(b.state_dict()))      # (load_state_dict keeps same-device tensors by reference)
     for it in range(2):
         for p, q in zip(ps, ref):
             g = torch.randn_like(p); p.grad = g.clone(); q.grad = g.clone()
