@@ -18,7 +18,7 @@ for path in sys.argv[1:3]:
         a[0] += int(launches); a[1] += float(total)
 out = {}
 for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad2_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel",
-          "un_bn_bwd_apply_kernel"):
+          "un_bn_bwd_apply_kernel", "hg_gemm_kernel", "cl_push_kernel", "bq_scan_kernel"):
     if k not in acc:
         continue
     f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
@@ -28,7 +28,7 @@ for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad2_kerne
     out[k] = {"launches_sampled": f[0], "fetch_kib_per_launch": fk, "write_kib_per_launch": wk,
               "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_round.sh), bench.py --steps 2 "
-                      "--warmup 1, canonical scene; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B "
+                      "--warmup 1 (the bench default workload unless the file name says otherwise); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B "
                       "per 128-B request: MI355X_MICROARCH.md HBM section)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 2) for k, v in out.items()}))
