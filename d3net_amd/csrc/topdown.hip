@@ -383,12 +383,14 @@ __global__ __launch_bounds__(256) void td_dobj_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------ small helpers
-__global__ void td_rows_kernel(const long long *__restrict__ word_ids, int Tw, int N, int S, int *__restrict__ widx, int *__restrict__ nidx,
-                               int *__restrict__ bidx) {
+// (token ids are clamped into the vocabulary: an out-of-range id must not become an out-of-bounds gather)
+__global__ void td_rows_kernel(const long long *__restrict__ word_ids, int Tw, int N, int S, int V, int *__restrict__ widx,
+                               int *__restrict__ nidx, int *__restrict__ bidx) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;   // time-major row r = t * N + n
     if (r >= S * N) return;
     const int tt = r / N, n = r - tt * N;
-    widx[r] = (int)word_ids[(long long)n * Tw + tt];
+    const long long w = word_ids[(long long)n * Tw + (tt < Tw ? tt : Tw - 1)];
+    widx[r] = (int)(w < 0 ? 0 : w >= V ? V - 1 : w);
     nidx[r] = n;
     bidx[r] = n * S + tt;                                  // the same row in batch-major order
 }
@@ -451,7 +453,7 @@ extern "C" size_t d3_topdown_ws_bytes(int N, int K, int S, int H, int E, int F) 
 }
 
 static int td_check(const d3_topdown_args *a) {
-    if (!a || a->N < 1 || a->K < 1 || a->S < 1 || a->V < 1) return D3_ERR_ARG;
+    if (!a || a->N < 1 || a->K < 1 || a->S < 1 || a->V < 1 || a->S > a->Tw) return D3_ERR_ARG;
     if ((a->H & 15) || (a->E & 3) || (a->F & 3) || a->F > 128 || (256 % a->F) || a->K > 1024) return D3_ERR_ARG;
     if (a->ws_bytes < td_layout(a->N, a->K, a->S, a->H, a->E, a->F).total) return D3_ERR_WORKSPACE;
     return 0;
@@ -474,7 +476,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
     float *msum = (float *)(ws + L.msum);
     const long long ldtd = H + F + E;          // map_topdown weight: (E, E + H + F) over [emb | h2 | target]
     const long long ldlang = F + H;            // map_lang weight: (E, F + H) over [attended | h1]
-    td_rows_kernel<<<(R + 255) / 256, 256, 0, s>>>(a->word_ids, a->Tw, N, S, widx, nidx, bidx);
+    td_rows_kernel<<<(R + 255) / 256, 256, 0, s>>>(a->word_ids, a->Tw, N, S, V, widx, nidx, bidx);
     td_attn_prep_kernel<<<N, 256, (size_t)2 * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, 1);
     D3_CHECK(hipMemsetAsync(H1, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(H2, 0, (size_t)N * H * 4, s));
@@ -734,9 +736,9 @@ extern "C" int d3_topdown_feat_proj(const float *obj, const float *W_feat, float
     return hg_launch(&p, 1, d3_stream(stream));
 }
 
-__global__ void td_word_idx_kernel(const long long *__restrict__ word, int *__restrict__ widx, int N) {
+__global__ void td_word_idx_kernel(const long long *__restrict__ word, int *__restrict__ widx, int N, int V) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < N) widx[n] = (int)word[n];
+    if (n < N) { const long long w = word[n]; widx[n] = (int)(w < 0 ? 0 : w >= V ? V - 1 : w); }
 }
 
 extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, const float *fp, int obj_div, const float *h1_in,
@@ -755,7 +757,7 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
     const long long ldtd = H + F + E, ldlang = F + H;
     int rc;
     if (256 % F) return D3_ERR_ARG;
-    td_word_idx_kernel<<<(N + 255) / 256, 256, 0, s>>>(word, widx, N);
+    td_word_idx_kernel<<<(N + 255) / 256, 256, 0, s>>>(word, widx, N, V);
     td_attn_prep_kernel<<<N, 256, (size_t)2 * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, obj_div);
     {
         d3_gemm_prob p = td_prob(N, E, x1, E);

@@ -250,6 +250,10 @@ class TopDownXEFunction(torch.autograd.Function):
         V, E = emb.shape
         H = params[_lib.TOPDOWN_PARAMS.index("W_hidd")].shape[0]
         dev = obj_feats.device
+        if not 1 <= S <= word_ids.shape[1]:
+            # (the step-by-step form indexes word_ids[:, step] and raises; lang_len must be the CAPTION length here, not the
+            # listener's description length)
+            raise IndexError("teacher forcing needs %d input words per sample, word_ids has %d" % (S, word_ids.shape[1]))
         a = _lib.TopdownArgs()
         a.N, a.K, a.S, a.V, a.H, a.E, a.F, a.Tw = N, K, S, V, H, E, F_, word_ids.shape[1]
         a.word_ids, a.emb, a.target, a.obj, a.mask = (t.data_ptr() for t in (word_ids, emb, target_feats, obj_feats, masks))

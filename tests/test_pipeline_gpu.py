@@ -66,6 +66,8 @@ def test_validation_hooks_and_inference_forward(dev):
         net = PipelineNet(cfg, {"train": tr, "val": tr}).to(dev).eval()
         net.detector.teacher = True
         batch = S.add_language(S.make_batch(scenes, dev), dev, chunk=4, vocab=V)
+        if mode == 1:
+            batch["lang_len"] = batch["spk_lang_len"]          # the speaker's lang_len is the caption length
         out = net.validation_step(dict(batch), 0)
         if mode == 0:
             assert out is None and "val_loss/total_loss" in net.logged
