@@ -1004,6 +1004,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 
     }
 }
 
+// Wide-stationary weight gradient (the stem: x 136 channels stationary, dy 16 channels gathered, K = 27).  The generic kernel
+// above gives a workgroup 16 accumulator tiles, i.e. 4 offsets x 4 of the 9 column tiles: 21 (offset group, column pass)
+// combinations, each of which re-reads its slice of x and RE-GATHERS dy -- 1.96 GB of fabric traffic per launch against 288 MB
+// algorithmic (profiles/r02_g: 1.14 ms, alone on the GPU at the end of the backward, on the critical path).  Here ONE
+// 16-wave workgroup holds all K x nt = 243 tiles: x's 32-row chunk is staged (transposed) once and shared by all waves; wave
+// w owns offsets {w, w + 16} with all nt column tiles (18 accumulator tiles = 72 VGPRs), so every dy row is gathered exactly
+// once per offset; the next chunk's kernel-map rows and x units are requested before the current chunk's MFMAs.  Each tile
+// has a single owner: no cross-wave reduction; row splits write partial dW summed by the fixed-order reduction.
+#define WGW_WAVES 16
+#define WGW_MAXNT 9
+template <int NTV>
+__global__ __launch_bounds__(WGW_WAVES * 64) void spconv_wgrad2_wide_kernel(const Wg2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
+    const int K = a.K;
+    unsigned short *St = (unsigned short *)smem;                                   // NTV*16 x LDT
+    int *tblS = (int *)(St + (size_t)NTV * 16 * WG2_LDT);                          // 32 x K
+    unsigned short *Gt = (unsigned short *)(tblS + 32 * C2_MAXK) + (size_t)wave * 2 * 16 * WG2_LDT;   // 2 slots x 16 x LDT per wave
+    const int nchunks = (a.Ms + 31) >> 5;
+    const int c_begin = blockIdx.x * a.cpw, c_end = min(nchunks, c_begin + a.cpw);
+    const int k0 = wave, k1 = wave + WGW_WAVES;                                    // this wave's offsets
+    f32x4 acc[2][NTV];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < NTV; i++) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // prefetch registers: one kernel-map entry and one 8-channel unit of the stationary operand per thread
+    const int sunits = 32 * a.Cs8;                      // <= 1024 (host check)
+    int tv = -1;
+    uint4 sv = make_uint4(0u, 0u, 0u, 0u);
+    auto prefetch = [&](int c) {
+        const int u0 = c * 32;
+        tv = -1;
+        if (a.tbl && t < 32 * K) { const long long e = (long long)u0 * K + t; if (e < (long long)a.Ms * K) tv = a.tbl[e]; }
+        sv = make_uint4(0u, 0u, 0u, 0u);
+        if (t < sunits) {
+            const int row = t / a.Cs8, c8 = t - row * a.Cs8;
+            if (u0 + row < a.Ms) sv = wg2_load8(a.Sm, a.sbf16, (long long)(u0 + row) * a.lds + c8 * 8);
+        }
+    };
+    if (c_begin < c_end) prefetch(c_begin);
+    for (int c = c_begin; c < c_end; c++) {
+        const int u0 = c * 32;
+        if (t < 32 * K) tblS[t] = a.tbl ? tv : (u0 + t < a.Ms ? u0 + t : -1);
+        if (t < sunits) { const int row = t / a.Cs8, c8 = t - row * a.Cs8; wg2_store_t(St, c8, row, sv); }
+        __syncthreads();
+        if (c + 1 < c_end) prefetch(c + 1);
+        // gathers of this wave's two offsets (32 rows x 16 channels = 64 units: one per lane and offset)
+        uint4 gv[2];
+        bool any[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = j == 0 ? k0 : k1;
+            gv[j] = make_uint4(0u, 0u, 0u, 0u);
+            bool got = false;
+            if (k < K) {
+                const int row = lane >> 1, c8 = lane & 1;
+                const int idx = (u0 + row < a.Ms) ? tblS[row * K + k] : -1;
+                if (idx >= 0) { gv[j] = wg2_load8(a.G, a.gbf16, (long long)idx * a.ldg + c8 * 8); got = true; }
+            }
+            any[j] = __any(got) != 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (any[j]) wg2_store_t(Gt + (size_t)j * 16 * WG2_LDT, lane & 1, lane >> 1, gv[j]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (!any[j]) continue;      // wave-uniform
+            const uint4 av = *(const uint4 *)&Gt[(size_t)j * 16 * WG2_LDT + r * WG2_LDT + g * 8];
+#pragma unroll
+            for (int i = 0; i < NTV; i++) {
+                const uint4 bv = *(const uint4 *)&St[(i * 16 + r) * WG2_LDT + g * 8];
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc[j][i], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // St / tblS are rewritten by the next chunk
+    }
+    // every tile has one owner: store (gathered operand = dy: P = dW[k]^T, rows = Cout channel, columns = Cin channel)
+    const long long wsz = (long long)K * a.Cin * a.Cout;
+    float *dst = a.dst + (long long)blockIdx.x * wsz;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int k = j == 0 ? k0 : k1;
+        if (k >= K) continue;
+        const int wk = a.flipk ? (K - 1 - k) : k;
+#pragma unroll
+        for (int i = 0; i < NTV; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int cg = g * 4 + q, cs = i * 16 + r;
+                const int ci = a.gx ? cg : cs, co = a.gx ? cs : cg;
+                if (ci < a.Cin && co < a.Cout) dst[((long long)wk * a.Cin + ci) * a.Cout + co] = acc[j][i][q];
+            }
+    }
+}
+
 // dW[e] = sum_r part[r][e]: 32 elements x 8 split groups per workgroup; group sums are combined in group order
 __global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, long long n, int R, int accum) {
     __shared__ float sh[8][32];
@@ -1022,11 +1121,23 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const float *__restr
     }
 }
 
-struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw; size_t lds, ws_bytes; };
+struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw, wide; size_t lds, ws_bytes; };
 
 static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
     Wg2Plan p;
     const int mt = (Cg + 15) / 16, nt = (Cs + 15) / 16, ntl = mt * nt;
+    p.wide = 0;
+    if (mt == 1 && nt > 4 && nt <= WGW_MAXNT && K <= 2 * WGW_WAVES && 32 * (Cs / 8) <= WGW_WAVES * 64 && Ms >= 4096) {
+        // one 16-wave workgroup per row split holds all K x nt tiles (spconv_wgrad2_wide_kernel)
+        p.wide = 1; p.tpo = nt; p.nu = 1; p.opw = 2; p.kg = 1; p.passes = 1;
+        const int nchunks = (Ms + 31) / 32;
+        int R = 256; if (R > (nchunks + 3) / 4) R = (nchunks + 3) / 4; if (R < 1) R = 1;
+        p.cpw = (nchunks + R - 1) / R;
+        p.R = (nchunks + p.cpw - 1) / p.cpw;
+        p.lds = (size_t)nt * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4 + (size_t)WGW_WAVES * 2 * 16 * WG2_LDT * 2;
+        p.ws_bytes = (size_t)p.R * K * Cin * Cout * 4;
+        return p;
+    }
     p.tpo = ntl <= 1 ? 1 : ntl <= 2 ? 2 : ntl <= 4 ? 4 : ntl <= 8 ? 8 : 16;
     if (mt == 1 && nt > 4) p.tpo = 4;   // column passes of 4 tiles, 4 offsets per wave (the stem: 16 x 136 channels)
     p.nu = (Cg / 8 * 32 + 63) / 64;    // 16-byte units per lane per offset
@@ -1095,7 +1206,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     const int Cg = xstat ? Cout : Cin, Cs = xstat ? Cin : Cout;
     const Wg2Plan p = wg2_plan(Ms, K, Cg, Cs, Cin, Cout);
     if (p.ws_bytes > ws_bytes) return D3_ERR_WORKSPACE;
-    const bool direct = (p.R == 1 && !accum);
+    const bool direct = (p.R == 1 && !accum) && !p.wide;
     const bool noreduce = (flags & D3_CONV_NOREDUCE) != 0;   // the caller sums the partials (batched over its layers)
     a.tbl = tbl; a.dst = direct ? dW : (float *)ws;
     if (!direct && p.R == 1 && ws_bytes < (size_t)wn * 4) return D3_ERR_WORKSPACE;
@@ -1106,6 +1217,26 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
                          (tbl ? 4.0 * (double)Ms * K : 0.0);
     void *pr = d3_prof_begin(1, bytes, 0.0, s);
     int rc = D3_ERR_ARG;
+    if (p.wide) {
+        if (ws_bytes < p.ws_bytes) return D3_ERR_WORKSPACE;
+        a.dst = (float *)ws;
+        static bool wide_attr[64] = {false};
+        const bool set = c2_attr_needed(wide_attr);
+#define WGW_CASE(NTV)                                                                                                              \
+        case NTV:                                                                                                                      \
+            if (set) D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_wide_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+            spconv_wgrad2_wide_kernel<NTV><<<p.R, WGW_WAVES * 64, p.lds, s>>>(a);                                                     \
+            break;
+        switch (a.nt) { WGW_CASE(5) WGW_CASE(6) WGW_CASE(7) WGW_CASE(8) WGW_CASE(9) default: return D3_ERR_ARG; }
+#undef WGW_CASE
+        D3_LAUNCH_CHECK();
+        if (!noreduce) {
+            wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
+            D3_LAUNCH_CHECK();
+        }
+        d3_prof_end(pr, s);
+        return 0;
+    }
 #define WG2_NU(TPOV)                                                                          \
     (p.nu <= 1 ? launch_wg2<TPOV, 1>(a, p, s) : p.nu <= 2 ? launch_wg2<TPOV, 2>(a, p, s)          \
      : p.nu <= 4 ? launch_wg2<TPOV, 4>(a, p, s) : p.nu <= 7 ? launch_wg2<TPOV, 7>(a, p, s)        \

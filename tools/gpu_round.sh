@@ -23,6 +23,7 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
 done
 # SQ pass: wave-cycle split + MFMA busy / op counts (8 SQ slots)
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d /tmp/pmc_${TAG}_SQ -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 $BARGS > $OUT/pmc_SQ.log 2>&1
-python tools/pmc_sq_summary.py $(find /tmp/pmc_${TAG}_SQ -name "*counter_collection.csv") > $OUT/pmc_sq_summary.txt 2>&1
+cp $(find /tmp/pmc_${TAG}_SQ -name "*counter_collection.csv" | head -1) $OUT/pmc_SQ_raw.csv 2>/dev/null
+python tools/pmc_sq_summary.py $OUT/kernel_stats.csv $(find /tmp/pmc_${TAG}_SQ -name "*counter_collection.csv") > $OUT/pmc_sq_summary.txt 2>&1
 python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json > /dev/null 2>&1
 cat $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; tail -3 $OUT/bench.err; cut -c1-400 $OUT/bench.json; head -12 $OUT/kernel_stats.csv | cut -c1-150; head -6 $OUT/pmc_FETCH_SIZE.csv; head -4 $OUT/pmc_WRITE_SIZE.csv; head -14 $OUT/pmc_sq_summary.txt
