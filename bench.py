@@ -263,7 +263,7 @@ def main():
 
     # per-kernel launch durations measured with HIP events on the launch stream during the timed region
     prof = {}
-    for fam, name in ((0, "spconv_fwd2_kernel"), (2, "spconv_fwd2_split_kernel"), (1, "spconv_wgrad2_kernel")):
+    for fam, name in ((0, "spconv_fwd2_kernel"), (2, "spconv_fwd2_split_kernel"), (1, "spconv_wgrad3_kernel")):   # family 1: every weight-gradient launch (wgrad3; wgrad2 / wide for the remaining shapes)
         n, ms, by, fl = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0)
         L.d3_prof_collect(fam, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
         prof[name] = dict(launches=n.value, total_ms=ms.value, bytes=by.value)   # the sampled launches

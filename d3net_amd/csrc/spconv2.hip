@@ -28,13 +28,10 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned short f2bf2(float f) {  // round to nearest even (finite inputs)
-    unsigned int u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ unsigned int pack2bf2(float lo, float hi) {
-    return (unsigned int)f2bf2(lo) | ((unsigned int)f2bf2(hi) << 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack2bf2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
+    const bf16x2_t p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned int, p);
 }
 
 #define C2_MAXK 27
@@ -815,7 +812,36 @@ struct Wg2Args {
     unsigned int invg, invs;    // ceil(65536 / Cg8), ceil(65536 / Cs8)
     int cpw;                    // chunks per workgroup
     int gx, flipk, Cin, Cout;   // gx: the gathered operand is x (P = dW[k]); else it is dy (P = dW[k]^T)
+    int rsg, dg, rss, dss;      // row-major LDS images (TR kernels): row stride and 8-row shift in bytes, per operand
+    int imgg, imgs;             // image sizes in bytes
 };
+
+// Row-major LDS image of a 32-row chunk read back through gfx950's transposing LDS read.  ds_read_b64_tr_b16: the 16 lanes of
+// a group address a 4 x 16 bf16 block (lane i: row i/4, columns 4(i%4)..+3) and lane i receives column i, rows 0..3 -- two
+// reads give the 8 consecutive rows of one channel that both MFMA operands need, without the 8 x ds_write_b16 transposed
+// staging (~80 instructions per MFMA in the first version of this kernel).  A 32-lane half of the wave holds the blocks of
+// rows 8g.. and 8(g+1)..: the row stride RSB (a multiple of 32 B, odd multiple where C*2 is a multiple of 128) and a shift
+// D per 8 rows keep the eight 32-byte row segments of a half on distinct banks.
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+typedef short v8s16_t __attribute__((ext_vector_type(8)));
+static void wg2_img(int C8, int *rsb, int *d, int *bytes) {
+    int r = (C8 * 16 + 31) / 32 * 32;
+    if ((r & 127) == 0) r += 32;
+    const int dd = (r & 63) == 0 ? 32 : 128;
+    *rsb = r; *d = dd; *bytes = 32 * r + 3 * dd;
+}
+__device__ __forceinline__ void wg2_put_r(unsigned char *img, int rsb, int d, int c8, int row, uint4 v) {
+    *(uint4 *)(img + row * rsb + (row >> 3) * d + c8 * 16) = v;
+}
+// lane base of the fragment reads: rows 8g + (r>>2) (+4 for the second read), 8 bytes per lane inside the 32-byte tile row
+__device__ __forceinline__ int wg2_lane_base(int rsb, int d, int r, int g) { return (8 * g + (r >> 2)) * rsb + g * d + (r & 3) * 8; }
+__device__ __forceinline__ bf16x8_t wg2_frag_tr(const unsigned char *img, int lane_base, int rsb, int tile) {
+    typedef v4s16_t __attribute__((address_space(3))) *lds_p;
+    const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + lane_base + tile * 32));
+    const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + lane_base + tile * 32 + 4 * rsb));
+    const v8s16_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
 
 __device__ __forceinline__ uint4 wg2_load8(const void *p, int bf16, long long off) {
     if (bf16) return *(const uint4 *)((const unsigned short *)p + off);
@@ -831,17 +857,19 @@ __device__ __forceinline__ void wg2_store_t(unsigned short *T, int c8, int row, 
     d[6 * WG2_LDT] = (unsigned short)(v.w & 0xFFFFu); d[7 * WG2_LDT] = (unsigned short)(v.w >> 16);
 }
 
-template <int TPO, int NU>
+template <int TPO, int NU, bool TR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 ? (NU <= 7 ? 2 : 1) : (NU <= 2 ? 3 : NU <= 7 ? 2 : 1), 8))) void spconv_wgrad2_kernel(const Wg2Args a) {
     constexpr int OPW = WG2_T / TPO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int K = a.K;
-    // per-wave LDS: Gt (mt*16 x LDT), St (nt*16 x LDT) bf16, table chunk 32*K ints
-    const size_t wave_bytes = (size_t)(a.mt + a.nt) * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4;
+    // per-wave LDS: the two operand images (TR: row-major, else transposed mt*16 / nt*16 x LDT bf16), table chunk 32*K ints
+    const size_t gt_bytes = TR ? (size_t)a.imgg : (size_t)a.mt * 16 * WG2_LDT * 2, st_bytes = TR ? (size_t)a.imgs : (size_t)a.nt * 16 * WG2_LDT * 2;
+    const size_t wave_bytes = gt_bytes + st_bytes + (size_t)32 * C2_MAXK * 4;
     unsigned short *Gt = (unsigned short *)(smem + (size_t)wave * wave_bytes);
-    unsigned short *St = Gt + (size_t)a.mt * 16 * WG2_LDT;
-    int *tblW = (int *)(St + (size_t)a.nt * 16 * WG2_LDT);
+    unsigned short *St = (unsigned short *)((unsigned char *)Gt + gt_bytes);
+    int *tblW = (int *)((unsigned char *)St + st_bytes);
+    const int lbg = wg2_lane_base(a.rsg, a.dg, r, g), lbs = wg2_lane_base(a.rss, a.dss, r, g);
     const int k0 = blockIdx.y * OPW;
     const int tile0 = blockIdx.z * TPO, ntl = a.mt * a.nt;
     const int nchunks = (a.Ms + 31) >> 5;
@@ -898,7 +926,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 
                 const int unit = ub + q * 64 + lane;
                 if (unit < 32 * sc8n) {
                     const int row = unit / sc8n, c8 = sc8lo + unit - row * sc8n;
-                    wg2_store_t(St, c8, row, sv[q]);
+                    if constexpr (TR) wg2_put_r((unsigned char *)St, a.rss, a.dss, c8, row, sv[q]);
+                    else wg2_store_t(St, c8, row, sv[q]);
                 }
             }
         }
@@ -944,7 +973,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 
                         const int unit = lane + q * 64;
                         if (unit < 32 * a.Cg8) {
                             const int row = (int)(((unsigned int)unit * a.invg) >> 16), c8 = unit - row * a.Cg8;
-                            wg2_store_t(Gt, c8, row, pre[pf][q]);
+                            if constexpr (TR) wg2_put_r((unsigned char *)Gt, a.rsg, a.dg, c8, row, pre[pf][q]);
+                            else wg2_store_t(Gt, c8, row, pre[pf][q]);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -955,10 +985,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 
                         const int tile = tile0 + i;
                         if (tile < ntl) {   // uniform
                             const int mi = tile / a.nt, ni = tile - mi * a.nt;
-                            const uint4 av = *(const uint4 *)&Gt[(mi * 16 + r) * WG2_LDT + g * 8];
-                            const uint4 bv = *(const uint4 *)&St[(ni * 16 + r) * WG2_LDT + g * 8];
-                            acc[j < OPW ? j : 0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc[j < OPW ? j : 0][i], 0, 0, 0);
+                            bf16x8_t av, bv;
+                            if constexpr (TR) {
+                                av = wg2_frag_tr((const unsigned char *)Gt, lbg, a.rsg, mi);
+                                bv = wg2_frag_tr((const unsigned char *)St, lbs, a.rss, ni);
+                            } else {
+                                av = __builtin_bit_cast(bf16x8_t, *(const uint4 *)&Gt[(mi * 16 + r) * WG2_LDT + g * 8]);
+                                bv = __builtin_bit_cast(bf16x8_t, *(const uint4 *)&St[(ni * 16 + r) * WG2_LDT + g * 8]);
+                            }
+                            acc[j < OPW ? j : 0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j < OPW ? j : 0][i], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1014,14 +1049,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG2_T > 16 
 // has a single owner: no cross-wave reduction; row splits write partial dW summed by the fixed-order reduction.
 #define WGW_WAVES 16
 #define WGW_MAXNT 9
-template <int NTV>
+template <int NTV, bool TR>
 __global__ __launch_bounds__(WGW_WAVES * 64) void spconv_wgrad2_wide_kernel(const Wg2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int K = a.K;
-    unsigned short *St = (unsigned short *)smem;                                   // NTV*16 x LDT
-    int *tblS = (int *)(St + (size_t)NTV * 16 * WG2_LDT);                          // 32 x K
-    unsigned short *Gt = (unsigned short *)(tblS + 32 * C2_MAXK) + (size_t)wave * 2 * 16 * WG2_LDT;   // 2 slots x 16 x LDT per wave
+    const size_t st_bytes = TR ? (size_t)a.imgs : (size_t)NTV * 16 * WG2_LDT * 2;
+    const size_t gslot = TR ? (size_t)a.imgg : (size_t)16 * WG2_LDT * 2;          // one gathered 32 x 16 image
+    unsigned short *St = (unsigned short *)smem;                                   // stationary chunk, shared by the waves
+    int *tblS = (int *)(smem + st_bytes);                                          // 32 x K
+    unsigned short *Gt = (unsigned short *)((unsigned char *)(tblS + 32 * C2_MAXK) + (size_t)wave * 2 * gslot);   // 2 slots per wave
+    const int lbg = wg2_lane_base(a.rsg, a.dg, r, g), lbs = wg2_lane_base(a.rss, a.dss, r, g);
     const int nchunks = (a.Ms + 31) >> 5;
     const int c_begin = blockIdx.x * a.cpw, c_end = min(nchunks, c_begin + a.cpw);
     const int k0 = wave, k1 = wave + WGW_WAVES;                                    // this wave's offsets
@@ -1048,7 +1086,11 @@ __global__ __launch_bounds__(WGW_WAVES * 64) void spconv_wgrad2_wide_kernel(cons
     for (int c = c_begin; c < c_end; c++) {
         const int u0 = c * 32;
         if (t < 32 * K) tblS[t] = a.tbl ? tv : (u0 + t < a.Ms ? u0 + t : -1);
-        if (t < sunits) { const int row = t / a.Cs8, c8 = t - row * a.Cs8; wg2_store_t(St, c8, row, sv); }
+        if (t < sunits) {
+            const int row = t / a.Cs8, c8 = t - row * a.Cs8;
+            if constexpr (TR) wg2_put_r((unsigned char *)St, a.rss, a.dss, c8, row, sv);
+            else wg2_store_t(St, c8, row, sv);
+        }
         __syncthreads();
         if (c + 1 < c_end) prefetch(c + 1);
         // gathers of this wave's two offsets (32 rows x 16 channels = 64 units: one per lane and offset)
@@ -1068,18 +1110,25 @@ __global__ __launch_bounds__(WGW_WAVES * 64) void spconv_wgrad2_wide_kernel(cons
         }
 #pragma unroll
         for (int j = 0; j < 2; j++)
-            if (any[j]) wg2_store_t(Gt + (size_t)j * 16 * WG2_LDT, lane & 1, lane >> 1, gv[j]);
+            if (any[j]) {
+                if constexpr (TR) wg2_put_r((unsigned char *)Gt + j * gslot, a.rsg, a.dg, lane & 1, lane >> 1, gv[j]);
+                else wg2_store_t(Gt + (size_t)j * 16 * WG2_LDT, lane & 1, lane >> 1, gv[j]);
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             if (!any[j]) continue;      // wave-uniform
-            const uint4 av = *(const uint4 *)&Gt[(size_t)j * 16 * WG2_LDT + r * WG2_LDT + g * 8];
+            bf16x8_t av;
+            if constexpr (TR) av = wg2_frag_tr((const unsigned char *)Gt + j * gslot, lbg, a.rsg, 0);
+            else av = __builtin_bit_cast(bf16x8_t, *(const uint4 *)&Gt[(size_t)j * 16 * WG2_LDT + r * WG2_LDT + g * 8]);
 #pragma unroll
             for (int i = 0; i < NTV; i++) {
-                const uint4 bv = *(const uint4 *)&St[(i * 16 + r) * WG2_LDT + g * 8];
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc[j][i], 0, 0, 0);
+                bf16x8_t bv;
+                if constexpr (TR) bv = wg2_frag_tr((const unsigned char *)St, lbs, a.rss, i);
+                else bv = __builtin_bit_cast(bf16x8_t, *(const uint4 *)&St[(i * 16 + r) * WG2_LDT + g * 8]);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j][i], 0, 0, 0);
             }
         }
         __syncthreads();   // St / tblS are rewritten by the next chunk
@@ -1121,12 +1170,285 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const float *__restr
     }
 }
 
-struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw, wide; size_t lds, ws_bytes; };
+// ------------------------------------------------------------------------------ weight gradient, third generation
+// What bounds spconv_wgrad2_kernel at the big levels is instruction issue, not memory: ~110 VALU/SALU instructions per
+// (32-row chunk, offset) and lane for one MFMA -- run-time operand types (both conversion paths compiled in), bounds checks
+// and exec-mask juggling around every gather, 64-bit address arithmetic -- and every offset group re-reads the stationary
+// chunk and the kernel-map rows (profiles/r02_i: 75 MB of HBM traffic per launch against 32 MB algorithmic).  This kernel
+// generalises the wide-stationary kernel above to every shape of levels 0-2:
+//   * one workgroup of NW waves shares an iteration's rows (S sub-chunks of 32): kernel-map rows and the stationary operand are
+//     staged ONCE (row-major, converted to bf16 on the way), double-buffered in LDS, the next iteration's requested from
+//     memory before this iteration's gathers (one barrier per iteration);
+//   * wave w owns the offsets kbase + w + j*NW (j < OW) with all MT x NT tiles: no cross-wave reduction, every gathered row
+//     is fetched once per offset;
+//   * gathers are raw buffer loads (an absent neighbour, index -1, is an out-of-range offset: the hardware returns zeros;
+//     rows past the end likewise), all OW*S*MT of a wave's iteration in flight together; compile-time shapes, 32-bit offsets:
+//     ~10 instructions per gathered unit;
+//   * transposing LDS reads (ds_read_b64_tr_b16) deliver both MFMA operands from the row-major images.
+// Row splits write partial dW (single owner per tile and split: deterministic) summed by the fixed-order reduction.
+struct Wg3Args {
+    const void *G; const void *Sm; const int *tbl; float *dst;
+    unsigned int gbytes, sbytes, tbytes;   // buffer extents in bytes
+    int growb, srowb;                      // row pitch in bytes
+    int Ms, Cs8, cpw, flipk, Cin, Cout, K;
+    unsigned int invs;                     // ceil(65536 / Cs8)
+    int rss, dss, imgs;                    // stationary image (wg2_img)
+};
 
-static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define WG3_RSRC_FLAGS 0x00020000          // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+
+__device__ __forceinline__ uint4 wg3_cvt8(const u32x4_t lo, const u32x4_t hi) {
+    return make_uint4(pack2bf2(__uint_as_float(lo.x), __uint_as_float(lo.y)), pack2bf2(__uint_as_float(lo.z), __uint_as_float(lo.w)),
+                      pack2bf2(__uint_as_float(hi.x), __uint_as_float(hi.y)), pack2bf2(__uint_as_float(hi.z), __uint_as_float(hi.w)));
+}
+
+// GX: the gathered operand is x (bf16), the stationary one dy (fp32); else dy (fp32) is gathered and x (bf16) stationary.
+// NW * OW * KG >= KV; with equality (27 = 9 waves x 3 offsets, 8 = 4 x 2 = 8 x 1) no wave carries an idle offset slot.
+typedef v4s16_t __attribute__((address_space(3))) *wg3_lds_p;
+template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX>
+__global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a) {
+    constexpr int NTH = NW * 64;
+    constexpr int TE = S * 32 * KV;                                    // kernel-map entries per iteration
+    constexpr int TL = (TE + NTH - 1) / NTH;                           //   ... per thread
+    constexpr int SU = (S * 32 * NT * 2 + NTH - 1) / NTH;              // stationary 8-channel units per thread and iteration
+    constexpr int RSBG = (MT * 32) % 128 == 0 ? MT * 32 + 32 : MT * 32, DG = RSBG % 64 == 0 ? 32 : 128;
+    constexpr int IMGG = (32 * RSBG + 3 * DG + 15) & ~15;
+    constexpr int GE = GX ? 1 : 2, SE = GX ? 2 : 1;                    // 16-byte loads per gathered / stationary 8-channel unit
+    constexpr int CG8 = 2 * MT;
+    constexpr bool FULL = NW * OW * KG == KV;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // LDS (byte offsets): 2 x stationary images | 2 x kernel-map rows | one gather image per wave
+    const int st_bytes = S * a.imgs;
+    const int tb_base = 2 * st_bytes;
+    const int gs_off = tb_base + 2 * TE * 4 + wave * IMGG;
+    const int lbg = gs_off + wg2_lane_base(RSBG, DG, r, g), lbs = wg2_lane_base(a.rss, a.dss, r, g);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.G, 0, a.gbytes, WG3_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Sm, 0, a.sbytes, WG3_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)a.tbl, 0, a.tbytes, WG3_RSRC_FLAGS);
+    const int nit = (a.Ms + 32 * S - 1) / (32 * S);
+    const int it_begin = blockIdx.x * a.cpw, it_end = min(nit, it_begin + a.cpw);
+    const int k0 = blockIdx.y * (NW * OW) + wave;                      // this wave's offsets: k0 + j * NW
+
+    f32x4 acc[OW][MT][NT];
+#pragma unroll
+    for (int j = 0; j < OW; j++)
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) acc[j][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the stationary units this thread stages (the same image slots every iteration)
+    int s_img[SU];
+    unsigned int s_off[SU];
+#pragma unroll
+    for (int i = 0; i < SU; i++) {
+        const int u = t + i * NTH;
+        s_img[i] = -1; s_off[i] = 0xFFFFFFE0u;                          // out of range: the loads return zeros
+        if (u < S * 32 * a.Cs8) {
+            const int srow = (int)(((unsigned int)u * a.invs) >> 16), c8 = u - srow * a.Cs8, r32 = srow & 31;
+            s_img[i] = (srow >> 5) * a.imgs + r32 * a.rss + (r32 >> 3) * a.dss + c8 * 16;
+            s_off[i] = (unsigned int)(srow * a.srowb + c8 * (GX ? 32 : 16));
+        }
+    }
+    // gather lanes: row / unit of this lane's q-th gathered unit; byte offset of its kernel-map entry (offset k0, sub-chunk 0)
+    int g_row[MT], g_c8[MT];
+#pragma unroll
+    for (int q = 0; q < MT; q++) { const int unit = lane + q * 64; g_row[q] = unit / CG8; g_c8[q] = unit - g_row[q] * CG8; }
+
+    int tv[TL];
+    u32x4_t sv[SU][SE];
+    auto prefetch = [&](int it) {
+        const unsigned int row0 = (unsigned int)it * (32 * S);
+#pragma unroll
+        for (int i = 0; i < TL; i++) {
+            const int e = t + i * NTH;
+            tv[i] = 0;
+            if (TL * NTH == TE || e < TE) tv[i] = __builtin_amdgcn_raw_buffer_load_b32(rt, (row0 * KV + e) * 4u, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < SU; i++) {
+            const unsigned int off = s_img[i] >= 0 ? row0 * (unsigned int)a.srowb + s_off[i] : 0xFFFFFFE0u;
+#pragma unroll
+            for (int h = 0; h < SE; h++) sv[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u * h, 0, 0);
+        }
+    };
+    if (it_begin < it_end) prefetch(it_begin);
+    for (int it = it_begin; it < it_end; it++) {
+        const int buf = (it - it_begin) & 1;
+        const int st_off = buf * st_bytes, tb_off = tb_base + buf * (TE * 4);
+#pragma unroll
+        for (int i = 0; i < TL; i++) {
+            const int e = t + i * NTH;
+            if (TL * NTH == TE || e < TE) *(int *)(smem + tb_off + e * 4) = tv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < SU; i++)
+            if (s_img[i] >= 0) {
+                uint4 v;
+                if constexpr (GX) v = wg3_cvt8(sv[i][0], sv[i][SE - 1]);
+                else v = make_uint4(sv[i][0].x, sv[i][0].y, sv[i][0].z, sv[i][0].w);
+                *(uint4 *)(smem + st_off + s_img[i]) = v;
+            }
+        __syncthreads();
+        if (it + 1 < it_end) prefetch(it + 1);
+        // this wave's gathers: OW offsets x S sub-chunks x MT units per lane, all in flight together
+        u32x4_t gv[OW][S][MT][GE];
+#pragma unroll
+        for (int j = 0; j < OW; j++) {
+            const int k = k0 + j * NW;
+            if (FULL || k < KV) {   // wave-uniform (scalar)
+#pragma unroll
+                for (int s = 0; s < S; s++)
+#pragma unroll
+                    for (int q = 0; q < MT; q++) {
+                        const int idx = *(const int *)(smem + tb_off + ((s * 32 + g_row[q]) * KV + k) * 4);
+                        const unsigned int off = (unsigned int)idx * (unsigned int)a.growb + g_c8[q] * (GX ? 16 : 32);
+#pragma unroll
+                        for (int h = 0; h < GE; h++) gv[j][s][q][h] = __builtin_amdgcn_raw_buffer_load_b128(rg, off + 16u * h, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            bf16x8_t af[OW][MT];
+#pragma unroll
+            for (int j = 0; j < OW; j++) {
+                const int k = k0 + j * NW;
+                if (FULL || k < KV) {
+#pragma unroll
+                    for (int q = 0; q < MT; q++) {
+                        uint4 v;
+                        if constexpr (GX) v = make_uint4(gv[j][s][q][0].x, gv[j][s][q][0].y, gv[j][s][q][0].z, gv[j][s][q][0].w);
+                        else v = wg3_cvt8(gv[j][s][q][0], gv[j][s][q][GE - 1]);
+                        *(uint4 *)(smem + gs_off + g_row[q] * RSBG + (g_row[q] >> 3) * DG + g_c8[q] * 16) = v;
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MT; mi++) {
+                        const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg3_lds_p)(smem + lbg + mi * 32));
+                        const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg3_lds_p)(smem + lbg + mi * 32 + 4 * RSBG));
+                        af[j][mi] = __builtin_bit_cast(bf16x8_t, (v8s16_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const int bo = st_off + s * a.imgs + lbs + ni * 32;
+                const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg3_lds_p)(smem + bo));
+                const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg3_lds_p)(smem + bo + 4 * a.rss));
+                const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, (v8s16_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int j = 0; j < OW; j++) {
+                    const int k = k0 + j * NW;
+                    if (FULL || k < KV) {
+#pragma unroll
+                        for (int mi = 0; mi < MT; mi++)
+                            acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][mi], bv, acc[j][mi][ni], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const long long wsz = (long long)KV * a.Cin * a.Cout;
+    float *dst = a.dst + (long long)blockIdx.x * wsz;
+#pragma unroll
+    for (int j = 0; j < OW; j++) {
+        const int k = k0 + j * NW;
+        if (!FULL && k >= KV) continue;
+        const int wk = a.flipk ? (KV - 1 - k) : k;
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int cg = mi * 16 + g * 4 + q, cs = ni * 16 + r;
+                    const int ci = GX ? cg : cs, co = GX ? cs : cg;
+                    if (ci < a.Cin && co < a.Cout) dst[((long long)wk * a.Cin + ci) * a.Cout + co] = acc[j][mi][ni][q];
+                }
+    }
+}
+
+// shapes the third-generation kernel is instantiated for: (MT, NT, K, gx) -> (NW, OW, S)
+struct Wg3Cfg { int mt, nt, k, gx, nw, ow, kg, s; };
+#define WG3_CONFIGS(X)                                                        \
+    X(1, 1, 27, 1, 9, 3, 1, 4)   /* 16 -> 16, level 0 */                       \
+    X(1, 2, 27, 0, 9, 3, 1, 2)   /* 32 -> 16 (first conv behind a concatenation) */ \
+    X(1, 2, 8, 1, 4, 2, 1, 4)    /* down 16 -> 32 */                           \
+    X(1, 2, 8, 0, 4, 2, 1, 4)    /* up 32 -> 16 */                             \
+    X(2, 2, 27, 1, 9, 3, 1, 2)   /* 32 -> 32, level 1 */                       \
+    X(2, 2, 27, 1, 9, 1, 3, 4)   /*   ... three offset groups (more workgroups per partial dW) */ \
+    X(2, 4, 27, 0, 9, 3, 1, 1)   /* 64 -> 32 */                                \
+    X(2, 4, 27, 0, 9, 1, 3, 2)                                                 \
+    X(2, 3, 8, 1, 8, 1, 1, 4)    /* down 32 -> 48 */                           \
+    X(2, 3, 8, 0, 8, 1, 1, 4)    /* up 48 -> 32 */                             \
+    X(3, 3, 27, 1, 9, 3, 1, 1)   /* 48 -> 48, level 2 */                       \
+    X(3, 3, 27, 1, 9, 1, 3, 2)                                                 \
+    X(3, 6, 27, 0, 9, 1, 3, 2)   /* 96 -> 48 */
+/* measured and left to the other kernels (tools/wgrad_bench.py, profiles/r02_k): the stem 136 -> 16 (the 16-wave wide-stationary
+ * kernel: 208 us against 273 us here at 649 k rows) and the stride-2 pairs of level 2 and deeper (within noise) */
+#define WG3_ROW(MT, NT, KV, GXV, NW, OW, KG, SV) {MT, NT, KV, GXV, NW, OW, KG, SV},
+static const Wg3Cfg wg3_cfgs[] = {WG3_CONFIGS(WG3_ROW)};
+#undef WG3_ROW
+static bool wg3_enabled() { const char *e = getenv("D3_WG3"); return !(e && e[0] == '0'); }   // D3_WG3=0: A/B measurements
+// row splits of a configuration: ~4096 waves per launch; the partials (written once, read once by the reduction) stay below
+// max(16 MB, 25 % of the algorithmic bytes)
+static int wg3_splits(const Wg3Cfg &c, int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gbf, bool sbf, int *cpw) {
+    const int nit = (Ms + 32 * c.s - 1) / (32 * c.s);
+    const long long wsz = (long long)K * Cin * Cout * 4;
+    const double alg = (double)Ms * K * 4 + (double)Mg * Cg * (gbf ? 2 : 4) + (double)Ms * Cs * (sbf ? 2 : 4);
+    double cap = 0.25 * alg; if (cap < 16.0 * 1048576) cap = 16.0 * 1048576;
+    int R = 4096 / (c.nw * c.kg); if (R < 1) R = 1;
+    const int capR = (int)(cap / (double)wsz); if (R > capR) R = capR;
+    if (R > (nit + 1) / 2) R = (nit + 1) / 2;
+    if (R < 2) R = 2;            // (always row-split: the partials go through the reduction; Ms >= 2048 gives nit >= 16)
+    *cpw = (nit + R - 1) / R;
+    return (nit + *cpw - 1) / *cpw;
+}
+static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gx, bool gbf, bool sbf) {
+    if (!wg3_enabled() || Ms < 2048 || (Cg & 15) || (Cs & 7)) return nullptr;
+    if (gx ? (!gbf || sbf) : (gbf || !sbf)) return nullptr;          // x bf16 and dy fp32 only
+    // 32-bit buffer offsets: operand extents with up to 2x row pitch (views of concatenated buffers)
+    if ((long long)Mg * Cg * 2 * (gbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * Cs * 2 * (sbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * K * 4 >= (1ll << 31)) return nullptr;
+    const int mt = Cg / 16, nt = (Cs + 15) / 16;
+    const Wg3Cfg *best = nullptr;
+    int best_waves = 0;
+    for (const Wg3Cfg &c : wg3_cfgs)
+        if (c.mt == mt && c.nt == nt && c.k == K && c.gx == (gx ? 1 : 0)) {
+            int cpw;
+            const int waves = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &cpw) * c.kg * c.nw;
+            if (waves >= 2048) return &c;        // the first (fewest offset groups) that fills the chip
+            if (waves > best_waves) { best = &c; best_waves = waves; }
+        }
+    return best;
+}
+
+struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw, wide, tr; int rsg, dg, imgg, rss, dss, imgs; size_t lds, ws_bytes; const Wg3Cfg *w3; };
+
+// D3_WG2_TR=0 selects the first staging scheme (transposed ds_write_b16 images) for A/B measurements
+static bool wg2_use_tr() { const char *e = getenv("D3_WG2_TR"); return !(e && e[0] == '0'); }
+
+static Wg2Plan wg2_plan(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gx, bool gbf, bool sbf) {
     Wg2Plan p;
     const int mt = (Cg + 15) / 16, nt = (Cs + 15) / 16, ntl = mt * nt;
     p.wide = 0;
+    p.tr = wg2_use_tr() ? 1 : 0;
+    wg2_img(Cg / 8, &p.rsg, &p.dg, &p.imgg);
+    wg2_img(Cs / 8, &p.rss, &p.dss, &p.imgs);
+    p.imgg = (p.imgg + 15) & ~15; p.imgs = (p.imgs + 15) & ~15;
+    p.w3 = wg3_pick(Ms, Mg, K, Cg, Cs, Cin, Cout, gx, gbf, sbf);
+    if (p.w3) {
+        const Wg3Cfg &c = *p.w3;
+        p.kg = c.kg;
+        p.R = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &p.cpw);
+        const long long wsz = (long long)K * Cin * Cout * 4;
+        p.lds = (size_t)2 * c.s * p.imgs + (size_t)2 * c.s * 32 * K * 4 + (size_t)c.nw * (((32 * ((c.mt * 32) % 128 == 0 ? c.mt * 32 + 32 : c.mt * 32) + 3 * 128) + 15) & ~15);
+        p.ws_bytes = (size_t)p.R * wsz;
+        p.tpo = 0; p.nu = 0; p.opw = c.ow; p.passes = 1;
+        return p;
+    }
     if (mt == 1 && nt > 4 && nt <= WGW_MAXNT && K <= 2 * WGW_WAVES && 32 * (Cs / 8) <= WGW_WAVES * 64 && Ms >= 4096) {
         // one 16-wave workgroup per row split holds all K x nt tiles (spconv_wgrad2_wide_kernel)
         p.wide = 1; p.tpo = nt; p.nu = 1; p.opw = 2; p.kg = 1; p.passes = 1;
@@ -1134,7 +1456,8 @@ static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
         int R = 256; if (R > (nchunks + 3) / 4) R = (nchunks + 3) / 4; if (R < 1) R = 1;
         p.cpw = (nchunks + R - 1) / R;
         p.R = (nchunks + p.cpw - 1) / p.cpw;
-        p.lds = (size_t)nt * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4 + (size_t)WGW_WAVES * 2 * 16 * WG2_LDT * 2;
+        p.lds = p.tr ? (size_t)p.imgs + (size_t)32 * C2_MAXK * 4 + (size_t)WGW_WAVES * 2 * p.imgg
+                     : (size_t)nt * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4 + (size_t)WGW_WAVES * 2 * 16 * WG2_LDT * 2;
         p.ws_bytes = (size_t)p.R * K * Cin * Cout * 4;
         return p;
     }
@@ -1154,30 +1477,47 @@ static Wg2Plan wg2_plan(int Ms, int K, int Cg, int Cs, int Cin, int Cout) {
     p.cpw = (nchunks + R - 1) / R;
     p.cpw = (p.cpw + 3) / 4 * 4;
     p.R = (nchunks + p.cpw - 1) / p.cpw;
-    const size_t wave_bytes = (size_t)(mt + nt) * 16 * WG2_LDT * 2 + (size_t)32 * C2_MAXK * 4;
+    const size_t wave_bytes = (p.tr ? (size_t)p.imgg + p.imgs : (size_t)(mt + nt) * 16 * WG2_LDT * 2) + (size_t)32 * C2_MAXK * 4;
     p.lds = 4 * wave_bytes; if (p.lds < 32 * 1024) p.lds = 32 * 1024;
     p.ws_bytes = p.R > 1 ? (size_t)p.R * wsz : 0;
     return p;
 }
 
+static Wg2Plan wg2_plan_flags(int Min, int Mout, int K, int Cin, int Cout, int flags) {
+    const bool xstat = (flags & D3_CONV_XSTAT) != 0, xbf = (flags & D3_CONV_XBF16) != 0, dybf = (flags & D3_CONV_DYBF16) != 0;
+    return xstat ? wg2_plan(Min, Mout, K, Cout, Cin, Cin, Cout, false, dybf, xbf) : wg2_plan(Mout, Min, K, Cin, Cout, Cin, Cout, true, xbf, dybf);
+}
+
+// flags: the D3_CONV_XSTAT / D3_CONV_XBF16 / D3_CONV_DYBF16 bits of the d3_spconv_wgrad2 call (the kernel choice depends on them)
 extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags) {
-    const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0;
-    return wg2_plan(xstat ? Min : Mout, K, xstat ? Cout : Cin, xstat ? Cin : Cout, Cin, Cout).ws_bytes;
+    return wg2_plan_flags(Min, Mout, K, Cin, Cout, flags).ws_bytes;
 }
 
 // number of row splits d3_spconv_wgrad2 uses for this shape (its partials: splits x K*CinW*Cout floats in ws)
 extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags) {
-    const int xstat = (flags & D3_CONV_XSTAT) ? 1 : 0;
-    return wg2_plan(xstat ? Min : Mout, K, xstat ? Cout : Cin, xstat ? Cin : Cout, Cin, Cout).R;
+    return wg2_plan_flags(Min, Mout, K, Cin, Cout, flags).R;
+}
+
+template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX>
+static int launch_wg3(const Wg3Args &a, const Wg2Plan &p, hipStream_t s) {
+    static_assert(NW * OW * KG >= KV, "offsets not covered");
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev))
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int TPO, int NU>
 static int launch_wg2(const Wg2Args &a, const Wg2Plan &p, hipStream_t s) {
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev)) {
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_kernel<TPO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_kernel<TPO, NU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_kernel<TPO, NU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     }
-    spconv_wgrad2_kernel<TPO, NU><<<dim3(p.R, p.kg, p.passes), 256, p.lds, s>>>(a);
+    if (p.tr) spconv_wgrad2_kernel<TPO, NU, true><<<dim3(p.R, p.kg, p.passes), 256, p.lds, s>>>(a);
+    else spconv_wgrad2_kernel<TPO, NU, false><<<dim3(p.R, p.kg, p.passes), 256, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -1204,19 +1544,42 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     if (xstat) { a.Sm = x; a.lds = ldx; a.sbf16 = xbf; a.G = dy; a.ldg = ldy; a.gbf16 = dybf; a.gx = 0; }
     else { a.Sm = dy; a.lds = ldy; a.sbf16 = dybf; a.G = x; a.ldg = ldx; a.gbf16 = xbf; a.gx = 1; }
     const int Cg = xstat ? Cout : Cin, Cs = xstat ? Cin : Cout;
-    const Wg2Plan p = wg2_plan(Ms, K, Cg, Cs, Cin, Cout);
+    const Wg2Plan p = wg2_plan_flags(Min, Mout, K, Cin, Cout, flags);
     if (p.ws_bytes > ws_bytes) return D3_ERR_WORKSPACE;
-    const bool direct = (p.R == 1 && !accum) && !p.wide;
+    const bool direct = (p.R == 1 && !accum) && !p.wide && !p.w3;
     const bool noreduce = (flags & D3_CONV_NOREDUCE) != 0;   // the caller sums the partials (batched over its layers)
     a.tbl = tbl; a.dst = direct ? dW : (float *)ws;
     if (!direct && p.R == 1 && ws_bytes < (size_t)wn * 4) return D3_ERR_WORKSPACE;
     a.Ms = Ms; a.K = K; a.mt = (Cg + 15) / 16; a.nt = (Cs + 15) / 16; a.Cg8 = Cg / 8; a.Cs8 = Cs / 8;
     a.invg = (65536u + a.Cg8 - 1) / a.Cg8; a.invs = (65536u + a.Cs8 - 1) / a.Cs8;
     a.cpw = p.cpw; a.flipk = (flags & D3_CONV_FLIPK) ? 1 : 0; a.Cin = CinW; a.Cout = Cout;
+    a.rsg = p.rsg; a.dg = p.dg; a.imgg = p.imgg; a.rss = p.rss; a.dss = p.dss; a.imgs = p.imgs;
     const double bytes = (xbf ? 2.0 : 4.0) * (double)Min * Cin + (dybf ? 2.0 : 4.0) * (double)Mout * Cout + 4.0 * (double)wn +
                          (tbl ? 4.0 * (double)Ms * K : 0.0);
     void *pr = d3_prof_begin(1, bytes, 0.0, s);
     int rc = D3_ERR_ARG;
+    if (p.w3) {
+        const Wg3Cfg &c = *p.w3;
+        const int Mg = xstat ? Mout : Min;
+        const long long gb = ((long long)(Mg - 1) * a.ldg + Cg) * (a.gbf16 ? 2 : 4), sb = ((long long)(Ms - 1) * a.lds + Cs) * (a.sbf16 ? 2 : 4);
+        if (gb >= (1ll << 31) || sb >= (1ll << 31) || Mg < 1) return D3_ERR_ARG;
+        Wg3Args b;
+        b.G = a.G; b.Sm = a.Sm; b.tbl = tbl; b.dst = (float *)ws;
+        b.gbytes = (unsigned int)gb; b.sbytes = (unsigned int)sb; b.tbytes = (unsigned int)((long long)Ms * K * 4);
+        b.growb = a.ldg * (a.gbf16 ? 2 : 4); b.srowb = a.lds * (a.sbf16 ? 2 : 4);
+        b.Ms = Ms; b.Cs8 = Cs / 8; b.cpw = p.cpw; b.flipk = a.flipk; b.Cin = CinW; b.Cout = Cout; b.K = K;
+        b.invs = a.invs; b.rss = p.rss; b.dss = p.dss; b.imgs = p.imgs;
+#define WG3_CASE(MT, NT, KV, GXV, NW, OW, KG, SV)                                                                \
+        if (c.mt == MT && c.nt == NT && c.k == KV && c.gx == GXV && c.kg == KG && c.ow == OW) rc = launch_wg3<MT, NT, KV, NW, OW, KG, SV, (GXV != 0)>(b, p, s);
+        WG3_CONFIGS(WG3_CASE)
+#undef WG3_CASE
+        if (rc == 0 && !noreduce) {
+            wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
+            D3_LAUNCH_CHECK();
+        }
+        d3_prof_end(pr, s);
+        return rc;
+    }
     if (p.wide) {
         if (ws_bytes < p.ws_bytes) return D3_ERR_WORKSPACE;
         a.dst = (float *)ws;
@@ -1224,8 +1587,12 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         const bool set = c2_attr_needed(wide_attr);
 #define WGW_CASE(NTV)                                                                                                              \
         case NTV:                                                                                                                      \
-            if (set) D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_wide_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
-            spconv_wgrad2_wide_kernel<NTV><<<p.R, WGW_WAVES * 64, p.lds, s>>>(a);                                                     \
+            if (set) {                                                                                                                 \
+                D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_wide_kernel<NTV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+                D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad2_wide_kernel<NTV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+            }                                                                                                                          \
+            if (p.tr) spconv_wgrad2_wide_kernel<NTV, true><<<p.R, WGW_WAVES * 64, p.lds, s>>>(a);                                      \
+            else spconv_wgrad2_wide_kernel<NTV, false><<<p.R, WGW_WAVES * 64, p.lds, s>>>(a);                                          \
             break;
         switch (a.nt) { WGW_CASE(5) WGW_CASE(6) WGW_CASE(7) WGW_CASE(8) WGW_CASE(9) default: return D3_ERR_ARG; }
 #undef WGW_CASE

@@ -518,7 +518,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
                 o.partw = (o.Cout + 15) / 16 * 16;
                 o.part_off = off; off += d3_align((size_t)o.nparts * 2 * o.partw * 4);
             }
-            const int xstat = (o.Cin > o.Cout) ? D3_CONV_XSTAT : 0;
+            const int xstat = ((o.Cin > o.Cout) ? D3_CONV_XSTAT : 0) | (n->T[o.in].dtype == 1 ? D3_CONV_XBF16 : 0);   // as in d3_net_backward
             o.wsplits = d3_spconv_wgrad2_splits(Min, Mout, o.K, o.Cin, o.Cout, xstat);
             o.wpart_bytes = d3_align((size_t)o.wsplits * o.K * o.Cin * o.Cout * 4 + 256);
         } else if (o.type == OP_STATS) {

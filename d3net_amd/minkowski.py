@@ -227,7 +227,7 @@ def _conv_wgrad(x, tbl_f, tbl_b, dy, W3, Mout, bwd_flags, xflag=0):
         tbl, wflags = tbl_f, 0
     if _GEN2 and not _EXACT and Cin % 8 == 0 and Cout % 8 == 0:
         L = _lib.lib()
-        ws = _workspace(max(L.d3_spconv_wgrad2_ws_bytes(x.size(0), Mout, K, Cin, Cout, wflags), 16), x.device, "wgrad")
+        ws = _workspace(max(L.d3_spconv_wgrad2_ws_bytes(x.size(0), Mout, K, Cin, Cout, wflags | xflag), 16), x.device, "wgrad")
         with _on(x.device):
             check(L.d3_spconv_wgrad2(_ptr(x), Cin, _ptr(tbl) if tbl is not None else None, _ptr(dy), Cout, _ptr(dW),
                                      x.size(0), Mout, K, Cin, Cout, Cin, wflags | xflag, _ptr(ws), ws.numel(), _stream()),

@@ -217,6 +217,8 @@ int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void 
                              const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                              const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma, float *dbeta,
                              int accum, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
+/* flags of the two queries: the D3_CONV_XSTAT / D3_CONV_XBF16 / D3_CONV_DYBF16 bits of the d3_spconv_wgrad2 call they size
+ * (the kernel, and with it the number of row splits, depends on the operand types) */
 size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags);
 int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,

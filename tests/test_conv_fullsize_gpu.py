@@ -226,9 +226,9 @@ def test_wgrad2_row_splits_and_reduction(dev, canon, level, kind, cin, cout, xbf
     xstat = cin > cout
     flags = (XSTAT | flip) if xstat else 0
     tbl = tbl_b if xstat else tbl_f
-    splits = L.d3_spconv_wgrad2_splits(Min, Mout, K, cin, cout, flags)
+    splits = L.d3_spconv_wgrad2_splits(Min, Mout, K, cin, cout, flags | (XBF16 if xbf else 0))
     assert splits > 1, "canonical levels 0/1 are row-split"
-    ws = torch.empty(max(L.d3_spconv_wgrad2_ws_bytes(Min, Mout, K, cin, cout, flags), 16), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(L.d3_spconv_wgrad2_ws_bytes(Min, Mout, K, cin, cout, flags | (XBF16 if xbf else 0)), 16), dtype=torch.uint8, device=dev)
     dW = torch.full((K, cin, cout), float("nan"), device=dev)
     xd = x.to(dev).bfloat16() if xbf else x.to(dev)
     dyd = dy.to(dev)

@@ -13,11 +13,13 @@ for path in sys.argv[1:3]:
     for line in list(open(path))[1:]:
         # kernel names contain commas (template arguments): the four numeric / counter fields are the last four
         name, counter, launches, _mean, total = line.rstrip("\n").rsplit(",", 4)
-        base = name.split("<")[0]
+        base = name.split("<")[0].strip('"').replace("void ", "")
+        if base in ("spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel"):   # bench.py's weight-gradient family
+            base = "spconv_wgrad3_kernel"
         a = acc[base][counter]
         a[0] += int(launches); a[1] += float(total)
 out = {}
-for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad2_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel",
+for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel",
           "un_bn_bwd_apply_kernel", "hg_gemm_kernel", "cl_push_kernel", "bq_scan_kernel"):
     if k not in acc:
         continue
