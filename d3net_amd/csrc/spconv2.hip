@@ -1374,36 +1374,47 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 // shapes the third-generation kernel is instantiated for: (MT, NT, K, gx) -> (NW, OW, S)
 struct Wg3Cfg { int mt, nt, k, gx, nw, ow, kg, s; };
 #define WG3_CONFIGS(X)                                                        \
-    X(1, 1, 27, 1, 9, 3, 1, 4)   /* 16 -> 16, level 0 */                       \
-    X(1, 2, 27, 0, 9, 3, 1, 2)   /* 32 -> 16 (first conv behind a concatenation) */ \
+    X(1, 1, 27, 1, 9, 3, 1, 8)   /* 16 -> 16, level 0 */                       \
+    X(1, 2, 27, 0, 9, 3, 1, 4)   /* 32 -> 16 (first conv behind a concatenation) */ \
     X(1, 2, 8, 1, 4, 2, 1, 4)    /* down 16 -> 32 */                           \
     X(1, 2, 8, 0, 4, 2, 1, 4)    /* up 32 -> 16 */                             \
-    X(2, 2, 27, 1, 9, 3, 1, 2)   /* 32 -> 32, level 1 */                       \
+    X(2, 2, 27, 1, 9, 3, 1, 4)   /* 32 -> 32, level 1 */                       \
     X(2, 2, 27, 1, 9, 1, 3, 4)   /*   ... three offset groups (more workgroups per partial dW) */ \
     X(2, 4, 27, 0, 9, 3, 1, 1)   /* 64 -> 32 */                                \
-    X(2, 4, 27, 0, 9, 1, 3, 2)                                                 \
+    X(2, 4, 27, 0, 9, 1, 3, 4)                                                 \
     X(2, 3, 8, 1, 8, 1, 1, 4)    /* down 32 -> 48 */                           \
     X(2, 3, 8, 0, 8, 1, 1, 4)    /* up 48 -> 32 */                             \
     X(3, 3, 27, 1, 9, 3, 1, 1)   /* 48 -> 48, level 2 */                       \
     X(3, 3, 27, 1, 9, 1, 3, 2)                                                 \
     X(3, 6, 27, 0, 9, 1, 3, 2)   /* 96 -> 48 */
-/* measured and left to the other kernels (tools/wgrad_bench.py, profiles/r02_k): the stem 136 -> 16 (the 16-wave wide-stationary
- * kernel: 208 us against 273 us here at 649 k rows) and the stride-2 pairs of level 2 and deeper (within noise) */
+/* (S: sub-chunks of 32 rows per iteration, i.e. gathers in flight per wave -- swept per shape with D3_WG3_S.)  Measured and left to
+ * the other kernels (tools/wgrad_bench.py, profiles/r02_k): the stem 136 -> 16 (the 16-wave wide-stationary kernel: 208 us against
+ * 273 us here at 649 k rows) and the stride-2 pairs of level 2 and deeper (within noise) */
 #define WG3_ROW(MT, NT, KV, GXV, NW, OW, KG, SV) {MT, NT, KV, GXV, NW, OW, KG, SV},
 static const Wg3Cfg wg3_cfgs[] = {WG3_CONFIGS(WG3_ROW)};
 #undef WG3_ROW
 static bool wg3_enabled() { const char *e = getenv("D3_WG3"); return !(e && e[0] == '0'); }   // D3_WG3=0: A/B measurements
-// row splits of a configuration: ~4096 waves per launch; the partials (written once, read once by the reduction) stay below
-// max(16 MB, 25 % of the algorithmic bytes)
-static int wg3_splits(const Wg3Cfg &c, int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gbf, bool sbf, int *cpw) {
+// Row splits of a configuration.  One workgroup per compute unit: measured on MI355X (tools/wgrad_bench.py, 649 k rows, 16 -> 16)
+// 256 / 384 / 512 / 1024 workgroups = 57 / 75 / 68 / 90 us -- a multiple of the CU count keeps the CUs evenly loaded, every extra
+// split is another partial dW written and read back.  The partials stay below max(16 MB, 25 % of the algorithmic bytes).
+static int wg3_ncu() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t p; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    return n;
+}
+static int wg3_splits(const Wg3Cfg &c, int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gbf, bool sbf, int *cpw, bool *capped) {
     const int nit = (Ms + 32 * c.s - 1) / (32 * c.s);
     const long long wsz = (long long)K * Cin * Cout * 4;
     const double alg = (double)Ms * K * 4 + (double)Mg * Cg * (gbf ? 2 : 4) + (double)Ms * Cs * (sbf ? 2 : 4);
     double cap = 0.25 * alg; if (cap < 16.0 * 1048576) cap = 16.0 * 1048576;
-    int R = 4096 / (c.nw * c.kg); if (R < 1) R = 1;
-    const int capR = (int)(cap / (double)wsz); if (R > capR) R = capR;
+    int target = wg3_ncu();
+    { const char *e = getenv("D3_WG3_R"); if (e && atoi(e) > 0) target = atoi(e); }   // (experiments)
+    int R = target / c.kg; if (R < 1) R = 1;
+    const int capR = (int)(cap / (double)wsz);
+    *capped = R > capR;
+    if (R > capR) R = capR;
     if (R > (nit + 1) / 2) R = (nit + 1) / 2;
-    if (R < 2) R = 2;            // (always row-split: the partials go through the reduction; Ms >= 2048 gives nit >= 16)
+    if (R < 2) R = 2;            // (always row-split: the partials go through the reduction; Ms >= 2048 gives nit >= 8)
     *cpw = (nit + R - 1) / R;
     return (nit + *cpw - 1) / *cpw;
 }
@@ -1413,14 +1424,20 @@ static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, in
     // 32-bit buffer offsets: operand extents with up to 2x row pitch (views of concatenated buffers)
     if ((long long)Mg * Cg * 2 * (gbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * Cs * 2 * (sbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * K * 4 >= (1ll << 31)) return nullptr;
     const int mt = Cg / 16, nt = (Cs + 15) / 16;
+    const char *es = getenv("D3_WG3_S");                               // (experiments: prefer the variants with this S)
+    const int want_s = es ? atoi(es) : 0;
+    bool have_s = false;
+    for (const Wg3Cfg &c : wg3_cfgs)
+        if (c.mt == mt && c.nt == nt && c.k == K && c.gx == (gx ? 1 : 0) && c.s == want_s) have_s = true;
     const Wg3Cfg *best = nullptr;
-    int best_waves = 0;
+    int best_wgs = 0;
     for (const Wg3Cfg &c : wg3_cfgs)
         if (c.mt == mt && c.nt == nt && c.k == K && c.gx == (gx ? 1 : 0)) {
-            int cpw;
-            const int waves = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &cpw) * c.kg * c.nw;
-            if (waves >= 2048) return &c;        // the first (fewest offset groups) that fills the chip
-            if (waves > best_waves) { best = &c; best_waves = waves; }
+            if (have_s && c.s != want_s) continue;
+            int cpw; bool capped;
+            const int wgs = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &cpw, &capped) * c.kg;
+            if (!capped) return &c;              // the first (fewest offset groups) whose splits fill the chip within the budget
+            if (wgs > best_wgs) { best = &c; best_wgs = wgs; }
         }
     return best;
 }
@@ -1442,7 +1459,8 @@ static Wg2Plan wg2_plan(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout
     if (p.w3) {
         const Wg3Cfg &c = *p.w3;
         p.kg = c.kg;
-        p.R = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &p.cpw);
+        bool capped;
+        p.R = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &p.cpw, &capped);
         const long long wsz = (long long)K * Cin * Cout * 4;
         p.lds = (size_t)2 * c.s * p.imgs + (size_t)2 * c.s * 32 * K * 4 + (size_t)c.nw * (((32 * ((c.mt * 32) % 128 == 0 ? c.mt * 32 + 32 : c.mt * 32) + 3 * 128) + 15) & ~15);
         p.ws_bytes = (size_t)p.R * wsz;
@@ -1570,7 +1588,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         b.Ms = Ms; b.Cs8 = Cs / 8; b.cpw = p.cpw; b.flipk = a.flipk; b.Cin = CinW; b.Cout = Cout; b.K = K;
         b.invs = a.invs; b.rss = p.rss; b.dss = p.dss; b.imgs = p.imgs;
 #define WG3_CASE(MT, NT, KV, GXV, NW, OW, KG, SV)                                                                \
-        if (c.mt == MT && c.nt == NT && c.k == KV && c.gx == GXV && c.kg == KG && c.ow == OW) rc = launch_wg3<MT, NT, KV, NW, OW, KG, SV, (GXV != 0)>(b, p, s);
+        if (c.mt == MT && c.nt == NT && c.k == KV && c.gx == GXV && c.kg == KG && c.ow == OW && c.s == SV) rc = launch_wg3<MT, NT, KV, NW, OW, KG, SV, (GXV != 0)>(b, p, s);
         WG3_CONFIGS(WG3_CASE)
 #undef WG3_CASE
         if (rc == 0 && !noreduce) {
