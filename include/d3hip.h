@@ -8,7 +8,9 @@
  *     stream-ordered on it;
  *   - return value: 0 = success, >0 = hipError_t, <0 = D3_ERR_* below;
  *   - no hidden allocation: ops that need scratch take `ws`/`ws_bytes` and have a
- *     `*_ws_bytes()` query; data-dependent output sizes use a two-phase
+ *     `*_ws_bytes()` query (the one exception: the network object of d3_net_create owns two
+ *     small grow-only job tables, allocated lazily inside d3_net_forward / d3_net_backward and
+ *     freed by d3_net_destroy -- see there); data-dependent output sizes use a two-phase
  *     `*_count` (writes sizes to `*_host`, synchronises the stream) / `*_fill` pair so
  *     the caller allocates, exactly as the reference's python layer does
  *     (reference: lib/pointgroup_ops/functions/pointgroup_ops.py).
@@ -264,7 +266,11 @@ int d3_bn_relu_bwd(const float *x, const float *dy, const float *mean, const flo
  * caller's arena (kept for the backward); backward needs a gradient arena of grad_bytes.  params[i] / pgrads[i] are
  * device pointers of parameter i and of its gradient (NULL = frozen; paccum[i] != 0: accumulate).  k3 / child / up:
  * the kernel-map tables of d3_kmap_* per level.  Data gradients run on `stream`, weight gradients on an internal
- * side stream that `stream` joins before the call returns. */
+ * side stream that `stream` joins before the call returns.
+ * Memory owned by the network object (the exception to "no hidden allocation"): forward keeps a device copy of its
+ * weight-packing job table (hipMalloc on first use / when the table grows; refreshing it synchronises `stream` once),
+ * backward a pinned-host + device pair for the batched weight-gradient reduction jobs (hipHostMalloc + hipMalloc,
+ * grow-only); a few KB each, released by d3_net_destroy. */
 void *d3_net_create(const int64_t *prog, int nops, const int64_t *tensors, int ntensors, const int64_t *bufs, int nbufs,
                     int nlevels, int nparams, int input_needs_grad, int out_tensor);
 void d3_net_destroy(void *net);
