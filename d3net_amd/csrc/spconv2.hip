@@ -1203,10 +1203,11 @@ __device__ __forceinline__ uint4 wg3_cvt8(const u32x4_t lo, const u32x4_t hi) {
                       pack2bf2(__uint_as_float(hi.x), __uint_as_float(hi.y)), pack2bf2(__uint_as_float(hi.z), __uint_as_float(hi.w)));
 }
 
-// GX: the gathered operand is x (bf16), the stationary one dy (fp32); else dy (fp32) is gathered and x (bf16) stationary.
+// GX: the gathered operand is x (bf16), the stationary one dy; else dy is gathered and x (bf16) stationary.  DYBF: dy is stored
+// as bf16 (the executor's single-consumer gradient buffers), else fp32 and converted on the way into LDS.
 // NW * OW * KG >= KV; with equality (27 = 9 waves x 3 offsets, 8 = 4 x 2 = 8 x 1) no wave carries an idle offset slot.
 typedef v4s16_t __attribute__((address_space(3))) *wg3_lds_p;
-template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX>
+template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX, bool DYBF>
 __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a) {
     constexpr int NTH = NW * 64;
     constexpr int TE = S * 32 * KV;                                    // kernel-map entries per iteration
@@ -1214,7 +1215,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
     constexpr int SU = (S * 32 * NT * 2 + NTH - 1) / NTH;              // stationary 8-channel units per thread and iteration
     constexpr int RSBG = (MT * 32) % 128 == 0 ? MT * 32 + 32 : MT * 32, DG = RSBG % 64 == 0 ? 32 : 128;
     constexpr int IMGG = (32 * RSBG + 3 * DG + 15) & ~15;
-    constexpr int GE = GX ? 1 : 2, SE = GX ? 2 : 1;                    // 16-byte loads per gathered / stationary 8-channel unit
+    constexpr int GE = (GX || DYBF) ? 1 : 2, SE = (GX && !DYBF) ? 2 : 1;   // 16-byte loads per gathered / stationary 8-channel unit
     constexpr int CG8 = 2 * MT;
     constexpr bool FULL = NW * OW * KG == KV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1250,7 +1251,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
         if (u < S * 32 * a.Cs8) {
             const int srow = (int)(((unsigned int)u * a.invs) >> 16), c8 = u - srow * a.Cs8, r32 = srow & 31;
             s_img[i] = (srow >> 5) * a.imgs + r32 * a.rss + (r32 >> 3) * a.dss + c8 * 16;
-            s_off[i] = (unsigned int)(srow * a.srowb + c8 * (GX ? 32 : 16));
+            s_off[i] = (unsigned int)(srow * a.srowb + c8 * (SE == 2 ? 32 : 16));
         }
     }
     // gather lanes: row / unit of this lane's q-th gathered unit; byte offset of its kernel-map entry (offset k0, sub-chunk 0)
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
         for (int i = 0; i < SU; i++)
             if (s_img[i] >= 0) {
                 uint4 v;
-                if constexpr (GX) v = wg3_cvt8(sv[i][0], sv[i][SE - 1]);
+                if constexpr (SE == 2) v = wg3_cvt8(sv[i][0], sv[i][SE - 1]);
                 else v = make_uint4(sv[i][0].x, sv[i][0].y, sv[i][0].z, sv[i][0].w);
                 *(uint4 *)(smem + st_off + s_img[i]) = v;
             }
@@ -1305,7 +1306,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
                     for (int q = 0; q < MT; q++) {
                         const int idx = *(const int *)(smem + tb_off + ((s * 32 + g_row[q]) * KV + k) * 4);
-                        const unsigned int off = (unsigned int)idx * (unsigned int)a.growb + g_c8[q] * (GX ? 16 : 32);
+                        const unsigned int off = (unsigned int)idx * (unsigned int)a.growb + g_c8[q] * (GE == 2 ? 32 : 16);
 #pragma unroll
                         for (int h = 0; h < GE; h++) gv[j][s][q][h] = __builtin_amdgcn_raw_buffer_load_b128(rg, off + 16u * h, 0, 0);
                     }
@@ -1321,7 +1322,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
                     for (int q = 0; q < MT; q++) {
                         uint4 v;
-                        if constexpr (GX) v = make_uint4(gv[j][s][q][0].x, gv[j][s][q][0].y, gv[j][s][q][0].z, gv[j][s][q][0].w);
+                        if constexpr (GE == 1) v = make_uint4(gv[j][s][q][0].x, gv[j][s][q][0].y, gv[j][s][q][0].z, gv[j][s][q][0].w);
                         else v = wg3_cvt8(gv[j][s][q][0], gv[j][s][q][GE - 1]);
                         *(uint4 *)(smem + gs_off + g_row[q] * RSBG + (g_row[q] >> 3) * DG + g_c8[q] * 16) = v;
                     }
@@ -1420,7 +1421,7 @@ static int wg3_splits(const Wg3Cfg &c, int Ms, int Mg, int K, int Cg, int Cs, in
 }
 static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gx, bool gbf, bool sbf) {
     if (!wg3_enabled() || Ms < 2048 || (Cg & 15) || (Cs & 7)) return nullptr;
-    if (gx ? (!gbf || sbf) : (gbf || !sbf)) return nullptr;          // x bf16 and dy fp32 only
+    if (gx ? !gbf : !sbf) return nullptr;                            // x bf16 only (dy fp32 or bf16)
     // 32-bit buffer offsets: operand extents with up to 2x row pitch (views of concatenated buffers)
     if ((long long)Mg * Cg * 2 * (gbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * Cs * 2 * (sbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * K * 4 >= (1ll << 31)) return nullptr;
     const int mt = Cg / 16, nt = (Cs + 15) / 16;
@@ -1517,12 +1518,15 @@ extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Co
 }
 
 template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX>
-static int launch_wg3(const Wg3Args &a, const Wg2Plan &p, hipStream_t s) {
+static int launch_wg3(const Wg3Args &a, const Wg2Plan &p, bool dybf, hipStream_t s) {
     static_assert(NW * OW * KG >= KV, "offsets not covered");
     static bool attr_done_dev[64] = {false};
-    if (c2_attr_needed(attr_done_dev))
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
+    if (c2_attr_needed(attr_done_dev)) {
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    }
+    if (dybf) spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, true><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
+    else spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, false><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -1588,7 +1592,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         b.Ms = Ms; b.Cs8 = Cs / 8; b.cpw = p.cpw; b.flipk = a.flipk; b.Cin = CinW; b.Cout = Cout; b.K = K;
         b.invs = a.invs; b.rss = p.rss; b.dss = p.dss; b.imgs = p.imgs;
 #define WG3_CASE(MT, NT, KV, GXV, NW, OW, KG, SV)                                                                \
-        if (c.mt == MT && c.nt == NT && c.k == KV && c.gx == GXV && c.kg == KG && c.ow == OW && c.s == SV) rc = launch_wg3<MT, NT, KV, NW, OW, KG, SV, (GXV != 0)>(b, p, s);
+        if (c.mt == MT && c.nt == NT && c.k == KV && c.gx == GXV && c.kg == KG && c.ow == OW && c.s == SV) rc = launch_wg3<MT, NT, KV, NW, OW, KG, SV, (GXV != 0)>(b, p, dybf != 0, s);
         WG3_CONFIGS(WG3_CASE)
 #undef WG3_CASE
         if (rc == 0 && !noreduce) {

@@ -207,6 +207,7 @@ __global__ void un_bn_bwd_final_kernel(const float *part, int nparts, int C, flo
 }
 // dx = gamma*inv*(g - mean(g) - xhat*mean(g*xhat)) (+ dx when accum: the second contribution to a residual /
 // concatenated gradient is added here instead of in a separate pass)
+template <bool OBF>
 __global__ void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ dy, int ldy,
                                        const float *__restrict__ mean, const float *__restrict__ var,
                                        const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -222,7 +223,7 @@ __global__ void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, con
     const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
     float4 *op = (float4 *)(dx + row * ldo + c);
     float old[4] = {0.f, 0.f, 0.f, 0.f};
-    if (accum) { const float4 ov = *op; old[0] = ov.x; old[1] = ov.y; old[2] = ov.z; old[3] = ov.w; }
+    if (!OBF && accum) { const float4 ov = *op; old[0] = ov.x; old[1] = ov.y; old[2] = ov.z; old[3] = ov.w; }
     const float invM = 1.f / (float)M;
     float o[4];
 #pragma unroll
@@ -234,7 +235,8 @@ __global__ void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, con
         const float mg = sums[c + j] * invM, mgx = sums[C + c + j] * invM;
         o[j] = old[j] + ga * inv * (g - mg - xh * mgx);
     }
-    *op = make_float4(o[0], o[1], o[2], o[3]);
+    if (OBF) *(uint2 *)((unsigned short *)dx + row * ldo + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // bf16 gradient buffer
+    else *op = make_float4(o[0], o[1], o[2], o[3]);
 }
 __global__ void un_add_kernel(float *__restrict__ dst, int ldd, const float *__restrict__ src, int lds, long long M, int C, int copy) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,6 +309,7 @@ struct Net {
     int nlevels = 0, nparams = 0, input_needs_grad = 0, out_tensor = -1;
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
+    std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
     bool planned = false, lastblock = false;
     size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
@@ -470,6 +473,40 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             if (b.type == OP_BNACT && b.out == o.in && b.fused_by < 0 && n->T[b.out].dtype == 1) { o.bn_of_in = (int)j; b.fused_by = (int)i; break; }
         }
     }
+    // Gradients with a single writer and a single reader pair are stored as bf16: the output gradient of a convolution whose
+    // output feeds exactly one BatchNorm (the first conv of every residual block) is written once by that BatchNorm's backward
+    // apply and read only by the convolution's own data- and weight-gradient kernels -- as MFMA operands, i.e. rounded to bf16
+    // on load anyway.  Rounding at the store instead is numerically identical and halves the bytes of the data gradient's
+    // 27-fold gather and of the weight gradient's dy operand.  D3_GRAD_BF16=0 keeps them in fp32 (A/B measurements).
+    n->gbf.assign(n->B.size(), 0);
+    {
+        const char *e = getenv("D3_GRAD_BF16");
+        const bool on = !(e && e[0] == '0');
+        for (size_t b = 0; on && b < n->B.size(); b++) {
+            if (n->galias[b] >= 0) continue;
+            if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
+            bool ok = true;
+            for (size_t x = 0; x < n->B.size(); x++)
+                if (n->galias[x] >= 0 && n->T[n->galias[x]].buf == (int)b) ok = false;      // a residual gradient aliases into it
+            int nprod = 0, ncons = 0;
+            for (auto &o : n->ops) {
+                if (o.type == OP_PADCAST && n->T[o.out].buf == (int)b) ok = false;
+                if (o.type == OP_STATS) continue;
+                if (o.type == OP_CONV && o.res >= 0 && n->T[o.res].buf == (int)b) ok = false;
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.out].buf == (int)b) {
+                    const TensorD &t = n->T[o.out];
+                    nprod++;
+                    if (o.type != OP_CONV || o.res >= 0 || t.coff != 0 || t.C != n->B[b].width || (t.C & 7)) ok = false;
+                }
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.in].buf == (int)b) {
+                    const TensorD &t = n->T[o.in];
+                    ncons++;
+                    if (o.type != OP_BNACT || o.in_grad_mode != 1 || t.coff != 0 || t.C != n->B[b].width) ok = false;
+                }
+            }
+            if (ok && nprod == 1 && ncons == 1) n->gbf[b] = 1;
+        }
+    }
     hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
     return n;
 }
@@ -505,7 +542,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     size_t off = 0, goff = 0;
     for (auto &b : n->B) {
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
-        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * 4);
+        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[&b - &n->B[0]] ? 2 : 4));
     }
     size_t bnscr = 0, wgws = 16;
     for (auto &o : n->ops) {
@@ -518,7 +555,8 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
                 o.partw = (o.Cout + 15) / 16 * 16;
                 o.part_off = off; off += d3_align((size_t)o.nparts * 2 * o.partw * 4);
             }
-            const int xstat = ((o.Cin > o.Cout) ? D3_CONV_XSTAT : 0) | (n->T[o.in].dtype == 1 ? D3_CONV_XBF16 : 0);   // as in d3_net_backward
+            const int xstat = ((o.Cin > o.Cout) ? D3_CONV_XSTAT : 0) | (n->T[o.in].dtype == 1 ? D3_CONV_XBF16 : 0) |
+                              (n->T[o.out].buf >= 0 && n->gbf[n->T[o.out].buf] ? D3_CONV_DYBF16 : 0);   // as in d3_net_backward
             o.wsplits = d3_spconv_wgrad2_splits(Min, Mout, o.K, o.Cin, o.Cout, xstat);
             o.wpart_bytes = d3_align((size_t)o.wsplits * o.K * o.Cin * o.Cout * 4 + 256);
         } else if (o.type == OP_STATS) {
@@ -697,8 +735,9 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
 }
 
 // gradient view of a tensor: (pointer, row stride); residual aliases are followed to their root
-static float *gptr(const Net *n, char *garena, const float *gout, float *gin, int tensor, int &ld, int &root) {
+static float *gptr(const Net *n, char *garena, const float *gout, float *gin, int tensor, int &ld, int &root, int *bf16 = nullptr) {
     const TensorD *t = &n->T[tensor];
+    if (bf16) *bf16 = 0;
     int coff = t->coff;
     for (int guard = 0; guard < 1000; guard++) {
         if (t->buf < 0) { ld = t->ld; root = -1; return gin; }
@@ -710,6 +749,10 @@ static float *gptr(const Net *n, char *garena, const float *gout, float *gin, in
     }
     ld = n->B[t->buf].width;
     root = t->buf;
+    if (n->gbf[t->buf]) {          // (whole-buffer views only: coff == 0)
+        if (bf16) *bf16 = 1;
+        return (float *)(garena + n->B[t->buf].goff);
+    }
     return (float *)(garena + n->B[t->buf].goff) + coff;
 }
 
@@ -750,7 +793,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             const TensorD &ti = n->T[o.in];
             int Min, Mout; conv_dims(n, o, Min, Mout);
             const int *tf, *tb; int flip; conv_tables(o, maps, tf, tb, flip);
-            int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
+            int ldgo, root_o, gobf; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o, &gobf);
             // weight gradient on the side stream
             if (pgrads[o.w] != nullptr) {
                 if (use_side) {
@@ -761,7 +804,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     side_used = true;
                 }
                 const bool xstat = o.Cin > o.Cout;
-                int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0);
+                int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_DYBF16 : 0);
                 const int *tw = tf;
                 if (xstat) { flags |= D3_CONV_XSTAT | (flip ? D3_CONV_FLIPK : 0); tw = tb; }
                 float *dW = pgrads[o.w];
@@ -797,15 +840,15 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     if (!n->lastblock)
                         rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, 0, stream);
+                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, gobf ? D3_CONV_XBF16 : 0, stream);
                     else
                     rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
                                                   (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
-                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, 0, stream);
+                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, gobf ? D3_CONV_XBF16 : 0, stream);
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
-                                        (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0), stream);
+                                        (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0), stream);
                 }
                 if (rc) return rc;
             }
@@ -836,11 +879,15 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>(bnscr, nb, C, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
             }
             if (o.in_grad_mode) {
-                int ldgi, root_i; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i);
+                int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
                 if (root_i >= 0) wait_pending(root_i);
                 const long long total = (long long)M * (C / 4);
-                un_bn_bwd_apply_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
-                                                                               o.eps, relu, o.in_grad_mode == 2 ? 1 : 0);
+                if (gibf)
+                    un_bn_bwd_apply_kernel<true><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
+                                                                                         o.eps, relu, 0);
+                else
+                    un_bn_bwd_apply_kernel<false><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
+                                                                                          o.eps, relu, o.in_grad_mode == 2 ? 1 : 0);
             }
         }
     }

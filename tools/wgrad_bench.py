@@ -64,11 +64,16 @@ def main():
                 w = lambda: ME._conv_wgrad(xb, tf, tb, dy, W, Mout, bfl, ME.D3_CONV_XBF16)
                 tms[mode] = timeit(w, iters)
                 res[mode] = w()
+            os.environ.update(MODES[0][1])
+            dyb = dy.to(torch.bfloat16)
+            wb = lambda: ME._conv_wgrad(xb, tf, tb, dyb, W, Mout, bfl, ME.D3_CONV_XBF16 | ME.D3_CONV_DYBF16)
+            t_b = timeit(wb, iters)
+            rel_b = float((wb() - res["gen3"]).abs().max() / (res["gen3"].abs().max() + 1e-20))
             alg = 2.0 * Min * Cin + 4.0 * Mout * Cout + 4.0 * K * Cin * Cout + 4.0 * (Min if Cin > Cout else Mout) * K
             ref = res["gen2"]
             rel = [float((res[m] - ref).abs().max() / (ref.abs().max() + 1e-20)) for m in ("gen3", "gen2+tr")]
-            print("%-22s %8d %8.1f | %s | %8.0f   %.1e %.1e" % (name, Mout, alg / 1e6, " ".join("%9.1f" % tms[m] for m, _ in MODES),
-                                                                 alg / tms["gen3"] / 1e3, rel[0], rel[1]))
+            print("%-22s %8d %8.1f | %s | %8.0f   %.1e %.1e | dy bf16: %7.1f us (vs gen3 %.1e)" %
+                  (name, Mout, alg / 1e6, " ".join("%9.1f" % tms[m] for m, _ in MODES), alg / tms["gen3"] / 1e3, rel[0], rel[1], t_b, rel_b))
         ts *= 2
 
 
