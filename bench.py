@@ -248,10 +248,21 @@ def main():
     PROF_STRIDE = 13   # every 13th convolution launch is bracketed by HIP events (coprime with the launches per step)
     L.d3_prof_enable(PROF_STRIDE)
     torch.cuda.synchronize()
+    host_prof = None
+    if os.environ.get("D3_BENCH_CPROFILE"):   # (diagnostics: host-side cProfile of the timed steps; the value is then not a clean number)
+        import cProfile
+        host_prof = cProfile.Profile()
+        host_prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, d = step()
     torch.cuda.synchronize()
+    if host_prof is not None:
+        import pstats
+        host_prof.disable()
+        with open(os.environ["D3_BENCH_CPROFILE"], "w") as f:
+            pstats.Stats(host_prof, stream=f).sort_stats("cumulative").print_stats(60)
+            pstats.Stats(host_prof, stream=f).sort_stats("tottime").print_stats(40)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -103,6 +103,8 @@ SIGNATURES = {
     "d3_nms3d_samecls": (i32, [vp, vp, vp, i32, i32, f64, i32, vp, vp]),
     "d3_instance_cross_iou": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
     "d3_nms_matrix": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, vp]),
+    "d3_cider_ws_bytes": (sz, [i32, i32, i32]),
+    "d3_cider_scores": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, f64, i32, vp, vp, vp, sz, vp]),
     "d3_graph_edges": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_edgeconv_ws_bytes": (sz, [i32, i32, i32]),
     "d3_edgeconv_bwd_ws_bytes": (sz, [i32, i32, i32]),

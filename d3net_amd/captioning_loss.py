@@ -7,29 +7,149 @@ import torch.nn.functional as F
 from .cider import cider_scores
 
 
-def compute_caption_reward(data_dict, cap_tables, sample_topn, idx2word, dataset_data, organized_data):
+class CiderCorpus:
+    """The annotation store (`organized[scene_id][object_id]` -> tokenised descriptions) as device tensors for
+    csrc/cider.hip: one row of token ids per reference sentence (+ "eos", as the reference joins them, loss_helper.py:60),
+    a vocabulary id where the word is in the vocabulary, a corpus-private id >= V otherwise (string equality == id
+    equality).  Built once per dataset."""
+    MAX_TOKENS, MAX_SET_NGRAMS, MAX_ID = 160, 2048, 65534
+
+    def __init__(self, organized, idx2word, device):
+        canon = {}
+        for i, w in idx2word.items():
+            canon[w] = min(int(i), canon.get(w, int(i)))
+        V = max(int(i) for i in idx2word) + 1
+        extra, rows, self.sets = {}, [], {}
+        for sid, objs in organized.items():
+            for oid, descs in objs.items():
+                first = len(rows)
+                for d in descs:
+                    rows.append([canon[w] if w in canon else extra.setdefault(w, V + len(extra)) for w in list(d["token"]) + ["eos"]])
+                self.sets[(sid, oid)] = (first, len(descs))
+        self.row_len = [len(r) for r in rows]
+        self.ok = bool(rows) and max(self.row_len) <= self.MAX_TOKENS and V + len(extra) <= self.MAX_ID and "eos" in canon
+        if not self.ok:
+            return
+        ldt = max(self.row_len)
+        tok = np.zeros((len(rows), ldt), np.int32)
+        for i, r in enumerate(rows):
+            tok[i, :len(r)] = r
+        self.tokens = torch.from_numpy(tok).to(device)
+        self.lens = torch.tensor(self.row_len, dtype=torch.int32, device=device)
+        self.ldt, self.eos, self.device = ldt, canon["eos"], device
+        lut = np.arange(V, dtype=np.int64)
+        for i, w in idx2word.items():
+            lut[int(i)] = canon[w]
+        self.lut = torch.from_numpy(lut).to(device) if (lut != np.arange(V)).any() else None   # two ids spelling one word
+        self._pinned, self._slot = [None] * 4, 0
+
+    def staging(self, n):
+        """pinned int32 staging buffer (ring of 4: an earlier asynchronous upload may still be in flight)"""
+        self._slot = (self._slot + 1) % 4
+        b = self._pinned[self._slot]
+        if b is None or b.numel() < n:
+            b = self._pinned[self._slot] = torch.empty(max(n, 4096), dtype=torch.int32).pin_memory()
+        return b
+
+
+_CORPORA = {}
+
+
+def _cider_device(corpus, entry_sets, cands, sample_topn):
+    """entry_sets: per valid description its (first row, #rows) in the corpus; cands: E = len(entry_sets) * sample_topn device
+    token tensors -> (E,) float64 device scores, or None when the batch does not fit the kernels' fixed tables."""
+    from . import _lib
+    from ._lib import check
+    E = len(cands)
+    uniq, u_of = {}, []
+    for fs in entry_sets:
+        u_of.append(uniq.setdefault(fs, len(uniq)))
+    U = len(uniq)
+    slot_row, u_off, mult = [], [0], [0] * U
+    for (first, cnt), u in uniq.items():
+        if cnt < 1 or 4 * sum(corpus.row_len[first:first + cnt]) > corpus.MAX_SET_NGRAMS:
+            return None
+        slot_row.extend(range(first, first + cnt)); u_off.append(len(slot_row))
+    for u in u_of:
+        mult[u] += sample_topn
+    ent_u = [u for u in u_of for _ in range(sample_topn)]
+    clen = [int(c.shape[0]) for c in cands]
+    if max(clen) + 1 > corpus.MAX_TOKENS:
+        return None
+    ldc = max(max(clen), 1)
+    pos = np.concatenate([e * ldc + np.arange(l) for e, l in enumerate(clen)]) if sum(clen) else np.zeros(0, np.int64)
+    SR = len(slot_row)
+    ngrams = 4 * sum(corpus.row_len[r] for r in slot_row)
+    hash_slots = 1024
+    while hash_slots < 4 * ngrams:
+        hash_slots *= 2
+    meta = np.concatenate([np.asarray(a, np.int32) for a in (slot_row, u_off, mult, ent_u, clen, pos)])
+    stage = corpus.staging(meta.size)
+    stage[:meta.size].copy_(torch.from_numpy(meta))
+    dev = corpus.device
+    md = stage[:meta.size].to(dev, non_blocking=True)
+    o = np.cumsum([0, SR, U + 1, U, E, E, pos.size])
+    d_slot, d_uoff, d_mult, d_ent, d_clen, d_pos = (md[o[i]:o[i + 1]] for i in range(6))
+    cand = torch.zeros((E, ldc), dtype=torch.int32, device=dev)
+    if pos.size:
+        flat = torch.cat([c.reshape(-1) for c in cands])
+        if corpus.lut is not None:
+            flat = corpus.lut[flat.long()]
+        cand.view(-1)[d_pos.long()] = flat.to(torch.int32)
+    L = _lib.lib()
+    ws = torch.empty(L.d3_cider_ws_bytes(SR, E, hash_slots), dtype=torch.uint8, device=dev)
+    out = torch.empty(E, dtype=torch.float64, device=dev)
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(L.d3_cider_scores(corpus.tokens.data_ptr(), corpus.ldt, corpus.lens.data_ptr(), d_slot.data_ptr(), d_uoff.data_ptr(),
+                                d_mult.data_ptr(), d_ent.data_ptr(), U, SR, cand.data_ptr(), ldc, d_clen.data_ptr(), E, corpus.eos, 6.0,
+                                hash_slots, out.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(),
+                                torch.cuda.current_stream().cuda_stream), "cider_scores")
+    return out
+
+
+def compute_caption_reward(data_dict, cap_tables, sample_topn, idx2word, dataset_data, organized_data, device_cider=True):
     """(loss_helper.py:15-96) CIDEr of every sampled caption against ALL ground-truth descriptions of its object, one
     scorer call for the whole batch (so the idf statistics are those of the batch).  Unannotated entries score 0.
     The reference also runs BLEU-4 here and multiplies it by a hard-coded weight of 0 (:83-88): not computed.
-    Token ids leave the device in one transfer per call rather than one `.item()` per token."""
+    On a GPU the n-gram statistics and the scores are computed on the device (csrc/cider.hip) from the token tensors as they
+    are: no token leaves the device; the host only looks up which reference set each description belongs to (cached in
+    `data_dict` for the second call of the step).  `device_cider=False`, CPU tensors or a batch beyond the kernels' fixed
+    tables use the host scorer (d3net_amd/cider.py), which is pinned bit-exact to the reference's."""
     assert len(cap_tables[0]) == sample_topn
-    chunk_ids, annotated = data_dict["chunk_ids"], data_dict["annotated"].reshape(-1)
-    Cn = chunk_ids.shape[1]
-    dataset_ids = data_dict["id"].unsqueeze(1).repeat(1, Cn).reshape(-1).tolist()
-    chunk_ids = chunk_ids.reshape(-1).tolist()
-    N = len(dataset_ids)
+    annotated = data_dict["annotated"].reshape(-1)
+    N = annotated.shape[0]
     scores = torch.zeros(N, sample_topn, device=annotated.device)
-    valid = (annotated == 1).nonzero().view(-1)
-    if valid.shape[0] == 0:
+    ent = data_dict.get("_reward_entries")
+    if ent is None or ent[0] is not data_dict["annotated"] or ent[1] is not data_dict["chunk_ids"]:   # host-side ids of the batch: one transfer per step
+        chunk_ids = data_dict["chunk_ids"]
+        Cn = chunk_ids.shape[1]
+        dataset_ids = data_dict["id"].unsqueeze(1).repeat(1, Cn).reshape(-1).tolist()
+        chunk_l = chunk_ids.reshape(-1).tolist()
+        valid = (annotated == 1).nonzero().view(-1)
+        keys = []
+        for n in valid.tolist():
+            raw = dataset_data[dataset_ids[n]][chunk_l[n]]
+            keys.append((raw["scene_id"], raw["object_id"]))
+        ent = data_dict["_reward_entries"] = (data_dict["annotated"], data_dict["chunk_ids"], valid, valid.tolist(), keys)
+    valid, valid_l, keys = ent[2:]
+    if not valid_l:
         return scores
-    valid_l = valid.tolist()
+    if device_cider and annotated.is_cuda:
+        corpus = _CORPORA.get(id(organized_data))
+        if corpus is None:
+            corpus = _CORPORA[id(organized_data)] = CiderCorpus(organized_data, idx2word, annotated.device)
+        if corpus.ok:
+            out = _cider_device(corpus, [corpus.sets[k] for k in keys], [cap_tables[n][k] for n in valid_l for k in range(sample_topn)],
+                                sample_topn)
+            if out is not None:
+                scores[valid] = out.to(scores.dtype).view(len(valid_l), sample_topn)
+                return scores
     lens = [len(cap_tables[n][k]) for n in valid_l for k in range(sample_topn)]
     flat = torch.cat([cap_tables[n][k].reshape(-1) for n in valid_l for k in range(sample_topn)]).tolist() if sum(lens) else []
     refs, cands, pos = [], [], 0
     ref_cache = {}
-    for n in valid_l:
-        raw = dataset_data[dataset_ids[n]][chunk_ids[n]]
-        key = (raw["scene_id"], raw["object_id"])
+    for n, key in zip(valid_l, keys):
         gt = ref_cache.get(key)
         if gt is None:
             gt = ref_cache[key] = [" ".join(d["token"] + ["eos"]) for d in organized_data[key[0]][key[1]]]

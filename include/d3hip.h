@@ -470,6 +470,20 @@ int d3_instance_cross_iou(const int *cluster_idxs, const int *offsets, long long
 int d3_nms_matrix(const float *ious, const float *scores, const unsigned char *keep, int n, float thr, int *order_scratch, int *picked,
                   int *npicked, void *stream);
 
+/* ---- CIDEr-D reward of the self-critical speaker update (csrc/cider.hip) -----------------------------
+ * Replaces lib/capeval/cider/cider_scorer.py:11-193 (precook / compute_doc_freq / counts2vec / sim) as called per RL step by
+ * lib/captioning/loss_helper.py:15-96 (host python over word tuples, twice per step).  Sentences are int32 token ids (< 65535;
+ * reference words outside the vocabulary get corpus-private ids): tokens (R, ldt) / lens (R) = the reference corpus.  One call
+ * scores E entries: entry e = candidate cand[e, :clen[e]] ("eos" appended when absent, like the reference) against the reference
+ * set ent_u[e] in [0, U); set u = corpus rows slot_row[u_off[u] .. u_off[u+1]) (SR rows in total), used by mult[u] entries (the
+ * document frequency counts a set once per entry).  hash_slots: power of two >= 2 x the distinct n-grams of the used sets.
+ * scores (E) float64 == Cider().compute_score per-entry scores (x10, sigma 6).  *overflow_dev != 0: a hash table overflowed or
+ * nothing was written -- the caller falls back to its host scorer.  Sentences are cut at 160 tokens. */
+size_t d3_cider_ws_bytes(int SR, int E, int hash_slots);
+int d3_cider_scores(const int *tokens, int ldt, const int *lens, const int *slot_row, const int *u_off, const int *mult,
+                    const int *ent_u, int U, int SR, const int *cand, int ldc, const int *clen, int E, int eos, double sigma,
+                    int hash_slots, double *scores, int *overflow_dev, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- proposal geometry (speaker / graph heads) ------------------------------------------ */
 /* Distance matrix of `_query_locals` (model/graph_module.py:184-227 == model/caption_module.py:800-842) for all
  * target proposals at once: corners (B,K,8,3), masks (B,K) -> dist (B,K,K), dist[b,t,j] as the reference's pc_dist

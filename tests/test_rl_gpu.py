@@ -120,3 +120,67 @@ def test_pipeline_mode3_runs_and_trains(dev):
         assert k in net.logged
     opt, _ = net.configure_optimizers()
     opt[0].step()
+
+
+def test_device_cider_reward_matches_reference_golden_and_host_scorer(dev):
+    """csrc/cider.hip against (a) the reward golden vectors produced by the reference's own `compute_caption_reward`
+    (lib/captioning/loss_helper.py:15-96) and (b) the host scorer (pinned bit-exact to the reference's CiderScorer) on a random
+    corpus with repeated words (tf > 1, clipping), candidates with and without "eos", empty candidates, reference words outside
+    the vocabulary, duplicated reference sets and topn > 1.  float64 scores: 1e-12 relative (device log / pow)."""
+    from test_oracle_rl import setup, unpad
+    from d3net_amd import captioning_loss as CL, cider as pcider
+    R, S, g, cfg, vocab, p, lp, d, opt = setup()
+    caps = unpad(g["rl/lang_cap"].astype(np.int64), g["rl/lang_cap_len"])
+    base = unpad(g["rl/baseline_cap"].astype(np.int64), g["rl/baseline_len"])
+    args = (R.TOPN, vocab["idx2word"], opt["train_dataset_data"], opt["organized_data"])
+    dd = {k: v.to(dev) for k, v in d.items()}
+    on = lambda t: [[c.to(dev) for c in row] for row in t]
+    CL._CORPORA.clear()
+    got_s = CL.compute_caption_reward(dict(dd), on(caps), *args)
+    got_b = CL.compute_caption_reward(dict(dd), on(base), *args)
+    assert id(opt["organized_data"]) in CL._CORPORA and CL._CORPORA[id(opt["organized_data"])].ok, "device path not taken"
+    assert np.allclose(got_s.cpu().numpy(), g["reward/sampled"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(got_b.cpu().numpy(), g["reward/baseline"], rtol=1e-6, atol=1e-7)
+
+    # random corpus, float64 scores against the host scorer
+    rng = np.random.default_rng(1)
+    V = 40
+    idx2word = {str(i): "w%d" % i for i in range(V)}
+    idx2word[str(V - 1)] = "eos"
+    organized = {}
+    for s in range(3):
+        organized["s%d" % s] = {}
+        for o in range(4):
+            descs = []
+            for _ in range(int(rng.integers(1, 6))):
+                toks = ["w%d" % int(t) for t in rng.integers(0, 12, int(rng.integers(1, 30)))]      # small alphabet: repeated n-grams
+                if rng.random() < 0.3:
+                    toks[int(rng.integers(0, len(toks)))] = "oov%d" % int(rng.integers(0, 3))         # not in the vocabulary
+                descs.append({"token": toks})
+            organized["s%d" % s][str(o)] = descs
+    corpus = CL.CiderCorpus(organized, idx2word, dev)
+    assert corpus.ok
+    topn = 2
+    keys = [("s%d" % int(rng.integers(0, 3)), str(int(rng.integers(0, 4)))) for _ in range(9)]
+    keys += keys[:2]                                                                                   # duplicated sets
+    cands = []
+    for _ in range(len(keys) * topn):
+        l = int(rng.integers(0, 14))
+        t = rng.integers(0, 12, l)
+        if l and rng.random() < 0.5:
+            t[-1] = V - 1                                                                                # ends in eos
+        cands.append(torch.from_numpy(t.astype(np.int64)).to(dev))
+    out = CL._cider_device(corpus, [corpus.sets[k] for k in keys], cands, topn)
+    assert out is not None
+    refs, cs = [], []
+    for i, k in enumerate(keys):
+        gt = [" ".join(dd_["token"] + ["eos"]) for dd_ in organized[k[0]][k[1]]]
+        for j in range(topn):
+            toks = [idx2word[str(int(t))] for t in cands[i * topn + j].tolist()]
+            if "eos" not in toks:
+                toks.append("eos")
+            refs.append(gt); cs.append(" ".join(toks))
+    _, want = pcider.cider_scores(refs, cs)
+    got = out.cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-13), np.abs(got - want).max()
+    assert want.max() > 0.1                                                                            # a non-trivial case
