@@ -161,11 +161,17 @@ __device__ __forceinline__ int cl_chase(const int *lab, int l) {
 __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                      const int *__restrict__ start_len, int n,
                                                      const int *__restrict__ root, int *lab, int *pushed,
-                                                     int *changed_flag, const int *__restrict__ capped_flag, int ascending) {
+                                                     int *changed_flag, const int *__restrict__ capped_flag, int ascending, int minima_only) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
     if (*capped_flag == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    // Opening sweep (ascending lists only): just the nodes without a smaller-index neighbour push -- the future seeds.  In a
+    // collapsed instance (every list = its first 1000 members) that is ONE node, whose push settles all 1000 labels without
+    // contention; the full sweep behind it then finds them settled through its cached filter read.  Without it every member
+    // pushed its own index at all later members at once: 500 k contended atomicMin per instance, most of the sweep's time
+    // (profiles/r02_q_cluster_timeline.txt: 2.1 ms).  Any sweep order reaches the same fixpoint.
+    if (minima_only && (ln == 0 || idx[st] < i)) return;
     const int si = sem[i];
     const int ri = root[i];
     const int li = cl_chase(lab, ld_dev(&lab[ri]));
@@ -288,8 +294,10 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     for (int it = 0;; it += 2) {
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3, asc);
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars + 4, w.scalars + 3, asc);
+        if (it == 0 && asc)
+            cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3, asc, 1);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3, asc, 0);
+        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars + 4, w.scalars + 3, asc, 0);
         if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
         cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
         cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);

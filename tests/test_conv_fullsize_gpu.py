@@ -241,3 +241,17 @@ def test_wgrad2_row_splits_and_reduction(dev, canon, level, kind, cin, cout, xbf
                             cin, flags | ACCUM | (XBF16 if xbf else 0), _ptr(ws), ws.numel(), _stream())
     assert rc == 0
     assert relerr(dW, 2 * ref) < 1e-4
+    if xbf:
+        # bf16 dy (the executor's single-consumer gradient buffers): rounding at the store instead of at the load -- the
+        # very same MFMA operands, hence the very same result as with the fp32 dy
+        fl = flags | XBF16 | DYBF16
+        assert L.d3_spconv_wgrad2_splits(Min, Mout, K, cin, cout, fl) >= 1
+        wsb = torch.empty(max(L.d3_spconv_wgrad2_ws_bytes(Min, Mout, K, cin, cout, fl), 16), dtype=torch.uint8, device=dev)
+        dW1 = torch.full((K, cin, cout), float("nan"), device=dev)
+        dW2 = torch.full((K, cin, cout), float("nan"), device=dev)
+        dyb = dyd.bfloat16()
+        assert L.d3_spconv_wgrad2(_ptr(xd), cin, _ptr(tbl) if tbl is not None else None, _ptr(dyd), cout, _ptr(dW1), Min, Mout, K, cin, cout,
+                                  cin, flags | XBF16, _ptr(ws), ws.numel(), _stream()) == 0
+        assert L.d3_spconv_wgrad2(_ptr(xd), cin, _ptr(tbl) if tbl is not None else None, _ptr(dyb), cout, _ptr(dW2), Min, Mout, K, cin, cout,
+                                  cin, fl, _ptr(wsb), wsb.numel(), _stream()) == 0
+        assert torch.equal(dW1, dW2)
