@@ -212,7 +212,7 @@ __global__ void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, con
                                        const float *__restrict__ mean, const float *__restrict__ var,
                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                        const float *__restrict__ sums, float *__restrict__ dx, int ldo, long long M,
-                                       int C, float eps, int relu, int accum) {
+                                       int C, float eps, int relu, int accum, unsigned short *__restrict__ shadow) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels per thread
     const int c4 = C >> 2;
     if (e >= M * c4) return;
@@ -237,6 +237,7 @@ __global__ void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, con
     }
     if (OBF) *(uint2 *)((unsigned short *)dx + row * ldo + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // bf16 gradient buffer
     else *op = make_float4(o[0], o[1], o[2], o[3]);
+    if (!OBF && shadow) *(uint2 *)(shadow + row * C + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // dense (M, C) bf16 copy
 }
 __global__ void un_add_kernel(float *__restrict__ dst, int ldd, const float *__restrict__ src, int lds, long long M, int C, int copy) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,6 +302,8 @@ struct OpD {
     int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
     size_t cnt_off, bcnt_off;         // ticket counters (arena / gradient arena)
     size_t wpart_off, wpart_bytes; int wsplits;   // CONV: weight-gradient partials in the gradient arena
+    int use_shadow;                   // CONV: reads its output gradient from the bf16 shadow of that (fp32) gradient buffer
+    int write_shadow;                 // BNACT: its backward apply also writes the bf16 shadow of the buffer it finalises
 };
 struct Net {
     std::vector<TensorD> T;
@@ -310,6 +313,8 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
+    std::vector<int> gshadow;         // per buffer: a bf16 shadow of its fp32 gradient exists (residual streams)
+    std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
     bool planned = false, lastblock = false;
     size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
@@ -372,7 +377,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -507,6 +512,47 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             if (ok && nprod == 1 && ncons == 1) n->gbf[b] = 1;
         }
     }
+    // Residual-stream gradients stay fp32 (they are accumulated in place and feed fp32 consumers), but the convolution that
+    // reads one as ITS output gradient uses it as a bf16 MFMA operand, gathered 27 times per row.  Where the last kernel to
+    // touch the buffer before that read is a BatchNorm backward apply over the whole buffer (the first BatchNorm of the next
+    // residual block adding its contribution), that kernel also writes the finished values as bf16 into a shadow buffer and
+    // the convolution's data- and weight-gradient kernels read the shadow: identical operands, half the gathered bytes.
+    n->gshadow.assign(n->B.size(), 0);
+    n->gshadow_off.assign(n->B.size(), 0);
+    {
+        const char *e = getenv("D3_GRAD_BF16");
+        const bool on = !(e && e[0] == '0');
+        auto root_of = [&](int tensor, int &coff, int &C) {          // as gptr(): follow residual aliases
+            const TensorD *t = &n->T[tensor];
+            coff = t->coff; C = t->C;
+            for (int guard = 0; guard < 1000; guard++) {
+                if (t->buf < 0) return -1;
+                if (tensor == n->out_tensor) return -2;
+                if (n->galias[t->buf] < 0) return t->buf;
+                tensor = n->galias[t->buf];
+                t = &n->T[tensor];
+                coff = t->coff;
+            }
+            return -3;
+        };
+        std::map<int, int> last_bn;        // root buffer -> BNACT op whose apply was the last writer (whole buffer), or -1
+        for (int i = (int)n->ops.size() - 1; on && i >= 0; i--) {
+            OpD &o = n->ops[i];
+            int coff, C;
+            if (o.type == OP_CONV) {
+                const int ro = root_of(o.out, coff, C);
+                if (ro >= 0 && !n->gbf[ro] && coff == 0 && C == n->B[ro].width && !(C & 7)) {
+                    auto it = last_bn.find(ro);
+                    if (it != last_bn.end() && it->second >= 0) { o.use_shadow = 1; n->ops[it->second].write_shadow = 1; n->gshadow[ro] = 1; }
+                }
+                if (o.in_grad_mode) { const int ri = root_of(o.in, coff, C); if (ri >= 0) last_bn[ri] = -1; }
+                if (o.res >= 0 && o.res_mode >= 2) { const int rr = root_of(o.res, coff, C); if (rr >= 0) last_bn[rr] = -1; }
+            } else if (o.type == OP_BNACT && o.in_grad_mode) {
+                const int ri = root_of(o.in, coff, C);
+                if (ri >= 0) last_bn[ri] = (!n->gbf[ri] && coff == 0 && C == n->B[ri].width) ? i : -1;
+            }
+        }
+    }
     hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
     return n;
 }
@@ -542,7 +588,9 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     size_t off = 0, goff = 0;
     for (auto &b : n->B) {
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
-        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[&b - &n->B[0]] ? 2 : 4));
+        const size_t bi = &b - &n->B[0];
+        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[bi] ? 2 : 4));
+        if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * b.width * 2); }
     }
     size_t bnscr = 0, wgws = 16;
     for (auto &o : n->ops) {
@@ -556,7 +604,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
                 o.part_off = off; off += d3_align((size_t)o.nparts * 2 * o.partw * 4);
             }
             const int xstat = ((o.Cin > o.Cout) ? D3_CONV_XSTAT : 0) | (n->T[o.in].dtype == 1 ? D3_CONV_XBF16 : 0) |
-                              (n->T[o.out].buf >= 0 && n->gbf[n->T[o.out].buf] ? D3_CONV_DYBF16 : 0);   // as in d3_net_backward
+                              ((n->T[o.out].buf >= 0 && n->gbf[n->T[o.out].buf]) || o.use_shadow ? D3_CONV_DYBF16 : 0);   // as in d3_net_backward
             o.wsplits = d3_spconv_wgrad2_splits(Min, Mout, o.K, o.Cin, o.Cout, xstat);
             o.wpart_bytes = d3_align((size_t)o.wsplits * o.K * o.Cin * o.Cout * 4 + 256);
         } else if (o.type == OP_STATS) {
@@ -794,6 +842,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             int Min, Mout; conv_dims(n, o, Min, Mout);
             const int *tf, *tb; int flip; conv_tables(o, maps, tf, tb, flip);
             int ldgo, root_o, gobf; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o, &gobf);
+            float *go32 = go;                      // (the residual add below reads the fp32 buffer)
+            if (o.use_shadow && root_o >= 0 && n->gshadow[root_o]) { go = (float *)(garena + n->gshadow_off[root_o]); gobf = 1; }
             // weight gradient on the side stream
             if (pgrads[o.w] != nullptr) {
                 if (use_side) {
@@ -856,7 +906,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 int ldr, root_r; float *gr = gptr(n, garena, gout, gin, o.res, ldr, root_r);
                 if (root_r >= 0) wait_pending(root_r);
                 const long long total = (long long)Mout * (o.Cout / 4);
-                if (total > 0) un_add_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(gr, ldr, go, ldgo, Mout, o.Cout, o.res_mode == 3 ? 1 : 0);
+                if (total > 0) un_add_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(gr, ldr, go32, ldgo, Mout, o.Cout, o.res_mode == 3 ? 1 : 0);
             }
         } else if (o.type == OP_BNACT) {
             if (!o.in_grad_mode && pgrads[o.gamma] == nullptr) continue;
@@ -882,12 +932,13 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
                 if (root_i >= 0) wait_pending(root_i);
                 const long long total = (long long)M * (C / 4);
+                unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] && ldgi == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
                 if (gibf)
                     un_bn_bwd_apply_kernel<true><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
-                                                                                         o.eps, relu, 0);
+                                                                                         o.eps, relu, 0, nullptr);
                 else
                     un_bn_bwd_apply_kernel<false><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
-                                                                                          o.eps, relu, o.in_grad_mode == 2 ? 1 : 0);
+                                                                                          o.eps, relu, o.in_grad_mode == 2 ? 1 : 0, sh);
             }
         }
     }
