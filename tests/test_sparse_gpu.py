@@ -389,3 +389,61 @@ def test_coordinate_pyramid_one_round_trip_matches_per_level_build(dev):
         assert torch.equal(a.coords[2 * ts], b.coords[2 * ts])
         assert torch.equal(a.k3(2 * ts), b.k3(2 * ts))
         ts *= 2
+
+
+@pytest.mark.parametrize("kind,cin,cout,dybf", [("k3", 16, 16, False), ("k3", 32, 16, False), ("k3", 32, 32, True), ("k3", 64, 32, True),
+                                                ("k3", 48, 48, False), ("down", 16, 32, False), ("up", 32, 16, True)])
+def test_wgrad3_strided_operands_ragged_rows_and_absent_neighbours(dev, kind, cin, cout, dybf):
+    """spconv_wgrad3_kernel's raw buffer gathers: operands that are column views of wider buffers (row pitch > channels, as the
+    executor's concatenation buffers), a row count that is no multiple of the kernel's iteration, kernel maps with absent
+    neighbours (index -1 -> an out-of-range buffer offset the hardware answers with zeros) and trailing rows; against the
+    second-generation kernel (D3_WG3=0) on dense copies of the same operands, and the bf16-dy variant against the fp32 one."""
+    import os
+    from d3net_amd import _lib
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    L = _lib.lib()
+    FLIPK, XSTAT, XBF16, DYBF16 = 1, 8, 32, 64
+    rng = np.random.default_rng(cin * 100 + cout)
+    if kind == "k3":
+        K, Min, Mout = 27, 5003, 5003
+        tbl = rng.integers(0, Min, (Mout, K)).astype(np.int32)
+        tbl[rng.random((Mout, K)) < 0.4] = -1
+        tbl_t = rng.integers(0, Mout, (Min, K)).astype(np.int32)
+        tbl_t[rng.random((Min, K)) < 0.4] = -1
+    else:
+        K = 8
+        Min, Mout = (9001, 2501) if kind == "down" else (2501, 9001)
+        tbl = rng.integers(0, Min, (Mout, K)).astype(np.int32); tbl[rng.random((Mout, K)) < 0.5] = -1
+        tbl_t = rng.integers(0, Mout, (Min, K)).astype(np.int32); tbl_t[rng.random((Min, K)) < 0.5] = -1
+    xstat = cin > cout
+    flags = (XSTAT | (FLIPK if kind == "k3" else 0)) if xstat else 0
+    t = torch.from_numpy(tbl_t if xstat else tbl).to(dev)
+    # x: columns [8, 8+cin) of a (Min, cin + 24) bf16 buffer; dy: columns [8, 8+cout) of a (Mout, cout + 16) buffer
+    xw = torch.from_numpy(rng.standard_normal((Min, cin + 24)).astype(np.float32)).to(dev).bfloat16()
+    dyw = torch.from_numpy(rng.standard_normal((Mout, cout + 16)).astype(np.float32)).to(dev)
+    if dybf:
+        dyw = dyw.bfloat16()
+    xv, dyv = xw[:, 8:8 + cin], dyw[:, 8:8 + cout]
+    fl = flags | XBF16 | (DYBF16 if dybf else 0)
+
+    def run(x, ldx, dy, ldy, f):
+        ws = torch.empty(max(L.d3_spconv_wgrad2_ws_bytes(Min, Mout, K, cin, cout, f), 16), dtype=torch.uint8, device=dev)
+        dW = torch.full((K, cin, cout), float("nan"), device=dev)
+        rc = L.d3_spconv_wgrad2(x.data_ptr(), ldx, _ptr(t), dy.data_ptr(), ldy, _ptr(dW), Min, Mout, K, cin, cout, cin, f, _ptr(ws),
+                                ws.numel(), _stream())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return dW
+
+    assert xv.data_ptr() % 16 == 0 and dyv.data_ptr() % 8 == 0
+    got = run(xv, cin + 24, dyv, cout + 16, fl)                       # strided views, third-generation kernel
+    os.environ["D3_WG3"] = "0"
+    try:
+        ref = run(xv.contiguous(), cin, dyv.contiguous(), cout, fl)    # dense copies, second-generation kernel
+    finally:
+        os.environ.pop("D3_WG3")
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < 2e-6, relerr(got, ref)
+    if dybf:                                                          # the same bf16 values handed over as fp32: identical result
+        same = run(xv, cin + 24, dyv.float().contiguous(), cout, flags | XBF16)
+        assert torch.equal(got, same)
