@@ -417,6 +417,8 @@ class TopDownSceneCaptionModule(nn.Module):
         one on the host (:285-300) -- each step keeps its (seq, logps, p, ended) snapshot on the device and the
         per-sample ranking is one stable sort at the end (ties keep the reference's append order: step, then beam).
         """
+        if self.native and target_feats.is_cuda:
+            return self._beam_decode_native(target_feats, obj_feats, valid_masks, beam_size, max_len, topn)
         N, b, V = target_feats.shape[0], beam_size, self.num_vocabs
         dev = target_feats.device
         eos = int(self.vocabulary["word2idx"]["eos"])
@@ -468,6 +470,78 @@ class TopDownSceneCaptionModule(nn.Module):
                 t, v = divmod(j, b)
                 beams.append({"seq": snaps[t][0][n, v], "logps": snaps[t][1][n, v], "p": float(Pc[n, j])})
             done.append(beams)
+        return done
+
+    def _beam_decode_native(self, target_feats, obj_feats, valid_masks, beam_size, max_len, topn=None):
+        """The same search on the native decode step (csrc/topdown.hip), in two parts:
+          1. the search itself runs without autograd on `d3_topdown_step` -- the b beams of a sample are b rows that share the
+             sample's object block, a beam re-ordering is a row gather of the two hidden states;
+          2. the log-probabilities of the beams that are returned (the `topn` best per sample) are recomputed with gradients by
+             ONE teacher-forced pass over those token sequences (`TopDownXEFunction`): a finished beam's hidden-state trajectory is
+             exactly the trajectory of feeding its own tokens from the start (re-ordering copies ancestors' states), so values and
+             gradients are those of differentiating through the search (the choices themselves carry no gradient) -- without
+             keeping 30 steps x b beams of library-op autograd nodes alive."""
+        N, b, V = target_feats.shape[0], beam_size, self.num_vocabs
+        dev = target_feats.device
+        sos, eos = int(self.vocabulary["word2idx"]["sos"]), int(self.vocabulary["word2idx"]["eos"])
+        vm = valid_masks.reshape(N, -1)
+        with torch.no_grad():
+            dec = _NativeDecoder(self, target_feats.detach().repeat_interleave(b, dim=0), obj_feats.detach(),
+                                 vm.repeat_interleave(b, dim=0), obj_div=b)
+            word = torch.full((N * b,), sos, dtype=torch.long, device=dev)
+            logits, _ = dec.step(word)
+            logp = F.log_softmax(logits.view(N, b, V)[:, :1], dim=-1)        # t = 0: a single live beam per sample (:176-179)
+            base = torch.arange(N, device=dev).unsqueeze(1) * b
+            sums = target_feats.new_zeros(N, 1)
+            seq = torch.zeros(N, b, 0, dtype=torch.long, device=dev)
+            allseq = torch.zeros(max_len, N, b, max_len, dtype=torch.long, device=dev)   # every step's beams, zero padded
+            snaps = []
+            for t in range(max_len):
+                live = logp.shape[1]
+                cand = (sums.unsqueeze(-1) + logp).reshape(N, live * V)
+                ix = torch.sort(cand, -1, True)[1][:, :b]                   # full sort as the reference (:181-182)
+                beam_ix, tok = ix // V, ix % V
+                if t > 0:
+                    seq = seq.gather(1, beam_ix.unsqueeze(-1).expand_as(seq))
+                chosen = logp.reshape(N, live * V).gather(1, ix)
+                seq = torch.cat([seq, tok.unsqueeze(-1)], -1)
+                sums = sums.gather(1, beam_ix) + chosen
+                ended = (tok == eos) if t < max_len - 1 else torch.ones_like(tok, dtype=torch.bool)
+                allseq[t, :, :, :t + 1] = seq
+                snaps.append((None, sums.clone(), ended))
+                sums = sums - 1000.0 * ended.to(sums.dtype)                 # finished beams stay, heavily penalised (:300)
+                if t == max_len - 1:
+                    break
+                state_ix = (base + beam_ix).reshape(-1)                     # rows are (sample, beam slot)
+                dec.h1[0], dec.h2[0] = dec.h1[0].index_select(0, state_ix), dec.h2[0].index_select(0, state_ix)
+                logits, _ = dec.step(tok.reshape(-1))
+                logp = F.log_softmax(logits, dim=-1).view(N, b, V)
+            P = torch.stack([torch.where(e, p_, torch.full_like(p_, float("-inf"))) for (_, p_, e) in snaps], 1).reshape(N, -1)
+            keep = b if topn is None else min(topn, b)
+            order = torch.sort(P, dim=1, descending=True, stable=True)[1][:, :b].cpu()
+            Pc = P.cpu()
+        picked = []                                                         # (sample, step, beam slot, p)
+        for n in range(N):
+            for j in order[n].tolist()[:keep]:
+                if Pc[n, j] == float("-inf"):
+                    break
+                t, v = divmod(j, b)
+                picked.append((n, t, v, float(Pc[n, j])))
+        done = [[] for _ in range(N)]
+        if not picked:
+            return done
+        # teacher-forced replay of the returned beams: inputs [sos, tok_0 .. tok_{l-2}] predict tok_0 .. tok_{l-1}
+        R, S = len(picked), max(t + 1 for _, t, _, _ in picked)
+        pk = torch.tensor([(n, t, v) for n, t, v, _ in picked], dtype=torch.long).to(dev)
+        rows = pk[:, 0]
+        toks = allseq[pk[:, 1], pk[:, 0], pk[:, 2], :S]                      # (R, S), zero behind a beam's own length
+        word_ids = torch.cat([torch.full((R, 1), sos, dtype=torch.long, device=dev), toks], 1)   # (R, S + 1)
+        sd = dict(self.named_parameters())
+        logits, _ = TopDownXEFunction.apply(self.embeddings, word_ids, vm.index_select(0, rows), S, obj_feats.index_select(0, rows),
+                                            target_feats.index_select(0, rows), *[sd[_TD_KEYS[k]] for k in _lib.TOPDOWN_PARAMS])
+        lp = F.log_softmax(logits, dim=-1).gather(2, toks.unsqueeze(-1)).squeeze(-1)              # (R, S)
+        for r, (n, t, v, p_) in enumerate(picked):
+            done[n].append({"seq": toks[r, :t + 1], "logps": lp[r, :t + 1], "p": p_})
         return done
 
     def trim_outputs(self, raw_word_ids, raw_logprobs):

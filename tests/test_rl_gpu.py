@@ -184,3 +184,37 @@ def test_device_cider_reward_matches_reference_golden_and_host_scorer(dev):
     got = out.cpu().numpy()
     assert np.allclose(got, want, rtol=1e-12, atol=1e-13), np.abs(got - want).max()
     assert want.max() > 0.1                                                                            # a non-trivial case
+
+
+def test_native_beam_search_with_teacher_forced_replay_equals_library_search(dev):
+    """TopDownSceneCaptionModule.beam_decode on the native decode step + one teacher-forced replay of the returned beams
+    (d3net_amd/speaker.py:_beam_decode_native) against the library-op search that differentiates through every step: identical
+    token sequences, chosen-token log-probabilities to 2e-4, parameter gradients of a loss over the returned beams to 1e-3."""
+    from test_oracle_rl import setup
+    from d3net_amd.speaker import TopDownSceneCaptionModule
+    R, S, g, cfg, vocab, p, lp, d, opt = setup()
+
+    def build(native):
+        cap = TopDownSceneCaptionModule(cfg, vocab, S.make_embeddings(), num_proposals=S.K, num_locals=S.L, use_relation=True)
+        cap.load_state_dict(p)
+        cap = cap.to(dev)
+        cap.native = native
+        return cap
+
+    si = {k: torch.from_numpy(v).to(dev) for k, v in S.step_inputs().items()}
+    res = {}
+    for native in (True, False):
+        cap = build(native)
+        done = cap.beam_decode(si["target"], si["obj"], si["mask"], R.BEAM, S.MAXLEN, topn=2)
+        sum(b["logps"].sum() * (1.0 + 0.1 * j) for s_ in done for j, b in enumerate(s_)).backward()
+        res[native] = (done, {n: q.grad.clone() for n, q in cap.named_parameters() if q.grad is not None})
+    (dn, gn), (dl, gl) = res[True], res[False]
+    assert len(dn) == len(dl)
+    for a, b in zip(dn, dl):
+        assert len(a) == len(b) == 2
+        for x, y in zip(a, b):
+            assert torch.equal(x["seq"], y["seq"]) and abs(x["p"] - y["p"]) < 1e-3
+            assert torch.allclose(x["logps"], y["logps"], atol=2e-4)
+    assert set(gn) == set(gl)
+    for n in gl:
+        assert torch.allclose(gn[n], gl[n], rtol=1e-3, atol=1e-5 + 1e-3 * float(gl[n].abs().max())), n
