@@ -7,7 +7,8 @@ What runs where: projections / 1x1 convs / LayerNorm / BatchNorm1d are plain lib
 (hipBLASLt / MIOpen through torch); the attention core (scores + distance bias + key mask + softmax + PV, forward and
 backward) is the hand-written kernel `d3_attn_fwd/bwd` (csrc/attention.hip), which consumes the UN-replicated distance
 weights and (B,T) masks instead of the (B*C,4,128,128) copies the reference builds with `.repeat`
-(model/match_module.py:191-197,324-326).  The packed GRU is torch's nn.GRU (MIOpen) for now.
+(model/match_module.py:191-197,324-326), on fp32 MFMA tiles.  The packed-sequence GRU of `LangModule` is the native
+`d3_gru_seq_forward/backward` (csrc/topdown.hip; `LangModule.native`).
 """
 import ctypes as C
 import math
