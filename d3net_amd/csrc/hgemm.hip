@@ -84,7 +84,10 @@ __global__ __launch_bounds__(NW * 64) void hg_gemm_kernel(const HgBatch batch) {
         const int step = KSPLIT ? NW : 1;
         int first = KSPLIT ? ((wave - gkb) & (NW - 1)) : 0;
         gkb += nkb;
-        constexpr int U = (NW == 16 || RT > 2) ? 2 : 4;   // (1024-thread workgroups: 128 VGPRs per lane)
+#ifndef HG_U16
+#define HG_U16 2
+#endif
+        constexpr int U = RT > 2 ? 2 : (NW == 16 ? HG_U16 : 4);   // (1024-thread workgroups: 128 VGPRs per lane)
         for (int kb0 = first; kb0 < nkb; kb0 += step * U) {
             f32x4 a[U][RT], b[U];
 #pragma unroll

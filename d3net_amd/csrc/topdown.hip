@@ -26,6 +26,9 @@
 #include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef GRU_U
+#define GRU_U 2      // k blocks of 16 in flight per wave and batch of loads (812 / 16 = 51 blocks over 8 waves: two batches)
+#endif
 
 int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s);
 size_t hg_colsum_ws_bytes(int njobs, int cmax);
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
         const float *w0 = W + (long long)col * K, *w1 = W + (long long)(H + col) * K, *w2 = W + (long long)(2 * H + col) * K;
         const int first = (wave - gkb) & (GRU_NW - 1);
         gkb += nkb;
-        constexpr int U = 2;
+        constexpr int U = GRU_U;
         for (int kb0 = first; kb0 < nkb; kb0 += GRU_NW * U) {
             f32x4 xa[U][RT], b0[U], b1[U], b2[U];
 #pragma unroll

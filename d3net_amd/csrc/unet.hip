@@ -305,6 +305,7 @@ struct OpD {
     int use_shadow;                   // CONV: reads its output gradient from the bf16 shadow of that (fp32) gradient buffer
     int write_shadow;                 // BNACT: its backward apply also writes the bf16 shadow of the buffer it finalises
 };
+#define RED_RING 8
 struct Net {
     std::vector<TensorD> T;
     std::vector<BufD> B;
@@ -326,7 +327,7 @@ struct Net {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;       // pool
     size_t ev_used = 0;
-    RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (double buffered) + device copy of the reduce jobs
+    RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (ring of RED_RING slots) + device copies of the reduce jobs
     size_t red_cap = 0; int red_flip = 0;
     hipEvent_t next_event() {
         if (ev_used == ev.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; ev.push_back(e); }
@@ -948,10 +949,11 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             if (n->red_host) hipHostFree(n->red_host);
             if (n->red_dev) hipFree(n->red_dev);
             n->red_cap = red.size() + 16;
-            D3_CHECK(hipHostMalloc((void **)&n->red_host, 2 * n->red_cap * sizeof(RedJob)));
-            D3_CHECK(hipMalloc((void **)&n->red_dev, 2 * n->red_cap * sizeof(RedJob)));
+            D3_CHECK(hipStreamSynchronize(ws_stream));   // (growing: nothing may still read the old tables)
+            D3_CHECK(hipHostMalloc((void **)&n->red_host, RED_RING * n->red_cap * sizeof(RedJob)));
+            D3_CHECK(hipMalloc((void **)&n->red_dev, RED_RING * n->red_cap * sizeof(RedJob)));
         }
-        n->red_flip ^= 1;
+        n->red_flip = (n->red_flip + 1) % RED_RING;   // a slot is rewritten only RED_RING backward calls later (no host sync needed in between)
         RedJob *hj = n->red_host + (size_t)n->red_flip * n->red_cap, *dj = n->red_dev + (size_t)n->red_flip * n->red_cap;
         memcpy(hj, red.data(), red.size() * sizeof(RedJob));
         D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, ws_stream));
