@@ -115,3 +115,36 @@ def test_native_packed_gru_matches_library_gru_at_config_shape(dev):
     for k in a[1]:
         err = float((a[1][k] - b[1][k]).abs().max()) / (float(a[1][k].abs().max()) + 1e-12)
         assert err < 1e-3, (k, err)
+
+
+def test_attention_mfma_form_equals_scalar_form(dev):
+    """csrc/attention.hip: the fp32-MFMA kernels against the scalar-FMA kernels of round 1 (D3_ATTN_SCALAR=1) on ragged shapes
+    (queries / keys not multiples of 16, head dims below 32, bias shared by groups of batch items, masked keys): the same fp32
+    arithmetic in another summation order."""
+    import os
+    from d3net_amd.listener import AttentionCoreFunction
+    torch.manual_seed(1)
+    for (B, h, nq, nk, dk, dv, div, use_bias, use_mask) in [(8, 4, 128, 128, 32, 32, 4, True, True), (4, 2, 37, 101, 12, 20, 2, True, True),
+                                                          (3, 4, 128, 5, 32, 32, 1, False, True), (2, 1, 1, 128, 32, 32, 1, False, False)]:
+        q = torch.randn(B, nq, h * dk, device=dev)
+        k = torch.randn(B, nk, h * dk, device=dev)
+        v = torch.randn(B, nk, h * dv, device=dev)
+        bias = torch.randn(B // div, h, nq, nk, device=dev) if use_bias else None
+        mask = (torch.rand(B, nk, device=dev) > 0.4).float() if use_mask else None
+        if mask is not None:
+            mask[:, 0] = 1
+        g = torch.randn(B, nq, h * dv, device=dev)
+        res = []
+        for scalar in (False, True):
+            if scalar:
+                os.environ["D3_ATTN_SCALAR"] = "1"
+            try:
+                qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+                out = AttentionCoreFunction.apply(qq, kk, vv, bias, mask, h, div)
+                out.backward(g)
+                torch.cuda.synchronize()
+                res.append((out.detach(), qq.grad, kk.grad, vv.grad))
+            finally:
+                os.environ.pop("D3_ATTN_SCALAR", None)
+        for a, b in zip(*res):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * (1 + float(b.abs().max()))), float((a - b).abs().max())
