@@ -314,7 +314,7 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
-    std::vector<int> gshadow;         // per buffer: a bf16 shadow of its fp32 gradient exists (residual streams)
+    std::vector<int> gshadow;         // per buffer: width of the bf16 shadow of (a column window of) its fp32 gradient, 0 = none
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
     bool planned = false, lastblock = false;
@@ -536,21 +536,28 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             }
             return -3;
         };
-        std::map<int, int> last_bn;        // root buffer -> BNACT op whose apply was the last writer (whole buffer), or -1
+        // root buffer -> (BNACT op whose apply was the last writer of the buffer, column window it wrote) or op -1.  A window is
+        // the whole buffer (residual streams) or one column half of a concatenation buffer's gradient (the skip connection:
+        // its last writer is the BatchNorm in front of the stride-2 convolution, accumulating into the left half only).
+        struct LastBn { int op, coff, C; };
+        std::map<int, LastBn> last_bn;
         for (int i = (int)n->ops.size() - 1; on && i >= 0; i--) {
             OpD &o = n->ops[i];
             int coff, C;
             if (o.type == OP_CONV) {
                 const int ro = root_of(o.out, coff, C);
-                if (ro >= 0 && !n->gbf[ro] && coff == 0 && C == n->B[ro].width && !(C & 7)) {
+                if (ro >= 0 && !n->gbf[ro] && !(C & 7)) {
                     auto it = last_bn.find(ro);
-                    if (it != last_bn.end() && it->second >= 0) { o.use_shadow = 1; n->ops[it->second].write_shadow = 1; n->gshadow[ro] = 1; }
+                    if (it != last_bn.end() && it->second.op >= 0 && it->second.coff == coff && it->second.C == C &&
+                        (!n->gshadow[ro] || n->gshadow[ro] == C)) {       // (one shadow window per buffer)
+                        o.use_shadow = 1; n->ops[it->second.op].write_shadow = 1; n->gshadow[ro] = C;
+                    }
                 }
-                if (o.in_grad_mode) { const int ri = root_of(o.in, coff, C); if (ri >= 0) last_bn[ri] = -1; }
-                if (o.res >= 0 && o.res_mode >= 2) { const int rr = root_of(o.res, coff, C); if (rr >= 0) last_bn[rr] = -1; }
+                if (o.in_grad_mode) { const int ri = root_of(o.in, coff, C); if (ri >= 0) last_bn[ri] = LastBn{-1, 0, 0}; }
+                if (o.res >= 0 && o.res_mode >= 2) { const int rr = root_of(o.res, coff, C); if (rr >= 0) last_bn[rr] = LastBn{-1, 0, 0}; }
             } else if (o.type == OP_BNACT && o.in_grad_mode) {
                 const int ri = root_of(o.in, coff, C);
-                if (ri >= 0) last_bn[ri] = (!n->gbf[ri] && coff == 0 && C == n->B[ri].width) ? i : -1;
+                if (ri >= 0) last_bn[ri] = n->gbf[ri] ? LastBn{-1, 0, 0} : LastBn{i, coff, C};
             }
         }
     }
@@ -591,7 +598,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
         const size_t bi = &b - &n->B[0];
         b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[bi] ? 2 : 4));
-        if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * b.width * 2); }
+        if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * n->gshadow[bi] * 2); }
     }
     size_t bnscr = 0, wgws = 16;
     for (auto &o : n->ops) {
@@ -844,7 +851,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             const int *tf, *tb; int flip; conv_tables(o, maps, tf, tb, flip);
             int ldgo, root_o, gobf; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o, &gobf);
             float *go32 = go;                      // (the residual add below reads the fp32 buffer)
-            if (o.use_shadow && root_o >= 0 && n->gshadow[root_o]) { go = (float *)(garena + n->gshadow_off[root_o]); gobf = 1; }
+            const int ldgo32 = ldgo;
+            if (o.use_shadow && root_o >= 0 && n->gshadow[root_o]) { go = (float *)(garena + n->gshadow_off[root_o]); gobf = 1; ldgo = n->gshadow[root_o]; }   // dense (M, C) bf16
             // weight gradient on the side stream
             if (pgrads[o.w] != nullptr) {
                 if (use_side) {
@@ -907,7 +915,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 int ldr, root_r; float *gr = gptr(n, garena, gout, gin, o.res, ldr, root_r);
                 if (root_r >= 0) wait_pending(root_r);
                 const long long total = (long long)Mout * (o.Cout / 4);
-                if (total > 0) un_add_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(gr, ldr, go32, ldgo, Mout, o.Cout, o.res_mode == 3 ? 1 : 0);
+                if (total > 0) un_add_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(gr, ldr, go32, ldgo32, Mout, o.Cout, o.res_mode == 3 ? 1 : 0);
             }
         } else if (o.type == OP_BNACT) {
             if (!o.in_grad_mode && pgrads[o.gamma] == nullptr) continue;
@@ -933,7 +941,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
                 if (root_i >= 0) wait_pending(root_i);
                 const long long total = (long long)M * (C / 4);
-                unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] && ldgi == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
+                unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
                 if (gibf)
                     un_bn_bwd_apply_kernel<true><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
                                                                                          o.eps, relu, 0, nullptr);
