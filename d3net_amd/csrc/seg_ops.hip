@@ -92,8 +92,10 @@ __global__ __launch_bounds__(SEG_THREADS) void sec_mean_kernel(const float *__re
 // The chunk is staged TRANSPOSED (channel-major, rows padded to a multiple of 4), so the chain lane of a channel reads
 // four consecutive rows with one ds_read_b128 and keeps 32 rows in flight behind the 32 dependent adds: the chain runs
 // at the issue rate of v_add_f32 instead of waiting for LDS.
+// gidx != nullptr: row r of the input is inp[gidx[2r + 1]] (the (cluster, point) pairs of `clusters_idx`: the mean of the
+// clusters' point coordinates without materialising the gathered (S, 3) copy)
 __global__ __launch_bounds__(256) void sec_mean_pc_kernel(const float *__restrict__ inp, const int *__restrict__ offsets,
-                                                         float *__restrict__ out, int nProposal, int C) {
+                                                         float *__restrict__ out, int nProposal, int C, const int *__restrict__ gidx) {
     __shared__ __attribute__((aligned(16))) float stage[2][MEANW_PROD][MEANW_CHUNK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = blockIdx.x;
     const int start = offsets[p], end = offsets[p + 1];
@@ -113,7 +115,16 @@ __global__ __launch_bounds__(256) void sec_mean_pc_kernel(const float *__restric
                 const long long cb = (long long)k * cf;
                 float v[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) { const long long f = j * 64 + lane; v[j] = (f < cf && cb + f < total) ? inp[base + cb + f] : 0.f; }
+                for (int j = 0; j < 16; j++) {
+                    const long long f = j * 64 + lane;
+                    v[j] = 0.f;
+                    if (f < cf && cb + f < total) {
+                        if (gidx) {
+                            const int row = (int)(((unsigned int)f * invC) >> 16), c = (int)f - row * C;
+                            v[j] = inp[(long long)gidx[((long long)start + (long long)k * rpc + row) * 2 + 1] * C + c];
+                        } else v[j] = inp[base + cb + f];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const int f = j * 64 + lane;
@@ -334,6 +345,78 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_minmax_flat_kernel(const floa
     }
     if (any) { if (IS_MAX) seg_atomic_max_f32(&out[(long long)p * C + c], v); else seg_atomic_min_f32(&out[(long long)p * C + c], v); }
 }
+// both extrema of the rows inp[gidx[2r + 1]] per segment in one pass (same structure as above)
+__global__ __launch_bounds__(SEG_THREADS) void seg_minmax_gather_kernel(const float *__restrict__ inp, const int *__restrict__ gidx,
+                                                                       const int *__restrict__ offsets, float *__restrict__ omin,
+                                                                       float *__restrict__ omax, int nProposal, int C) {
+    __shared__ float rmin[SEG_THREADS], rmax[SEG_THREADS];
+    const int active = (SEG_THREADS / C) * C, rpp = active / C, t = threadIdx.x;
+    const int c = t % C;
+    const int total = offsets[nProposal], first = offsets[0];
+    int per = (total - first + gridDim.x - 1) / gridDim.x;
+    per = (per + rpp - 1) / rpp * rpp;
+    const int R0 = first + blockIdx.x * per, R1 = min(total, R0 + per);
+    if (R0 >= R1) return;                                   // uniform
+    const int p0 = seg_find(offsets, nProposal, R0);
+    if (offsets[p0 + 1] >= R1) {
+        float lo = INFINITY, hi = -INFINITY;
+        if (t < active)
+            for (int r = R0 + t / C; r < R1; r += rpp) {
+                const float x = inp[(long long)gidx[(long long)r * 2 + 1] * C + c];
+                if (x < lo) lo = x;
+                if (x > hi) hi = x;
+            }
+        rmin[t] = lo; rmax[t] = hi;
+        __syncthreads();
+        if (t < C) {
+            float a = rmin[t], b = rmax[t];
+            for (int k = t + C; k < active; k += C) { if (rmin[k] < a) a = rmin[k]; if (rmax[k] > b) b = rmax[k]; }
+            if (a < INFINITY) seg_atomic_min_f32(&omin[(long long)p0 * C + t], a);
+            if (b > -INFINITY) seg_atomic_max_f32(&omax[(long long)p0 * C + t], b);
+        }
+        return;
+    }
+    if (t >= active) return;
+    int r = R0 + t / C;
+    if (r >= R1) return;
+    int p = seg_find(offsets, nProposal, r);
+    int pend = offsets[p + 1];
+    float lo = INFINITY, hi = -INFINITY;
+    bool any = false;
+    for (; r < R1; r += rpp) {
+        if (r >= pend) {
+            if (any) { seg_atomic_min_f32(&omin[(long long)p * C + c], lo); seg_atomic_max_f32(&omax[(long long)p * C + c], hi); }
+            while (r >= pend) { p++; pend = offsets[p + 1]; }
+            lo = INFINITY; hi = -INFINITY; any = false;
+        }
+        const float x = inp[(long long)gidx[(long long)r * 2 + 1] * C + c];
+        if (x < lo) lo = x;
+        if (x > hi) hi = x;
+        any = true;
+    }
+    if (any) { seg_atomic_min_f32(&omin[(long long)p * C + c], lo); seg_atomic_max_f32(&omax[(long long)p * C + c], hi); }
+}
+// out[r] = [cluster, trunc((coords[point] - mean[cluster]) * scale[cluster] + offset[cluster])] as int64: the per-point part of
+// `clusters_voxelization` (model/pointgroup.py:141-166: subtract the mean, scale, shift, `.long()`, concatenate the cluster id),
+// every fp32 operation rounded separately like the elementwise library kernels it replaces
+__global__ void cluster_transform_kernel(const float *__restrict__ coords, const int *__restrict__ cidx, const float *__restrict__ mean,
+                                         const float *__restrict__ scale, const float *__restrict__ offset, long long *__restrict__ out,
+                                         long long S) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= S) return;
+    const int cl = cidx[r * 2], pt = cidx[r * 2 + 1];
+    const float sc = scale[cl];
+    long long o[4];
+    o[0] = cl;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v = __fadd_rn(__fmul_rn(__fsub_rn(coords[(long long)pt * 3 + k], mean[(long long)cl * 3 + k]), sc), offset[(long long)cl * 3 + k]);
+        o[k + 1] = (long long)v;
+    }
+    long long *op = out + r * 4;
+    op[0] = o[0]; op[1] = o[1]; op[2] = o[2]; op[3] = o[3];
+}
+
 // first row attaining the (already final) maximum: strict '>' in ascending row order == smallest such row
 __global__ __launch_bounds__(SEG_THREADS) void roipool_arg_flat_kernel(const float *__restrict__ feats,
                                                                       const int *__restrict__ offsets,
@@ -389,7 +472,7 @@ extern "C" int d3_sec_mean(const float *inp, const int *offsets, float *out, int
     D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
-    if (C <= 64) sec_mean_pc_kernel<<<nProposal, 256, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
+    if (C <= 64) sec_mean_pc_kernel<<<nProposal, 256, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C, nullptr);
     else sec_mean_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
     D3_LAUNCH_CHECK();
     return 0;
@@ -445,6 +528,31 @@ extern "C" int d3_get_iou(const int *proposals_idx, const int *proposals_offset,
     if (nProposal <= 0 || nInstance <= 0) return 0;
     get_iou_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(
         proposals_idx, proposals_offset, instance_labels, instance_pointnum, proposals_iou, nInstance, nProposal);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- cluster normalisation helpers of PointGroup.clusters_voxelization (model/pointgroup.py:125-178): the three passes over
+// the S (cluster, point) pairs without the gathered / subtracted / scaled (S, 3) temporaries of the library-op form.
+// clusters_idx (S,2) int32 [cluster, point]; offsets (P+1); coords (N,3).
+extern "C" int d3_cluster_coords_stats(const float *coords, const int *clusters_idx, const int *offsets, float *mean, float *cmin,
+                                       float *cmax, int nProposal, void *stream) {
+    D3_CLEAR();
+    if (nProposal <= 0) return 0;
+    hipStream_t s = d3_stream(stream);
+    sec_mean_pc_kernel<<<nProposal, 256, 0, s>>>(coords, offsets, mean, nProposal, 3, clusters_idx);
+    const long long n = (long long)nProposal * 3;
+    seg_init_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(cmin, nullptr, n, INFINITY, 0);
+    seg_init_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(cmax, nullptr, n, -INFINITY, 0);
+    seg_minmax_gather_kernel<<<SEG_FLAT_GRID, SEG_THREADS, 0, s>>>(coords, clusters_idx, offsets, cmin, cmax, nProposal, 3);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_cluster_transform(const float *coords, const int *clusters_idx, const float *mean, const float *scale,
+                                    const float *offset, long long *out, long long S, void *stream) {
+    D3_CLEAR();
+    if (S <= 0) return 0;
+    cluster_transform_kernel<<<(int)((S + 255) / 256), 256, 0, d3_stream(stream)>>>(coords, clusters_idx, mean, scale, offset, out, S);
     D3_LAUNCH_CHECK();
     return 0;
 }

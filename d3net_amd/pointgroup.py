@@ -217,17 +217,14 @@ class PointGroup(nn.Module):
         rand: optional (2,3) tensor standing in for the two `torch.rand(3)` draws of the reference (:161)."""
         dev = feats.device
         c_idxs = clusters_idx[:, 1].long()
-        cid = clusters_idx[:, 0].long()
         clusters_feats = heads.gather_cluster_rows(feats, c_idxs)
-        clusters_coords = coords[c_idxs]
-
         _mark("cv_gather")
-        clusters_coords_mean = pointgroup_ops.sec_mean(clusters_coords, clusters_offset)      # (P,3)
+        # per-cluster mean / extrema of the member coordinates straight from the (cluster, point) pairs, no (S,3) temporaries
+        # (csrc/seg_ops.hip: d3_cluster_coords_stats; min(x - mean) == min(x) - mean under monotone rounding)
+        clusters_coords_mean, raw_min, raw_max = pointgroup_ops.cluster_coords_stats(coords, clusters_idx, clusters_offset)
         _mark("cv_sec_mean")
-        clusters_coords = clusters_coords - torch.index_select(clusters_coords_mean, 0, cid)
-        clusters_coords_min = pointgroup_ops.sec_min(clusters_coords, clusters_offset)
-        clusters_coords_max = pointgroup_ops.sec_max(clusters_coords, clusters_offset)
-
+        clusters_coords_min = raw_min - clusters_coords_mean
+        clusters_coords_max = raw_max - clusters_coords_mean
         _mark("cv_sec_minmax")
         clusters_size = clusters_coords_max - clusters_coords_min
         clusters_center = (clusters_coords_max + clusters_coords_min) / 2 + clusters_coords_mean
@@ -236,8 +233,6 @@ class PointGroup(nn.Module):
         clusters_scale = torch.clamp(clusters_scale, min=None, max=scale)
         min_xyz = clusters_coords_min * clusters_scale.unsqueeze(-1)
         max_xyz = clusters_coords_max * clusters_scale.unsqueeze(-1)
-        clusters_scale = torch.index_select(clusters_scale, 0, cid)
-        clusters_coords = clusters_coords * clusters_scale.unsqueeze(-1)
 
         rng = max_xyz - min_xyz
         if rand is None:
@@ -247,10 +242,8 @@ class PointGroup(nn.Module):
         r01 = _STAGE.put(torch.stack([r0, r1]).float(), dev)
         offset = - min_xyz + torch.clamp(fullscale - rng - 0.001, min=0) * r01[0] + \
             torch.clamp(fullscale - rng + 0.001, max=0) * r01[1]
-        clusters_coords = clusters_coords + torch.index_select(offset, 0, cid)
-
-        clusters_coords = clusters_coords.long()                                               # truncation (:166)
-        clusters_coords = torch.cat([cid.view(-1, 1), clusters_coords], 1).contiguous()        # (S,4) on the device
+        # (coords[point] - mean) * scale + offset, truncated (:166), with the cluster id in front: one pass over the S pairs
+        clusters_coords = pointgroup_ops.cluster_transform(coords, clusters_idx, clusters_coords_mean, clusters_scale, offset)
         n_clusters = int(clusters_offset.numel() - 1)
         _mark("cv_elementwise")
         voxel_coords, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(clusters_coords, n_clusters, mode)

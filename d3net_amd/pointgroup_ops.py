@@ -407,3 +407,27 @@ class SecMax(Function):
 
 
 sec_max = SecMax.apply
+
+
+def cluster_coords_stats(coords, clusters_idx, clusters_offset):
+    """mean / min / max (P,3) of the clusters' member coordinates from the (S,2) [cluster, point] pairs: what
+    `sec_mean(coords[idx])`, `sec_min(coords[idx])`, `sec_max(coords[idx])` return, without the gathered copy (d3_cluster_coords_stats)"""
+    assert coords.is_cuda and coords.dtype == torch.float32 and coords.is_contiguous() and coords.shape[1] == 3
+    assert clusters_idx.dtype == torch.int32 and clusters_idx.is_contiguous() and clusters_offset.dtype == torch.int32
+    P = clusters_offset.numel() - 1
+    out = torch.empty((3, P, 3), dtype=torch.float32, device=coords.device)
+    with _on(coords.device):
+        check(_lib.lib().d3_cluster_coords_stats(_ptr(coords), _ptr(clusters_idx), _ptr(clusters_offset), _ptr(out[0]), _ptr(out[1]),
+                                                 _ptr(out[2]), P, _stream()), "cluster_coords_stats")
+    return out[0], out[1], out[2]
+
+
+def cluster_transform(coords, clusters_idx, mean, scale, offset):
+    """(S,4) int64 [cluster, trunc((coords[point] - mean[cluster]) * scale[cluster] + offset[cluster])] (d3_cluster_transform)"""
+    S = clusters_idx.shape[0]
+    mean, scale, offset = mean.contiguous(), scale.contiguous(), offset.contiguous()
+    out = torch.empty((S, 4), dtype=torch.int64, device=coords.device)
+    with _on(coords.device):
+        check(_lib.lib().d3_cluster_transform(_ptr(coords), _ptr(clusters_idx), _ptr(mean), _ptr(scale), _ptr(offset), _ptr(out), S,
+                                              _stream()), "cluster_transform")
+    return out

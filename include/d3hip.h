@@ -41,6 +41,16 @@ const char *d3_arch(void); /* "gfx950" */
 int d3_sec_mean(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
 int d3_sec_min(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
 int d3_sec_max(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
+/* The per-point passes of PointGroup.clusters_voxelization (model/pointgroup.py:125-178) over the S (cluster, point) pairs of
+ * clusters_idx (S,2) without the gathered / shifted / scaled (S,3) temporaries of the library-op form:
+ *   coords_stats: mean (P,3) = sec_mean of the clusters' point coordinates (same serial x/count chain, bit-exact), cmin / cmax
+ *                 (P,3) = their per-cluster extrema (raw coordinates: min(x - m) == min(x) - m under monotone rounding);
+ *   transform   : out (S,4) int64 = [cluster, trunc((coords[point] - mean[cluster]) * scale[cluster] + offset[cluster])],
+ *                 each fp32 operation rounded separately (:141-166). */
+int d3_cluster_coords_stats(const float *coords, const int *clusters_idx, const int *offsets, float *mean, float *cmin, float *cmax,
+                            int nProposal, void *stream);
+int d3_cluster_transform(const float *coords, const int *clusters_idx, const float *mean, const float *scale, const float *offset,
+                         long long *out, long long S, void *stream);
 /* PG_OP.roipool_fp / roipool_bp  (src/roipool/roipool.cu:12-57) */
 int d3_roipool_fp(const float *feats, const int *proposals_offset, float *output_feats, int *output_maxidx,
                   int nProposal, int C, void *stream);

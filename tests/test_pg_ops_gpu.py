@@ -333,3 +333,46 @@ def test_full_size_ballquery_and_cluster_properties(dev):
     # the full-size result equals the sequential oracle BFS (cheap: O(nActive))
     rci, rco = o.bfs_cluster(sem, idx, sl, 50)
     assert np.array_equal(ci, rci) and np.array_equal(co, rco)
+
+
+def test_cluster_coordinate_stats_and_transform_equal_the_library_op_form(dev):
+    """d3_cluster_coords_stats / d3_cluster_transform (the per-point passes of PointGroup.clusters_voxelization,
+    model/pointgroup.py:125-178) against the chain of library ops they replace -- gather, sec_mean / sec_min / sec_max of the
+    shifted copy, index_select, multiply, add, `.long()`, cat -- bit for bit, on clusters of very different sizes (one point,
+    a few, tens of thousands), with the reference's scale / offset arithmetic in between."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(11)
+    N = 120000
+    coords = torch.from_numpy((rng.random((N, 3)) * 4).astype(np.float32)).to(dev)
+    sizes = [1, 2, 7, 50, 333, 4096, 40000, 1, 25000, 19]
+    pts = [rng.choice(N, s, replace=False) for s in sizes]
+    cidx = np.concatenate([np.stack([np.full(s, i), p], 1) for i, (s, p) in enumerate(zip(sizes, pts))]).astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    clusters_idx, clusters_offset = torch.from_numpy(cidx).to(dev), torch.from_numpy(offs).to(dev)
+    fullscale, scale = 14, 50
+    r01 = torch.from_numpy(rng.random((2, 3)).astype(np.float32)).to(dev)
+    # library-op form (what clusters_voxelization did before)
+    c_idxs, cid = clusters_idx[:, 1].long(), clusters_idx[:, 0].long()
+    cc = coords[c_idxs]
+    mean = P.sec_mean(cc, clusters_offset)
+    cc = cc - torch.index_select(mean, 0, cid)
+    cmin, cmax = P.sec_min(cc, clusters_offset), P.sec_max(cc, clusters_offset)
+
+    def scalars(cmin, cmax):
+        sc = 1 / ((cmax - cmin) / fullscale).max(1)[0] - 0.01
+        sc = torch.clamp(sc, min=None, max=scale)
+        min_xyz, max_xyz = cmin * sc.unsqueeze(-1), cmax * sc.unsqueeze(-1)
+        rg = max_xyz - min_xyz
+        off = -min_xyz + torch.clamp(fullscale - rg - 0.001, min=0) * r01[0] + torch.clamp(fullscale - rg + 0.001, max=0) * r01[1]
+        return sc, off
+
+    sc, off = scalars(cmin, cmax)
+    ref = cc * torch.index_select(sc, 0, cid).unsqueeze(-1) + torch.index_select(off, 0, cid)
+    ref = torch.cat([cid.view(-1, 1), ref.long()], 1).contiguous()
+    # fused form
+    mean2, rmin, rmax = P.cluster_coords_stats(coords, clusters_idx, clusters_offset)
+    assert torch.equal(mean2, mean)
+    assert torch.equal(rmin - mean2, cmin) and torch.equal(rmax - mean2, cmax)
+    sc2, off2 = scalars(rmin - mean2, rmax - mean2)
+    got = P.cluster_transform(coords, clusters_idx, mean2, sc2, off2)
+    assert got.dtype == torch.int64 and torch.equal(got, ref)
