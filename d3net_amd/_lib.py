@@ -25,6 +25,8 @@ SIGNATURES = {
     "d3_sec_mean": (i32, [vp, vp, vp, i32, i32, vp]),
     "d3_sec_min": (i32, [vp, vp, vp, i32, i32, vp]),
     "d3_sec_max": (i32, [vp, vp, vp, i32, i32, vp]),
+    "d3_cluster_select": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "d3_cluster_merge": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "d3_cluster_coords_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "d3_cluster_transform": (i32, [vp, vp, vp, vp, vp, vp, i64, vp]),
     "d3_roipool_fp": (i32, [vp, vp, vp, vp, i32, i32, vp]),

@@ -1,0 +1,73 @@
+// clusterprep.hip -- the index plumbing around PointGroup's two clusterings as two launches (gfx950).
+//
+// Reference: model/pointgroup.py:288-316.  Before the clusterings the object points (semantic class > 0) are compacted:
+//     batch_idxs_ = batch_idxs[object_idxs]; coords_ = coords[object_idxs]; pt_offsets_ = pt_offsets[object_idxs];
+//     semantic_preds_ = semantic_preds[object_idxs].int(); shifted = coords_ + pt_offsets_
+// and after them the (cluster, compact point) pairs of both branches are mapped back to scene point ids, their batch ids
+// looked up, the second branch's cluster ids / offsets shifted behind the first's and everything concatenated -- in the
+// reference's way, including its one-element-short batch-id concatenation (:316: `proposals_batchId_shift_all[1:]`).
+// As library ops that is ~25 launches per step (six 400-750 k-row gathers with 64-bit indices among them, ~0.5 ms);
+// integer copies: bit-exact by construction (tests/test_pg_ops_gpu.py compares with the library-op chain).
+#include "common.h"
+
+__global__ void cp_select_kernel(const float *__restrict__ locs, const float *__restrict__ offs, const long long *__restrict__ sem,
+                                 const int *__restrict__ batch, const long long *__restrict__ obj, int n, int *__restrict__ batch_o,
+                                 float *__restrict__ coords_o, float *__restrict__ shifted_o, int *__restrict__ sem_o) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const long long o = obj[r];
+    batch_o[r] = batch[o];
+    sem_o[r] = (int)sem[o];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float c = locs[o * 3 + k];
+        coords_o[(long long)r * 3 + k] = c;
+        shifted_o[(long long)r * 3 + k] = __fadd_rn(c, offs[o * 3 + k]);
+    }
+}
+
+extern "C" int d3_cluster_select(const float *locs, const float *pt_offsets, const int64_t *semantic_preds, const int *batch_idxs,
+                                 const int64_t *object_idxs, int n, int *batch_out, float *coords_out, float *shifted_out,
+                                 int *semantic_out, void *stream) {
+    D3_CLEAR();
+    if (n <= 0) return 0;
+    cp_select_kernel<<<(n + 255) / 256, 256, 0, d3_stream(stream)>>>(locs, pt_offsets, (const long long *)semantic_preds, batch_idxs,
+                                                                    (const long long *)object_idxs, n, batch_out, coords_out, shifted_out,
+                                                                    semantic_out);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// idx1 (S1,2) / off1 (P1+1): clusters of the original coordinates; idx2 / off2: of the shifted ones (compact point ids).
+// out_idx (S1+S2, 2): [cluster id (second set + P1), scene point id]; out_off (P1+P2+1); out_bid (max(S1+S2-1, 0)): batch id of
+// every pair, the first pair of the second set dropped (the reference's concatenation).
+__global__ void cp_merge_kernel(const int *__restrict__ idx1, int S1, const int *__restrict__ off1, int P1,
+                                const int *__restrict__ idx2, int S2, const int *__restrict__ off2, int P2,
+                                const long long *__restrict__ obj, const int *__restrict__ batch, int *__restrict__ out_idx,
+                                int *__restrict__ out_off, int *__restrict__ out_bid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < S1 + S2) {
+        const bool second = e >= S1;
+        const int *src = second ? idx2 + (long long)(e - S1) * 2 : idx1 + (long long)e * 2;
+        const int pt = (int)obj[src[1]];
+        out_idx[(long long)e * 2] = src[0] + (second ? P1 : 0);
+        out_idx[(long long)e * 2 + 1] = pt;
+        const int b = batch[pt];
+        if (!second) out_bid[e] = b;
+        else if (e > S1) out_bid[e - 1] = b;      // (pair S1, the first of the second set, has no slot)
+    }
+    if (e <= P1) out_off[e] = off1[e];
+    else if (e <= P1 + P2) out_off[e] = off2[e - P1] + S1;
+}
+
+extern "C" int d3_cluster_merge(const int *idx1, int S1, const int *off1, int P1, const int *idx2, int S2, const int *off2, int P2,
+                                const int64_t *object_idxs, const int *batch_idxs, int *out_idx, int *out_off, int *out_bid,
+                                void *stream) {
+    D3_CLEAR();
+    if (S1 < 0 || S2 < 0 || P1 < 0 || P2 < 0) return D3_ERR_ARG;
+    int n = S1 + S2; if (P1 + P2 + 1 > n) n = P1 + P2 + 1;
+    cp_merge_kernel<<<(n + 255) / 256, 256, 0, d3_stream(stream)>>>(idx1, S1, off1, P1, idx2, S2, off2, P2, (const long long *)object_idxs,
+                                                                   batch_idxs, out_idx, out_off, out_bid);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

@@ -350,11 +350,10 @@ class PointGroup(nn.Module):
             batch_idxs = data_dict["locs_scaled"][:, 0].int()
             if not self.requires_gt_mask:
                 object_idxs = torch.nonzero(semantic_preds > 0, as_tuple=False).view(-1)   # ">0" as in the reference (:288)
-                batch_idxs_ = batch_idxs[object_idxs].contiguous()
+                # the object points' batch ids / coordinates / shifted coordinates / classes in one pass (csrc/clusterprep.hip)
+                batch_idxs_, coords_, shifted_xyz, semantic_preds_ = pointgroup_ops.cluster_select(
+                    data_dict["locs"], cluster_offsets.detach(), semantic_preds, batch_idxs, object_idxs)
                 batch_offsets_ = self.get_batch_offsets(batch_idxs_, batch_size)
-                coords_ = data_dict["locs"][object_idxs].contiguous()
-                pt_offsets_ = cluster_offsets[object_idxs]
-                semantic_preds_ = semantic_preds[object_idxs].int().contiguous()
 
                 def cluster_branch(xyz, mean_active, marks=False):
                     # (padded lists: same neighbours, no host round trip for nActive; bfs_cluster reads either form)
@@ -366,13 +365,11 @@ class PointGroup(nn.Module):
                     p_idx, p_off = pointgroup_ops.bfs_cluster(semantic_preds_, idx_, start_len_, self.cluster_npoint_thre, True)   # (ascending lists)
                     if marks:
                         _mark("cl_bfs")
-                    p_idx[:, 1] = object_idxs[p_idx[:, 1].long()].int()
-                    return p_idx, p_off, batch_idxs[p_idx[:, 1].long()].int()
+                    return p_idx, p_off          # (compact point ids: mapped back to scene ids by the merge below)
 
                 # The two clusterings (shifted :296-299, original :304-307) are independent until the merge: the shifted
                 # one runs on a side stream from a helper thread (ctypes releases the GIL inside libd3hip), so its count
                 # phases, which synchronise their own stream, overlap the other branch instead of serialising with it.
-                shifted_xyz = (coords_ + pt_offsets_).detach().contiguous()
                 _mark("cl_prepare")
                 cur = torch.cuda.current_stream()
                 if self.concurrent_clustering:
@@ -384,23 +381,19 @@ class PointGroup(nn.Module):
                             return cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
                     fut = _cluster_worker().submit(work)
                     try:
-                        proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive, True)
+                        first = cluster_branch(coords_, self.cluster_meanActive, True)
                     finally:
                         shifted = fut.result()      # (an exception of the helper is re-raised here)
                     cur.wait_stream(side)
-                    proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = shifted
                     for t in shifted:
                         t.record_stream(cur)
                 else:
-                    proposals_idx_shift, proposals_offset_shift, proposals_batchId_shift_all = cluster_branch(
-                        shifted_xyz, self.cluster_shift_meanActive)
-                    proposals_idx, proposals_offset, proposals_batchId_all = cluster_branch(coords_, self.cluster_meanActive)
-                # merge (:312-316), including the reference's one-element-short batch-id concat
-                proposals_idx_shift[:, 0] += (proposals_offset.size(0) - 1)
-                proposals_offset_shift += proposals_offset[-1]
-                proposals_idx = torch.cat((proposals_idx, proposals_idx_shift), dim=0)
-                proposals_offset = torch.cat((proposals_offset, proposals_offset_shift[1:]))
-                proposals_batchId_all = torch.cat((proposals_batchId_all, proposals_batchId_shift_all[1:]))
+                    shifted = cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
+                    first = cluster_branch(coords_, self.cluster_meanActive)
+                # merge (:299-316): scene point ids, batch ids, the shifted set's cluster ids / offsets behind the first set's,
+                # including the reference's one-element-short batch-id concat -- one launch (d3_cluster_merge)
+                proposals_idx, proposals_offset, proposals_batchId_all = pointgroup_ops.cluster_merge(
+                    first[0], first[1], shifted[0], shifted[1], object_idxs, batch_idxs)
             else:
                 proposals_idx = data_dict["gt_proposals_idx"].to(pt_feats.device)
                 proposals_offset = data_dict["gt_proposals_offset"].to(pt_feats.device)

@@ -409,6 +409,38 @@ class SecMax(Function):
 sec_max = SecMax.apply
 
 
+def cluster_select(locs, pt_offsets, semantic_preds, batch_idxs, object_idxs):
+    """-> batch_idxs_ (n) int32, coords_ (n,3), shifted (n,3) = coords_ + offsets_, semantic_preds_ (n) int32 of the object points
+    (d3_cluster_select: model/pointgroup.py:288-296 in one pass)"""
+    locs, pt_offsets = locs.contiguous(), pt_offsets.contiguous()
+    assert locs.dtype == torch.float32 and pt_offsets.dtype == torch.float32 and semantic_preds.dtype == torch.int64
+    assert batch_idxs.dtype == torch.int32 and object_idxs.dtype == torch.int64
+    n, dev = object_idxs.numel(), locs.device
+    b = torch.empty(n, dtype=torch.int32, device=dev)
+    sem = torch.empty(n, dtype=torch.int32, device=dev)
+    xyz = torch.empty((2, n, 3), dtype=torch.float32, device=dev)
+    with _on(dev):
+        check(_lib.lib().d3_cluster_select(_ptr(locs), _ptr(pt_offsets), _ptr(semantic_preds.contiguous()), _ptr(batch_idxs.contiguous()),
+                                           _ptr(object_idxs.contiguous()), n, _ptr(b), _ptr(xyz[0]), _ptr(xyz[1]), _ptr(sem), _stream()),
+              "cluster_select")
+    return b, xyz[0], xyz[1], sem
+
+
+def cluster_merge(idx1, off1, idx2, off2, object_idxs, batch_idxs):
+    """the two clusterings' (cluster, compact point) pairs -> proposals_idx (S1+S2,2), proposals_offset (P1+P2+1),
+    proposals_batchId_all (S1+S2-1) as model/pointgroup.py:299-316 builds them (d3_cluster_merge)"""
+    S1, S2, P1, P2 = idx1.shape[0], idx2.shape[0], off1.numel() - 1, off2.numel() - 1
+    dev = idx1.device
+    out_idx = torch.empty((S1 + S2, 2), dtype=torch.int32, device=dev)
+    out_off = torch.empty(P1 + P2 + 1, dtype=torch.int32, device=dev)
+    out_bid = torch.empty(max(S1 + S2 - 1, 0) if S2 > 0 else S1, dtype=torch.int32, device=dev)
+    with _on(dev):
+        check(_lib.lib().d3_cluster_merge(_ptr(idx1.contiguous()), S1, _ptr(off1.contiguous()), P1, _ptr(idx2.contiguous()), S2,
+                                          _ptr(off2.contiguous()), P2, _ptr(object_idxs), _ptr(batch_idxs), _ptr(out_idx), _ptr(out_off),
+                                          _ptr(out_bid), _stream()), "cluster_merge")
+    return out_idx, out_off, out_bid
+
+
 def cluster_coords_stats(coords, clusters_idx, clusters_offset):
     """mean / min / max (P,3) of the clusters' member coordinates from the (S,2) [cluster, point] pairs: what
     `sec_mean(coords[idx])`, `sec_min(coords[idx])`, `sec_max(coords[idx])` return, without the gathered copy (d3_cluster_coords_stats)"""

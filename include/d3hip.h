@@ -41,6 +41,17 @@ const char *d3_arch(void); /* "gfx950" */
 int d3_sec_mean(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
 int d3_sec_min(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
 int d3_sec_max(const float *inp, const int *offsets, float *out, int nProposal, int C, void *stream);
+/* Index plumbing around the two clusterings of PointGroup.forward (model/pointgroup.py:288-316; csrc/clusterprep.hip):
+ *   select: the object points' batch ids, coordinates, shifted coordinates (coords + offsets) and semantic ids, compacted by
+ *           object_idxs (n int64 scene point ids) -- four gathers, a cast and an add of the reference in one pass;
+ *   merge : the (cluster, compact point) pairs of both clusterings mapped back to scene point ids, their batch ids, the second
+ *           set's cluster ids / offsets shifted behind the first's, concatenated as the reference does (out_bid has S1+S2-1
+ *           entries: the reference drops the first pair of the second set, :316). */
+int d3_cluster_select(const float *locs, const float *pt_offsets, const int64_t *semantic_preds, const int *batch_idxs,
+                      const int64_t *object_idxs, int n, int *batch_out, float *coords_out, float *shifted_out, int *semantic_out,
+                      void *stream);
+int d3_cluster_merge(const int *idx1, int S1, const int *off1, int P1, const int *idx2, int S2, const int *off2, int P2,
+                     const int64_t *object_idxs, const int *batch_idxs, int *out_idx, int *out_off, int *out_bid, void *stream);
 /* The per-point passes of PointGroup.clusters_voxelization (model/pointgroup.py:125-178) over the S (cluster, point) pairs of
  * clusters_idx (S,2) without the gathered / shifted / scaled (S,3) temporaries of the library-op form:
  *   coords_stats: mean (P,3) = sec_mean of the clusters' point coordinates (same serial x/count chain, bit-exact), cmin / cmax

@@ -376,3 +376,40 @@ def test_cluster_coordinate_stats_and_transform_equal_the_library_op_form(dev):
     sc2, off2 = scalars(rmin - mean2, rmax - mean2)
     got = P.cluster_transform(coords, clusters_idx, mean2, sc2, off2)
     assert got.dtype == torch.int64 and torch.equal(got, ref)
+
+
+def test_cluster_select_and_merge_equal_the_library_op_chain(dev):
+    """d3_cluster_select / d3_cluster_merge against the library ops of model/pointgroup.py:288-316 they replace (gathers by
+    object_idxs, the shifted coordinates, the in-place id / offset shifts and the three concatenations with the reference's
+    one-element-short batch-id vector), incl. empty first / second cluster sets."""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(5)
+    N = 50000
+    locs = torch.from_numpy(rng.random((N, 3)).astype(np.float32)).to(dev)
+    offs = torch.from_numpy((rng.random((N, 3)) - 0.5).astype(np.float32)).to(dev)
+    sem = torch.from_numpy(rng.integers(0, 20, N)).to(dev)
+    batch = torch.from_numpy(np.sort(rng.integers(0, 4, N)).astype(np.int32)).to(dev)
+    obj = torch.nonzero(sem > 1).view(-1)
+    b_, c_, sh_, s_ = P.cluster_select(locs, offs, sem, batch, obj)
+    assert torch.equal(b_, batch[obj]) and torch.equal(c_, locs[obj]) and torch.equal(s_, sem[obj].int())
+    assert torch.equal(sh_, locs[obj] + offs[obj])
+    n = obj.numel()
+
+    def fake(nc, lo, hi):
+        sizes = rng.integers(lo, hi, nc) if nc else np.zeros(0, np.int64)
+        idx = np.concatenate([np.stack([np.full(s, i), rng.integers(0, n, s)], 1) for i, s in enumerate(sizes)] + [np.zeros((0, 2), np.int64)])
+        return torch.from_numpy(idx.astype(np.int32)).to(dev), torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(dev)
+
+    for nc1, nc2 in ((7, 5), (0, 4), (6, 0), (1, 1)):
+        i1, o1 = fake(nc1, 50, 400)
+        i2, o2 = fake(nc2, 50, 400)
+        got = P.cluster_merge(i1, o1, i2, o2, obj, batch)
+        # the library-op chain
+        a, b = i1.clone(), i2.clone()
+        a[:, 1] = obj[a[:, 1].long()].int(); b[:, 1] = obj[b[:, 1].long()].int()
+        ba, bb = batch[a[:, 1].long()].int(), batch[b[:, 1].long()].int()
+        b[:, 0] += (o1.size(0) - 1)
+        o2s = o2 + o1[-1]
+        ref = (torch.cat((a, b), 0), torch.cat((o1, o2s[1:])), torch.cat((ba, bb[1:])))
+        for g, r in zip(got, ref):
+            assert g.dtype == r.dtype and torch.equal(g, r), (nc1, nc2, g.shape, r.shape)
