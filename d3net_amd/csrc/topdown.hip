@@ -546,7 +546,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
 }
 
 // ------------------------------------------------------------------------------ backward through time
-struct TdBwdLayout { size_t dlog, dc0, dH2, dgi1, dgh1, dgi2, dgh2, dx1, dx2, dq, tmpL, dh1q, dh1c, dh2c, dfp, dwp, dx1s, dattS, cs, cs_bytes, total; };
+struct TdBwdLayout { size_t dlog, dc0, dH2, dgi1, dgh1, dgi2, dgh2, dx1, dx2, dq, tmpL, dh1q, dh1c, dh2c, dfp, dwp, dx1s, dattS, Wa, Wb, cs, cs_bytes, total; };
 static TdBwdLayout td_bwd_layout(int N, int K, int S, int V, int H, int E, int F) {
     TdBwdLayout L;
     size_t o = 0;
@@ -558,6 +558,7 @@ static TdBwdLayout td_bwd_layout(int N, int K, int S, int V, int H, int E, int F
     L.tmpL = take((size_t)N * (F + H) * 4); L.dh1q = take((size_t)N * H * 4); L.dh1c = take((size_t)N * H * 4); L.dh2c = take((size_t)N * H * 4);
     L.dfp = take((size_t)N * K * H * 4); L.dwp = take(R * H * 4); L.dx1s = take((size_t)N * E * 4);
     L.dattS = take(R * F * 4);
+    L.Wa = take((size_t)3 * H * (F + H) * 4); L.Wb = take((size_t)3 * H * H * 4);   // composed weights of the backward chain
     L.cs_bytes = hg_colsum_ws_bytes(8, V > 3 * H ? V : 3 * H); L.cs = take(L.cs_bytes);
     L.total = o;
     return L;
@@ -588,6 +589,7 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
     float *dx1 = (float *)(bw + B.dx1), *dx2 = (float *)(bw + B.dx2), *dq = (float *)(bw + B.dq), *tmpL = (float *)(bw + B.tmpL);
     float *dh1q = (float *)(bw + B.dh1q), *dh1c = (float *)(bw + B.dh1c), *dh2c = (float *)(bw + B.dh2c);
     float *dfp = (float *)(bw + B.dfp), *dwp = (float *)(bw + B.dwp), *dx1s = (float *)(bw + B.dx1s), *dattS = (float *)(bw + B.dattS);
+    float *Wa = (float *)(bw + B.Wa), *Wb = (float *)(bw + B.Wb);
     const int *act = (const int *)(ws + L.act), *nact = (const int *)(ws + L.nact);
     const long long ldtd = H + F + E, ldlang = F + H;
     const size_t RH = (size_t)R * H;
@@ -620,25 +622,35 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
     D3_CHECK(hipMemsetAsync(dh1c, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(dh2c, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(dfp, 0, (size_t)N * K * H * 4, s));
+    // The backward recurrence is a chain of dependent ~8 us launches; two links are pure compositions of linear maps and are
+    // taken out of it by composing the weights once per call (0.5 GFLOP):
+    //   [datt | dh1 part] = (dgi2 Wih2) W_lang     = dgi2 Wa,  Wa = Wih2 W_lang        (3H x (F+H))
+    //   dh2 carry        += (dgi1 Wih1) W_td[:, h2] = dgi1 Wb,  Wb = Wih1 W_td[:, E:E+H] (3H x H)
+    // so dx2 / dx1 (still needed, for the weight gradients batched over time) leave the critical path: 8 -> 6 launches per step.
+    {
+        d3_gemm_prob p[2];
+        p[0] = td_prob(3 * H, F + H, Wa, F + H);
+        p[0].nseg = 1; p[0].seg[0] = td_seg(a->Wih2, E, a->W_lang, ldlang, E, nullptr, 0, 1);
+        p[1] = td_prob(3 * H, H, Wb, H);
+        p[1].nseg = 1; p[1].seg[0] = td_seg(a->Wih1, E, a->W_td + E, ldtd, E, nullptr, 0, 1);
+        if ((rc = hg_launch(p, 2, s))) return rc;
+    }
     const int nh = (N * H + 255) / 256;
     for (int t = S - 1; t >= 0; t--) {
         const size_t rN = (size_t)t * N;
-        float *h1p = H1 + rN * H, *h1n = H1 + (rN + N) * H, *h2p = H2 + rN * H;
+        float *h1p = H1 + rN * H, *h2p = H2 + rN * H;
         // GRU2 gates: dh2[t+1] = classifier part + carry from step t+1
         td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dH2 + rN * H, H, dh2c, H, nullptr, 0, g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H,
                                                    g2 + 3 * RH + rN * H, h2p, H, dgi2 + rN * 3 * H, 3 * H, dgh2 + rN * 3 * H, dh2c, N, H, nullptr, 0);
-        {   // dh2c += dgh2 Whh2 ; dx2 = dgi2 Wih2   (one launch)
-            d3_gemm_prob p[2];
+        {   // dh2c += dgh2 Whh2 ; [datt | dh1 part] = dgi2 Wa ; dx2 = dgi2 Wih2 (off the chain)   (one launch)
+            d3_gemm_prob p[3];
             p[0] = td_prob(N, H, dh2c, H);
             p[0].nseg = 1; p[0].seg[0] = td_seg(dgh2 + rN * 3 * H, 3 * H, a->Whh2, H, 3 * H, nullptr, 0, 1); p[0].accum = 1;
-            p[1] = td_prob(N, E, dx2 + rN * E, E);
-            p[1].nseg = 1; p[1].seg[0] = td_seg(dgi2 + rN * 3 * H, 3 * H, a->Wih2, E, 3 * H, nullptr, 0, 1);
-            if ((rc = hg_launch(p, 2, s))) return rc;
-        }
-        {   // [datt | dh1 part] = dx2 W_lang
-            d3_gemm_prob p = td_prob(N, F + H, tmpL, F + H);
-            p.nseg = 1; p.seg[0] = td_seg(dx2 + rN * E, E, a->W_lang, ldlang, E, nullptr, 0, 1);
-            if ((rc = hg_launch(&p, 1, s))) return rc;
+            p[1] = td_prob(N, F + H, tmpL, F + H);
+            p[1].nseg = 1; p[1].seg[0] = td_seg(dgi2 + rN * 3 * H, 3 * H, Wa, F + H, 3 * H, nullptr, 0, 1);
+            p[2] = td_prob(N, E, dx2 + rN * E, E);
+            p[2].nseg = 1; p[2].seg[0] = td_seg(dgi2 + rN * 3 * H, 3 * H, a->Wih2, E, 3 * H, nullptr, 0, 1);
+            if ((rc = hg_launch(p, 3, s))) return rc;
         }
         td_attn_bwd_kernel<<<N, 256, (size_t)(F + K + 4) * 4, s>>>(tmpL, F + H, av + rN * K, att + rN * F, F, fp, q + rN * H, H, a->w_att,
                                                                  a->obj, act, nact, dq + rN * H, H, dfp, dwp + rN * H, dattS + rN * F, K, H, F);
@@ -649,20 +661,16 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         }
         td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dh1c, H, tmpL + F, F + H, dh1q, H, g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H,
                                                    g1 + 3 * RH + rN * H, h1p, H, dgi1 + rN * 3 * H, 3 * H, dgh1 + rN * 3 * H, dh1c, N, H, nullptr, 0);
-        {   // dh1c += dgh1 Whh1 ; dx1 = dgi1 Wih1
-            d3_gemm_prob p[2];
+        {   // dh1c += dgh1 Whh1 ; dh2c += dgi1 Wb ; dx1 = dgi1 Wih1 (off the chain)
+            d3_gemm_prob p[3];
             p[0] = td_prob(N, H, dh1c, H);
             p[0].nseg = 1; p[0].seg[0] = td_seg(dgh1 + rN * 3 * H, 3 * H, a->Whh1, H, 3 * H, nullptr, 0, 1); p[0].accum = 1;
-            p[1] = td_prob(N, E, dx1 + rN * E, E);
-            p[1].nseg = 1; p[1].seg[0] = td_seg(dgi1 + rN * 3 * H, 3 * H, a->Wih1, E, 3 * H, nullptr, 0, 1);
-            if ((rc = hg_launch(p, 2, s))) return rc;
+            p[1] = td_prob(N, H, dh2c, H);
+            p[1].nseg = 1; p[1].seg[0] = td_seg(dgi1 + rN * 3 * H, 3 * H, Wb, H, 3 * H, nullptr, 0, 1); p[1].accum = 1;
+            p[2] = td_prob(N, E, dx1 + rN * E, E);
+            p[2].nseg = 1; p[2].seg[0] = td_seg(dgi1 + rN * 3 * H, 3 * H, a->Wih1, E, 3 * H, nullptr, 0, 1);
+            if ((rc = hg_launch(p, 3, s))) return rc;
         }
-        {   // dh2c += dx1 W_td[:, E:E+H]
-            d3_gemm_prob p = td_prob(N, H, dh2c, H);
-            p.nseg = 1; p.seg[0] = td_seg(dx1 + rN * E, E, a->W_td + E, ldtd, E, nullptr, 0, 1); p.accum = 1;
-            if ((rc = hg_launch(&p, 1, s))) return rc;
-        }
-        (void)h1n;
     }
     // ---- weight gradients, batched over time (k-major operands, K = R rows)
     {
