@@ -44,6 +44,61 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float *__restrict
         if (pr < npair) part[(long long)blockIdx.x * npair + pr] = acc[q];
     }
 }
+// The same partial sums on v_mfma_f32_16x16x4_f32 (exact fp32 products): the scalar kernel above reads LDS twice per FMA and
+// runs at 1.1 TB/s (96 us at 746 k rows x (16 + 20) channels); here a wave owns a slice of its workgroup's rows and feeds the
+// MFMA straight from memory -- A[o][r] = dy[r][o] and B[r][i] = x[r][i] are both "16 consecutive channels of one row" per
+// 16-lane group -- the bias gradient rides along as a constant-one column of x; the four waves are summed through LDS.
+// part layout as above.  I <= 31 (one column is the bias), O <= 32.
+typedef float tw_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void tall_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                             float *__restrict__ part, int N, int I, int O) {
+    __shared__ float red[4][2][2][256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int I1 = I + 1, npair = O * I1;
+    const int per = ((N + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    const int r0 = blockIdx.x * per, r1 = min(N, r0 + per);
+    tw_f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ot = (O + 15) >> 4, it = (I1 + 15) >> 4;
+    for (int rb = r0 + wave * 16; rb < r1; rb += 64) {           // 16 rows per wave and step
+        float av[2][4], bv[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int r = rb + g * 4 + c;
+            const bool ok = r < r1;
+#pragma unroll
+            for (int a = 0; a < 2; a++) { const int o = a * 16 + i; av[a][c] = (ok && o < O) ? dy[(long long)r * O + o] : 0.f; }
+#pragma unroll
+            for (int b = 0; b < 2; b++) { const int col = b * 16 + i; bv[b][c] = !ok ? 0.f : (col < I ? x[(long long)r * I + col] : (col == I ? 1.f : 0.f)); }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            if (a >= ot) break;
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                if (b >= it) break;
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][c], bv[b][c], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[wave][a][b][q * 64 + lane] = acc[a][b][q];
+    __syncthreads();
+    // D layout: row (o) = g*4 + q, col (i) = lane & 15
+    for (int e = t; e < 2 * 2 * 256; e += 256) {
+        const int a = e >> 9, b = (e >> 8) & 1, q = (e >> 6) & 3, ln = e & 63;
+        const int o = a * 16 + (ln >> 4) * 4 + q, col = b * 16 + (ln & 15);
+        if (o < O && col < I1) part[(long long)blockIdx.x * npair + o * I1 + col] = (red[0][a][b][q * 64 + ln] + red[1][a][b][q * 64 + ln]) + (red[2][a][b][q * 64 + ln] + red[3][a][b][q * 64 + ln]);
+    }
+}
 // one wave per (o, i) pair; lanes stride over the workgroup partials, fp64 wave reduction in fixed order
 __global__ void tall_wgrad_reduce_kernel(const float *__restrict__ part, int nblocks, int I, int O, float *dW, float *db) {
     const int pr = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
@@ -70,7 +125,8 @@ extern "C" int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *
     int grid = TW_GRID;
     if (N < grid * TW_ROWS) grid = (N + TW_ROWS - 1) / TW_ROWS;
     if (grid < 1) grid = 1;
-    tall_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float *)ws, N, I, O);
+    if (I <= 31) tall_wgrad_mfma_kernel<<<grid, 256, 0, s>>>(x, dy, (float *)ws, N, I, O);
+    else tall_wgrad_kernel<<<grid, 256, 0, s>>>(x, dy, (float *)ws, N, I, O);
     const int npair = O * (I + 1);
     tall_wgrad_reduce_kernel<<<(npair + 3) / 4, 256, 0, s>>>((const float *)ws, grid, I, O, dW, db);
     D3_LAUNCH_CHECK();
