@@ -39,13 +39,19 @@ __global__ __launch_bounds__(256) void gm_edges_kernel(const float *__restrict__
     const long long Emax_total = (long long)gridDim.x * KL;
     for (int k = t; k < K; k += blockDim.x) valid[k] = mask[(long long)b * K + k] == 1.f ? 1 : 0;
     __syncthreads();
-    for (int r = t; r < K; r += blockDim.x) {
+    // one wave per adjacency row, lanes along the columns (a thread walking its own 1 KB row read it uncoalesced, twice: most
+    // of the kernel's 130 us at K = 256)
+    const int lane = t & 63, wave = t >> 6, nwv = blockDim.x >> 6;
+    for (int r = wave; r < K; r += nwv) {
         int c = 0;
         if (valid[r]) {
             const float *row = adj + ((long long)b * K + r) * K;
-            for (int j = 0; j < K; j++) c += (valid[j] && row[j] == 1.f) ? 1 : 0;
+            for (int j0 = 0; j0 < K; j0 += 64) {
+                const int j = j0 + lane;
+                c += __popcll(__ballot(j < K && valid[j < K ? j : 0] && row[j < K ? j : 0] == 1.f));
+            }
         }
-        rowcnt[r] = c < L ? c : L;     // an adjacency row holds exactly L ones (top-L of _query_locals)
+        if (lane == 0) rowcnt[r] = c < L ? c : L;     // an adjacency row holds exactly L ones (top-L of _query_locals)
     }
     __syncthreads();
     if (t == 0) {
@@ -70,17 +76,23 @@ __global__ __launch_bounds__(256) void gm_edges_kernel(const float *__restrict__
         pred_src[(long long)b * KL + e] = (E == n && e < n) ? (long long)b * KL + e : Emax_total;
     }
     __syncthreads();
-    for (int r = t; r < K; r += blockDim.x) {
-        out_start[(long long)b * K + r] = rowstart[r]; out_cnt[(long long)b * K + r] = rowcnt[r];
-        if (!valid[r] || rowcnt[r] == 0) continue;
+    for (int r = t; r < K; r += blockDim.x) { out_start[(long long)b * K + r] = rowstart[r]; out_cnt[(long long)b * K + r] = rowcnt[r]; }
+    for (int r = wave; r < K; r += nwv) {
+        if (!valid[r] || rowcnt[r] == 0) continue;          // wave-uniform
         const float *row = adj + ((long long)b * K + r) * K;
-        int e = rowstart[r], left = rowcnt[r];
-        for (int j = 0; j < K && left > 0; j++) {
-            if (valid[j] && row[j] == 1.f) {
+        int e0 = rowstart[r], taken = 0;
+        const int want = rowcnt[r];
+        for (int j0 = 0; j0 < K && taken < want; j0 += 64) {
+            const int j = j0 + lane;
+            const bool hit = j < K && valid[j < K ? j : 0] && row[j < K ? j : 0] == 1.f;
+            const unsigned long long bal = __ballot(hit);
+            const int pos = taken + (int)__popcll(bal & ((1ull << lane) - 1ull));   // column order == the serial walk's order
+            if (hit && pos < want) {
+                const int e = e0 + pos;
                 src[(long long)b * KL + e] = b * K + r; dst[(long long)b * KL + e] = b * K + j; dsts[e] = j;
                 if (e < n) { eidx[((long long)b * 2 + 0) * KL + e] = (float)cidx[r]; eidx[((long long)b * 2 + 1) * KL + e] = (float)cidx[j]; }
-                e++; left--;
             }
+            taken += (int)__popcll(bal);
         }
     }
     __syncthreads();
