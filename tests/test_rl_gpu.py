@@ -185,6 +185,22 @@ def test_device_cider_reward_matches_reference_golden_and_host_scorer(dev):
     assert np.allclose(got, want, rtol=1e-12, atol=1e-13), np.abs(got - want).max()
     assert want.max() > 0.1                                                                            # a non-trivial case
 
+    # long sentences: several 64-position rounds per n-gram order in cd_vec_kernel (descriptions go up to 126 tokens)
+    organized2 = {"s0": {str(o): [{"token": ["w%d" % int(t) for t in rng.integers(0, 9, int(rng.integers(60, 150)))]}
+                                  for _ in range(3)] for o in range(2)}}
+    corpus2 = CL.CiderCorpus(organized2, idx2word, dev)
+    assert corpus2.ok
+    keys2 = [("s0", "0"), ("s0", "1"), ("s0", "0")]
+    cands2 = [torch.from_numpy(rng.integers(0, 9, int(l)).astype(np.int64)).to(dev) for l in (70, 129, 3)]
+    out2 = CL._cider_device(corpus2, [corpus2.sets[k] for k in keys2], cands2, 1)
+    if out2 is not None:                                   # (a set beyond the LDS hash falls back to the host scorer: None)
+        refs2 = [[" ".join(dd_["token"] + ["eos"]) for dd_ in organized2[k[0]][k[1]]] for k in keys2]
+        cs2 = [" ".join([idx2word[str(int(t))] for t in c.tolist()] + ["eos"]) for c in cands2]
+        _, want2 = pcider.cider_scores(refs2, cs2)
+        assert np.allclose(out2.cpu().numpy(), want2, rtol=1e-12, atol=1e-13), np.abs(out2.cpu().numpy() - want2).max()
+    else:
+        assert 4 * sum(len(d_["token"]) + 1 for d_ in organized2["s0"]["0"]) > CL.CiderCorpus.MAX_SET_NGRAMS
+
 
 def test_native_beam_search_with_teacher_forced_replay_equals_library_search(dev):
     """TopDownSceneCaptionModule.beam_decode on the native decode step + one teacher-forced replay of the returned beams
