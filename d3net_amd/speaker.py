@@ -499,7 +499,9 @@ class TopDownSceneCaptionModule(nn.Module):
             for t in range(max_len):
                 live = logp.shape[1]
                 cand = (sums.unsqueeze(-1) + logp).reshape(N, live * V)
-                ix = torch.sort(cand, -1, True)[1][:, :b]                   # full sort as the reference (:181-182)
+                # the b best of the live*V candidates, best first: what the reference's full descending sort (:181-182) keeps
+                # (an exact tie between two candidates' float scores is the only way the two could order differently)
+                ix = torch.topk(cand, b, dim=-1, largest=True, sorted=True)[1]
                 beam_ix, tok = ix // V, ix % V
                 if t > 0:
                     seq = seq.gather(1, beam_ix.unsqueeze(-1).expand_as(seq))
