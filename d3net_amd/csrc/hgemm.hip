@@ -26,6 +26,7 @@
 // Roofline: these GEMMs are latency / launch bound at M = 32 (0.3 GFLOP per decode step); the batched ones (classifier
 // over all time steps: 992 x 512 x 3004) are bound by the fp32 matrix rate.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -142,6 +143,102 @@ __global__ __launch_bounds__(NW * 64) void hg_gemm_kernel(const HgBatch batch) {
     }
 }
 
+// Tall problems (the batched ones: classifier over all time steps 992 x 512 x 3004 and its two gradients, feature projections
+// over B*K rows, the EdgeConv message MLPs): the wave-per-tile kernel above re-reads A once per 16-column tile and B once per
+// 64-row group straight from L2 (480 MB for the classifier forward: L2 bound at ~17 TFLOP/s).  Here a workgroup owns a 64 x 64
+// tile of C and stages 16-deep slabs of both operands through LDS (k-major images: the MFMA fragment of a lane group is 16
+// consecutive rows / columns of one k), the next slab's global loads in flight behind the current slab's MFMAs; each wave
+// computes a 32 x 32 quarter (2 x 2 MFMA tiles).  Same operand forms (row gather, k-major, segments) and epilogues.
+#define HT_BM 64
+#define HT_BN 64
+#define HT_BK 32     // two 16-deep k quads per thread and slab: every slab costs one memory round trip, 3 workgroups per CU at 992 x 3004
+#define HT_KQ (HT_BK / 16)
+#define HT_LD 72      // LDS row pitch: 4 consecutive k rows land 8 banks apart (two lanes per bank: the minimum for 64 x 4 B)
+__global__ __launch_bounds__(256) void hg_gemm_tiled_kernel(const HgBatch batch) {
+    __shared__ float As[2][HT_BK][HT_LD], Bs[2][HT_BK][HT_LD];
+    const d3_gemm_prob &p = batch.p[blockIdx.z];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * HT_BM, n0 = blockIdx.x * HT_BN;
+    if (m0 >= p.M || n0 >= p.N) return;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;        // this wave's quarter
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging assignment: thread -> (row r of the tile, 4 consecutive k) of A and of B: 64 rows x 4 k-quads = 256 threads
+    const int sr = t >> 2, sk = (t & 3) * 4;
+    f32x4 ra[HT_KQ], rb[HT_KQ];
+    auto fetch = [&](const d3_gemm_seg &sg, int kb) {
+        const int row = m0 + sr, col = n0 + sr;
+        const bool av = row < p.M, bv = col < p.N;
+        const long long ar = av ? (sg.ia ? (long long)sg.ia[row] : (long long)row) : 0;
+        const float *ab = sg.a_kmajor ? sg.A + ar : sg.A + ar * sg.lda;
+        const float *bb = sg.b_kmajor ? sg.B + (bv ? col : 0) : sg.B + (long long)(bv ? col : 0) * sg.ldb;
+        const int avec = (!sg.a_kmajor && (sg.lda & 3) == 0 && (((size_t)sg.A) & 15) == 0) ? 1 : 0;
+        const int bvec = (!sg.b_kmajor && (sg.ldb & 3) == 0 && (((size_t)sg.B) & 15) == 0) ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < HT_KQ; u++) {
+            const int k0 = kb * HT_BK + u * 16 + sk;
+            ra[u] = hg_load4(ab, sg.lda, sg.a_kmajor, avec, k0, sg.K, av);
+            rb[u] = hg_load4(bb, sg.ldb, sg.b_kmajor, bvec, k0, sg.K, bv);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < HT_KQ; u++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { As[buf][u * 16 + sk + c][sr] = ra[u][c]; Bs[buf][u * 16 + sk + c][sr] = rb[u][c]; }
+    };
+    // flat list of (segment, k slab)
+    int nslab = 0;
+    for (int s = 0; s < p.nseg; s++) nslab += (p.seg[s].K + HT_BK - 1) / HT_BK;
+    auto locate = [&](int slab, int &sidx, int &kb) {
+        sidx = 0; kb = slab;
+        while (sidx < p.nseg - 1 && kb >= (p.seg[sidx].K + HT_BK - 1) / HT_BK) { kb -= (p.seg[sidx].K + HT_BK - 1) / HT_BK; sidx++; }
+    };
+    int sidx, kb;
+    locate(0, sidx, kb);
+    fetch(p.seg[sidx], kb);
+    stash(0);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; slab++) {
+        const int buf = slab & 1;
+        if (slab + 1 < nslab) { locate(slab + 1, sidx, kb); fetch(p.seg[sidx], kb); }      // in flight behind the MFMAs below
+#pragma unroll
+        for (int q = 0; q < HT_BK / 4; q++) {
+            float a[2], b[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) a[mt] = As[buf][q * 4 + g][wm + mt * 16 + i];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) b[nt] = Bs[buf][q * 4 + g][wn + nt * 16 + i];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (slab + 1 < nslab) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: D layout col = lane & 15, row = (lane >> 4) * 4 + q
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = m0 + wm + mt * 16 + g * 4 + q, c = n0 + wn + nt * 16 + i;
+                if (row >= p.M || c >= p.N) continue;
+                float v = acc[mt][nt][q];
+                if (p.bias) v += p.bias[c];
+                if (p.add) v += p.add[(long long)row * p.ldadd + c];
+                if (p.relu && v < 0.f) v = 0.f;
+                const long long orow = p.perm_nb > 0 ? (long long)(row % p.perm_nb) * p.perm_s + row / p.perm_nb : (long long)row;
+                float *o = p.C + orow * p.ldc + c;
+                *o = p.accum ? *o + v : v;
+            }
+}
+
 static int hg_check(const d3_gemm_prob &p) {
     if (p.nseg < 1 || p.nseg > 3 || p.M < 0 || p.N < 1 || !p.C) return D3_ERR_ARG;
     for (int s = 0; s < p.nseg; s++)
@@ -183,7 +280,10 @@ int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
         if (tiles16 < 2048) {    // few tiles: still split K so that the chip is covered
             HG_SPLIT(2, (maxM + 31) / 32);
         } else {
-            hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
+            static int tiled = -1;
+            if (tiled < 0) { const char *e = getenv("D3_HG_TILED"); tiled = (e && e[0] == '0') ? 0 : 1; }   // (A/B)
+            if (tiled) hg_gemm_tiled_kernel<<<dim3((ctiles * 16 + HT_BN - 1) / HT_BN, (maxM + HT_BM - 1) / HT_BM, nprobs), 256, 0, s>>>(b);
+            else hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
         }
     }
 #undef HG_SPLIT
