@@ -146,16 +146,16 @@ __global__ __launch_bounds__(NW * 64) void hg_gemm_kernel(const HgBatch batch) {
 // Tall problems (the batched ones: classifier over all time steps 992 x 512 x 3004 and its two gradients, feature projections
 // over B*K rows, the EdgeConv message MLPs): the wave-per-tile kernel above re-reads A once per 16-column tile and B once per
 // 64-row group straight from L2 (480 MB for the classifier forward: L2 bound at ~17 TFLOP/s).  Here a workgroup owns a 64 x 64
-// tile of C and stages 16-deep slabs of both operands through LDS (k-major images: the MFMA fragment of a lane group is 16
-// consecutive rows / columns of one k), the next slab's global loads in flight behind the current slab's MFMAs; each wave
+// tile of C and stages 32-deep slabs of both operands through LDS (row-major, one 16-byte read per lane feeds four MFMAs),
+// the next slab's global loads in flight behind the current slab's MFMAs; each wave
 // computes a 32 x 32 quarter (2 x 2 MFMA tiles).  Same operand forms (row gather, k-major, segments) and epilogues.
 #define HT_BM 64
 #define HT_BN 64
 #define HT_BK 32     // two 16-deep k quads per thread and slab: every slab costs one memory round trip, 3 workgroups per CU at 992 x 3004
 #define HT_KQ (HT_BK / 16)
-#define HT_LD 72      // LDS row pitch: 4 consecutive k rows land 8 banks apart (two lanes per bank: the minimum for 64 x 4 B)
+#define HT_RP (HT_BK + 4)   // LDS row pitch (floats) of the row-major operand slabs: 16-byte aligned rows, 16 lanes of a k quad on distinct banks
 __global__ __launch_bounds__(256) void hg_gemm_tiled_kernel(const HgBatch batch) {
-    __shared__ float As[2][HT_BK][HT_LD], Bs[2][HT_BK][HT_LD];
+    __shared__ __attribute__((aligned(16))) float As[2][HT_BM][HT_RP], Bs[2][HT_BN][HT_RP];
     const d3_gemm_prob &p = batch.p[blockIdx.z];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * HT_BM, n0 = blockIdx.x * HT_BN;
@@ -186,9 +186,7 @@ __global__ __launch_bounds__(256) void hg_gemm_tiled_kernel(const HgBatch batch)
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < HT_KQ; u++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) { As[buf][u * 16 + sk + c][sr] = ra[u][c]; Bs[buf][u * 16 + sk + c][sr] = rb[u][c]; }
+        for (int u = 0; u < HT_KQ; u++) { *(f32x4 *)&As[buf][sr][u * 16 + sk] = ra[u]; *(f32x4 *)&Bs[buf][sr][u * 16 + sk] = rb[u]; }
     };
     // flat list of (segment, k slab)
     int nslab = 0;
@@ -206,16 +204,19 @@ __global__ __launch_bounds__(256) void hg_gemm_tiled_kernel(const HgBatch batch)
         const int buf = slab & 1;
         if (slab + 1 < nslab) { locate(slab + 1, sidx, kb); fetch(p.seg[sidx], kb); }      // in flight behind the MFMAs below
 #pragma unroll
-        for (int q = 0; q < HT_BK / 4; q++) {
-            float a[2], b[2];
+        for (int u = 0; u < HT_KQ; u++) {
+            // lane (i, g): four consecutive k (u*16 + g*4 ..) of row / column i -- one 16-byte LDS read feeds four MFMAs
+            f32x4 a[2], b[2];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) a[mt] = As[buf][q * 4 + g][wm + mt * 16 + i];
+            for (int mt = 0; mt < 2; mt++) a[mt] = *(const f32x4 *)&As[buf][wm + mt * 16 + i][u * 16 + g * 4];
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) b[nt] = Bs[buf][q * 4 + g][wn + nt * 16 + i];
+            for (int nt = 0; nt < 2; nt++) b[nt] = *(const f32x4 *)&Bs[buf][wn + nt * 16 + i][u * 16 + g * 4];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q], b[nt][q], acc[mt][nt], 0, 0, 0);
         }
         if (slab + 1 < nslab) stash(buf ^ 1);
         __syncthreads();
