@@ -561,7 +561,15 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             }
         }
     }
-    hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
+    {   // weight gradients are off the critical path: lowest priority, so the data-gradient chain of the caller's stream wins
+        // when both want the machine (D3_SIDE_PRIO=0: plain stream)
+        int lo = 0, hi = 0;
+        const char *e = getenv("D3_SIDE_PRIO");
+        if (!(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo);
+        else
+            hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
+    }
     return n;
 }
 
