@@ -199,6 +199,17 @@ class LangModule(nn.Module):
 
 
 # --------------------------------------------------------------------------------------------- match
+class PointwiseConv1d(nn.Conv1d):
+    """`nn.Conv1d(cin, cout, 1)` with the same parameters and state-dict keys, computed as the channel GEMM it is.  Through the
+    convolution library a kernel-size-1 Conv1d on (B*C, 128, 128) runs a generic convolution forward (84-360 us per call) and a
+    NAIVE weight-gradient kernel (`naive_conv_ab_nonpacked_wrw...`: 0.33 ms per call in the listener step, 1.85 ms in the
+    joint one: profiles/r02_ac_kernel_stats_*.csv); as a matmul it is a few microseconds of batched GEMM either way."""
+
+    def forward(self, x):
+        y = torch.matmul(self.weight.squeeze(-1), x)            # (cout, cin) @ (B, cin, L) -> (B, cout, L)
+        return y if self.bias is None else y + self.bias.view(1, -1, 1)
+
+
 class TransformerMatchModule(nn.Module):
     """(reference: model/match_module.py:143-336)"""
 
@@ -211,12 +222,12 @@ class TransformerMatchModule(nn.Module):
         self.det_channel = cfg.model.m
         self.chunk_size = cfg.data.num_des_per_scene
         self.features_concat = nn.Sequential(
-            nn.Conv1d(self.det_channel, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(hidden_size),
-            nn.Conv1d(hidden_size, hidden_size, 1))
+            PointwiseConv1d(self.det_channel, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(hidden_size),
+            PointwiseConv1d(hidden_size, hidden_size, 1))
         self.match = nn.Sequential(
-            nn.Conv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(),
-            nn.Conv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(),
-            nn.Conv1d(hidden_size, 1, 1))
+            PointwiseConv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(),
+            PointwiseConv1d(hidden_size, hidden_size, 1), nn.BatchNorm1d(hidden_size), nn.PReLU(),
+            PointwiseConv1d(hidden_size, 1, 1))
         self.lang_fc = nn.Sequential(nn.Linear(lang_size, hidden_size), nn.ReLU(), nn.Dropout(p=0.1), nn.LayerNorm(hidden_size))
         self.lang_self_attn = MultiHeadAttention(d_model=hidden_size, d_k=16, d_v=16, h=head)
         dh = hidden_size // head
