@@ -199,6 +199,10 @@ class LangModule(nn.Module):
 
 
 # --------------------------------------------------------------------------------------------- match
+import os as _os
+_CONV1D_LIB = _os.environ.get("D3_CONV1D_LIB") == "1"      # (A/B measurements: the convolution-library path)
+
+
 class PointwiseConv1d(nn.Conv1d):
     """`nn.Conv1d(cin, cout, 1)` with the same parameters and state-dict keys, computed as the channel GEMM it is.  Through the
     convolution library a kernel-size-1 Conv1d on (B*C, 128, 128) runs a generic convolution forward (84-360 us per call) and a
@@ -206,6 +210,8 @@ class PointwiseConv1d(nn.Conv1d):
     joint one: profiles/r02_ac_kernel_stats_*.csv); as a matmul it is a few microseconds of batched GEMM either way."""
 
     def forward(self, x):
+        if _CONV1D_LIB:
+            return super().forward(x)
         y = torch.matmul(self.weight.squeeze(-1), x)            # (cout, cin) @ (B, cin, L) -> (B, cout, L)
         return y if self.bias is None else y + self.bias.view(1, -1, 1)
 
