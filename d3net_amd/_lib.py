@@ -86,6 +86,7 @@ SIGNATURES = {
     "d3_offset_loss_ws_bytes": (sz, []),
     "d3_offset_loss": (i32, [vp, vp, vp, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),
     "d3_scatter_add_rows": (i32, [vp, vp, vp, i64, i32, vp]),
+    "d3_gather_rows": (i32, [vp, vp, vp, i64, i32, vp]),
     "d3_cross_entropy_ws_bytes": (sz, []),
     "d3_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "d3_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

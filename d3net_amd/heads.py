@@ -74,6 +74,17 @@ def cross_entropy(z, label, ignore_index=-100):
     return torch.nn.functional.cross_entropy(z, label, ignore_index=ignore_index)
 
 
+def _gather_rows(feats, idx):
+    """feats[idx] (idx int64) through d3_gather_rows; library index_select for shapes the kernel does not take"""
+    if not (feats.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32 and feats.is_contiguous() and feats.size(1) % 4 == 0
+            and idx.dtype == torch.int64 and idx.dim() == 1):
+        return feats.index_select(0, idx)
+    out = torch.empty((idx.numel(), feats.size(1)), dtype=feats.dtype, device=feats.device)
+    with _on(feats.device):
+        check(_lib.lib().d3_gather_rows(_ptr(feats), _ptr(idx.contiguous()), _ptr(out), idx.numel(), feats.size(1), _stream()), "gather_rows")
+    return out
+
+
 class _Devoxelize(Function):
     """feats[p2v] with the backward as a rule-ordered per-voxel sum over v2p (deterministic, no atomics) instead of the
     library's sort-based index_put backward"""
@@ -82,7 +93,7 @@ class _Devoxelize(Function):
     def forward(ctx, feats, p2v, v2p):
         ctx.save_for_backward(v2p)
         ctx.M = feats.size(0)
-        return feats.index_select(0, p2v)
+        return _gather_rows(feats, p2v)
 
     @staticmethod
     def backward(ctx, dpt):
@@ -236,7 +247,7 @@ class _GatherRows(Function):
     def forward(ctx, feats, idx):
         ctx.save_for_backward(idx)
         ctx.rows = feats.size(0)
-        return feats.index_select(0, idx)
+        return _gather_rows(feats, idx)
 
     @staticmethod
     def backward(ctx, g):

@@ -342,6 +342,8 @@ int d3_adamw(const long long *ptrs, const int *numel, const void *blocks, int nb
 /* out[idx[s], :] += g[s, :] (out zero-filled by the caller): backward of the cluster feature gather
  * (model/pointgroup.py:130); deterministic when every output row receives at most two addends, as it does there */
 int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream);
+/* out (S,C) = feats[idx]: the forward of the same gathers (C % 4 == 0) */
+int d3_gather_rows(const float *feats, const int64_t *idx, float *out, long long S, int C, void *stream);
 size_t d3_cross_entropy_ws_bytes(void);
 int d3_cross_entropy(const float *z, const int64_t *label, float *grad, float *out, int N, int C, int ignore_index,
                      void *ws, size_t ws_bytes, void *stream);
