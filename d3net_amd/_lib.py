@@ -33,6 +33,7 @@ SIGNATURES = {
     "d3_roipool_bp": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "d3_get_iou": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     "d3_voxelize_fp": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "d3_voxelize_fp2": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]),
     "d3_voxelize_bp": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "d3_point_recover_fp": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "d3_point_recover_bp": (i32, [vp, vp, vp, i32, i32, i32, vp]),

@@ -51,6 +51,45 @@ __global__ void voxelize_fp_kernel(const float *__restrict__ feats, float *__res
     out[e] = acc;
 }
 
+// The input pooling of PointGroup.feed (model/pointgroup.py:468-471): voxelization(cat(feats, locs), v2p_map) without the
+// concatenated (N, Ca+Cb) copy and without the zero-filled accumulator read back (0.8 GB of traffic for the 4-scene batch):
+// plane < Ca reads feats_a, else feats_b; the sum starts at +0 like the zero-initialised output of the reference's wrapper.
+__global__ void voxelize_fp2_kernel(const float *__restrict__ fa, int Ca, const float *__restrict__ fb, int Cb, float *__restrict__ out,
+                                    const int *__restrict__ rules, long long total, int maxActive, bool average) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int nPlanes = Ca + Cb;
+    const int row = (int)(e / nPlanes), plane = (int)(e % nPlanes);
+    const int *r = rules + (long long)row * (maxActive + 1);
+    const bool ina = plane < Ca;
+    const float *src = ina ? fa : fb;
+    const int ld = ina ? Ca : Cb, col = ina ? plane : plane - Ca;
+    const int nActive = r[0];
+    int id[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) id[j] = r[j < maxActive ? 1 + j : 0];
+    float acc = 0.f;
+    const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = src[(long long)(j < nActive ? id[j] : 0) * ld + col];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < nActive) acc = __fadd_rn(acc, __fmul_rn(multiplier, v[j]));
+    for (int i0 = 5; i0 <= nActive; i0 += 8) {
+        int idn[8];
+        float vn[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) idn[j] = r[i0 + j <= nActive ? i0 + j : 0];
+#pragma unroll
+        for (int j = 0; j < 8; j++) vn[j] = src[(long long)(i0 + j <= nActive ? idn[j] : 0) * ld + col];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (i0 + j <= nActive) acc = __fadd_rn(acc, __fmul_rn(multiplier, vn[j]));
+    }
+    out[e] = acc;
+}
+
 // scatter: d_feats[r[i], plane] += multiplier * d_out[row, plane]   (voxelize.cu:35-53)
 __global__ void voxelize_bp_kernel(const float *__restrict__ d_out, float *__restrict__ d_feats,
                                    const int *__restrict__ rules, long long total, int maxActive, int nPlanes,
@@ -95,6 +134,17 @@ extern "C" int d3_voxelize_fp(const float *feats, float *output_feats, const int
                               int maxActive, int nPlane, void *stream) {
     D3_CLEAR();
     return launch_fp(feats, output_feats, output_map, nActive, maxActive, nPlane, mode == 4, stream);
+}
+extern "C" int d3_voxelize_fp2(const float *feats_a, int Ca, const float *feats_b, int Cb, float *output_feats, const int *output_map,
+                               int mode, int nActive, int maxActive, void *stream) {
+    D3_CLEAR();
+    if (Ca < 1 || Cb < 0) return D3_ERR_ARG;
+    const long long total = (long long)nActive * (Ca + Cb);
+    if (total <= 0) return 0;
+    voxelize_fp2_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(feats_a, Ca, feats_b, Cb, output_feats, output_map, total,
+                                                                                 maxActive, mode == 4);
+    D3_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int d3_voxelize_bp(const float *d_output_feats, float *d_feats, const int *output_map, int mode,
                               int nActive, int maxActive, int nPlane, void *stream) {

@@ -494,10 +494,15 @@ class PointGroup(nn.Module):
     def feed(self, data_dict, epoch=0):
         """(reference :466-479)"""
         data_dict["epoch"] = epoch
-        if self.cfg.model.use_coords:
-            data_dict["feats"] = torch.cat((data_dict["feats"], data_dict["locs"]), 1)
-        data_dict["voxel_feats"] = pointgroup_ops.voxelization(data_dict["feats"].contiguous(), data_dict["v2p_map"],
-                                                               self.cfg.data.mode)
+        f = data_dict["feats"]
+        if self.cfg.model.use_coords and f.is_cuda and f.dtype == torch.float32 and not f.requires_grad:
+            # voxelization(cat(feats, locs)) without the concatenated copy (csrc/voxelize.hip: d3_voxelize_fp2)
+            data_dict["voxel_feats"] = pointgroup_ops.voxelization_cat(f, data_dict["locs"], data_dict["v2p_map"], self.cfg.data.mode)
+        else:
+            if self.cfg.model.use_coords:
+                data_dict["feats"] = torch.cat((data_dict["feats"], data_dict["locs"]), 1)
+            data_dict["voxel_feats"] = pointgroup_ops.voxelization(data_dict["feats"].contiguous(), data_dict["v2p_map"],
+                                                                   self.cfg.data.mode)
         data_dict = self.forward(data_dict)
         if data_dict["epoch"] > self.prepare_epochs or self.freeze_backbone:
             data_dict = self.convert_stack_to_batch(data_dict, perms=data_dict.get("slot_perms"))

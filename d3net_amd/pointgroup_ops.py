@@ -409,6 +409,21 @@ class SecMax(Function):
 sec_max = SecMax.apply
 
 
+def voxelization_cat(feats_a, feats_b, map_rule, mode=4):
+    """voxelization(torch.cat((feats_a, feats_b), 1), map_rule, mode) for inputs that need no gradient (the network input:
+    model/pointgroup.py:468-471), without the concatenated copy (d3_voxelize_fp2)"""
+    assert map_rule.is_contiguous() and map_rule.is_cuda and map_rule.dtype == torch.int32
+    assert feats_a.is_cuda and feats_a.dtype == torch.float32 and feats_b.dtype == torch.float32 and feats_a.size(0) == feats_b.size(0)
+    assert not feats_a.requires_grad and not feats_b.requires_grad
+    feats_a, feats_b = feats_a.contiguous(), feats_b.contiguous()
+    M, maxActive = map_rule.size(0), map_rule.size(1) - 1
+    out = torch.empty((M, feats_a.size(1) + feats_b.size(1)), dtype=torch.float32, device=feats_a.device)
+    with _on(feats_a.device):
+        check(_lib.lib().d3_voxelize_fp2(_ptr(feats_a), feats_a.size(1), _ptr(feats_b), feats_b.size(1), _ptr(out), _ptr(map_rule),
+                                         int(mode), M, maxActive, _stream()), "voxelize_fp2")
+    return out
+
+
 def cluster_select(locs, pt_offsets, semantic_preds, batch_idxs, object_idxs):
     """-> batch_idxs_ (n) int32, coords_ (n,3), shifted (n,3) = coords_ + offsets_, semantic_preds_ (n) int32 of the object points
     (d3_cluster_select: model/pointgroup.py:288-296 in one pass)"""

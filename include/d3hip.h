@@ -77,6 +77,10 @@ int d3_get_iou(const int *proposals_idx, const int *proposals_offset, const int6
  * accumulated into (the caller zero-fills them, as functions/pointgroup_ops.py:57,70 do). */
 int d3_voxelize_fp(const float *feats, float *output_feats, const int *output_map, int mode, int nActive,
                    int maxActive, int nPlane, void *stream);
+/* voxelize_fp of the column concatenation [feats_a | feats_b] without materialising it; writes (does not accumulate into)
+ * output_feats (M, Ca+Cb): PointGroup.feed's `voxelization(cat(feats, locs), v2p_map)` (model/pointgroup.py:468-471) */
+int d3_voxelize_fp2(const float *feats_a, int Ca, const float *feats_b, int Cb, float *output_feats, const int *output_map, int mode,
+                    int nActive, int maxActive, void *stream);
 int d3_voxelize_bp(const float *d_output_feats, float *d_feats, const int *output_map, int mode, int nActive,
                    int maxActive, int nPlane, void *stream);
 int d3_point_recover_fp(const float *feats, float *output_feats, const int *idx_map, int nActive,

@@ -413,3 +413,18 @@ def test_cluster_select_and_merge_equal_the_library_op_chain(dev):
         ref = (torch.cat((a, b), 0), torch.cat((o1, o2s[1:])), torch.cat((ba, bb[1:])))
         for g, r in zip(got, ref):
             assert g.dtype == r.dtype and torch.equal(g, r), (nc1, nc2, g.shape, r.shape)
+
+
+def test_voxelization_of_a_column_concatenation_without_the_copy(dev):
+    """d3_voxelize_fp2 == voxelization(cat(feats, locs)) bit for bit (modes mean / sum, crowded voxels)"""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(2)
+    N = 30000
+    coords = torch.from_numpy(np.concatenate([np.zeros((N, 1)), rng.integers(0, 14, (N, 3))], 1).astype(np.int64)).to(dev)
+    feats = torch.from_numpy(rng.standard_normal((N, 131)).astype(np.float32)).to(dev)
+    locs = torch.from_numpy(rng.random((N, 3)).astype(np.float32)).to(dev)
+    for mode in (4, 3):
+        _, _, v2p = P.voxelization_idx(coords, 1, mode)
+        ref = P.voxelization(torch.cat((feats, locs), 1).contiguous(), v2p, mode)
+        got = P.voxelization_cat(feats, locs, v2p, mode)
+        assert int(v2p[:, 0].max()) > 8 and torch.equal(got, ref)
