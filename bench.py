@@ -206,7 +206,13 @@ def main():
         broadcast_module(model)
     # the executors' flat gradient buffers are all-reduced in place (RCCL, sum -> mean); the other parameters share one
     # packed collective; the bucket layout is static (identical on every rank whatever its scenes produce)
-    grad_sync = BucketGradAllReduce(params, detector) if world > 1 else None
+    # -- and the speaker / listener heads' bucket starts from inside the backward, as soon as it crosses into the detector
+    grad_sync = None
+    if world > 1:
+        det_ids = {id(p) for p in detector.parameters()}
+        grad_sync = BucketGradAllReduce(params, detector, early=[p for p in params if id(p) not in det_ids])
+        if model is not detector:
+            model.grad_boundary = grad_sync
 
     batch = S.make_batch(scenes, dev)
     if config != "detector":
@@ -350,6 +356,10 @@ def main():
                                        "achieved": (v["bytes"] / max(v["total_ms"], 1e-9)) / 1e6}
                                    for k, v in prof.items() if k != dom}},
         }
+        if grad_sync is not None:
+            out["config"]["grad_sync"] = {"collectives_per_step": 1 + len(detector.static_gradient_buckets()) + (1 if grad_sync.early else 0),
+                                          "heads_bucket_floats": sum(p.numel() for p in grad_sync.early),
+                                          "heads_bucket_started_inside_backward": grad_sync.early_launches}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config)
         print(json.dumps(out), flush=True)

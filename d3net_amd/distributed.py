@@ -5,6 +5,8 @@ strategy="ddp_find_unused_parameters_false"`), i.e. bucketed gradient all-reduce
 (SURVEY.md section 8e).  Here: one fused all-reduce of a flat gradient buffer per step over RCCL/xGMI
 (backend "nccl" on ROCm), averaged over ranks; BatchNorm statistics stay per rank, as in the reference.
 Works on any backend (the CPU tests use gloo)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -71,11 +73,69 @@ class BucketGradAllReduce:
     `owner`: an object with `static_gradient_buckets()` -> [(flat tensor, [parameters], executor)] (PointGroup), or --
     legacy form used by the CPU tests -- a callable returning ([flat tensors], [covered parameters])."""
 
-    def __init__(self, params, owner):
+    def __init__(self, params, owner, early=()):
         self.params = [p for p in params if p.requires_grad]
         self.owner = owner
         self._checked = False
         self._rest = None
+        # overlap with the backward: `early` = parameters whose gradients are complete before the detector's backward
+        # starts (the speaker / listener heads: their nodes were created after every detector node, so the autograd
+        # engine -- highest sequence number first -- has run all of them when it reaches a GradBoundary placed on the
+        # detector's outputs).  Their bucket is then packed and all-reduced from the backward itself
+        # (boundary_reached) and runs on the collective stream underneath the U-Net backward; a step in which the
+        # boundary is never reached (no proposals, no gradient into the detector) issues the same collective from
+        # __call__ instead, so every rank still issues the same collectives in the same order.
+        ids = {id(p) for p in self.params}
+        self.early = [p for p in early if id(p) in ids] if os.environ.get("D3_EARLY_ALLREDUCE", "1") != "0" else []
+        self._expected = 0
+        self._fired = 0
+        self._early_work = None
+        self.early_launches = 0     # steps whose heads bucket started inside backward()
+
+    # ---- early bucket -------------------------------------------------------------------------------------------
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def boundary(self, *tensors):
+        """Identity on the detector's outputs that marks, in the autograd graph, the point below which no `early`
+        parameter receives gradient any more.  Call once per detector pass of the step, on every output that carries
+        gradient into the detector; returns the tensors to hand to the heads."""
+        live = [i for i, t in enumerate(tensors) if t.requires_grad]
+        if not self.early or not self._active() or not torch.is_grad_enabled() or not live:
+            return tensors
+        self._expected += 1
+        out = list(tensors)
+        for i, t in zip(live, _GradBoundary.apply(self, *[tensors[i] for i in live])):
+            out[i] = t
+        return tuple(out)
+
+    def boundary_reached(self):
+        self._fired += 1
+        # (not before the first __call__ has compared the layout across ranks and probed ReduceOp.AVG: those are
+        # collectives too, and every rank must issue them in the same position)
+        if self._checked and self._fired == self._expected and self._early_work is None:   # the last pass' boundary
+            self._launch_early()
+            self.early_launches += 1
+
+    def _launch_early(self):
+        dev = self.early[0].device
+        avg = _avg_supported(dev)
+        packed = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.early])
+        work = dist.all_reduce(packed, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._early_work = (work, packed, avg)
+
+    def _finish_early(self, world):
+        work, packed, avg = self._early_work
+        work.wait()
+        if not avg:
+            packed.div_(world)
+        for p, v in zip(self.early, packed.split([p.numel() for p in self.early])):
+            if p.grad is None:
+                p.grad = v.view_as(p).clone()
+            else:
+                p.grad.copy_(v.view_as(p))
+        self._early_work = None
+        self._expected = self._fired = 0
 
     def _buckets(self):
         if hasattr(self.owner, "static_gradient_buckets"):
@@ -100,11 +160,16 @@ class BucketGradAllReduce:
         buckets = self._buckets()
         if self._rest is None:
             cov = {id(p) for _, ps, _ in buckets for p in ps}
+            self.early = [p for p in self.early if id(p) not in cov]
+            cov |= {id(p) for p in self.early}
             self._rest = [p for p in self.params if id(p) not in cov]
         rest = self._rest
-        dev = buckets[0][0].device if buckets else rest[0].device
+        dev = buckets[0][0].device if buckets else (rest[0] if rest else self.early[0]).device
         if not self._checked:
-            self._check_signature([f.numel() for f, _, _ in buckets] + [sum(p.numel() for p in rest)], dev)
+            self._check_signature([sum(p.numel() for p in self.early)] + [f.numel() for f, _, _ in buckets]
+                                  + [sum(p.numel() for p in rest)], dev)
+        if self.early and self._early_work is None:   # the boundary was not reached in this step's backward: same collective, now
+            self._launch_early()
         # RCCL averages inside the collective (no extra pass over the 31 MB buffer); gloo (the CPU tests) has no AVG
         avg = _avg_supported(dev)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
@@ -127,6 +192,23 @@ class BucketGradAllReduce:
             w.wait()
             if not avg:
                 flat.div_(world)
+        if self.early:
+            self._finish_early(world)
+
+
+class _GradBoundary(torch.autograd.Function):
+    """identity; its backward tells the reducer that the backward pass has left the heads"""
+
+    @staticmethod
+    def forward(ctx, reducer, *tensors):
+        ctx.reducer = reducer
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.reducer.boundary_reached()
+        return (None,) + grads
 
 
 def broadcast_module(module, src=0):

@@ -98,7 +98,14 @@ class PipelineNet(nn.Module):
     def _detect(self, data_dict):
         data_dict = self.detector.feed(data_dict, self.current_epoch)
         _, data_dict = self.detector.parse_feed_ret(data_dict, self.current_epoch)
-        return self.detector.loss(data_dict, self.current_epoch)
+        data_dict = self.detector.loss(data_dict, self.current_epoch)
+        gb = self.__dict__.get("grad_boundary")
+        if gb is not None and torch.is_tensor(data_dict.get("proposal_feats_batched")):
+            # multi-GPU: everything the heads hand back to the detector comes through the proposal features; when the
+            # backward pass crosses this point the heads' gradients are complete and their all-reduce can start
+            # underneath the detector's backward (distributed.BucketGradAllReduce.boundary)
+            data_dict["proposal_feats_batched"], = gb.boundary(data_dict["proposal_feats_batched"])
+        return data_dict
 
     def training_step(self, data_dict, idx=0):
         self.logged = {}

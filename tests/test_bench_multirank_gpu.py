@@ -24,3 +24,11 @@ def test_two_rank_bench_line(dev):
     assert out["value"] > 0 and out["final_loss"] == out["final_loss"]          # finite
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
     assert "cpu_baseline" not in out                                            # rank 0 at N=1 only
+    # the heads' bucket starts from inside backward() in every step after the first (which compares the layouts first):
+    # 1 dry-run + 1 warm-up + 2 timed steps -> 3 early starts; and it changes nothing in the result
+    gs = out["config"]["grad_sync"]
+    assert gs["heads_bucket_floats"] > 0 and gs["heads_bucket_started_inside_backward"] == 3, gs
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, D3_EARLY_ALLREDUCE="0"), cwd=ROOT)
+    late = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert late["config"]["grad_sync"]["heads_bucket_floats"] == 0
+    assert abs(late["final_loss"] - out["final_loss"]) <= 1e-4 * abs(out["final_loss"]), (late["final_loss"], out["final_loss"])

@@ -155,6 +155,68 @@ def test_bucket_layout_is_static_when_a_rank_has_no_gradients():
         assert torch.allclose(a0, want, atol=1e-6)
 
 
+def _early_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
+    torch.manual_seed(rank)
+    det = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 7))     # "detector": layer 1 in an executor-style flat buffer
+    head = torch.nn.Sequential(torch.nn.Linear(7, 6), torch.nn.Linear(6, 3))     # "speaker": the early bucket
+    net = torch.nn.ModuleList([det, head])
+    broadcast_module(net)
+    ex = _FakeExecutor(det[1].parameters())
+    sync = BucketGradAllReduce(net.parameters(), _Owner(ex), early=list(head.parameters()))
+    out = {}
+    # step 0: layout check first (late launch); step 1: one detector pass, the bucket starts inside backward();
+    # step 2: two detector passes (the joint step), it starts at the second boundary only; step 3: rank 1 has no
+    # proposals -> its boundary is never reached -> it issues the same collective from sync() instead
+    for step, passes in enumerate((1, 1, 2, 1)):
+        for p in net.parameters():
+            p.grad = None
+        ex.fresh_grads = True
+        torch.manual_seed(1000 * step + rank)
+        loss = 0
+        fired_at = []
+        for k in range(passes):
+            x = torch.randn(16, 5)
+            f = det(x)
+            if step == 3 and rank == 1:
+                loss = loss + f.detach().sum() * 0 + det[0](x).pow(2).sum()     # heads unused on this rank
+            else:
+                f, = sync.boundary(f)
+                f.register_hook(lambda g, k=k: fired_at.append((k, sync._early_work is not None)))   # runs BEFORE the boundary node
+                loss = loss + head(f).pow(2).sum()
+        loss.backward()
+        started_in_backward = sync._early_work is not None
+        local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        sync()
+        out[step] = dict(local=local, avg=[p.grad.clone() for p in net.parameters()], early=started_in_backward,
+                         counters=(sync._expected, sync._fired))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_bucket_starts_inside_backward_and_keeps_the_collective_order():
+    """the heads' bucket is all-reduced from the backward pass once it has crossed every detector boundary of the step;
+    results equal the plain mean in every case, including a rank that never reaches its boundary"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_early_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    for step in range(4):
+        for a0, a1, l0, l1 in zip(r0[step]["avg"], r1[step]["avg"], r0[step]["local"], r1[step]["local"]):
+            assert torch.allclose(a0, a1)
+            z = torch.zeros_like(a0)
+            assert torch.allclose(a0, ((l0 if l0 is not None else z) + (l1 if l1 is not None else z)) / 2, atol=1e-6)
+        assert r0[step]["counters"] == (0, 0) and r1[step]["counters"] == (0, 0)      # re-armed for the next step
+    assert not r0[0]["early"] and not r1[0]["early"]          # first step: layout comparison comes first
+    assert r0[1]["early"] and r1[1]["early"] and r0[2]["early"] and r1[2]["early"]
+    assert r0[3]["early"] and not r1[3]["early"]               # rank 1 launched it late; no hang, same averages
+
+
 def _logged_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
