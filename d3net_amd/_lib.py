@@ -29,6 +29,7 @@ SIGNATURES = {
     "d3_cluster_merge": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "d3_cluster_coords_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "d3_cluster_transform": (i32, [vp, vp, vp, vp, vp, vp, i64, vp]),
+    "d3_cluster_norm_params": (i32, [vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "d3_roipool_fp": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "d3_roipool_bp": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "d3_get_iou": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),

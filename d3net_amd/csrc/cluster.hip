@@ -875,11 +875,12 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
     cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
     if (nCluster > 0) {
-        static bool attr_done = false;
+        static bool attr_done_dev[64] = {false};   // the attribute is per device
         const size_t lds = (size_t)B2_LDS_INTS * sizeof(int);
-        if (!attr_done) {
+        int dev_id = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64 || !attr_done_dev[dev_id]) {
             D3_CHECK(hipFuncSetAttribute((const void *)cl_bfs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
+            if (dev_id >= 0 && dev_id < 64) attr_done_dev[dev_id] = true;
         }
         D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.star, 0, (size_t)n * sizeof(int), s));

@@ -33,14 +33,15 @@ __global__ __launch_bounds__(256) void gm_edges_kernel(const float *__restrict__
                                                        long long *__restrict__ feat_src, long long *__restrict__ pred_src) {
     extern __shared__ int sm[];
     int *valid = sm, *cidx = valid + K, *rowcnt = cidx + K, *rowstart = rowcnt + K, *incnt = rowstart + K, *instart = incnt + K;
-    int *dsts = instart + K + 1;   // K*L slots of this scene's edge targets
+    int *dsts = instart + K + 1;   // K*L slots: target column | source row << 16 of this scene's edges
+    unsigned *colmask = (unsigned *)(dsts + K * L);   // per target column: bitmask of the rows that own an edge to it (8 words, K <= 256)
     __shared__ int tot[3];
     const int b = blockIdx.x, t = threadIdx.x, KL = K * L;
     const long long Emax_total = (long long)gridDim.x * KL;
     for (int k = t; k < K; k += blockDim.x) valid[k] = mask[(long long)b * K + k] == 1.f ? 1 : 0;
+    for (int k = t; k < K * 8; k += blockDim.x) colmask[k] = 0u;
     __syncthreads();
-    // one wave per adjacency row, lanes along the columns (a thread walking its own 1 KB row read it uncoalesced, twice: most
-    // of the kernel's 130 us at K = 256)
+    // one wave per adjacency row, lanes along the columns (a thread walking its own 1 KB row read it uncoalesced, twice)
     const int lane = t & 63, wave = t >> 6, nwv = blockDim.x >> 6;
     for (int r = wave; r < K; r += nwv) {
         int c = 0;
@@ -54,13 +55,29 @@ __global__ __launch_bounds__(256) void gm_edges_kernel(const float *__restrict__
         if (lane == 0) rowcnt[r] = c < L ? c : L;     // an adjacency row holds exactly L ones (top-L of _query_locals)
     }
     __syncthreads();
-    if (t == 0) {
-        int nv = 0, e = 0, ns = 0;
-        for (int k = 0; k < K; k++) {
-            cidx[k] = nv; nv += valid[k];
-            rowstart[k] = e; e += rowcnt[k]; ns += rowcnt[k] > 0 ? 1 : 0;
+    // exclusive prefix sums over the K <= 256 rows by one wave, four rows per lane (a single thread walking them: 12 us each)
+    if (wave == 0) {
+        int v4[4], c4[4], sv = 0, sc = 0, sn = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = lane * 4 + q;
+            v4[q] = k < K ? valid[k] : 0; c4[q] = k < K ? rowcnt[k] : 0;
+            sv += v4[q]; sc += c4[q]; sn += c4[q] > 0 ? 1 : 0;
         }
-        tot[0] = e; tot[1] = ns; tot[2] = nv;
+        int pv = sv, pc = sc;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int av = __shfl_up(pv, o), ac = __shfl_up(pc, o);
+            if (lane >= o) { pv += av; pc += ac; }
+        }
+        for (int o = 32; o > 0; o >>= 1) sn += __shfl_xor(sn, o);
+        int ev = pv - sv, ec = pc - sc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = lane * 4 + q;
+            if (k < K) { cidx[k] = ev; rowstart[k] = ec; }
+            ev += v4[q]; ec += c4[q];
+        }
+        if (lane == 63) { tot[0] = pc; tot[1] = sn; tot[2] = pv; }
     }
     __syncthreads();
     const int E = tot[0], nsrc = tot[1], ntar = nsrc > 0 ? E / nsrc : 0, n = nsrc * ntar;
@@ -89,30 +106,42 @@ __global__ __launch_bounds__(256) void gm_edges_kernel(const float *__restrict__
             const int pos = taken + (int)__popcll(bal & ((1ull << lane) - 1ull));   // column order == the serial walk's order
             if (hit && pos < want) {
                 const int e = e0 + pos;
-                src[(long long)b * KL + e] = b * K + r; dst[(long long)b * KL + e] = b * K + j; dsts[e] = j;
+                src[(long long)b * KL + e] = b * K + r; dst[(long long)b * KL + e] = b * K + j; dsts[e] = j | (r << 16);
+                atomicOr(&colmask[j * 8 + (r >> 5)], 1u << (r & 31));
                 if (e < n) { eidx[((long long)b * 2 + 0) * KL + e] = (float)cidx[r]; eidx[((long long)b * 2 + 1) * KL + e] = (float)cidx[j]; }
             }
             taken += (int)__popcll(bal);
         }
     }
     __syncthreads();
+    // incoming lists in edge order: a row owns at most one edge to a target, edges are ordered by row, so the rank of edge
+    // (r -> v) among v's incoming edges is the number of rows below r in v's row mask (each thread walking all E edges per
+    // target, twice, was most of this kernel's 130 us)
     for (int v = t; v < K; v += blockDim.x) {
         int c = 0;
-        for (int e = 0; e < E; e++) c += dsts[e] == v ? 1 : 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) c += __popc(colmask[v * 8 + w]);
         incnt[v] = c;
     }
     __syncthreads();
-    if (t == 0) {
-        int o = 0;
-        for (int k = 0; k < K; k++) { instart[k] = o; o += incnt[k]; }
-        instart[K] = o;
+    if (wave == 0) {
+        int c4[4], sc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int k = lane * 4 + q; c4[q] = k < K ? incnt[k] : 0; sc += c4[q]; }
+        int pc = sc;
+        for (int o = 1; o < 64; o <<= 1) { const int ac = __shfl_up(pc, o); if (lane >= o) pc += ac; }
+        int ec = pc - sc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int k = lane * 4 + q; if (k < K) instart[k] = ec; ec += c4[q]; }
+        if (lane == 63) instart[K] = pc;
     }
     __syncthreads();
     for (int v = t; v <= K; v += blockDim.x) in_ptr[(long long)b * (K + 1) + v] = instart[v];
-    for (int v = t; v < K; v += blockDim.x) {
-        int o = instart[v];
-        for (int e = 0; e < E; e++)
-            if (dsts[e] == v) in_list[(long long)b * KL + o++] = e;
+    for (int e = t; e < E; e += blockDim.x) {
+        const int v = dsts[e] & 0xffff, r = dsts[e] >> 16;
+        int rank = __popc(colmask[v * 8 + (r >> 5)] & ((1u << (r & 31)) - 1u));
+        for (int w = 0; w < (r >> 5); w++) rank += __popc(colmask[v * 8 + w]);
+        in_list[(long long)b * KL + instart[v] + rank] = e;
     }
 }
 
@@ -121,7 +150,7 @@ extern "C" int d3_graph_edges(const float *adj, const float *mask, int B, int K,
                               long long *pred_src, void *stream) {
     D3_CLEAR();
     if (B < 1 || K < 1 || K > GM_MAXK || L < 1) return D3_ERR_ARG;
-    const size_t lds = (size_t)(6 * K + 1 + K * L) * 4;
+    const size_t lds = (size_t)(6 * K + 1 + K * L + 8 * K) * 4;
     gm_edges_kernel<<<B, 256, lds, d3_stream(stream)>>>(adj, mask, K, L, src, dst, edge_index, cnt, in_ptr, in_list, out_start, out_cnt,
                                                         feat_src, pred_src);
     D3_LAUNCH_CHECK();

@@ -417,6 +417,60 @@ __global__ void cluster_transform_kernel(const float *__restrict__ coords, const
     op[0] = o[0]; op[1] = o[1]; op[2] = o[2]; op[3] = o[3];
 }
 
+// The per-cluster arithmetic of `clusters_voxelization` between the coordinate statistics and the per-point transform
+// (model/pointgroup.py:146-165): size, centre, the scale that fits the cluster into fullscale^3 (capped), and the random
+// placement offset -- ~30 elementwise library launches on (P,3) tensors, each ~4.7 us of pure launch latency.  Every fp32
+// operation is rounded separately and in the library's form: `x / python_scalar` is a multiplication by the fp32 reciprocal
+// of the scalar, `1 / x` a correctly rounded division, `python_scalar - x` one subtraction.
+__global__ void cluster_norm_kernel(const float *__restrict__ mean, const float *__restrict__ raw_min, const float *__restrict__ raw_max,
+                                    int P, float fullscale, float scale_cap, float r00, float r01, float r02, float r10, float r11,
+                                    float r12, float *__restrict__ size, float *__restrict__ center, float *__restrict__ cscale,
+                                    float *__restrict__ offset) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float inv_full = __fdiv_rn(1.f, fullscale);
+    const float r0[3] = {r00, r01, r02}, r1[3] = {r10, r11, r12};
+    float cmin[3], cmax[3], mx = -INFINITY;
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float m = mean[p * 3 + k];
+        cmin[k] = __fsub_rn(raw_min[p * 3 + k], m);
+        cmax[k] = __fsub_rn(raw_max[p * 3 + k], m);
+        const float ext = __fsub_rn(cmax[k], cmin[k]);
+        size[p * 3 + k] = ext;
+        center[p * 3 + k] = __fadd_rn(__fmul_rn(__fadd_rn(cmax[k], cmin[k]), 0.5f), m);
+        const float d = __fmul_rn(ext, inv_full);
+        nan |= d != d;
+        mx = fmaxf(mx, d);
+    }
+    if (nan) mx = NAN;                                       // torch.max propagates NaN
+    float sc = __fsub_rn(__fdiv_rn(1.f, mx), 0.01f);          // 1 / x - 0.01
+    sc = (sc != sc) ? sc : fminf(sc, scale_cap);               // clamp(max=scale) keeps NaN
+    cscale[p] = sc;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float lo = __fmul_rn(cmin[k], sc), hi = __fmul_rn(cmax[k], sc);
+        const float rng = __fsub_rn(hi, lo);
+        const float room = __fsub_rn(fullscale, rng);
+        float a = __fsub_rn(room, 0.001f), b = __fadd_rn(room, 0.001f);
+        a = (a != a) ? a : fmaxf(a, 0.f);                      // clamp(min=0)
+        b = (b != b) ? b : fminf(b, 0.f);                      // clamp(max=0)
+        offset[p * 3 + k] = __fadd_rn(__fadd_rn(-lo, __fmul_rn(a, r0[k])), __fmul_rn(b, r1[k]));
+    }
+}
+extern "C" int d3_cluster_norm_params(const float *mean, const float *raw_min, const float *raw_max, int P, float fullscale,
+                                      float scale_cap, const float *rand6, float *size, float *center, float *cscale, float *offset,
+                                      void *stream) {
+    D3_CLEAR();
+    if (P <= 0) return 0;
+    if (!rand6) return D3_ERR_ARG;
+    cluster_norm_kernel<<<(P + 255) / 256, 256, 0, d3_stream(stream)>>>(mean, raw_min, raw_max, P, fullscale, scale_cap, rand6[0], rand6[1],
+                                                                         rand6[2], rand6[3], rand6[4], rand6[5], size, center, cscale, offset);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 // first row attaining the (already final) maximum: strict '>' in ascending row order == smallest such row
 __global__ __launch_bounds__(SEG_THREADS) void roipool_arg_flat_kernel(const float *__restrict__ feats,
                                                                       const int *__restrict__ offsets,

@@ -209,11 +209,11 @@ __global__ void td_gru_bwd_gates_kernel(const float *d0, long long ld0, const fl
 //   features, constant over the time steps: `msum`) + sum_active a[k] obj[k];
 //   backward: sum_k a[k] da[k] = datt . attended (no K x F product), ds[k] != 0 only for active k; the gradient w.r.t. the
 //   object features, dobj[k] = sum_t a_t[k] datt_t, is accumulated after the time loop from the saved a / datt.
-__global__ __launch_bounds__(256) void td_attn_prep_kernel(const float *__restrict__ mask, const float *__restrict__ obj,
-                                                           int *__restrict__ act, int *__restrict__ nact, float *__restrict__ msum,
-                                                           int K, int F, int obj_div) {
-    __shared__ int cnt;
-    extern __shared__ float sm[];          // 2*F partial sums
+#define TD_PREP_T 1024
+__global__ __launch_bounds__(TD_PREP_T) void td_attn_prep_kernel(const float *__restrict__ mask, const float *__restrict__ obj,
+                                                                 int *__restrict__ act, int *__restrict__ nact, float *__restrict__ msum,
+                                                                 int K, int F, int obj_div) {
+    extern __shared__ float sm[];          // (TD_PREP_T / F) * F partial sums
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const long long ns = n / obj_div;
     if (t < 64) {                          // wave 0: active list in ascending k (ballot + prefix popcount)
@@ -225,19 +225,32 @@ __global__ __launch_bounds__(256) void td_attn_prep_kernel(const float *__restri
             if (on) act[(long long)n * K + base + __popcll(bal & ((1ull << lane) - 1ull))] = k;
             base += __popcll(bal);
         }
-        if (lane == 0) { cnt = base; nact[n] = base; }
+        if (lane == 0) nact[n] = base;
     }
-    __syncthreads();
-    const int half = t / F, c = t - half * F;
-    float s = 0.f;
-    if (half < 2) {
-        const int k0 = half * ((K + 1) / 2), k1 = min(K, k0 + (K + 1) / 2);
-        for (int k = k0; k < k1; k++)
+    // masked objects' feature sum: TD_PREP_T / F slices of the proposals, each summed in ascending k (loads unconditional and
+    // batched, the mask is a factor), the slices then added in slice order: fixed order, deterministic
+    const int nsl = TD_PREP_T / F, sl = t / F, c = t - sl * F;
+    if (sl < nsl) {
+        const int per = (K + nsl - 1) / nsl, k0 = sl * per, k1 = min(K, k0 + per);
+        float s = 0.f;
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            float v[4], m[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { v[q] = obj[(ns * K + k + q) * F + c]; m[q] = mask[(long long)n * K + k + q]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) s += (m[q] == 0.f) ? v[q] : 0.f;
+        }
+        for (; k < k1; k++)
             if (mask[(long long)n * K + k] == 0.f) s += obj[(ns * K + k) * F + c];
-        sm[half * F + c] = s;
+        sm[sl * F + c] = s;
     }
     __syncthreads();
-    if (t < F) msum[(long long)n * F + t] = sm[t] + sm[F + t];
+    if (t < F) {
+        float s = sm[t];
+        for (int q = 1; q < nsl; q++) s += sm[q * F + t];
+        msum[(long long)n * F + t] = s;
+    }
 }
 
 // one workgroup per sample; attn_out: (N, K, S) slice t of `topdown_attn` (NULL: not wanted)
@@ -480,7 +493,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
     const long long ldtd = H + F + E;          // map_topdown weight: (E, E + H + F) over [emb | h2 | target]
     const long long ldlang = F + H;            // map_lang weight: (E, F + H) over [attended | h1]
     td_rows_kernel<<<(R + 255) / 256, 256, 0, s>>>(a->word_ids, a->Tw, N, S, V, widx, nidx, bidx);
-    td_attn_prep_kernel<<<N, 256, (size_t)2 * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, 1);
+    td_attn_prep_kernel<<<N, TD_PREP_T, (size_t)(TD_PREP_T / F) * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, 1);
     D3_CHECK(hipMemsetAsync(H1, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(H2, 0, (size_t)N * H * 4, s));
     {   // batched, recurrence-free parts: map_feat(obj) and the [embedding | target] part of map_topdown (+ bias)
@@ -769,7 +782,7 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
     int rc;
     if (256 % F) return D3_ERR_ARG;
     td_word_idx_kernel<<<(N + 255) / 256, 256, 0, s>>>(word, widx, N, V);
-    td_attn_prep_kernel<<<N, 256, (size_t)2 * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, obj_div);
+    td_attn_prep_kernel<<<N, TD_PREP_T, (size_t)(TD_PREP_T / F) * F * 4, s>>>(a->mask, a->obj, act, nact, msum, K, F, obj_div);
     {
         d3_gemm_prob p = td_prob(N, E, x1, E);
         p.nseg = 3;

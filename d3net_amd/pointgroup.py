@@ -223,25 +223,15 @@ class PointGroup(nn.Module):
         # (csrc/seg_ops.hip: d3_cluster_coords_stats; min(x - mean) == min(x) - mean under monotone rounding)
         clusters_coords_mean, raw_min, raw_max = pointgroup_ops.cluster_coords_stats(coords, clusters_idx, clusters_offset)
         _mark("cv_sec_mean")
-        clusters_coords_min = raw_min - clusters_coords_mean
-        clusters_coords_max = raw_max - clusters_coords_mean
         _mark("cv_sec_minmax")
-        clusters_size = clusters_coords_max - clusters_coords_min
-        clusters_center = (clusters_coords_max + clusters_coords_min) / 2 + clusters_coords_mean
-
-        clusters_scale = 1 / ((clusters_coords_max - clusters_coords_min) / fullscale).max(1)[0] - 0.01
-        clusters_scale = torch.clamp(clusters_scale, min=None, max=scale)
-        min_xyz = clusters_coords_min * clusters_scale.unsqueeze(-1)
-        max_xyz = clusters_coords_max * clusters_scale.unsqueeze(-1)
-
-        rng = max_xyz - min_xyz
         if rand is None:
             r0, r1 = torch.rand(3), torch.rand(3)   # CPU generator, same order as the reference
         else:
             r0, r1 = rand[0].cpu(), rand[1].cpu()
-        r01 = _STAGE.put(torch.stack([r0, r1]).float(), dev)
-        offset = - min_xyz + torch.clamp(fullscale - rng - 0.001, min=0) * r01[0] + \
-            torch.clamp(fullscale - rng + 0.001, max=0) * r01[1]
+        # size / centre / grid scale / random placement offset per cluster (:146-165): one launch, bit-equal to the ~30
+        # elementwise library launches on (P,3) tensors it replaces (csrc/seg_ops.hip: d3_cluster_norm_params)
+        clusters_size, clusters_center, clusters_scale, offset = pointgroup_ops.cluster_norm_params(
+            clusters_coords_mean, raw_min, raw_max, fullscale, scale, r0.float(), r1.float())
         # (coords[point] - mean) * scale + offset, truncated (:166), with the cluster id in front: one pass over the S pairs
         clusters_coords = pointgroup_ops.cluster_transform(coords, clusters_idx, clusters_coords_mean, clusters_scale, offset)
         n_clusters = int(clusters_offset.numel() - 1)

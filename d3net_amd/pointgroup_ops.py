@@ -469,6 +469,23 @@ def cluster_coords_stats(coords, clusters_idx, clusters_offset):
     return out[0], out[1], out[2]
 
 
+def cluster_norm_params(mean, raw_min, raw_max, fullscale, scale_cap, r0, r1):
+    """per-cluster size (P,3), centre (P,3), grid scale (P,) and placement offset (P,3) of `clusters_voxelization`
+    (model/pointgroup.py:146-165) in one launch (d3_cluster_norm_params); r0, r1: the two host-side `torch.rand(3)` draws"""
+    P = mean.shape[0]
+    dev = mean.device
+    mean, raw_min, raw_max = mean.contiguous(), raw_min.contiguous(), raw_max.contiguous()
+    size = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    center, offset = torch.empty_like(size), torch.empty_like(size)
+    cscale = torch.empty((P,), dtype=torch.float32, device=dev)
+    rand6 = (C.c_float * 6)(*[float(v) for v in r0.tolist()], *[float(v) for v in r1.tolist()])
+    with _on(dev):
+        check(_lib.lib().d3_cluster_norm_params(_ptr(mean), _ptr(raw_min), _ptr(raw_max), P, float(fullscale), float(scale_cap),
+                                                C.cast(rand6, C.c_void_p), _ptr(size), _ptr(center), _ptr(cscale),
+                                                _ptr(offset), _stream()), "cluster_norm_params")
+    return size, center, cscale, offset
+
+
 def cluster_transform(coords, clusters_idx, mean, scale, offset):
     """(S,4) int64 [cluster, trunc((coords[point] - mean[cluster]) * scale[cluster] + offset[cluster])] (d3_cluster_transform)"""
     S = clusters_idx.shape[0]

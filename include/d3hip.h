@@ -62,6 +62,13 @@ int d3_cluster_coords_stats(const float *coords, const int *clusters_idx, const 
                             int nProposal, void *stream);
 int d3_cluster_transform(const float *coords, const int *clusters_idx, const float *mean, const float *scale, const float *offset,
                          long long *out, long long S, void *stream);
+/* The per-cluster arithmetic between the two (model/pointgroup.py:146-165): size = cmax - cmin, center = (cmax + cmin) / 2 + mean
+ * (cmin / cmax relative to the mean), cscale = min(1 / max_k((cmax - cmin) / fullscale) - 0.01, scale_cap), and the placement
+ * offset = -cmin * cscale + clamp(fullscale - range - 0.001, min 0) * r0 + clamp(fullscale - range + 0.001, max 0) * r1 with
+ * range = (cmax - cmin) * cscale.  rand6 = HOST pointer to the six floats [r0 | r1] (the reference's two `torch.rand(3)` draws,
+ * :161), passed as kernel arguments.  Bit-equal to the ~30 elementwise library launches it replaces. */
+int d3_cluster_norm_params(const float *mean, const float *raw_min, const float *raw_max, int P, float fullscale, float scale_cap,
+                           const float *rand6, float *size, float *center, float *cscale, float *offset, void *stream);
 /* PG_OP.roipool_fp / roipool_bp  (src/roipool/roipool.cu:12-57) */
 int d3_roipool_fp(const float *feats, const int *proposals_offset, float *output_feats, int *output_maxidx,
                   int nProposal, int C, void *stream);

@@ -376,6 +376,21 @@ def test_cluster_coordinate_stats_and_transform_equal_the_library_op_form(dev):
     sc2, off2 = scalars(rmin - mean2, rmax - mean2)
     got = P.cluster_transform(coords, clusters_idx, mean2, sc2, off2)
     assert got.dtype == torch.int64 and torch.equal(got, ref)
+    # the per-cluster arithmetic in one launch (d3_cluster_norm_params): bit-equal to the elementwise library chain, incl. a
+    # one-point cluster (zero extent -> 1/0 = inf -> capped scale) and clusters wider than the grid
+    size3, center3, sc3, off3 = P.cluster_norm_params(mean2, rmin, rmax, fullscale, scale, r01[0].cpu(), r01[1].cpu())
+    assert torch.equal(sc3, sc2) and torch.equal(off3, off2)
+    assert torch.equal(size3, cmax - cmin) and torch.equal(center3, (cmax + cmin) / 2 + mean2)
+    # many random clusters with odd extents (tiny, huge, degenerate along one axis)
+    Pn = 5000
+    m = torch.from_numpy((rng.random((Pn, 3)) * 6).astype(np.float32)).to(dev)
+    ext = torch.from_numpy((10.0 ** rng.uniform(-4, 1.2, (Pn, 3))).astype(np.float32)).to(dev)
+    ext[::17, 1] = 0
+    lo, hi = m - ext * 0.37, m + ext * 0.63
+    size4, center4, sc4, off4 = P.cluster_norm_params(m, lo, hi, fullscale, scale, r01[0].cpu(), r01[1].cpu())
+    sc_ref, off_ref = scalars(lo - m, hi - m)
+    assert torch.equal(sc4, sc_ref) and torch.equal(off4, off_ref)
+    assert torch.equal(size4, (hi - m) - (lo - m)) and torch.equal(center4, ((hi - m) + (lo - m)) / 2 + m)
 
 
 def test_cluster_select_and_merge_equal_the_library_op_chain(dev):

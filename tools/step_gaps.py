@@ -4,6 +4,7 @@ to AdamW kernel) the kernels of the busiest queue in launch order, with per kern
 the summed idle time in FRONT of it (start − end of the previous kernel on that queue).  A chain of dependent 7 µs kernels
 shows up as gaps of the same order as the kernels.  usage: step_gaps.py <kernel_trace.csv> [top=40] [side queue id to list]"""
 import csv
+import os
 import sys
 from collections import defaultdict
 
@@ -47,6 +48,12 @@ def main():
                 dn[m[2][:26]] += min(m[1], e[1]) - max(m[0], e[0])
             print("   q%s @%8.3f ms %8.1f us  %-40s | main: %s" % (q, (e[0] - t0) / 1e6, (e[1] - e[0]) / 1e3, e[2][:40],
                                                                  ", ".join("%s %.0f" % (k, v / 1e3) for k, v in sorted(dn.items(), key=lambda x: -x[1])[:3])))
+    if os.environ.get("D3_GAPS_DUMP"):   # every main-queue kernel of the step in launch order: start, duration, idle before it
+        with open(os.environ["D3_GAPS_DUMP"], "w") as f:
+            pe = es[0][0]
+            for e in es:
+                f.write("%9.3f %7.1f %7.1f  %s\n" % ((e[0] - es[0][0]) / 1e6, (e[1] - e[0]) / 1e3, max(0, e[0] - pe) / 1e3, e[2]))
+                pe = max(pe, e[1])
     agg = defaultdict(lambda: [0, 0, 0])
     prev_end = es[0][0]
     for e in es:
