@@ -196,7 +196,39 @@ def _rl_cap_loss(data_dict, loss_opt):
     return cap_loss, data_dict
 
 
-def compute_cap_loss(data_dict, loss_opt={}):
+class _MaskedXE(torch.autograd.Function):
+    """caption cross-entropy + word accuracy + the gradient of the logits in two launches (csrc/heads.hip: d3_masked_xe)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, good):
+        from . import _lib
+        from ._lib import check
+        from .pointgroup_ops import _on, _ptr, _stream
+        N, S, V = pred.shape
+        dev = pred.device
+        pred = pred.contiguous()
+        assert target.shape == (N, S) and target.stride(1) == 1 and target.dtype == torch.int64
+        good8 = good.contiguous().view(torch.uint8) if good.dtype == torch.bool else good.to(torch.uint8).contiguous()
+        L = _lib.lib()
+        nws = int(L.d3_masked_xe_ws_bytes(N, S))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        dpred = torch.empty_like(pred)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        with _on(dev):
+            check(L.d3_masked_xe(_ptr(pred), _ptr(target), target.stride(0), _ptr(good8), N, S, V, _ptr(dpred), _ptr(out), _ptr(ws), nws,
+                                 _stream()), "masked_xe")
+        ctx.save_for_backward(dpred)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g, _g_acc):
+        dpred, = ctx.saved_tensors
+        return dpred.mul_(g), None, None      # (the saved gradient is used once)
+
+
+def compute_cap_loss(data_dict, loss_opt={}, native=True):
     """(loss_helper.py:177-224) XE over the descriptions whose target box is good (IoU > min_iou_threshold).
     Same value as the reference's `pred[good]` selection, without its host round trip: the targets of the other
     descriptions are set to the ignored index 0, and an all-bad batch gives 0 (the reference's else branch)."""
@@ -208,6 +240,13 @@ def compute_cap_loss(data_dict, loss_opt={}):
     target = data_dict["lang_ids"].reshape(-1, max_len)[:, 1:num_words]
     good = data_dict["good_bbox_masks"]
     V = pred.shape[2]
+    if native and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.int64 and target.stride(1) == 1 \
+            and target.shape[1] == pred.shape[1] and good.dim() == 1:
+        cap_loss, cap_acc = _MaskedXE.apply(pred, target, good)
+        z = data_dict["bbox_feature"].new_zeros(())
+        data_dict["cap_rwd"], data_dict["loc_rwd"], data_dict["ttl_rwd"] = z, z, z
+        data_dict["cap_loss"], data_dict["cap_acc"] = cap_loss, cap_acc
+        return cap_loss, data_dict
     t = torch.where(good.unsqueeze(1), target, torch.zeros_like(target)).reshape(-1)
     m = t != 0
     cnt = m.sum()
@@ -227,13 +266,59 @@ def radian_to_label(radians, num_bins=6):
     return torch.bucketize(radians, boundaries)
 
 
-def compute_node_orientation_loss(data_dict, num_bins=6):
+class _OrientationLoss(torch.autograd.Function):
+    """the whole loss on the device in one launch (csrc/heads.hip: d3_orientation_loss); the gradient w.r.t. the
+    orientation logits comes out of the same pass"""
+
+    @staticmethod
+    def forward(ctx, preds, edge_index, nsrc, ntar, assign, rots, rot_masks, num_bins):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check
+        from .pointgroup_ops import _on, _ptr, _stream
+        B, E, nb = preds.shape
+        assert nb == num_bins and preds.stride(2) == 1
+        bounds = torch.arange(np.pi / num_bins, np.pi - 1e-8, np.pi / num_bins).float().tolist()   # `radian_to_label`
+        barr = (C.c_float * max(len(bounds), 1))(*bounds)
+        dev = preds.device
+        edge_index, assign = edge_index.contiguous(), assign.contiguous()
+        rots, rot_masks = rots.contiguous(), rot_masks.contiguous().float()
+        nsrc, ntar = nsrc.contiguous().long(), ntar.contiguous().long()
+        dpreds = torch.empty((B, E, nb), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        with _on(dev):
+            check(_lib.lib().d3_orientation_loss(_ptr(preds), preds.stride(0), preds.stride(1), _ptr(edge_index), _ptr(nsrc), _ptr(ntar),
+                                                 _ptr(assign), _ptr(rots), _ptr(rot_masks), B, E, assign.shape[1], rots.shape[1],
+                                                 nb, C.cast(barr, C.c_void_p), len(bounds), _ptr(dpreds), _ptr(out), _stream()),
+                  "orientation_loss")
+        ctx.save_for_backward(dpreds)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g, _g_acc):
+        dpreds, = ctx.saved_tensors
+        return dpreds * g, None, None, None, None, None, None, None
+
+
+def _orientation_native_ok(data_dict, num_bins):
+    p, ei = data_dict["edge_orientations"], data_dict["edge_index"]
+    return (p.is_cuda and p.dtype == torch.float32 and p.dim() == 3 and p.stride(2) == 1 and p.shape[2] == num_bins and num_bins <= 16
+            and ei.dtype == torch.float32 and data_dict["object_assignment"].dtype == torch.int64
+            and data_dict["scene_object_rotations"].dtype == torch.float32 and p.shape[1] == ei.shape[2])
+
+
+def compute_node_orientation_loss(data_dict, num_bins=6, native=True):
     """(loss_helper.py:244-307) relative rotation of the GT objects assigned to the two ends of every graph edge.
     All scenes at once on the padded (B, K*L) edge tensors: the reference loops over the scenes and slices the first
     n = n_source * n_target edges of each (a host round trip per scene); here edges >= n get weight 0."""
     assign = data_dict["object_assignment"]
     edge_indices, edge_preds = data_dict["edge_index"], data_dict["edge_orientations"]
     nsrc, ntar = data_dict["num_edge_source"], data_dict["num_edge_target"]
+    if native and _orientation_native_ok(data_dict, num_bins):
+        return _OrientationLoss.apply(edge_preds, edge_indices, nsrc, ntar, assign, data_dict["scene_object_rotations"],
+                                      data_dict["scene_object_rotation_masks"], num_bins)
     B, K = assign.shape
     E = edge_indices.shape[2]
     rots = torch.gather(data_dict["scene_object_rotations"], 1, assign.view(B, K, 1, 1).repeat(1, 1, 3, 3))

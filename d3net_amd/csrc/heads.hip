@@ -399,6 +399,184 @@ extern "C" int d3_score_loss(const float *scores, const float *ious, int P, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- caption cross-entropy
+// `compute_cap_loss` (lib/captioning/loss_helper.py:177-224): XE over the words of the descriptions whose target box is good,
+// target 0 = ignored, summed and divided by the number of counted words; word accuracy likewise.  One workgroup per
+// (description, step) row of the (N, S, V) logits: row maximum / first arg-max, log-sum-exp, the row's loss term and -- in the
+// same launch -- the gradient row (softmax - onehot) / count (the count of valid targets is recomputed by every workgroup from
+// the N*S targets: 7 KB); a second one-workgroup launch adds the row terms in row order: deterministic.  Replaces ~26 library
+// launches (where / compare / log-softmax / nll / argmax / reductions and their backward).
+#define XE_T 256
+__global__ __launch_bounds__(XE_T) void xe_rows_kernel(const float *__restrict__ pred, const long long *__restrict__ target,
+                                                      long long ldt, const unsigned char *__restrict__ good, int N, int S, int V,
+                                                      float *__restrict__ dpred, float *__restrict__ rowterm) {
+    __shared__ float redf[XE_T];
+    __shared__ int redi[XE_T];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int n = r / S, st = r - n * S;
+    // number of counted words over the whole batch (every workgroup: N*S targets)
+    int cnt = 0;
+    for (int i = t; i < N * S; i += XE_T) {
+        const int ni = i / S;
+        cnt += (good[ni] && target[(long long)ni * ldt + (i - ni * S)] != 0) ? 1 : 0;
+    }
+    redi[t] = cnt;
+    __syncthreads();
+    for (int o = XE_T / 2; o > 0; o >>= 1) { if (t < o) redi[t] += redi[t + o]; __syncthreads(); }
+    const int total = redi[0];
+    __syncthreads();
+    const float denom = (float)(total > 1 ? total : 1);
+    const long long tg = good[n] ? target[(long long)n * ldt + st] : 0;
+    const float *x = pred + (long long)r * V;
+    float mx = -INFINITY;
+    int am = 0x7FFFFFFF;
+    for (int c = t; c < V; c += XE_T) { const float v = x[c]; if (v > mx) { mx = v; am = c; } }
+    redf[t] = mx; redi[t] = am;
+    __syncthreads();
+    for (int o = XE_T / 2; o > 0; o >>= 1) {
+        if (t < o) {
+            const float v = redf[t + o]; const int a = redi[t + o];
+            if (v > redf[t] || (v == redf[t] && a < redi[t])) { redf[t] = v; redi[t] = a; }
+        }
+        __syncthreads();
+    }
+    mx = redf[0]; am = redi[0];
+    __syncthreads();
+    float se = 0.f;
+    for (int c = t; c < V; c += XE_T) se += expf(x[c] - mx);
+    redf[t] = se;
+    __syncthreads();
+    for (int o = XE_T / 2; o > 0; o >>= 1) { if (t < o) redf[t] += redf[t + o]; __syncthreads(); }
+    se = redf[0];
+    const bool valid = tg != 0 && tg < V && tg > 0;
+    const float scale = valid ? 1.f / denom : 0.f;
+    float *d = dpred + (long long)r * V;
+    const float inv = 1.f / se;
+    for (int c = t; c < V; c += XE_T) d[c] = scale * (expf(x[c] - mx) * inv - (c == (int)tg ? 1.f : 0.f));
+    if (t == 0) {
+        rowterm[r * 2 + 0] = valid ? -((x[tg] - mx) - logf(se)) : 0.f;
+        rowterm[r * 2 + 1] = (valid && am == (int)tg) ? 1.f : 0.f;
+        if (r == 0) rowterm[(long long)N * S * 2] = denom;
+    }
+}
+__global__ __launch_bounds__(XE_T) void xe_reduce_kernel(const float *__restrict__ rowterm, int R, float *__restrict__ out) {
+    __shared__ float a[XE_T], b[XE_T];
+    const int t = threadIdx.x;
+    const int per = (R + XE_T - 1) / XE_T;
+    float sa = 0.f, sb = 0.f;
+    for (int i = t * per; i < min(R, (t + 1) * per); i++) { sa += rowterm[i * 2]; sb += rowterm[i * 2 + 1]; }
+    a[t] = sa; b[t] = sb;
+    __syncthreads();
+    if (t == 0) {
+        float x = 0.f, y = 0.f;
+        for (int i = 0; i < XE_T; i++) { x += a[i]; y += b[i]; }
+        const float denom = rowterm[(long long)R * 2];
+        out[0] = x / denom; out[1] = y / denom;
+    }
+}
+extern "C" size_t d3_masked_xe_ws_bytes(int N, int S) { return ((size_t)N * S * 2 + 1) * sizeof(float); }
+extern "C" int d3_masked_xe(const float *pred, const long long *target, long long ld_target, const unsigned char *good, int N, int S,
+                            int V, float *dpred, float *out2, void *ws, size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (N < 1 || S < 1 || V < 2) return D3_ERR_ARG;
+    if (ws == nullptr || ws_bytes < d3_masked_xe_ws_bytes(N, S)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    xe_rows_kernel<<<N * S, XE_T, 0, s>>>(pred, target, ld_target, good, N, S, V, dpred, (float *)ws);
+    xe_reduce_kernel<<<1, XE_T, 0, s>>>((const float *)ws, N * S, out2);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- orientation loss
+// `compute_node_orientation_loss` (lib/captioning/loss_helper.py:244-307) in one launch: per graph edge the relative rotation
+// of the GT objects assigned to its two ends (trace of R_s R_t^T -> angle -> bin), the rotation-mask / live-edge weight, the
+// weighted cross-entropy over the num_bins orientation logits, the accuracy, and the gradient w.r.t. the logits -- ~45
+// library launches (gathers of 3x3 matrices, a batched matmul, acos, bucketize, log-softmax, nll, argmax, their backward)
+// on 10 k edges.  One workgroup; per-thread partial sums combined by a fixed-order tree: deterministic.
+#define OL_T 1024
+#define OL_MAXB 16
+struct OlBounds { float v[OL_MAXB]; int n; };
+__global__ __launch_bounds__(OL_T) void orient_loss_kernel(const float *__restrict__ preds, long long ldb, long long lde,
+                                                          const float *__restrict__ eidx, const long long *__restrict__ nsrc,
+                                                          const long long *__restrict__ ntar, const long long *__restrict__ assign,
+                                                          const float *__restrict__ rot, const float *__restrict__ rmask, int B,
+                                                          int E, int K, int G, int nb, OlBounds bd, float *__restrict__ dpreds,
+                                                          float *__restrict__ out) {
+    __shared__ float red[3][OL_T];
+    const int t = threadIdx.x;
+    const long long R = (long long)B * E;
+    float s_ce = 0.f, s_m = 0.f, s_hit = 0.f;
+    for (long long r = t; r < R; r += OL_T) {
+        const int b = (int)(r / E), e = (int)(r - (long long)b * E);
+        const float live = (long long)e < nsrc[b] * ntar[b] ? 1.f : 0.f;
+        int sn = (int)(long long)eidx[((long long)b * 2 + 0) * E + e], tn = (int)(long long)eidx[((long long)b * 2 + 1) * E + e];
+        sn = min(max(sn, 0), K - 1); tn = min(max(tn, 0), K - 1);
+        long long as = assign[(long long)b * K + sn], at = assign[(long long)b * K + tn];
+        as = as < 0 ? 0 : (as >= G ? G - 1 : as); at = at < 0 ? 0 : (at >= G ? G - 1 : at);
+        const float *Rs = rot + ((long long)b * G + as) * 9, *Rt = rot + ((long long)b * G + at) * 9;
+        float tr = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {       // diag_i of R_s R_t^T = sum_k Rs[i][k] Rt[i][k]
+            float d = Rs[i * 3] * Rt[i * 3];
+            d = fmaf(Rs[i * 3 + 1], Rt[i * 3 + 1], d);
+            d = fmaf(Rs[i * 3 + 2], Rt[i * 3 + 2], d);
+            tr = i == 0 ? d : tr + d;
+        }
+        const float c = fminf(fmaxf(0.5f * (tr - 1.f), -1.f), 1.f);
+        const float rad = acosf(c);
+        int label = 0;                       // torch.bucketize(right=False): number of boundaries strictly below the value
+        for (int q = 0; q < bd.n; q++) label += bd.v[q] < rad ? 1 : 0;
+        const float m = rmask[(long long)b * G + as] * rmask[(long long)b * G + at] * live;
+        const float *x = preds + (long long)b * ldb + (long long)e * lde;
+        float xv[OL_MAXB], mx = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int q = 0; q < OL_MAXB; q++) {
+            xv[q] = q < nb ? x[q] : -INFINITY;
+            if (xv[q] > mx) { mx = xv[q]; am = q; }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int q = 0; q < OL_MAXB; q++) se += q < nb ? expf(xv[q] - mx) : 0.f;
+        const float lse = logf(se);
+        if (label >= nb) label = nb - 1;      // (cannot happen: num_bins - 1 boundaries)
+        float xl = 0.f;
+#pragma unroll
+        for (int q = 0; q < OL_MAXB; q++) xl = q == label ? xv[q] : xl;
+        const float ce = -((xl - mx) - lse);
+        s_ce += ce * m; s_m += m; s_hit += (am == label && m == 1.f) ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < OL_MAXB; q++)
+            if (q < nb) dpreds[r * nb + q] = m * (expf(xv[q] - mx) / se - (q == label ? 1.f : 0.f));
+    }
+    red[0][t] = s_ce; red[1][t] = s_m; red[2][t] = s_hit;
+    __syncthreads();
+    for (int o = OL_T / 2; o > 0; o >>= 1) {
+        if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
+        __syncthreads();
+    }
+    const float den = red[1][0] + 1e-8f;
+    if (t == 0) { out[0] = red[0][0] / den; out[1] = red[2][0] / den; }
+    const float inv = 1.f / den;
+    for (long long r = t; r < R; r += OL_T)
+        for (int q = 0; q < nb; q++) dpreds[r * nb + q] *= inv;
+}
+extern "C" int d3_orientation_loss(const float *preds, long long ld_batch, long long ld_edge, const float *edge_index,
+                                   const long long *num_src, const long long *num_tar, const long long *assign, const float *rotations,
+                                   const float *rot_masks, int B, int E, int K, int G, int num_bins, const float *bounds_host,
+                                   int nbounds, float *dpreds, float *out2, void *stream) {
+    D3_CLEAR();
+    if (B < 1 || E < 1 || K < 1 || G < 1 || num_bins < 1 || num_bins > OL_MAXB || nbounds < 0 || nbounds > OL_MAXB || (nbounds && !bounds_host))
+        return D3_ERR_ARG;
+    OlBounds bd;
+    bd.n = nbounds;
+    for (int i = 0; i < OL_MAXB; i++) bd.v[i] = i < nbounds ? bounds_host[i] : 0.f;
+    orient_loss_kernel<<<1, OL_T, 0, d3_stream(stream)>>>(preds, ld_batch, ld_edge, edge_index, num_src, num_tar, assign, rotations,
+                                                        rot_masks, B, E, K, G, num_bins, bd, dpreds, out2);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- stack -> batch
 // PointGroup.convert_stack_to_batch + get_object_assignments (reference model/pointgroup.py:216-263) in three launches
 // instead of ~45 library launches over a few dozen proposals.  Proposal p of scene b with rank r among the kept

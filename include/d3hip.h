@@ -334,6 +334,23 @@ int d3_offset_loss(const float *pt, const float *coords, const float *info, int 
  * dscore: (P) d loss / d score; out[0] = loss. */
 int d3_score_loss(const float *scores, const float *ious, int P, int nInst, float fg, float bg, float *gt_iou,
                   float *dscore, float *out, void *stream);
+/* compute_cap_loss (lib/captioning/loss_helper.py:177-224) in two launches: pred (N,S,V) logits, target (N, S) int64 with row
+ * pitch ld_target (a view of lang_ids[:, 1:S+1]), good (N) bool = descriptions whose target box passed the IoU threshold (the
+ * others count as ignored, like target 0).  out2 = [sum of the word losses / count, word accuracy], count = max(#counted
+ * words, 1); dpred (N,S,V) = d loss / d logits.  ws: d3_masked_xe_ws_bytes(N, S).  Deterministic. */
+size_t d3_masked_xe_ws_bytes(int N, int S);
+int d3_masked_xe(const float *pred, const long long *target, long long ld_target, const unsigned char *good, int N, int S, int V,
+                 float *dpred, float *out2, void *ws, size_t ws_bytes, void *stream);
+/* compute_node_orientation_loss (lib/captioning/loss_helper.py:244-307) in one launch.  preds: the num_bins orientation logits of
+ * edge e of scene b at preds[b * ld_batch + e * ld_edge + 0..num_bins) (a view of the (B, E, num_bins + 1) edge predictions);
+ * edge_index (B,2,E) float (compacted node ids; padded entries 0), num_src / num_tar (B) int64 (edges >= num_src * num_tar of a
+ * scene get weight 0), assign (B,K) int64 = GT object of every proposal slot, rotations (B,G,3,3), rot_masks (B,G) fp32;
+ * bounds_host = HOST pointer to the nbounds = num_bins - 1 bin boundaries (`radian_to_label`, :226-242), passed as kernel
+ * arguments.  out2 = [loss, accuracy]; dpreds (B*E, num_bins) = d loss / d logits.  Deterministic (fixed-order reduction). */
+int d3_orientation_loss(const float *preds, long long ld_batch, long long ld_edge, const float *edge_index,
+                        const long long *num_src, const long long *num_tar, const long long *assign, const float *rotations,
+                        const float *rot_masks, int B, int E, int K, int G, int num_bins, const float *bounds_host,
+                        int nbounds, float *dpreds, float *out2, void *stream);
 /* PointGroup.convert_stack_to_batch + get_object_assignments (reference model/pointgroup.py:216-263).  Kept proposals
  * (feats (P,m), crop (P,9): centre, size, -, semantic class, -; scores (P); bids (P) scene of each) are scattered to the
  * padded, per-scene shuffled (B,K,.) tensors, which the caller has zeroed: slot = b*K + inv_perm[b][rank of p in b]

@@ -272,3 +272,96 @@ def test_fused_adamw_follows_load_state_dict(dev):
         a2.step(); b.step()
     for p, q in zip(ps, ref):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+
+
+def test_orientation_loss_one_launch_matches_library_form_and_reference(dev):
+    """d3_orientation_loss (csrc/heads.hip) against the library-op form of compute_node_orientation_loss and the reference's own
+    value (tests/golden/speaker_golden.npz ori/*, lib/captioning/loss_helper.py:244-307): loss, accuracy, gradient of the
+    logits; then on rotations by exact multiples of 90 degrees (angles ON the bin boundaries), padded edge slots, a scene
+    without live edges, and through the strided view of the (B, E, bins + 1) edge predictions the model hands over."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import gen_speaker_golden as G
+    from d3net_amd.captioning_loss import compute_node_orientation_loss
+    g = np.load(os.path.join(here, "golden", "speaker_golden.npz"))
+
+    def both(inp):
+        outs = []
+        for native in (True, False):
+            d = {k: v.clone() for k, v in inp.items()}
+            full = d.pop("edge_preds_full").requires_grad_(True)
+            d["edge_orientations"] = full[:, :, :-1]
+            loss, acc = compute_node_orientation_loss(d, 6, native=native)
+            (loss * 1.7).backward()
+            outs.append((float(loss), float(acc), full.grad.clone()))
+        return outs
+
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in G.orientation_inputs().items()}
+    eo = inp.pop("edge_orientations")
+    inp["edge_preds_full"] = torch.cat([eo, torch.randn(eo.shape[0], eo.shape[1], 1, device=dev)], -1)
+    (ln, an, gn), (ll, al, gl) = both(inp)
+    assert abs(ln - float(g["ori/loss"])) < 1e-5 and abs(an - float(g["ori/acc"])) < 1e-6
+    assert abs(ln - ll) < 1e-5 and abs(an - al) < 1e-6
+    assert torch.allclose(gn, gl, atol=1e-7, rtol=1e-4) and float(gn[:, :, -1].abs().max()) == 0.0
+    # boundary angles: rotations about z by k * 30 degrees (cos exactly representable only for some) and exact quarter turns
+    rng = np.random.default_rng(3)
+    B, K, L, Gn = 3, 256, 10, 128
+    E = K * L
+
+    def rotz(a):
+        c, s_ = np.float32(np.cos(a)), np.float32(np.sin(a))
+        return np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+
+    quarter = [np.array(m, np.float32) for m in ([[1, 0, 0], [0, 1, 0], [0, 0, 1]], [[0, -1, 0], [1, 0, 0], [0, 0, 1]],
+                                                 [[-1, 0, 0], [0, -1, 0], [0, 0, 1]], [[0, 1, 0], [-1, 0, 0], [0, 0, 1]])]
+    rots = np.stack([np.stack([quarter[rng.integers(4)] if rng.random() < 0.5 else rotz(rng.integers(12) * np.pi / 6)
+                               for _ in range(Gn)]) for _ in range(B)])
+    ei = np.zeros((B, 2, E), np.float32)
+    nsrc, ntar = np.array([200, 0, 37], np.int64), np.array([10, 0, 9], np.int64)
+    for b in range(B):
+        n = int(nsrc[b] * ntar[b])
+        ei[b, :, :n] = rng.integers(0, K, (2, n))
+    inp2 = dict(object_assignment=torch.from_numpy(rng.integers(0, Gn, (B, K)).astype(np.int64)).to(dev),
+                edge_index=torch.from_numpy(ei).to(dev), num_edge_source=torch.from_numpy(nsrc).to(dev),
+                num_edge_target=torch.from_numpy(ntar).to(dev), scene_object_rotations=torch.from_numpy(rots).to(dev),
+                scene_object_rotation_masks=torch.from_numpy((rng.random((B, Gn)) > 0.3).astype(np.float32)).to(dev),
+                edge_preds_full=torch.randn(B, E, 7, device=dev))
+    (ln, an, gn), (ll, al, gl) = both(inp2)
+    assert abs(ln - ll) < 2e-5 * max(1.0, abs(ll)) and abs(an - al) < 1e-5, (ln, ll, an, al)
+    assert torch.allclose(gn, gl, atol=1e-7, rtol=1e-4)
+    # no live edge anywhere: loss 0, accuracy 0, zero gradient
+    inp3 = dict(inp2, num_edge_source=torch.zeros(B, dtype=torch.long, device=dev))
+    (ln, an, gn), (ll, al, gl) = both(inp3)
+    assert ln == 0.0 and an == 0.0 and ll == 0.0 and float(gn.abs().max()) == 0.0
+
+
+def test_caption_cross_entropy_two_launches_matches_library_form(dev):
+    """d3_masked_xe against the library-op form of compute_cap_loss (lib/captioning/loss_helper.py:177-224): loss, word accuracy
+    and the gradient of the logits at the config's shape (32 descriptions x 29 steps x V = 3004), with descriptions whose box is
+    not good, padded (0) targets, an exactly tied row maximum, and the all-bad batch (loss 0, zero gradient)."""
+    from d3net_amd.captioning_loss import compute_cap_loss
+    torch.manual_seed(4)
+    N, S, V, ML = 32, 29, 3004, 32
+    ids = torch.randint(1, V, (N, ML), device=dev)
+    lens = torch.randint(3, S + 1, (N,), device=dev)
+    ids = torch.where(torch.arange(ML, device=dev).view(1, -1) <= lens.view(-1, 1), ids, torch.zeros_like(ids))
+    good = torch.rand(N, device=dev) > 0.3
+    logits = torch.randn(N, S, V, device=dev)
+    logits[0, 0, 7] = logits[0, 0, 1900] = 9.0          # tie: the first index wins in both forms
+    ids[0, 1] = 7
+
+    def run(native, good):
+        p = logits.clone().requires_grad_(True)
+        d = dict(lang_cap=p, lang_ids=ids, good_bbox_masks=good, bbox_feature=logits)
+        loss, d = compute_cap_loss(d, {"use_rl": False, "max_len": ML}, native=native)
+        (loss * 0.6).backward()
+        return float(loss), float(d["cap_acc"]), p.grad
+
+    (ln, an, gn), (ll, al, gl) = run(True, good), run(False, good)
+    assert abs(ln - ll) < 2e-6 * abs(ll) and abs(an - al) < 1e-6, (ln, ll, an, al)
+    assert torch.allclose(gn, gl, atol=1e-9, rtol=1e-4)
+    bad = torch.zeros_like(good)
+    (ln, an, gn), (ll, al, gl) = run(True, bad), run(False, bad)
+    assert ln == 0.0 and ll == 0.0 and an == 0.0 and float(gn.abs().max()) == 0.0
