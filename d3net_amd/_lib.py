@@ -85,6 +85,9 @@ SIGNATURES = {
     "d3_adamw_chunk": (i32, []),
     "d3_adamw": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, f64, vp]),
     "d3_score_loss": (i32, [vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
+    "d3_caption_select_target": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "d3_caption_inputs_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "d3_caption_inputs_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3_masked_xe_ws_bytes": (sz, [i32, i32]),
     "d3_masked_xe": (i32, [vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
     "d3_orientation_loss": (i32, [vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]),

@@ -342,6 +342,59 @@ def _aabb_iou(c1, c2):
     return inter / ((mx1 - mn1).prod(-1) + (mx2 - mn2).prod(-1) - inter + 1e-8)
 
 
+class _CaptionInputs(torch.autograd.Function):
+    """Per-description inputs of the captioner straight from the per-scene tensors (csrc/proposals.hip: d3_caption_inputs_*):
+    obj (N,K,F) = bbox_feature[scene] (+ the target's edge features on its adjacency-row neighbours, caption_module.py:866-885),
+    target_feats (N,F) = bbox_feature[scene, target], valid (N,K) = the target's local-context mask row.  No per-description
+    copies of the (B,K,L,F) edge features / (B,K,K) masks, no masked_scatter; the backward sums a scene's descriptions in
+    order (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, base, edge, adj, locals_, target_ids, per_scene):
+        B, K, Fd = base.shape
+        N = target_ids.numel()
+        dev = base.device
+        L = edge.shape[2] if edge is not None else 1
+        base_c = base.contiguous()
+        edge_c = edge.contiguous() if edge is not None else None
+        adj_c = adj.contiguous().float() if edge is not None else None
+        loc_c = locals_.contiguous().float() if locals_ is not None else None
+        tid = target_ids.contiguous()
+        obj = torch.empty((N, K, Fd), dtype=torch.float32, device=dev)
+        tf = torch.empty((N, Fd), dtype=torch.float32, device=dev)
+        valid = torch.empty((N, K), dtype=torch.float32, device=dev) if loc_c is not None else None
+        nbr = torch.empty((N, L), dtype=torch.int32, device=dev)
+        with _on(dev):
+            check(_lib.lib().d3_caption_inputs_fwd(_ptr(base_c), _ptr(edge_c) if edge_c is not None else None,
+                                                   _ptr(adj_c) if adj_c is not None else None,
+                                                   _ptr(loc_c) if loc_c is not None else None, _ptr(tid), N, per_scene, K, L, Fd,
+                                                   _ptr(obj), _ptr(tf), _ptr(valid) if valid is not None else None, _ptr(nbr), _stream()),
+                  "caption_inputs_fwd")
+        ctx.save_for_backward(tid, nbr)
+        ctx.dims = (B, K, L, Fd, N, per_scene, edge is not None)
+        if valid is None:
+            valid = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(valid)
+        return obj, tf, valid
+
+    @staticmethod
+    def backward(ctx, g_obj, g_tf, _g_valid):
+        tid, nbr = ctx.saved_tensors
+        B, K, L, Fd, N, per_scene, has_edge = ctx.dims
+        dev = tid.device
+        if g_obj is None:
+            g_obj = torch.zeros((N, K, Fd), dtype=torch.float32, device=dev)
+        g_obj = g_obj.contiguous()
+        g_tf = g_tf.contiguous() if g_tf is not None else None
+        d_base = torch.empty((B, K, Fd), dtype=torch.float32, device=dev)
+        d_edge = torch.zeros((B, K, L, Fd), dtype=torch.float32, device=dev) if has_edge else None
+        with _on(dev):
+            check(_lib.lib().d3_caption_inputs_bwd(_ptr(g_obj), _ptr(g_tf) if g_tf is not None else None, _ptr(tid), _ptr(nbr), N,
+                                                   per_scene, K, L, Fd, _ptr(d_base), _ptr(d_edge) if d_edge is not None else None,
+                                                   _stream()), "caption_inputs_bwd")
+        return d_base, d_edge, None, None, None, None
+
+
 class TopDownSceneCaptionModule(nn.Module):
     """(reference: model/caption_module.py:13-898)"""
 
@@ -565,26 +618,43 @@ class TopDownSceneCaptionModule(nn.Module):
     def select_target(self, bbox_objness, bbox_center, bbox_corner, bbox_center_label, bbox_corner_label, ref_box_label,
                       ref_box_corner_label, is_annotated, bbox_id_label=None):
         """(:416-508) target proposal per description: best IoU with the referred box when annotated, else a random
-        non-empty proposal (python `random`, one draw per such sample, in sample order) assigned to its nearest GT."""
-        N, K, _ = bbox_center.shape
+        non-empty proposal (python `random`, one draw per such sample, in sample order) assigned to its nearest GT.
+        The proposal / GT tensors are PER SCENE ((B,K,.), (B,G,.)); description n belongs to scene n // (N // B) -- the
+        reference replicates them per description first."""
+        N = ref_box_corner_label.shape[0]
+        B, K, _ = bbox_center.shape
+        per = N // B
         if self.use_oracle:
             raise NotImplementedError("use_oracle (model.no_detection) is off in every shipped config")
-        ious = _aabb_iou(bbox_corner, ref_box_corner_label.unsqueeze(1))          # (N,K)
-        ann_ids = ious.argmax(1)
-        ann_ious = ious.gather(1, ann_ids.unsqueeze(1)).squeeze(1)
-        ann_lab = ref_box_label.argmax(-1)
-        target_ids, target_ious, labels = ann_ids.clone(), ann_ious.clone(), ann_lab.clone()
+        if self.native and bbox_corner.is_cuda and bbox_corner.dtype == torch.float32:
+            dev = bbox_corner.device
+            ref_box_label = ref_box_label.float()
+            target_ids = torch.empty(N, dtype=torch.int64, device=dev)
+            labels = torch.empty(N, dtype=torch.int64, device=dev)
+            target_ious = torch.empty(N, dtype=torch.float32, device=dev)
+            with _on(dev):   # one launch: IoU of the referred box with the scene's K proposals, first maximum; label arg-max
+                check(_lib.lib().d3_caption_select_target(_ptr(bbox_corner.contiguous()), _ptr(ref_box_corner_label.contiguous().float()),
+                                                          _ptr(ref_box_label.contiguous()), N, per, K, ref_box_label.shape[1],
+                                                          _ptr(target_ids), _ptr(target_ious), _ptr(labels), _stream()),
+                      "caption_select_target")
+        else:
+            bidx = torch.arange(N, device=bbox_corner.device) // per
+            ious = _aabb_iou(bbox_corner.index_select(0, bidx), ref_box_corner_label.unsqueeze(1))          # (N,K)
+            ann_ids = ious.argmax(1)
+            target_ids, target_ious = ann_ids.clone(), ious.gather(1, ann_ids.unsqueeze(1)).squeeze(1)
+            labels = ref_box_label.argmax(-1)
         not_ann = (is_annotated != 1).nonzero().view(-1).tolist()
         if not_ann:
             objness = bbox_objness.cpu()
             for n in not_ann:
-                valid = (objness[n] == 1).nonzero().view(-1)
+                b = n // per
+                valid = (objness[b] == 1).nonzero().view(-1)
                 pool = valid if len(valid) > 0 else torch.arange(K)
                 t = int(pool[random.randrange(len(pool))])                         # == random.choice(valid_ids)
-                d = ((bbox_center[n, t].unsqueeze(0) - bbox_center_label[n]) ** 2).sum(-1)   # nn_distance default (squared L2)
+                d = ((bbox_center[b, t].unsqueeze(0) - bbox_center_label[b]) ** 2).sum(-1)   # nn_distance default (squared L2)
                 a = int(d.argmin())
                 target_ids[n], labels[n] = t, a
-                target_ious[n] = _aabb_iou(bbox_corner[n, t], bbox_corner_label[n, a])
+                target_ious[n] = _aabb_iou(bbox_corner[b, t], bbox_corner_label[b, a])
         return target_ids, target_ious, labels
 
     def _query_locals(self, corners, target_ids, object_masks, include_self=True, overlay_threshold=0.5):
@@ -611,24 +681,30 @@ class TopDownSceneCaptionModule(nn.Module):
         N = des_lens.shape[0]
         Cn = N // data_dict["center_label"].shape[0]
         rep = lambda t: t.unsqueeze(1).repeat(1, Cn, *([1] * (t.dim() - 1))).reshape(N, *t.shape[1:])
-        center_labels, corner_labels = rep(data_dict["center_label"]), rep(data_dict["gt_bbox"])
-        obj_feats, obj_centers = rep(data_dict["bbox_feature"]), rep(data_dict["proposal_center_batched"])
-        obj_corners, obj_masks = rep(data_dict["proposal_bbox_batched"]), rep(data_dict["proposal_batch_mask"])
+        obj_masks = rep(data_dict["proposal_batch_mask"])
         num_words = int(des_lens.max())
 
-        target_ids, target_ious, labels = self.select_target(obj_masks, obj_centers, obj_corners, center_labels, corner_labels,
-                                                             ref_labels, ref_corners, is_annotated)
+        target_ids, target_ious, labels = self.select_target(
+            data_dict["proposal_batch_mask"], data_dict["proposal_center_batched"], data_dict["proposal_bbox_batched"],
+            data_dict["center_label"], data_dict["gt_bbox"], ref_labels, ref_corners, is_annotated)
         data_dict["assigned_bbox_id_labels"] = labels
-        target_feats = obj_feats.gather(1, target_ids.view(N, 1, 1).expand(-1, 1, self.feat_size)).squeeze(1)
-        if L == -1:
-            valid_masks = obj_masks
-        else:   # one launch for the B scenes, then pick the rows of the N targets
-            allm = query_locals_all(data_dict["proposal_bbox_batched"], data_dict["proposal_batch_mask"], L, True,
-                                    0.5, self.query_mode)
-            valid_masks = rep(allm).gather(1, target_ids.view(N, 1, 1).expand(-1, 1, K)).squeeze(1)
+        allm = None
+        if L != -1:   # one launch for the B scenes, then the rows of the N targets
+            allm = query_locals_all(data_dict["proposal_bbox_batched"], data_dict["proposal_batch_mask"], L, True, 0.5, self.query_mode)
+        base = data_dict["bbox_feature"]
+        if self.native and base.is_cuda and base.dtype == torch.float32 and self.feat_size % 4 == 0:
+            # per-description inputs straight from the per-scene tensors (no (N,K,L,F) / (N,K,K) copies, no masked_scatter)
+            obj_feats, target_feats, vm = _CaptionInputs.apply(base, data_dict["edge_feature"] if self.use_relation else None,
+                                                               data_dict["adjacent_mat"] if self.use_relation else None, allm,
+                                                               target_ids, Cn)
+            valid_masks = vm if allm is not None else obj_masks
+        else:
+            obj_feats = rep(base)
+            target_feats = obj_feats.gather(1, target_ids.view(N, 1, 1).expand(-1, 1, self.feat_size)).squeeze(1)
+            valid_masks = obj_masks if allm is None else rep(allm).gather(1, target_ids.view(N, 1, 1).expand(-1, 1, K)).squeeze(1)
+            if self.use_relation:
+                obj_feats = self._add_relation_feat(rep(data_dict["edge_feature"]), rep(data_dict["adjacent_mat"]), obj_feats, target_ids)
         valid_masks = valid_masks.unsqueeze(-1)
-        if self.use_relation:
-            obj_feats = self._add_relation_feat(rep(data_dict["edge_feature"]), rep(data_dict["adjacent_mat"]), obj_feats, target_ids)
 
         if use_rl:   # self-critical: sampled = best beams (with gradients), baseline = greedy (:588-633)
             assert beam_opt

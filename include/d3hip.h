@@ -541,6 +541,23 @@ int d3_cider_scores(const int *tokens, int ldt, const int *lens, const int *slot
  * for target id t before its top-k (invalid / overlaid (IoU >= overlay_threshold) -> 1e30, self -> 0 or 1e30). */
 int d3_query_locals_dist(const float *corners, const float *masks, float *dist, int B, int K, int include_self,
                          float overlay_threshold, int center_mode, void *stream);
+/* The captioner's per-description inputs straight from the per-scene tensors (model/caption_module.py:416-508 `select_target`,
+ * :530-560, :866-885 `_add_relation_feat`); description n belongs to scene n / per_scene.
+ *   select_target: target_ids[n] = first arg-max over the scene's K proposals of the AABB IoU (lib/utils/bbox.py:247-271, fp32,
+ *                  operation by operation as the library ops) between corners (B,K,8,3) and ref_corners (N,8,3); target_ious[n]
+ *                  that IoU; labels[n] = first arg-max of ref_labels (N,G).
+ *   inputs_fwd   : obj (N,K,F) = base[b] with edge[b][t][j] (edge: (B,K,L,F), NULL: none) added at the j-th one of the target's
+ *                  adjacency row adj[b][t] (B,K,K); target_feats (N,F) = base[b][t]; valid (N,K) = locals[b][t] (NULL: skipped);
+ *                  nbr (N,L) int32 = those slots (saved for the backward).
+ *   inputs_bwd   : d_base (B,K,F), d_edge (B,K,L,F; zero-filled by the caller, NULL: none) from g_obj (N,K,F), g_target (N,F) or
+ *                  NULL; a scene's descriptions are summed in ascending order (deterministic, no atomics). */
+int d3_caption_select_target(const float *corners, const float *ref_corners, const float *ref_labels, int N, int per_scene, int K,
+                             int G, long long *target_ids, float *target_ious, long long *labels, void *stream);
+int d3_caption_inputs_fwd(const float *base, const float *edge, const float *adj, const float *locals, const long long *target_ids,
+                          int N, int per_scene, int K, int L, int F, float *obj, float *target_feats, float *valid, int *nbr,
+                          void *stream);
+int d3_caption_inputs_bwd(const float *g_obj, const float *g_target, const long long *target_ids, const int *nbr, int N, int per_scene,
+                          int K, int L, int F, float *d_base, float *d_edge, void *stream);
 
 #ifdef __cplusplus
 }

@@ -189,3 +189,76 @@ def test_native_graph_module_matches_per_scene_form_with_gradients(dev):
     for k in a[1]:
         assert float((a[1][k] - b[1][k]).abs().max()) < 1e-3 * (float(a[1][k].abs().max()) + 1e-9), k
     assert float((a[2] - b[2]).abs().max()) < 1e-3 * float(a[2].abs().max())
+
+
+def test_caption_inputs_from_per_scene_tensors_equal_the_replicated_form(dev):
+    """d3_caption_select_target / d3_caption_inputs_fwd / _bwd against the reference's form (replicate every per-scene tensor per
+    description, gather, masked_scatter: model/caption_module.py:416-508, :530-560, :866-885) at the config's shape: identical
+    target ids / IoUs / labels / object features / masks (bit for bit), gradients of the proposal and edge features to 1e-6,
+    including two descriptions of a scene that pick the same target."""
+    import random
+    from d3net_amd.speaker import TopDownSceneCaptionModule, query_locals_all
+    import gen_speaker_golden as G
+    torch.manual_seed(2)
+    B, Cn, K, L, Fd = 4, 8, 256, 10, 128
+    N = B * Cn
+    cfg, vocab, emb = G.make_cfg(), G.make_vocab(), G.make_embeddings()
+    cap = TopDownSceneCaptionModule(cfg, vocab, emb, num_proposals=K, num_locals=L, use_relation=True).to(dev)
+    rng = np.random.default_rng(5)
+    ctr = rng.random((B, K, 3)).astype(np.float32) * 4
+    sz = (0.2 + rng.random((B, K, 3))).astype(np.float32)
+    sg = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+    corners = torch.from_numpy(ctr[:, :, None] + sg[None, None] * sz[:, :, None] / 2).to(dev)
+    mask = torch.from_numpy((rng.random((B, K)) < 0.45).astype(np.float32)).to(dev)
+    pick = rng.integers(0, K, N)
+    pick[1] = pick[0]                                              # same target twice in scene 0
+    refc = corners.view(B, 1, K, 8, 3).expand(B, Cn, K, 8, 3).reshape(N, K, 8, 3)[torch.arange(N), torch.from_numpy(pick).to(dev)]
+    refc = refc + 0.03 * torch.randn(N, 1, 3, device=dev)
+    ref_lab = torch.zeros(N, 128, device=dev)
+    ref_lab[torch.arange(N), torch.from_numpy(rng.integers(0, 128, N)).to(dev)] = 1
+    adj = query_locals_all(corners, mask, L, False, 0.5, "corner")
+    d = dict(proposal_batch_mask=mask, proposal_center_batched=torch.from_numpy(ctr).to(dev), proposal_bbox_batched=corners,
+             center_label=torch.randn(B, 128, 3, device=dev), gt_bbox=torch.randn(B, 128, 8, 3, device=dev),
+             ref_box_label=ref_lab.view(B, Cn, 128), ref_box_corner_label=refc.view(B, Cn, 8, 3),
+             annotated=torch.ones(B, Cn, device=dev), adjacent_mat=adj,
+             lang_ids=torch.randint(1, 30, (B, Cn, cfg.data.max_spk_len + 2), device=dev),
+             lang_len=torch.full((B, Cn), 6, device=dev))
+    base0, edge0 = torch.randn(B, K, Fd, device=dev), torch.randn(B, K, L, Fd, device=dev)
+    wobj, wtf = torch.randn(N, K, Fd, device=dev), torch.randn(N, Fd, device=dev)
+    got = {}
+
+    def hook(mode, *a):       # capture the captioner's inputs instead of running the recurrence
+        got[mode] = a
+        raise StopIteration
+
+    outs = {}
+    for mode, native in (("native", True), ("library", False)):
+        cap.native = native
+        base, edge = base0.clone().requires_grad_(True), edge0.clone().requires_grad_(True)
+        dd = dict(d, bbox_feature=base, edge_feature=edge)
+        import d3net_amd.speaker as SP
+        orig_apply, orig_step = SP.TopDownXEFunction.apply, cap.step
+        SP.TopDownXEFunction.apply = staticmethod(lambda emb_, wid, vm, S, obj, tf, *p: hook(mode, vm, obj, tf))
+        cap.step = lambda word, hid, tf, obj, vm, proj: hook(mode, vm.squeeze(-1), obj, tf)
+        try:
+            cap._forward_sample_batch(dd, True, False)
+        except StopIteration:
+            pass
+        finally:
+            SP.TopDownXEFunction.apply, cap.step = orig_apply, orig_step
+        vm, obj, tf = got[mode]
+        ((obj * wobj).sum() + (tf * wtf).sum()).backward()
+        outs[mode] = (dd["assigned_bbox_id_labels"], vm.reshape(N, K).float(), obj, tf, base.grad, edge.grad)
+    a, b = outs["native"], outs["library"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert torch.allclose(a[4], b[4], atol=1e-5, rtol=1e-5) and torch.allclose(a[5], b[5], atol=1e-5, rtol=1e-5)
+    assert float(a[5].abs().sum()) > 0
+    # target ids / IoUs of the kernel against the library-op IoU chain
+    cap.native = True
+    ids_n, ious_n, lab_n = cap.select_target(mask, d["proposal_center_batched"], corners, d["center_label"], d["gt_bbox"], ref_lab, refc,
+                                             torch.ones(N, device=dev))
+    cap.native = False
+    ids_l, ious_l, lab_l = cap.select_target(mask, d["proposal_center_batched"], corners, d["center_label"], d["gt_bbox"], ref_lab, refc,
+                                             torch.ones(N, device=dev))
+    assert torch.equal(ids_n, ids_l) and torch.equal(ious_n, ious_l) and torch.equal(lab_n, lab_l)
+    assert torch.equal(ids_n.cpu(), torch.from_numpy(pick))
