@@ -84,6 +84,9 @@ SIGNATURES = {
     "d3_stack_to_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_adamw_chunk": (i32, []),
     "d3_adamw": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, f64, vp]),
+    "d3_point_heads_ws_bytes": (sz, []),
+    "d3_point_heads_fwd": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                 vp, sz, vp]),
     "d3_score_loss": (i32, [vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
     "d3_caption_select_target": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "d3_caption_inputs_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),

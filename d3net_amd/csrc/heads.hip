@@ -133,6 +133,156 @@ extern "C" int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *
     return 0;
 }
 
+// ------------------------------------------------------------------------------ point heads, forward
+// The two point-level heads of PointGroup on the (N, m = 16) backbone output (reference model/pointgroup.py:77-85, 277-283):
+//   semantic_scores = sem_seg(x) (m -> C <= 32), semantic_preds = row arg-max, and
+//   pt_offsets = Linear(m,3)(ReLU(BatchNorm1d(Linear(m,m)(x)))).
+// As library calls: three GEMMs with K = 16 (77 / 40 / 41 us at 746 k rows: the BLAS picks generic tiles), a 76 us row-max
+// reduction, batch-norm statistics + transform + clamp -- 440 us for ~340 MB of compulsory traffic.  Here:
+//   pth_fwd_kernel : x read ONCE; a wave owns 16 rows per step: the three 16x16 output tiles (scores 0..15, scores 16..31,
+//                    hidden) as 12 v_mfma_f32_16x16x4f32 (exact fp32 products) from one float4 of x per lane with the weights
+//                    resident in registers; row arg-max across the 16-lane groups (first maximum); per-channel sum / sum of
+//                    squares of the hidden layer for the batch norm (per-workgroup partials, fixed order);
+//   pth_bn_kernel  : statistics -> mean / 1/sqrt(var + eps) (fp64, fixed order) + the running-statistics update of
+//                    nn.BatchNorm1d (or, in eval mode, the running statistics themselves);
+//   pth_out_kernel : y = ReLU(BN(h)) (kept for the backward) and the (N,3) offsets, one thread per row.
+typedef float ph_f32x4 __attribute__((ext_vector_type(4)));
+#define PH_GRID 2048
+__global__ __launch_bounds__(256) void pth_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Ws, const float *__restrict__ bs,
+                                                     const float *__restrict__ W0, const float *__restrict__ b0, int N, int C,
+                                                     float *__restrict__ scores, long long *__restrict__ preds, float *__restrict__ h,
+                                                     float *__restrict__ part) {
+    __shared__ float red[4][2][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, q = lane >> 4;
+    float ws0[4], ws1[4], wh[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int k = 4 * q + c;
+        ws0[c] = j < C ? Ws[j * 16 + k] : 0.f;
+        ws1[c] = 16 + j < C ? Ws[(16 + j) * 16 + k] : 0.f;
+        wh[c] = W0[j * 16 + k];
+    }
+    const float bias0 = j < C ? bs[j] : 0.f, bias1 = 16 + j < C ? bs[16 + j] : 0.f, biash = b0[j];
+    float s1 = 0.f, s2 = 0.f;
+    const long long ntiles = ((long long)N + 15) >> 4;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long row0 = tile << 4;
+        const long long ra = row0 + j;
+        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ra < N) xa = *(const float4 *)(x + ra * 16 + 4 * q);
+        const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+        ph_f32x4 a0 = {bias0, bias0, bias0, bias0}, a1 = {bias1, bias1, bias1, bias1}, ah = {biash, biash, biash, biash};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], ws0[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], ws1[c], a1, 0, 0, 0);
+            ah = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], wh[c], ah, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long row = row0 + 4 * q + r;
+            const bool ok = row < N;
+            if (ok) {
+                if (j < C) scores[row * C + j] = a0[r];
+                if (16 + j < C) scores[row * C + 16 + j] = a1[r];
+                h[row * 16 + j] = ah[r];
+                s1 += ah[r]; s2 += ah[r] * ah[r];
+            }
+            float bv = j < C ? a0[r] : -INFINITY;
+            int bi = j;
+            if (16 + j < C && a1[r] > bv) { bv = a1[r]; bi = 16 + j; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (ok && j == 0) preds[row] = bi;
+        }
+    }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lane < 16) { red[wave][0][lane] = s1; red[wave][1][lane] = s2; }
+    __syncthreads();
+    if (t < 32) {
+        const int w = t >> 4, c = t & 15;
+        part[(long long)blockIdx.x * 32 + w * 16 + c] = (red[0][w][c] + red[1][w][c]) + (red[2][w][c] + red[3][w][c]);
+    }
+}
+// stat[0..15] = mean, stat[16..31] = 1 / sqrt(var + eps)
+__global__ __launch_bounds__(1024) void pth_bn_kernel(const float *__restrict__ part, int nblocks, long long N, float eps, float momentum,
+                                                     int training, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                     long long *__restrict__ tracked, float *__restrict__ stat) {
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;     // one wave per channel
+    if (!training) {
+        if (lane == 0) { stat[c] = running_mean[c]; stat[16 + c] = 1.f / sqrtf(running_var[c] + eps); }
+        return;
+    }
+    double sa = 0., sb = 0.;
+    for (int b = lane; b < nblocks; b += 64) { sa += (double)part[(long long)b * 32 + c]; sb += (double)part[(long long)b * 32 + 16 + c]; }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+    if (lane != 0) return;
+    const double m = sa / (double)N;
+    double v = sb / (double)N - m * m;
+    if (v < 0.) v = 0.;
+    stat[c] = (float)m; stat[16 + c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v * ((double)N / (double)(N > 1 ? N - 1 : 1)));
+    }
+    if (c == 0 && tracked) tracked[0] += 1;
+}
+__global__ __launch_bounds__(256) void pth_out_kernel(const float *__restrict__ h, const float *__restrict__ stat,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     const float *__restrict__ W3, const float *__restrict__ b3, long long N,
+                                                     float *__restrict__ y, float *__restrict__ off) {
+    __shared__ float sm[16 * 4 + 48 + 3];
+    float *mean = sm, *inv = sm + 16, *g = sm + 32, *bt = sm + 48, *w = sm + 64, *bb = sm + 112;
+    const int t = threadIdx.x;
+    if (t < 16) { mean[t] = stat[t]; inv[t] = stat[16 + t]; g[t] = gamma[t]; bt[t] = beta[t]; }
+    if (t < 48) w[t] = W3[t];
+    if (t < 3) bb[t] = b3[t];
+    __syncthreads();
+    const long long r = (long long)blockIdx.x * blockDim.x + t;
+    if (r >= N) return;
+    float o0 = bb[0], o1 = bb[1], o2 = bb[2];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+        const float4 v = *(const float4 *)(h + r * 16 + c4 * 4);
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = c4 * 4 + e;
+            const float z = fmaf((in[e] - mean[c]) * inv[c], g[c], bt[c]);
+            out[e] = z > 0.f ? z : 0.f;
+            o0 = fmaf(out[e], w[c], o0); o1 = fmaf(out[e], w[16 + c], o1); o2 = fmaf(out[e], w[32 + c], o2);
+        }
+        *(float4 *)(y + r * 16 + c4 * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+    off[r * 3] = o0; off[r * 3 + 1] = o1; off[r * 3 + 2] = o2;
+}
+extern "C" size_t d3_point_heads_ws_bytes(void) { return (size_t)PH_GRID * 32 * sizeof(float); }
+extern "C" int d3_point_heads_fwd(const float *x, long long N, int m, int C, const float *Ws, const float *bs, const float *W0,
+                                  const float *b0, const float *gamma, const float *beta, const float *W3, const float *b3, float eps,
+                                  float momentum, int training, float *running_mean, float *running_var, long long *num_batches_tracked,
+                                  float *scores, long long *preds, float *h, float *y, float *offsets, float *stat, void *ws,
+                                  size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (N <= 0) return 0;
+    if (m != 16 || C < 1 || C > 32) return D3_ERR_ARG;
+    if (ws == nullptr || ws_bytes < d3_point_heads_ws_bytes()) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    const long long ntiles = (N + 15) >> 4;
+    int grid = (int)((ntiles + 3) / 4 < PH_GRID ? (ntiles + 3) / 4 : PH_GRID);
+    pth_fwd_kernel<<<grid, 256, 0, s>>>(x, Ws, bs, W0, b0, (int)N, C, scores, preds, h, (float *)ws);
+    pth_bn_kernel<<<1, 1024, 0, s>>>((const float *)ws, grid, N, eps, momentum, training, running_mean, running_var, num_batches_tracked,
+                                    stat);
+    pth_out_kernel<<<(int)((N + 255) / 256), 256, 0, s>>>(h, stat, gamma, beta, W3, b3, N, y, offsets);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ softmax cross entropy
 // per row: loss = logsumexp(z) - z[label] (label != ignore), grad = softmax(z) - onehot (0 for ignored rows).
 // part[block][2] = (sum of losses, number of counted rows) in fp32; the reduce kernel produces loss_sum, count.

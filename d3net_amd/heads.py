@@ -45,6 +45,88 @@ def linear(module, x):
     return module(x)
 
 
+class _PointHeads(Function):
+    """sem_seg + offset_net of PointGroup in three launches (csrc/heads.hip: d3_point_heads_fwd); the backward keeps the
+    existing pieces: HIP weight gradients for the three tall Linear layers, library ops for the small data gradients and
+    the batch-norm backward"""
+
+    @staticmethod
+    def forward(ctx, x, Ws, bs, W0, b0, gamma, beta, W3, b3, bn):
+        N, m = x.shape
+        Cc = Ws.size(0)
+        dev = x.device
+        x = x.contiguous()
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        scores, h, y, off, stat = f(N, Cc), f(N, m), f(N, m), f(N, 3), f(2 * m)
+        preds = torch.empty(N, dtype=torch.int64, device=dev)
+        L = _lib.lib()
+        ws = _workspace(L.d3_point_heads_ws_bytes(), dev, "ptheads")
+        training = bool(bn.training or bn.running_mean is None)
+        upd = training and bn.track_running_stats and bn.running_mean is not None
+        with _on(dev):
+            check(L.d3_point_heads_fwd(_ptr(x), N, m, Cc, _ptr(Ws.contiguous()), _ptr(bs.contiguous()), _ptr(W0.contiguous()),
+                                       _ptr(b0.contiguous()), _ptr(gamma.contiguous()), _ptr(beta.contiguous()), _ptr(W3.contiguous()),
+                                       _ptr(b3.contiguous()), float(bn.eps), float(bn.momentum), int(training),
+                                       _ptr(bn.running_mean) if (upd or not training) else None,
+                                       _ptr(bn.running_var) if (upd or not training) else None,
+                                       _ptr(bn.num_batches_tracked) if upd and bn.num_batches_tracked is not None else None,
+                                       _ptr(scores), _ptr(preds), _ptr(h), _ptr(y), _ptr(off), _ptr(stat), _ptr(ws), ws.numel(), _stream()),
+                  "point_heads_fwd")
+        ctx.save_for_backward(x, Ws, W0, gamma, W3, h, y, stat)
+        ctx.bn_args = (training, float(bn.eps), bn.running_mean, bn.running_var)
+        ctx.mark_non_differentiable(preds)
+        return scores, preds, off
+
+    @staticmethod
+    def backward(ctx, g_s, _g_p, g_o):
+        x, Ws, W0, gamma, W3, h, y, stat = ctx.saved_tensors
+        training, eps, rm, rv = ctx.bn_args
+        m = x.size(1)
+        L = _lib.lib()
+        dev = x.device
+
+        def wgrad(inp, dy, O, I):
+            dW = torch.empty((O, I), dtype=torch.float32, device=dev)
+            db = torch.empty(O, dtype=torch.float32, device=dev)
+            ws = _workspace(L.d3_tall_wgrad_ws_bytes(I, O), dev, "tallw")
+            with _on(dev):
+                check(L.d3_tall_wgrad(_ptr(inp), _ptr(dy), _ptr(dW), _ptr(db), inp.size(0), I, O, _ptr(ws), ws.numel(), _stream()),
+                      "tall_wgrad")
+            return dW, db
+
+        dx = None
+        dWs = dbs = dW0 = db0 = dg = dbeta = dW3 = db3 = None
+        if g_o is not None:
+            g_o = g_o.contiguous()
+            dW3, db3 = wgrad(y, g_o, 3, m)
+            dy = (g_o @ W3) * (y > 0)
+            dh, dg, dbeta = torch.ops.aten.native_batch_norm_backward(dy, h, gamma, rm, rv, stat[:m], stat[m:], training, eps,
+                                                                      [True, True, True])
+            dh = dh.contiguous()
+            dW0, db0 = wgrad(x, dh, m, m)
+            dx = dh @ W0
+        if g_s is not None:
+            g_s = g_s.contiguous()
+            dWs, dbs = wgrad(x, g_s, Ws.size(0), m)
+            dx = g_s @ Ws if dx is None else dx.addmm_(g_s, Ws)
+        return dx, dWs, dbs, dW0, db0, dg, dbeta, dW3, db3, None
+
+
+def point_heads(sem_seg, offset_net, x):
+    """(semantic_scores, semantic_preds, pt_offsets) of PointGroup's two point-level heads (model/pointgroup.py:77-85,
+    277-283); the fused HIP path for the shipped shape (m = 16, <= 32 classes, Linear-BN-ReLU-Linear offset head)"""
+    on = offset_net
+    bn = on[1]
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) == 16 and x.size(0) >= TALL_ROWS
+            and isinstance(bn, torch.nn.BatchNorm1d) and bn.affine and bn.momentum is not None and sem_seg.weight.size(0) <= 32
+            and on[0].weight.shape == (16, 16) and on[3].weight.shape == (3, 16) and sem_seg.bias is not None
+            and on[0].bias is not None and on[3].bias is not None and isinstance(on[2], torch.nn.ReLU)):
+        return _PointHeads.apply(x, sem_seg.weight, sem_seg.bias, on[0].weight, on[0].bias, bn.weight, bn.bias, on[3].weight,
+                                 on[3].bias, bn)
+    semantic_scores = linear(sem_seg, x)
+    return semantic_scores, semantic_scores.max(1)[1], linear(on[3], on[2](on[1](linear(on[0], x))))
+
+
 class _CrossEntropy(Function):
     @staticmethod
     def forward(ctx, z, label, ignore_index):

@@ -321,11 +321,9 @@ class PointGroup(nn.Module):
         _mark("backbone_fwd")
         pt_feats = heads.devoxelize(out_feats, data_dict["p2v_map"], data_dict.get("v2p_map"))   # (N, m)
 
-        semantic_scores = heads.linear(self.sem_seg, pt_feats)
-        semantic_preds = semantic_scores.max(1)[1]
+        # both point heads in three launches: x read once, arg-max and the batch-norm statistics in the same pass (csrc/heads.hip)
+        semantic_scores, semantic_preds, pt_offsets = heads.point_heads(self.sem_seg, self.offset_net, pt_feats)
         data_dict["semantic_scores"] = semantic_scores
-        on = self.offset_net
-        pt_offsets = heads.linear(on[3], on[2](on[1](heads.linear(on[0], pt_feats))))
         data_dict["pt_offsets"] = pt_offsets
 
         _mark("heads")

@@ -329,6 +329,16 @@ int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *db, int N, 
 size_t d3_offset_loss_ws_bytes(void);
 int d3_offset_loss(const float *pt, const float *coords, const float *info, int ldi, const int64_t *ids, long long ignore,
                    float *g1, float *g2, float *out, int N, void *ws, size_t ws_bytes, void *stream);
+/* The two point-level heads of PointGroup (model/pointgroup.py:77-85, 277-283) on x (N, m = 16): scores (N,C) = x Ws^T + bs
+ * (C <= 32), preds (N) int64 = first row arg-max, h (N,16) = x W0^T + b0, y (N,16) = ReLU(BatchNorm1d(h)) with batch statistics
+ * (training != 0: running_mean / running_var / num_batches_tracked updated like nn.BatchNorm1d when given) or the running
+ * statistics (training == 0), offsets (N,3) = y W3^T + b3.  stat (32) = [mean | 1/sqrt(var + eps)] (for the backward).
+ * Three launches; x is read once.  ws: d3_point_heads_ws_bytes(). */
+size_t d3_point_heads_ws_bytes(void);
+int d3_point_heads_fwd(const float *x, long long N, int m, int C, const float *Ws, const float *bs, const float *W0, const float *b0,
+                       const float *gamma, const float *beta, const float *W3, const float *b3, float eps, float momentum,
+                       int training, float *running_mean, float *running_var, long long *num_batches_tracked, float *scores,
+                       long long *preds, float *h, float *y, float *offsets, float *stat, void *ws, size_t ws_bytes, void *stream);
 /* Proposal score loss of PointGroup.loss (reference model/pointgroup.py:436-452: ious.max(1), get_segmented_scores,
  * binary_cross_entropy_with_logits(...).mean()) in one launch.  ious: (P, nInst) row-major.  gt_iou: (P) row maxima;
  * dscore: (P) d loss / d score; out[0] = loss. */

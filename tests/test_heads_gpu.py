@@ -365,3 +365,46 @@ def test_caption_cross_entropy_two_launches_matches_library_form(dev):
     bad = torch.zeros_like(good)
     (ln, an, gn), (ll, al, gl) = run(True, bad), run(False, bad)
     assert ln == 0.0 and ll == 0.0 and an == 0.0 and float(gn.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,C", [(164253, 20), (20001, 7), (8200, 32)])
+def test_point_heads_three_launches_match_the_module_form(dev, N, C):
+    """d3_point_heads_fwd (semantic scores + arg-max + Linear-BN-ReLU-Linear offsets, model/pointgroup.py:77-85, 277-283) against
+    the nn.Module form: outputs, predictions, running statistics / num_batches_tracked, gradients of every parameter and of the
+    input; then eval mode (running statistics) and a no-grad call."""
+    import copy
+    from d3net_amd import heads
+    torch.manual_seed(N)
+    m = 16
+    sem = torch.nn.Linear(m, C).to(dev)
+    off = torch.nn.Sequential(torch.nn.Linear(m, m), torch.nn.BatchNorm1d(m, eps=1e-4, momentum=0.1), torch.nn.ReLU(),
+                              torch.nn.Linear(m, 3)).to(dev)
+    with torch.no_grad():
+        off[1].weight.uniform_(0.5, 1.5); off[1].bias.uniform_(-0.3, 0.3)
+    sem2, off2 = copy.deepcopy(sem), copy.deepcopy(off)
+    x0 = torch.randn(N, m, device=dev) * 1.3 + 0.2
+    gs, go = torch.randn(N, C, device=dev), torch.randn(N, 3, device=dev)
+    for training in (True, False):
+        for mod in (off, off2):
+            mod.train(training)
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        s1, p1, o1 = heads.point_heads(sem, off, xa)
+        s2 = sem2(xb); o2 = off2(xb); p2 = s2.max(1)[1]
+        assert rel(s1, s2) < 1e-5 and rel(o1, o2) < 2e-5
+        same = (p1 == p2).float().mean()
+        assert float(same) > 0.9999, float(same)         # near-ties may flip with the summation order
+        assert rel(off[1].running_mean, off2[1].running_mean) < 1e-5 and rel(off[1].running_var, off2[1].running_var) < 1e-5
+        assert int(off[1].num_batches_tracked) == int(off2[1].num_batches_tracked)
+        ((s1 * gs).sum() + (o1 * go).sum()).backward()
+        ((s2 * gs).sum() + (o2 * go).sum()).backward()
+        assert rel(xa.grad, xb.grad) < 1e-4
+        for (n1, q1), (n2, q2) in zip(list(sem.named_parameters()) + list(off.named_parameters()),
+                                      list(sem2.named_parameters()) + list(off2.named_parameters())):
+            if n1 == "0.bias" and training:      # the batch norm removes the mean: this gradient is exactly 0, both are rounding noise
+                assert float(q1.grad.abs().max()) < 5e-3 and float(q2.grad.abs().max()) < 5e-3
+            else:
+                assert rel(q1.grad, q2.grad) < 2e-4, (n1, rel(q1.grad, q2.grad))
+            q1.grad = None; q2.grad = None
+    with torch.no_grad():
+        s3, p3, o3 = heads.point_heads(sem, off, x0)
+    assert rel(s3, sem2(x0)) < 1e-5 and rel(o3, off2(x0)) < 2e-5
