@@ -84,6 +84,8 @@ SIGNATURES = {
     "d3_stack_to_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_adamw_chunk": (i32, []),
     "d3_adamw": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, f64, vp]),
+    "d3_point_heads_dy": (i32, [vp, vp, vp, i64, vp, vp]),
+    "d3_point_heads_dx": (i32, [vp, vp, vp, vp, i64, i32, vp, vp]),
     "d3_point_heads_ws_bytes": (sz, []),
     "d3_point_heads_fwd": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                  vp, sz, vp]),

@@ -147,7 +147,7 @@ extern "C" int d3_tall_wgrad(const float *x, const float *dy, float *dW, float *
 //                    nn.BatchNorm1d (or, in eval mode, the running statistics themselves);
 //   pth_out_kernel : y = ReLU(BN(h)) (kept for the backward) and the (N,3) offsets, one thread per row.
 typedef float ph_f32x4 __attribute__((ext_vector_type(4)));
-#define PH_GRID 2048
+#define PH_GRID 1024
 __global__ __launch_bounds__(256) void pth_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Ws, const float *__restrict__ bs,
                                                      const float *__restrict__ W0, const float *__restrict__ b0, int N, int C,
                                                      float *__restrict__ scores, long long *__restrict__ preds, float *__restrict__ h,
@@ -219,7 +219,18 @@ __global__ __launch_bounds__(1024) void pth_bn_kernel(const float *__restrict__ 
         return;
     }
     double sa = 0., sb = 0.;
-    for (int b = lane; b < nblocks; b += 64) { sa += (double)part[(long long)b * 32 + c]; sb += (double)part[(long long)b * 32 + 16 + c]; }
+    for (int b0 = lane; b0 < nblocks; b0 += 256) {       // four partial rows per lane in flight; same order every run
+        float pa[4], pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = b0 + u * 64;
+            const long long o = (long long)(b < nblocks ? b : 0) * 32;
+            pa[u] = part[o + c]; pb[u] = part[o + 16 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (b0 + u * 64 < nblocks) { sa += (double)pa[u]; sb += (double)pb[u]; }
+    }
     for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
     if (lane != 0) return;
     const double m = sa / (double)N;
@@ -261,6 +272,98 @@ __global__ __launch_bounds__(256) void pth_out_kernel(const float *__restrict__ 
         *(float4 *)(y + r * 16 + c4 * 4) = make_float4(out[0], out[1], out[2], out[3]);
     }
     off[r * 3] = o0; off[r * 3 + 1] = o1; off[r * 3 + 2] = o2;
+}
+// backward pieces of the point heads.  dy = (g_off W3) * (y > 0): the data gradient of the last Linear with the ReLU mask, one
+// thread per row (the library: a K = 3 GEMM, a compare and a multiply).
+__global__ __launch_bounds__(256) void pth_dy_kernel(const float *__restrict__ g_off, const float *__restrict__ W3,
+                                                    const float *__restrict__ y, long long N, float *__restrict__ dy) {
+    __shared__ float w[48];
+    if (threadIdx.x < 48) w[threadIdx.x] = W3[threadIdx.x];
+    __syncthreads();
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const float g0 = g_off[r * 3], g1 = g_off[r * 3 + 1], g2 = g_off[r * 3 + 2];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+        const float4 yv = *(const float4 *)(y + r * 16 + c4 * 4);
+        const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = c4 * 4 + e;
+            const float v = fmaf(g2, w[32 + c], fmaf(g1, w[16 + c], g0 * w[c]));
+            o[e] = ys[e] > 0.f ? v : 0.f;
+        }
+        *(float4 *)(dy + r * 16 + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+// dx = dh W0 + g_s Ws  (N,16): both data gradients that reach the backbone output in one pass.  Computed transposed on
+// v_mfma_f32_16x16x4f32 -- A = the weights (constant registers; M = input channel), B = 16 rows of dh / g_s as one float4 per
+// lane (N = row) -- so that a lane ends with four consecutive channels of one row: one float4 store.
+__global__ __launch_bounds__(256) void pth_dx_kernel(const float *__restrict__ dh, const float *__restrict__ W0,
+                                                    const float *__restrict__ gs, const float *__restrict__ Ws, long long N, int C,
+                                                    float *__restrict__ dx) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, kq = lane >> 4;
+    float a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int k = 4 * kq + c;
+        a0[c] = W0[k * 16 + i];
+        a1[c] = k < C ? Ws[k * 16 + i] : 0.f;
+        a2[c] = 16 + k < C ? Ws[(16 + k) * 16 + i] : 0.f;
+    }
+    const bool vec = (C & 3) == 0;
+    const long long ntiles = (N + 15) >> 4;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long r = (tile << 4) + i;
+        const bool ok = r < N;
+        float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (dh != nullptr) { const float4 v = *(const float4 *)(dh + r * 16 + 4 * kq); b0[0] = v.x; b0[1] = v.y; b0[2] = v.z; b0[3] = v.w; }
+            if (gs != nullptr) {
+                if (vec) {
+                    if (4 * kq + 3 < C) { const float4 v = *(const float4 *)(gs + r * C + 4 * kq); b1[0] = v.x; b1[1] = v.y; b1[2] = v.z; b1[3] = v.w; }
+                    if (16 + 4 * kq + 3 < C) { const float4 v = *(const float4 *)(gs + r * C + 16 + 4 * kq); b2[0] = v.x; b2[1] = v.y; b2[2] = v.z; b2[3] = v.w; }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int k = 4 * kq + c;
+                        if (k < C) b1[c] = gs[r * C + k];
+                        if (16 + k < C) b2[c] = gs[r * C + 16 + k];
+                    }
+                }
+            }
+        }
+        ph_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b0[c], acc, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b1[c], acc, 0, 0, 0);
+        if (C > 16) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[c], b2[c], acc, 0, 0, 0);
+        }
+        // D[m = 4*kq + q][n = i]: channels 4*kq .. 4*kq+3 of row i
+        if (ok) *(float4 *)(dx + r * 16 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+extern "C" int d3_point_heads_dy(const float *g_off, const float *W3, const float *y, long long N, float *dy, void *stream) {
+    D3_CLEAR();
+    if (N <= 0) return 0;
+    pth_dy_kernel<<<(int)((N + 255) / 256), 256, 0, d3_stream(stream)>>>(g_off, W3, y, N, dy);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_point_heads_dx(const float *dh, const float *W0, const float *g_scores, const float *Ws, long long N, int C, float *dx,
+                                 void *stream) {
+    D3_CLEAR();
+    if (N <= 0) return 0;
+    if (C < 1 || C > 32 || (dh == nullptr && g_scores == nullptr)) return D3_ERR_ARG;
+    const long long ntiles = (N + 15) >> 4;
+    const int grid = (int)((ntiles + 3) / 4 < 2048 ? (ntiles + 3) / 4 : 2048);
+    pth_dx_kernel<<<grid, 256, 0, d3_stream(stream)>>>(dh, W0, g_scores, Ws, N, C, dx);
+    D3_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" size_t d3_point_heads_ws_bytes(void) { return (size_t)PH_GRID * 32 * sizeof(float); }
 extern "C" int d3_point_heads_fwd(const float *x, long long N, int m, int C, const float *Ws, const float *bs, const float *W0,

@@ -94,21 +94,28 @@ class _PointHeads(Function):
                       "tall_wgrad")
             return dW, db
 
-        dx = None
+        N = x.size(0)
+        dx = dh = None
         dWs = dbs = dW0 = db0 = dg = dbeta = dW3 = db3 = None
         if g_o is not None:
             g_o = g_o.contiguous()
             dW3, db3 = wgrad(y, g_o, 3, m)
-            dy = (g_o @ W3) * (y > 0)
+            dy = torch.empty_like(y)
+            with _on(dev):      # (g_o W3) * (y > 0) in one pass
+                check(L.d3_point_heads_dy(_ptr(g_o), _ptr(W3.contiguous()), _ptr(y), N, _ptr(dy), _stream()), "point_heads_dy")
             dh, dg, dbeta = torch.ops.aten.native_batch_norm_backward(dy, h, gamma, rm, rv, stat[:m], stat[m:], training, eps,
                                                                       [True, True, True])
             dh = dh.contiguous()
             dW0, db0 = wgrad(x, dh, m, m)
-            dx = dh @ W0
         if g_s is not None:
             g_s = g_s.contiguous()
             dWs, dbs = wgrad(x, g_s, Ws.size(0), m)
-            dx = g_s @ Ws if dx is None else dx.addmm_(g_s, Ws)
+        if ctx.needs_input_grad[0] and (dh is not None or g_s is not None):
+            dx = torch.empty_like(x)
+            with _on(dev):      # dh W0 + g_s Ws in one pass
+                check(L.d3_point_heads_dx(_ptr(dh) if dh is not None else None, _ptr(W0.contiguous()),
+                                          _ptr(g_s) if g_s is not None else None, _ptr(Ws.contiguous()), N, Ws.size(0), _ptr(dx),
+                                          _stream()), "point_heads_dx")
         return dx, dWs, dbs, dW0, db0, dg, dbeta, dW3, db3, None
 
 

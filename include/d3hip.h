@@ -339,6 +339,12 @@ int d3_point_heads_fwd(const float *x, long long N, int m, int C, const float *W
                        const float *gamma, const float *beta, const float *W3, const float *b3, float eps, float momentum,
                        int training, float *running_mean, float *running_var, long long *num_batches_tracked, float *scores,
                        long long *preds, float *h, float *y, float *offsets, float *stat, void *ws, size_t ws_bytes, void *stream);
+/* Backward pieces of the point heads: dy (N,16) = (g_off (N,3) W3 (3,16)) * (y > 0);  dx (N,16) = dh (N,16) W0 (16,16) +
+ * g_scores (N,C) Ws (C,16) (either term may be NULL) -- the data gradients of the three tall Linear layers in one pass each
+ * (the weight gradients: d3_tall_wgrad). */
+int d3_point_heads_dy(const float *g_off, const float *W3, const float *y, long long N, float *dy, void *stream);
+int d3_point_heads_dx(const float *dh, const float *W0, const float *g_scores, const float *Ws, long long N, int C, float *dx,
+                      void *stream);
 /* Proposal score loss of PointGroup.loss (reference model/pointgroup.py:436-452: ious.max(1), get_segmented_scores,
  * binary_cross_entropy_with_logits(...).mean()) in one launch.  ious: (P, nInst) row-major.  gt_iou: (P) row maxima;
  * dscore: (P) d loss / d score; out[0] = loss. */
