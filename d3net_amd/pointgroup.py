@@ -206,7 +206,9 @@ class PointGroup(nn.Module):
     @staticmethod
     def get_batch_offsets(batch_idxs, batch_size):
         """(B+1) int32 offsets of the (sorted) batch index column (reference :110-122), without host syncs."""
-        counts = torch.bincount(batch_idxs.long(), minlength=batch_size)[:batch_size]
+        # (torch.bincount reads min / max back to the host: two blocking round trips per call)
+        ids = _const(("arange_i32", batch_size), batch_idxs.device, lambda: torch.arange(batch_size, dtype=torch.int32))
+        counts = (batch_idxs.view(-1, 1) == ids.view(1, -1)).sum(0)
         offsets = torch.zeros(batch_size + 1, dtype=torch.int32, device=batch_idxs.device)
         offsets[1:] = torch.cumsum(counts, 0).int()
         return offsets
