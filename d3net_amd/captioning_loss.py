@@ -285,21 +285,21 @@ class _OrientationLoss(torch.autograd.Function):
         rots, rot_masks = rots.contiguous(), rot_masks.contiguous().float()
         nsrc, ntar = nsrc.contiguous().long(), ntar.contiguous().long()
         dpreds = torch.empty((B, E, nb), dtype=torch.float32, device=dev)
-        out = torch.empty(2, dtype=torch.float32, device=dev)
+        out = torch.empty(3 + 3 * 256, dtype=torch.float32, device=dev)   # [loss, accuracy, weight sum | workgroup partials]
         with _on(dev):
             check(_lib.lib().d3_orientation_loss(_ptr(preds), preds.stride(0), preds.stride(1), _ptr(edge_index), _ptr(nsrc), _ptr(ntar),
                                                  _ptr(assign), _ptr(rots), _ptr(rot_masks), B, E, assign.shape[1], rots.shape[1],
                                                  nb, C.cast(barr, C.c_void_p), len(bounds), _ptr(dpreds), _ptr(out), _stream()),
                   "orientation_loss")
-        ctx.save_for_backward(dpreds)
+        ctx.save_for_backward(dpreds, out)
         loss, acc = out[0], out[1]
         ctx.mark_non_differentiable(acc)
         return loss, acc
 
     @staticmethod
     def backward(ctx, g, _g_acc):
-        dpreds, = ctx.saved_tensors
-        return dpreds * g, None, None, None, None, None, None, None
+        dpreds, out = ctx.saved_tensors
+        return dpreds * (g / out[2]), None, None, None, None, None, None, None
 
 
 def _orientation_native_ok(data_dict, num_bins):

@@ -26,7 +26,7 @@ int hg_colsum_multi(const float *const *x, const long long *ld, const int *R, co
 #define GM_MAXK 256
 
 // adj (B,K,K) 0/1, mask (B,K) -> see d3_graph_edges in include/d3hip.h
-__global__ __launch_bounds__(256) void gm_edges_kernel(const float *__restrict__ adj, const float *__restrict__ mask, int K, int L,
+__global__ __launch_bounds__(1024) void gm_edges_kernel(const float *__restrict__ adj, const float *__restrict__ mask, int K, int L,
                                                        int *__restrict__ src, int *__restrict__ dst, float *__restrict__ eidx,
                                                        int *__restrict__ cnt, int *__restrict__ in_ptr, int *__restrict__ in_list,
                                                        int *__restrict__ out_start, int *__restrict__ out_cnt,
@@ -151,7 +151,7 @@ extern "C" int d3_graph_edges(const float *adj, const float *mask, int B, int K,
     D3_CLEAR();
     if (B < 1 || K < 1 || K > GM_MAXK || L < 1) return D3_ERR_ARG;
     const size_t lds = (size_t)(6 * K + 1 + K * L + 8 * K) * 4;
-    gm_edges_kernel<<<B, 256, lds, d3_stream(stream)>>>(adj, mask, K, L, src, dst, edge_index, cnt, in_ptr, in_list, out_start, out_cnt,
+    gm_edges_kernel<<<B, 1024, lds, d3_stream(stream)>>>(adj, mask, K, L, src, dst, edge_index, cnt, in_ptr, in_list, out_start, out_cnt,
                                                         feat_src, pred_src);
     D3_LAUNCH_CHECK();
     return 0;

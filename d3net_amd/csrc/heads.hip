@@ -612,42 +612,48 @@ extern "C" int d3_scatter_add_rows(const float *g, const int64_t *idx, float *ou
 // launches over a few dozen proposals:  gt_iou = max_j ious[p, j];  gt_score = 1 above fg, 0 below bg, linear between;
 // loss = mean_p BCEWithLogits(score_p, gt_score_p) with torch's stable form (1 - z) x + m + log(exp(-m) + exp(-x - m)),
 // m = max(-x, 0).  out[0] = loss; dscore[p] = (sigmoid(x) - z) / P (scaled by the upstream gradient on the host side).
-#define SL_T 1024
-__global__ __launch_bounds__(SL_T) void score_loss_kernel(const float *__restrict__ scores, const float *__restrict__ ious, int P,
+#define SL_T 256
+// a wave per proposal, lanes along its IoU row, one proposal per wave over the whole grid (one workgroup walking all proposals
+// paid a memory round trip per proposal and wave: 48-62 us at 430 x 160); term[p] = the proposal's loss
+__global__ __launch_bounds__(SL_T) void score_rows_kernel(const float *__restrict__ scores, const float *__restrict__ ious, int P,
                                                          int nInst, float fg, float bg, float *__restrict__ gt_iou,
-                                                         float *__restrict__ dscore, float *__restrict__ out) {
-    __shared__ float red[SL_T];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float part = 0.f;
+                                                         float *__restrict__ dscore, float *__restrict__ term) {
+    const int p = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (p >= P) return;
     const float k = 1.f / (fg - bg), b = bg / (bg - fg);
-    // a wave per proposal, lanes along its IoU row (a thread walking its own row read it uncoalesced: 48 us at 430 x 160);
-    // the loss terms are then added by one thread in proposal order: deterministic
-    for (int p0 = 0; p0 < P; p0 += SL_T) {
-        const int pend = min(P, p0 + SL_T);
-        for (int p = p0 + wave; p < pend; p += SL_T / 64) {
-            float m = -INFINITY;
-            for (int j = lane; j < nInst; j += 64) m = fmaxf(m, ious[(long long)p * nInst + j]);
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if (lane == 0) {
-                gt_iou[p] = m;
-                const float z = (m > fg) ? 1.f : (m < bg) ? 0.f : m * k + b;
-                const float x = scores[p];
-                const float mv = fmaxf(-x, 0.f);
-                red[p - p0] = (1.f - z) * x + mv + logf(expf(-mv) + expf(-x - mv));
-                dscore[p] = (1.f / (1.f + expf(-x)) - z) / (float)P;
-            }
-        }
+    float m = -INFINITY;
+    for (int j = lane; j < nInst; j += 64) m = fmaxf(m, ious[(long long)p * nInst + j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) {
+        gt_iou[p] = m;
+        const float z = (m > fg) ? 1.f : (m < bg) ? 0.f : m * k + b;
+        const float x = scores[p];
+        const float mv = fmaxf(-x, 0.f);
+        term[p] = (1.f - z) * x + mv + logf(expf(-mv) + expf(-x - mv));
+        dscore[p] = (1.f / (1.f + expf(-x)) - z) / (float)P;
+    }
+}
+// the terms added by one thread in proposal order: deterministic, and the order of the former single-workgroup kernel
+__global__ void score_sum_kernel(const float *__restrict__ term, int P, float *__restrict__ out) {
+    __shared__ float buf[1024];
+    float part = 0.f;
+    for (int p0 = 0; p0 < P; p0 += 1024) {
+        const int n = min(1024, P - p0);
+        if ((int)threadIdx.x < n) buf[threadIdx.x] = term[p0 + threadIdx.x];
         __syncthreads();
-        if (t == 0) { for (int i = 0; p0 + i < pend; i++) part += red[i]; }
+        if (threadIdx.x == 0) for (int i = 0; i < n; i++) part += buf[i];
         __syncthreads();
     }
-    if (t == 0) out[0] = part / (float)P;
+    if (threadIdx.x == 0) out[0] = part / (float)P;
 }
 extern "C" int d3_score_loss(const float *scores, const float *ious, int P, int nInst, float fg, float bg, float *gt_iou,
                              float *dscore, float *out, void *stream) {
     D3_CLEAR();
     if (P <= 0 || nInst <= 0) return D3_ERR_ARG;
-    score_loss_kernel<<<1, SL_T, 0, d3_stream(stream)>>>(scores, ious, P, nInst, fg, bg, gt_iou, dscore, out);
+    hipStream_t s = d3_stream(stream);
+    float *term = out + 1;       // out: 1 + P floats (the per-proposal terms behind the loss)
+    score_rows_kernel<<<(P + 3) / 4, SL_T, 0, s>>>(scores, ious, P, nInst, fg, bg, gt_iou, dscore, term);
+    score_sum_kernel<<<1, 1024, 0, s>>>(term, P, out);
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -745,8 +751,11 @@ extern "C" int d3_masked_xe(const float *pred, const long long *target, long lon
 // of the GT objects assigned to its two ends (trace of R_s R_t^T -> angle -> bin), the rotation-mask / live-edge weight, the
 // weighted cross-entropy over the num_bins orientation logits, the accuracy, and the gradient w.r.t. the logits -- ~45
 // library launches (gathers of 3x3 matrices, a batched matmul, acos, bucketize, log-softmax, nll, argmax, their backward)
-// on 10 k edges.  One workgroup; per-thread partial sums combined by a fixed-order tree: deterministic.
-#define OL_T 1024
+// on 10 k edges.  One edge per thread (a single workgroup walking ten edges per thread paid three dependent round trips per
+// edge: 38 us), per-workgroup sums by a fixed-order tree, the workgroups' sums added in order by a second launch: deterministic.
+// dpreds is the UNSCALED gradient mask * (softmax - onehot); the caller divides by out3[2].
+#define OL_T 256
+#define OL_MAXG 256
 #define OL_MAXB 16
 struct OlBounds { float v[OL_MAXB]; int n; };
 __global__ __launch_bounds__(OL_T) void orient_loss_kernel(const float *__restrict__ preds, long long ldb, long long lde,
@@ -754,12 +763,12 @@ __global__ __launch_bounds__(OL_T) void orient_loss_kernel(const float *__restri
                                                           const long long *__restrict__ ntar, const long long *__restrict__ assign,
                                                           const float *__restrict__ rot, const float *__restrict__ rmask, int B,
                                                           int E, int K, int G, int nb, OlBounds bd, float *__restrict__ dpreds,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ part) {
     __shared__ float red[3][OL_T];
     const int t = threadIdx.x;
     const long long R = (long long)B * E;
     float s_ce = 0.f, s_m = 0.f, s_hit = 0.f;
-    for (long long r = t; r < R; r += OL_T) {
+    for (long long r = (long long)blockIdx.x * OL_T + t; r < R; r += (long long)gridDim.x * OL_T) {
         const int b = (int)(r / E), e = (int)(r - (long long)b * E);
         const float live = (long long)e < nsrc[b] * ntar[b] ? 1.f : 0.f;
         int sn = (int)(long long)eidx[((long long)b * 2 + 0) * E + e], tn = (int)(long long)eidx[((long long)b * 2 + 1) * E + e];
@@ -808,11 +817,15 @@ __global__ __launch_bounds__(OL_T) void orient_loss_kernel(const float *__restri
         if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
         __syncthreads();
     }
-    const float den = red[1][0] + 1e-8f;
-    if (t == 0) { out[0] = red[0][0] / den; out[1] = red[2][0] / den; }
-    const float inv = 1.f / den;
-    for (long long r = t; r < R; r += OL_T)
-        for (int q = 0; q < nb; q++) dpreds[r * nb + q] *= inv;
+    if (t == 0) { part[blockIdx.x * 3] = red[0][0]; part[blockIdx.x * 3 + 1] = red[1][0]; part[blockIdx.x * 3 + 2] = red[2][0]; }
+}
+// out3 = [loss, accuracy, sum of the edge weights + 1e-8]: the workgroups' partial sums added in workgroup order
+__global__ void orient_sum_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float a = 0.f, m = 0.f, h = 0.f;
+    for (int i = 0; i < nblocks; i++) { a += part[i * 3]; m += part[i * 3 + 1]; h += part[i * 3 + 2]; }
+    const float den = m + 1e-8f;
+    out[0] = a / den; out[1] = h / den; out[2] = den;
 }
 extern "C" int d3_orientation_loss(const float *preds, long long ld_batch, long long ld_edge, const float *edge_index,
                                    const long long *num_src, const long long *num_tar, const long long *assign, const float *rotations,
@@ -824,8 +837,13 @@ extern "C" int d3_orientation_loss(const float *preds, long long ld_batch, long 
     OlBounds bd;
     bd.n = nbounds;
     for (int i = 0; i < OL_MAXB; i++) bd.v[i] = i < nbounds ? bounds_host[i] : 0.f;
-    orient_loss_kernel<<<1, OL_T, 0, d3_stream(stream)>>>(preds, ld_batch, ld_edge, edge_index, num_src, num_tar, assign, rotations,
-                                                        rot_masks, B, E, K, G, num_bins, bd, dpreds, out2);
+    const long long R = (long long)B * E;
+    int grid = (int)((R + OL_T - 1) / OL_T);
+    if (grid > OL_MAXG) grid = OL_MAXG;
+    float *part = out2 + 3;      // out2: 3 + 3 * 256 floats (the workgroups' partial sums behind the results)
+    orient_loss_kernel<<<grid, OL_T, 0, d3_stream(stream)>>>(preds, ld_batch, ld_edge, edge_index, num_src, num_tar, assign, rotations,
+                                                           rot_masks, B, E, K, G, num_bins, bd, dpreds, part);
+    orient_sum_kernel<<<1, 64, 0, d3_stream(stream)>>>(part, grid, out2);
     D3_LAUNCH_CHECK();
     return 0;
 }

@@ -248,7 +248,7 @@ class _ScoreLoss(Function):
         x = scores.reshape(-1).contiguous()
         P = x.numel()
         gt_iou, ds = torch.empty_like(x), torch.empty_like(x)
-        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        out = torch.empty(1 + P, dtype=torch.float32, device=x.device)   # [loss | per-proposal terms]
         with _on(x.device):
             check(_lib.lib().d3_score_loss(_ptr(x), _ptr(ious), P, ious.size(1), float(fg), float(bg), _ptr(gt_iou), _ptr(ds),
                                            _ptr(out), _stream()), "score_loss")

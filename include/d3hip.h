@@ -347,7 +347,7 @@ int d3_point_heads_dx(const float *dh, const float *W0, const float *g_scores, c
                       void *stream);
 /* Proposal score loss of PointGroup.loss (reference model/pointgroup.py:436-452: ious.max(1), get_segmented_scores,
  * binary_cross_entropy_with_logits(...).mean()) in one launch.  ious: (P, nInst) row-major.  gt_iou: (P) row maxima;
- * dscore: (P) d loss / d score; out[0] = loss. */
+ * dscore: (P) d loss / d score; out: 1 + P floats, out[0] = loss, out[1 + p] = proposal p's term (summed in proposal order). */
 int d3_score_loss(const float *scores, const float *ious, int P, int nInst, float fg, float bg, float *gt_iou,
                   float *dscore, float *out, void *stream);
 /* compute_cap_loss (lib/captioning/loss_helper.py:177-224) in two launches: pred (N,S,V) logits, target (N, S) int64 with row
@@ -362,7 +362,8 @@ int d3_masked_xe(const float *pred, const long long *target, long long ld_target
  * edge_index (B,2,E) float (compacted node ids; padded entries 0), num_src / num_tar (B) int64 (edges >= num_src * num_tar of a
  * scene get weight 0), assign (B,K) int64 = GT object of every proposal slot, rotations (B,G,3,3), rot_masks (B,G) fp32;
  * bounds_host = HOST pointer to the nbounds = num_bins - 1 bin boundaries (`radian_to_label`, :226-242), passed as kernel
- * arguments.  out2 = [loss, accuracy]; dpreds (B*E, num_bins) = d loss / d logits.  Deterministic (fixed-order reduction). */
+ * arguments.  out2: 3 + 768 floats, out2[0..2] = [loss, accuracy, W = sum of the edge weights + 1e-8] (the rest: per-workgroup
+ * partial sums); dpreds (B*E, num_bins) = W * d loss / d logits (the caller divides by W).  Deterministic (fixed-order reduction). */
 int d3_orientation_loss(const float *preds, long long ld_batch, long long ld_edge, const float *edge_index,
                         const long long *num_src, const long long *num_tar, const long long *assign, const float *rotations,
                         const float *rot_masks, int B, int E, int K, int G, int num_bins, const float *bounds_host,
