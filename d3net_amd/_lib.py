@@ -27,6 +27,7 @@ SIGNATURES = {
     "d3_sec_max": (i32, [vp, vp, vp, i32, i32, vp]),
     "d3_cluster_select": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3_cluster_merge": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "d3_proposal_prepare": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "d3_cluster_coords_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "d3_cluster_transform": (i32, [vp, vp, vp, vp, vp, vp, i64, vp]),
     "d3_cluster_norm_params": (i32, [vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, vp]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "d3_stack_to_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "d3_adamw_chunk": (i32, []),
     "d3_adamw": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, f64, vp]),
+    "d3_gather_rows_pad": (i32, [vp, i64, vp, vp, i64, i32, i32, vp]),
     "d3_point_heads_dy": (i32, [vp, vp, vp, i64, vp, vp]),
     "d3_point_heads_dx": (i32, [vp, vp, vp, vp, i64, i32, vp, vp]),
     "d3_point_heads_ws_bytes": (sz, []),

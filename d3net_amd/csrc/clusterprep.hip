@@ -71,3 +71,42 @@ extern "C" int d3_cluster_merge(const int *idx1, int S1, const int *off1, int P1
     D3_LAUNCH_CHECK();
     return 0;
 }
+
+// Per-proposal bookkeeping between the score head and the proposal selection (model/pointgroup.py:338-372): number of points,
+// the score / size threshold mask, the batch id read at the cluster start (with the reference's one-element-short batch-id
+// vector: the index is clamped to its last element), and the (P,9) crop box [centre | size | 0 | semantic class of the first
+// point | score] -- a dozen library launches on a few hundred proposals.  sig = sigmoid(score), computed by the caller.
+__global__ void cp_proposals_kernel(const float *__restrict__ sig, const int *__restrict__ offsets, const int *__restrict__ bid_all,
+                                    int nbid, const int *__restrict__ pidx, const long long *__restrict__ sem,
+                                    const float *__restrict__ center, const float *__restrict__ size, float score_thr,
+                                    float npoint_thr, int P, float *__restrict__ npoint, unsigned char *__restrict__ mask,
+                                    int *__restrict__ bid, float *__restrict__ crop) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int st = offsets[p];
+    const float np = (float)(offsets[p + 1] - st);
+    const float sg = sig[p];
+    npoint[p] = np;
+    mask[p] = (sg > score_thr && np > npoint_thr) ? 1 : 0;
+    int s2 = st;
+    if (s2 > nbid - 1) s2 = nbid - 1;
+    if (s2 < 0) s2 = 0;
+    bid[p] = nbid > 0 ? bid_all[s2] : 0;
+    float *c = crop + (long long)p * 9;
+    c[0] = center[p * 3]; c[1] = center[p * 3 + 1]; c[2] = center[p * 3 + 2];
+    c[3] = size[p * 3]; c[4] = size[p * 3 + 1]; c[5] = size[p * 3 + 2];
+    c[6] = 0.f;
+    c[7] = crop != nullptr && sem != nullptr ? (float)sem[pidx[(long long)st * 2 + 1]] : 0.f;
+    c[8] = sg;
+}
+extern "C" int d3_proposal_prepare(const float *sig, const int *offsets, const int *batch_id_all, int n_batch_id, const int *proposals_idx,
+                                   const int64_t *semantic_preds, const float *center, const float *size, float score_thr,
+                                   float npoint_thr, int P, float *npoint, unsigned char *mask, int *batch_id, float *crop, void *stream) {
+    D3_CLEAR();
+    if (P <= 0) return 0;
+    cp_proposals_kernel<<<(P + 255) / 256, 256, 0, d3_stream(stream)>>>(sig, offsets, batch_id_all, n_batch_id, proposals_idx,
+                                                                       (const long long *)semantic_preds, center, size, score_thr, npoint_thr,
+                                                                       P, npoint, mask, batch_id, crop);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

@@ -598,6 +598,29 @@ extern "C" int d3_gather_rows(const float *feats, const int64_t *idx, float *out
     return 0;
 }
 
+// out[r] = idx[r] in [0, rows) ? feats[idx[r]] : 0 -- a gather whose "no source" entries read a zero row (the library form
+// concatenates a zero row to feats first: a full copy), any C; and its transpose for unique indices (out zero-filled by the caller)
+__global__ void gather_rows_pad_kernel(const float *__restrict__ feats, long long rows, const long long *__restrict__ idx,
+                                       float *__restrict__ out, long long total, int C, int scatter) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long long r = e / C;
+    const int c = (int)(e - r * C);
+    const long long i = idx[r];
+    const bool ok = i >= 0 && i < rows;
+    if (!scatter) out[e] = ok ? feats[i * C + c] : 0.f;
+    else if (ok) out[i * C + c] = feats[e];       // (feats = the gradient rows, out = the (rows, C) gradient; indices unique)
+}
+extern "C" int d3_gather_rows_pad(const float *feats, long long rows, const int64_t *idx, float *out, long long S, int C, int scatter,
+                                  void *stream) {
+    D3_CLEAR();
+    const long long total = S * C;
+    if (total <= 0) return 0;
+    gather_rows_pad_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(feats, rows, (const long long *)idx, out, total, C, scatter);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream) {
     D3_CLEAR();
     const long long total = S * C;

@@ -408,31 +408,40 @@ class PointGroup(nn.Module):
             data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset)
 
             _mark("pr_roipool_score")
-            proposals_npoint = (proposals_offset[1:] - proposals_offset[:-1]).float()           # == the loop at :342-344
             sig = torch.sigmoid(scores.view(-1))
-            thres_mask = torch.logical_and(sig > self.cfg.test.TEST_SCORE_THRESH,
-                                           proposals_npoint > self.cfg.test.TEST_NPOINT_THRESH)
+            fused = (self.cfg.model.crop_bbox and sig.is_cuda and proposals_offset.dtype == torch.int32 and proposals_idx.dtype == torch.int32
+                     and proposals_batchId_all.dtype == torch.int32 and semantic_preds.dtype == torch.int64
+                     and proposals_idx.is_contiguous() and semantic_preds.is_contiguous())
+            if fused:   # npoint, threshold mask, batch id at the cluster start, crop box: one launch (csrc/clusterprep.hip)
+                proposals_npoint, thres_mask, bid_start, crop = pointgroup_ops.proposal_prepare(
+                    sig.detach(), proposals_offset.contiguous(), proposals_batchId_all.contiguous(), proposals_idx, semantic_preds,
+                    proposals_center, proposals_size, self.cfg.test.TEST_SCORE_THRESH, self.cfg.test.TEST_NPOINT_THRESH)
+            else:
+                proposals_npoint = (proposals_offset[1:] - proposals_offset[:-1]).float()           # == the loop at :342-344
+                thres_mask = torch.logical_and(sig > self.cfg.test.TEST_SCORE_THRESH,
+                                               proposals_npoint > self.cfg.test.TEST_NPOINT_THRESH)
+                # NOTE the reference reads the one-short batch-id vector at the cluster starts (:349); cluster starts of
+                # the shifted set therefore read element start+1 of that set -- same cluster, same batch id.
+                starts = proposals_offset[:-1].long().clamp(max=max(proposals_batchId_all.numel() - 1, 0))
+                bid_start = proposals_batchId_all[starts]
             data_dict["proposals_npoint"] = proposals_npoint
             data_dict["proposal_thres_mask"] = thres_mask
-
-            # NOTE the reference reads the one-short batch-id vector at the cluster starts (:349); cluster starts of
-            # the shifted set therefore read element start+1 of that set -- same cluster, same batch id.
-            starts = proposals_offset[:-1].long().clamp(max=max(proposals_batchId_all.numel() - 1, 0))
             _mark("pr_mask")
             keep = torch.nonzero(thres_mask).squeeze(1)    # one host round trip for the four selections below
             _mark("pr_nonzero")
-            proposals_batchId = proposals_batchId_all[starts].index_select(0, keep)
+            proposals_batchId = bid_start.index_select(0, keep)
             data_dict["proposals_batchId"] = proposals_batchId
             data_dict["proposal_feats"] = proposals_score_feats.index_select(0, keep)
             data_dict["proposal_objectness_scores"] = sig.index_select(0, keep)
 
             _mark("pr_index")
             if self.cfg.model.crop_bbox:
-                crop = scores.new_zeros(num_proposals, 9)
-                crop[:, :3] = proposals_center
-                crop[:, 3:6] = proposals_size
-                crop[:, 7] = semantic_preds[proposals_idx[proposals_offset[:-1].long(), 1].long()].to(crop.dtype)
-                crop[:, 8] = sig
+                if not fused:
+                    crop = scores.new_zeros(num_proposals, 9)
+                    crop[:, :3] = proposals_center
+                    crop[:, 3:6] = proposals_size
+                    crop[:, 7] = semantic_preds[proposals_idx[proposals_offset[:-1].long(), 1].long()].to(crop.dtype)
+                    crop[:, 8] = sig
                 data_dict["proposal_crop_bbox"] = crop.index_select(0, keep)
             _mark("pr_select")
         return data_dict

@@ -469,6 +469,23 @@ def cluster_coords_stats(coords, clusters_idx, clusters_offset):
     return out[0], out[1], out[2]
 
 
+def proposal_prepare(sig, proposals_offset, batch_id_all, proposals_idx, semantic_preds, center, size, score_thr, npoint_thr):
+    """(npoint (P) float, mask (P) bool, batch id at the cluster start (P) int32, crop box (P,9)) of model/pointgroup.py:338-372 in
+    one launch (d3_proposal_prepare)"""
+    P = proposals_offset.numel() - 1
+    dev = sig.device
+    npoint = torch.empty(P, dtype=torch.float32, device=dev)
+    mask = torch.empty(P, dtype=torch.bool, device=dev)
+    bid = torch.empty(P, dtype=torch.int32, device=dev)
+    crop = torch.empty((P, 9), dtype=torch.float32, device=dev)
+    with _on(dev):
+        check(_lib.lib().d3_proposal_prepare(_ptr(sig.contiguous()), _ptr(proposals_offset), _ptr(batch_id_all), batch_id_all.numel(),
+                                             _ptr(proposals_idx), _ptr(semantic_preds), _ptr(center.contiguous()), _ptr(size.contiguous()),
+                                             float(score_thr), float(npoint_thr), P, _ptr(npoint), _ptr(mask), _ptr(bid), _ptr(crop),
+                                             _stream()), "proposal_prepare")
+    return npoint, mask, bid, crop
+
+
 def cluster_norm_params(mean, raw_min, raw_max, fullscale, scale_cap, r0, r1):
     """per-cluster size (P,3), centre (P,3), grid scale (P,) and placement offset (P,3) of `clusters_voxelization`
     (model/pointgroup.py:146-165) in one launch (d3_cluster_norm_params); r0, r1: the two host-side `torch.rand(3)` draws"""

@@ -124,6 +124,33 @@ class EdgeConvFunction(torch.autograd.Function):
         return dx, dW0, db0, dW2, db2, None
 
 
+class _GatherRowsPad(torch.autograd.Function):
+    """rows[idx] with out-of-range entries reading a zero row (csrc/heads.hip: d3_gather_rows_pad); the in-range indices are
+    unique, so the backward is the same launch transposed"""
+
+    @staticmethod
+    def forward(ctx, rows, idx):
+        rows = rows.contiguous()
+        idx = idx.contiguous()
+        ctx.save_for_backward(idx)
+        ctx.shape = rows.shape
+        out = torch.empty((idx.numel(), rows.shape[1]), dtype=torch.float32, device=rows.device)
+        with _on(rows.device):
+            check(_lib.lib().d3_gather_rows_pad(_ptr(rows), rows.shape[0], _ptr(idx), _ptr(out), idx.numel(), rows.shape[1], 0, _stream()),
+                  "gather_rows_pad")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        g = g.contiguous()
+        d = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        with _on(g.device):
+            check(_lib.lib().d3_gather_rows_pad(_ptr(g), ctx.shape[0], _ptr(idx), _ptr(d), idx.numel(), ctx.shape[1], 1, _stream()),
+                  "gather_rows_pad")
+        return d, None
+
+
 class GraphModule(nn.Module):
     """(reference: model/graph_module.py:116-324)"""
 
@@ -156,20 +183,21 @@ class GraphModule(nn.Module):
             node, msg = EdgeConvFunction.apply(node, m[0].weight, m[0].bias, m[2].weight, m[2].bias, e)
         valid = (object_masks == 1).unsqueeze(-1)
         data_dict["bbox_feature"] = torch.where(valid, obj_feats + node.view(B, K, -1), torch.zeros_like(obj_feats))   # (:311-312)
-        edge_feats = obj_feats.new_zeros(B, K, L, self.out_size)
-        edge_preds = obj_feats.new_zeros(B, K * L, self.num_bins + 1)
-        edge_indices = torch.zeros_like(e["edge_index"])
-        num_sources = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
-        num_targets = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
         if self.return_orientation and msg is not None:
-            zrow = lambda t: torch.cat([t, t.new_zeros(1, t.shape[1])], 0)
-            edge_feats = zrow(msg).index_select(0, e["feat_src"].view(-1)).view(B, K, L, self.out_size)
+            # padded placement of the messages / predictions: an index past the end reads a zero row (no zero-row concat copy)
+            edge_feats = _GatherRowsPad.apply(msg, e["feat_src"].view(-1)).view(B, K, L, self.out_size)
             m = self.edge_layer.map_edge
             _, last = EdgeConvFunction.apply(node, m[0].weight, m[0].bias, m[2].weight, m[2].bias, e)
             pred = self.edge_predict(last)
-            edge_preds = zrow(pred).index_select(0, e["pred_src"].view(-1)).view(B, K * L, self.num_bins + 1)
+            edge_preds = _GatherRowsPad.apply(pred, e["pred_src"].view(-1)).view(B, K * L, self.num_bins + 1)
             edge_indices = e["edge_index"]
             num_sources, num_targets = e["cnt"][:, 1].long(), e["cnt"][:, 2].long()
+        else:
+            edge_feats = obj_feats.new_zeros(B, K, L, self.out_size)
+            edge_preds = obj_feats.new_zeros(B, K * L, self.num_bins + 1)
+            edge_indices = torch.zeros_like(e["edge_index"])
+            num_sources = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
+            num_targets = torch.zeros(B, dtype=torch.long, device=obj_feats.device)
         data_dict["adjacent_mat"] = adjacent_mat
         data_dict["edge_index"] = edge_indices
         data_dict["edge_feature"] = edge_feats
@@ -616,7 +644,7 @@ class TopDownSceneCaptionModule(nn.Module):
         return out_ids, out_lps
 
     def select_target(self, bbox_objness, bbox_center, bbox_corner, bbox_center_label, bbox_corner_label, ref_box_label,
-                      ref_box_corner_label, is_annotated, bbox_id_label=None):
+                      ref_box_corner_label, is_annotated, bbox_id_label=None, not_annotated=None):
         """(:416-508) target proposal per description: best IoU with the referred box when annotated, else a random
         non-empty proposal (python `random`, one draw per such sample, in sample order) assigned to its nearest GT.
         The proposal / GT tensors are PER SCENE ((B,K,.), (B,G,.)); description n belongs to scene n // (N // B) -- the
@@ -643,7 +671,8 @@ class TopDownSceneCaptionModule(nn.Module):
             ann_ids = ious.argmax(1)
             target_ids, target_ious = ann_ids.clone(), ious.gather(1, ann_ids.unsqueeze(1)).squeeze(1)
             labels = ref_box_label.argmax(-1)
-        not_ann = (is_annotated != 1).nonzero().view(-1).tolist()
+        # (`not_annotated`: their number when the caller already knows it -- 0 saves the host round trip)
+        not_ann = [] if not_annotated == 0 else (is_annotated != 1).nonzero().view(-1).tolist()
         if not_ann:
             objness = bbox_objness.cpu()
             for n in not_ann:
@@ -682,11 +711,13 @@ class TopDownSceneCaptionModule(nn.Module):
         Cn = N // data_dict["center_label"].shape[0]
         rep = lambda t: t.unsqueeze(1).repeat(1, Cn, *([1] * (t.dim() - 1))).reshape(N, *t.shape[1:])
         obj_masks = rep(data_dict["proposal_batch_mask"])
-        num_words = int(des_lens.max())
+        # ONE host round trip for the two scalars the driver needs: the longest description and whether any sample lacks an
+        # annotation (the reference reads both separately: des_lens.max(), and a python loop over is_annotated)
+        num_words, n_not_ann = torch.stack([des_lens.max().long(), (is_annotated != 1).sum()]).tolist()
 
         target_ids, target_ious, labels = self.select_target(
             data_dict["proposal_batch_mask"], data_dict["proposal_center_batched"], data_dict["proposal_bbox_batched"],
-            data_dict["center_label"], data_dict["gt_bbox"], ref_labels, ref_corners, is_annotated)
+            data_dict["center_label"], data_dict["gt_bbox"], ref_labels, ref_corners, is_annotated, not_annotated=n_not_ann)
         data_dict["assigned_bbox_id_labels"] = labels
         allm = None
         if L != -1:   # one launch for the B scenes, then the rows of the N targets

@@ -52,6 +52,13 @@ int d3_cluster_select(const float *locs, const float *pt_offsets, const int64_t 
                       void *stream);
 int d3_cluster_merge(const int *idx1, int S1, const int *off1, int P1, const int *idx2, int S2, const int *off2, int P2,
                      const int64_t *object_idxs, const int *batch_idxs, int *out_idx, int *out_off, int *out_bid, void *stream);
+/* Per-proposal bookkeeping between the score head and the proposal selection (model/pointgroup.py:338-372): npoint (P) = points
+ * per proposal, mask (P) bytes = sig > score_thr && npoint > npoint_thr, batch_id (P) = batch_id_all[min(offsets[p],
+ * n_batch_id - 1)] (the reference's one-element-short batch-id vector), crop (P,9) = [center | size | 0 | semantic_preds of the
+ * proposal's first point | sig].  sig = sigmoid of the proposal scores. */
+int d3_proposal_prepare(const float *sig, const int *offsets, const int *batch_id_all, int n_batch_id, const int *proposals_idx,
+                        const int64_t *semantic_preds, const float *center, const float *size, float score_thr, float npoint_thr,
+                        int P, float *npoint, unsigned char *mask, int *batch_id, float *crop, void *stream);
 /* The per-point passes of PointGroup.clusters_voxelization (model/pointgroup.py:125-178) over the S (cluster, point) pairs of
  * clusters_idx (S,2) without the gathered / shifted / scaled (S,3) temporaries of the library-op form:
  *   coords_stats: mean (P,3) = sec_mean of the clusters' point coordinates (same serial x/count chain, bit-exact), cmin / cmax
@@ -389,6 +396,11 @@ int d3_adamw(const long long *ptrs, const int *numel, const void *blocks, int nb
 int d3_scatter_add_rows(const float *g, const int64_t *idx, float *out, long long S, int C, void *stream);
 /* out (S,C) = feats[idx]: the forward of the same gathers (C % 4 == 0) */
 int d3_gather_rows(const float *feats, const int64_t *idx, float *out, long long S, int C, void *stream);
+/* out[r] = idx[r] in [0, rows) ? feats[idx[r]] : 0 (scatter == 0; S rows of C floats), or its transpose for UNIQUE indices
+ * (scatter != 0: out[idx[r]] = feats[r] for the in-range entries, out (rows, C) zero-filled by the caller): the padded
+ * placement of the relation graph's edge messages / predictions (model/graph_module.py:291-308) without the zero-row copy. */
+int d3_gather_rows_pad(const float *feats, long long rows, const int64_t *idx, float *out, long long S, int C, int scatter,
+                       void *stream);
 size_t d3_cross_entropy_ws_bytes(void);
 int d3_cross_entropy(const float *z, const int64_t *label, float *grad, float *out, int N, int C, int ignore_index,
                      void *ws, size_t ws_bytes, void *stream);

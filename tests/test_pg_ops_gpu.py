@@ -443,3 +443,29 @@ def test_voxelization_of_a_column_concatenation_without_the_copy(dev):
         ref = P.voxelization(torch.cat((feats, locs), 1).contiguous(), v2p, mode)
         got = P.voxelization_cat(feats, locs, v2p, mode)
         assert int(v2p[:, 0].max()) > 8 and torch.equal(got, ref)
+
+
+def test_proposal_bookkeeping_one_launch_equals_the_library_op_chain(dev):
+    """d3_proposal_prepare against the library ops of model/pointgroup.py:338-372 (points per proposal, score / size threshold
+    mask, the batch id read at the cluster start from the one-element-short batch-id vector, the (P,9) crop box): bit-equal"""
+    from d3net_amd import pointgroup_ops as P
+    rng = np.random.default_rng(21)
+    Pn, N = 300, 5000
+    sizes = rng.integers(1, 200, Pn)
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(dev)
+    S = int(offs[-1])
+    pidx = torch.from_numpy(np.stack([np.repeat(np.arange(Pn), sizes), rng.integers(0, N, S)], 1).astype(np.int32)).to(dev)
+    bid_all = torch.from_numpy(rng.integers(0, 4, S - 1).astype(np.int32)).to(dev)          # one short, like the reference's concat
+    sem = torch.from_numpy(rng.integers(0, 20, N).astype(np.int64)).to(dev)
+    sig = torch.sigmoid(torch.randn(Pn, device=dev))
+    center, size = torch.randn(Pn, 3, device=dev), torch.rand(Pn, 3, device=dev)
+    thr_s, thr_n = 0.35, 50
+    npoint, mask, bid, crop = P.proposal_prepare(sig, offs, bid_all, pidx, sem, center, size, thr_s, thr_n)
+    npoint_ref = (offs[1:] - offs[:-1]).float()
+    mask_ref = torch.logical_and(sig > thr_s, npoint_ref > thr_n)
+    starts = offs[:-1].long().clamp(max=bid_all.numel() - 1)
+    crop_ref = torch.zeros(Pn, 9, device=dev)
+    crop_ref[:, :3] = center; crop_ref[:, 3:6] = size
+    crop_ref[:, 7] = sem[pidx[offs[:-1].long(), 1].long()].float(); crop_ref[:, 8] = sig
+    assert torch.equal(npoint, npoint_ref) and torch.equal(mask, mask_ref) and mask.dtype == torch.bool
+    assert torch.equal(bid, bid_all[starts]) and torch.equal(crop, crop_ref)
