@@ -24,7 +24,16 @@ from ._lib import check
 _ws_cache = {}
 
 
+# the calling thread's current stream / device straight from the runtime bindings: `torch.cuda.current_stream()` builds a
+# Stream object (~5 us) and `torch.cuda.current_device()` walks the lazy-init checks; at ~45 library calls per step inside
+# the host-bound stretches of the step (after a count phase the host has no lead over the GPU) that is time the GPU waits for
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -57,7 +66,10 @@ _NOGUARD = _NoGuard()
 def _on(device):
     """device guard for the raw library calls: a no-op (sub-microsecond) when `device` is already current --
     `torch.cuda.device(...)` costs ~10 us per use, which at ~600 operator calls per step is host time the GPU waits for"""
-    return _NOGUARD if device.index is None or device.index == torch.cuda.current_device() else torch.cuda.device(device)
+    if device.index is None:
+        return _NOGUARD
+    cur = _RAW_DEVICE() if _RAW_DEVICE is not None else torch.cuda.current_device()
+    return _NOGUARD if device.index == cur else torch.cuda.device(device)
 
 
 def _device_of(*tensors):
