@@ -389,7 +389,9 @@ __global__ __launch_bounds__(256) void td_dobj_kernel(const float *__restrict__ 
         for (int e = t; e < sc * K; e += 256) { const int tt = e / K, k = e - tt * K; aS[e] = a[((long long)(s0 + tt) * N + n) * K + k]; }
         for (int e = t; e < sc * F; e += 256) { const int tt = e / F, cc = e - tt * F; dS[e] = dattS[((long long)(s0 + tt) * N + n) * F + cc]; }
         __syncthreads();
-        for (int k = kb; k < K; k += kst) {
+        // (the proposals are split over gridDim.y workgroups: one workgroup per sample left 32 CUs walking 32 k outputs each)
+        const int kper = (K + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * kper, k1 = min(K, k0 + kper);
+        for (int k = k0 + kb; k < k1; k += kst) {
             float v = 0.f;
             for (int tt = 0; tt < sc; tt++) v += aS[tt * K + k] * dS[tt * F + c];
             float *o = dobj + ((long long)n * K + k) * F + c;
@@ -724,7 +726,7 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         if ((rc = hg_launch(p, 3, s))) return rc;
         // dobj = sum_t a_t (x) datt_t (the attention's weighted sum), then += dfp W_feat (through map_feat)
         const int SC = S < 32 ? S : 32;
-        td_dobj_kernel<<<N, 256, (size_t)SC * (K + F) * 4, s>>>(av, dattS, gd->dobj, S, N, K, F, SC);
+        td_dobj_kernel<<<dim3(N, K >= 64 ? 8 : 1), 256, (size_t)SC * (K + F) * 4, s>>>(av, dattS, gd->dobj, S, N, K, F, SC);
         d3_gemm_prob po = td_prob(N * K, F, gd->dobj, F);
         po.nseg = 1; po.seg[0] = td_seg(dfp, H, a->W_feat, F, H, nullptr, 0, 1); po.accum = 1;
         if ((rc = hg_launch(&po, 1, s))) return rc;
