@@ -21,6 +21,20 @@ def main():
     rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows]
+    if os.environ.get("D3_GAPS_SMALLGRID"):   # kernels that run long on few workgroups (a chip of 256 CUs mostly idle): name, workgroups, us
+        seen = {}
+        for r in rows[len(rows) // 2:]:
+            try:
+                wg = max(1, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) * max(1, int(r.get("Grid_Size_Y", 1)) // max(1, int(r.get("Workgroup_Size_Y", 1)))) \
+                    * max(1, int(r.get("Grid_Size_Z", 1)) // max(1, int(r.get("Workgroup_Size_Z", 1))))
+            except (KeyError, ValueError):
+                continue
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            if us >= float(os.environ["D3_GAPS_SMALLGRID"]) and wg < 200:
+                k = (short(r["Kernel_Name"]), wg)
+                seen[k] = max(seen.get(k, 0), us)
+        for (nm, wg), us in sorted(seen.items(), key=lambda x: -x[1]):
+            print("small grid: %-56s %5d workgroups %8.1f us" % (nm, wg, us))
     adam = [i for i, e in enumerate(ev) if e[2].startswith("adamw_kernel")]
     if len(adam) < 3:
         print("fewer than 3 steps in the trace")
