@@ -206,8 +206,47 @@ static d3_gemm_prob ec_prob(int M, int N, float *C, long long ldc) {
 extern "C" size_t d3_edgeconv_ws_bytes(int Emax, int Cin, int Cout) {
     return d3_align((size_t)Emax * 2 * Cin * 4) + d3_align((size_t)Emax * Cout * 4);
 }
+#define EC_KSPLIT 4
 extern "C" size_t d3_edgeconv_bwd_ws_bytes(int Emax, int Cin, int Cout) {
-    return d3_align((size_t)Emax * Cout * 4) * 2 + d3_align((size_t)Emax * 2 * Cin * 4) + d3_align(hg_colsum_ws_bytes(2, Cout));
+    return d3_align((size_t)Emax * Cout * 4) * 2 + d3_align((size_t)Emax * 2 * Cin * 4) + d3_align(hg_colsum_ws_bytes(2, Cout)) +
+           d3_align((size_t)EC_KSPLIT * Cout * 2 * Cin * 4);
+}
+// out = part[0] + part[1] + part[2] + part[3] (fixed order)
+__global__ void ec_sum_parts_kernel(const float *__restrict__ part, long long n, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float v = part[e];
+#pragma unroll
+    for (int q = 1; q < EC_KSPLIT; q++) v += part[q * n + e];
+    out[e] = v;
+}
+// dW (Mo, No) = A^T B over the Emax edge rows (both operands k-major): the reduction is 10 k deep and the output 128 x 128 ..
+// 128 x 256, i.e. 32-64 workgroups walking 10 k rows each (32 us); four row ranges as four problems of ONE launch, then a
+// fixed-order sum of the four partial products
+static int ec_wgrad_split(const float *A, int Mo, const float *Bm, int No, long long Emax, float *dW, float *part, hipStream_t s) {
+    static int split = -1;
+    if (split < 0) { const char *e = getenv("D3_EC_KSPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    if (!split) {      // (A/B: one problem, the reduction walked by 32-64 workgroups)
+        d3_gemm_prob p1 = ec_prob(Mo, No, dW, No);
+        p1.seg[0] = ec_seg(A, Mo, Bm, No, (int)Emax, 1, 1);
+        return hg_launch(&p1, 1, s);
+    }
+    d3_gemm_prob p[EC_KSPLIT];
+    const long long per = ((Emax + EC_KSPLIT - 1) / EC_KSPLIT + 3) / 4 * 4;
+    int np = 0;
+    for (int q = 0; q < EC_KSPLIT; q++) {
+        const long long k0 = q * per, k1 = k0 + per < Emax ? k0 + per : Emax;
+        if (k0 >= k1) break;
+        p[np] = ec_prob(Mo, No, part + (long long)np * Mo * No, No);
+        p[np].seg[0] = ec_seg(A + k0 * Mo, Mo, Bm + k0 * No, No, (int)(k1 - k0), 1, 1);
+        np++;
+    }
+    int rc = hg_launch(p, np, s);
+    if (rc) return rc;
+    if (np < EC_KSPLIT) hipMemsetAsync(part + (long long)np * Mo * No, 0, (size_t)(EC_KSPLIT - np) * Mo * No * sizeof(float), s);
+    const long long n = (long long)Mo * No;
+    ec_sum_parts_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(part, n, dW);
+    return 0;
 }
 
 // x (B*K, Cin); W0 (Cout, 2 Cin), b0; W2 (Cout, Cout), b2 -> node (B*K, Cout), msg (B*K*L, Cout).  ws keeps [Ein | hid].
@@ -278,6 +317,8 @@ extern "C" int d3_edgeconv_bwd(const float *W0, const float *W2, const int *src,
     const float *Ein = (const float *)ws, *hid = (const float *)((const char *)ws + d3_align((size_t)Emax * 2 * Cin * 4));
     float *dm = (float *)ws2, *dh = (float *)((char *)ws2 + d3_align((size_t)Emax * Cout * 4));
     float *dE = (float *)((char *)ws2 + 2 * d3_align((size_t)Emax * Cout * 4));
+    float *wpart = (float *)((char *)ws2 + 2 * d3_align((size_t)Emax * Cout * 4) + d3_align((size_t)Emax * 2 * Cin * 4) +
+                             d3_align(hg_colsum_ws_bytes(2, Cout)));
     (void)src;
     const long long tot = Emax * Cout;
     ec_bwd_dm_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(d_msg, d_node, dst, dm, Emax, Cout);
@@ -285,17 +326,15 @@ extern "C" int d3_edgeconv_bwd(const float *W0, const float *W2, const int *src,
     {   // dh = dm W2 (relu-masked); dW2 = dm^T hid; db2 = colsum(dm)
         d3_gemm_prob p[2];
         p[0] = ec_prob((int)Emax, Cout, dh, Cout); p[0].seg[0] = ec_seg(dm, Cout, W2, Cout, Cout, 0, 1);
-        p[1] = ec_prob(Cout, Cout, dW2, Cout); p[1].seg[0] = ec_seg(dm, Cout, hid, Cout, (int)Emax, 1, 1);
         if ((rc = hg_launch(&p[0], 1, s))) return rc;
-        if ((rc = hg_launch(&p[1], 1, s))) return rc;
+        if ((rc = ec_wgrad_split(dm, Cout, hid, Cout, Emax, dW2, wpart, s))) return rc;
         ec_relu_mask_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(dh, hid, tot);
     }
     {   // dE = dh W0; dW0 = dh^T Ein; db0 = colsum(dh)
         d3_gemm_prob p[2];
         p[0] = ec_prob((int)Emax, 2 * Cin, dE, 2 * Cin); p[0].seg[0] = ec_seg(dh, Cout, W0, 2 * Cin, Cout, 0, 1);
-        p[1] = ec_prob(Cout, 2 * Cin, dW0, 2 * Cin); p[1].seg[0] = ec_seg(dh, Cout, Ein, 2 * Cin, (int)Emax, 1, 1);
         if ((rc = hg_launch(&p[0], 1, s))) return rc;
-        if ((rc = hg_launch(&p[1], 1, s))) return rc;
+        if ((rc = ec_wgrad_split(dh, Cout, Ein, 2 * Cin, Emax, dW0, wpart, s))) return rc;
         // both bias gradients in one two-stage column sum (dm is not modified after the first block)
         const float *cx[2] = {dm, dh}; const long long cl[2] = {Cout, Cout}; const int cr[2] = {(int)Emax, (int)Emax}, cc[2] = {Cout, Cout};
         float *co[2] = {db2, db0};
