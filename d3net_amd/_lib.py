@@ -92,6 +92,7 @@ SIGNATURES = {
     "d3_point_heads_fwd": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                  vp, sz, vp]),
     "d3_score_loss": (i32, [vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]),
+    "d3_query_locals_mask": (i32, [vp, vp, i32, i32, i32, vp]),
     "d3_caption_select_target": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "d3_caption_inputs_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "d3_caption_inputs_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),

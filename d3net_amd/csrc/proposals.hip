@@ -66,6 +66,39 @@ extern "C" int d3_query_locals_dist(const float *corners, const float *masks, fl
     return 0;
 }
 
+// mask[row][j] = 1 for the L smallest entries of dist[row][0..K), 0 elsewhere -- `torch.topk(dist, L, largest=False)` followed by
+// a scatter of ones (graph_module.py:218-227): the library takes everything below the L-th value and fills up with entries
+// equal to it in ascending index order, i.e. the order (value, index); an entry's rank in that order is counted directly
+// (K <= 1024: K^2 comparisons per row out of LDS).  One wave per row; replaces the top-k gather, its sort, a fill and a scatter.
+__global__ __launch_bounds__(256) void query_locals_mask_kernel(const float *__restrict__ dist, float *__restrict__ mask, int rows,
+                                                                int K, int L) {
+    extern __shared__ float qm_sm[];      // 4 waves x K
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float *d = qm_sm + wave * K;
+    if (row < rows)
+        for (int j = lane; j < K; j += 64) d[j] = dist[(size_t)row * K + j];
+    __syncthreads();
+    if (row >= rows) return;
+    for (int j0 = lane; j0 < K; j0 += 64) {
+        const float v = d[j0];
+        int rank = 0;
+        for (int j = 0; j < K; j++) {
+            const float o = d[j];
+            rank += (o < v || (o == v && j < j0)) ? 1 : 0;
+        }
+        mask[(size_t)row * K + j0] = rank < L ? 1.f : 0.f;
+    }
+}
+extern "C" int d3_query_locals_mask(const float *dist, float *mask, int rows, int K, int L, void *stream) {
+    D3_CLEAR();
+    if (rows <= 0) return 0;
+    if (K < 1 || K > 4096 || L < 0) return D3_ERR_ARG;
+    query_locals_mask_kernel<<<(rows + 3) / 4, 256, (size_t)4 * K * sizeof(float), d3_stream(stream)>>>(dist, mask, rows, K, L);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- captioner inputs
 // Reference: model/caption_module.py:416-508 (`select_target`: per description the proposal with the best IoU against the
 // referred box), :530-560 (the target's feature row, its local-context mask), :866-885 (`_add_relation_feat`: the target's L edge

@@ -39,8 +39,16 @@ def query_locals_all(corners, object_masks, num_locals, include_self, overlay_th
         check(_lib.lib().d3_query_locals_dist(_ptr(corners), _ptr(masks), _ptr(dist), B, K, int(include_self),
                                               float(overlay_threshold), int(query_mode == "center"), _stream()),
               "query_locals_dist")
+    if NATIVE_TOPK_MASK and K <= 4096:
+        out = torch.empty_like(dist)
+        with _on(corners.device):      # the L smallest of every row as a 0/1 mask, ties by ascending index like the library's top-k
+            check(_lib.lib().d3_query_locals_mask(_ptr(dist), _ptr(out), B * K, K, int(num_locals), _stream()), "query_locals_mask")
+        return out
     _, topk_ids = torch.topk(dist, num_locals, largest=False, dim=2)
     return torch.zeros_like(dist).scatter_(2, topk_ids, 1)
+
+
+NATIVE_TOPK_MASK = True     # False: torch.topk + scatter (tests compare the two)
 
 
 # ------------------------------------------------------------------------------------------- EdgeConv

@@ -570,6 +570,9 @@ int d3_cider_scores(const int *tokens, int ldt, const int *lens, const int *slot
  * for target id t before its top-k (invalid / overlaid (IoU >= overlay_threshold) -> 1e30, self -> 0 or 1e30). */
 int d3_query_locals_dist(const float *corners, const float *masks, float *dist, int B, int K, int include_self,
                          float overlay_threshold, int center_mode, void *stream);
+/* mask (rows, K) = 1 at the L smallest entries of every row of dist (rows, K), ties by ascending index -- torch.topk(largest =
+ * False) + scatter of ones (model/graph_module.py:218-227 / caption_module.py:833-842) in one launch. */
+int d3_query_locals_mask(const float *dist, float *mask, int rows, int K, int L, void *stream);
 /* The captioner's per-description inputs straight from the per-scene tensors (model/caption_module.py:416-508 `select_target`,
  * :530-560, :866-885 `_add_relation_feat`); description n belongs to scene n / per_scene.
  *   select_target: target_ids[n] = first arg-max over the scene's K proposals of the AABB IoU (lib/utils/bbox.py:247-271, fp32,

@@ -262,3 +262,29 @@ def test_caption_inputs_from_per_scene_tensors_equal_the_replicated_form(dev):
                                              torch.ones(N, device=dev))
     assert torch.equal(ids_n, ids_l) and torch.equal(ious_n, ious_l) and torch.equal(lab_n, lab_l)
     assert torch.equal(ids_n.cpu(), torch.from_numpy(pick))
+
+
+def test_local_context_mask_kernel_equals_topk_scatter(dev):
+    """d3_query_locals_mask against torch.topk(largest=False) + scatter on the distance rows of query_locals_all, including rows
+    with fewer than L valid candidates (ties among the masked 1e30 entries) and fully masked target rows"""
+    import d3net_amd.speaker as SP
+    rng = np.random.default_rng(8)
+    B, K, L = 4, 256, 10
+    ctr = rng.random((B, K, 3)).astype(np.float32) * 4
+    sz = (0.2 + rng.random((B, K, 3))).astype(np.float32)
+    sg = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+    corners = torch.from_numpy(ctr[:, :, None] + sg[None, None] * sz[:, :, None] / 2).to(dev)
+    mask = torch.from_numpy((rng.random((B, K)) < 0.45).astype(np.float32)).to(dev)
+    mask[1] = 0; mask[1, :6] = 1            # a scene with 6 proposals: every row falls back on masked entries
+    mask[2] = 0                              # an empty scene
+    for include_self, thr in ((False, 0.5), (True, 0.5), (True, 0.05)):
+        SP.NATIVE_TOPK_MASK = True
+        a = SP.query_locals_all(corners, mask, L, include_self, thr, "corner")
+        SP.NATIVE_TOPK_MASK = False
+        b = SP.query_locals_all(corners, mask, L, include_self, thr, "corner")
+        SP.NATIVE_TOPK_MASK = True
+        assert torch.equal(a.sum(-1), torch.full((B, K), float(L), device=dev))
+        valid_cols = mask.unsqueeze(1).expand(-1, K, -1) == 1
+        assert torch.equal(a * valid_cols, b * valid_cols)            # identical wherever a valid proposal is concerned
+        full = (b * valid_cols).sum(-1) == L
+        assert torch.equal(a[full], b[full])                           # rows decided without ties: identical masks
