@@ -90,6 +90,54 @@ __global__ void voxelize_fp2_kernel(const float *__restrict__ fa, int Ca, const 
     out[e] = acc;
 }
 
+// The same pooling with one WAVE per voxel, lanes along the channels: the rule row is read once per wave (the thread-per-element
+// form pays a 64-bit division by 134 and re-reads the rule row per element), the <= 4 x 3 gathers of a lane are in flight
+// together.  Same operations per output in the same order: bit-equal.
+__global__ __launch_bounds__(256) void voxelize_fp2_rows_kernel(const float *__restrict__ fa, int Ca, const float *__restrict__ fb, int Cb,
+                                                               float *__restrict__ out, const int *__restrict__ rules, int M, int maxActive,
+                                                               bool average) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nPlanes = Ca + Cb;
+    const int *r = rules + row * (maxActive + 1);
+    const int rv = (lane <= maxActive && lane < 5) ? r[lane] : 0;
+    const int nActive = __shfl(rv, 0);
+    int id[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) id[j] = __shfl(rv, 1 + j);
+    const float multiplier = (average && nActive > 0) ? __fdiv_rn(1.0f, (float)nActive) : 1.0f;
+    for (int p0 = 0; p0 < nPlanes; p0 += 192) {
+        float v[3][4];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int plane = p0 + q * 64 + lane;
+            const bool on = plane < nPlanes;
+            const bool ina = plane < Ca;
+            const float *src = ina ? fa : fb;
+            const int ld = ina ? Ca : Cb, col = on ? (ina ? plane : plane - Ca) : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[q][j] = src[(long long)((on && j < nActive) ? id[j] : 0) * ld + col];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int plane = p0 + q * 64 + lane;
+            if (plane >= nPlanes) continue;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < nActive) acc = __fadd_rn(acc, __fmul_rn(multiplier, v[q][j]));
+            if (nActive > 4) {       // crowded voxel: the remaining points one by one, in rule order
+                const bool ina = plane < Ca;
+                const float *src = ina ? fa : fb;
+                const int ld = ina ? Ca : Cb, col = ina ? plane : plane - Ca;
+                for (int i = 5; i <= nActive; i++) acc = __fadd_rn(acc, __fmul_rn(multiplier, src[(long long)r[i] * ld + col]));
+            }
+            out[row * nPlanes + plane] = acc;
+        }
+    }
+}
+
 // scatter: d_feats[r[i], plane] += multiplier * d_out[row, plane]   (voxelize.cu:35-53)
 __global__ void voxelize_bp_kernel(const float *__restrict__ d_out, float *__restrict__ d_feats,
                                    const int *__restrict__ rules, long long total, int maxActive, int nPlanes,
@@ -141,8 +189,14 @@ extern "C" int d3_voxelize_fp2(const float *feats_a, int Ca, const float *feats_
     if (Ca < 1 || Cb < 0) return D3_ERR_ARG;
     const long long total = (long long)nActive * (Ca + Cb);
     if (total <= 0) return 0;
-    voxelize_fp2_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(feats_a, Ca, feats_b, Cb, output_feats, output_map, total,
-                                                                                 maxActive, mode == 4);
+    static int rows_form = -1;
+    if (rows_form < 0) { const char *e = getenv("D3_VOX_ROWS"); rows_form = (e && e[0] == '0') ? 0 : 1; }
+    if (rows_form && Ca + Cb >= 48)      // wide rows: a wave per voxel
+        voxelize_fp2_rows_kernel<<<(nActive + 3) / 4, 256, 0, d3_stream(stream)>>>(feats_a, Ca, feats_b, Cb, output_feats, output_map, nActive,
+                                                                                  maxActive, mode == 4);
+    else
+        voxelize_fp2_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(feats_a, Ca, feats_b, Cb, output_feats, output_map, total,
+                                                                                     maxActive, mode == 4);
     D3_LAUNCH_CHECK();
     return 0;
 }
