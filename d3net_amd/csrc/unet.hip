@@ -305,7 +305,7 @@ struct OpD {
     int use_shadow;                   // CONV: reads its output gradient from the bf16 shadow of that (fp32) gradient buffer
     int write_shadow;                 // BNACT: its backward apply also writes the bf16 shadow of the buffer it finalises
 };
-#define RED_RING 8
+#define RED_RING 16
 struct Net {
     std::vector<TensorD> T;
     std::vector<BufD> B;
@@ -851,8 +851,35 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     float *bnscr = (float *)(garena + n->bnscr_off);
     std::vector<RedJob> red;
     long long red_blocks = 0;
+    // row-split partials -> dW in batched launches on the weight-gradient stream: one when only the last few convolutions of
+    // the backward (the first of the network: level 0, small weights) are left, one at the very end -- a single launch at the
+    // end left its 137 us exposed behind the stem's weight gradient, after the caller's stream had nothing left to do
+    auto flush_red = [&]() -> int {
+        if (red.empty()) return 0;
+        if (red.size() > n->red_cap) {
+            if (n->red_host) hipHostFree(n->red_host);
+            if (n->red_dev) hipFree(n->red_dev);
+            n->red_cap = red.size() + 16;
+            D3_CHECK(hipStreamSynchronize(ws_stream));   // (growing: nothing may still read the old tables)
+            D3_CHECK(hipHostMalloc((void **)&n->red_host, RED_RING * n->red_cap * sizeof(RedJob)));
+            D3_CHECK(hipMalloc((void **)&n->red_dev, RED_RING * n->red_cap * sizeof(RedJob)));
+        }
+        n->red_flip = (n->red_flip + 1) % RED_RING;   // a slot is rewritten only RED_RING / 2 backward calls later (no host sync needed in between)
+        RedJob *hj = n->red_host + (size_t)n->red_flip * n->red_cap, *dj = n->red_dev + (size_t)n->red_flip * n->red_cap;
+        memcpy(hj, red.data(), red.size() * sizeof(RedJob));
+        D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, ws_stream));
+        un_wgrad_reduce_batched_kernel<<<(int)red_blocks, 256, 0, ws_stream>>>(dj, (int)red.size());
+        red.clear();
+        red_blocks = 0;
+        return 0;
+    };
+    static const int flush_tail = getenv("D3_RED_TAIL") ? atoi(getenv("D3_RED_TAIL")) : 5;
+    int tail_idx = -1;
+    for (int i = 0, c = 0; i < (int)n->ops.size() && flush_tail > 0; i++)
+        if (n->ops[i].type == OP_CONV && pgrads[n->ops[i].w] != nullptr && ++c == flush_tail) { tail_idx = i; break; }
     for (int i = (int)n->ops.size() - 1; i >= 0; i--) {
         OpD &o = n->ops[i];
+        if (i == tail_idx) { int frc = flush_red(); if (frc) return frc; }
         if (o.type == OP_CONV) {
             const TensorD &ti = n->T[o.in];
             int Min, Mout; conv_dims(n, o, Min, Mout);
@@ -959,22 +986,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             }
         }
     }
-    // all row-split partials -> dW, one launch at the end of the side stream
-    if (!red.empty()) {
-        if (red.size() > n->red_cap) {
-            if (n->red_host) hipHostFree(n->red_host);
-            if (n->red_dev) hipFree(n->red_dev);
-            n->red_cap = red.size() + 16;
-            D3_CHECK(hipStreamSynchronize(ws_stream));   // (growing: nothing may still read the old tables)
-            D3_CHECK(hipHostMalloc((void **)&n->red_host, RED_RING * n->red_cap * sizeof(RedJob)));
-            D3_CHECK(hipMalloc((void **)&n->red_dev, RED_RING * n->red_cap * sizeof(RedJob)));
-        }
-        n->red_flip = (n->red_flip + 1) % RED_RING;   // a slot is rewritten only RED_RING backward calls later (no host sync needed in between)
-        RedJob *hj = n->red_host + (size_t)n->red_flip * n->red_cap, *dj = n->red_dev + (size_t)n->red_flip * n->red_cap;
-        memcpy(hj, red.data(), red.size() * sizeof(RedJob));
-        D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, ws_stream));
-        un_wgrad_reduce_batched_kernel<<<(int)red_blocks, 256, 0, ws_stream>>>(dj, (int)red.size());
-    }
+    { int frc = flush_red(); if (frc) return frc; }
     // join: the caller's stream waits for the last weight gradient
     if (side_used) {
         hipEvent_t e = n->next_event();
