@@ -225,7 +225,7 @@ class _MaskedXE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_acc):
         dpred, = ctx.saved_tensors
-        return dpred.mul_(g), None, None      # (the saved gradient is used once)
+        return dpred * g, None, None
 
 
 def compute_cap_loss(data_dict, loss_opt={}, native=True):
