@@ -133,6 +133,10 @@ SIGNATURES = {
     "d3_edgeconv_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "d3_prof_enable": (i32, [i32]),
+    "d3_tuning_set": (i32, [C.c_char_p, i32]),
+    "d3_tuning_get": (i32, [C.c_char_p, vp]),
+    "d3_tuning_count": (i32, []),
+    "d3_tuning_name": (C.c_char_p, [i32]),
     "d3_prof_collect": (i32, [i32, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
     "d3_bn_ws_bytes": (sz, [i32]),
@@ -169,6 +173,29 @@ class TopdownGrads(C.Structure):
     """d3_topdown_grads (include/d3hip.h)"""
     _fields_ = ([("dlogits", vp)] + [("d" + k, vp) for k in TOPDOWN_PARAMS] +
                 [("dobj", vp), ("dtarget", vp), ("ws", vp), ("ws_bytes", sz)])
+
+
+class tuning:
+    """`with _lib.tuning(D3_WG3=0): ...` -- flip measurement / test switches of the library for a block (csrc/tuning.hip: the
+    library parses its environment once; this is how tests and the A/B tools change a switch afterwards)."""
+
+    def __init__(self, **switches):
+        self.switches, self.saved = switches, {}
+
+    def __enter__(self):
+        l = lib()
+        for k, v in self.switches.items():
+            old = C.c_int(0)
+            check(l.d3_tuning_get(k.encode(), C.byref(old)), "tuning_get(%s)" % k)
+            self.saved[k] = old.value
+            check(l.d3_tuning_set(k.encode(), int(v)), "tuning_set(%s)" % k)
+        return self
+
+    def __exit__(self, *exc):
+        l = lib()
+        for k, v in self.saved.items():
+            l.d3_tuning_set(k.encode(), v)
+        return False
 
 
 def lib():

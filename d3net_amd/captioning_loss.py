@@ -136,9 +136,13 @@ def compute_caption_reward(data_dict, cap_tables, sample_topn, idx2word, dataset
     if not valid_l:
         return scores
     if device_cider and annotated.is_cuda:
-        corpus = _CORPORA.get(id(organized_data))
-        if corpus is None:
-            corpus = _CORPORA[id(organized_data)] = CiderCorpus(organized_data, idx2word, annotated.device)
+        # keyed by (annotation object, device) and holding a reference to the object: a bare id() can be reused by a
+        # different annotation dict once the first one is freed (train / val switch) and would then return its corpus
+        ck = (id(organized_data), str(annotated.device))
+        entry = _CORPORA.get(ck)
+        if entry is None or entry[0] is not organized_data:
+            entry = _CORPORA[ck] = (organized_data, CiderCorpus(organized_data, idx2word, annotated.device))
+        corpus = entry[1]
         if corpus.ok:
             out = _cider_device(corpus, [corpus.sets[k] for k in keys], [cap_tables[n][k] for n in valid_l for k in range(sample_topn)],
                                 sample_topn)

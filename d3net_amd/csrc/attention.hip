@@ -421,7 +421,7 @@ __global__ __launch_bounds__(AM_NW * 64) void attn_bwd_cols_mfma_kernel(const fl
     }
 }
 
-static bool am_scalar() { const char *e = getenv("D3_ATTN_SCALAR"); return e && e[0] == '1'; }   // (A/B measurements, tests)
+static bool am_scalar() { return d3_tune(D3T_ATTN_SCALAR) == 1; }   // (A/B measurements, tests)
 static int am_attrs() {
     static bool done[64] = {false};
     int dev = 0;

@@ -884,7 +884,7 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         }
         D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.star, 0, (size_t)n * sizeof(int), s));
-        const bool no_star = getenv("D3_BFS_NO_STAR") != nullptr;   // (tests: force the level loop for every cluster)
+        const bool no_star = d3_tune(D3T_BFS_NO_STAR) != 0;   // (tests: force the level loop for every cluster)
         if (!no_star)
             cl_star_kernel<<<(nCluster + 3) / 4, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.seeds, w.koff, w.sizes, nCluster, w.star,
                                                            cluster_idxs);
@@ -892,7 +892,7 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         int rc = d3_exclusive_scan_i32(w.klen, w.estart, n, w.temp, w.temp_bytes, s);
         if (rc) return rc;
         cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.lid, w.estart, (int4 *)erec, n);
-        const bool debug = getenv("D3_BFS_DEBUG") != nullptr;
+        const bool debug = d3_tune(D3T_BFS_DEBUG) != 0;
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
                                                         w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
         if (debug) {

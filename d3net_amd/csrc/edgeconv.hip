@@ -224,8 +224,7 @@ __global__ void ec_sum_parts_kernel(const float *__restrict__ part, long long n,
 // 128 x 256, i.e. 32-64 workgroups walking 10 k rows each (32 us); four row ranges as four problems of ONE launch, then a
 // fixed-order sum of the four partial products
 static int ec_wgrad_split(const float *A, int Mo, const float *Bm, int No, long long Emax, float *dW, float *part, hipStream_t s) {
-    static int split = -1;
-    if (split < 0) { const char *e = getenv("D3_EC_KSPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    const bool split = d3_tune(D3T_EC_KSPLIT) != 0;
     if (!split) {      // (A/B: one problem, the reduction walked by 32-64 workgroups)
         d3_gemm_prob p1 = ec_prob(Mo, No, dW, No);
         p1.seg[0] = ec_seg(A, Mo, Bm, No, (int)Emax, 1, 1);

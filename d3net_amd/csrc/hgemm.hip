@@ -281,8 +281,7 @@ int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
         if (tiles16 < 2048) {    // few tiles: still split K so that the chip is covered
             HG_SPLIT(2, (maxM + 31) / 32);
         } else {
-            static int tiled = -1;
-            if (tiled < 0) { const char *e = getenv("D3_HG_TILED"); tiled = (e && e[0] == '0') ? 0 : 1; }   // (A/B)
+            const bool tiled = d3_tune(D3T_HG_TILED) != 0;   // (A/B)
             if (tiled) hg_gemm_tiled_kernel<<<dim3((ctiles * 16 + HT_BN - 1) / HT_BN, (maxM + HT_BM - 1) / HT_BM, nprobs), 256, 0, s>>>(b);
             else hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
         }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void det_nms3d_kernel(const float *__restrict_
                     const double inter = l * w * h;
                     double o = old_type ? inter / bx[j][6] : inter / (bx[i][6] + bx[j][6] - inter + 1e-8);
                     if (cl[i] != cl[j]) o = 0.;
-                    kill = !(o <= thr);
+                    kill = o > thr;   // (numpy's `o > thr`: a NaN overlap -- zero-volume boxes with old_type -- keeps the box)
                     if (kill) alive[j] = 0;
                 }
             }

@@ -184,11 +184,13 @@ __device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
 
 // LDS use of the wave-per-tile kernel besides the weights
 #define C2_TBL_INTS (16 * C2_MAXK)
-#define C2_WAVE_LDS_BASE(NTV) (4 * C2_TBL_INTS * 4 + 4 * 32 * 4 + 4 * 2 * (NTV) * 16 * 4)
-#define C2_WAVE_LDS_BYTES(NTV) (C2_WAVE_LDS_BASE(NTV) + (NTV) * 16 * 16)   // + BatchNorm parameters, float4 per channel
+#define C2_WAVE_LDS_BASE(NTV, NWV) ((NWV) * C2_TBL_INTS * 4 + (NWV) * 32 * 4 + (NWV) * 2 * (NTV) * 16 * 4)
+#define C2_WAVE_LDS_BYTES(NTV, NWV) (C2_WAVE_LDS_BASE(NTV, NWV) + (NTV) * 16 * 16)   // + BatchNorm parameters, float4 per channel
 
-// Wave-per-tile kernel (big levels): 256 threads = 4 independent waves, persistent over a contiguous range of
-// 4-tile groups (XCD-contiguous: block b runs on XCD b % 8, so XCD x gets the x-th eighth of the rows and the
+// Wave-per-tile kernel (big levels): NW independent waves per workgroup (4, or 16 when the layer's packed weights are
+// large: ONE LDS copy then serves 16 waves -- a 117 KB stem / 124 KB 48->48 weight set fits the CU's 160 KB once, and a
+// 55 KB 32->32 set is staged by 256 workgroups instead of 1024), persistent over a contiguous range of
+// NW-tile groups (XCD-contiguous: block b runs on XCD b % 8, so XCD x gets the x-th eighth of the rows and the
 // neighbour rows its tiles gather stay in that XCD's L2).
 // Every dependent global access of a wave is a full L2/HBM round trip and the MFMA work between them is tiny, so the
 // kernel is organised around round trips, not FLOPs: (1) the kernel-map rows of the NEXT tile are prefetched into
@@ -205,19 +207,20 @@ __device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
 #define C2_F32_OCCDROP 1
 #endif
 #define C2_OCC(NTV, XB) ((NTV) <= 4 ? ((XB) ? C2_OCC_SMALL : C2_OCC_SMALL - C2_F32_OCCDROP) : (NTV) <= 9 ? ((XB) ? 3 : 2) : 2)
-template <int NT, bool WLDS, bool XBF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, XBF), 8))) void spconv_fwd2_kernel(const Conv2Args a) {
+template <int NT, bool WLDS, bool XBF, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int U = (!XBF && NT <= 2) ? C2_F32_U : C2_U(NT);
+    // (16-wave workgroups run at 128 VGPRs: the fp32-input variants keep 4 gathers of 32 B in flight there instead of 8)
+    constexpr int U = (!XBF && NT <= 2) ? (NW == 16 ? 4 : C2_F32_U) : C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int K = a.K, S = a.S;
     const size_t wbytes = WLDS ? (size_t)K * S * NT * 256 : 0;
     int *tblS = (int *)(smem + wbytes) + wave * C2_TBL_INTS;
-    float *redS = (float *)(smem + wbytes + 4 * C2_TBL_INTS * 4);
+    float *redS = (float *)(smem + wbytes + NW * C2_TBL_INTS * 4);
     const unsigned short *Wb = WLDS ? (const unsigned short *)smem : a.Wp;
     const int nb = gridDim.x, b = blockIdx.x;
     const int lb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-    const int ntg = (a.ntiles + 3) >> 2;
+    const int ntg = (a.ntiles + NW - 1) / NW;
     const int per = (ntg + nb - 1) / nb;
     const int tg0 = lb * per, tg1 = min(ntg, tg0 + per);
     int v[7];
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, 
             if (tile_ < a.ntiles && e < 16 * K && base_ + e < lim_) v[it] = a.tbl ? a.tbl[base_ + e] : (int)(base_ + e); \
         }                                                                                                     \
     }
-    if (C2_PREFETCH) C2_LOAD_TBL(tg0 * 4 + wave)
-    float4 *bnS = (float4 *)(smem + wbytes + C2_WAVE_LDS_BASE(NT));   // (mean, 1/std, gamma, beta) per channel
+    if (C2_PREFETCH) C2_LOAD_TBL(tg0 * NW + wave)
+    float4 *bnS = (float4 *)(smem + wbytes + C2_WAVE_LDS_BASE(NT, NW));   // (mean, 1/std, gamma, beta) per channel
     if (a.bnx && t < NT * 16) {
         float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < a.Cout) {
@@ -245,12 +248,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, 
         const uint4 *src = (const uint4 *)a.Wp;
         uint4 *dst = (uint4 *)smem;
         const int n16 = (int)(wbytes >> 4);
-        for (int i0 = 0; i0 < n16; i0 += 1024) {
+        for (int i0 = 0; i0 < n16; i0 += 4 * 64 * NW) {
             uint4 w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const int i = i0 + q * 256 + t; w4[q] = make_uint4(0u, 0u, 0u, 0u); if (i < n16) w4[q] = src[i]; }
+            for (int q = 0; q < 4; q++) { const int i = i0 + q * 64 * NW + t; w4[q] = make_uint4(0u, 0u, 0u, 0u); if (i < n16) w4[q] = src[i]; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const int i = i0 + q * 256 + t; if (i < n16) dst[i] = w4[q]; }
+            for (int q = 0; q < 4; q++) { const int i = i0 + q * 64 * NW + t; if (i < n16) dst[i] = w4[q]; }
         }
     }
     if (WLDS || a.bnx) __syncthreads();
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, 
     const int nsteps = (K * S + 3) >> 2;
 
     for (int tg = tg0; tg < tg1; tg++) {
-        const int tile = tg * 4 + wave;
+        const int tile = tg * NW + wave;
         if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
         const int row0 = tile * 16;
         if (!C2_PREFETCH) C2_LOAD_TBL(tile)
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, 
             const int e = lane + it * 64;
             if (e < 16 * K) tblS[e] = v[it];
         }
-        if (C2_PREFETCH && tg + 1 < tg1) C2_LOAD_TBL(tile + 4)
+        if (C2_PREFETCH && tg + 1 < tg1) C2_LOAD_TBL(tile + NW)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -417,12 +420,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C2_OCC(NT, 
         if (t < 2 * NT * 16) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) s += redS[w * 2 * NT * 16 + t];
+            for (int w = 0; w < NW; w++) s += redS[w * 2 * NT * 16 + t];
             if (a.fin_counter) c2_part_store(&a.part[(long long)b * 2 * NT * 16 + t], s);
             else a.part[(long long)b * 2 * NT * 16 + t] = s;
         }
         if (a.fin_counter)   // (flag word: the spare LDS behind the statistics rows; no static LDS in front of the dynamic region)
-            c2_last_block_finalize(a, (int)gridDim.x, (int)gridDim.x, (int *)(redS + 4 * 2 * NT * 16));
+            c2_last_block_finalize(a, (int)gridDim.x, (int)gridDim.x, (int *)(redS + NW * 2 * NT * 16));
     }
 }
 
@@ -596,21 +599,32 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
     }
 }
 
-struct Conv2Plan { int split, W, grid, wlds, ntw, gy; size_t lds; };
+#define C2_NW16_MAXNT 4      // 16-wave variants are instantiated for <= 4 column tiles
+static int c2_ncu() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t pr; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    return n;
+}
+struct Conv2Plan { int split, W, grid, wlds, ntw, gy, nw; size_t lds; };
 
 static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout) {
     Conv2Plan p;
     const int NT = (Cout + 15) / 16, ntiles = (Mout + 15) / 16;
     const size_t wbytes = (size_t)K * (Cin / 8) * NT * 256;
-    p.ntw = NT; p.gy = 1;
+    p.ntw = NT; p.gy = 1; p.nw = 4;
     if (ntiles >= 1024) {
         p.split = 0; p.W = 1;
-        const int ntg = (ntiles + 3) / 4;
-        static const int cap = getenv("D3_C2_GRIDCAP") ? atoi(getenv("D3_C2_GRIDCAP")) : 1024;   // (experiments)
+        // 16 waves around ONE LDS copy of a large weight set (one workgroup per CU), 4 waves per workgroup otherwise
+        const size_t big_from = (size_t)d3_tune(D3T_C2_NW16_KB) * 1024, lds_max = (size_t)d3_tune(D3T_C2_WLDS_KB) * 1024;
+        if (NT <= C2_NW16_MAXNT && wbytes >= big_from && wbytes + C2_WAVE_LDS_BYTES(NT, 16) <= lds_max && wbytes + C2_WAVE_LDS_BYTES(NT, 16) <= 160 * 1024)
+            p.nw = 16;
+        const int ntg = (ntiles + p.nw - 1) / p.nw;
+        int cap = d3_tune(D3T_C2_GRIDCAP);   // (experiments)
+        if (p.nw == 16) cap = c2_ncu();      // LDS admits one such workgroup per CU
         const int per = (ntg + cap - 1) / cap;
         p.grid = (ntg + per - 1) / per;
-        p.wlds = (wbytes + C2_WAVE_LDS_BYTES(NT) <= 72 * 1024) ? 1 : 0;
-        p.lds = (p.wlds ? wbytes : 0) + C2_WAVE_LDS_BYTES(NT);
+        p.wlds = (p.nw == 16 || wbytes + C2_WAVE_LDS_BYTES(NT, 4) <= 72 * 1024) ? 1 : 0;
+        p.lds = (p.wlds ? wbytes : 0) + C2_WAVE_LDS_BYTES(NT, p.nw);
     } else {
         p.split = 1; p.grid = ntiles; p.wlds = 0;
         // few tiles: one column tile per workgroup (the gather is repeated per column group, from L2)
@@ -636,7 +650,7 @@ extern "C" int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout) {
 extern "C" int d3_spconv_fwd2_plan(int Mout, int K, int Cin, int Cout, int *out) {
     if (!out || K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
-    out[0] = p.split; out[1] = p.W; out[2] = p.grid; out[3] = p.wlds; out[4] = p.ntw; out[5] = p.gy;
+    out[0] = p.split; out[1] = p.split ? p.W : p.nw; out[2] = p.grid; out[3] = p.wlds; out[4] = p.ntw; out[5] = p.gy;
     return 0;
 }
 
@@ -657,6 +671,19 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    }
+    if constexpr (NT <= C2_NW16_MAXNT) {
+        if (p.nw == 16) {
+            static bool attr16_done_dev[64] = {false};
+            if (c2_attr_needed(attr16_done_dev)) {
+                D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            if (a.xbf16) spconv_fwd2_kernel<NT, true, true, 16><<<p.grid, 1024, p.lds, s>>>(a);
+            else spconv_fwd2_kernel<NT, true, false, 16><<<p.grid, 1024, p.lds, s>>>(a);
+            D3_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (a.xbf16) {
         if (p.wlds) spconv_fwd2_kernel<NT, true, true><<<p.grid, 256, p.lds, s>>>(a);
@@ -1394,7 +1421,7 @@ struct Wg3Cfg { int mt, nt, k, gx, nw, ow, kg, s; };
 #define WG3_ROW(MT, NT, KV, GXV, NW, OW, KG, SV) {MT, NT, KV, GXV, NW, OW, KG, SV},
 static const Wg3Cfg wg3_cfgs[] = {WG3_CONFIGS(WG3_ROW)};
 #undef WG3_ROW
-static bool wg3_enabled() { const char *e = getenv("D3_WG3"); return !(e && e[0] == '0'); }   // D3_WG3=0: A/B measurements
+static bool wg3_enabled() { return d3_tune(D3T_WG3) != 0; }   // D3_WG3=0: A/B measurements
 // Row splits of a configuration.  One workgroup per compute unit: measured on MI355X (tools/wgrad_bench.py, 649 k rows, 16 -> 16)
 // 256 / 384 / 512 / 1024 workgroups = 57 / 75 / 68 / 90 us -- a multiple of the CU count keeps the CUs evenly loaded, every extra
 // split is another partial dW written and read back.  The partials stay below max(16 MB, 25 % of the algorithmic bytes).
@@ -1409,7 +1436,7 @@ static int wg3_splits(const Wg3Cfg &c, int Ms, int Mg, int K, int Cg, int Cs, in
     const double alg = (double)Ms * K * 4 + (double)Mg * Cg * (gbf ? 2 : 4) + (double)Ms * Cs * (sbf ? 2 : 4);
     double cap = 0.25 * alg; if (cap < 16.0 * 1048576) cap = 16.0 * 1048576;
     int target = wg3_ncu();
-    { const char *e = getenv("D3_WG3_R"); if (e && atoi(e) > 0) target = atoi(e); }   // (experiments)
+    if (d3_tune(D3T_WG3_R) > 0) target = d3_tune(D3T_WG3_R);   // (experiments)
     int R = target / c.kg; if (R < 1) R = 1;
     const int capR = (int)(cap / (double)wsz);
     *capped = R > capR;
@@ -1425,8 +1452,7 @@ static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, in
     // 32-bit buffer offsets: operand extents with up to 2x row pitch (views of concatenated buffers)
     if ((long long)Mg * Cg * 2 * (gbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * Cs * 2 * (sbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * K * 4 >= (1ll << 31)) return nullptr;
     const int mt = Cg / 16, nt = (Cs + 15) / 16;
-    const char *es = getenv("D3_WG3_S");                               // (experiments: prefer the variants with this S)
-    const int want_s = es ? atoi(es) : 0;
+    const int want_s = d3_tune(D3T_WG3_S);                             // (experiments: prefer the variants with this S)
     bool have_s = false;
     for (const Wg3Cfg &c : wg3_cfgs)
         if (c.mt == mt && c.nt == nt && c.k == K && c.gx == (gx ? 1 : 0) && c.s == want_s) have_s = true;
@@ -1446,7 +1472,7 @@ static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, in
 struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw, wide, tr; int rsg, dg, imgg, rss, dss, imgs; size_t lds, ws_bytes; const Wg3Cfg *w3; };
 
 // D3_WG2_TR=0 selects the first staging scheme (transposed ds_write_b16 images) for A/B measurements
-static bool wg2_use_tr() { const char *e = getenv("D3_WG2_TR"); return !(e && e[0] == '0'); }
+static bool wg2_use_tr() { return d3_tune(D3T_WG2_TR) != 0; }
 
 static Wg2Plan wg2_plan(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout, bool gx, bool gbf, bool sbf) {
     Wg2Plan p;

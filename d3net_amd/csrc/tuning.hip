@@ -1,0 +1,74 @@
+// tuning.hip -- the ONE place where libd3hip.so reads its environment.
+//
+// Every measurement / test switch of the library lives in this table.  The environment is parsed
+// exactly once, at the first d3_tune() of the process; launch paths read an array slot, never getenv().  Tests and the
+// A/B tools flip a switch at run time through d3_tuning_set() (include/d3hip.h) instead of mutating the environment.
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+namespace {
+struct Entry { const char *name; int dflt; };
+// order == enum D3Tune (common.h)
+const Entry kTable[D3T_COUNT] = {
+    {"D3_ATTN_SCALAR", 0},          // 1: round-1 scalar attention kernels (cross-check)
+    {"D3_BFS_NO_STAR", 0},          // 1: force the BFS level loop for every cluster (tests)
+    {"D3_BFS_DEBUG", 0},            // 1: clustering debug dumps
+    {"D3_EC_KSPLIT", 1},            // 0: EdgeConv weight gradients as one problem
+    {"D3_HG_TILED", 1},             // 0: wave-per-tile heads GEMM for the tall problems
+    {"D3_C2_GRIDCAP", 1024},        // persistent workgroups per convolution launch
+    {"D3_WG3", 1},                  // 0: second-generation weight-gradient kernel
+    {"D3_WG3_R", 0},                // > 0: weight gradient target workgroup count
+    {"D3_WG3_S", 0},                // > 0: prefer weight-gradient variants with this sub-chunk count
+    {"D3_WG2_TR", 1},               // 0: first LDS staging scheme of the second-generation weight gradient
+    {"D3_LASTBLOCK_FINALIZE", 0},   // 1: last workgroup of a convolution finalizes the BatchNorm statistics
+    {"D3_GRAD_BF16", 1},            // 0: every gradient buffer in fp32
+    {"D3_SIDE_PRIO", 1},            // 0: plain (not lowest-priority) weight-gradient stream
+    {"D3_SIDE_MIN_ROWS", 32768},    // level-0 rows from which the weight gradients run on the side stream
+    {"D3_RED_TAIL", 5},             // flush the batched weight-gradient reduction when this many convolutions are left
+    {"D3_VOX_ROWS", 1},             // 0: thread-per-element input voxelisation
+    {"D3_C2_WLDS_KB", 160},         // 16-wave convolution workgroups: total LDS (weights + tile state) up to this many KB
+    {"D3_C2_NW16_KB", 24},          // packed weights of at least this many KB: 16 waves share one LDS copy (1 << 20: never)
+};
+std::atomic<int> g_val[D3T_COUNT];
+std::once_flag g_once;
+
+void parse_once() {
+    for (int i = 0; i < D3T_COUNT; i++) {
+        const char *e = getenv(kTable[i].name);
+        g_val[i].store((e && e[0]) ? atoi(e) : kTable[i].dflt, std::memory_order_relaxed);
+    }
+}
+int find(const char *name) {
+    for (int i = 0; name && i < D3T_COUNT; i++)
+        if (!strcmp(name, kTable[i].name)) return i;
+    return -1;
+}
+}  // namespace
+
+int d3_tune(int key) {
+    std::call_once(g_once, parse_once);
+    return g_val[key].load(std::memory_order_relaxed);
+}
+
+extern "C" int d3_tuning_set(const char *name, int value) {
+    std::call_once(g_once, parse_once);
+    const int i = find(name);
+    if (i < 0) return D3_ERR_ARG;
+    g_val[i].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int d3_tuning_get(const char *name, int *value) {
+    std::call_once(g_once, parse_once);
+    const int i = find(name);
+    if (i < 0 || !value) return D3_ERR_ARG;
+    *value = g_val[i].load(std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int d3_tuning_count(void) { return D3T_COUNT; }
+
+extern "C" const char *d3_tuning_name(int i) { return (i >= 0 && i < D3T_COUNT) ? kTable[i].name : nullptr; }

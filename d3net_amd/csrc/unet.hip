@@ -462,8 +462,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     // backward 5.4 -> 5.7 ms -- every workgroup has to wait for its write-through partial row and take a memory-side
     // ticket before it retires, which costs more than the 160 tiny finalize launches it saves.  Off unless
     // D3_LASTBLOCK_FINALIZE=1 (kept for hardware with a coherent L2).
-    const char *lb = getenv("D3_LASTBLOCK_FINALIZE");
-    n->lastblock = lb && lb[0] == '1';
+    n->lastblock = d3_tune(D3T_LASTBLOCK_FINALIZE) == 1;
     for (size_t j = 0; n->lastblock && j < n->ops.size(); j++) {
         OpD &b = n->ops[j];
         if (b.type != OP_BNACT || b.srcs.size() != 1) continue;
@@ -486,8 +485,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     // 27-fold gather and of the weight gradient's dy operand.  D3_GRAD_BF16=0 keeps them in fp32 (A/B measurements).
     n->gbf.assign(n->B.size(), 0);
     {
-        const char *e = getenv("D3_GRAD_BF16");
-        const bool on = !(e && e[0] == '0');
+        const bool on = d3_tune(D3T_GRAD_BF16) != 0;
         for (size_t b = 0; on && b < n->B.size(); b++) {
             if (n->galias[b] >= 0) continue;
             if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
@@ -521,8 +519,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     n->gshadow.assign(n->B.size(), 0);
     n->gshadow_off.assign(n->B.size(), 0);
     {
-        const char *e = getenv("D3_GRAD_BF16");
-        const bool on = !(e && e[0] == '0');
+        const bool on = d3_tune(D3T_GRAD_BF16) != 0;
         auto root_of = [&](int tensor, int &coff, int &C) {          // as gptr(): follow residual aliases
             const TensorD *t = &n->T[tensor];
             coff = t->coff; C = t->C;
@@ -564,8 +561,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     {   // weight gradients are off the critical path: lowest priority, so the data-gradient chain of the caller's stream wins
         // when both want the machine (D3_SIDE_PRIO=0: plain stream)
         int lo = 0, hi = 0;
-        const char *e = getenv("D3_SIDE_PRIO");
-        if (!(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+        if (d3_tune(D3T_SIDE_PRIO) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
             hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo);
         else
             hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
@@ -837,7 +833,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     // gradients stay on the caller's stream (no events).  Big ones use the side stream; the "a side-stream kernel still
     // reads this gradient buffer" hazard gets an event only for the convolutions whose output gradient is later
     // accumulated into in place (residual aliases: known from the program, OpD::wg_hazard).
-    static const int side_min_rows = getenv("D3_SIDE_MIN_ROWS") ? atoi(getenv("D3_SIDE_MIN_ROWS")) : 32768;   // (experiments)
+    const int side_min_rows = d3_tune(D3T_SIDE_MIN_ROWS);   // (experiments)
     const bool use_side = n->rows[0] >= side_min_rows;
     hipStream_t ws_stream = use_side ? n->side : s;
     std::map<int, hipEvent_t> pending;   // gradient buffer root -> event after its last side-stream reader
@@ -857,10 +853,10 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     auto flush_red = [&]() -> int {
         if (red.empty()) return 0;
         if (red.size() > n->red_cap) {
+            D3_CHECK(hipStreamSynchronize(ws_stream));   // (growing: nothing may still read the old tables -- BEFORE they are freed)
             if (n->red_host) hipHostFree(n->red_host);
             if (n->red_dev) hipFree(n->red_dev);
             n->red_cap = red.size() + 16;
-            D3_CHECK(hipStreamSynchronize(ws_stream));   // (growing: nothing may still read the old tables)
             D3_CHECK(hipHostMalloc((void **)&n->red_host, RED_RING * n->red_cap * sizeof(RedJob)));
             D3_CHECK(hipMalloc((void **)&n->red_dev, RED_RING * n->red_cap * sizeof(RedJob)));
         }
@@ -873,7 +869,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
         red_blocks = 0;
         return 0;
     };
-    static const int flush_tail = getenv("D3_RED_TAIL") ? atoi(getenv("D3_RED_TAIL")) : 5;
+    const int flush_tail = d3_tune(D3T_RED_TAIL);
     int tail_idx = -1;
     for (int i = 0, c = 0; i < (int)n->ops.size() && flush_tail > 0; i++)
         if (n->ops[i].type == OP_CONV && pgrads[n->ops[i].w] != nullptr && ++c == flush_tail) { tail_idx = i; break; }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void voxelize_fp2_rows_kernel(const float *__r
         for (int q = 0; q < 3; q++) {
             const int plane = p0 + q * 64 + lane;
             const bool on = plane < nPlanes;
-            const bool ina = plane < Ca;
+            const bool ina = plane < Ca || !on;   // lanes past the last plane read (and discard) element 0 of `fa`: `fb` may be empty (Cb == 0)
             const float *src = ina ? fa : fb;
             const int ld = ina ? Ca : Cb, col = on ? (ina ? plane : plane - Ca) : 0;
 #pragma unroll
@@ -189,8 +189,7 @@ extern "C" int d3_voxelize_fp2(const float *feats_a, int Ca, const float *feats_
     if (Ca < 1 || Cb < 0) return D3_ERR_ARG;
     const long long total = (long long)nActive * (Ca + Cb);
     if (total <= 0) return 0;
-    static int rows_form = -1;
-    if (rows_form < 0) { const char *e = getenv("D3_VOX_ROWS"); rows_form = (e && e[0] == '0') ? 0 : 1; }
+    const int rows_form = d3_tune(D3T_VOX_ROWS);
     if (rows_form && Ca + Cb >= 48)      // wide rows: a wave per voxel
         voxelize_fp2_rows_kernel<<<(nActive + 3) / 4, 256, 0, d3_stream(stream)>>>(feats_a, Ca, feats_b, Cb, output_feats, output_map, nActive,
                                                                                   maxActive, mode == 4);

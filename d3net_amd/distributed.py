@@ -91,6 +91,17 @@ class BucketGradAllReduce:
         self._fired = 0
         self._early_work = None
         self.early_launches = 0     # steps whose heads bucket started inside backward()
+        # Evidence, not assumption: "every head gradient is final when the last boundary fires" rests on the
+        # autograd engine's ready-queue order.  Every early parameter reports its accumulation through a
+        # post-accumulate-grad hook; an accumulation that arrives AFTER the bucket was packed (a head parameter also used
+        # inside the detector, a node on another ready queue, a second backward() before the sync) is recorded, and
+        # `_finish_early` additionally compares every gradient's identity and version counter with the snapshot taken at
+        # pack time -- a mismatch raises instead of silently installing a stale average.
+        self._late = []
+        self._snap = None
+        for i, p in enumerate(self.early):
+            if hasattr(p, "register_post_accumulate_grad_hook"):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_early_grad(i))
 
     # ---- early bucket -------------------------------------------------------------------------------------------
     def _active(self):
@@ -117,9 +128,15 @@ class BucketGradAllReduce:
             self._launch_early()
             self.early_launches += 1
 
+    def _on_early_grad(self, i):
+        if self._early_work is not None:      # the bucket is already on the wire: this gradient is not in it
+            self._late.append(i)
+
     def _launch_early(self):
         dev = self.early[0].device
         avg = _avg_supported(dev)
+        self._late = []
+        self._snap = [(p.grad, -1 if p.grad is None else p.grad._version) for p in self.early]
         packed = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.early])
         work = dist.all_reduce(packed, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self._early_work = (work, packed, avg)
@@ -127,6 +144,16 @@ class BucketGradAllReduce:
     def _finish_early(self, world):
         work, packed, avg = self._early_work
         work.wait()
+        stale = sorted(set(self._late) | {i for i, (p, (g, v)) in enumerate(zip(self.early, self._snap))
+                                          if p.grad is not g or (g is not None and g._version != v)})
+        if stale:
+            self._early_work, self._snap, self._late = None, None, []
+            self._expected = self._fired = 0
+            raise RuntimeError("BucketGradAllReduce: %d gradient(s) of the early (heads) bucket changed after the bucket was packed "
+                               "inside backward() (first: early[%d]) -- a head parameter receives gradient below the detector "
+                               "boundary, or backward() ran more than once before the sync (gradient accumulation).  The averaged "
+                               "bucket would silently drop that contribution; run with D3_EARLY_ALLREDUCE=0." % (len(stale), stale[0]))
+        self._snap = None
         if not avg:
             packed.div_(world)
         for p, v in zip(self.early, packed.split([p.numel() for p in self.early])):

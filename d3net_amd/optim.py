@@ -6,7 +6,14 @@ multi-tensor launch per ~30 tensors (8 launches, 0.27 ms for the detector's ~300
 A device table of (param, grad, exp_avg, exp_avg_sq) pointers is kept per group.  Per step the host only collects the
 gradient addresses (the native U-Net executor keeps its flat gradient buffer, the few head gradients are re-allocated by
 `zero_grad(set_to_none=True)`); when any of them moved, the address column is refreshed through a pinned staging buffer
-(one asynchronous 10 KB copy, no synchronisation)."""
+(one asynchronous 10 KB copy, no synchronisation).
+
+The step count is PER PARAMETER, as in `torch.optim.AdamW` (bias correction `1 - beta^t` with t = the number of updates this
+tensor has received): ScoreNet / `score_linear` only start receiving gradients once proposals exist
+(`epoch > prepare_epochs`, model/pointgroup.py:332) and must then start at t = 1, not at the backbone's t.  The tensors of a
+table are ordered by their step count, so tensors with equal counts ("cohorts") own a contiguous range of the block map and
+get one launch with their own bias corrections -- one launch in the steady state.  `state_dict()` carries
+`state[p]["step"]`, so checkpoints move to and from `torch.optim.AdamW` in both directions."""
 import math
 import operator
 
@@ -28,16 +35,42 @@ class FusedAdamW(torch.optim.Optimizer):
 
     RING = 4   # pinned staging slots per group: an address refresh never rewrites a buffer whose copy may still be queued
 
+    def _flush_steps(self):
+        """cohort step counters of the cached tables -> state[p]["step"] (python ints)"""
+        for tb in self._tables.values():
+            for t, lo, hi, _b0, _nb in tb.get("cohorts", ()):
+                for p in tb["plist"][lo:hi]:
+                    self.state[p]["step"] = t
+
+    def state_dict(self):
+        """torch.optim.AdamW's layout: per-parameter `step` (a float32 scalar tensor), `exp_avg`, `exp_avg_sq`"""
+        self._flush_steps()
+        for st in self.state.values():
+            if "step" in st and not torch.is_tensor(st["step"]):
+                st["step"] = torch.tensor(float(st["step"]))
+        try:
+            return super().state_dict()
+        finally:
+            for st in self.state.values():
+                if torch.is_tensor(st.get("step")):
+                    st["step"] = int(st["step"])
+
     def load_state_dict(self, state_dict):
-        """moments are replaced: the cached device tables (which hold their addresses) are dropped; the step count comes from
-        the checkpoint (per-group `step`, or torch.optim.AdamW's per-parameter `state[p]["step"]`)"""
+        """moments are replaced: the cached device tables (which hold their addresses) are dropped; the step counts come from
+        the checkpoint: torch.optim.AdamW's per-parameter `state[p]["step"]`, or -- checkpoints written by the first
+        version of this class -- one per-group `step` applied to every tensor that has moments"""
         super().load_state_dict(state_dict)
         self._tables = {}
         for group in self.param_groups:
-            if "step" not in group:
-                steps = [int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
-                if steps:
-                    group["step"] = max(steps)
+            legacy = group.pop("step", None)
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st is None or "exp_avg" not in st:
+                    continue
+                if "step" in st:
+                    st["step"] = int(st["step"])
+                elif legacy is not None:
+                    st["step"] = int(legacy)
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -53,6 +86,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def _build(self, gi, plist):
         for p in plist:
             self._validate(p)
+        # equal step counts adjacent (most-stepped first; stable): one contiguous block-map range, one launch per cohort
+        plist.sort(key=lambda p: -int(self.state[p].get("step", 0)))
         dev = plist[0].device
         fresh = [p for p in plist if "exp_avg" not in self.state[p]]
         if fresh:   # moments of the tensors seen for the first time: one flat buffer
@@ -73,7 +108,14 @@ class FusedAdamW(torch.optim.Optimizer):
         hv[:, 3] = [self.state[p]["exp_avg_sq"].data_ptr() for p in plist]
         numel = np.array([p.numel() for p in plist], dtype=np.int32)
         blocks = np.array([(t, c) for t, n in enumerate(numel) for c in range((int(n) + chunk - 1) // chunk)], dtype=np.int32)
-        tb = {"pptr": [p.data_ptr() for p in plist], "gptr": hv[:, 1].tolist(), "host": host, "ring": ring, "slot": 0,
+        nblk = [(int(n) + chunk - 1) // chunk for n in numel]
+        cohorts, lo, b0 = [], 0, 0      # [step count, first tensor, end tensor, first block, blocks]
+        for i in range(1, len(plist) + 1):
+            if i == len(plist) or int(self.state[plist[i]].get("step", 0)) != int(self.state[plist[lo]].get("step", 0)):
+                nb = sum(nblk[lo:i])
+                cohorts.append([int(self.state[plist[lo]].get("step", 0)), lo, i, b0, nb])
+                lo, b0 = i, b0 + nb
+        tb = {"pptr": [p.data_ptr() for p in plist], "gptr": hv[:, 1].tolist(), "host": host, "ring": ring, "slot": 0, "cohorts": cohorts,
               "mptr": [self.state[p]["exp_avg"].data_ptr() for p in plist],
               "nblocks": int(blocks.shape[0]), "ptrs": host.to(dev), "numel": torch.from_numpy(numel).to(dev),
               "blocks": torch.from_numpy(blocks.reshape(-1)).to(dev), "device": dev}
@@ -106,6 +148,8 @@ class FusedAdamW(torch.optim.Optimizer):
         plist = [p for p in params if p.grad is not None]
         if not plist:
             return {"nblocks": 0, "plist": [], "ngrad": -1}
+        self._flush_steps()            # the table being replaced owns the current counts
+        self._tables.pop(gi, None)
         tb = self._build(gi, plist)
         tb["plist"] = plist
         tb["ngrad"] = len(plist)
@@ -122,10 +166,12 @@ class FusedAdamW(torch.optim.Optimizer):
             tb = self._table(gi, group)
             if tb["nblocks"] == 0:
                 continue
-            group["step"] = t = int(group.get("step", 0)) + 1
             b1, b2 = group["betas"]
             with torch.cuda.device(tb["device"]):
-                check(L.d3_adamw(tb["ptrs"].data_ptr(), tb["numel"].data_ptr(), tb["blocks"].data_ptr(), tb["nblocks"],
-                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), torch.cuda.current_stream().cuda_stream), "adamw")
+                st = torch.cuda.current_stream().cuda_stream
+                for co in tb["cohorts"]:       # tensors with the same number of updates behind them: one launch
+                    co[0] = t = co[0] + 1
+                    check(L.d3_adamw(tb["ptrs"].data_ptr(), tb["numel"].data_ptr(), tb["blocks"].data_ptr() + 8 * co[3], co[4],
+                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                     1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), st), "adamw")
         return loss

@@ -272,6 +272,16 @@ int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int
 int d3_prof_enable(int on);
 int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes, double *total_flops);
 
+/* Measurement / test switches.  The library reads its environment ONCE (csrc/tuning.hip: one
+ * table, one parse at first use); these entry points let tests and the A/B tools flip a switch at run time instead of
+ * mutating the environment.  name = the switch's environment name ("D3_WG3", "D3_BFS_NO_STAR", ...); unknown name ->
+ * D3_ERR_ARG.  No reference counterpart: the reference's only switch on this path is CUDA_LAUNCH_BLOCKING
+ * (scripts/train.py), read by the CUDA runtime. */
+int d3_tuning_set(const char *name, int value);
+int d3_tuning_get(const char *name, int *value);
+int d3_tuning_count(void);
+const char *d3_tuning_name(int i);
+
 /* MinkowskiBatchNorm (+ MinkowskiReLU) over the rows of an (M,C) feature matrix
  * (reference: model/pointgroup.py:65,72-73; model/common.py:36-40).  Training-mode batch statistics.
  * stats : mean (C) and biased var (C) in fp32 (deterministic fp64 two-stage reduction); when running_mean /

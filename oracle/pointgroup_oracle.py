@@ -35,13 +35,16 @@ class PointGroupOracle:
 
     # ------------------------------------------------------------------------------- network pieces
     def _bn_sparse(self, x, name, relu=True):
+        if not self.training:   # model.eval(): running statistics
+            return so.bn_relu(x, self.p[name + ".bn.weight"], self.p[name + ".bn.bias"], 1e-4, relu,
+                              running=(self.p[name + ".bn.running_mean"], self.p[name + ".bn.running_var"]), training=False)
         return so.bn_relu(x, self.p[name + ".bn.weight"], self.p[name + ".bn.bias"], 1e-4, relu,
                           training=True)  # batch statistics (training mode), running buffers untouched
 
     def _unet(self, x, cm, planes, prefix):
         params = {k[len(prefix) + 1:]: v for k, v in self.p.items() if k.startswith(prefix + ".")}
         return so.OracleUNet(params, planes, block_reps=self.cfg.model.block_reps if prefix == "backbone" else 2,
-                             prefix="1" if prefix == "backbone" else "0").forward(x, cm)
+                             prefix="1" if prefix == "backbone" else "0", training=self.training).forward(x, cm)
 
     def backbone(self, voxel_feats, voxel_coords):
         cm = so.OracleCoords(voxel_coords)
@@ -57,7 +60,11 @@ class PointGroupOracle:
     def offset_net(self, x):
         p = self.p
         h = F.linear(x, p["offset_net.0.weight"], p["offset_net.0.bias"])
-        h = F.batch_norm(h, None, None, p["offset_net.1.weight"], p["offset_net.1.bias"], True, 0.1, 1e-4)
+        if self.training:
+            h = F.batch_norm(h, None, None, p["offset_net.1.weight"], p["offset_net.1.bias"], True, 0.1, 1e-4)
+        else:
+            h = F.batch_norm(h, p["offset_net.1.running_mean"], p["offset_net.1.running_var"], p["offset_net.1.weight"],
+                             p["offset_net.1.bias"], False, 0.1, 1e-4)
         return F.linear(torch.relu(h), p["offset_net.3.weight"], p["offset_net.3.bias"])
 
     # ---------------------------------------------------------------- reference :125-178

@@ -174,8 +174,9 @@ class OracleUNet(torch.nn.Module):
     (reference: model/pointgroup.py:69-74, model/common.py:22-53,73-118).  Parameters are created by the
     caller (shared with the HIP model) as a flat name->tensor dict with the reference's state-dict names."""
 
-    def __init__(self, params, nPlanes, block_reps=2, eps=1e-4, prefix="1"):
+    def __init__(self, params, nPlanes, block_reps=2, eps=1e-4, prefix="1", training=True):
         super().__init__()
+        self.bn_training = training     # False: running statistics (model.eval() of the reference's MinkowskiBatchNorm)
         self.p = params
         self.nPlanes = list(nPlanes)
         self.reps = block_reps
@@ -183,6 +184,9 @@ class OracleUNet(torch.nn.Module):
         self.prefix = prefix
 
     def _bn(self, x, name, relu=True):
+        if not self.bn_training:
+            return bn_relu(x, self.p[name + ".bn.weight"], self.p[name + ".bn.bias"], self.eps, relu,
+                           running=(self.p[name + ".bn.running_mean"], self.p[name + ".bn.running_var"]), training=False)
         return bn_relu(x, self.p[name + ".bn.weight"], self.p[name + ".bn.bias"], self.eps, relu)
 
     def _res(self, x, name, cm, ts, cin, cout):

@@ -217,6 +217,59 @@ def test_early_bucket_starts_inside_backward_and_keeps_the_collective_order():
     assert r0[3]["early"] and not r1[3]["early"]               # rank 1 launched it late; no hang, same averages
 
 
+def _stale_early_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
+    torch.manual_seed(rank)
+    det = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 7))
+    head = torch.nn.Sequential(torch.nn.Linear(7, 6), torch.nn.Linear(6, 3))
+    net = torch.nn.ModuleList([det, head])
+    broadcast_module(net)
+    ex = _FakeExecutor(det[1].parameters())
+    sync = BucketGradAllReduce(net.parameters(), _Owner(ex), early=list(head.parameters()))
+    out = {}
+    # step 0: layout check (late path, always fine).  step 1: gradient accumulation -- two backward() calls before one
+    # sync: the bucket is packed inside the first, the second adds to the head gradients afterwards.  step 2: a head
+    # parameter is ALSO used below the boundary (inside the "detector"), so its gradient completes after the pack.
+    for step in range(3):
+        for p in net.parameters():
+            p.grad = None
+        ex.fresh_grads = True
+        torch.manual_seed(1000 * step + rank)
+        x = torch.randn(16, 5)
+        if step == 2:
+            h = det[0](x) * head[0].bias.sum()            # a head parameter inside the detector part of the graph
+            f, = sync.boundary(det[1](h))
+            head(f).pow(2).sum().backward()
+        else:
+            for _ in range(2 if step == 1 else 1):
+                f, = sync.boundary(det(x))
+                head(f).pow(2).sum().backward()
+        try:
+            sync()
+            out[step] = "ok"
+        except RuntimeError as e:
+            out[step] = str(e)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_bucket_refuses_gradients_that_change_after_it_was_packed():
+    """the early launch is gated on evidence -- post-accumulate hooks + version counters -- and fails
+    loudly on every rank instead of installing a stale average"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_stale_early_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in (ret[0], ret[1]):
+        assert r[0] == "ok"
+        assert "changed after the bucket was packed" in r[1] and "D3_EARLY_ALLREDUCE=0" in r[1]
+        assert "changed after the bucket was packed" in r[2]
+
+
 def _logged_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

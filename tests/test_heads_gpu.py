@@ -274,6 +274,63 @@ def test_fused_adamw_follows_load_state_dict(dev):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
 
 
+def test_fused_adamw_per_parameter_step_counts_and_checkpoint_round_trip(dev):
+    """torch.optim.AdamW bias-corrects PER PARAMETER.  A tensor that starts receiving gradients late (ScoreNet /
+    score_linear once `epoch > prepare_epochs`, model/pointgroup.py:332) must start at t = 1: its first updates are ~lr in
+    magnitude, not ~lr/3.  And the fused optimizer's state_dict loads into torch.optim.AdamW (and back)."""
+    from d3net_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+    shapes = [(40, 9), (4100,), (7,), (3, 5)]
+    late = {1, 3}                                              # these tensors get their first gradient at step 4
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedAdamW(pa, lr=3e-3, weight_decay=0.02), torch.optim.AdamW(pb, lr=3e-3, weight_decay=0.02)
+
+    def grads(it):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i in late and it < 4:
+                a.grad = None; b.grad = None
+            else:
+                g = torch.randn_like(a); a.grad = g.clone(); b.grad = g.clone()
+
+    for it in range(1, 8):
+        grads(it)
+        before = [p.detach().clone() for p in pa]
+        oa.step(); ob.step()
+        if it == 4:                                            # first update of a late tensor: |delta| ~ lr (bias correction at t = 1)
+            d = (pa[1].detach() - before[1] * (1 - 3e-3 * 0.02)).abs()
+            assert 0.9 * 3e-3 < float(d.median()) < 1.1 * 3e-3, float(d.median())
+    for a, b in zip(pa, pb):
+        assert rel(a.detach(), b.detach()) < 1e-6
+        assert rel(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6
+    sd = oa.state_dict()
+    steps = [float(sd["state"][i]["step"]) for i in range(len(shapes))]
+    assert steps == [7.0, 4.0, 7.0, 4.0], steps
+    # fused -> torch.optim.AdamW -> two more steps on both -> still the same
+    import copy
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oc = torch.optim.AdamW(pc, lr=3e-3, weight_decay=0.02)
+    oc.load_state_dict(copy.deepcopy(sd))
+    for it in range(8, 10):
+        for a, c in zip(pa, pc):
+            g = torch.randn_like(a); a.grad = g.clone(); c.grad = g.clone()
+        oa.step(); oc.step()
+    for a, c in zip(pa, pc):
+        assert rel(a.detach(), c.detach()) < 1e-6
+    # torch -> fused
+    od = FusedAdamW(pa, lr=3e-3, weight_decay=0.02)
+    with torch.no_grad():
+        for a, c in zip(pa, pc):
+            a.copy_(c)
+    od.load_state_dict(copy.deepcopy(oc.state_dict()))
+    for a, c in zip(pa, pc):
+        g = torch.randn_like(a); a.grad = g.clone(); c.grad = g.clone()
+    od.step(); oc.step()
+    for a, c in zip(pa, pc):
+        assert rel(a.detach(), c.detach()) < 1e-6
+    assert [float(v["step"]) for v in od.state_dict()["state"].values()] == [10.0, 7.0, 10.0, 7.0]
+
+
 def test_orientation_loss_one_launch_matches_library_form_and_reference(dev):
     """d3_orientation_loss (csrc/heads.hip) against the library-op form of compute_node_orientation_loss and the reference's own
     value (tests/golden/speaker_golden.npz ori/*, lib/captioning/loss_helper.py:244-307): loss, accuracy, gradient of the

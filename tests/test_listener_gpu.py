@@ -135,16 +135,13 @@ def test_attention_mfma_form_equals_scalar_form(dev):
             mask[:, 0] = 1
         g = torch.randn(B, nq, h * dv, device=dev)
         res = []
+        from d3net_amd import _lib
         for scalar in (False, True):
-            if scalar:
-                os.environ["D3_ATTN_SCALAR"] = "1"
-            try:
+            with _lib.tuning(D3_ATTN_SCALAR=int(scalar)):
                 qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
                 out = AttentionCoreFunction.apply(qq, kk, vv, bias, mask, h, div)
                 out.backward(g)
                 torch.cuda.synchronize()
                 res.append((out.detach(), qq.grad, kk.grad, vv.grad))
-            finally:
-                os.environ.pop("D3_ATTN_SCALAR", None)
         for a, b in zip(*res):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * (1 + float(b.abs().max()))), float((a - b).abs().max())

@@ -1,0 +1,224 @@
+"""North-star metric parity that can fail: mAP@0.5 AND CIDEr@0.5IoU of a TRAINED detector + speaker on HELD-OUT scenes,
+HIP bf16 path (what bench.py times) vs the fp32 CPU oracle on the same weights and the same scenes.
+
+Reference path being mirrored: `PipelineNet.validation_step / validation_epoch_end` (model/pipeline.py:457-700) ->
+`eval_caption_step / eval_caption_epoch` (lib/captioning/eval_helper.py:102-307) -> CIDEr (lib/capeval/cider/cider_scorer.py:11-193);
+detection: `parse_predictions` + `APCalculator` (scripts/eval.py:128-166, lib/det/ap_helper.py:24-249).
+
+Set-up (no dataset is available offline; SURVEY.md section 7 "metric parity without data"):
+  * synthetic rooms with 6 hollow boxes of random class (6 object classes) whose point features carry the class NOISILY,
+    so the trained semantic / offset heads make mistakes -- the operating point is not saturated;
+  * every object has reference captions that are a function of what the model can see: its class, its size bucket and
+    the class of its nearest neighbour ("the <class> is <size> next to the <class>") -- learnable, so CIDEr is well above 0;
+  * the 7-level backbone + ScoreNet + relation graph + top-down captioner are trained jointly (mode 1, cross-entropy) with
+    the bf16 MFMA executor for a few hundred AdamW steps on the training scenes;
+  * evaluation in `eval()` (running BatchNorm statistics, per-proposal greedy decode) on scenes never trained on:
+    HIP = the product's `validation_step` / `validation_epoch_end` + the device evaluator;
+    oracle = PointGroupOracle(training=False) -> speaker_oracle.graph_module -> speaker_oracle.forward_scene_batch, scored by
+    the same (golden-pinned, host-side) metric code.
+Bound (BASELINE.json north_star): |metric_hip - metric_oracle| <= 0.5 % of the oracle's, for mAP@0.5 and CIDEr@0.5IoU,
+with the oracle's mAP@0.5 required inside (0.3, 0.95) and its CIDEr@0.5IoU > 0.2 so that equality is not 0 == 0 or 1 == 1.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+OBJ_CLASSES = [2, 3, 4, 5, 6, 7]                      # semantic ids of the six object classes (0 wall, 1 floor)
+CLS_WORDS = ["chair", "table", "sofa", "bed", "shelf", "desk"]
+SIZE_WORDS = ["small", "large"]
+FILLER = ["the", "is", "next", "to", "a", "there", "near"]
+WORDS = ["pad_", "unk", "sos", "eos"] + CLS_WORDS + SIZE_WORDS + FILLER
+DIMS = (56, 44, 24)
+SGN = np.array([[1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1], [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1]], np.float32)
+
+
+def make_vocab():
+    return {"word2idx": {w: i for i, w in enumerate(WORDS)}, "idx2word": {str(i): w for i, w in enumerate(WORDS)},
+            "special_tokens": {"bos_token": "sos", "eos_token": "eos", "unk_token": "unk", "pad_token": "pad_"}}
+
+
+def make_scene(seed, sigma):
+    """one room; per-box random class; noisy class evidence in the first 20 feature channels"""
+    from d3net_amd import synthetic as S
+    rng = np.random.default_rng(1000 + seed)
+    occ, sem, inst, boxes = S.occupancy_grid(DIMS, 6, (7, 15), (5, 13), seed=seed)
+    cls = rng.choice(OBJ_CLASSES, size=len(boxes))
+    for i in range(len(boxes)):
+        sem[inst == i] = cls[i]
+    sc = S.scene_from_grid(occ, sem, inst, seed=seed + 1, feat_seed=seed + 2)
+    onehot = np.eye(20, dtype=np.float32)[np.clip(sc["sem_labels"], 0, 19)]
+    sc["feats"][:, :20] = onehot + sigma * sc["feats"][:, :20]
+    sc["box_cls"] = cls
+    return sc
+
+
+def captions_of(batch_host, b):
+    """reference captions of scene b's GT objects: {object slot: [token lists]} from class / size bucket / nearest neighbour"""
+    centers, sizes = batch_host["center_label"][b].numpy(), batch_host["size_label"][b].numpy()
+    mask, cls = batch_host["box_label_mask"][b].numpy() > 0, batch_host["sem_cls_label"][b].numpy()
+    ids = np.nonzero(mask)[0]
+    out = {}
+    for o in ids:
+        others = [j for j in ids if j != o]
+        nb = min(others, key=lambda j: float(np.abs(centers[j] - centers[o]).sum())) if others else o
+        cw = CLS_WORDS[OBJ_CLASSES.index(int(cls[o]))] if int(cls[o]) in OBJ_CLASSES else "unk"
+        nw = CLS_WORDS[OBJ_CLASSES.index(int(cls[nb]))] if int(cls[nb]) in OBJ_CLASSES else "unk"
+        sw = SIZE_WORDS[int(float(np.prod(sizes[o])) > 0.2 * 0.2 * 0.16)]
+        out[int(o)] = [["the", cw, "is", sw, "next", "to", "the", nw], ["there", "is", "a", sw, cw, "near", "the", nw]]
+    return out
+
+
+def make_lang_batch(scenes, dev, chunk, seed, scene_ids):
+    """device batch of `scenes` with structured captions (S.add_language picks the referred objects and fills every other key)"""
+    from d3net_amd import synthetic as S
+    V = len(WORDS)
+    batch = S.add_language(S.make_batch(scenes, dev), dev, chunk=chunk, vocab=V, seed=seed)
+    host = {k: batch[k].cpu() for k in ("center_label", "size_label", "box_label_mask", "sem_cls_label", "ref_box_label")}
+    w2i = {w: i for i, w in enumerate(WORDS)}
+    rng = np.random.default_rng(seed + 77)
+    B = len(scenes)
+    ids = np.zeros((B, chunk, batch["lang_ids"].shape[2]), np.int64)
+    lens = np.zeros((B, chunk), np.int64)
+    raw = []
+    for b in range(B):
+        caps = captions_of(host, b)
+        for o, refs in caps.items():
+            for r in refs:
+                raw.append({"scene_id": scene_ids[b], "object_id": str(o), "token": r})
+        for c in range(chunk):
+            o = int(host["ref_box_label"][b, c].argmax())
+            toks = caps[o][int(rng.integers(0, 2))] if o in caps else ["unk"]
+            row = [w2i["sos"]] + [w2i[t] for t in toks] + [w2i["eos"]]
+            ids[b, c, :len(row)] = row
+            lens[b, c] = len(row)
+    batch["lang_ids"] = torch.from_numpy(ids).to(dev)
+    batch["lang_len"] = torch.from_numpy(lens).to(dev)
+    batch["spk_lang_len"] = batch["lang_len"]
+    batch["scene_id"] = list(scene_ids)
+    return batch, raw
+
+
+def _gt_keys(batch):
+    c, s = batch["center_label"].cpu().numpy(), batch["size_label"].cpu().numpy()
+    cls = batch["sem_cls_label"].cpu().numpy() - 2
+    cls[cls < 0] = 17
+    return dict(gt_bbox=torch.from_numpy(c[:, :, None] + SGN[None, None] * s[:, :, None] / 2),
+                gt_bbox_label=batch["box_label_mask"].cpu(), sem_cls_label=torch.from_numpy(cls))
+
+
+def run_parity(dev, sigma=1.0, steps=400, n_train=16, n_val=16, chunk=4, lr=2e-3, seed=0, exact_too=True, verbose=True):
+    """train on the device, evaluate held-out scenes with the HIP path(s) and the CPU oracle -> dict of metrics"""
+    from d3net_amd import synthetic as S, minkowski as ME, evaluator as ev
+    from d3net_amd.caption_eval import eval_caption_step, eval_caption_epoch
+    from d3net_amd.config import default_conf
+    from d3net_amd.optim import FusedAdamW
+    from d3net_amd.pipeline import PipelineNet
+    from oracle import speaker_oracle as spo
+    from oracle.pointgroup_oracle import PointGroupOracle
+
+    V = len(WORDS)
+    cfg = default_conf("pointgroup_captioning.yaml", overrides={"data": {"num_des_per_scene": chunk, "batch_size": 4}})
+    assert len(cfg.model.blocks) == 7, "the shipped 7-level backbone"
+    vocab = make_vocab()
+    glove = np.random.default_rng(3).standard_normal((V, 300)).astype(np.float32)
+    train_scenes = [make_scene(100 + i, sigma) for i in range(n_train)]
+    val_scenes = [make_scene(500 + i, sigma) for i in range(n_val)]
+    val_ids = ["scene%04d_00" % (900 + i) for i in range(n_val)]
+    val_batches, raw_val = [], []
+    for i in range(0, n_val, 4):
+        b, raw = make_lang_batch(val_scenes[i:i + 4], dev, chunk, seed=50 + i, scene_ids=val_ids[i:i + 4])
+        b["cluster_rand"] = torch.rand(2, 3, generator=torch.Generator().manual_seed(i))
+        b["slot_perms"] = [torch.randperm(cfg.model.max_num_proposal, generator=torch.Generator().manual_seed(10 * i + j)) for j in range(4)]
+        val_batches.append(b); raw_val += raw
+    ds = types.SimpleNamespace(vocabulary=vocab, glove=glove, raw_data=raw_val, chunked_data=None, organized=None)
+    torch.manual_seed(seed)
+    net = PipelineNet(cfg, {"train": ds, "val": ds}).to(dev).train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = FusedAdamW(params, lr=lr, weight_decay=1e-4)
+    opt.register_step_pre_hook(lambda *a: net.detector.drop_stale_grads())
+    train_batches = [make_lang_batch(train_scenes[i:i + 4], dev, chunk, seed=7 + i, scene_ids=["scene%04d_00" % (i + j) for j in range(4)])[0]
+                     for i in range(0, n_train, 4)]
+    for it in range(steps):
+        net.zero_grad(set_to_none=True)
+        loss, d = net.training_step(dict(train_batches[it % len(train_batches)]))
+        loss.backward()
+        opt.step()
+        if verbose and (it % 100 == 0 or it == steps - 1):
+            print("step %d: loss %.3f (detector %.3f, caption %.3f, cap_acc %.3f)" % (it, float(loss), float(d["total_loss"][0]),
+                                                                                        float(d["cap_loss"]), float(d["cap_acc"])))
+    torch.cuda.synchronize()
+    net.eval()
+    res = {}
+
+    # ---- HIP: the product's validation hooks + the evaluator
+    def hip_eval(exact):
+        calc = ev.APCalculator(0.5)
+        outs, nprop = [], 0
+        ME.set_exact(exact)
+        try:
+            for b in val_batches:
+                outs.append(net.validation_step(dict(b), 0))
+                with torch.no_grad():
+                    d = net.detector.feed(dict(b), 0)
+                d.update(_gt_keys(b))
+                calc.step(ev.parse_predictions(d, device_nms=False), ev.parse_groundtruths(d))
+                nprop += int(d["proposal_batch_mask"].sum())
+        finally:
+            ME.set_exact(False)
+        log = net.validation_epoch_end(outs)
+        cands = {}
+        for o in outs:
+            cands.update(o)
+        return dict(mAP=calc.compute_metrics()["mAP"], cider=float(log["cider"]), bleu4=float(log["bleu-4"]), proposals=nprop, cands=cands)
+
+    res["bf16"] = hip_eval(False)
+    if exact_too:
+        res["exact"] = hip_eval(True)
+
+    # ---- oracle: fp32 on the host, eval-mode BatchNorm, per-proposal greedy decode
+    det_sd = net.detector.state_dict()
+    spk = {k: v.detach().cpu().clone() for k, v in net.speaker.state_dict().items()}
+    gp = {k[len("graph."):]: v for k, v in spk.items() if k.startswith("graph.")}
+    cp = {k[len("caption."):]: v for k, v in spk.items() if k.startswith("caption.")}
+    orc = PointGroupOracle(cfg, det_sd, training=False)
+    calc = ev.APCalculator(0.5)
+    cands, nprop = {}, 0
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        for b in val_batches:
+            host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()}
+            od = orc.feed(host, 0, rand=host["cluster_rand"], perms=host["slot_perms"])
+            od.update(_gt_keys(host))
+            calc.step(ev.parse_predictions(od), ev.parse_groundtruths(od))
+            nprop += int(od["proposal_batch_mask"].sum())
+            od.update(spo.graph_module(gp, od, cfg.model.num_graph_steps, cfg.model.num_locals))
+            out = spo.forward_scene_batch(cp, od, cfg, cfg.model.max_num_proposal, cfg.model.num_locals, vocab["word2idx"]["sos"])
+            od["lang_cap"] = out["lang_cap"]
+            od["gt_bbox"] = host["gt_bbox"]          # (the language batch's gt_bbox: same corners, lib/dataset/pipeline.py:300)
+            cands.update(eval_caption_step(od, vocab))
+    bleu, cider, rouge, _ = eval_caption_epoch(cands, raw_val, max_len=cfg.eval.max_des_len + 2, min_iou=cfg.eval.min_iou_threshold)
+    res["oracle"] = dict(mAP=calc.compute_metrics()["mAP"], cider=float(cider[0]), bleu4=float(bleu[0][3]), proposals=nprop, cands=cands)
+    for k in ("bf16", "exact"):
+        if k in res:
+            same = sum(1 for key, v in res[k]["cands"].items() if key in cands and v["caption"] == cands[key]["caption"])
+            res[k]["same_captions"] = (same, len(cands))
+    if verbose:
+        for k, v in res.items():
+            print("%-6s mAP@0.5 %.4f  CIDEr@0.5IoU %.4f  BLEU-4 %.4f  proposals %d  %s" % (k, v["mAP"], v["cider"], v["bleu4"], v["proposals"],
+                                                                                           v.get("same_captions", "")))
+    return res
+
+
+def test_heldout_map_and_cider_hip_bf16_within_half_percent_of_fp32_oracle(dev):
+    res = run_parity(dev)
+    o, h = res["oracle"], res["bf16"]
+    assert 0.3 < o["mAP"] < 0.95, ("operating point saturated or degenerate", o["mAP"])
+    assert o["cider"] > 0.2, o["cider"]
+    for name in ("bf16", "exact"):
+        h = res[name]
+        assert abs(h["mAP"] - o["mAP"]) <= 0.005 * o["mAP"], (name, "mAP@0.5", h["mAP"], o["mAP"])
+        assert abs(h["cider"] - o["cider"]) <= 0.005 * o["cider"], (name, "CIDEr@0.5IoU", h["cider"], o["cider"])

@@ -238,8 +238,8 @@ def test_bfs_cluster_collapsed_instances_star_shortcut(dev, star, monkeypatch):
     the late members are reached by nobody and drop out as singletons -- the reference's behaviour).  Both code paths
     (D3_BFS_NO_STAR forces the level loop) must equal the sequential oracle, in shuffled point order."""
     from d3net_amd import pointgroup_ops as P
-    if not star:
-        monkeypatch.setenv("D3_BFS_NO_STAR", "1")
+    from d3net_amd import _lib
+    assert _lib.lib().d3_tuning_set(b"D3_BFS_NO_STAR", 0 if star else 1) == 0     # (library switches: csrc/tuning.hip)
     rng = np.random.default_rng(84)
     sizes = [60, 999, 1000, 1001, 1500, 40, 300]
     centres = rng.random((len(sizes), 3)).astype(np.float32) * 3
@@ -256,9 +256,12 @@ def test_bfs_cluster_collapsed_instances_star_shortcut(dev, star, monkeypatch):
     idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
     rci, rco = o.bfs_cluster(sem, idx, sl, 50)
     assert sorted(np.diff(rco).tolist()) == [60, 300, 999, 1000, 1000, 1000, 1200]
-    for asc in (False, True):
-        ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, asc)
-        assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), (star, asc)
+    try:
+        for asc in (False, True):
+            ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, asc)
+            assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), (star, asc)
+    finally:
+        _lib.lib().d3_tuning_set(b"D3_BFS_NO_STAR", 0)
 
 
 @pytest.mark.parametrize("order", ["forward", "reverse", "shuffled"])

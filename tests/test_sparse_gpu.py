@@ -437,11 +437,9 @@ def test_wgrad3_strided_operands_ragged_rows_and_absent_neighbours(dev, kind, ci
 
     assert xv.data_ptr() % 16 == 0 and dyv.data_ptr() % 8 == 0
     got = run(xv, cin + 24, dyv, cout + 16, fl)                       # strided views, third-generation kernel
-    os.environ["D3_WG3"] = "0"
-    try:
+    from d3net_amd import _lib
+    with _lib.tuning(D3_WG3=0):
         ref = run(xv.contiguous(), cin, dyv.contiguous(), cout, fl)    # dense copies, second-generation kernel
-    finally:
-        os.environ.pop("D3_WG3")
     assert torch.isfinite(got).all()
     assert relerr(got, ref) < 2e-6, relerr(got, ref)
     if dybf:                                                          # the same bf16 values handed over as fp32: identical result

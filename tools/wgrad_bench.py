@@ -12,7 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from d3net_amd import minkowski as ME, synthetic as S  # noqa: E402
 
-MODES = (("gen3", {"D3_WG3": "1", "D3_WG2_TR": "1"}), ("gen2+tr", {"D3_WG3": "0", "D3_WG2_TR": "1"}), ("gen2", {"D3_WG3": "0", "D3_WG2_TR": "0"}))
+MODES = (("gen3", {"D3_WG3": 1, "D3_WG2_TR": 1}), ("gen2+tr", {"D3_WG3": 0, "D3_WG2_TR": 1}), ("gen2", {"D3_WG3": 0, "D3_WG2_TR": 0}))
+
+
+def set_mode(env):
+    """library switches are flipped through the C ABI (csrc/tuning.hip parses the environment only once)"""
+    from d3net_amd import _lib
+    for k, v in env.items():
+        assert _lib.lib().d3_tuning_set(k.encode(), v) == 0
 
 
 def timeit(fn, iters):
@@ -60,11 +67,11 @@ def main():
             dy = torch.randn(Mout, Cout, device=dev)
             res, tms = {}, {}
             for mode, env in MODES:
-                os.environ.update(env)
+                set_mode(env)
                 w = lambda: ME._conv_wgrad(xb, tf, tb, dy, W, Mout, bfl, ME.D3_CONV_XBF16)
                 tms[mode] = timeit(w, iters)
                 res[mode] = w()
-            os.environ.update(MODES[0][1])
+            set_mode(MODES[0][1])
             dyb = dy.to(torch.bfloat16)
             wb = lambda: ME._conv_wgrad(xb, tf, tb, dyb, W, Mout, bfl, ME.D3_CONV_XBF16 | ME.D3_CONV_DYBF16)
             t_b = timeit(wb, iters)
