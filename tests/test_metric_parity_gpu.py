@@ -41,6 +41,9 @@ def make_vocab():
             "special_tokens": {"bos_token": "sos", "eos_token": "eos", "unk_token": "unk", "pad_token": "pad_"}}
 
 
+AMP = 3.0       # amplitude of the one-hot class evidence
+
+
 def make_scene(seed, sigma):
     """one room; per-box random class; noisy class evidence in the first 20 feature channels"""
     from d3net_amd import synthetic as S
@@ -51,7 +54,8 @@ def make_scene(seed, sigma):
         sem[inst == i] = cls[i]
     sc = S.scene_from_grid(occ, sem, inst, seed=seed + 1, feat_seed=seed + 2)
     onehot = np.eye(20, dtype=np.float32)[np.clip(sc["sem_labels"], 0, 19)]
-    sc["feats"][:, :20] = onehot + sigma * sc["feats"][:, :20]
+    sc["feats"][:, :20] = AMP * onehot + sigma * sc["feats"][:, :20]
+    sc["feats"][:, 20:] = 0.0        # (the remaining channels carry nothing: fixed random values there are only something to memorise)
     sc["box_cls"] = cls
     return sc
 
@@ -110,7 +114,7 @@ def _gt_keys(batch):
                 gt_bbox_label=batch["box_label_mask"].cpu(), sem_cls_label=torch.from_numpy(cls))
 
 
-def run_parity(dev, sigma=1.0, steps=400, n_train=16, n_val=16, chunk=4, lr=2e-3, seed=0, exact_too=True, verbose=True):
+def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3, seed=0, exact_too=True, verbose=True, with_oracle=True):
     """train on the device, evaluate held-out scenes with the HIP path(s) and the CPU oracle -> dict of metrics"""
     from d3net_amd import synthetic as S, minkowski as ME, evaluator as ev
     from d3net_amd.caption_eval import eval_caption_step, eval_caption_epoch
@@ -142,15 +146,52 @@ def run_parity(dev, sigma=1.0, steps=400, n_train=16, n_val=16, chunk=4, lr=2e-3
     opt.register_step_pre_hook(lambda *a: net.detector.drop_stale_grads())
     train_batches = [make_lang_batch(train_scenes[i:i + 4], dev, chunk, seed=7 + i, scene_ids=["scene%04d_00" % (i + j) for j in range(4)])[0]
                      for i in range(0, n_train, 4)]
+    # the class evidence of the TRAINING scenes is re-drawn every step (one-hot + sigma * N(0,1)): the detector has to learn to
+    # denoise through its receptive field instead of memorising 16 fixed noise patterns; held-out scenes keep theirs fixed
+    clean = [torch.nn.functional.one_hot(b["sem_labels"].clamp(0, 19), 20).float() for b in train_batches]
+    gen = torch.Generator(device=dev).manual_seed(seed + 1)
     for it in range(steps):
         net.zero_grad(set_to_none=True)
-        loss, d = net.training_step(dict(train_batches[it % len(train_batches)]))
+        tb = dict(train_batches[it % len(train_batches)])
+        f = tb["feats"].clone()
+        f[:, :20] = AMP * clean[it % len(train_batches)] + sigma * torch.randn(f.shape[0], 20, device=dev, generator=gen)
+        tb["feats"] = f
+        if it == steps - 150:        # settle: the last steps at a quarter of the learning rate
+            for gr in opt.param_groups:
+                gr["lr"] = lr / 4
+        loss, d = net.training_step(tb)
         loss.backward()
         opt.step()
         if verbose and (it % 100 == 0 or it == steps - 1):
-            print("step %d: loss %.3f (detector %.3f, caption %.3f, cap_acc %.3f)" % (it, float(loss), float(d["total_loss"][0]),
-                                                                                        float(d["cap_loss"]), float(d["cap_acc"])))
+            lab = tb["sem_labels"]
+            om = lab > 1
+            acc = float((d["semantic_scores"][0].argmax(1)[om] == lab[om]).float().mean())
+            print("step %d: loss %.3f (detector %.3f, semantic %.3f, caption %.3f, cap_acc %.3f, object-point acc %.3f)" %
+                  (it, float(loss.detach()), float(d["total_loss"][0].detach()), float(d["semantic_loss"][0].detach()), float(d["cap_loss"].detach()),
+                   float(d["cap_acc"]), acc))
     torch.cuda.synchronize()
+    if verbose:      # diagnostics: how well does the detector do on the held-out scenes, train-mode vs eval-mode BatchNorm
+        saved = {k: v.clone() for k, v in net.named_buffers()}       # (a train-mode forward updates the running statistics)
+        for mode in ("train", "eval"):
+            net.train(mode == "train")
+            with torch.no_grad():
+                for k, v in net.named_buffers():
+                    v.copy_(saved[k])
+            acc, nobj, nraw, nkeep, calc = 0.0, 0, 0, 0, ev.APCalculator(0.5)
+            with torch.no_grad():
+                for b in val_batches:
+                    d = net.detector.feed(dict(b), 0)
+                    lab = b["sem_labels"]
+                    m = lab > 1
+                    acc += float((d["semantic_scores"].argmax(1)[m] == lab[m]).float().sum()); nobj += int(m.sum())
+                    nraw += int(d["num_raw_proposals"]); nkeep += int(d["proposal_batch_mask"].sum())
+                    d.update(_gt_keys(b))
+                    calc.step(ev.parse_predictions(d, device_nms=False), ev.parse_groundtruths(d))
+            print("held-out, %s-mode BatchNorm: object-point accuracy %.3f, raw clusters %d, proposals %d, mAP@0.5 %.4f"
+                  % (mode, acc / max(nobj, 1), nraw, nkeep, calc.compute_metrics()["mAP"]))
+        with torch.no_grad():
+            for k, v in net.named_buffers():
+                v.copy_(saved[k])
     net.eval()
     res = {}
 
@@ -179,7 +220,10 @@ def run_parity(dev, sigma=1.0, steps=400, n_train=16, n_val=16, chunk=4, lr=2e-3
     if exact_too:
         res["exact"] = hip_eval(True)
 
+    if not with_oracle:
+        return res
     # ---- oracle: fp32 on the host, eval-mode BatchNorm, per-proposal greedy decode
+    spo.TIE_RULE = "index"      # ties of the neighbour top-k: lower slot first, the rule csrc/proposals.hip implements (see oracle/speaker_oracle.py)
     det_sd = net.detector.state_dict()
     spk = {k: v.detach().cpu().clone() for k, v in net.speaker.state_dict().items()}
     gp = {k[len("graph."):]: v for k, v in spk.items() if k.startswith("graph.")}
@@ -200,6 +244,7 @@ def run_parity(dev, sigma=1.0, steps=400, n_train=16, n_val=16, chunk=4, lr=2e-3
             od["lang_cap"] = out["lang_cap"]
             od["gt_bbox"] = host["gt_bbox"]          # (the language batch's gt_bbox: same corners, lib/dataset/pipeline.py:300)
             cands.update(eval_caption_step(od, vocab))
+    spo.TIE_RULE = "topk"
     bleu, cider, rouge, _ = eval_caption_epoch(cands, raw_val, max_len=cfg.eval.max_des_len + 2, min_iou=cfg.eval.min_iou_threshold)
     res["oracle"] = dict(mAP=calc.compute_metrics()["mAP"], cider=float(cider[0]), bleu4=float(bleu[0][3]), proposals=nprop, cands=cands)
     for k in ("bf16", "exact"):

@@ -138,7 +138,8 @@ def test_device_cider_reward_matches_reference_golden_and_host_scorer(dev):
     CL._CORPORA.clear()
     got_s = CL.compute_caption_reward(dict(dd), on(caps), *args)
     got_b = CL.compute_caption_reward(dict(dd), on(base), *args)
-    assert id(opt["organized_data"]) in CL._CORPORA and CL._CORPORA[id(opt["organized_data"])].ok, "device path not taken"
+    hit = [v for (oid, _dev), v in CL._CORPORA.items() if oid == id(opt["organized_data"])]
+    assert hit and hit[0][0] is opt["organized_data"] and hit[0][1].ok, "device path not taken"
     assert np.allclose(got_s.cpu().numpy(), g["reward/sampled"], rtol=1e-6, atol=1e-7)
     assert np.allclose(got_b.cpu().numpy(), g["reward/baseline"], rtol=1e-6, atol=1e-7)
 

@@ -75,6 +75,8 @@ def main():
             print("%-18s %8d %8.1f | %-28s | %9.1f %9.1f | %9.1f %9.1f | %.1e" %
                   ("L%d k3 %d->%d" % (lev, cin, cout), M, wp.numel() / 1024, " -> ".join(plans), res["nw4", "bf16"], res["nw16", "bf16"],
                    res["nw4", "fp32"], res["nw16", "fp32"], rel))
+        if lev < 2:
+            cm.down(ts)      # creates the next coordinate level
         ts *= 2
 
 
