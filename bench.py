@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- scenes/sec of D3Net's training step on MI355X (BASELINE.json metric).
 
-    python bench.py [--config speaker|detector|listener|joint] --gpus N --steps K --warmup W       (N=1 default)
+    python bench.py [--config speaker|detector|listener|joint] --gpus N --steps K --warmup W [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment bench.py starts its N ranks ITSELF (one child process group through
+torch.distributed.run, as the reference spawns its DDP ranks: scripts/train.py:265-268), decided before anything touches the
+GPU; rank 0's line is relayed and the children's return code is this process's.
 
 Default workload = the configuration BASELINE.json's metric is quoted on ("scenes/sec fwd+bwd (PointGroup+speaker)",
 configs[2]): `PipelineNet` mode 1 (reference step: model/pipeline.py:152-185) with conf/pointgroup_captioning.yaml --
@@ -45,17 +49,24 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the untimed exact-fp32 (reference precision) steps")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-teacher", action="store_true", help="cluster on the network's own predictions")
     ap.add_argument("--small", action="store_true", help="quarter-size scenes (debug)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the config's scenes per rank per step (4); strong: the GLOBAL batch is fixed at 8 scenes, 8/N per rank")
     return ap.parse_args()
 
 
-CPU_THREADS = 8   # torch-CPU sparse conv is fastest at ~8 threads (256 threads on the GPU box: 1000x slower)
+CPU_THREADS = 8            # torch-CPU sparse conv is fastest at ~8 threads (256 threads on the GPU box: 1000x slower)
+CPU_THREAD_SWEEP = (4, 8, 16)   # the sweep behind that "8", re-run with every bench line (the best one is `cpu_baseline.value`)
 
 
 # ------------------------------------------------------------------------------------------ workloads
-def make_scenes(config, rank, small=False):
-    """the synthetic scenes of one rank's step (numpy, host side)"""
+STRONG_GLOBAL_BATCH = 8
+
+
+def make_scenes(config, rank, small=False, scene_ids=None):
+    """the synthetic scenes of one rank's step (numpy, host side); scene_ids: global scene numbers (strong scaling)"""
     from d3net_amd import synthetic as S
     if config == "detector":
         if small:
@@ -64,10 +75,11 @@ def make_scenes(config, rank, small=False):
             occ, sem, inst, _ = S.occupancy_grid()
         return [S.scene_from_grid(occ, sem, inst, feat_seed=2 + rank)]   # same geometry, per-rank features
     scenes = []
-    for b in range(4):   # data.batch_size 4 (conf/pointgroup_captioning.yaml); 40-box variant of SURVEY.md 8(d)
+    ids = [4 * rank + b for b in range(4)] if scene_ids is None else scene_ids   # data.batch_size 4 (conf/pointgroup_captioning.yaml)
+    for g in ids:        # 40-box variant of SURVEY.md 8(d)
         dims, nb, side = ((100, 75, 50), 10, (6, 16)) if small else ((200, 150, 100), 40, (8, 30))
-        occ, sem, inst, _ = S.occupancy_grid(dims, nb, side, side, seed=4 * rank + b)
-        scenes.append(S.scene_from_grid(occ, sem, inst, seed=1 + b, feat_seed=2 + 4 * rank + b))
+        occ, sem, inst, _ = S.occupancy_grid(dims, nb, side, side, seed=g)
+        scenes.append(S.scene_from_grid(occ, sem, inst, seed=1 + g % 4, feat_seed=2 + g))
     return scenes
 
 
@@ -82,16 +94,84 @@ def make_dataset(n_scenes, chunk, joint):
     return {"train": ds}
 
 
-def cpu_baseline_child(config):
+def code_sha():
+    """content hash of what the PMC traffic figures depend on (bench.py + the HIP sources): profiles/pmc_traffic.json carries
+    the hash of the tree it was measured on, and the bench line says `traffic_stale` when that is not this tree"""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "d3net_amd", "csrc")
+    for f in [os.path.abspath(__file__)] + sorted(os.path.join(csrc, n) for n in os.listdir(csrc) if n.endswith((".hip", ".h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_info():
+    """CPU model, sockets, physical cores and hardware threads of this host (lscpu; /proc/cpuinfo as a fallback)"""
+    import subprocess
+    info = {"model": None, "sockets": None, "physical_cores": None, "threads": os.cpu_count()}
+    try:
+        kv = {}
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name")
+        info["sockets"] = int(kv.get("Socket(s)", 0)) or None
+        if info["sockets"] and kv.get("Core(s) per socket"):
+            info["physical_cores"] = info["sockets"] * int(kv["Core(s) per socket"])
+    except Exception:
+        pass
+    if info["model"] is None:
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    info["model"] = line.split(":", 1)[1].strip()
+                    break
+        except Exception:
+            pass
+    return info
+
+
+def compulsory_bytes(detector, batch):
+    """Compulsory HBM bytes of ONE step's two sparse U-Nets + input pooling by SURVEY.md 8(d)'s formulas (every feature row read
+    once and written once, weights once, one (in, out) int32 pair per kernel-map entry; bf16 storage e = 2; backward = 2x the
+    forward): per convolution `e*(Nin*Cin + Nout*Cout) + e*K*Cin*Cout + 8*P`; input pooling `4*N*C + 4*M*(mA+1) + 4*M*C`.
+    Row counts and kernel-map pair counts are those of the step's own coordinate pyramids (read once, outside the timed region)."""
+    from d3net_amd import netexec
+    total, detail = 0.0, {}
+    for name, ex in detector._execs.items():
+        if ex is None or ex.debug_last is None:
+            continue
+        rows, pairs3 = ex.debug_last[1], ex.debug_pairs
+        fwd = 0.0
+        for op in ex.b.ops:
+            if op[0] != netexec.OP_CONV:
+                continue
+            _, x, out, _res, _w, kind, mlevel, K, cin, _st = op[:10]
+            lin, lout = ex.b.tensors[x][0], ex.b.tensors[out][0]
+            cout = ex.b.tensors[out][1]
+            nin, nout = rows[lin], rows[lout]
+            P = pairs3[mlevel] if kind == netexec.MAP_K3 else (max(nin, nout) if kind in (netexec.MAP_DOWN, netexec.MAP_UP) else nout)
+            fwd += 2.0 * (nin * cin + nout * cout) + 2.0 * K * cin * cout + 8.0 * P
+        detail[name] = {"rows": list(rows), "forward_bytes": fwd}
+        total += 3.0 * fwd
+    N, C = batch["feats"].shape[0], batch["feats"].shape[1] + 3
+    M, mA1 = batch["v2p_map"].shape
+    pool = 4.0 * N * C + 4.0 * M * mA1 + 4.0 * M * C
+    detail["input_pooling_bytes"] = pool
+    return total + pool, detail
+
+
+def cpu_baseline_child(config, threads=0):
     """`bench.py --cpu-baseline-only`: the oracle (CPU restatement of the reference step) timed on this host, on a bounded
-    sample of the same workload.  Never touches the GPU.  Prints one JSON object."""
+    sample of the same workload: forward + loss + backward + AdamW step.  Never touches the GPU.  Prints one JSON object."""
     import numpy as np
     import torch
     from d3net_amd import synthetic as S
     from d3net_amd.config import default_conf
     from oracle import pg_oracle as pg
     from oracle.pointgroup_oracle import PointGroupOracle
-    cores = min(os.cpu_count() or 1, CPU_THREADS)
+    cores = min(os.cpu_count() or 1, threads or CPU_THREADS)
     torch.set_num_threads(cores)
     cfg = default_conf(CONF[config])
     torch.manual_seed(cfg.general.manual_seed)
@@ -114,6 +194,8 @@ def cpu_baseline_child(config):
         lang["lang_len"] = lang["spk_lang_len"]
     orc = PointGroupOracle(cfg, state)
     orc.teacher = True
+    leaves = [v for v in orc.p.values() if v.requires_grad] + ([v for v in spk.values() if v.requires_grad] if spk is not None else [])
+    opt = torch.optim.AdamW(leaves, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)   # (model/pipeline.py:738-757)
     t0 = time.time()
     d = orc.loss(orc.feed(cpu, 0))
     loss = d["total_loss"]
@@ -135,33 +217,75 @@ def cpu_baseline_child(config):
             loss = loss + F.cross_entropy(logits[good].reshape(-1, logits.shape[-1]), tgt[good].reshape(-1), ignore_index=0)
         what = "detector + relation graph + captioner (XE)"
     loss.backward()
+    opt.step()
     dt = time.time() - t0
     print(json.dumps({"value": 1.0 / dt, "unit": "scenes/sec", "cores": cores, "kind": "port",
-                      "sample": "1 scene (of the step's %d; %d points) x 1 step, forward+loss+backward, no optimizer: %s "
+                      "sample": "1 scene (of the step's %d; %d points) x 1 step, forward+loss+backward+AdamW: %s "
                                 "through oracle/ (torch-CPU gather-mm sparse conv and the reference's brute-force ball query on %d "
                                 "threads; BFS / segment ops single-threaded): %.1f s" % (1 if config == "detector" else 4,
                                                                                          cpu["locs"].shape[0], what, cores, dt)}), flush=True)
 
 
 def cpu_baseline(config, limit_s=420):
-    """run the baseline in a child process (bounded; it must never take the GPU number down with it)"""
+    """run the baseline in child processes (bounded; it must never take the GPU number down with it): one per thread count
+    of CPU_THREAD_SWEEP, the fastest is reported, all are listed; the host's CPU model / physical cores come from lscpu"""
     import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", config],
-                           capture_output=True, text=True, timeout=limit_s,
-                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(CPU_THREADS)))
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "error": "cpu baseline exceeded %d s" % limit_s}
+    best, sweep, err = None, [], None
+    t_start = time.time()
+    for th in [t for t in CPU_THREAD_SWEEP if t <= (os.cpu_count() or 1)] or [os.cpu_count() or 1]:
+        left = limit_s - (time.time() - t_start)
+        if left < 30:
+            break
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", config, "--cpu-threads", str(th)],
+                               capture_output=True, text=True, timeout=left,
+                               env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(th)))
+            line = next((l for l in reversed(r.stdout.strip().splitlines()) if l.startswith("{")), None)
+            if line is None:
+                err = (r.stderr or r.stdout)[-300:]
+                continue
+            res = json.loads(line)
+            sweep.append({"threads": th, "value": res["value"]})
+            if best is None or res["value"] > best["value"]:
+                best = res
+        except subprocess.TimeoutExpired:
+            err = "cpu baseline exceeded %d s" % limit_s
+            break
+    if best is None:
+        return {"value": None, "error": err}
+    best["thread_sweep"] = sweep
+    best["host"] = cpu_info()
+    return best
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as ONE child process group (torch.distributed.run,
+    rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Runs before this process imports torch.cuda / touches HIP, and
+    the ranks are children (never an exec of a process that initialised the GPU)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    env = dict(os.environ, D3_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (RCCL / dmabuf IPC on this pool)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+    if line is not None:
+        out = json.loads(line)
+        out.setdefault("config", {})["launched_by"] = "bench.py itself: %d child ranks via torch.distributed.run, rc %d" % (args.gpus, r.returncode)
+        print(json.dumps(out), flush=True)
+    else:
+        sys.stdout.write(r.stdout)
+    return r.returncode
 
 
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        return cpu_baseline_child(args.config)
+        return cpu_baseline_child(args.config, args.cpu_threads)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     import torch
     import torch.distributed as dist
 
@@ -187,7 +311,11 @@ def main():
     config = args.config
     cfg = default_conf(CONF[config])
     torch.manual_seed(cfg.general.manual_seed)
-    scenes = make_scenes(config, rank, args.small)
+    scene_ids = None
+    if args.scaling == "strong":     # the GLOBAL batch is fixed (8 scenes); rank r steps scenes r, r + W, ...
+        assert config != "detector" and STRONG_GLOBAL_BATCH % world == 0, "strong scaling: 8 scenes over 1 / 2 / 4 / 8 ranks (not --config detector)"
+        scene_ids = list(range(rank, STRONG_GLOBAL_BATCH, world))
+    scenes = make_scenes(config, rank, args.small, scene_ids)
     n_scenes = len(scenes)
     chunk = cfg.data.num_des_per_scene
     if config == "detector":
@@ -246,6 +374,18 @@ def main():
     torch.cuda.synchronize()
     # the interpreter's cyclic collector: a full (generation-2) pass every ~26 steps walks the whole module / tensor heap
     # (2-7 ms each, tools/step_jitter.py); freezing the long-lived objects after warm-up keeps those passes short
+    # compulsory bytes of a step from this batch's own coordinate pyramids: one extra untimed step that keeps
+    # the level row counts and counts the kernel-map pairs
+    for ex in detector._execs.values():
+        if ex is not None:
+            ex.debug_keep = True
+    step(); torch.cuda.synchronize()
+    comp_bytes, comp_detail = compulsory_bytes(detector, batch)
+    for ex in detector._execs.values():
+        if ex is not None:
+            ex.debug_keep, ex.debug_last = False, None
+    if config == "joint":
+        comp_bytes *= 2          # two detector passes per step
     import gc
     gc.collect()
     gc.freeze()
@@ -312,12 +452,15 @@ def main():
         achieved = (pd["bytes"] / max(pd["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM traffic per launch of the dominant kernel from the PMC counters (cannot be sampled from inside this
         # process): the committed rocprofv3 --pmc measurement of this same command (tools/gpu_round.sh)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             pmc = pmc.get(config, pmc)
             traffic = pmc[dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command; (2*FETCH+WRITE)*1024)"
+            measured_on = pmc.get("code_sha")
+            traffic_stale = measured_on != code_sha()      # measured on another state of bench.py / csrc: quoted, but flagged
+            traffic_src = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command; (2*FETCH+WRITE)*1024); "
+                           "measured on code %s, this is %s" % (measured_on, code_sha()))
         except Exception:
             pass
         workload = {
@@ -333,18 +476,22 @@ def main():
         out = {
             "metric": METRIC[config], "value": world * n_scenes * args.steps / elapsed,
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload + " (%d voxels, %d points, 134 ch per step)" % (n_voxels, n_points),
                        "scenes_per_gpu": n_scenes, "global_batch": world * n_scenes, "points": n_points, "voxels": n_voxels,
                        "raw_proposals": int(d.get("num_raw_proposals", 0)),
                        "proposals_per_scene": float(d["proposal_batch_mask"].sum() / n_scenes) if "proposal_batch_mask" in d else None,
                        "parallelism": "scene-parallel dp%d" % world,
+                       "world": {"size_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
+                                 "backend": dist.get_backend() if world > 1 else None,
+                                 "scaling": "weak: %d scenes per rank per step" % n_scenes if args.scaling == "weak" else
+                                            "strong: global batch fixed at %d scenes, %d per rank" % (STRONG_GLOBAL_BATCH, n_scenes)},
                        "precision": "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate; heads fp32",
                        "setup": "1 untimed dry-run step before the warm-up (workspace allocation, code-object loads)"},
             "final_loss": final_loss, "fp32_exact": fp32,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": pd["bytes"] / max(pd["launches"], 1),
                          "launches_per_step": pd["launches"] * PROF_STRIDE / args.steps, "avg_launch_us": avg_ms * 1e3,
                          "launches_sampled": pd["launches"],
@@ -356,6 +503,13 @@ def main():
                                        "achieved": (v["bytes"] / max(v["total_ms"], 1e-9)) / 1e6}
                                    for k, v in prof.items() if k != dom}},
         }
+        step_ms = 1e3 * elapsed / args.steps
+        out["step_roofline"] = {"bound": "hbm", "compulsory_bytes_per_step": comp_bytes, "achieved": comp_bytes / (step_ms * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": comp_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "what": "SURVEY.md 8(d) compulsory traffic of the step's two sparse U-Nets (forward + 2x backward, bf16 "
+                                        "storage, one int32 pair per kernel-map entry) + input pooling, over the whole step time "
+                                        "(clustering, heads, captioner and optimizer included in the time, not in the bytes)",
+                                "detail": comp_detail}
         if grad_sync is not None:
             out["config"]["grad_sync"] = {"collectives_per_step": 1 + len(detector.static_gradient_buckets()) + (1 if grad_sync.early else 0),
                                           "heads_bucket_floats": sum(p.numel() for p in grad_sync.early),
@@ -369,4 +523,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -149,6 +149,7 @@ class NativeUNet:
         self.fresh_grads = False     # set by the owner's zero_grad(): the next backward writes instead of accumulating
         self.debug_keep = False      # tests: keep the last forward's activation arena + level rows in `debug_last`
         self.debug_last = None
+        self.debug_pairs = None
 
     # ------------------------------------------------------------------ lazily created native state
     def _net(self):
@@ -281,6 +282,8 @@ class _NetFunction(Function):
         out = arena[out_off:out_off + M * Co * 4].view(torch.float32).view(M, Co)
         if net.debug_keep:
             net.debug_last = (arena, list(rows))
+            # kernel-3 pairs per level (entries of the dense neighbour table that exist): bench.py's compulsory-byte count
+            net.debug_pairs = [int((t >= 0).sum()) for t in keep if t.dim() == 2 and t.size(1) == 27]
         ctx.net, ctx.maps, ctx.arena, ctx.feats, ctx.grad_bytes = net, (k3, child, up, keep), arena, feats, grad_bytes
         ctx.rows = rows
         ctx.training = training

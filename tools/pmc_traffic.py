@@ -32,5 +32,14 @@ for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kerne
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_round.sh), bench.py --steps 2 "
                       "--warmup 1 (the bench default workload unless the file name says otherwise); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B "
                       "per 128-B request: MI355X_MICROARCH.md HBM section)"}
+# stamp: the state of bench.py + csrc this was measured on (bench.py prints traffic_stale when it differs)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    out["code_sha"] = bench.code_sha()
+except Exception as e:   # (never lose a measurement over the stamp)
+    out["code_sha"] = None
+    print("no code_sha: %r" % (e,), file=sys.stderr)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 2) for k, v in out.items()}))
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 2) for k, v in out.items() if isinstance(v, dict)}))
