@@ -36,7 +36,10 @@ struct BqWs {
     int nchunks, nsuper;
 };
 
-static bool bq_carve(void *ws, size_t ws_bytes, int n, BqWs &w) {
+struct BqGrid;
+static void bqg_carve(D3Carver &c, int n, BqGrid &g);
+static bool bq_carve(void *ws, size_t ws_bytes, int n, BqWs &w, BqGrid *g = nullptr);
+static bool bq_carve(void *ws, size_t ws_bytes, int n, BqWs &w, BqGrid *g) {
     D3Carver c(ws, ws_bytes);
     size_t nn = (size_t)(n > 0 ? n : 1);
     w.nchunks = (int)((nn + BQ_CHUNK - 1) / BQ_CHUNK);
@@ -50,6 +53,7 @@ static bool bq_carve(void *ws, size_t ws_bytes, int n, BqWs &w) {
     w.total = c.take<int>(64);
     w.temp_bytes = d3_scan_temp_bytes(n);
     w.temp = c.take<char>(w.temp_bytes);
+    if (g) bqg_carve(c, n, *g);        // the cell grid of the padded form sits behind the scan's tables
     return ws != nullptr && c.ok();
 }
 
@@ -65,6 +69,7 @@ extern "C" size_t d3_ballquery_ws_bytes_single_pass(int n) {
     return d3_align(d3_ballquery_ws_bytes(n), 4096) + (size_t)(n > 0 ? n : 1) * BQ_CAP * sizeof(int);
 }
 
+static size_t bqg_cap_host(int n) { size_t c = 1024; while (c < (size_t)n * 2) c <<= 1; return c; }
 extern "C" size_t d3_ballquery_ws_bytes(int n) {
     BqWs w;
     D3Carver c(nullptr, 0);
@@ -75,6 +80,14 @@ extern "C" size_t d3_ballquery_ws_bytes(int n) {
     c.take<int>(nn); c.take<int>(nn); c.take<int>(64);
     c.take<char>(d3_scan_temp_bytes(n));
     (void)w;
+    // + the cell grid (d3_ballquery_padded)
+    const size_t cap = bqg_cap_host(n);
+    c.take<unsigned long long>(nn); c.take<unsigned long long>(nn); c.take<unsigned long long>(cap);
+    c.take<int>(nn); c.take<int>(nn); c.take<int>(nn); c.take<int>(nn); c.take<int>(nn + 1); c.take<int>(cap); c.take<int>(nn); c.take<int>(nn);
+    c.take<int>(64); c.take<float>(nn * 3); c.take<float>(nn * 6);
+    size_t tb = d3_sort_pairs_u64_temp_bytes(n);
+    if (d3_scan_temp_bytes(n) > tb) tb = d3_scan_temp_bytes(n);
+    c.take<char>(tb);
     return c.off + 256;
 }
 
@@ -297,6 +310,309 @@ extern "C" int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const 
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ cell grid
+// The padded ball query (the form the model's two clustering branches use) searches a UNIFORM CELL GRID instead of scanning
+// the points in their given order: cell edge = 1.001 * r, so every neighbour of a point lies in the 27 cells around its
+// own (two coordinates closer than r differ by less than 1 - 1e-3 cell edges: the floors differ by at most one, whatever
+// the fp32 rounding of x * (1 / edge)).  The ordered chunk scan loses its grip exactly where PointGroup needs it most -- the
+// SHIFTED coordinates, where a chunk of 64 consecutive points spans many instance centres and nothing is culled.
+//   1. key = (batch, cell) per point; a STABLE radix sort of (key, point index) orders the points by cell and keeps the
+//      indices of a cell ascending; cells = runs of equal keys, (key -> run) goes into an open-addressing hash.
+//   2. one wave per query: 27 hash probes (one per lane) give the candidate runs; candidates are read contiguously from
+//      the sorted copies (index + coordinates), tested with the reference's expression (bfs_cluster.cu:36, every
+//      operation rounded separately), and the hits are put in ascending index order: <= 64 candidates by a bitonic
+//      network across the lanes, more through a per-wave LDS buffer (bitonic sort; beyond 1024 hits the buffer is cut
+//      back to its 1000 smallest and later candidates must beat the 1000th) -- the reference's "first 1000 in index
+//      order" (bfs_cluster.cu:38-44) without any order assumption on the input.
+//   3. CLIQUE CELLS.  If the bounding box of ALL points in the 27 cells around cell c has a diagonal shorter than r, every
+//      query of c finds exactly those points: identical lists.  Then only the cell's smallest index (its "leader")
+//      searches; the other members' start_len entries point at the leader's slot.  A collapsed instance (what accurate
+//      offset predictions produce: thousands of points within a millimetre of their centre) is one such cell -- its
+//      list is written once instead of once per member (4 KB each), and the clustering kernels that walk it afterwards
+//      (union / label push / star) read one cached copy.  Consumers only ever index idx[start + e], e < len.
+#define BQG_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define BQG_BUF 2048            // per-wave LDS hit buffer (ints)
+#define BQG_BIAS 16384
+
+struct BqGrid {
+    unsigned long long *key, *skey, *tkeys;
+    int *pid, *sidx, *head, *rid, *cstart, *tval, *leader, *leader_of, *ncells;
+    float *sxyz, *cbox;
+    void *temp; size_t temp_bytes;
+    size_t cap;
+};
+static size_t bqg_cap(int n) { size_t c = 1024; while (c < (size_t)n * 2) c <<= 1; return c; }
+static void bqg_carve(D3Carver &c, int n, BqGrid &g) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    g.cap = bqg_cap(n);
+    g.key = c.take<unsigned long long>(nn); g.skey = c.take<unsigned long long>(nn); g.tkeys = c.take<unsigned long long>(g.cap);
+    g.pid = c.take<int>(nn); g.sidx = c.take<int>(nn); g.head = c.take<int>(nn); g.rid = c.take<int>(nn);
+    g.cstart = c.take<int>(nn + 1); g.tval = c.take<int>(g.cap); g.leader = c.take<int>(nn); g.leader_of = c.take<int>(nn);
+    g.ncells = c.take<int>(64);
+    g.sxyz = c.take<float>(nn * 3); g.cbox = c.take<float>(nn * 6);
+    g.temp_bytes = d3_sort_pairs_u64_temp_bytes(n);
+    const size_t sb = d3_scan_temp_bytes(n);
+    if (sb > g.temp_bytes) g.temp_bytes = sb;
+    g.temp = c.take<char>(g.temp_bytes);
+}
+
+__device__ __forceinline__ unsigned long long bqg_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+// cell coordinate of x: clamped (a monotone, non-expanding map keeps neighbours within +-1 cell); NaN lands in cell 0 and
+// fails every distance test
+__device__ __forceinline__ int bqg_cell(float x, float inv) {
+    const float f = floorf(__fmul_rn(x, inv));
+    return (f >= (float)(BQG_BIAS - 2)) ? BQG_BIAS - 2 : (f <= (float)(-BQG_BIAS + 2)) ? -BQG_BIAS + 2 : (f == f ? (int)f : 0);
+}
+__device__ __forceinline__ unsigned long long bqg_pack(int b, int cx, int cy, int cz) {
+    return ((unsigned long long)(unsigned)(b & 0x7FFFF) << 45) | ((unsigned long long)(unsigned)(cx + BQG_BIAS) << 30) |
+           ((unsigned long long)(unsigned)(cy + BQG_BIAS) << 15) | (unsigned long long)(unsigned)(cz + BQG_BIAS);
+}
+// run id of `key`, or -1
+__device__ __forceinline__ int bqg_find(const unsigned long long *__restrict__ tkeys, const int *__restrict__ tval, size_t mask,
+                                        unsigned long long key) {
+    size_t slot = bqg_hash(key) & mask;
+    for (;;) {
+        const unsigned long long k = tkeys[slot];
+        if (k == key) return tval[slot];
+        if (k == BQG_EMPTY) return -1;
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ void bqg_key_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n, float inv,
+                               unsigned long long *key, int *pid, unsigned long long *tkeys, size_t cap) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) tkeys[i] = BQG_EMPTY;
+    if (i >= (size_t)n) return;
+    key[i] = bqg_pack(batch_idxs[i], bqg_cell(xyz[i * 3 + 0], inv), bqg_cell(xyz[i * 3 + 1], inv), bqg_cell(xyz[i * 3 + 2], inv));
+    pid[i] = (int)i;
+}
+__global__ void bqg_head_kernel(const unsigned long long *__restrict__ skey, const int *__restrict__ sidx,
+                                const float *__restrict__ xyz, int n, int *head, float *sxyz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
+    const int p = sidx[i];
+    sxyz[i * 3 + 0] = xyz[p * 3 + 0]; sxyz[i * 3 + 1] = xyz[p * 3 + 1]; sxyz[i * 3 + 2] = xyz[p * 3 + 2];
+}
+__global__ void bqg_cells_kernel(const unsigned long long *__restrict__ skey, const int *__restrict__ head,
+                                 const int *__restrict__ rid, int n, int *cstart, unsigned long long *tkeys, int *tval,
+                                 size_t mask, int *ncells) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == n - 1) { const int nc = rid[i] + head[i]; ncells[0] = nc; cstart[nc] = n; }
+    if (!head[i]) return;
+    const int c = rid[i];
+    cstart[c] = i;
+    const unsigned long long key = skey[i];
+    size_t slot = bqg_hash(key) & mask;
+    for (;;) {      // keys are distinct (one insert per run): claim the first empty slot
+        const unsigned long long prev = atomicCAS(&tkeys[slot], BQG_EMPTY, key);
+        if (prev == BQG_EMPTY) { tval[slot] = c; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+// one wave per cell: bounding box of its points
+__global__ __launch_bounds__(256) void bqg_cellbox_kernel(const int *__restrict__ cstart, const int *__restrict__ ncells,
+                                                         const float *__restrict__ sxyz, float *cbox) {
+    const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (c >= ncells[0]) return;
+    const int s0 = cstart[c], s1 = cstart[c + 1];
+    float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
+    for (int i = s0 + d3_lane(); i < s1; i += 64) {
+        const float a = sxyz[i * 3 + 0], b = sxyz[i * 3 + 1], d = sxyz[i * 3 + 2];
+        x = fminf(x, a); X = fmaxf(X, a); y = fminf(y, b); Y = fmaxf(Y, b); z = fminf(z, d); Z = fmaxf(Z, d);
+    }
+    if (s1 - s0 > 1) { x = wave_min(x); y = wave_min(y); z = wave_min(z); X = wave_max(X); Y = wave_max(Y); Z = wave_max(Z); }
+    else { x = __shfl(x, 0); y = __shfl(y, 0); z = __shfl(z, 0); X = x; Y = y; Z = z; }
+    if (d3_lane() == 0) { float *o = cbox + (size_t)c * 6; o[0] = x; o[1] = y; o[2] = z; o[3] = X; o[4] = Y; o[5] = Z; }
+}
+// one thread per cell: candidates and bounding box of its 27-cell neighbourhood -> leader (smallest member) of a clique cell
+__global__ void bqg_clique_kernel(const unsigned long long *__restrict__ skey, const int *__restrict__ sidx,
+                                  const int *__restrict__ cstart, const int *__restrict__ ncells,
+                                  const unsigned long long *__restrict__ tkeys, const int *__restrict__ tval, size_t mask,
+                                  const float *__restrict__ cbox, float radius2, int *leader) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells[0]) return;
+    const int s0 = cstart[c];
+    const unsigned long long key = skey[s0];
+    const int b = (int)(key >> 45), cx = (int)((key >> 30) & 0x7FFF), cy = (int)((key >> 15) & 0x7FFF), cz = (int)(key & 0x7FFF);
+    int T = 0;
+    float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
+    for (int j = 0; j < 27; j++) {
+        const int dx = j / 9 - 1, dy = (j / 3) % 3 - 1, dz = j % 3 - 1;
+        const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx > 0x7FFF || ny > 0x7FFF || nz > 0x7FFF) continue;
+        const unsigned long long nk = ((unsigned long long)(unsigned)b << 45) | ((unsigned long long)nx << 30) | ((unsigned long long)ny << 15) | (unsigned long long)nz;
+        const int r = (j == 13) ? c : bqg_find(tkeys, tval, mask, nk);
+        if (r < 0) continue;
+        T += cstart[r + 1] - cstart[r];
+        const float *o = cbox + (size_t)r * 6;
+        x = fminf(x, o[0]); y = fminf(y, o[1]); z = fminf(z, o[2]); X = fmaxf(X, o[3]); Y = fmaxf(Y, o[4]); Z = fmaxf(Z, o[5]);
+    }
+    // every pair inside the box is closer than the diagonal; 1e-5 covers the roundings of both this expression and the
+    // reference's distance expression (differences of nearby fp32 numbers are exact, the squares and sums round at 2^-24)
+    const float ex = X - x, ey = Y - y, ez = Z - z;
+    const float diag2 = ex * ex + ey * ey + ez * ez;
+    const bool clique = T > 64 && cstart[c + 1] - s0 > 1 && diag2 * 1.00001f < radius2 && diag2 == diag2;
+    leader[c] = clique ? sidx[s0] : -1;
+}
+
+__device__ __forceinline__ int bqg_bitonic64(int v, int lane) {   // ascending across the 64 lanes
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int o = __shfl_xor(v, j);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            v = (lower == up) ? min(v, o) : max(v, o);
+        }
+    }
+    return v;
+}
+// ascending bitonic sort of buf[0..P) (P a power of two >= 64) by ONE wave
+__device__ __forceinline__ void bqg_sort_lds(int *buf, int P, int lane) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (P >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const int a = buf[i], b = buf[p];
+                if ((a > b) == ((i & k) == 0)) { buf[i] = b; buf[p] = a; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bqg_query_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n,
+                                                       float radius, float inv, const int *__restrict__ sidx,
+                                                       const float *__restrict__ sxyz, const int *__restrict__ cstart,
+                                                       const unsigned long long *__restrict__ tkeys,
+                                                       const int *__restrict__ tval, size_t mask,
+                                                       const int *__restrict__ leader, int *__restrict__ leader_of,
+                                                       int *__restrict__ len_out, int *__restrict__ idx) {
+    __shared__ int bufS[4][BQG_BUF];
+    __shared__ int preS[4][32], cstS[4][32];
+    const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (q >= n) return;                      // (whole waves: no workgroup barrier below)
+    const int lane = d3_lane(), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long lt = d3_lanemask_lt();
+    const float radius2 = __fmul_rn(radius, radius);
+    const float ox = xyz[q * 3 + 0], oy = xyz[q * 3 + 1], oz = xyz[q * 3 + 2];
+    const int b = batch_idxs[q];
+    const int cx = bqg_cell(ox, inv) + BQG_BIAS, cy = bqg_cell(oy, inv) + BQG_BIAS, cz = bqg_cell(oz, inv) + BQG_BIAS;
+    // lane j < 27: run of neighbour cell j
+    int rs = 0, rn = 0, run = -1;
+    if (lane < 27) {
+        const int nx = cx + lane / 9 - 1, ny = cy + (lane / 3) % 3 - 1, nz = cz + lane % 3 - 1;
+        if (nx >= 0 && ny >= 0 && nz >= 0 && nx <= 0x7FFF && ny <= 0x7FFF && nz <= 0x7FFF) {
+            const unsigned long long nk = ((unsigned long long)(unsigned)(b & 0x7FFFF) << 45) | ((unsigned long long)nx << 30) |
+                                          ((unsigned long long)ny << 15) | (unsigned long long)nz;
+            run = bqg_find(tkeys, tval, mask, nk);
+            if (run >= 0) { rs = cstart[run]; rn = cstart[run + 1] - rs; }
+        }
+    }
+    // clique cell: everybody but the leader shares the leader's list
+    const int own = __shfl(run, 13);
+    const int ld = own >= 0 ? leader[own] : -1;
+    if (ld >= 0 && ld != q) { if (lane == 0) leader_of[q] = ld; return; }
+    if (lane == 0) leader_of[q] = q;
+    // exclusive prefix of the run lengths over the 27 lanes
+    int pre = rn;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+    const int T = __shfl(pre, 26);
+    pre -= rn;
+    if (lane < 27) { preS[wave][lane] = pre; cstS[wave][lane] = rs; }
+    if (lane >= 27 && lane < 32) { preS[wave][lane] = 0x7FFFFFFF; cstS[wave][lane] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int *buf = bufS[wave];
+    const long long base = (long long)q * BQ_CAP;
+    int cnt = 0, thr = 0x7FFFFFFF;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool live = t < T;
+        // run of candidate t: the last j with pre[j] <= t (empty runs share their successor's prefix: skipped by the search)
+        int j = 0;
+#pragma unroll
+        for (int s = 16; s > 0; s >>= 1) if (j + s < 27 && preS[wave][j + s] <= t) j += s;
+        const int pos = live ? cstS[wave][j] + (t - preS[wave][j]) : 0;
+        const int k = sidx[pos];
+        const float x = sxyz[pos * 3 + 0], y = sxyz[pos * 3 + 1], z = sxyz[pos * 3 + 2];
+        const float dx = __fsub_rn(ox, x), dy = __fsub_rn(oy, y), dz = __fsub_rn(oz, z);
+        // ((dx*dx + dy*dy) + dz*dz), every operation rounded separately (bfs_cluster.cu:36)
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const bool hit = live && d2 < radius2 && k < thr;
+        if (T <= 64) {     // one round: order the hits across the lanes
+            const int v = bqg_bitonic64(hit ? k : 0x7FFFFFFF, lane);
+            cnt = (int)__popcll(__ballot(hit));
+            if (lane < cnt) idx[base + lane] = v;
+            if (lane == 0) len_out[q] = cnt;
+            return;
+        }
+        const unsigned long long hm = __ballot(hit);
+        if (hit) buf[cnt + (int)__popcll(hm & lt)] = k;
+        cnt += (int)__popcll(hm);
+        if (cnt > BQG_BUF - 64) {   // (wave-uniform) cut back to the 1000 smallest so far; later candidates must beat the 1000th
+            for (int e = cnt + lane; e < BQG_BUF; e += 64) buf[e] = 0x7FFFFFFF;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            bqg_sort_lds(buf, BQG_BUF, lane);
+            cnt = BQ_CAP;
+            thr = buf[BQ_CAP - 1];
+        }
+    }
+    // T > 64: sort what was collected
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    for (int e = cnt + lane; e < P; e += 64) buf[e] = 0x7FFFFFFF;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bqg_sort_lds(buf, P, lane);
+    if (cnt > BQ_CAP) cnt = BQ_CAP;
+    for (int e = lane; e < cnt; e += 64) idx[base + e] = buf[e];
+    if (lane == 0) len_out[q] = cnt;
+}
+__global__ void bqg_pack_kernel(const int *__restrict__ len, const int *__restrict__ leader_of, int *start_len, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int l = leader_of[i];
+    start_len[i * 2 + 0] = l * BQ_CAP;
+    start_len[i * 2 + 1] = len[l];
+}
+
+static int bqg_padded(const float *xyz, const int *batch_idxs, int n, float radius, int *start_len, BqWs &w, BqGrid &g,
+                      int *idx_padded, hipStream_t s) {
+    const float inv = 1.0f / (radius * 1.001f);
+    const size_t span = g.cap > (size_t)n ? g.cap : (size_t)n;
+    bqg_key_kernel<<<(int)((span + 255) / 256), 256, 0, s>>>(xyz, batch_idxs, n, inv, g.key, g.pid, g.tkeys, g.cap);
+    int rc = d3_sort_pairs_u64(g.key, g.skey, g.pid, g.sidx, n, g.temp, g.temp_bytes, s);
+    if (rc) return rc;
+    bqg_head_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, xyz, n, g.head, g.sxyz);
+    rc = d3_exclusive_scan_i32(g.head, g.rid, n, g.temp, g.temp_bytes, s);
+    if (rc) return rc;
+    bqg_cells_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.head, g.rid, n, g.cstart, g.tkeys, g.tval, g.cap - 1, g.ncells);
+    bqg_cellbox_kernel<<<(n + 3) / 4, 256, 0, s>>>(g.cstart, g.ncells, g.sxyz, g.cbox);          // (<= n cells)
+    bqg_clique_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, g.cstart, g.ncells, g.tkeys, g.tval, g.cap - 1, g.cbox,
+                                                     radius * radius, g.leader);
+    bqg_query_kernel<<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, n, radius, inv, g.sidx, g.sxyz, g.cstart, g.tkeys, g.tval,
+                                                g.cap - 1, g.leader, g.leader_of, w.len, idx_padded);
+    bqg_pack_kernel<<<(n + 255) / 256, 256, 0, s>>>(w.len, g.leader_of, start_len, n);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 // Padded (sync-free) form: every point owns a fixed slot of d3_ballquery_cap() entries, start_len[q] = (q * cap, len).
 // No scan, no compaction, no host round trip for nActive: the consumers (d3_bfs_cluster_*) only ever index
 // idx[start + e], e < len, so the padded layout is a valid (idx, start_len) pair for them.  idx_padded: n * cap ints.
@@ -313,8 +629,10 @@ extern "C" int d3_ballquery_padded(const float *xyz, const int *batch_idxs, cons
     if (n <= 0) return 0;
     if ((long long)n * BQ_CAP > 0x7FFFFFFFLL) return D3_ERR_ARG;
     BqWs w;
-    if (!bq_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    BqGrid g;
+    if (!bq_carve(ws, ws_bytes, n, w, &g)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
+    if (d3_tune(D3T_BQ_GRID) != 0 && radius > 0.f) return bqg_padded(xyz, batch_idxs, n, radius, start_len, w, g, idx_padded, s);
     int rc = bq_boxes(xyz, n, w, s);
     if (rc) return rc;
     bq_scan_kernel<2><<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, batch_offsets, n, radius, w.clo, w.chi, w.slo, w.shi,

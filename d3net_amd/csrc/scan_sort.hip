@@ -39,3 +39,22 @@ int d3_sort_pairs_i32(const int *kin, int *kout, const int *vin, int *vout, int 
     D3_CHECK(rocprim::radix_sort_pairs(temp, need, kin, kout, vin, vout, (size_t)n, 0, (unsigned)bits, s));
     return 0;
 }
+
+// stable ascending sort of (64-bit key, int32 value) pairs (the ball query's cell grid: points ordered by cell, ascending
+// point index inside a cell because the sort is stable)
+size_t d3_sort_pairs_u64_temp_bytes(int n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                    (const int *)nullptr, (int *)nullptr, (size_t)(n > 0 ? n : 1), 0, 64);
+    return d3_align(bytes + 256);
+}
+
+int d3_sort_pairs_u64(const unsigned long long *kin, unsigned long long *kout, const int *vin, int *vout, int n, void *temp,
+                      size_t temp_bytes, hipStream_t s) {
+    if (n <= 0) return 0;
+    size_t need = 0;
+    D3_CHECK(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, 64, s));
+    if (need > temp_bytes) return D3_ERR_WORKSPACE;
+    D3_CHECK(rocprim::radix_sort_pairs(temp, need, kin, kout, vin, vout, (size_t)n, 0, 64, s));
+    return 0;
+}

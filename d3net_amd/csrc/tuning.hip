@@ -31,6 +31,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_VOX_ROWS", 1},             // 0: thread-per-element input voxelisation
     {"D3_C2_WLDS_KB", 160},         // 16-wave convolution workgroups: total LDS (weights + tile state) up to this many KB
     {"D3_C2_NW16_KB", 24},          // packed weights of at least this many KB: 16 waves share one LDS copy (1 << 20: never)
+    {"D3_BQ_GRID", 1},              // 0: padded ball query by the ordered chunk scan instead of the cell grid
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

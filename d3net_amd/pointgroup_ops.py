@@ -235,7 +235,8 @@ ballquery_batch_p = BallQueryBatchP.apply
 
 def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=2 << 30):
     """Sync-free ball query for callers that hand the result straight to `bfs_cluster`: every point owns a fixed slot
-    of `cap` entries (start_len[q] = (q * cap, len)), so there is no nActive to fetch, no scan and no compaction.  Same
+    of `cap` entries (start_len[q] = (s * cap, len) with s = q, or the leader of q's clique cell whose list q shares:
+    csrc/ballquery.hip), so there is no nActive to fetch, no scan and no compaction.  Same
     neighbours in the same order as `ballquery_batch_p` (lib/pointgroup_ops/functions/pointgroup_ops.py:143-180);
     returns None when the padded buffer would exceed `max_bytes` (the caller then uses `ballquery_batch_p`)."""
     n = coords.size(0)

@@ -133,9 +133,11 @@ int d3_ballquery_count(const float *xyz, const int *batch_idxs, const int *batch
 int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,
                       const int *start_len, const void *ws, size_t ws_bytes, int *idx, long long idx_capacity,
                       void *stream);
-/* Padded, sync-free ball query: point q owns idx_padded[q * d3_ballquery_cap() ...], start_len[q] = (q * cap, len).
- * Same neighbours in the same order as d3_ballquery_count/fill; no nActive, no host round trip.  Valid input of
- * d3_bfs_cluster_count / d3_bfs_cluster_fill2 (which only read idx[start + e], e < len).  idx_padded: n * cap ints;
+/* Padded, sync-free ball query: idx_padded holds n slots of d3_ballquery_cap() entries and start_len[q] = (s * cap, len)
+ * with s = q, or -- when every point in the 27 search cells around q's cell lies within one ball (a collapsed instance:
+ * all those queries have the same list) -- the smallest point index of q's cell, whose slot then holds the one shared copy.
+ * Same neighbours in the same order as d3_ballquery_count/fill (uniform cell grid instead of the ordered scan:
+ * csrc/ballquery.hip); no nActive, no host round trip.  Valid input of d3_bfs_cluster_* (they only index idx[start + e]).
  * ws: d3_ballquery_ws_bytes(n).  Replaces the same reference call as d3_ballquery_count (bfs_cluster.cu:13-63). */
 int d3_ballquery_cap(void);
 int d3_ballquery_padded(const float *xyz, const int *batch_idxs, const int *batch_offsets, int n, float radius,

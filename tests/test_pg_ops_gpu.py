@@ -175,13 +175,91 @@ def test_ballquery_padded_matches_compact_and_feeds_bfs(dev):
     pidx, psl = P.ballquery_batch_p_padded(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03)
     pidx, psl_h = N(pidx), N(psl)
     cap = pidx.size // n
-    assert np.array_equal(psl_h[:, 1], rsl[:, 1]) and np.array_equal(psl_h[:, 0], np.arange(n, dtype=np.int64) * cap)
+    # (a point's list sits in its own slot, or -- members of a clique cell, csrc/ballquery.hip -- in the slot of the cell's leader)
+    assert np.array_equal(psl_h[:, 1], rsl[:, 1]) and (psl_h[:, 0] % cap == 0).all() and (psl_h[:, 0] // cap < n).all()
     for q in rng.permutation(n)[:400]:
-        assert np.array_equal(pidx[q * cap:q * cap + rsl[q, 1]], ridx[rsl[q, 0]:rsl[q, 0] + rsl[q, 1]])
+        assert np.array_equal(pidx[psl_h[q, 0]:psl_h[q, 0] + rsl[q, 1]], ridx[rsl[q, 0]:rsl[q, 0] + rsl[q, 1]])
     rci, rco = o.bfs_cluster(sem, ridx, rsl, 20)
     ci, co = P.bfs_cluster(T(sem, dev), T(pidx, dev), psl, 20)
     assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
     assert P.ballquery_batch_p_padded(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, max_bytes=1024) is None
+
+
+def _padded_lists_equal(pidx, psl, ridx, rsl, qs):
+    for q in qs:
+        a = pidx[psl[q, 0]:psl[q, 0] + psl[q, 1]]
+        b = ridx[rsl[q, 0]:rsl[q, 0] + rsl[q, 1]]
+        if not np.array_equal(a, b):
+            return q
+    return None
+
+
+@pytest.mark.parametrize("grid", [1, 0])
+def test_ballquery_padded_cell_grid_regimes(dev, grid):
+    """The cell-grid search of the padded form (csrc/ballquery.hip) in every regime, against the C oracle's brute force
+    (src/bfs_cluster/bfs_cluster.cu:15-60): sparse surfaces (<= 64 candidates: one bitonic pass across the lanes), a blob
+    wider than a cell (hundreds to thousands of candidates, capped lists: LDS sort, the 1000-smallest cut), EXACTLY collapsed
+    instances of 70 / 999 / 1000 / 1001 / 3000 points (clique cells: one list, shared by every member), a collapsed
+    instance sitting on a cell corner (its members fall into up to 8 cells), negative coordinates, points exactly on cell
+    boundaries, three batch items with one empty, shuffled point order.  grid = 0: the ordered chunk scan, same results."""
+    from d3net_amd import _lib, pointgroup_ops as P
+    rng = np.random.default_rng(90)
+    r = 0.03
+    edge = np.float32(r * 1.001)
+    parts = []
+    g = np.stack(np.meshgrid(np.arange(60), np.arange(50), indexing="ij"), -1).reshape(-1, 2).astype(np.float32) * 0.02
+    parts.append(np.concatenate([g - 0.4, np.full((len(g), 1), -0.2, np.float32)], 1))                # a sheet, negative coordinates
+    parts.append(rng.normal(0, 0.012, (2600, 3)).astype(np.float32) + np.array([1.0, 0.3, 0.2], np.float32))   # blob wider than a cell
+    parts.append(rng.normal(0, 0.004, (2300, 3)).astype(np.float32) + np.array([0.2, 0.9, 0.1], np.float32))   # blob inside ~one cell, not a clique
+    for m, c in ((70, (0.5, 0.5, 0.5)), (999, (0.7, 0.5, 0.5)), (1000, (0.9, 0.5, 0.5)), (1001, (1.1, 0.5, 0.5)), (3000, (1.3, 0.5, 0.5))):
+        parts.append(np.repeat(np.array([c], np.float32), m, 0))                                       # exactly collapsed instances
+    corner = np.array([edge * 20, edge * 21, edge * 22], np.float32)                                   # on a cell corner, +- 1 ulp
+    jig = np.stack([np.nextafter(corner, np.float32(s), dtype=np.float32) for s in (-1, 1)])[rng.integers(0, 2, (1500, 3)), np.arange(3)]
+    parts.append(jig.astype(np.float32))
+    parts.append((np.arange(0, 40)[:, None] * edge * np.array([[1, 0, 0]], np.float32) + np.array([0, 2.0, 0], np.float32)).astype(np.float32))  # on cell boundaries
+    xyz = np.concatenate(parts).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    n = len(xyz)
+    cut1, cut2 = n // 2, n // 2                       # batch item 1 is empty
+    bi = np.concatenate([np.zeros(cut1, np.int32), np.full(n - cut2, 2, np.int32)]); bo = np.array([0, cut1, cut2, n], np.int32)
+    ridx, rsl = o.ballquery_batch_p(xyz, bi, bo, r, 300)
+    assert rsl[:, 1].max() == 1000 and (rsl[:, 1] == 1000).sum() > 3000 and (rsl[:, 1] < 20).sum() > 1000
+    with _lib.tuning(D3_BQ_GRID=grid):
+        pidx, psl = P.ballquery_batch_p_padded(T(xyz, dev), T(bi, dev), T(bo, dev), r)
+    pidx, psl = N(pidx), N(psl)
+    assert np.array_equal(psl[:, 1], rsl[:, 1])
+    bad = _padded_lists_equal(pidx, psl, ridx, rsl, range(n))
+    assert bad is None, ("list of point", bad)
+    shared = int((psl[:, 0] != np.arange(n) * 1000).sum())
+    assert (shared > 4000) if grid else (shared == 0), shared       # the collapsed instances share their leader's list
+    sem = np.ones(n, np.int32)
+    rci, rco = o.bfs_cluster(sem, ridx, rsl, 50)
+    ci, co = P.bfs_cluster(T(sem, dev), T(pidx, dev), T(psl, dev), 50, True)
+    assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci)
+
+
+def test_ballquery_padded_cell_grid_equals_chunk_scan_at_scene_size(dev):
+    """one 40-box bench scene (~150 k object points), both clustering inputs (original and exactly shifted coordinates): the
+    cell-grid lists == the ordered chunk scan's lists (itself pinned to the oracle above and in the tests around)"""
+    from d3net_amd import _lib, pointgroup_ops as P, synthetic as S
+    occ, sem, inst, _ = S.occupancy_grid((200, 150, 100), 40, (8, 30), (8, 30), seed=0)
+    sc = S.scene_from_grid(occ, sem, inst, seed=1, feat_seed=2)
+    keep = sc["sem_labels"] > 0
+    xyz = sc["locs"][keep]
+    info, _ = S.instance_info(sc["locs"], sc["instance_ids"])
+    off = np.where((sc["instance_ids"] >= 0)[:, None], info[:, :3] - sc["locs"], 0).astype(np.float32)[keep]
+    n = len(xyz)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    for pts in (xyz, (xyz + off).astype(np.float32)):
+        res = []
+        for grid in (0, 1):
+            with _lib.tuning(D3_BQ_GRID=grid):
+                pidx, psl = P.ballquery_batch_p_padded(T(pts, dev), T(bi, dev), T(bo, dev), 0.03)
+            res.append((N(pidx), N(psl)))
+        (i0, s0), (i1, s1) = res
+        assert np.array_equal(s0[:, 1], s1[:, 1])
+        bad = _padded_lists_equal(i1, s1, i0, s0, np.random.default_rng(3).permutation(n)[:20000])
+        assert bad is None, bad
 
 
 def test_ballquery_empty_batch_item_and_tiny(dev):
