@@ -63,8 +63,10 @@ SIGNATURES = {
     "d3_spconv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_pack_bytes": (sz, [i32, i32, i32]),
+    "d3_spconv_pack_bytes_ex": (sz, [i32, i32, i32, i32]),
     "d3_spconv_pack": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "d3_spconv_fwd2_nparts": (i32, [i32, i32, i32, i32]),
+    "d3_spconv_fwd2_nparts_ex": (i32, [i32, i32, i32, i32, i32]),
     "d3_spconv_fwd2_plan": (i32, [i32, i32, i32, i32, pi]),
     "d3_spconv_fwd2": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_fwd2_bnbwd": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -82,9 +82,9 @@ extern "C" size_t d3_ballquery_ws_bytes(int n) {
     (void)w;
     // + the cell grid (d3_ballquery_padded)
     const size_t cap = bqg_cap_host(n);
-    c.take<unsigned long long>(nn); c.take<unsigned long long>(nn); c.take<unsigned long long>(cap);
-    c.take<int>(nn); c.take<int>(nn); c.take<int>(nn); c.take<int>(nn); c.take<int>(nn + 1); c.take<int>(cap); c.take<int>(nn); c.take<int>(nn);
-    c.take<int>(64); c.take<float>(nn * 3); c.take<float>(nn * 6);
+    c.take<unsigned long long>(nn); c.take<unsigned long long>(nn); c.take<char>(cap * 16);
+    c.take<int>(nn); c.take<int>(nn); c.take<int>(nn); c.take<int>(nn); c.take<int>(nn + 1); c.take<int>(nn); c.take<int>(cap); c.take<int>(nn);
+    c.take<int>(64); c.take<int>(nn); c.take<float>(nn * 3); c.take<float>(nn * 6);
     size_t tb = d3_sort_pairs_u64_temp_bytes(n);
     if (d3_scan_temp_bytes(n) > tb) tb = d3_scan_temp_bytes(n);
     c.take<char>(tb);
@@ -332,12 +332,16 @@ extern "C" int d3_ballquery_fill(const float *xyz, const int *batch_idxs, const 
 //      list is written once instead of once per member (4 KB each), and the clustering kernels that walk it afterwards
 //      (union / label push / star) read one cached copy.  Consumers only ever index idx[start + e], e < len.
 #define BQG_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define BQG_BUF 2048            // per-wave LDS hit buffer (ints)
+#define BQG_BUF 2048            // per-wave LDS hit buffer (ints) of the dense kernel
 #define BQG_BIAS 16384
 
+// hash slot: (key, first sorted position of the cell, points in the cell) -- ONE 16-byte load answers a probe
+struct __attribute__((aligned(16))) BqSlot { unsigned long long key; int start, count; };
+
 struct BqGrid {
-    unsigned long long *key, *skey, *tkeys;
-    int *pid, *sidx, *head, *rid, *cstart, *tval, *leader, *leader_of, *ncells;
+    unsigned long long *key, *skey;
+    BqSlot *tbl;
+    int *pid, *sidx, *head, *rid, *cstart, *cslot, *tlead, *leader_of, *scal, *dense;
     float *sxyz, *cbox;
     void *temp; size_t temp_bytes;
     size_t cap;
@@ -346,10 +350,10 @@ static size_t bqg_cap(int n) { size_t c = 1024; while (c < (size_t)n * 2) c <<= 
 static void bqg_carve(D3Carver &c, int n, BqGrid &g) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     g.cap = bqg_cap(n);
-    g.key = c.take<unsigned long long>(nn); g.skey = c.take<unsigned long long>(nn); g.tkeys = c.take<unsigned long long>(g.cap);
+    g.key = c.take<unsigned long long>(nn); g.skey = c.take<unsigned long long>(nn); g.tbl = c.take<BqSlot>(g.cap);
     g.pid = c.take<int>(nn); g.sidx = c.take<int>(nn); g.head = c.take<int>(nn); g.rid = c.take<int>(nn);
-    g.cstart = c.take<int>(nn + 1); g.tval = c.take<int>(g.cap); g.leader = c.take<int>(nn); g.leader_of = c.take<int>(nn);
-    g.ncells = c.take<int>(64);
+    g.cstart = c.take<int>(nn + 1); g.cslot = c.take<int>(nn); g.tlead = c.take<int>(g.cap); g.leader_of = c.take<int>(nn);
+    g.scal = c.take<int>(64); g.dense = c.take<int>(nn);
     g.sxyz = c.take<float>(nn * 3); g.cbox = c.take<float>(nn * 6);
     g.temp_bytes = d3_sort_pairs_u64_temp_bytes(n);
     const size_t sb = d3_scan_temp_bytes(n);
@@ -371,22 +375,23 @@ __device__ __forceinline__ unsigned long long bqg_pack(int b, int cx, int cy, in
     return ((unsigned long long)(unsigned)(b & 0x7FFFF) << 45) | ((unsigned long long)(unsigned)(cx + BQG_BIAS) << 30) |
            ((unsigned long long)(unsigned)(cy + BQG_BIAS) << 15) | (unsigned long long)(unsigned)(cz + BQG_BIAS);
 }
-// run id of `key`, or -1
-__device__ __forceinline__ int bqg_find(const unsigned long long *__restrict__ tkeys, const int *__restrict__ tval, size_t mask,
-                                        unsigned long long key) {
+// slot of `key` (its start / count in `out`), or -1.  The first probe's slot and its leader entry are loaded together.
+__device__ __forceinline__ int bqg_find(const BqSlot *__restrict__ tbl, size_t mask, unsigned long long key, BqSlot &out) {
     size_t slot = bqg_hash(key) & mask;
     for (;;) {
-        const unsigned long long k = tkeys[slot];
-        if (k == key) return tval[slot];
+        const int4 raw = *(const int4 *)&tbl[slot];
+        const unsigned long long k = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned)raw.x;
+        if (k == key) { out.key = k; out.start = raw.z; out.count = raw.w; return (int)slot; }
         if (k == BQG_EMPTY) return -1;
         slot = (slot + 1) & mask;
     }
 }
 
 __global__ void bqg_key_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n, float inv,
-                               unsigned long long *key, int *pid, unsigned long long *tkeys, size_t cap) {
+                               unsigned long long *key, int *pid, BqSlot *tbl, int *tlead, size_t cap, int *scal) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) tkeys[i] = BQG_EMPTY;
+    if (i < cap) { tbl[i].key = BQG_EMPTY; tbl[i].start = 0; tbl[i].count = 0; tlead[i] = -1; }
+    if (i < 8) scal[i] = 0;
     if (i >= (size_t)n) return;
     key[i] = bqg_pack(batch_idxs[i], bqg_cell(xyz[i * 3 + 0], inv), bqg_cell(xyz[i * 3 + 1], inv), bqg_cell(xyz[i * 3 + 2], inv));
     pid[i] = (int)i;
@@ -400,27 +405,27 @@ __global__ void bqg_head_kernel(const unsigned long long *__restrict__ skey, con
     sxyz[i * 3 + 0] = xyz[p * 3 + 0]; sxyz[i * 3 + 1] = xyz[p * 3 + 1]; sxyz[i * 3 + 2] = xyz[p * 3 + 2];
 }
 __global__ void bqg_cells_kernel(const unsigned long long *__restrict__ skey, const int *__restrict__ head,
-                                 const int *__restrict__ rid, int n, int *cstart, unsigned long long *tkeys, int *tval,
-                                 size_t mask, int *ncells) {
+                                 const int *__restrict__ rid, int n, int *cstart, int *cslot, BqSlot *tbl, size_t mask, int *scal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (i == n - 1) { const int nc = rid[i] + head[i]; ncells[0] = nc; cstart[nc] = n; }
+    if (i == n - 1) { const int nc = rid[i] + head[i]; scal[0] = nc; cstart[nc] = n; }
     if (!head[i]) return;
     const int c = rid[i];
     cstart[c] = i;
     const unsigned long long key = skey[i];
     size_t slot = bqg_hash(key) & mask;
     for (;;) {      // keys are distinct (one insert per run): claim the first empty slot
-        const unsigned long long prev = atomicCAS(&tkeys[slot], BQG_EMPTY, key);
-        if (prev == BQG_EMPTY) { tval[slot] = c; return; }
+        const unsigned long long prev = atomicCAS(&tbl[slot].key, BQG_EMPTY, key);
+        if (prev == BQG_EMPTY) { tbl[slot].start = i; cslot[c] = (int)slot; return; }
         slot = (slot + 1) & mask;
     }
 }
-// one wave per cell: bounding box of its points
-__global__ __launch_bounds__(256) void bqg_cellbox_kernel(const int *__restrict__ cstart, const int *__restrict__ ncells,
-                                                         const float *__restrict__ sxyz, float *cbox) {
+// one wave per cell: point count into its hash slot, bounding box of its points (stored at the cell's first sorted position)
+__global__ __launch_bounds__(256) void bqg_cellbox_kernel(const int *__restrict__ cstart, const int *__restrict__ cslot,
+                                                         const int *__restrict__ scal, const float *__restrict__ sxyz,
+                                                         BqSlot *tbl, float *cbox) {
     const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (c >= ncells[0]) return;
+    if (c >= scal[0]) return;
     const int s0 = cstart[c], s1 = cstart[c + 1];
     float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
     for (int i = s0 + d3_lane(); i < s1; i += 64) {
@@ -429,37 +434,39 @@ __global__ __launch_bounds__(256) void bqg_cellbox_kernel(const int *__restrict_
     }
     if (s1 - s0 > 1) { x = wave_min(x); y = wave_min(y); z = wave_min(z); X = wave_max(X); Y = wave_max(Y); Z = wave_max(Z); }
     else { x = __shfl(x, 0); y = __shfl(y, 0); z = __shfl(z, 0); X = x; Y = y; Z = z; }
-    if (d3_lane() == 0) { float *o = cbox + (size_t)c * 6; o[0] = x; o[1] = y; o[2] = z; o[3] = X; o[4] = Y; o[5] = Z; }
+    if (d3_lane() == 0) {
+        float *o = cbox + (size_t)s0 * 6; o[0] = x; o[1] = y; o[2] = z; o[3] = X; o[4] = Y; o[5] = Z;
+        tbl[cslot[c]].count = s1 - s0;
+    }
 }
 // one thread per cell: candidates and bounding box of its 27-cell neighbourhood -> leader (smallest member) of a clique cell
 __global__ void bqg_clique_kernel(const unsigned long long *__restrict__ skey, const int *__restrict__ sidx,
-                                  const int *__restrict__ cstart, const int *__restrict__ ncells,
-                                  const unsigned long long *__restrict__ tkeys, const int *__restrict__ tval, size_t mask,
-                                  const float *__restrict__ cbox, float radius2, int *leader) {
+                                  const int *__restrict__ cstart, const int *__restrict__ cslot, const int *__restrict__ scal,
+                                  const BqSlot *__restrict__ tbl, size_t mask, const float *__restrict__ cbox, float radius2,
+                                  int *tlead) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells[0]) return;
-    const int s0 = cstart[c];
+    if (c >= scal[0]) return;
+    const int s0 = cstart[c], own_n = cstart[c + 1] - s0;
+    if (own_n < 2) return;
     const unsigned long long key = skey[s0];
-    const int b = (int)(key >> 45), cx = (int)((key >> 30) & 0x7FFF), cy = (int)((key >> 15) & 0x7FFF), cz = (int)(key & 0x7FFF);
+    const unsigned long long kb = key & ~((1ull << 45) - 1);
+    const int cx = (int)((key >> 30) & 0x7FFF), cy = (int)((key >> 15) & 0x7FFF), cz = (int)(key & 0x7FFF);
     int T = 0;
     float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
     for (int j = 0; j < 27; j++) {
-        const int dx = j / 9 - 1, dy = (j / 3) % 3 - 1, dz = j % 3 - 1;
-        const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+        const int nx = cx + j / 9 - 1, ny = cy + (j / 3) % 3 - 1, nz = cz + j % 3 - 1;
         if (nx < 0 || ny < 0 || nz < 0 || nx > 0x7FFF || ny > 0x7FFF || nz > 0x7FFF) continue;
-        const unsigned long long nk = ((unsigned long long)(unsigned)b << 45) | ((unsigned long long)nx << 30) | ((unsigned long long)ny << 15) | (unsigned long long)nz;
-        const int r = (j == 13) ? c : bqg_find(tkeys, tval, mask, nk);
-        if (r < 0) continue;
-        T += cstart[r + 1] - cstart[r];
-        const float *o = cbox + (size_t)r * 6;
+        BqSlot sl;
+        if (bqg_find(tbl, mask, kb | ((unsigned long long)nx << 30) | ((unsigned long long)ny << 15) | (unsigned long long)nz, sl) < 0) continue;
+        T += sl.count;
+        const float *o = cbox + (size_t)sl.start * 6;
         x = fminf(x, o[0]); y = fminf(y, o[1]); z = fminf(z, o[2]); X = fmaxf(X, o[3]); Y = fmaxf(Y, o[4]); Z = fmaxf(Z, o[5]);
     }
     // every pair inside the box is closer than the diagonal; 1e-5 covers the roundings of both this expression and the
     // reference's distance expression (differences of nearby fp32 numbers are exact, the squares and sums round at 2^-24)
     const float ex = X - x, ey = Y - y, ez = Z - z;
     const float diag2 = ex * ex + ey * ey + ez * ez;
-    const bool clique = T > 64 && cstart[c + 1] - s0 > 1 && diag2 * 1.00001f < radius2 && diag2 == diag2;
-    leader[c] = clique ? sidx[s0] : -1;
+    if (T > 64 && diag2 * 1.00001f < radius2 && diag2 == diag2) tlead[cslot[c]] = sidx[s0];
 }
 
 __device__ __forceinline__ int bqg_bitonic64(int v, int lane) {   // ascending across the 64 lanes
@@ -491,98 +498,134 @@ __device__ __forceinline__ void bqg_sort_lds(int *buf, int P, int lane) {
     }
 }
 
-__global__ __launch_bounds__(256) void bqg_query_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n,
-                                                       float radius, float inv, const int *__restrict__ sidx,
-                                                       const float *__restrict__ sxyz, const int *__restrict__ cstart,
-                                                       const unsigned long long *__restrict__ tkeys,
-                                                       const int *__restrict__ tval, size_t mask,
-                                                       const int *__restrict__ leader, int *__restrict__ leader_of,
-                                                       int *__restrict__ len_out, int *__restrict__ idx) {
-    __shared__ int bufS[4][BQG_BUF];
-    __shared__ int preS[4][32], cstS[4][32];
-    const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (q >= n) return;                      // (whole waves: no workgroup barrier below)
-    const int lane = d3_lane(), wave = (int)(threadIdx.x >> 6);
-    const unsigned long long lt = d3_lanemask_lt();
-    const float radius2 = __fmul_rn(radius, radius);
-    const float ox = xyz[q * 3 + 0], oy = xyz[q * 3 + 1], oz = xyz[q * 3 + 2];
+// the 27 probes of query q (lane j < 27 owns neighbour cell j): run start / length per lane, their exclusive prefix in LDS,
+// the total T, and the leader entry of the query's own cell
+struct BqProbe { int T, leader; float ox, oy, oz; };
+__device__ __forceinline__ BqProbe bqg_probe(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int q, float inv,
+                                             const BqSlot *__restrict__ tbl, const int *__restrict__ tlead, size_t mask,
+                                             int lane, int *preS, int *cstS) {
+    BqProbe r;
+    r.ox = xyz[q * 3 + 0]; r.oy = xyz[q * 3 + 1]; r.oz = xyz[q * 3 + 2];
     const int b = batch_idxs[q];
-    const int cx = bqg_cell(ox, inv) + BQG_BIAS, cy = bqg_cell(oy, inv) + BQG_BIAS, cz = bqg_cell(oz, inv) + BQG_BIAS;
-    // lane j < 27: run of neighbour cell j
-    int rs = 0, rn = 0, run = -1;
+    const int cx = bqg_cell(r.ox, inv) + BQG_BIAS, cy = bqg_cell(r.oy, inv) + BQG_BIAS, cz = bqg_cell(r.oz, inv) + BQG_BIAS;
+    int rs = 0, rn = 0, ld = -1;
     if (lane < 27) {
         const int nx = cx + lane / 9 - 1, ny = cy + (lane / 3) % 3 - 1, nz = cz + lane % 3 - 1;
         if (nx >= 0 && ny >= 0 && nz >= 0 && nx <= 0x7FFF && ny <= 0x7FFF && nz <= 0x7FFF) {
             const unsigned long long nk = ((unsigned long long)(unsigned)(b & 0x7FFFF) << 45) | ((unsigned long long)nx << 30) |
                                           ((unsigned long long)ny << 15) | (unsigned long long)nz;
-            run = bqg_find(tkeys, tval, mask, nk);
-            if (run >= 0) { rs = cstart[run]; rn = cstart[run + 1] - rs; }
+            // first probe: slot and leader entry requested together (one round trip when the key sits in its home slot)
+            size_t slot = bqg_hash(nk) & mask;
+            int4 raw = *(const int4 *)&tbl[slot];
+            int l0 = tlead[slot];
+            for (;;) {
+                const unsigned long long k = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned)raw.x;
+                if (k == nk) { rs = raw.z; rn = raw.w; ld = l0; break; }
+                if (k == BQG_EMPTY) break;
+                slot = (slot + 1) & mask;
+                raw = *(const int4 *)&tbl[slot];
+                l0 = tlead[slot];
+            }
         }
     }
-    // clique cell: everybody but the leader shares the leader's list
-    const int own = __shfl(run, 13);
-    const int ld = own >= 0 ? leader[own] : -1;
-    if (ld >= 0 && ld != q) { if (lane == 0) leader_of[q] = ld; return; }
-    if (lane == 0) leader_of[q] = q;
-    // exclusive prefix of the run lengths over the 27 lanes
+    r.leader = __shfl(ld, 13);
     int pre = rn;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
-    const int T = __shfl(pre, 26);
+    r.T = __shfl(pre, 26);
     pre -= rn;
-    if (lane < 27) { preS[wave][lane] = pre; cstS[wave][lane] = rs; }
-    if (lane >= 27 && lane < 32) { preS[wave][lane] = 0x7FFFFFFF; cstS[wave][lane] = 0; }
+    if (lane < 27) { preS[lane] = pre; cstS[lane] = rs; }
+    if (lane >= 27 && lane < 32) { preS[lane] = 0x7FFFFFFF; cstS[lane] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int *buf = bufS[wave];
-    const long long base = (long long)q * BQ_CAP;
-    int cnt = 0, thr = 0x7FFFFFFF;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int t = t0 + lane;
-        const bool live = t < T;
-        // run of candidate t: the last j with pre[j] <= t (empty runs share their successor's prefix: skipped by the search)
-        int j = 0;
+    return r;
+}
+// candidate t of the flattened candidate list -> (point index, hit)
+__device__ __forceinline__ bool bqg_test(const BqProbe &r, int t, const int *preS, const int *cstS, const int *__restrict__ sidx,
+                                         const float *__restrict__ sxyz, float radius2, int &k) {
+    const bool live = t < r.T;
+    int j = 0;   // run of candidate t: the last j with pre[j] <= t (empty runs share their successor's prefix and are skipped)
 #pragma unroll
-        for (int s = 16; s > 0; s >>= 1) if (j + s < 27 && preS[wave][j + s] <= t) j += s;
-        const int pos = live ? cstS[wave][j] + (t - preS[wave][j]) : 0;
-        const int k = sidx[pos];
-        const float x = sxyz[pos * 3 + 0], y = sxyz[pos * 3 + 1], z = sxyz[pos * 3 + 2];
-        const float dx = __fsub_rn(ox, x), dy = __fsub_rn(oy, y), dz = __fsub_rn(oz, z);
-        // ((dx*dx + dy*dy) + dz*dz), every operation rounded separately (bfs_cluster.cu:36)
-        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        const bool hit = live && d2 < radius2 && k < thr;
-        if (T <= 64) {     // one round: order the hits across the lanes
-            const int v = bqg_bitonic64(hit ? k : 0x7FFFFFFF, lane);
-            cnt = (int)__popcll(__ballot(hit));
-            if (lane < cnt) idx[base + lane] = v;
-            if (lane == 0) len_out[q] = cnt;
-            return;
-        }
-        const unsigned long long hm = __ballot(hit);
-        if (hit) buf[cnt + (int)__popcll(hm & lt)] = k;
-        cnt += (int)__popcll(hm);
-        if (cnt > BQG_BUF - 64) {   // (wave-uniform) cut back to the 1000 smallest so far; later candidates must beat the 1000th
-            for (int e = cnt + lane; e < BQG_BUF; e += 64) buf[e] = 0x7FFFFFFF;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            bqg_sort_lds(buf, BQG_BUF, lane);
-            cnt = BQ_CAP;
-            thr = buf[BQ_CAP - 1];
-        }
-    }
-    // T > 64: sort what was collected
-    int P = 64;
-    while (P < cnt) P <<= 1;
-    for (int e = cnt + lane; e < P; e += 64) buf[e] = 0x7FFFFFFF;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bqg_sort_lds(buf, P, lane);
-    if (cnt > BQ_CAP) cnt = BQ_CAP;
-    for (int e = lane; e < cnt; e += 64) idx[base + e] = buf[e];
+    for (int s = 16; s > 0; s >>= 1) if (j + s < 27 && preS[j + s] <= t) j += s;
+    const int pos = live ? cstS[j] + (t - preS[j]) : 0;
+    k = sidx[pos];
+    const float x = sxyz[pos * 3 + 0], y = sxyz[pos * 3 + 1], z = sxyz[pos * 3 + 2];
+    const float dx = __fsub_rn(r.ox, x), dy = __fsub_rn(r.oy, y), dz = __fsub_rn(r.oz, z);
+    // ((dx*dx + dy*dy) + dz*dz), every operation rounded separately (bfs_cluster.cu:36)
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return live && d2 < radius2;
+}
+
+// sparse pass: one wave per query; followers of a clique leader and queries with <= 64 candidates finish here, the others
+// are queued for the dense pass (which needs an 8 KB hit buffer per wave -- kept out of this kernel's occupancy)
+__global__ __launch_bounds__(256) void bqg_query_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n,
+                                                       float radius, float inv, const int *__restrict__ sidx,
+                                                       const float *__restrict__ sxyz, const BqSlot *__restrict__ tbl,
+                                                       const int *__restrict__ tlead, size_t mask, int *__restrict__ leader_of,
+                                                       int *__restrict__ len_out, int *__restrict__ idx, int *dense, int *scal) {
+    __shared__ int preS[4][32], cstS[4][32];
+    const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (q >= n) return;                      // (whole waves: no workgroup barrier below)
+    const int lane = d3_lane(), wave = (int)(threadIdx.x >> 6);
+    const BqProbe r = bqg_probe(xyz, batch_idxs, q, inv, tbl, tlead, mask, lane, preS[wave], cstS[wave]);
+    if (r.leader >= 0 && r.leader != q) { if (lane == 0) leader_of[q] = r.leader; return; }   // shares the leader's list
+    if (lane == 0) leader_of[q] = q;
+    if (r.T > 64) { if (lane == 0) dense[atomicAdd(&scal[1], 1)] = q; return; }
+    int k;
+    const bool hit = bqg_test(r, lane, preS[wave], cstS[wave], sidx, sxyz, __fmul_rn(radius, radius), k);
+    const int v = bqg_bitonic64(hit ? k : 0x7FFFFFFF, lane);
+    const int cnt = (int)__popcll(__ballot(hit));
+    if (lane < cnt) idx[(long long)q * BQ_CAP + lane] = v;
     if (lane == 0) len_out[q] = cnt;
+}
+// dense pass: persistent waves over the queued queries
+__global__ __launch_bounds__(256) void bqg_dense_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs,
+                                                       float radius, float inv, const int *__restrict__ sidx,
+                                                       const float *__restrict__ sxyz, const BqSlot *__restrict__ tbl,
+                                                       const int *__restrict__ tlead, size_t mask, int *__restrict__ len_out,
+                                                       int *__restrict__ idx, const int *__restrict__ dense,
+                                                       const int *__restrict__ scal) {
+    __shared__ int bufS[4][BQG_BUF];
+    __shared__ int preS[4][32], cstS[4][32];
+    const int lane = d3_lane(), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long lt = d3_lanemask_lt();
+    const float radius2 = __fmul_rn(radius, radius);
+    int *buf = bufS[wave];
+    const int nd = scal[1], nw = (int)(gridDim.x * 4);
+    for (int w = (int)(blockIdx.x * 4) + wave; w < nd; w += nw) {
+        const int q = dense[w];
+        const BqProbe r = bqg_probe(xyz, batch_idxs, q, inv, tbl, tlead, mask, lane, preS[wave], cstS[wave]);
+        int cnt = 0, thr = 0x7FFFFFFF;
+        for (int t0 = 0; t0 < r.T; t0 += 64) {
+            int k;
+            const bool hit = bqg_test(r, t0 + lane, preS[wave], cstS[wave], sidx, sxyz, radius2, k) && k < thr;
+            const unsigned long long hm = __ballot(hit);
+            if (hit) buf[cnt + (int)__popcll(hm & lt)] = k;
+            cnt += (int)__popcll(hm);
+            if (cnt > BQG_BUF - 64) {   // (wave-uniform) cut back to the 1000 smallest so far; later candidates must beat the 1000th
+                for (int e = cnt + lane; e < BQG_BUF; e += 64) buf[e] = 0x7FFFFFFF;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                bqg_sort_lds(buf, BQG_BUF, lane);
+                cnt = BQ_CAP;
+                thr = buf[BQ_CAP - 1];
+            }
+        }
+        int P = 64;
+        while (P < cnt) P <<= 1;
+        for (int e = cnt + lane; e < P; e += 64) buf[e] = 0x7FFFFFFF;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bqg_sort_lds(buf, P, lane);
+        if (cnt > BQ_CAP) cnt = BQ_CAP;
+        const long long base = (long long)q * BQ_CAP;
+        for (int e = lane; e < cnt; e += 64) idx[base + e] = buf[e];
+        if (lane == 0) len_out[q] = cnt;
+        __builtin_amdgcn_wave_barrier();     // buf / preS are rewritten by the next query
+    }
 }
 __global__ void bqg_pack_kernel(const int *__restrict__ len, const int *__restrict__ leader_of, int *start_len, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -596,18 +639,23 @@ static int bqg_padded(const float *xyz, const int *batch_idxs, int n, float radi
                       int *idx_padded, hipStream_t s) {
     const float inv = 1.0f / (radius * 1.001f);
     const size_t span = g.cap > (size_t)n ? g.cap : (size_t)n;
-    bqg_key_kernel<<<(int)((span + 255) / 256), 256, 0, s>>>(xyz, batch_idxs, n, inv, g.key, g.pid, g.tkeys, g.cap);
+    bqg_key_kernel<<<(int)((span + 255) / 256), 256, 0, s>>>(xyz, batch_idxs, n, inv, g.key, g.pid, g.tbl, g.tlead, g.cap, g.scal);
     int rc = d3_sort_pairs_u64(g.key, g.skey, g.pid, g.sidx, n, g.temp, g.temp_bytes, s);
     if (rc) return rc;
     bqg_head_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, xyz, n, g.head, g.sxyz);
     rc = d3_exclusive_scan_i32(g.head, g.rid, n, g.temp, g.temp_bytes, s);
     if (rc) return rc;
-    bqg_cells_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.head, g.rid, n, g.cstart, g.tkeys, g.tval, g.cap - 1, g.ncells);
-    bqg_cellbox_kernel<<<(n + 3) / 4, 256, 0, s>>>(g.cstart, g.ncells, g.sxyz, g.cbox);          // (<= n cells)
-    bqg_clique_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, g.cstart, g.ncells, g.tkeys, g.tval, g.cap - 1, g.cbox,
-                                                     radius * radius, g.leader);
-    bqg_query_kernel<<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, n, radius, inv, g.sidx, g.sxyz, g.cstart, g.tkeys, g.tval,
-                                                g.cap - 1, g.leader, g.leader_of, w.len, idx_padded);
+    bqg_cells_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.head, g.rid, n, g.cstart, g.cslot, g.tbl, g.cap - 1, g.scal);
+    bqg_cellbox_kernel<<<(n + 3) / 4, 256, 0, s>>>(g.cstart, g.cslot, g.scal, g.sxyz, g.tbl, g.cbox);          // (<= n cells)
+    bqg_clique_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, g.cstart, g.cslot, g.scal, g.tbl, g.cap - 1, g.cbox,
+                                                     radius * radius, g.tlead);
+    bqg_query_kernel<<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, n, radius, inv, g.sidx, g.sxyz, g.tbl, g.tlead, g.cap - 1,
+                                                g.leader_of, w.len, idx_padded, g.dense, g.scal);
+    // dense pass: as many workgroups as the chip holds (LDS: 5 per CU), each wave walks the queue
+    int nblk = (n + 3) / 4;
+    if (nblk > 1280) nblk = 1280;
+    bqg_dense_kernel<<<nblk, 256, 0, s>>>(xyz, batch_idxs, radius, inv, g.sidx, g.sxyz, g.tbl, g.tlead, g.cap - 1, w.len,
+                                         idx_padded, g.dense, g.scal);
     bqg_pack_kernel<<<(n + 255) / 256, 256, 0, s>>>(w.len, g.leader_of, start_len, n);
     D3_LAUNCH_CHECK();
     return 0;

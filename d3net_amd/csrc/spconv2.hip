@@ -24,6 +24,7 @@
 #include "common.h"
 #include "prof.h"
 #include <cstdlib>
+#include <cstring>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -70,8 +71,34 @@ __global__ void spconv_pack_kernel(const float *__restrict__ W, uint4 *__restric
     Wp[e] = make_uint4(pack2bf2(v[0], v[1]), pack2bf2(v[2], v[3]), pack2bf2(v[4], v[5]), pack2bf2(v[6], v[7]));
 }
 
+// fp32 fragments (D3_CONV_F32: the reference's precision on v_mfma_f32_16x16x4_f32): same element order, 8 floats per element
+__global__ void spconv_pack_f32_kernel(const float *__restrict__ W, float4 *__restrict__ Wp, int K, int Cin, int Cout,
+                                       int NT, int flipk, int transw) {
+    const int S = Cin >> 3;
+    const long long total = (long long)K * S * NT * 16;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int col = (int)(e & 15);
+    const int n = (int)((e >> 4) % NT);
+    const int c8 = (int)((e / (16 * NT)) % S);
+    const int k = (int)(e / ((long long)16 * NT * S));
+    const int co = n * 16 + col, wk = flipk ? (K - 1 - k) : k;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int ci = c8 * 8 + j;
+        v[j] = 0.f;
+        if (co < Cout) v[j] = transw ? W[((long long)wk * Cout + co) * Cin + ci] : W[((long long)wk * Cin + ci) * Cout + co];
+    }
+    Wp[e * 2] = make_float4(v[0], v[1], v[2], v[3]);
+    Wp[e * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 extern "C" size_t d3_spconv_pack_bytes(int K, int Cin, int Cout) {
     return (size_t)K * (Cin / 8) * ((Cout + 15) / 16) * 256;
+}
+extern "C" size_t d3_spconv_pack_bytes_ex(int K, int Cin, int Cout, int flags) {
+    return d3_spconv_pack_bytes(K, Cin, Cout) * ((flags & D3_CONV_F32) ? 2 : 1);
 }
 
 extern "C" int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream) {
@@ -79,6 +106,10 @@ extern "C" int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout
     if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1) return D3_ERR_ARG;
     const int NT = (Cout + 15) / 16;
     const long long total = (long long)K * (Cin / 8) * NT * 16;
+    if (flags & D3_CONV_F32)
+        spconv_pack_f32_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(
+            W, (float4 *)Wp, K, Cin, Cout, NT, (flags & D3_CONV_FLIPK) ? 1 : 0, (flags & D3_CONV_TRANSW) ? 1 : 0);
+    else
     spconv_pack_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>(
         W, (uint4 *)Wp, K, Cin, Cout, NT, (flags & D3_CONV_FLIPK) ? 1 : 0, (flags & D3_CONV_TRANSW) ? 1 : 0);
     D3_LAUNCH_CHECK();
@@ -97,6 +128,7 @@ struct Conv2Args {
     int Mout, K, Cout, S;       // S = Cin / 8 slots per offset
     unsigned int inv;           // ceil(65536 / S): i = (s * inv) >> 16 == s / S for s < 4096
     int xbf16, accum, ntiles, NT;   // NT = ceil(Cout / 16)
+    int f32;                        // D3_CONV_F32: fp32 weight fragments, v_mfma_f32_16x16x4_f32 (host-side dispatch only)
     unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
     // BatchNorm-backward epilogue (data gradient of a BN -> ReLU -> conv unit): the stored value is g = dy * relu'(bn(x))
     // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
@@ -182,6 +214,32 @@ __device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// One reduction step of a 16x16 tile (transposed product: first operand = weight fragment, second = gathered rows).
+// bf16: one v_mfma_f32_16x16x32_bf16 over the lane's 8 channels; F32M (D3_CONV_F32, fp32 gathers only): eight
+// v_mfma_f32_16x16x4_f32 -- step j pairs float j of the weight element with float j of the gathered 8 channels, i.e. the
+// reduction index (lane group, j) is the same channel on both sides: exact fp32 products, fp32 accumulation.
+template <bool XBF, bool F32M>
+__device__ __forceinline__ f32x4 c2_mma(f32x4 acc, const uint4 wlo, const uint4 whi, const uint4 rlo, const uint4 rhi) {
+    if (F32M) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wlo.x), __uint_as_float(rlo.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wlo.y), __uint_as_float(rlo.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wlo.z), __uint_as_float(rlo.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wlo.w), __uint_as_float(rlo.w), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(whi.x), __uint_as_float(rhi.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(whi.y), __uint_as_float(rhi.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(whi.z), __uint_as_float(rhi.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(whi.w), __uint_as_float(rhi.w), acc, 0, 0, 0);
+        return acc;
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wlo), c2_cvt_raw<XBF>(rlo, rhi), acc, 0, 0, 0);
+}
+// weight element `e` (16-byte bf16 fragment, or 32-byte fp32 fragment) of a packed buffer
+template <bool F32M>
+__device__ __forceinline__ void c2_wload(const unsigned short *Wb, int e, uint4 &lo, uint4 &hi) {
+    if (F32M) { const uint4 *p = (const uint4 *)Wb + (size_t)e * 2; lo = p[0]; hi = p[1]; }
+    else { lo = *((const uint4 *)Wb + e); hi = lo; }
+}
+
 // LDS use of the wave-per-tile kernel besides the weights
 #define C2_TBL_INTS (16 * C2_MAXK)
 #define C2_WAVE_LDS_BASE(NTV, NWV) ((NWV) * C2_TBL_INTS * 4 + (NWV) * 32 * 4 + (NWV) * 2 * (NTV) * 16 * 4)
@@ -207,14 +265,15 @@ __device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
 #define C2_F32_OCCDROP 1
 #endif
 #define C2_OCC(NTV, XB) ((NTV) <= 4 ? ((XB) ? C2_OCC_SMALL : C2_OCC_SMALL - C2_F32_OCCDROP) : (NTV) <= 9 ? ((XB) ? 3 : 2) : 2)
-template <int NT, bool WLDS, bool XBF, int NW = 4>
+template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
+    static_assert(!(F32M && XBF), "fp32 MFMA needs fp32 gathers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (16-wave workgroups run at 128 VGPRs: the fp32-input variants keep 4 gathers of 32 B in flight there instead of 8)
     constexpr int U = (!XBF && NT <= 2) ? (NW == 16 ? 4 : C2_F32_U) : C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int K = a.K, S = a.S;
-    const size_t wbytes = WLDS ? (size_t)K * S * NT * 256 : 0;
+    const size_t wbytes = WLDS ? (size_t)K * S * NT * (F32M ? 512 : 256) : 0;
     int *tblS = (int *)(smem + wbytes) + wave * C2_TBL_INTS;
     float *redS = (float *)(smem + wbytes + NW * C2_TBL_INTS * 4);
     const unsigned short *Wb = WLDS ? (const unsigned short *)smem : a.Wp;
@@ -308,21 +367,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                 const int c8 = s - k * S;
                 const bool ok = (m0 + u < nsteps) && (k < K);
                 const int idx = ok ? tblS[r * K + k] : -1;
-                boff[u] = ok ? (((k * S + c8) * NT) * 16 + r) * 8 : r * 8;
+                boff[u] = ok ? ((k * S + c8) * NT) * 16 + r : r;      // weight ELEMENT index (16 B bf16 / 32 B fp32 each)
                 rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u];
                 if (idx >= 0) c2_load_raw<XBF>(a.x, (long long)idx * a.ldx + c8 * 8, rlo[u], rhi[u]);
             }
-            if (WLDS) {
+            if (WLDS || F32M) {
                 __builtin_amdgcn_sched_barrier(0);   // every gather is in flight before the first conversion
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     if (m0 + u < nsteps) {   // wave-uniform
-                        const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
 #pragma unroll
                         for (int n = 0; n < NT; n++) {
-                            const uint4 bv = *(const uint4 *)(Wb + boff[u] + n * 128);
+                            uint4 wl, wh;
+                            c2_wload<F32M>(Wb, boff[u] + n * 16, wl, wh);
                             // transposed product: D[m = channel][n = row] += W^T[channel][k] * X^T[k][row]
-                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), A, acc[n], 0, 0, 0);
+                            acc[n] = c2_mma<XBF, F32M>(acc[n], wl, wh, rlo[u], rhi[u]);
                         }
                     }
                 }
@@ -331,7 +390,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                 if (NT <= 4) {   // the fragments of step u + 1 are requested before the MFMAs of step u
                     uint4 wnext[NT];
 #pragma unroll
-                    for (int n = 0; n < NT; n++) wnext[n] = *(const uint4 *)(Wb + boff[0] + n * 128);
+                    for (int n = 0; n < NT; n++) wnext[n] = *((const uint4 *)Wb + boff[0] + n * 16);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < U; u++) {
@@ -341,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                             for (int n = 0; n < NT; n++) wcur[n] = wnext[n];
                             if (u + 1 < U && m0 + u + 1 < nsteps) {
 #pragma unroll
-                                for (int n = 0; n < NT; n++) wnext[n] = *(const uint4 *)(Wb + boff[u + 1] + n * 128);
+                                for (int n = 0; n < NT; n++) wnext[n] = *((const uint4 *)Wb + boff[u + 1] + n * 16);
                             }
                             const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
 #pragma unroll
@@ -359,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                             for (int nb = 0; nb < NT; nb += 4) {
                                 uint4 wv[4];
 #pragma unroll
-                                for (int j = 0; j < 4; j++) if (nb + j < NT) wv[j] = *(const uint4 *)(Wb + boff[u] + (nb + j) * 128);
+                                for (int j = 0; j < 4; j++) if (nb + j < NT) wv[j] = *((const uint4 *)Wb + boff[u] + (nb + j) * 16);
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                                 for (int j = 0; j < 4; j++)
@@ -432,11 +491,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
 // Workgroup-per-tile kernel (few-row levels): grid = (16-row tiles, column groups of NTW 16-wide tiles).  The
 // W = blockDim.x/64 waves split the MFMA steps of the tile, their accumulators are summed through LDS in wave order,
 // and the workgroup owns complete output columns: no atomics, no cross-workgroup reduction, deterministic.
-template <int NTW, bool XBF>
+template <int NTW, bool XBF, bool F32M = false>
 __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args a) {
+    static_assert(!(F32M && XBF), "fp32 MFMA needs fp32 gathers");
     constexpr int U = 4;
     constexpr int CW = NTW * 16;                     // output columns of this workgroup
-    constexpr bool SMALL = NTW <= (XBF ? 3 : 2);     // register budget: 128 VGPRs at 1024 threads
+    constexpr bool SMALL = !F32M && NTW <= (XBF ? 3 : 2);     // register budget: 128 VGPRs at 1024 threads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
     const int W = blockDim.x >> 6, K = a.K, S = a.S;
@@ -511,7 +571,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             const bool ok = (m < nsteps) && (i < na);
             const int k = actS[ok ? i : 0];
             const int idx = ok ? tblS[r * K + k] : -1;
-            boff[u] = (((k * S + (ok ? c8 : 0)) * a.NT + n0) * 16 + r) * 8;
+            boff[u] = ((k * S + (ok ? c8 : 0)) * a.NT + n0) * 16 + r;      // weight ELEMENT index
             rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u];
             if (idx >= 0) c2_load_raw<XBF>(a.x, (long long)idx * a.ldx + c8 * 8, rlo[u], rhi[u]);
         }
@@ -523,7 +583,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
 #pragma unroll
                 for (int n = 0; n < NTW; n++) {
                     wv[u][n] = make_uint4(0u, 0u, 0u, 0u);
-                    if (m0 + u * W < nsteps && n0 + n < a.NT) wv[u][n] = *(const uint4 *)(a.Wp + boff[u] + n * 128);
+                    if (m0 + u * W < nsteps && n0 + n < a.NT) wv[u][n] = *((const uint4 *)a.Wp + boff[u] + n * 16);
                 }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -540,17 +600,23 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (m0 + u * W < nsteps) {
-                    uint4 wv[NTW];
+                    uint4 wv[NTW], wh[NTW];
 #pragma unroll
                     for (int n = 0; n < NTW; n++) {
-                        wv[n] = make_uint4(0u, 0u, 0u, 0u);
-                        if (n0 + n < a.NT) wv[n] = *(const uint4 *)(a.Wp + boff[u] + n * 128);
+                        wv[n] = make_uint4(0u, 0u, 0u, 0u); wh[n] = wv[n];
+                        if (n0 + n < a.NT) c2_wload<F32M>(a.Wp, boff[u] + n * 16, wv[n], wh[n]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (F32M) {      // (not transposed here: first operand = gathered rows, second = weights)
+#pragma unroll
+                        for (int n = 0; n < NTW; n++)
+                            if (n0 + n < a.NT) acc[n] = c2_mma<false, true>(acc[n], rlo[u], rhi[u], wv[n], wh[n]);
+                    } else {
                     const bf16x8_t A = c2_cvt_raw<XBF>(rlo[u], rhi[u]);
 #pragma unroll
                     for (int n = 0; n < NTW; n++)
                         if (n0 + n < a.NT) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, wv[n]), acc[n], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -607,10 +673,10 @@ static int c2_ncu() {
 }
 struct Conv2Plan { int split, W, grid, wlds, ntw, gy, nw; size_t lds; };
 
-static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout) {
+static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout, bool f32 = false) {
     Conv2Plan p;
     const int NT = (Cout + 15) / 16, ntiles = (Mout + 15) / 16;
-    const size_t wbytes = (size_t)K * (Cin / 8) * NT * 256;
+    const size_t wbytes = (size_t)K * (Cin / 8) * NT * (f32 ? 512 : 256);
     p.ntw = NT; p.gy = 1; p.nw = 4;
     if (ntiles >= 1024) {
         p.split = 0; p.W = 1;
@@ -644,6 +710,10 @@ static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout) {
 extern "C" int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout) {
     return conv2_plan(Mout, K, Cin, Cout).grid;
 }
+// flags: D3_CONV_F32 changes the weight footprint and with it the workgroup shape
+extern "C" int d3_spconv_fwd2_nparts_ex(int Mout, int K, int Cin, int Cout, int flags) {
+    return conv2_plan(Mout, K, Cin, Cout, (flags & D3_CONV_F32) != 0).grid;
+}
 
 // which kernel d3_spconv_fwd2* runs for this shape: out[6] = {split (1: spconv_fwd2_split_kernel), waves per workgroup,
 // grid.x, weights resident in LDS, column tiles per workgroup, grid.y}
@@ -664,7 +734,25 @@ static bool c2_attr_needed(bool *done) {
 }
 
 template <int NT>
+static int launch_fwd2_f32(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev)) {
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, false, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        if constexpr (NT <= C2_NW16_MAXNT)
+            D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if constexpr (NT <= C2_NW16_MAXNT) {
+        if (p.nw == 16) { spconv_fwd2_kernel<NT, true, false, 16, true><<<p.grid, 1024, p.lds, s>>>(a); D3_LAUNCH_CHECK(); return 0; }
+    }
+    if (p.wlds) spconv_fwd2_kernel<NT, true, false, 4, true><<<p.grid, 256, p.lds, s>>>(a);
+    else spconv_fwd2_kernel<NT, false, false, 4, true><<<p.grid, 256, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+template <int NT>
 static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
+    if (a.f32) return launch_fwd2_f32<NT>(a, p, s);
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev)) {   // allow more than 64 KB of dynamic LDS
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -702,6 +790,12 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     }
+    if (a.f32) {
+        static bool attr32_done_dev[64] = {false};
+        if (c2_attr_needed(attr32_done_dev))
+            D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        spconv_fwd2_split_kernel<NTW, false, true><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
+    } else
     if (a.xbf16) spconv_fwd2_split_kernel<NTW, true><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
     else spconv_fwd2_split_kernel<NTW, false><<<dim3(p.grid, p.gy), p.W * 64, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
@@ -719,6 +813,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
     const int xbf16 = (flags & D3_CONV_XBF16) ? 1 : 0;
+    const int f32 = (flags & D3_CONV_F32) ? 1 : 0;
+    if (f32 && xbf16) return D3_ERR_ARG;      // the reference-precision path gathers fp32 rows
     if ((xbf16 && (ldx & 7)) || (!xbf16 && (ldx & 3)) || ldx < Cin || ldo < Cout) return D3_ERR_ARG;
     if ((Cout & 3) || (ldo & 3) || (res && (ldr & 3))) return D3_ERR_ARG;   // float4 epilogue
     hipStream_t s = d3_stream(stream);
@@ -727,7 +823,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     a.ldx = ldx; a.ldo = ldo; a.ldr = ldr; a.Mout = Mout; a.K = K; a.Cout = Cout; a.S = Cin / 8;
     a.inv = (65536u + a.S - 1) / a.S;
     a.invK = (65536u + K - 1) / K;
-    a.xbf16 = xbf16; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
+    a.xbf16 = xbf16; a.f32 = f32; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
     a.bnx = nullptr; a.bn_mean = a.bn_var = a.bn_gamma = a.bn_beta = nullptr; a.ldbx = 0; a.bn_relu = 0; a.bn_eps = 0.f;
     if (bn) {
         if (bn->ldx & 3) return D3_ERR_ARG;
@@ -739,8 +835,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         a.fin_counter = fin->counter; a.fin_mode = fin->mode; a.fin_M = fin->M; a.fin_accum = fin->accum;
         a.fin_a = fin->a; a.fin_b = fin->b; a.fin_c = fin->c; a.fin_d = fin->d; a.fin_momentum = fin->momentum;
     }
-    const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout);
-    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + 2.0 * (double)K * Cin * Cout +
+    const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout, f32 != 0);
+    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + (f32 ? 4.0 : 2.0) * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
     void *pr = d3_prof_begin(p.split ? 2 : 0, bytes, 0.0, s);
     int rc;
@@ -1469,6 +1565,79 @@ static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, in
     return best;
 }
 
+
+// ------------------------------------------------------------------------------ weight gradient, reference precision
+// D3_CONV_F32: dW[k] = sum_u G[tbl[u,k]]^T (x) Sm[u] with exact fp32 products on v_mfma_f32_16x16x4_f32.  No LDS staging:
+// the MFMA operands are read straight from memory -- A[i = lane & 15][kk = lane >> 4] = (x side)[row kk][ci0 + i],
+// B[kk][j = lane & 15] = (dy side)[row kk][co0 + j], four rows per step, 64 contiguous bytes per row and tile.  Grid =
+// (row ranges, offsets); a workgroup's 4 waves take interleaved 4-row groups of the range, accumulate up to 2 x 2 tiles per
+// pass, and are summed through LDS in wave order; row ranges write partial dW that wgrad2_reduce_kernel adds in range
+// order: deterministic, no atomics.  HBM: every operand row is read once per (offset, pass) -- priced for parity runs, not
+// for the bf16 headline.
+struct WgfArgs {
+    const float *G, *Sm;        // gathered operand (rows tbl[u][k]) and stationary operand (row u)
+    const int *tbl;             // (Ms, K) or NULL (identity, K == 1)
+    float *dst;                 // partials [R][K][CinW][Cout]
+    int ldg, lds, Ms, K, gx;    // gx: the gathered operand is x (else dy: D3_CONV_XSTAT)
+    int Cin, CinW, Cout, flipk, rows_per;   // rows per range (multiple of 16)
+};
+__global__ __launch_bounds__(256) void spconv_wgrad_f32_kernel(const WgfArgs a) {
+    __shared__ float redS[4][4][4][64];     // wave, tile, q, lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kk = lane >> 4;
+    const int r = blockIdx.x, k = blockIdx.y;
+    const int u0 = r * a.rows_per, u1 = min(a.Ms, u0 + a.rows_per);
+    const int kd = a.flipk ? a.K - 1 - k : k;
+    const float *X = a.gx ? a.G : a.Sm, *Y = a.gx ? a.Sm : a.G;      // x side (ci), dy side (co)
+    const int ldx = a.gx ? a.ldg : a.lds, ldy = a.gx ? a.lds : a.ldg;
+    const int MT = (a.Cin + 15) / 16, NT = (a.Cout + 15) / 16;
+    float *out = a.dst + ((size_t)r * a.K + kd) * a.CinW * a.Cout;
+    for (int mb = 0; mb < MT; mb += 2) {
+        for (int nb = 0; nb < NT; nb += 2) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int ci0 = mb * 16 + i16, ci1 = ci0 + 16, co0 = nb * 16 + i16, co1 = co0 + 16;
+            const bool m1 = mb + 1 < MT, n1 = nb + 1 < NT;
+            for (int u = u0 + wave * 4; u < u1; u += 16) {
+                const int row = u + kk;
+                const bool live = row < u1;
+                int g = live ? (a.tbl ? a.tbl[(long long)row * a.K + k] : row) : -1;
+                const long long gr = g >= 0 ? g : 0, sr = live ? row : 0;
+                const long long xr = a.gx ? gr : sr, yr = a.gx ? sr : gr;
+                const bool ok = live && g >= 0;
+                float x0 = X[xr * ldx + (ci0 < a.Cin ? ci0 : 0)], x1 = m1 ? X[xr * ldx + (ci1 < a.Cin ? ci1 : 0)] : 0.f;
+                float y0 = Y[yr * ldy + (co0 < a.Cout ? co0 : 0)], y1 = n1 ? Y[yr * ldy + (co1 < a.Cout ? co1 : 0)] : 0.f;
+                if (!ok || ci0 >= a.Cin) x0 = 0.f;
+                if (!ok || ci1 >= a.Cin) x1 = 0.f;
+                if (!ok || co0 >= a.Cout) y0 = 0.f;
+                if (!ok || co1 >= a.Cout) y1 = 0.f;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y0, acc[0][0], 0, 0, 0);
+                if (n1) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y1, acc[0][1], 0, 0, 0);
+                if (m1) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y0, acc[1][0], 0, 0, 0);
+                if (m1 && n1) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();     // (redS of the previous pass has been read)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) redS[wave][p * 2 + q][e][lane] = acc[p][q][e];
+            __syncthreads();
+            // D layout: row (= ci) (lane >> 4) * 4 + e, column (= co) lane & 15; 4 tiles x 256 elements over 256 threads
+            for (int tIdx = 0; tIdx < 4; tIdx++) {
+                const int p = tIdx >> 1, q = tIdx & 1;
+                const int t = threadIdx.x, ln = t & 63, e = t >> 6;
+                const float v = redS[0][tIdx][e][ln] + redS[1][tIdx][e][ln] + redS[2][tIdx][e][ln] + redS[3][tIdx][e][ln];
+                const int ci = (mb + p) * 16 + (ln >> 4) * 4 + e, co = (nb + q) * 16 + (ln & 15);
+                if (mb + p < MT && nb + q < NT && ci < a.CinW && co < a.Cout) out[(size_t)ci * a.Cout + co] = v;
+            }
+        }
+    }
+}
+
 struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw, wide, tr; int rsg, dg, imgg, rss, dss, imgs; size_t lds, ws_bytes; const Wg3Cfg *w3; };
 
 // D3_WG2_TR=0 selects the first staging scheme (transposed ds_write_b16 images) for A/B measurements
@@ -1530,6 +1699,21 @@ static Wg2Plan wg2_plan(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout
 
 static Wg2Plan wg2_plan_flags(int Min, int Mout, int K, int Cin, int Cout, int flags) {
     const bool xstat = (flags & D3_CONV_XSTAT) != 0, xbf = (flags & D3_CONV_XBF16) != 0, dybf = (flags & D3_CONV_DYBF16) != 0;
+    if (flags & D3_CONV_F32) {       // spconv_wgrad_f32_kernel: row ranges x offsets, always through the partials
+        Wg2Plan p;
+        memset(&p, 0, sizeof(p));
+        const int Ms = xstat ? Min : Mout;
+        int R = (2048 + K - 1) / K;
+        const int maxR = (Ms + 255) / 256; if (R > maxR) R = maxR;
+        const long long wsz = (long long)K * Cin * Cout * 4;
+        const long long maxR_mem = (64ll << 20) / wsz; if (R > maxR_mem) R = (int)maxR_mem;
+        if (R < 1) R = 1;
+        p.cpw = ((Ms + R - 1) / R + 15) / 16 * 16;          // rows per range
+        if (p.cpw < 16) p.cpw = 16;
+        p.R = (Ms + p.cpw - 1) / p.cpw; if (p.R < 1) p.R = 1;
+        p.ws_bytes = (size_t)p.R * wsz;
+        return p;
+    }
     return xstat ? wg2_plan(Min, Mout, K, Cout, Cin, Cin, Cout, false, dybf, xbf) : wg2_plan(Mout, Min, K, Cin, Cout, Cin, Cout, true, xbf, dybf);
 }
 
@@ -1588,6 +1772,26 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     const long long wn = (long long)K * CinW * Cout;   // dW is (K, CinW, Cout): x may carry zero-padded channels
     const int Ms = xstat ? Min : Mout;
     if (Ms <= 0) { if (!accum) D3_CHECK(hipMemsetAsync(dW, 0, wn * 4, s)); return 0; }
+    if (flags & D3_CONV_F32) {
+        if (xbf || dybf) return D3_ERR_ARG;
+        const Wg2Plan p = wg2_plan_flags(Min, Mout, K, Cin, Cout, flags);
+        if ((size_t)p.R * wn * 4 > ws_bytes) return D3_ERR_WORKSPACE;
+        WgfArgs f;
+        if (xstat) { f.Sm = (const float *)x; f.lds = ldx; f.G = (const float *)dy; f.ldg = ldy; f.gx = 0; }
+        else { f.Sm = (const float *)dy; f.lds = ldy; f.G = (const float *)x; f.ldg = ldx; f.gx = 1; }
+        f.tbl = tbl; f.dst = (float *)ws; f.Ms = Ms; f.K = K; f.Cin = Cin; f.CinW = CinW; f.Cout = Cout;
+        f.flipk = (flags & D3_CONV_FLIPK) ? 1 : 0; f.rows_per = p.cpw;
+        const double bytes32 = 4.0 * (double)Min * Cin + 4.0 * (double)Mout * Cout + 4.0 * (double)wn + (tbl ? 4.0 * (double)Ms * K : 0.0);
+        void *pr32 = d3_prof_begin(1, bytes32, 0.0, s);
+        spconv_wgrad_f32_kernel<<<dim3(p.R, K), 256, 0, s>>>(f);
+        D3_LAUNCH_CHECK();
+        if (!(flags & D3_CONV_NOREDUCE)) {
+            wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
+            D3_LAUNCH_CHECK();
+        }
+        d3_prof_end(pr32, s);
+        return 0;
+    }
     Wg2Args a;
     if (xstat) { a.Sm = x; a.lds = ldx; a.sbf16 = xbf; a.G = dy; a.ldg = ldy; a.gbf16 = dybf; a.gx = 0; }
     else { a.Sm = dy; a.lds = ldy; a.sbf16 = dybf; a.G = x; a.ldg = ldx; a.gbf16 = xbf; a.gx = 1; }

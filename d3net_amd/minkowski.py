@@ -28,8 +28,10 @@ from ._lib import check
 from .pointgroup_ops import _on, _ptr, _stream, _workspace
 
 D3_CONV_FLIPK, D3_CONV_TRANSW, D3_CONV_EXACT, D3_CONV_XSTAT, D3_CONV_ACCUM, D3_CONV_XBF16, D3_CONV_DYBF16 = 1, 2, 4, 8, 16, 32, 64
+D3_CONV_F32 = 256   # reference precision on the matrix cores: fp32 operands, v_mfma_f32_16x16x4_f32 (csrc/spconv2.hip)
 
-_EXACT = False  # True: fp32 FMA kernels (validation); False: bf16 MFMA with fp32 accumulate
+_EXACT = False  # True: the reference's precision (fp32 storage, fp32 products, fp32 accumulate); False: bf16 MFMA operands
+_EXACT_FMA = False   # with _EXACT: the one-thread-per-output FMA validation kernels instead of the fp32 MFMA kernels
 
 
 def set_exact(flag):
@@ -169,16 +171,28 @@ def cat(*tensors):
 _GEN2 = True   # second-generation kernels (csrc/spconv2.hip) whenever the channel counts allow
 
 
+def _f32():
+    """exact mode runs the fp32-MFMA kernels (D3_CONV_F32) unless the FMA validation kernels are asked for"""
+    return D3_CONV_F32 if (_EXACT and not _EXACT_FMA) else 0
+
+
 def _conv_call(x, tbl, W3, Mout, K, Cin, Cout, flags):
+    if _f32() and _GEN2 and Cin % 8 != 0 and Cout % 4 == 0 and not flags & D3_CONV_TRANSW:
+        # (the 134-channel stem in exact mode: zero-padded to a multiple of 8 channels, like the executor's PADCAST)
+        pad = (-Cin) % 8
+        x = torch.nn.functional.pad(x, (0, pad))
+        W3 = torch.nn.functional.pad(W3, (0, 0, 0, pad))
+        Cin += pad
     out = torch.empty((Mout, Cout), dtype=torch.float32, device=x.device)
-    if _GEN2 and not _EXACT and Cin % 8 == 0 and Cout % 4 == 0:
+    if _GEN2 and (not _EXACT or _f32()) and Cin % 8 == 0 and Cout % 4 == 0:
         L = _lib.lib()
-        wp = _workspace(L.d3_spconv_pack_bytes(K, Cin, Cout), x.device, "wpack")
+        f32 = _f32()
+        wp = _workspace(L.d3_spconv_pack_bytes_ex(K, Cin, Cout, f32), x.device, "wpack")
         with _on(x.device):
-            check(L.d3_spconv_pack(_ptr(W3), _ptr(wp), K, Cin, Cout, flags & (D3_CONV_FLIPK | D3_CONV_TRANSW), _stream()),
+            check(L.d3_spconv_pack(_ptr(W3), _ptr(wp), K, Cin, Cout, flags & (D3_CONV_FLIPK | D3_CONV_TRANSW) | f32, _stream()),
                   "spconv_pack")
             check(L.d3_spconv_fwd2(_ptr(x), Cin, _ptr(tbl) if tbl is not None else None, _ptr(wp), _ptr(out), Cout,
-                                   None, 0, None, x.size(0), Mout, K, Cin, Cout, flags & D3_CONV_XBF16, _stream()),
+                                   None, 0, None, x.size(0), Mout, K, Cin, Cout, flags & D3_CONV_XBF16 | f32, _stream()),
                   "spconv_fwd2")
         return out
     with _on(x.device):
@@ -225,12 +239,17 @@ def _conv_wgrad(x, tbl_f, tbl_b, dy, W3, Mout, bwd_flags, xflag=0):
         tbl, wflags = tbl_b, D3_CONV_XSTAT | (bwd_flags & D3_CONV_FLIPK)
     else:
         tbl, wflags = tbl_f, 0
-    if _GEN2 and not _EXACT and Cin % 8 == 0 and Cout % 8 == 0:
+    CinP = Cin
+    if _f32() and _GEN2 and Cin % 8 != 0 and Cout % 8 == 0:     # (the stem in exact mode: zero-padded channels, dW keeps Cin rows)
+        CinP = Cin + (-Cin) % 8
+        x = torch.nn.functional.pad(x, (0, CinP - Cin))
+    if _GEN2 and (not _EXACT or _f32()) and CinP % 8 == 0 and Cout % 8 == 0:
         L = _lib.lib()
-        ws = _workspace(max(L.d3_spconv_wgrad2_ws_bytes(x.size(0), Mout, K, Cin, Cout, wflags | xflag), 16), x.device, "wgrad")
+        wflags |= _f32()
+        ws = _workspace(max(L.d3_spconv_wgrad2_ws_bytes(x.size(0), Mout, K, CinP, Cout, wflags | xflag), 16), x.device, "wgrad")
         with _on(x.device):
-            check(L.d3_spconv_wgrad2(_ptr(x), Cin, _ptr(tbl) if tbl is not None else None, _ptr(dy), Cout, _ptr(dW),
-                                     x.size(0), Mout, K, Cin, Cout, Cin, wflags | xflag, _ptr(ws), ws.numel(), _stream()),
+            check(L.d3_spconv_wgrad2(_ptr(x), CinP, _ptr(tbl) if tbl is not None else None, _ptr(dy), Cout, _ptr(dW),
+                                     x.size(0), Mout, K, CinP, Cout, Cin, wflags | xflag, _ptr(ws), ws.numel(), _stream()),
                   "spconv_wgrad2")
         return dW
     with _on(x.device):

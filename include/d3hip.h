@@ -212,6 +212,9 @@ int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int 
 #define D3_CONV_ACCUM 16
 #define D3_CONV_XBF16 32   /* x is stored as bf16 (ushort), Cin % 8 == 0; not with D3_CONV_EXACT */
 #define D3_CONV_DYBF16 64  /* dy is stored as bf16 (d3_spconv_wgrad2 only) */
+#define D3_CONV_F32 256    /* d3_spconv_pack / d3_spconv_fwd2* / d3_spconv_wgrad2: the REFERENCE'S PRECISION on the matrix cores -- fp32
+                            * operands (x, dy fp32; weights packed as fp32 fragments: d3_spconv_pack_bytes_ex), exact fp32 products on
+                            * v_mfma_f32_16x16x4_f32, fp32 accumulation.  Not with D3_CONV_XBF16 / D3_CONV_DYBF16. */
 #define D3_CONV_NOREDUCE 128 /* d3_spconv_wgrad2: leave the row-split partials in ws (d3_spconv_wgrad2_splits() of them, or one
                               * when accumulating); the caller sums them (the executor does it for all layers in one launch) */
 int d3_spconv_fwd(const float *x, const int *tbl, const float *W, float *out, int Min, int Mout, int K, int Cin,
@@ -235,8 +238,10 @@ int d3_spconv_wgrad(const float *x, const int *tbl, const float *dy, float *dW, 
  *   wgrad2 : dW (K,CinW,Cout) f32 (CinW <= Cin: x may carry zero-padded channels) written (accumulated into with D3_CONV_ACCUM); ws >= d3_spconv_wgrad2_ws_bytes()
  *            holds row-split partials that are summed in fixed order (deterministic, no atomics). */
 size_t d3_spconv_pack_bytes(int K, int Cin, int Cout);
+size_t d3_spconv_pack_bytes_ex(int K, int Cin, int Cout, int flags);   /* flags & D3_CONV_F32: fp32 fragments (2x) */
 int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream);
 int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout);
+int d3_spconv_fwd2_nparts_ex(int Mout, int K, int Cin, int Cout, int flags);   /* flags & D3_CONV_F32: that call's partial rows */
 /* which kernel fwd2 runs for a shape (tests assert the variant they mean to cover): out[6] = {split (1 = the few-row
  * spconv_fwd2_split_kernel, 0 = the persistent wave-per-tile spconv_fwd2_kernel), waves per workgroup, grid.x,
  * weights resident in LDS, column tiles per workgroup, grid.y} */

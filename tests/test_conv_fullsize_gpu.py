@@ -255,3 +255,59 @@ def test_wgrad2_row_splits_and_reduction(dev, canon, level, kind, cin, cout, xbf
         assert L.d3_spconv_wgrad2(_ptr(xd), cin, _ptr(tbl) if tbl is not None else None, _ptr(dyb), cout, _ptr(dW2), Min, Mout, K, cin, cout,
                                   cin, fl, _ptr(wsb), wsb.numel(), _stream()) == 0
         assert torch.equal(dW1, dW2)
+
+
+# ------------------------------------------------------------------------------------------- reference precision (D3_CONV_F32)
+F32 = 256
+
+
+@pytest.mark.parametrize("level,kind,cin,cout", CASES + [(1, "down", 32, 48)])
+def test_f32_mfma_kernels_match_the_fp32_oracle(dev, canon, level, kind, cin, cout):
+    """D3_CONV_F32 (csrc/spconv2.hip): fp32 operands, exact fp32 products on v_mfma_f32_16x16x4_f32, fp32 accumulation -- the
+    reference's precision (MinkowskiEngine is fp32 throughout: model/common.py:32-41).  Forward, data gradient and weight
+    gradient at canonical row counts against the fp32 oracle: 2e-6 of the output scale (summation order only), i.e. four
+    orders of magnitude below the bf16 path's 2e-2.  (1, down, 32 -> 48) lands on 8,282 rows: the few-row split kernel."""
+    from d3net_amd import _lib
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    L = _lib.lib()
+    tbl_f, tbl_b, Min, Mout, K, flip, conv = _geom(canon, level, kind)
+    rng = np.random.default_rng(level * 100 + cin + cout + 31)
+    x = torch.from_numpy(rng.standard_normal((Min, cin)).astype(np.float32)).requires_grad_(True)
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rng.standard_normal((Mout, cout)).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((Mout, cout)).astype(np.float32))
+    so.set_precision("fp32")
+    ref = conv(x, W)
+    ref.backward(dy)
+    xd, Wd, dyd, resd = x.detach().to(dev), W.detach().to(dev).contiguous(), dy.to(dev), res.to(dev)
+
+    def pack(flags):
+        Kk, a, b = Wd.shape
+        ci, co = (b, a) if flags & TRANSW else (a, b)
+        wp = torch.empty(L.d3_spconv_pack_bytes_ex(Kk, ci, co, F32), dtype=torch.uint8, device=dev)
+        assert L.d3_spconv_pack(_ptr(Wd), _ptr(wp), Kk, ci, co, flags | F32, _stream()) == 0
+        return wp
+
+    # forward (+ residual epilogue)
+    out = torch.full((Mout, cout), float("nan"), device=dev)
+    _fwd2(L, xd, tbl_f, pack(0), out, Mout, K, cin, cout, flags=F32, res=resd)
+    assert relerr(out, ref.detach() + res) < 2e-6, relerr(out, ref.detach() + res)
+    # the bf16-input flag is refused with D3_CONV_F32
+    assert L.d3_spconv_fwd2(_ptr(xd), cin, _ptr(tbl_f) if tbl_f is not None else None, _ptr(pack(0)), _ptr(out), cout, None, 0, None,
+                            Min, Mout, K, cin, cout, F32 | XBF16, _stream()) == -3
+    # data gradient
+    if cin % 4 == 0 and cin != 136:
+        dx = torch.full((Min, cin), float("nan"), device=dev)
+        _fwd2(L, dyd, tbl_b, pack(flip | TRANSW), dx, Min, K, cout, cin, flags=F32)
+        assert relerr(dx, x.grad) < 2e-6, relerr(dx, x.grad)
+    # weight gradient (x- or dy-stationary as the executor picks), accumulate semantics
+    xstat = cin > cout
+    flags = ((XSTAT | flip) if xstat else 0) | F32
+    tbl = tbl_b if xstat else tbl_f
+    ws = torch.empty(max(L.d3_spconv_wgrad2_ws_bytes(Min, Mout, K, cin, cout, flags), 16), dtype=torch.uint8, device=dev)
+    dW = torch.full((K, cin, cout), float("nan"), device=dev)
+    args = (_ptr(xd), cin, _ptr(tbl) if tbl is not None else None, _ptr(dyd), cout, _ptr(dW), Min, Mout, K, cin, cout, cin)
+    assert L.d3_spconv_wgrad2(*args, flags, _ptr(ws), ws.numel(), _stream()) == 0
+    assert relerr(dW, W.grad) < 5e-6, relerr(dW, W.grad)
+    assert L.d3_spconv_wgrad2(*args, flags | ACCUM, _ptr(ws), ws.numel(), _stream()) == 0
+    assert relerr(dW, 2 * W.grad) < 5e-6
