@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-teacher", action="store_true", help="cluster on the network's own predictions")
     ap.add_argument("--small", action="store_true", help="quarter-size scenes (debug)")
+    ap.add_argument("--exact", action="store_true",
+                    help="time the step at the REFERENCE'S precision (minkowski.set_exact: fp32 storage, fp32 MFMA convolutions) instead of bf16")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: the config's scenes per rank per step (4); strong: the GLOBAL batch is fixed at 8 scenes, 8/N per rank")
     return ap.parse_args()
@@ -364,6 +366,8 @@ def main():
         opt.step()
         return loss, d
 
+    if args.exact:
+        ME.set_exact(True)
     L = _lib.lib()
     # set-up, not a step of the run: one dry pass sizes the cached workspaces (the clustering scratch is several GB) and
     # loads the code objects, so that a run with a very small --warmup does not time one-off allocations ("setup")
@@ -429,7 +433,9 @@ def main():
 
     # reference precision beside the bf16 number: a few untimed-for-`value` steps with the exact-fp32 kernels
     fp32 = None
-    if world == 1 and not args.no_fp32:
+    if args.exact:
+        ME.set_exact(False)
+    if world == 1 and not args.no_fp32 and not args.exact:
         ME.set_exact(True)
         try:
             step(); torch.cuda.synchronize()
@@ -440,8 +446,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             fp32 = {"value": n_scenes * k / dt, "unit": "scenes/sec", "ms_per_step": 1e3 * dt / k, "steps": k,
-                    "note": "same step with minkowski.set_exact(True): fp32 storage and fp32 FMA convolutions (the "
-                            "reference's precision; validation kernels, not tuned), module-by-module path"}
+                    "note": "same step with minkowski.set_exact(True): the reference's precision -- fp32 storage, exact fp32 products on "
+                            "v_mfma_f32_16x16x4_f32 (D3_CONV_F32 kernels), through the native executor's fp32 program"}
         finally:
             ME.set_exact(False)
 
@@ -477,7 +483,7 @@ def main():
             "metric": METRIC[config], "value": world * n_scenes * args.steps / elapsed,
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.exact else "bf16", "data": "synthetic",
             "config": {"workload": workload + " (%d voxels, %d points, 134 ch per step)" % (n_voxels, n_points),
                        "scenes_per_gpu": n_scenes, "global_batch": world * n_scenes, "points": n_points, "voxels": n_voxels,
                        "raw_proposals": int(d.get("num_raw_proposals", 0)),
@@ -487,7 +493,8 @@ def main():
                                  "backend": dist.get_backend() if world > 1 else None,
                                  "scaling": "weak: %d scenes per rank per step" % n_scenes if args.scaling == "weak" else
                                             "strong: global batch fixed at %d scenes, %d per rank" % (STRONG_GLOBAL_BATCH, n_scenes)},
-                       "precision": "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate; heads fp32",
+                       "precision": ("fp32 storage, exact fp32 products on v_mfma_f32_16x16x4_f32, fp32 accumulate (the reference's precision)" if args.exact else
+                                     "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate; heads fp32"),
                        "setup": "1 untimed dry-run step before the warm-up (workspace allocation, code-object loads)"},
             "final_loss": final_loss, "fp32_exact": fp32,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1569,73 +1569,116 @@ static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, in
 // ------------------------------------------------------------------------------ weight gradient, reference precision
 // D3_CONV_F32: dW[k] = sum_u G[tbl[u,k]]^T (x) Sm[u] with exact fp32 products on v_mfma_f32_16x16x4_f32.  No LDS staging:
 // the MFMA operands are read straight from memory -- A[i = lane & 15][kk = lane >> 4] = (x side)[row kk][ci0 + i],
-// B[kk][j = lane & 15] = (dy side)[row kk][co0 + j], four rows per step, 64 contiguous bytes per row and tile.  Grid =
-// (row ranges, offsets); a workgroup's 4 waves take interleaved 4-row groups of the range, accumulate up to 2 x 2 tiles per
-// pass, and are summed through LDS in wave order; row ranges write partial dW that wgrad2_reduce_kernel adds in range
-// order: deterministic, no atomics.  HBM: every operand row is read once per (offset, pass) -- priced for parity runs, not
-// for the bf16 headline.
+// B[kk][j = lane & 15] = (dy side)[row kk][co0 + j], four rows per step, 64 contiguous bytes per row and tile.
+// A workgroup owns (a row range, a group of OW offsets, a BG x BS block of tiles): the stationary operand's rows are read
+// ONCE per step and serve all OW offsets (one workgroup per offset re-read them 27 times: 2.3 GB per level-0 launch); its
+// 4 waves take interleaved 4-row groups, keep OW x BG x BS accumulator tiles (<= 18), and are summed through LDS in
+// wave order; row ranges write partial dW that wgrad2_reduce_kernel adds in range order: deterministic, no atomics.
 struct WgfArgs {
     const float *G, *Sm;        // gathered operand (rows tbl[u][k]) and stationary operand (row u)
     const int *tbl;             // (Ms, K) or NULL (identity, K == 1)
     float *dst;                 // partials [R][K][CinW][Cout]
     int ldg, lds, Ms, K, gx;    // gx: the gathered operand is x (else dy: D3_CONV_XSTAT)
-    int Cin, CinW, Cout, flipk, rows_per;   // rows per range (multiple of 16)
+    int Cg, Cs;                 // channels of the gathered / stationary operand
+    int CinW, Cout, flipk, rows_per;   // rows per range (multiple of 16)
+    int ngb, nsb;               // tile blocks of the gathered / stationary side
 };
+template <int BG, int BS, int OW>
 __global__ __launch_bounds__(256) void spconv_wgrad_f32_kernel(const WgfArgs a) {
-    __shared__ float redS[4][4][4][64];     // wave, tile, q, lane
+    __shared__ float redS[4][4][64];     // wave, q, lane: one tile at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kk = lane >> 4;
-    const int r = blockIdx.x, k = blockIdx.y;
+    const int r = blockIdx.x;
+    const int k0 = blockIdx.y * OW;
+    const int gb = (int)blockIdx.z / a.nsb, sb = (int)blockIdx.z - gb * a.nsb;
     const int u0 = r * a.rows_per, u1 = min(a.Ms, u0 + a.rows_per);
-    const int kd = a.flipk ? a.K - 1 - k : k;
-    const float *X = a.gx ? a.G : a.Sm, *Y = a.gx ? a.Sm : a.G;      // x side (ci), dy side (co)
-    const int ldx = a.gx ? a.ldg : a.lds, ldy = a.gx ? a.lds : a.ldg;
-    const int MT = (a.Cin + 15) / 16, NT = (a.Cout + 15) / 16;
-    float *out = a.dst + ((size_t)r * a.K + kd) * a.CinW * a.Cout;
-    for (int mb = 0; mb < MT; mb += 2) {
-        for (int nb = 0; nb < NT; nb += 2) {
-            f32x4 acc[2][2];
+    f32x4 acc[OW][BG][BS];
 #pragma unroll
-            for (int p = 0; p < 2; p++)
+    for (int o = 0; o < OW; o++)
 #pragma unroll
-                for (int q = 0; q < 2; q++) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int ci0 = mb * 16 + i16, ci1 = ci0 + 16, co0 = nb * 16 + i16, co1 = co0 + 16;
-            const bool m1 = mb + 1 < MT, n1 = nb + 1 < NT;
-            for (int u = u0 + wave * 4; u < u1; u += 16) {
-                const int row = u + kk;
-                const bool live = row < u1;
-                int g = live ? (a.tbl ? a.tbl[(long long)row * a.K + k] : row) : -1;
-                const long long gr = g >= 0 ? g : 0, sr = live ? row : 0;
-                const long long xr = a.gx ? gr : sr, yr = a.gx ? sr : gr;
-                const bool ok = live && g >= 0;
-                float x0 = X[xr * ldx + (ci0 < a.Cin ? ci0 : 0)], x1 = m1 ? X[xr * ldx + (ci1 < a.Cin ? ci1 : 0)] : 0.f;
-                float y0 = Y[yr * ldy + (co0 < a.Cout ? co0 : 0)], y1 = n1 ? Y[yr * ldy + (co1 < a.Cout ? co1 : 0)] : 0.f;
-                if (!ok || ci0 >= a.Cin) x0 = 0.f;
-                if (!ok || ci1 >= a.Cin) x1 = 0.f;
-                if (!ok || co0 >= a.Cout) y0 = 0.f;
-                if (!ok || co1 >= a.Cout) y1 = 0.f;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y0, acc[0][0], 0, 0, 0);
-                if (n1) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y1, acc[0][1], 0, 0, 0);
-                if (m1) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y0, acc[1][0], 0, 0, 0);
-                if (m1 && n1) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y1, acc[1][1], 0, 0, 0);
-            }
-            __syncthreads();     // (redS of the previous pass has been read)
+        for (int p = 0; p < BG; p++)
 #pragma unroll
-            for (int p = 0; p < 2; p++)
+            for (int q = 0; q < BS; q++) acc[o][p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cg[BG], cs[BS];
 #pragma unroll
-                for (int q = 0; q < 2; q++)
+    for (int p = 0; p < BG; p++) cg[p] = (gb * BG + p) * 16 + i16;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) redS[wave][p * 2 + q][e][lane] = acc[p][q][e];
-            __syncthreads();
-            // D layout: row (= ci) (lane >> 4) * 4 + e, column (= co) lane & 15; 4 tiles x 256 elements over 256 threads
-            for (int tIdx = 0; tIdx < 4; tIdx++) {
-                const int p = tIdx >> 1, q = tIdx & 1;
-                const int t = threadIdx.x, ln = t & 63, e = t >> 6;
-                const float v = redS[0][tIdx][e][ln] + redS[1][tIdx][e][ln] + redS[2][tIdx][e][ln] + redS[3][tIdx][e][ln];
-                const int ci = (mb + p) * 16 + (ln >> 4) * 4 + e, co = (nb + q) * 16 + (ln & 15);
-                if (mb + p < MT && nb + q < NT && ci < a.CinW && co < a.Cout) out[(size_t)ci * a.Cout + co] = v;
+    for (int q = 0; q < BS; q++) cs[q] = (sb * BS + q) * 16 + i16;
+    for (int u = u0 + wave * 4; u < u1; u += 16) {
+        const int row = u + kk;
+        const bool live = row < u1;
+        const long long sr = live ? row : 0;
+        float sv[BS];
+#pragma unroll
+        for (int q = 0; q < BS; q++) { sv[q] = a.Sm[sr * a.lds + (cs[q] < a.Cs ? cs[q] : 0)]; if (!live || cs[q] >= a.Cs) sv[q] = 0.f; }
+        // every load of the step is issued before the first MFMA (a use right behind a load serialises the round trips):
+        // the OW kernel-map entries, then the OW x BG gathered values -- absent neighbours / offsets read row 0 and are zeroed
+        int g[OW];
+#pragma unroll
+        for (int o = 0; o < OW; o++) g[o] = (live && k0 + o < a.K) ? (a.tbl ? a.tbl[(long long)row * a.K + k0 + o] : row) : -1;
+        float gv[OW][BG];
+#pragma unroll
+        for (int o = 0; o < OW; o++) {
+            const long long gr = g[o] >= 0 ? g[o] : 0;
+#pragma unroll
+            for (int p = 0; p < BG; p++) gv[o][p] = a.G[gr * a.ldg + (cg[p] < a.Cg ? cg[p] : 0)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < OW; o++) {
+#pragma unroll
+            for (int p = 0; p < BG; p++) {
+                const float v = (g[o] < 0 || cg[p] >= a.Cg) ? 0.f : gv[o][p];
+#pragma unroll
+                for (int q = 0; q < BS; q++)     // D[x-side channel][dy-side channel]: the x operand goes first
+                    acc[o][p][q] = a.gx ? __builtin_amdgcn_mfma_f32_16x16x4f32(v, sv[q], acc[o][p][q], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_16x16x4f32(sv[q], v, acc[o][p][q], 0, 0, 0);
             }
         }
     }
+    // D layout: row (= ci) (lane >> 4) * 4 + e, column (= co) lane & 15
+#pragma unroll
+    for (int o = 0; o < OW; o++) {
+        if (k0 + o >= a.K) break;      // (uniform)
+        const int kd = a.flipk ? a.K - 1 - (k0 + o) : k0 + o;
+        float *out = a.dst + ((size_t)r * a.K + kd) * a.CinW * a.Cout;
+#pragma unroll
+        for (int p = 0; p < BG; p++)
+#pragma unroll
+            for (int q = 0; q < BS; q++) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; e++) redS[wave][e][lane] = acc[o][p][q][e];
+                __syncthreads();
+                const int t = threadIdx.x, ln = t & 63, e = t >> 6;
+                const float v = redS[0][e][ln] + redS[1][e][ln] + redS[2][e][ln] + redS[3][e][ln];
+                const int tg = (gb * BG + p) * 16, ts = (sb * BS + q) * 16;
+                const int ci = (a.gx ? tg : ts) + (ln >> 4) * 4 + e, co = (a.gx ? ts : tg) + (ln & 15);
+                if (ci < a.CinW && co < a.Cout) out[(size_t)ci * a.Cout + co] = v;
+            }
+    }
+}
+struct WgfCfg { int bg, bs, ow; };
+// block of tiles per workgroup and offsets per group: OW * BG * BS <= 18 accumulator tiles
+static WgfCfg wgf_cfg(int Cg, int Cs, int K) {
+    const int tg = (Cg + 15) / 16, ts = (Cs + 15) / 16;
+    WgfCfg c;
+    c.bg = tg >= 3 ? 3 : tg; c.bs = ts >= 3 ? 3 : ts;
+    // (register budget: accumulators + the step's gathered values must leave room for >= 2 waves per SIMD -- the kernel is a
+    // chain of memory round trips, one wave per SIMD left it at 400 us for a level-0 16 -> 16 layer)
+    static const int ow_of[4][4] = {{0, 0, 0, 0}, {0, 14, 9, 5}, {0, 9, 4, 3}, {0, 5, 3, 2}};
+    c.ow = ow_of[c.bg][c.bs];
+    if (K <= 8 && c.ow > 8) c.ow = 8;
+    if (K == 1) c.ow = 1;
+    return c;
+}
+static int launch_wgf(const WgfArgs &a, const WgfCfg &c, int R, hipStream_t s) {
+    const dim3 grid(R, (a.K + c.ow - 1) / c.ow, a.ngb * a.nsb);
+#define WGF_CASE(BGV, BSV, OWV) if (c.bg == BGV && c.bs == BSV && c.ow == OWV) { spconv_wgrad_f32_kernel<BGV, BSV, OWV><<<grid, 256, 0, s>>>(a); D3_LAUNCH_CHECK(); return 0; }
+    WGF_CASE(1, 1, 14) WGF_CASE(1, 1, 8) WGF_CASE(1, 2, 9) WGF_CASE(1, 2, 8) WGF_CASE(2, 1, 9) WGF_CASE(2, 1, 8) WGF_CASE(1, 3, 5)
+    WGF_CASE(3, 1, 5) WGF_CASE(2, 2, 4) WGF_CASE(2, 3, 3) WGF_CASE(3, 2, 3) WGF_CASE(3, 3, 2)
+    WGF_CASE(1, 1, 1) WGF_CASE(1, 2, 1) WGF_CASE(2, 1, 1) WGF_CASE(1, 3, 1) WGF_CASE(3, 1, 1) WGF_CASE(2, 2, 1) WGF_CASE(2, 3, 1) WGF_CASE(3, 2, 1) WGF_CASE(3, 3, 1)
+#undef WGF_CASE
+    return D3_ERR_ARG;
 }
 
 struct Wg2Plan { int tpo, nu, opw, kg, passes, R, cpw, wide, tr; int rsg, dg, imgg, rss, dss, imgs; size_t lds, ws_bytes; const Wg3Cfg *w3; };
@@ -1699,11 +1742,13 @@ static Wg2Plan wg2_plan(int Ms, int Mg, int K, int Cg, int Cs, int Cin, int Cout
 
 static Wg2Plan wg2_plan_flags(int Min, int Mout, int K, int Cin, int Cout, int flags) {
     const bool xstat = (flags & D3_CONV_XSTAT) != 0, xbf = (flags & D3_CONV_XBF16) != 0, dybf = (flags & D3_CONV_DYBF16) != 0;
-    if (flags & D3_CONV_F32) {       // spconv_wgrad_f32_kernel: row ranges x offsets, always through the partials
+    if (flags & D3_CONV_F32) {       // spconv_wgrad_f32_kernel: (row ranges) x (offset groups) x (tile blocks), always through the partials
         Wg2Plan p;
         memset(&p, 0, sizeof(p));
         const int Ms = xstat ? Min : Mout;
-        int R = (2048 + K - 1) / K;
+        const WgfCfg cf = wgf_cfg(xstat ? Cout : Cin, xstat ? Cin : Cout, K);
+        const int per_range = ((K + cf.ow - 1) / cf.ow) * ((((xstat ? Cout : Cin) + 15) / 16 + cf.bg - 1) / cf.bg) * ((((xstat ? Cin : Cout) + 15) / 16 + cf.bs - 1) / cf.bs);
+        int R = (1536 + per_range - 1) / per_range;
         const int maxR = (Ms + 255) / 256; if (R > maxR) R = maxR;
         const long long wsz = (long long)K * Cin * Cout * 4;
         const long long maxR_mem = (64ll << 20) / wsz; if (R > maxR_mem) R = (int)maxR_mem;
@@ -1777,14 +1822,15 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         const Wg2Plan p = wg2_plan_flags(Min, Mout, K, Cin, Cout, flags);
         if ((size_t)p.R * wn * 4 > ws_bytes) return D3_ERR_WORKSPACE;
         WgfArgs f;
-        if (xstat) { f.Sm = (const float *)x; f.lds = ldx; f.G = (const float *)dy; f.ldg = ldy; f.gx = 0; }
-        else { f.Sm = (const float *)dy; f.lds = ldy; f.G = (const float *)x; f.ldg = ldx; f.gx = 1; }
-        f.tbl = tbl; f.dst = (float *)ws; f.Ms = Ms; f.K = K; f.Cin = Cin; f.CinW = CinW; f.Cout = Cout;
+        if (xstat) { f.Sm = (const float *)x; f.lds = ldx; f.G = (const float *)dy; f.ldg = ldy; f.gx = 0; f.Cs = Cin; f.Cg = Cout; }
+        else { f.Sm = (const float *)dy; f.lds = ldy; f.G = (const float *)x; f.ldg = ldx; f.gx = 1; f.Cs = Cout; f.Cg = Cin; }
+        f.tbl = tbl; f.dst = (float *)ws; f.Ms = Ms; f.K = K; f.CinW = CinW; f.Cout = Cout;
         f.flipk = (flags & D3_CONV_FLIPK) ? 1 : 0; f.rows_per = p.cpw;
+        const WgfCfg cf = wgf_cfg(f.Cg, f.Cs, K);
+        f.ngb = ((f.Cg + 15) / 16 + cf.bg - 1) / cf.bg; f.nsb = ((f.Cs + 15) / 16 + cf.bs - 1) / cf.bs;
         const double bytes32 = 4.0 * (double)Min * Cin + 4.0 * (double)Mout * Cout + 4.0 * (double)wn + (tbl ? 4.0 * (double)Ms * K : 0.0);
         void *pr32 = d3_prof_begin(1, bytes32, 0.0, s);
-        spconv_wgrad_f32_kernel<<<dim3(p.R, K), 256, 0, s>>>(f);
-        D3_LAUNCH_CHECK();
+        { const int lrc = launch_wgf(f, cf, p.R, s); if (lrc) return lrc; }
         if (!(flags & D3_CONV_NOREDUCE)) {
             wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
             D3_LAUNCH_CHECK();

@@ -15,7 +15,10 @@
 //   * backward: data gradients on the caller's stream, weight gradients on a side stream (they are off the
 //     critical path: nothing downstream consumes them until the optimizer), residual gradients alias instead of
 //     copy, gradient accumulation is fused into the kernels that produce the second contribution;
-//   * all weights are re-packed to bf16 MFMA fragment order by ONE launch per forward.
+//   * all weights are re-packed to bf16 MFMA fragment order by ONE launch per forward;
+//   * REFERENCE PRECISION: a program whose buffers are all fp32 (netexec.py builds it for minkowski.set_exact(True)) runs the
+//     same schedule with fp32 activations / gradients, fp32 weight fragments and the D3_CONV_F32 kernels of spconv2.hip
+//     (exact fp32 products on v_mfma_f32_16x16x4_f32) -- MinkowskiEngine's own precision (model/common.py:32-41).
 // Kernels used: spconv2.hip (d3_spconv_fwd2 / d3_spconv_wgrad2) and the strided BatchNorm kernels below.
 #include "common.h"
 #include <vector>
@@ -24,6 +27,8 @@
 #include <stdlib.h>
 
 extern "C" size_t d3_spconv_pack_bytes(int K, int Cin, int Cout);
+extern "C" size_t d3_spconv_pack_bytes_ex(int K, int Cin, int Cout, int flags);
+extern "C" int d3_spconv_fwd2_nparts_ex(int Mout, int K, int Cin, int Cout, int flags);
 
 // ------------------------------------------------------------------------------ small kernels
 __device__ __forceinline__ unsigned int un_pack2bf(float lo, float hi) {
@@ -32,7 +37,7 @@ __device__ __forceinline__ unsigned int un_pack2bf(float lo, float hi) {
     return (a >> 16) | (b & 0xFFFF0000u);
 }
 
-struct PackJob { const float *W; size_t dst_off; int K, S, CinW, Cout, NT, flipk, transw, Cin; long long start; };
+struct PackJob { const float *W; size_t dst_off; int K, S, CinW, Cout, NT, flipk, transw, Cin, f32; long long start; };
 
 // all convolution weights of a network -> bf16 MFMA fragment order (layout of spconv2.hip's spconv_pack_kernel)
 __global__ void un_pack_batched_kernel(const PackJob *__restrict__ jobs, int njobs, long long total, char *arena) {
@@ -56,7 +61,20 @@ __global__ void un_pack_batched_kernel(const PackJob *__restrict__ jobs, int njo
         if (j.transw) { if (co < j.Cout && ci < j.CinW) v[q] = j.W[((long long)wk * j.Cout + co) * j.CinW + ci]; }
         else if (co < j.Cout && ci < j.CinW) v[q] = j.W[((long long)wk * j.CinW + ci) * j.Cout + co];
     }
+    if (j.f32) {      // fp32 fragments (D3_CONV_F32): same element order, 32 bytes per element
+        float4 *d = (float4 *)(arena + j.dst_off) + l * 2;
+        d[0] = make_float4(v[0], v[1], v[2], v[3]); d[1] = make_float4(v[4], v[5], v[6], v[7]);
+        return;
+    }
     ((uint4 *)(arena + j.dst_off))[l] = make_uint4(un_pack2bf(v[0], v[1]), un_pack2bf(v[2], v[3]), un_pack2bf(v[4], v[5]), un_pack2bf(v[6], v[7]));
+}
+// ... and with an fp32 destination (reference-precision programs)
+__global__ void un_padcast_f32_kernel(const float *__restrict__ x, float *__restrict__ y, long long M, int Cs, int Cd) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * Cd) return;
+    const long long row = e / Cd;
+    const int c = (int)(e - row * Cd);
+    y[e] = (c < Cs) ? x[row * Cs + c] : 0.f;
 }
 
 // x (M, Cs) fp32 -> y (M, Cd) bf16, zero padded (Cd % 8 == 0): the stem convolution's operand
@@ -318,6 +336,7 @@ struct Net {
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
     bool planned = false, lastblock = false;
+    bool f32 = false;                 // every buffer fp32: reference-precision program (D3_CONV_F32 kernels, no bf16 gradients)
     size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
     // packing jobs (device copy refreshed when a parameter pointer or the arena moves)
     std::vector<PackJob> jobs;
@@ -371,6 +390,8 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         const int64_t *b = bufs + (size_t)i * 3;
         n->B.push_back(BufD{(int)b[0], (int)b[1], (int)b[2], 0, 0, 1});
     }
+    n->f32 = true;
+    for (auto &b : n->B) if (b.dtype == 1) n->f32 = false;
     for (int i = 0; i < nops; i++) {
         const int64_t *p = prog + (size_t)i * 16;
         OpD o;
@@ -475,7 +496,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         if (o.type != OP_CONV || o.in_grad_mode != 1) continue;
         for (size_t j = 0; j < n->ops.size(); j++) {
             OpD &b = n->ops[j];
-            if (b.type == OP_BNACT && b.out == o.in && b.fused_by < 0 && n->T[b.out].dtype == 1) { o.bn_of_in = (int)j; b.fused_by = (int)i; break; }
+            if (b.type == OP_BNACT && b.out == o.in && b.fused_by < 0 && (n->T[b.out].dtype == 1 || n->f32)) { o.bn_of_in = (int)j; b.fused_by = (int)i; break; }
         }
     }
     // Gradients with a single writer and a single reader pair are stored as bf16: the output gradient of a convolution whose
@@ -485,7 +506,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     // 27-fold gather and of the weight gradient's dy operand.  D3_GRAD_BF16=0 keeps them in fp32 (A/B measurements).
     n->gbf.assign(n->B.size(), 0);
     {
-        const bool on = d3_tune(D3T_GRAD_BF16) != 0;
+        const bool on = d3_tune(D3T_GRAD_BF16) != 0 && !n->f32;
         for (size_t b = 0; on && b < n->B.size(); b++) {
             if (n->galias[b] >= 0) continue;
             if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
@@ -519,7 +540,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     n->gshadow.assign(n->B.size(), 0);
     n->gshadow_off.assign(n->B.size(), 0);
     {
-        const bool on = d3_tune(D3T_GRAD_BF16) != 0;
+        const bool on = d3_tune(D3T_GRAD_BF16) != 0 && !n->f32;
         auto root_of = [&](int tensor, int &coff, int &C) {          // as gptr(): follow residual aliases
             const TensorD *t = &n->T[tensor];
             coff = t->coff; C = t->C;
@@ -608,15 +629,17 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     for (auto &o : n->ops) {
         if (o.type == OP_CONV) {
             int Min, Mout; conv_dims(n, o, Min, Mout);
-            o.wp_fwd = off; off += d3_align(d3_spconv_pack_bytes(o.K, o.Cin, o.Cout));
-            o.wp_bwd = off; if (o.needs_dgrad_pack) off += d3_align(d3_spconv_pack_bytes(o.K, o.Cout, o.Cin));
+            const int pf = n->f32 ? D3_CONV_F32 : 0;
+            o.wp_fwd = off; off += d3_align(d3_spconv_pack_bytes_ex(o.K, o.Cin, o.Cout, pf));
+            o.wp_bwd = off; if (o.needs_dgrad_pack) off += d3_align(d3_spconv_pack_bytes_ex(o.K, o.Cout, o.Cin, pf));
             if (o.stats) {
-                o.nparts = d3_spconv_fwd2_nparts(Mout, o.K, o.Cin, o.Cout);
+                o.nparts = d3_spconv_fwd2_nparts_ex(Mout, o.K, o.Cin, o.Cout, pf);
                 o.partw = (o.Cout + 15) / 16 * 16;
                 o.part_off = off; off += d3_align((size_t)o.nparts * 2 * o.partw * 4);
             }
             const int xstat = ((o.Cin > o.Cout) ? D3_CONV_XSTAT : 0) | (n->T[o.in].dtype == 1 ? D3_CONV_XBF16 : 0) |
-                              ((n->T[o.out].buf >= 0 && n->gbf[n->T[o.out].buf]) || o.use_shadow ? D3_CONV_DYBF16 : 0);   // as in d3_net_backward
+                              ((n->T[o.out].buf >= 0 && n->gbf[n->T[o.out].buf]) || o.use_shadow ? D3_CONV_DYBF16 : 0) |
+                              (n->f32 ? D3_CONV_F32 : 0);   // as in d3_net_backward
             o.wsplits = d3_spconv_wgrad2_splits(Min, Mout, o.K, o.Cin, o.Cout, xstat);
             o.wpart_bytes = d3_align((size_t)o.wsplits * o.K * o.Cin * o.Cout * 4 + 256);
         } else if (o.type == OP_STATS) {
@@ -634,7 +657,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
         if (o.type != OP_BNACT || o.fused_by < 0) continue;
         const OpD &cv = n->ops[o.fused_by];
         int Min, Mout; conv_dims(n, cv, Min, Mout);
-        o.bparts = d3_spconv_fwd2_nparts(Min, cv.K, cv.Cout, cv.CinW);
+        o.bparts = d3_spconv_fwd2_nparts_ex(Min, cv.K, cv.Cout, cv.CinW, n->f32 ? D3_CONV_F32 : 0);
         o.bpart_off = goff; goff += d3_align((size_t)o.bparts * 2 * ((cv.CinW + 15) / 16 * 16) * 4);
     }
     for (auto &o : n->ops) if (o.type == OP_CONV) { o.wpart_off = goff; goff += o.wpart_bytes; }
@@ -702,6 +725,7 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                     j.Cin = o.Cout; j.S = o.Cout / 8; j.CinW = o.Cout; j.Cout = o.CinW; j.flipk = (o.map == MAP_K3) ? 1 : 0; j.transw = 1;
                 }
                 j.NT = (j.Cout + 15) / 16;
+                j.f32 = n->f32 ? 1 : 0;
                 j.start = start;
                 start += (long long)j.K * j.S * j.NT * 16;
                 jobs.push_back(j);
@@ -731,6 +755,10 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
             const long long M = n->rows[to.level];
             const int Cs = n->T[o.in].C;
             const long long total = M * (to.C / 2);
+            if (to.dtype != 1) {
+                const long long tot32 = M * to.C;
+                if (tot32 > 0) un_padcast_f32_kernel<<<(int)((tot32 + 255) / 256), 256, 0, s>>>((const float *)input, (float *)tptr(n, arena, input, o.out), M, Cs, to.C);
+            } else
             if (total > 0) un_padcast_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>((const float *)input, (unsigned short *)tptr(n, arena, input, o.out), M, Cs, to.C);
         } else if (o.type == OP_STATS) {
             if (!training) continue;
@@ -751,10 +779,10 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                 rc = d3_spconv_fwd2_fin(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
                                         res, ldr, part, (int *)(arena + o.cnt_off), mean, var,
                                         b.rmean >= 0 ? (float *)params[b.rmean] : nullptr, b.rvar >= 0 ? (float *)params[b.rvar] : nullptr,
-                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, ti.dtype == 1 ? D3_CONV_XBF16 : 0, stream);
+                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
             } else {
                 rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
-                                    res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, ti.dtype == 1 ? D3_CONV_XBF16 : 0, stream);
+                                    res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
             }
             if (rc) return rc;
         } else if (o.type == OP_BNACT) {
@@ -894,7 +922,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     side_used = true;
                 }
                 const bool xstat = o.Cin > o.Cout;
-                int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_DYBF16 : 0);
+                int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_DYBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0);
                 const int *tw = tf;
                 if (xstat) { flags |= D3_CONV_XSTAT | (flip ? D3_CONV_FLIPK : 0); tw = tb; }
                 float *dW = pgrads[o.w];
@@ -902,7 +930,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 char *wpart = garena + o.wpart_off;
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
                                           flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)ws_stream);
-                if (o.wsplits > 1 || paccum[o.w]) {   // (a single split without accumulation was written to dW directly)
+                if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)
                     RedJob j;
                     memset(&j, 0, sizeof(j));
                     j.part = (const float *)wpart; j.dW = dW; j.n = (long long)o.K * o.CinW * o.Cout; j.R = o.wsplits;
@@ -930,15 +958,15 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     if (!n->lastblock)
                         rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, gobf ? D3_CONV_XBF16 : 0, stream);
+                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
                     else
                     rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
                                                   (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
-                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, gobf ? D3_CONV_XBF16 : 0, stream);
+                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
-                                        (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0), stream);
+                                        (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
                 }
                 if (rc) return rc;
             }

@@ -29,8 +29,9 @@ def _fbits(x):
 
 
 class _Builder:
-    def __init__(self):
+    def __init__(self, act_dtype=BF16):
         self.tensors, self.bufs, self.ops, self.params, self.grad_params, self.bns = [], [], [], [], [], []
+        self.act_dtype = act_dtype      # storage of the BN -> ReLU outputs / the padded stem input: bf16, or fp32 (reference precision)
 
     def buf(self, level, width, dtype):
         self.bufs.append((level, width, dtype))
@@ -63,8 +64,10 @@ class _Builder:
         self.ops.append(list(fields) + [0] * (16 - len(fields)))
 
     # ---- op emitters
-    def bnact(self, x, bn, out_dtype=BF16, relu=True):
+    def bnact(self, x, bn, out_dtype=None, relu=True):
         """MinkowskiBatchNorm (+ fused MinkowskiReLU) on tensor x -> new tensor."""
+        if out_dtype is None:
+            out_dtype = self.act_dtype
         b = bn.bn
         assert b.track_running_stats and b.affine and b.num_features == self.C(x)
         y = self.new(self.level(x), self.C(x), out_dtype)
@@ -125,12 +128,15 @@ class _Builder:
 class NativeUNet:
     """`stem` (MinkowskiConvolution or None) -> UBlock -> MinkowskiBatchNorm -> ReLU as one native program."""
 
-    def __init__(self, stem, ublock, final_bn, in_channels, input_needs_grad):
-        b = _Builder()
+    def __init__(self, stem, ublock, final_bn, in_channels, input_needs_grad, exact=False):
+        """exact: the reference's precision -- every buffer fp32; csrc/unet.hip then runs the D3_CONV_F32 kernels (fp32 weight
+        fragments, exact fp32 products on v_mfma_f32_16x16x4_f32) and keeps every gradient in fp32"""
+        b = _Builder(F32 if exact else BF16)
+        self.exact = bool(exact)
         x = b.external(in_channels)
         if stem is not None:
             cpad = (in_channels + 7) // 8 * 8
-            xp = b.new(0, cpad, BF16)
+            xp = b.new(0, cpad, b.act_dtype)
             b.op(OP_PADCAST, x, xp)
             x = b.conv(xp, stem, 0, cin_w=in_channels)
         else:

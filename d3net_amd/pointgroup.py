@@ -137,6 +137,7 @@ class PointGroup(nn.Module):
         # native executors (csrc/unet.hip) for the two sparse U-Nets: one C-ABI call per forward / backward instead of
         # one python call per module.  Built lazily; the module tree above stays the owner of every parameter.
         self.native_unet = True
+        self.native_exact = True      # minkowski.set_exact(True) also runs through the native executor (False: module by module)
         self.__dict__["_execs"] = {}
 
     def _side_stream(self, device):
@@ -145,21 +146,24 @@ class PointGroup(nn.Module):
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    def _exec(self, name):
-        ex = self._execs.get(name)
+    def _exec(self, name, exact=False):
+        """the native executor of `name` ("backbone" / "score_net"); exact: its reference-precision twin (fp32 storage,
+        fp32 MFMA kernels) -- same parameters, its own program and gradient buffer (minkowski.set_exact)"""
+        key = name + "/f32" if exact else name
+        ex = self._execs.get(key)
         if ex is None:
             if name == "backbone":
                 in_channel = self.backbone[0].in_channels
-                ex = netexec.NativeUNet(self.backbone[0], self.backbone[1], self.backbone[2], in_channel, False)
+                ex = netexec.NativeUNet(self.backbone[0], self.backbone[1], self.backbone[2], in_channel, False, exact=exact)
             else:
-                ex = netexec.NativeUNet(None, self.score_net[0], self.score_net[1], self.cfg.model.m, True)
-            self._execs[name] = ex
+                ex = netexec.NativeUNet(None, self.score_net[0], self.score_net[1], self.cfg.model.m, True, exact=exact)
+            self._execs[key] = ex
         return ex
 
     def _run_unet(self, name, module, x):
         """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""
-        if self.native_unet and not ME._EXACT and x.F.size(0) > 0:
-            return self._exec(name)(x.F, x.coordinate_manager, self.training)
+        if self.native_unet and not (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)) and x.F.size(0) > 0:
+            return self._exec(name, exact=ME._EXACT)(x.F, x.coordinate_manager, self.training)
         return module(x).features
 
     def static_gradient_buckets(self):

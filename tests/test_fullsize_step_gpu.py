@@ -109,8 +109,34 @@ def test_canonical_step_exact_mode_equals_oracle(dev, canonical):
     vals = sorted(errs.values())
     print("exact step vs oracle: parameter-gradient rel-L2 median %.2e, 90%% %.2e, worst %.2e (%s)" %
           (vals[len(vals) // 2], vals[len(vals) * 9 // 10], errs[worst], worst))
-    assert vals[len(vals) // 2] < 3e-2, vals[len(vals) // 2]
-    assert vals[len(vals) * 9 // 10] < 1e-1, vals[len(vals) * 9 // 10]
+    # (fp32 MFMA executor, MI355X: median 8.0e-3, 90 % 1.0e-2, worst 1.7e-2)
+    assert vals[len(vals) // 2] < 2e-2, vals[len(vals) // 2]
+    assert vals[len(vals) * 9 // 10] < 5e-2, vals[len(vals) * 9 // 10]
+
+
+def test_canonical_step_exact_executor_equals_exact_module_path(dev, canonical):
+    """minkowski.set_exact(True) through the NATIVE executor (fp32 program: csrc/unet.hip with the D3_CONV_F32 kernels) against the
+    same step run module by module with the same kernels: one schedule, two drivers -- loss to 1e-5, parameter gradients to 2e-3 median / 2e-2 worst relative L2 (the
+    fused epilogues change the summation order of the BatchNorm reductions; a mask flip at a ReLU moves single entries)"""
+    c = canonical
+    model = c["model"]
+    loss_e, _ = _hip_step(c, dev, exact=True)
+    assert model._execs.get("backbone/f32") is not None, "the reference-precision executor did not run"
+    g_exec = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():      # (the executor's gradient views are only marked stale by zero_grad(): autograd would add to them)
+        p.grad = None
+    model.native_exact = False
+    try:
+        loss_m, _ = _hip_step(c, dev, exact=True)
+    finally:
+        model.native_exact = True
+    assert abs(float(loss_e) - float(loss_m)) <= 1e-5 * abs(float(loss_m)), (float(loss_e), float(loss_m))
+    errs = {n: l2err(g_exec[n], p.grad) for n, p in model.named_parameters() if p.grad is not None and not _degenerate(n, p.grad)}
+    worst = max(errs, key=errs.get)
+    vals = sorted(errs.values())
+    print("exact executor vs exact module path: gradient rel-L2 median %.2e, worst %.2e (%s)" % (vals[len(vals) // 2], errs[worst], worst))
+    # (measured on MI355X: median 3.7e-4, worst 2.0e-3 -- fp32 against fp32 with different reduction orders through ~70 ReLU layers)
+    assert vals[len(vals) // 2] < 2e-3 and errs[worst] < 2e-2, (vals[len(vals) // 2], worst, errs[worst])
 
 
 def test_canonical_step_bf16_executor_close_to_oracle(dev, canonical):
