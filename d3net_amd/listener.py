@@ -20,6 +20,7 @@ from torch.autograd import Function
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from . import _lib
+from . import nativelinear as NL
 from ._lib import check
 from .pointgroup_ops import _on, _ptr, _stream
 
@@ -82,9 +83,11 @@ class ScaledDotProductAttention(nn.Module):
         attention_weights (B/weights_div, h, nq, nk), added to the scaled scores (way == "add")."""
         if attention_weights is not None and way != "add":
             raise NotImplementedError("only the additive weights the reference uses (match_module.py:238) are implemented")
-        out = AttentionCoreFunction.apply(self.fc_q(queries), self.fc_k(keys), self.fc_v(values), attention_weights,
-                                          key_mask, self.h, weights_div)
-        return self.fc_o(out)
+        # the three projections share one launch, forward and backward (d3net_amd/nativelinear.py over csrc/hgemm.hip)
+        q, k, v = NL.linear_multi([(queries, self.fc_q.weight, self.fc_q.bias), (keys, self.fc_k.weight, self.fc_k.bias),
+                                   (values, self.fc_v.weight, self.fc_v.bias)])
+        out = AttentionCoreFunction.apply(q, k, v, attention_weights, key_mask, self.h, weights_div)
+        return NL.linear(out, self.fc_o.weight, self.fc_o.bias)
 
 
 class MultiHeadAttention(nn.Module):
@@ -98,7 +101,7 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, queries, keys, values, key_mask=None, attention_weights=None, way="add", weights_div=1):
         out = self.attention(queries, keys, values, key_mask, attention_weights, way, weights_div)
-        return self.layer_norm(queries + self.dropout(out))
+        return NL.add_layer_norm(queries, self.dropout(out), self.layer_norm)      # LayerNorm(queries + dropout(out)), one pass
 
 
 # ------------------------------------------------------------------------------------------ language
@@ -215,6 +218,28 @@ class PointwiseConv1d(nn.Conv1d):
         y = torch.matmul(self.weight.squeeze(-1), x)            # (cout, cin) @ (B, cin, L) -> (B, cout, L)
         return y if self.bias is None else y + self.bias.view(1, -1, 1)
 
+    def forward_channels_last(self, x):
+        """x (B, L, cin) -> (B, L, cout): the same product with the channels in the last dimension -- ONE tall GEMM over the
+        B * L positions on csrc/hgemm.hip instead of a batched matmul per item"""
+        return NL.linear(x, self.weight.squeeze(-1), self.bias)
+
+
+def pointwise_stack_channels_last(seq, x):
+    """run an nn.Sequential of PointwiseConv1d / BatchNorm1d / PReLU (model/match_module.py:160-169 `features_concat`,
+    `match`) on a channels-LAST tensor (B, L, C): BatchNorm1d over (B, C, L) normalises every channel over the B * L
+    positions -- nn.BatchNorm1d on the (B * L, C) rows; PReLU's per-channel slope broadcasts over the last dimension."""
+    B, Lp = x.shape[:2]
+    for m in seq:
+        if isinstance(m, PointwiseConv1d):
+            x = m.forward_channels_last(x)
+        elif isinstance(m, nn.BatchNorm1d):
+            x = m(x.reshape(B * Lp, -1)).view(B, Lp, -1)
+        elif isinstance(m, nn.PReLU):
+            x = torch.nn.functional.prelu(x.reshape(B * Lp, -1), m.weight).view(B, Lp, -1)
+        else:
+            raise NotImplementedError(type(m))
+    return x
+
 
 class TransformerMatchModule(nn.Module):
     """(reference: model/match_module.py:143-336)"""
@@ -242,14 +267,20 @@ class TransformerMatchModule(nn.Module):
 
     def multiplex_attention(self, v_features, l_features, l_masks, dist_weights, weights_div):
         """v (B*C,K,128), l (B*C,T,256), l_masks (B*C,T), dist_weights (B',h,K,K) shared by weights_div items"""
-        l_features = self.lang_fc(l_features)
+        if _CONV1D_LIB:
+            l_features = self.lang_fc(l_features)
+        else:   # Linear -> ReLU (one hgemm problem with the ReLU epilogue) -> Dropout -> LayerNorm (csrc/layernorm.hip)
+            fc, _, drop, ln = self.lang_fc
+            l_features = NL.add_layer_norm(drop(NL.linear(l_features, fc.weight, fc.bias, relu=True)), None, ln)
         l_features = self.lang_self_attn(l_features, l_features, l_features, key_mask=l_masks)
         v_features = self.cross_attn[0](v_features, l_features, l_features, key_mask=l_masks)
         for i in range(self.depth):
             v_features = self.self_attn[i + 1](v_features, v_features, v_features, attention_weights=dist_weights,
                                                weights_div=weights_div)
             v_features = self.cross_attn[i + 1](v_features, l_features, l_features, key_mask=l_masks)
-        return self.match(v_features.permute(0, 2, 1).contiguous()).squeeze(1)       # (B*C, K)
+        if _CONV1D_LIB:
+            return self.match(v_features.permute(0, 2, 1).contiguous()).squeeze(1)       # (B*C, K)
+        return pointwise_stack_channels_last(self.match, v_features).squeeze(-1)          # (B*C, K), no transposes
 
     def _dist_weights(self, centers):
         """row-normalised inverse centre distances, one copy per head (:220-238); detached"""
@@ -280,7 +311,10 @@ class TransformerMatchModule(nn.Module):
     def forward(self, data_dict, use_rl=False):
         centers = data_dict["proposal_center_batched"]
         dist_weights = self._dist_weights(centers) if self.use_dist_weight_matrix else None
-        feats = self.features_concat(data_dict["proposal_feats_batched"].permute(0, 2, 1)).permute(0, 2, 1)
+        if _CONV1D_LIB:
+            feats = self.features_concat(data_dict["proposal_feats_batched"].permute(0, 2, 1)).permute(0, 2, 1)
+        else:
+            feats = pointwise_stack_channels_last(self.features_concat, data_dict["proposal_feats_batched"])
         B, K = feats.shape[:2]
         masks = data_dict["proposal_batch_mask"].float()
         feats = self.self_attn[0](feats, feats, feats, attention_weights=dist_weights)     # no proposal mask (:260)

@@ -436,6 +436,18 @@ int d3_attn_fwd(const float *q, const float *k, const float *v, const float *bia
 int d3_attn_bwd(const float *q, const float *k, const float *v, const float *P, const float *dout, float *dS,
                 float *dq, float *dk, float *dv, int B, int h, int nq, int nk, int dkdim, int dvdim, void *stream);
 
+/* Fused residual add + LayerNorm (csrc/layernorm.hip): y = LayerNorm(a + b) * gamma + beta over the last dimension D of R
+ * rows (b may be NULL), torch.nn.LayerNorm semantics (biased variance, eps inside the root).  Replaces
+ * `self.layer_norm(queries + out)` of MultiHeadAttention (model/transformer/attention.py:170-176) and the LayerNorm of
+ * `lang_fc` (model/match_module.py:170-173).  mean / rstd (R each) are kept for the backward; bwd: dx = d(a) = d(b),
+ * dgamma / dbeta (D each, written); ws >= d3_layernorm_ws_bytes(R, D).  D <= 1024. */
+int d3_layernorm_fwd(const float *a, const float *b, const float *gamma, const float *beta, float *y, float *mean,
+                     float *rstd, int R, int D, float eps, void *stream);
+size_t d3_layernorm_ws_bytes(int R, int D);
+int d3_layernorm_bwd(const float *a, const float *b, const float *gamma, const float *mean, const float *rstd,
+                     const float *dy, float *dx, float *dgamma, float *dbeta, int R, int D, void *ws, size_t ws_bytes,
+                     void *stream);
+
 /* ---- small-batch fp32 GEMMs of the proposal-level heads (csrc/hgemm.hip) ---------------------------
  * Every nn.Linear / nn.GRUCell product of the speaker and listener heads (model/caption_module.py:72-133,
  * model/graph_module.py:101-108, model/lang_module.py:51-55):

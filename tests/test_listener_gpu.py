@@ -145,3 +145,73 @@ def test_attention_mfma_form_equals_scalar_form(dev):
                 res.append((out.detach(), qq.grad, kk.grad, vv.grad))
         for a, b in zip(*res):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * (1 + float(b.abs().max()))), float((a - b).abs().max())
+
+
+def test_native_projections_layernorm_and_channel_gemms_match_the_library_ops(dev):
+    """d3net_amd/nativelinear.py (fc_q / fc_k / fc_v / fc_o, lang_fc, the kernel-size-1 Conv1d stacks as channels-last GEMMs on
+    csrc/hgemm.hip; LayerNorm(a + b) on csrc/layernorm.hip) against the library-op formulation of the SAME module
+    (`listener._CONV1D_LIB = True`: nn.Linear / nn.Conv1d / nn.LayerNorm) at the shape of conf/pointgroup_grounding.yaml:
+    4 scenes x 8 descriptions, 128 proposals, T = 128.  Reference: model/match_module.py:143-336,
+    model/transformer/attention.py:134-176.  Outputs 1e-4, every parameter gradient 2e-3 of its scale."""
+    import d3net_amd.listener as LI
+    from gen_listener_golden import make_cfg
+    torch.manual_seed(5)
+    cfg = make_cfg()
+    net = LI.TransformerMatchModule(cfg).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B, Cn, K, T = 4, cfg.data.num_des_per_scene, cfg.model.max_num_proposal, 128
+    g = torch.Generator().manual_seed(1)
+    d0 = {"proposal_center_batched": torch.rand(B, K, 3, generator=g).to(dev) * 3,
+          "proposal_feats_batched": torch.randn(B, K, cfg.model.m, generator=g).to(dev),
+          "proposal_batch_mask": (torch.rand(B, K, generator=g) > 0.4).float().to(dev),
+          "istrain": torch.tensor([0]),
+          "lang_hiddens": torch.randn(B * Cn, T, 256, generator=g).to(dev),
+          "lang_masks": (torch.arange(T)[None, :] < torch.randint(5, T, (B * Cn, 1), generator=g)).float().to(dev)}
+    res = {}
+    for lib in (True, False):
+        LI._CONV1D_LIB = lib
+        try:
+            net.zero_grad(set_to_none=True)
+            random.seed(2)
+            out = net(dict(d0))["cluster_ref"]
+            w = torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)
+            (out * w).sum().backward()
+            torch.cuda.synchronize()
+            res[lib] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+        finally:
+            LI._CONV1D_LIB = False
+    (o_lib, g_lib), (o_nat, g_nat) = res[True], res[False]
+    assert o_lib.shape == (B * Cn, K)
+    assert torch.allclose(o_nat, o_lib, rtol=1e-4, atol=1e-4 * float(o_lib.abs().max())), float((o_nat - o_lib).abs().max())
+    assert set(g_lib) == set(g_nat)
+    for n in g_lib:
+        scale = float(g_lib[n].abs().max()) + 1e-12
+        # (+ 2e-5: a bias in front of a BatchNorm has a zero gradient up to rounding -- both sides hold ~1e-6 of noise there)
+        assert float((g_nat[n] - g_lib[n]).abs().max()) <= 2e-3 * scale + 2e-5, (n, float((g_nat[n] - g_lib[n]).abs().max()), scale)
+
+
+def test_add_layer_norm_kernel_vs_torch(dev):
+    """csrc/layernorm.hip against torch.nn.functional.layer_norm (+ the residual add), ragged row counts and widths"""
+    from d3net_amd import nativelinear as NL
+    torch.manual_seed(0)
+    for R, D, with_b in ((4096, 128, True), (37, 128, False), (1000, 300, True), (5, 64, True), (130, 1000, False)):
+        ln = torch.nn.LayerNorm(D).to(dev)
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5); ln.bias.normal_()
+        a = torch.randn(R, D, device=dev, requires_grad=True)
+        b = torch.randn(R, D, device=dev, requires_grad=True) if with_b else None
+        y = NL.add_layer_norm(a, b, ln)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        got = (y.detach(), a.grad.clone(), None if b is None else b.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone())
+        a2 = a.detach().clone().requires_grad_(True)
+        b2 = b.detach().clone().requires_grad_(True) if with_b else None
+        ln.zero_grad()
+        y2 = ln(a2 if b2 is None else a2 + b2)
+        y2.backward(gy)
+        ref = (y2.detach(), a2.grad, None if b2 is None else b2.grad, ln.weight.grad, ln.bias.grad)
+        for u, v in zip(got, ref):
+            if u is not None:
+                assert torch.allclose(u, v, rtol=1e-4, atol=1e-4 * (1 + float(v.abs().max()))), (R, D, float((u - v).abs().max()))
