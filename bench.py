@@ -518,9 +518,12 @@ def main():
                                         "(clustering, heads, captioner and optimizer included in the time, not in the bytes)",
                                 "detail": comp_detail}
         if grad_sync is not None:
-            out["config"]["grad_sync"] = {"collectives_per_step": 1 + len(detector.static_gradient_buckets()) + (1 if grad_sync.early else 0),
+            items = grad_sync._items()
+            out["config"]["grad_sync"] = {"collectives_per_step": 1 + sum(len(it["ranges"]) for it in items) + (1 if grad_sync.early else 0),
                                           "heads_bucket_floats": sum(p.numel() for p in grad_sync.early),
-                                          "heads_bucket_started_inside_backward": grad_sync.early_launches}
+                                          "heads_bucket_started_inside_backward": grad_sync.early_launches,
+                                          "executor_chunks": [[hi - lo for lo, hi in it["ranges"]] for it in items],
+                                          "executor_chunk_collectives_started_inside_backward": grad_sync.chunk_launches}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config)
         print(json.dumps(out), flush=True)

@@ -135,6 +135,8 @@ SIGNATURES = {
     "d3_edgeconv_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "d3_query_locals_dist": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "d3_prof_enable": (i32, [i32]),
+    "d3_net_set_chunks": (i32, [vp, vp, i32]),
+    "d3_net_chunk_wait": (i32, [vp, i32, vp]),
     "d3_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "d3_layernorm_ws_bytes": (sz, [i32, i32]),
     "d3_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),

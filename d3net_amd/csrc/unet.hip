@@ -346,6 +346,12 @@ struct Net {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;       // pool
     size_t ev_used = 0;
+    // gradient chunks (data-parallel overlap): chunk k of the flat parameter-gradient buffer is complete once the backward has
+    // processed op chunk_op[k] (ops run in reverse program order, parameters are registered in program order: a chunk is a
+    // contiguous tail range); two events per chunk -- side stream (weight-gradient reductions) and caller's stream
+    // (BatchNorm parameter gradients) -- let a collective stream start the chunk's all-reduce while the backward goes on
+    std::vector<int> chunk_op;
+    std::vector<hipEvent_t> chunk_ev_side, chunk_ev_main;
     RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (ring of RED_RING slots) + device copies of the reduce jobs
     size_t red_cap = 0; int red_flip = 0;
     hipEvent_t next_event() {
@@ -597,8 +603,35 @@ extern "C" void d3_net_destroy(void *h) {
     if (n->red_host) hipHostFree(n->red_host);
     if (n->red_dev) hipFree(n->red_dev);
     for (auto e : n->ev) hipEventDestroy(e);
+    for (auto e : n->chunk_ev_side) hipEventDestroy(e);
+    for (auto e : n->chunk_ev_main) hipEventDestroy(e);
     if (n->side) hipStreamDestroy(n->side);
     delete n;
+}
+
+// op_idx[k] (descending): the backward has finished chunk k's parameters when it has processed op op_idx[k]
+extern "C" int d3_net_set_chunks(void *h, const int *op_idx, int nchunks) {
+    Net *n = (Net *)h;
+    if (!n || nchunks < 0 || nchunks > 64) return D3_ERR_ARG;
+    for (int k = 0; k < nchunks; k++) {
+        if (op_idx[k] < 0 || op_idx[k] >= (int)n->ops.size() || (k > 0 && op_idx[k] >= op_idx[k - 1])) return D3_ERR_ARG;
+    }
+    n->chunk_op.assign(op_idx, op_idx + nchunks);
+    while ((int)n->chunk_ev_side.size() < nchunks) {
+        hipEvent_t a, b;
+        D3_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        D3_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        n->chunk_ev_side.push_back(a); n->chunk_ev_main.push_back(b);
+    }
+    return 0;
+}
+// make `stream` wait until chunk k of the LAST d3_net_backward call is complete (its events were recorded by that call)
+extern "C" int d3_net_chunk_wait(void *h, int k, void *stream) {
+    Net *n = (Net *)h;
+    if (!n || k < 0 || k >= (int)n->chunk_op.size()) return D3_ERR_ARG;
+    D3_CHECK(hipStreamWaitEvent(d3_stream(stream), n->chunk_ev_side[k], 0));
+    D3_CHECK(hipStreamWaitEvent(d3_stream(stream), n->chunk_ev_main[k], 0));
+    return 0;
 }
 
 static int bn_blocks2(int M, int C) {
@@ -901,8 +934,19 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     int tail_idx = -1;
     for (int i = 0, c = 0; i < (int)n->ops.size() && flush_tail > 0; i++)
         if (n->ops[i].type == OP_CONV && pgrads[n->ops[i].w] != nullptr && ++c == flush_tail) { tail_idx = i; break; }
+    size_t next_chunk = 0;
+    auto chunk_done = [&](int i) -> int {      // op i has been processed: close every chunk that ends here
+        while (next_chunk < n->chunk_op.size() && n->chunk_op[next_chunk] >= i) {
+            int frc = flush_red(); if (frc) return frc;
+            D3_CHECK(hipEventRecord(n->chunk_ev_side[next_chunk], ws_stream));
+            D3_CHECK(hipEventRecord(n->chunk_ev_main[next_chunk], s));
+            next_chunk++;
+        }
+        return 0;
+    };
     for (int i = (int)n->ops.size() - 1; i >= 0; i--) {
         OpD &o = n->ops[i];
+        if (i < (int)n->ops.size() - 1) { int crc = chunk_done(i + 1); if (crc) return crc; }
         if (i == tail_idx) { int frc = flush_red(); if (frc) return frc; }
         if (o.type == OP_CONV) {
             const TensorD &ti = n->T[o.in];
@@ -1011,6 +1055,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
         }
     }
     { int frc = flush_red(); if (frc) return frc; }
+    { int crc = chunk_done(0); if (crc) return crc; }
     // join: the caller's stream waits for the last weight gradient
     if (side_used) {
         hipEvent_t e = n->next_event();

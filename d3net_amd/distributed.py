@@ -61,36 +61,42 @@ def _avg_supported(device):
 
 class BucketGradAllReduce:
     """Gradient averaging for models whose sub-networks keep their gradients in flat buffers (the native U-Net executors,
-    d3net_amd/netexec.py): those buffers are all-reduced in place -- one collective each, no packing -- and the remaining
-    parameters (point-level heads, speaker / listener) share one packed collective.
+    d3net_amd/netexec.py): those buffers are all-reduced in place -- no packing -- and the remaining parameters (point-level
+    heads, speaker / listener) share packed collectives.
 
-    The collective schedule is STATIC: it is derived from the `requires_grad` parameter list and the owner's executor
-    set, never from which gradients happen to exist on this rank.  A rank whose step produced no proposals (its ScoreNet
-    backward never ran) contributes zeros and receives the other ranks' average, exactly what DDP does for a zero
-    gradient; every rank therefore issues the same collectives with the same sizes, in the same order, every step.  The
-    layout signature is compared across ranks once, at the first call.
+    The collective SCHEDULE is static and ordered: [heads' bucket (`early`), executor 1's chunks, executor 2's chunks, ...,
+    the packed rest].  It is derived from the `requires_grad` parameter list and the owner's executor set, never from which
+    gradients happen to exist on this rank: a rank whose step produced no proposals (its ScoreNet backward never ran)
+    contributes zeros and receives the other ranks' average, exactly what DDP does for a zero gradient.  The layout
+    signature is compared across ranks once, at the first call.
+
+    OVERLAP with the backward: an item of the schedule may be started from INSIDE `backward()` as soon as its gradients are
+    final, but only when every item before it has been started -- so all ranks always issue the same collectives in the
+    same order, whatever each rank's step looked like; what has not been started when `__call__` runs is started there,
+    in order.  Items become ready through evidence, not assumption:
+      * the heads' bucket when the backward crosses the last `boundary()` placed on the detector's outputs (and
+        `_finish` verifies that no gradient of it changed afterwards: post-accumulate hooks + version counters);
+      * an executor's chunks when its native backward has been enqueued (`NativeUNet.on_backward`): chunk k of the flat
+        buffer -- a tail range: parameter gradients complete in reverse program order -- is all-reduced on its own stream
+        behind the two events `d3_net_backward` recorded for it, while the rest of that backward is still running.
 
     `owner`: an object with `static_gradient_buckets()` -> [(flat tensor, [parameters], executor)] (PointGroup), or --
     legacy form used by the CPU tests -- a callable returning ([flat tensors], [covered parameters])."""
 
-    def __init__(self, params, owner, early=()):
+    def __init__(self, params, owner, early=(), chunks=3):
         self.params = [p for p in params if p.requires_grad]
         self.owner = owner
+        self.chunks = int(os.environ.get("D3_GRAD_CHUNKS", chunks))
         self._checked = False
         self._rest = None
-        # overlap with the backward: `early` = parameters whose gradients are complete before the detector's backward
-        # starts (the speaker / listener heads: their nodes were created after every detector node, so the autograd
-        # engine -- highest sequence number first -- has run all of them when it reaches a GradBoundary placed on the
-        # detector's outputs).  Their bucket is then packed and all-reduced from the backward itself
-        # (boundary_reached) and runs on the collective stream underneath the U-Net backward; a step in which the
-        # boundary is never reached (no proposals, no gradient into the detector) issues the same collective from
-        # __call__ instead, so every rank still issues the same collectives in the same order.
         ids = {id(p) for p in self.params}
         self.early = [p for p in early if id(p) in ids] if os.environ.get("D3_EARLY_ALLREDUCE", "1") != "0" else []
+        self._overlap = os.environ.get("D3_EARLY_ALLREDUCE", "1") != "0"
         self._expected = 0
         self._fired = 0
         self._early_work = None
         self.early_launches = 0     # steps whose heads bucket started inside backward()
+        self.chunk_launches = 0     # executor chunk collectives started inside backward() (all steps)
         # Evidence, not assumption (ADVICE r2): "every head gradient is final when the last boundary fires" rests on the
         # autograd engine's ready-queue order.  Every early parameter reports its accumulation through a
         # post-accumulate-grad hook; an accumulation that arrives AFTER the bucket was packed (a head parameter also used
@@ -102,11 +108,90 @@ class BucketGradAllReduce:
         for i, p in enumerate(self.early):
             if hasattr(p, "register_post_accumulate_grad_hook"):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_early_grad(i))
+        self._exec_items = None     # [dict(flat, params, ex, ranges, works, launched, count)] in schedule order
+        self._streams = {}
 
-    # ---- early bucket -------------------------------------------------------------------------------------------
+    # ---- schedule -------------------------------------------------------------------------------------------------
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    def _buckets(self):
+        if hasattr(self.owner, "static_gradient_buckets"):
+            return self.owner.static_gradient_buckets()
+        flats, covered = self.owner()
+        return [(f, covered if i == 0 else [], None) for i, f in enumerate(flats)]
+
+    def _items(self):
+        """executor items of the schedule (built once): chunk ranges of every flat buffer + the backward hook"""
+        if self._exec_items is None:
+            items = []
+            for flat, ps, ex in self._buckets():
+                ranges = [(0, flat.numel())]
+                if ex is not None and self._overlap and hasattr(ex, "set_grad_chunks") and self.chunks > 1:
+                    ranges = ex.set_grad_chunks(self.chunks)          # [(lo, hi)] in completion order (tail first)
+                it = dict(flat=flat, params=ps, ex=ex, ranges=ranges, works=[], launched=False, count=-1)
+                if ex is not None and self._overlap and hasattr(ex, "on_backward"):
+                    ex.on_backward = lambda net, it=it: self._exec_ready(it)
+                items.append(it)
+            self._exec_items = items
+        return self._exec_items
+
+    def _stream_for(self, dev, k):
+        if dev.type != "cuda":
+            return None
+        key = (dev.index, k)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=dev)
+        return self._streams[key]
+
+    def _launch_exec(self, it, inside_backward):
+        """in-place all-reduce of an executor's flat buffer, chunk by chunk in completion order"""
+        ex, flat = it["ex"], it["flat"]
+        if ex is not None:
+            ex.prepare_for_allreduce()     # zero-fill if no backward wrote it this step; install the views as .grad
+        avg = _avg_supported(flat.device)
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        for k, (lo, hi) in enumerate(it["ranges"]):
+            view = flat[lo:hi]
+            st = self._stream_for(flat.device, k) if (inside_backward and ex is not None and len(it["ranges"]) > 1) else None
+            if st is not None:
+                # the chunk's own stream waits for the two events the native backward recorded for chunk k; the collective is
+                # ordered behind that stream, not behind the caller's (which still has the rest of the backward queued)
+                ex.chunk_wait(k, st)
+                with torch.cuda.stream(st):
+                    view.record_stream(st)
+                    w = dist.all_reduce(view, op=op, async_op=True)
+            else:
+                w = dist.all_reduce(view, op=op, async_op=True)
+            it["works"].append((w, view, avg))
+        it["launched"] = True
+        it["count"] = getattr(ex, "backward_count", 0) if ex is not None else 0
+        if inside_backward:
+            self.chunk_launches += len(it["ranges"])
+
+    def _advance(self, inside_backward):
+        """start every not-yet-started item that is ready, in schedule order, stopping at the first that is not"""
+        if not self._checked or not self._overlap:
+            return
+        if self.early and self._early_work is None:
+            if not (self._expected > 0 and self._fired == self._expected):
+                return
+            self._launch_early()
+            self.early_launches += 1
+        for it in self._items():
+            if it["launched"]:
+                continue
+            ex = it["ex"]
+            if ex is None or not getattr(ex, "backward_done", False):
+                return
+            self._launch_exec(it, inside_backward)
+
+    def _exec_ready(self, it):
+        """NativeUNet.on_backward: the executor's native backward has been enqueued"""
+        if self._active():
+            self._advance(True)
+
+    # ---- early bucket -------------------------------------------------------------------------------------------
     def boundary(self, *tensors):
         """Identity on the detector's outputs that marks, in the autograd graph, the point below which no `early`
         parameter receives gradient any more.  Call once per detector pass of the step, on every output that carries
@@ -125,8 +210,7 @@ class BucketGradAllReduce:
         # (not before the first __call__ has compared the layout across ranks and probed ReduceOp.AVG: those are
         # collectives too, and every rank must issue them in the same position)
         if self._checked and self._fired == self._expected and self._early_work is None:   # the last pass' boundary
-            self._launch_early()
-            self.early_launches += 1
+            self._advance(True)
 
     def _on_early_grad(self, i):
         if self._early_work is not None:      # the bucket is already on the wire: this gradient is not in it
@@ -164,12 +248,6 @@ class BucketGradAllReduce:
         self._early_work = None
         self._expected = self._fired = 0
 
-    def _buckets(self):
-        if hasattr(self.owner, "static_gradient_buckets"):
-            return self.owner.static_gradient_buckets()
-        flats, covered = self.owner()
-        return [(f, covered if i == 0 else [], None) for i, f in enumerate(flats)]
-
     def _check_signature(self, sizes, device):
         """every rank must run the same schedule: compare (count, sizes) once"""
         sig = torch.tensor([float(len(sizes))] + [float(n) for n in sizes], dtype=torch.float64, device=device)
@@ -184,27 +262,26 @@ class BucketGradAllReduce:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()
-        buckets = self._buckets()
+        items = self._items()
         if self._rest is None:
-            cov = {id(p) for _, ps, _ in buckets for p in ps}
+            cov = {id(p) for it in items for p in it["params"]}
             self.early = [p for p in self.early if id(p) not in cov]
             cov |= {id(p) for p in self.early}
             self._rest = [p for p in self.params if id(p) not in cov]
         rest = self._rest
-        dev = buckets[0][0].device if buckets else (rest[0] if rest else self.early[0]).device
+        dev = items[0]["flat"].device if items else (rest[0] if rest else self.early[0]).device
         if not self._checked:
-            self._check_signature([sum(p.numel() for p in self.early)] + [f.numel() for f, _, _ in buckets]
+            self._check_signature([sum(p.numel() for p in self.early)] + [hi - lo for it in items for lo, hi in it["ranges"]]
                                   + [sum(p.numel() for p in rest)], dev)
-        if self.early and self._early_work is None:   # the boundary was not reached in this step's backward: same collective, now
+        # everything that was not started from inside the backward, in schedule order
+        if self.early and self._early_work is None:
             self._launch_early()
+        for it in items:
+            if not it["launched"]:
+                self._launch_exec(it, False)
         # RCCL averages inside the collective (no extra pass over the 31 MB buffer); gloo (the CPU tests) has no AVG
         avg = _avg_supported(dev)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        works = []
-        for flat, ps, ex in buckets:
-            if ex is not None:
-                ex.prepare_for_allreduce()     # zero-fill if no backward wrote it this step; install the views as .grad
-            works.append(dist.all_reduce(flat, op=op, async_op=True))
         if rest:
             packed = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in rest])
             dist.all_reduce(packed, op=op)
@@ -215,12 +292,23 @@ class BucketGradAllReduce:
                     p.grad = v.view_as(p).clone()
                 else:
                     p.grad.copy_(v.view_as(p))
-        for w, (flat, _, _) in zip(works, buckets):
-            w.wait()
-            if not avg:
-                flat.div_(world)
+        stale_exec = None
+        for it in items:
+            for w, view, wavg in it["works"]:
+                w.wait()
+                if not wavg:
+                    view.div_(world)
+            ex = it["ex"]
+            if ex is not None and getattr(ex, "backward_count", it["count"]) != it["count"]:
+                stale_exec = ex       # its backward ran again AFTER its buffer went on the wire
+            it["works"], it["launched"], it["count"] = [], False, -1
+            if ex is not None and hasattr(ex, "backward_done"):
+                ex.backward_done = False
         if self.early:
             self._finish_early(world)
+        if stale_exec is not None:
+            raise RuntimeError("BucketGradAllReduce: an executor's backward ran again after its gradient buffer had been all-reduced "
+                               "from inside backward() (gradient accumulation over several backward() calls); run with D3_EARLY_ALLREDUCE=0.")
 
 
 class _GradBoundary(torch.autograd.Function):

@@ -156,6 +156,11 @@ class NativeUNet:
         self.debug_keep = False      # tests: keep the last forward's activation arena + level rows in `debug_last`
         self.debug_last = None
         self.debug_pairs = None
+        # data-parallel overlap (d3net_amd/distributed.py): called with `self` once the native backward has been enqueued
+        self.on_backward = None
+        self.backward_done = False   # a native backward ran since the reducer last reset it
+        self.backward_count = 0
+        self._chunk_ranges = None
 
     # ------------------------------------------------------------------ lazily created native state
     def _net(self):
@@ -213,6 +218,46 @@ class NativeUNet:
                     views.append(None)
             self._grad_views = views
         return self._grad_views
+
+    def set_grad_chunks(self, nchunks):
+        """Split the flat gradient buffer into `nchunks` tail ranges of about equal size that complete one after the other during
+        the backward (parameters are registered in program order, the backward runs the program in reverse) and tell the
+        native executor where each one ends (d3_net_set_chunks: it flushes the weight-gradient reductions there and records
+        the chunk's events).  -> [(lo, hi)] offsets into the flat buffer, in completion order."""
+        ps, gp, ops = self.b.params, self.b.grad_params, self.b.ops
+        self._grads(ps[0].device)
+        offs, off = [], 0
+        for p, g in zip(ps, gp):
+            offs.append(off)
+            off += p.numel() if g else 0
+        total = off
+        if total < (1 << 20):                # (a 0.1 MB ScoreNet buffer: one collective)
+            nchunks = 1
+        first_param = []                     # per op: its first parameter index (ops without parameters: None)
+        for op in ops:
+            idx = [int(op[4])] if op[0] == OP_CONV else ([int(op[4]), int(op[5])] if op[0] == OP_BNACT else [])
+            first_param.append(min(idx) if idx else None)
+        bounds, want = [], [total * (nchunks - 1 - k) // nchunks for k in range(nchunks)]     # descending lower bounds, last = 0
+        k = 0
+        for i in range(len(ops) - 1, -1, -1):
+            if first_param[i] is None or k >= nchunks - 1:
+                continue
+            if offs[first_param[i]] <= want[k]:
+                bounds.append((i, offs[first_param[i]]))
+                k += 1
+        first_op = next(i for i in range(len(ops)) if first_param[i] is not None)
+        bounds.append((first_op, 0))
+        ranges, hi, op_idx = [], total, []
+        for i, lo in bounds:
+            if lo < hi:
+                ranges.append((lo, hi)); op_idx.append(i); hi = lo
+        check(_lib.lib().d3_net_set_chunks(self._net(), (C.c_int * len(op_idx))(*op_idx), len(op_idx)), "net_set_chunks")
+        self._chunk_ranges = ranges
+        return ranges
+
+    def chunk_wait(self, k, stream):
+        """make `stream` wait for chunk k of the last native backward"""
+        check(_lib.lib().d3_net_chunk_wait(self._net(), k, C.c_void_p(stream.cuda_stream)), "net_chunk_wait")
 
     def owned_params(self):
         """trainable parameters whose gradient lives in this executor's flat buffer"""
@@ -332,4 +377,8 @@ class _NetFunction(Function):
                                     pg, acc, C.c_void_p(gin.data_ptr()) if gin is not None else None, _stream()), "net_backward")
         # garena / arena are only touched by work already enqueued on this stream and on the executor's side stream,
         # which this stream has joined: the caching allocator may reuse them for later work on this stream
+        net.backward_count += 1
+        net.backward_done = True
+        if net.on_backward is not None:      # data-parallel: the reducer may start this buffer's chunk collectives now
+            net.on_backward(net)
         return (gin, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)

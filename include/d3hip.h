@@ -337,6 +337,14 @@ int d3_net_forward(void *net, const void *const *params, const int *const *k3, c
 int d3_net_backward(void *net, const void *const *params, const int *const *k3, const int *const *child,
                     const int *const *up, const void *input, void *arena, void *grad_arena, const float *gout,
                     float *const *pgrads, const int *paccum, float *gin, void *stream);
+/* Data-parallel overlap (the reference's DDP buckets: scripts/train.py:265-268 through Lightning).  The parameter gradients
+ * of a backward complete in reverse program order, so a contiguous TAIL range of the flat gradient buffer is final long
+ * before the call's last kernel.  d3_net_set_chunks: op_idx[k] (strictly descending) = the op after which chunk k is
+ * complete; d3_net_backward then flushes the pending weight-gradient reductions there and records two events per chunk.
+ * d3_net_chunk_wait makes `stream` wait for chunk k of the last backward -- the caller starts that chunk's all-reduce on
+ * it while the rest of the backward is still running.  nchunks <= 64; 0 switches the feature off. */
+int d3_net_set_chunks(void *net, const int *op_idx, int nchunks);
+int d3_net_chunk_wait(void *net, int k, void *stream);
 
 /* ---- point-level heads (csrc/heads.hip) -------------------------------------------------------------
  * sem_seg / offset_net (model/pointgroup.py:77-85,274-279) and the semantic loss (:389-390) at N ~ 165k rows:

@@ -44,8 +44,12 @@ def test_two_rank_bench_line(dev):
     # 1 dry-run + 1 warm-up + 1 pyramid-census step + 2 timed steps -> 4 early starts; and it changes nothing in the result
     gs = out["config"]["grad_sync"]
     assert gs["heads_bucket_floats"] > 0 and gs["heads_bucket_started_inside_backward"] == 4, gs
+    # ... and behind it, still inside backward(), the executors' buffers: ScoreNet's in one piece, the backbone's 31 MB in
+    # three tail chunks gated by the events d3_net_backward records (4 collectives x 4 steps)
+    assert [len(c) for c in gs["executor_chunks"]] == [1, 3] and gs["executor_chunk_collectives_started_inside_backward"] == 16, gs
     late = _run([], dict(_env(), D3_EARLY_ALLREDUCE="0"))
     assert late["config"]["grad_sync"]["heads_bucket_floats"] == 0
+    assert late["config"]["grad_sync"]["executor_chunk_collectives_started_inside_backward"] == 0
     assert abs(late["final_loss"] - out["final_loss"]) <= 1e-4 * abs(out["final_loss"]), (late["final_loss"], out["final_loss"])
 
 

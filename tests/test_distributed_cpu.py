@@ -270,6 +270,118 @@ def test_early_bucket_refuses_gradients_that_change_after_it_was_packed():
         assert "changed after the bucket was packed" in r[2]
 
 
+class _ChunkedFakeExecutor(_FakeExecutor):
+    """+ the overlap interface of netexec.NativeUNet: tail chunks of the flat buffer in completion order, the backward hook"""
+
+    def __init__(self, module):
+        super().__init__(module.parameters())
+        self.module = module
+        self.on_backward, self.backward_done, self.backward_count = None, False, 0
+
+    def set_grad_chunks(self, nchunks):
+        sizes = [p.numel() for p in self.params]
+        total, bounds, acc = sum(sizes), [], 0
+        for i in range(len(sizes) - 1, -1, -1):      # parameters complete in reverse order
+            acc += sizes[i]
+            if len(bounds) < nchunks - 1 and acc >= total * (len(bounds) + 1) // nchunks:
+                bounds.append(total - acc)
+        bounds.append(0)
+        ranges, hi = [], total
+        for lo in bounds:
+            if lo < hi:
+                ranges.append((lo, hi)); hi = lo
+        return ranges
+
+    def chunk_wait(self, k, stream):
+        raise AssertionError("no streams on the CPU")
+
+
+class _FakeNativeBackward(torch.autograd.Function):
+    """like netexec._NetFunction: ONE autograd node computes every parameter gradient of the sub-network into the executor's
+    flat buffer, then tells the reducer"""
+
+    @staticmethod
+    def forward(ctx, x, ex):
+        with torch.enable_grad():
+            xin = x.detach().requires_grad_(True)
+            y = ex.module(xin)
+        ctx.ex, ctx.xin, ctx.y = ex, xin, y
+        return y.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        ex = ctx.ex
+        grads = torch.autograd.grad(ctx.y, [ctx.xin] + ex.params, g)
+        for p, v, gr in zip(ex.params, ex.views, grads[1:]):
+            if ex.fresh_grads:
+                v.copy_(gr)
+            else:
+                v.add_(gr)
+            p.grad = v
+        ex.fresh_grads = False
+        ex.backward_count += 1
+        ex.backward_done = True
+        if ex.on_backward is not None:
+            ex.on_backward(ex)
+        return grads[0], None
+
+
+def _chunk_worker(rank, world, port, ret, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["D3_EARLY_ALLREDUCE"] = "1" if overlap else "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3net_amd.distributed import BucketGradAllReduce, broadcast_module
+    torch.manual_seed(rank)
+    backbone = torch.nn.Sequential(*[torch.nn.Linear(9, 9) for _ in range(6)])       # "backbone": executor-owned, chunked
+    point_head = torch.nn.Linear(9, 2)                                               # detector head outside the executor ("rest")
+    head = torch.nn.Sequential(torch.nn.Linear(9, 6), torch.nn.Linear(6, 3))         # "speaker": the early bucket
+    net = torch.nn.ModuleList([backbone, point_head, head])
+    broadcast_module(net)
+    ex = _ChunkedFakeExecutor(backbone)
+    sync = BucketGradAllReduce(net.parameters(), _Owner(ex), early=list(head.parameters()), chunks=3)
+    out = {}
+    for step in range(3):
+        for p in net.parameters():
+            p.grad = None
+        ex.fresh_grads = True
+        torch.manual_seed(1000 * step + rank)
+        x = torch.randn(16, 9)
+        f = _FakeNativeBackward.apply(x.requires_grad_(True), ex)
+        fb, = sync.boundary(f)
+        loss = head(fb).pow(2).sum() + point_head(f).pow(2).sum()
+        before = sync.chunk_launches
+        loss.backward()
+        inside = sync.chunk_launches - before
+        local = [p.grad.clone() for p in net.parameters()]
+        sync()
+        out[step] = dict(loss=float(loss), inside=inside, local=local, avg=[p.grad.clone() for p in net.parameters()],
+                         views=all(p.grad is v for p, v in zip(ex.params, ex.views)))
+    ret[(rank, overlap)] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backbone_bucket_is_all_reduced_in_chunks_from_inside_backward():
+    """the executor's flat gradient buffer is split by backward completion order and its chunks are
+    all-reduced from INSIDE backward() (>= 3 collectives started there in every step after the first, which compares the
+    layouts), behind the heads' bucket in the static schedule; averages and loss identical to the run without overlap"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    for overlap in (True, False):
+        mp.spawn(_chunk_worker, args=(world, _free_port(), ret, overlap), nprocs=world, join=True)
+    for step in range(3):
+        a0, a1 = ret[(0, True)][step], ret[(1, True)][step]
+        b0 = ret[(0, False)][step]
+        assert a0["inside"] == a1["inside"] == (0 if step == 0 else 3), (step, a0["inside"], a1["inside"])
+        assert b0["inside"] == 0
+        assert a0["views"] and a1["views"]
+        assert a0["loss"] == b0["loss"]
+        for g0, g1, l0, l1, gb in zip(a0["avg"], a1["avg"], a0["local"], a1["local"], b0["avg"]):
+            assert torch.allclose(g0, g1) and torch.allclose(g0, (l0 + l1) / 2, atol=1e-6) and torch.allclose(g0, gb, atol=1e-7)
+
+
 def _logged_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
