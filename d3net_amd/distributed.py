@@ -110,6 +110,12 @@ class BucketGradAllReduce:
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_early_grad(i))
         self._exec_items = None     # [dict(flat, params, ex, ranges, works, launched, count)] in schedule order
         self._streams = {}
+        # D3_CHUNK_STREAMS=1: every chunk collective waits on its OWN stream for the two events d3_net_backward recorded for
+        # the chunk, i.e. it overlaps the rest of that backward.  Off by default: this build could only exercise it through
+        # gloo on one shared device (where it is pathologically slow: 84 s per step, two processes' streams and gloo's
+        # staging copies serialise), never over RCCL -- an unmeasured path must not be the default of the scaling run.
+        # Without it the chunks are still separate collectives started inside backward(), ordered behind the caller's stream.
+        self._chunk_streams = os.environ.get("D3_CHUNK_STREAMS", "0") == "1"
 
     # ---- schedule -------------------------------------------------------------------------------------------------
     def _active(self):
@@ -153,7 +159,7 @@ class BucketGradAllReduce:
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         for k, (lo, hi) in enumerate(it["ranges"]):
             view = flat[lo:hi]
-            st = self._stream_for(flat.device, k) if (inside_backward and ex is not None and len(it["ranges"]) > 1) else None
+            st = self._stream_for(flat.device, k) if (self._chunk_streams and inside_backward and ex is not None and len(it["ranges"]) > 1) else None
             if st is not None:
                 # the chunk's own stream waits for the two events the native backward recorded for chunk k; the collective is
                 # ordered behind that stream, not behind the caller's (which still has the rest of the backward queued)
