@@ -52,6 +52,10 @@ struct GruArgs {
     const float *gi_pre; long long ldgi;
     const int *lens; int t_step;
     float *hid_out; long long ldhid;
+    // second input-side segment and an explicit row stride of Wih (round 3: the captioner's COMPOSED input weights -- GRU-2
+    // reads [attended | h1] against Wih2 W_lang, GRU-1 reads h2 against Wih1 W_td[:, h2] on top of gates precomputed for all
+    // steps): Wih is (3H, I + Ib) with row stride ldw (0: I); x may be NULL (no first segment); with gi_pre AND x the two add
+    const float *xb; long long ldxb; int Ib; long long ldw;
 };
 
 __device__ __forceinline__ f32x4 td_load4(const float *row, int k0, int K, bool valid) {
@@ -75,12 +79,14 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
     const int col = ct * 16 + i;           // hidden unit of this lane's B rows (H % 16 == 0: host check)
     int gkb = 0;
 #pragma unroll
-    for (int seg = 0; seg < 2; seg++) {
-        if (seg == 0 && a.gi_pre) continue;
-        const int K = seg == 0 ? a.I : H;
-        const float *X = seg == 0 ? a.x : a.h;
-        const long long ldx = seg == 0 ? a.ldx : a.ldh;
-        const float *W = seg == 0 ? a.Wih : a.Whh;
+    for (int seg = 0; seg < 3; seg++) {      // input-side segment(s), then the recurrent one
+        if (seg == 0 && !a.x) continue;
+        if (seg == 1 && !a.xb) continue;
+        const int K = seg == 0 ? a.I : seg == 1 ? a.Ib : H;
+        const float *X = seg == 0 ? a.x : seg == 1 ? a.xb : a.h;
+        const long long ldx = seg == 0 ? a.ldx : seg == 1 ? a.ldxb : a.ldh;
+        const long long ldw = seg == 2 ? (long long)H : (a.ldw ? a.ldw : (long long)a.I);
+        const float *W = seg == 0 ? a.Wih : seg == 1 ? a.Wih + a.I : a.Whh;
         const int nkb = (K + 15) >> 4;
         const float *xr[RT];
         bool xv[RT];
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
             xv[r] = row < a.N;
             xr[r] = X + (long long)(xv[r] ? row : 0) * ldx;
         }
-        const float *w0 = W + (long long)col * K, *w1 = W + (long long)(H + col) * K, *w2 = W + (long long)(2 * H + col) * K;
+        const float *w0 = W + (long long)col * ldw, *w1 = W + (long long)(H + col) * ldw, *w2 = W + (long long)(2 * H + col) * ldw;
         const int first = (wave - gkb) & (GRU_NW - 1);
         gkb += nkb;
         constexpr int U = GRU_U;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
                         for (int r = 0; r < RT; r++) {
                             accR[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b0[u][q], accR[r], 0, 0, 0);
                             accZ[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b1[u][q], accZ[r], 0, 0, 0);
-                            if (seg == 0) accNI[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b2[u][q], accNI[r], 0, 0, 0);
+                            if (seg < 2) accNI[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b2[u][q], accNI[r], 0, 0, 0);
                             else accNH[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b2[u][q], accNH[r], 0, 0, 0);
                         }
                 }
@@ -150,12 +156,11 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
             if (a.r) { a.r[o] = 0.f; a.z[o] = 1.f; a.n[o] = 0.f; a.ghn[o] = 0.f; }   // identity step for the backward
             continue;
         }
-        float gr, gz, gn;
+        float gr = s[0], gz = s[1], gn = s[2];     // (s[0], s[1]: input + recurrent parts; s[2]: input part, 0 without x segments)
         if (a.gi_pre) {
             const float *gi = a.gi_pre + (long long)row * a.ldgi;
-            gr = gi[c]; gz = gi[H + c]; gn = gi[2 * H + c];
-        } else { gr = s[0] + a.bih[c]; gz = s[1] + a.bih[H + c]; gn = s[2] + a.bih[2 * H + c]; }
-        if (a.gi_pre) { gr += s[0]; gz += s[1]; }
+            gr += gi[c]; gz += gi[H + c]; gn += gi[2 * H + c];
+        } else { gr += a.bih[c]; gz += a.bih[H + c]; gn += a.bih[2 * H + c]; }
         const float rr = 1.f / (1.f + expf(-(gr + a.bhh[c])));
         const float zz = 1.f / (1.f + expf(-(gz + a.bhh[H + c])));
         const float gh = s[3] + a.bhh[2 * H + c];
@@ -448,7 +453,7 @@ static d3_gemm_prob td_prob(int M, int N, float *C, long long ldc) {
 
 // ------------------------------------------------------------------------------ workspace layout
 struct TdLayout {
-    size_t widx, nidx, bidx, act, nact, msum, fp, TD, x1, x2, H1, H2, g1, g2, q, a, att, c0, total;   // byte offsets; g1/g2: r,z,n,ghn blocks
+    size_t widx, nidx, bidx, act, nact, msum, fp, TD, x1, x2, H1, H2, g1, g2, q, a, att, c0, gi1, Wa, Wb, bc2, total;   // byte offsets; g1/g2: r,z,n,ghn blocks
 };
 static TdLayout td_layout(int N, int K, int S, int H, int E, int F) {
     TdLayout L;
@@ -462,6 +467,8 @@ static TdLayout td_layout(int N, int K, int S, int H, int E, int F) {
     L.H1 = take((R + N) * H * 4); L.H2 = take((R + N) * H * 4);
     L.g1 = take(4 * R * H * 4); L.g2 = take(4 * R * H * 4);
     L.q = take(R * H * 4); L.a = take(R * K * 4); L.att = take(R * F * 4); L.c0 = take(R * H * 4);
+    // composed weights (shared with the backward) and GRU-1's input-side gates for all steps
+    L.gi1 = take(R * 3 * H * 4); L.Wa = take((size_t)3 * H * (F + H) * 4); L.Wb = take((size_t)3 * H * H * 4); L.bc2 = take((size_t)3 * H * 4);
     L.total = o;
     return L;
 }
@@ -510,19 +517,35 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
         if ((rc = hg_launch(&p[0], 1, s))) return rc;
         if ((rc = hg_launch(&p[1], 1, s))) return rc;
     }
+    // The recurrence is a chain of dependent ~10 us launches; two of its six links per step are compositions of linear maps and
+    // are taken out of it by composing the weights once per call (as the backward does):
+    //   GRU-1 input gates = Wih1 (TD[t] + W_td[:, h2] h2) + b = GI1[t] + (Wih1 W_td[:, h2]) h2 = GI1[t] + Wb h2      (GI1 batched over t)
+    //   GRU-2 input gates = Wih2 (W_lang [att | h1] + b_lang) + b = (Wih2 W_lang) [att | h1] + (Wih2 b_lang + b) = Wa [att | h1] + bc2
+    // x1 / x2 themselves (operands of the weight gradients) are computed after the loop, batched over time: 6 -> 4 launches per step.
+    float *gi1 = (float *)(ws + L.gi1), *Wa = (float *)(ws + L.Wa), *Wb = (float *)(ws + L.Wb), *bc2 = (float *)(ws + L.bc2);
+    {
+        d3_gemm_prob p[4];
+        p[0] = td_prob(3 * H, F + H, Wa, F + H);
+        p[0].nseg = 1; p[0].seg[0] = td_seg(a->Wih2, E, a->W_lang, ldlang, E, nullptr, 0, 1);
+        p[1] = td_prob(3 * H, H, Wb, H);
+        p[1].nseg = 1; p[1].seg[0] = td_seg(a->Wih1, E, a->W_td + E, ldtd, E, nullptr, 0, 1);
+        p[2] = td_prob(3 * H, 1, bc2, 1);                      // bc2 = Wih2 b_lang + bih2
+        p[2].nseg = 1; p[2].seg[0] = td_seg(a->Wih2, E, a->b_lang, E, E);
+        p[2].add = a->bih2; p[2].ldadd = 1;
+        p[3] = td_prob(R, 3 * H, gi1, 3 * H);                  // GI1 = TD Wih1^T + bih1, all steps
+        p[3].nseg = 1; p[3].seg[0] = td_seg(TD, E, a->Wih1, E, E);
+        p[3].bias = a->bih1;
+        if ((rc = hg_launch(p, 3, s))) return rc;
+        if ((rc = hg_launch(&p[3], 1, s))) return rc;
+    }
     const size_t RH = (size_t)R * H;
     for (int t = 0; t < S; t++) {
         const size_t rN = (size_t)t * N;
         float *h1p = H1 + rN * H, *h1n = H1 + (rN + N) * H, *h2p = H2 + rN * H, *h2n = H2 + (rN + N) * H;
-        {   // x1 = TD[t] + h2 W_td[:, E:E+H]^T
-            d3_gemm_prob p = td_prob(N, E, x1 + rN * E, E);
-            p.nseg = 1; p.seg[0] = td_seg(h2p, H, a->W_td + E, ldtd, H);
-            p.add = TD + rN * E; p.ldadd = E;
-            if ((rc = hg_launch(&p, 1, s))) return rc;
-        }
         {
-            GruArgs g{x1 + rN * E, E, E, h1p, H, a->Wih1, a->Whh1, a->bih1, a->bhh1, h1n, H,
-                      g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H, g1 + 3 * RH + rN * H, N, H, nullptr, 0, nullptr, 0, nullptr, 0};
+            GruArgs g{h2p, H, H, h1p, H, Wb, a->Whh1, nullptr, a->bhh1, h1n, H,
+                      g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H, g1 + 3 * RH + rN * H, N, H, gi1 + rN * 3 * H, 3 * H, nullptr, 0, nullptr, 0,
+                      nullptr, 0, 0, H};
             if ((rc = td_gru_fwd(g, s))) return rc;
         }
         {   // q = map_hidd(h1)
@@ -532,19 +555,24 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
         }
         td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, act, nact, msum, av + rN * K,
                                                                              att + rN * F, F, a->attn, t, S, K, H, F, 1);
-        {   // x2 = map_lang([attended | h1])
-            d3_gemm_prob p = td_prob(N, E, x2 + rN * E, E);
-            p.nseg = 2;
-            p.seg[0] = td_seg(att + rN * F, F, a->W_lang, ldlang, F);
-            p.seg[1] = td_seg(h1n, H, a->W_lang + F, ldlang, H);
-            p.bias = a->b_lang;
-            if ((rc = hg_launch(&p, 1, s))) return rc;
-        }
         {
-            GruArgs g{x2 + rN * E, E, E, h2p, H, a->Wih2, a->Whh2, a->bih2, a->bhh2, h2n, H,
-                      g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H, g2 + 3 * RH + rN * H, N, H, nullptr, 0, nullptr, 0, nullptr, 0};
+            GruArgs g{att + rN * F, F, F, h2p, H, Wa, a->Whh2, bc2, a->bhh2, h2n, H,
+                      g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H, g2 + 3 * RH + rN * H, N, H, nullptr, 0, nullptr, 0, nullptr, 0,
+                      h1n, H, H, F + H};
             if ((rc = td_gru_fwd(g, s))) return rc;
         }
+    }
+    {   // x1 = TD + H2[:-1] W_td[:, h2]^T ; x2 = [att | H1[1:]] W_lang^T + b_lang -- all steps, one launch (operands of the backward)
+        d3_gemm_prob p[2];
+        p[0] = td_prob(R, E, x1, E);
+        p[0].nseg = 1; p[0].seg[0] = td_seg(H2, H, a->W_td + E, ldtd, H);
+        p[0].add = TD; p[0].ldadd = E;
+        p[1] = td_prob(R, E, x2, E);
+        p[1].nseg = 2;
+        p[1].seg[0] = td_seg(att, F, a->W_lang, ldlang, F);
+        p[1].seg[1] = td_seg(H1 + (size_t)N * H, H, a->W_lang + F, ldlang, H);
+        p[1].bias = a->b_lang;
+        if ((rc = hg_launch(p, 2, s))) return rc;
     }
     {   // classifier over all steps: c0 = relu(h2 Wc0^T + b), logits (batch-major rows) = c0 Wc2^T + b
         d3_gemm_prob p = td_prob(R, H, c0, H);
@@ -604,7 +632,7 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
     float *dx1 = (float *)(bw + B.dx1), *dx2 = (float *)(bw + B.dx2), *dq = (float *)(bw + B.dq), *tmpL = (float *)(bw + B.tmpL);
     float *dh1q = (float *)(bw + B.dh1q), *dh1c = (float *)(bw + B.dh1c), *dh2c = (float *)(bw + B.dh2c);
     float *dfp = (float *)(bw + B.dfp), *dwp = (float *)(bw + B.dwp), *dx1s = (float *)(bw + B.dx1s), *dattS = (float *)(bw + B.dattS);
-    float *Wa = (float *)(bw + B.Wa), *Wb = (float *)(bw + B.Wb);
+    float *Wa = (float *)(ws + L.Wa), *Wb = (float *)(ws + L.Wb);      // composed by the forward (same call's workspace)
     const int *act = (const int *)(ws + L.act), *nact = (const int *)(ws + L.nact);
     const long long ldtd = H + F + E, ldlang = F + H;
     const size_t RH = (size_t)R * H;
@@ -642,14 +670,6 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
     //   [datt | dh1 part] = (dgi2 Wih2) W_lang     = dgi2 Wa,  Wa = Wih2 W_lang        (3H x (F+H))
     //   dh2 carry        += (dgi1 Wih1) W_td[:, h2] = dgi1 Wb,  Wb = Wih1 W_td[:, E:E+H] (3H x H)
     // so dx2 / dx1 (still needed, for the weight gradients batched over time) leave the critical path: 8 -> 6 launches per step.
-    {
-        d3_gemm_prob p[2];
-        p[0] = td_prob(3 * H, F + H, Wa, F + H);
-        p[0].nseg = 1; p[0].seg[0] = td_seg(a->Wih2, E, a->W_lang, ldlang, E, nullptr, 0, 1);
-        p[1] = td_prob(3 * H, H, Wb, H);
-        p[1].nseg = 1; p[1].seg[0] = td_seg(a->Wih1, E, a->W_td + E, ldtd, E, nullptr, 0, 1);
-        if ((rc = hg_launch(p, 2, s))) return rc;
-    }
     const int nh = (N * H + 255) / 256;
     for (int t = S - 1; t >= 0; t--) {
         const size_t rN = (size_t)t * N;
