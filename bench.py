@@ -59,8 +59,8 @@ def parse():
     return ap.parse_args()
 
 
-CPU_THREADS = 8            # torch-CPU sparse conv is fastest at ~8 threads (256 threads on the GPU box: 1000x slower)
-CPU_THREAD_SWEEP = (4, 8, 16)   # the sweep behind that "8", re-run with every bench line (the best one is `cpu_baseline.value`)
+CPU_THREADS = 8            # default thread count of the CPU baseline child (the parent sweeps CPU_THREAD_SWEEP; all 256 hardware threads of the GPU box: 1000x slower)
+CPU_THREAD_SWEEP = (8, 16, 32)   # the sweep behind that "8", re-run with every bench line (the best one is `cpu_baseline.value`)
 
 
 # ------------------------------------------------------------------------------------------ workloads
@@ -438,8 +438,8 @@ def main():
     if world == 1 and not args.no_fp32 and not args.exact:
         ME.set_exact(True)
         try:
-            step(); torch.cuda.synchronize()
-            k = 3
+            step(); step(); torch.cuda.synchronize()      # (the fp32 program's own plan / workspaces / code objects)
+            k = 5
             t1 = time.perf_counter()
             for _ in range(k):
                 step()
