@@ -59,6 +59,8 @@ SIGNATURES = {
     "d3_kmap_down_count": (i32, [vp, i32, i32, vp, sz, vp, vp, pi, vp]),
     "d3_kmap_down_fill": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, i32, vp]),
     "d3_kmap_pyramid": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, pi, vp]),
+    "d3_kmap_pyramid_begin": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_void_p), vp]),
+    "d3_kmap_pyramid_end": (i32, [vp, pi, i32]),
     "d3_kmap_down_fill2": (i32, [i32, i32, vp, vp, vp, vp, vp]),
     "d3_spconv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

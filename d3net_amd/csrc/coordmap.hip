@@ -10,6 +10,8 @@
 // needs no scatter and no atomics (d3net_amd/csrc/spconv.hip).  Table builds are hash-probe bound:
 // bytes = 16*M (coords) + 4*M*K (table) against an L2-resident 12-byte-per-slot hash.
 #include "common.h"
+#include <mutex>
+#include <vector>
 
 #define CM_EMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -279,11 +281,21 @@ __global__ void cmp_set_kernel(int *p, int v) { *p = v; }
 
 // coords0 (M0,4); levels 1..nlevels-1 are written to coords_out[(l-1)*M0*4 ...], parent / kidx / flag of level l
 // (rows of level l) to [l*M0 ...]; rows_host[l] = row count of level l.  ws >= d3_coordmap_ws_bytes(M0).
-extern "C" int d3_kmap_pyramid(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out,
-                               int *parent, int *kidx, int *flag, int *rows_dev, int *rows_host, void *stream) {
+// The host round trip of the pyramid, split in two so that the caller can put independent device work between the row-count
+// copy and the wait for it (PointGroup.feed enqueues the input voxelisation there: the device pools the features while the
+// host reads the level sizes and enqueues the table fills -- the 60-200 us the stream used to idle at this point are hidden).
+// A ticket owns a small pinned buffer and an event; tickets are pooled.
+struct PyrTicket { int *pinned; hipEvent_t ev; int nlevels; };
+static std::mutex g_pyr_mu;
+static std::vector<PyrTicket *> g_pyr_free;
+#define PYR_MAXLEV 16
+
+extern "C" int d3_kmap_pyramid_begin(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out,
+                                     int *parent, int *kidx, int *flag, int *rows_dev, void **ticket, void *stream) {
     D3_CLEAR();
-    for (int l = 0; l < nlevels; l++) rows_host[l] = 0;
-    if (M0 <= 0 || nlevels < 1) return 0;
+    if (!ticket || nlevels < 1 || nlevels > PYR_MAXLEV) return D3_ERR_ARG;
+    *ticket = nullptr;
+    if (M0 <= 0) return 0;
     CmWs w;
     if (ws == nullptr || cm_layout(ws, ws_bytes, M0, w) > ws_bytes) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
@@ -306,13 +318,56 @@ extern "C" int d3_kmap_pyramid(const int *coords0, int M0, int nlevels, void *ws
         cur = nxt; ts *= 2;
     }
     D3_LAUNCH_CHECK();
-    int h[3] = {0, 0, 0};
-    D3_CHECK(hipMemcpyAsync(rows_host, rows_dev, sizeof(int) * nlevels, hipMemcpyDeviceToHost, s));
-    D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
-    D3_CHECK(hipStreamSynchronize(s));
-    if (h[2] == 1) return D3_ERR_RANGE;
-    if (h[2] == 2) return D3_ERR_OVERFLOW;
+    PyrTicket *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pyr_mu);
+        if (!g_pyr_free.empty()) { t = g_pyr_free.back(); g_pyr_free.pop_back(); }
+    }
+    if (!t) {
+        t = new PyrTicket{nullptr, nullptr, 0};
+        hipError_t he = hipHostMalloc((void **)&t->pinned, (PYR_MAXLEV + 4) * sizeof(int));
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&t->ev, hipEventDisableTiming);
+        if (he != hipSuccess) { delete t; return (int)he; }
+    }
+    t->nlevels = nlevels;
+    D3_CHECK(hipMemcpyAsync(t->pinned, rows_dev, sizeof(int) * nlevels, hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipMemcpyAsync(t->pinned + PYR_MAXLEV, w.scalars, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    D3_CHECK(hipEventRecord(t->ev, s));
+    *ticket = t;
     return 0;
+}
+
+// waits for the counts of d3_kmap_pyramid_begin (rows_host: nlevels ints) and returns the ticket to the pool
+extern "C" int d3_kmap_pyramid_end(void *ticket, int *rows_host, int nlevels) {
+    D3_CLEAR();
+    for (int l = 0; l < nlevels; l++) rows_host[l] = 0;
+    if (!ticket) return 0;                      // (an empty level 0: nothing was enqueued)
+    PyrTicket *t = (PyrTicket *)ticket;
+    if (t->nlevels != nlevels) return D3_ERR_ARG;
+    const hipError_t e = hipEventSynchronize(t->ev);
+    int h2 = 0;
+    if (e == hipSuccess) {
+        for (int l = 0; l < nlevels; l++) rows_host[l] = t->pinned[l];
+        h2 = t->pinned[PYR_MAXLEV + 2];
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pyr_mu);
+        g_pyr_free.push_back(t);
+    }
+    D3_CHECK(e);
+    if (h2 == 1) return D3_ERR_RANGE;
+    if (h2 == 2) return D3_ERR_OVERFLOW;
+    return 0;
+}
+
+extern "C" int d3_kmap_pyramid(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out,
+                               int *parent, int *kidx, int *flag, int *rows_dev, int *rows_host, void *stream) {
+    void *t = nullptr;
+    for (int l = 0; l < nlevels; l++) rows_host[l] = 0;
+    if (M0 <= 0 || nlevels < 1) return 0;
+    int rc = d3_kmap_pyramid_begin(coords0, M0, nlevels, ws, ws_bytes, coords_out, parent, kidx, flag, rows_dev, &t, stream);
+    if (rc) return rc;
+    return d3_kmap_pyramid_end(t, rows_host, nlevels);
 }
 
 // d3_kmap_down_fill with the first-row flags passed in (the pyramid keeps them per level)

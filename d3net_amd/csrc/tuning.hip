@@ -32,6 +32,8 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_C2_WLDS_KB", 160},         // 16-wave convolution workgroups: total LDS (weights + tile state) up to this many KB
     {"D3_C2_NW16_KB", 24},          // packed weights of at least this many KB: 16 waves share one LDS copy (1 << 20: never)
     {"D3_BQ_GRID", 1},              // 0: padded ball query by the ordered chunk scan instead of the cell grid
+    {"D3_SIDE_OP_ROWS", 0},         // convolutions below this many rows keep their weight gradient on the caller's stream (no event pair)
+    {"D3_LASTBLOCK_ROWS", 0},       // convolutions with at most this many output rows finalize the following BatchNorm's statistics themselves
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

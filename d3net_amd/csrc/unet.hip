@@ -336,6 +336,7 @@ struct Net {
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
     bool planned = false, lastblock = false;
+    int lb_rows = 0;                  // convolutions with at most this many output rows finalize the BatchNorm statistics themselves
     bool f32 = false;                 // every buffer fp32: reference-precision program (D3_CONV_F32 kernels, no bf16 gradients)
     size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
     // packing jobs (device copy refreshed when a parameter pointer or the arena moves)
@@ -489,8 +490,12 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
     // backward 5.4 -> 5.7 ms -- every workgroup has to wait for its write-through partial row and take a memory-side
     // ticket before it retires, which costs more than the 160 tiny finalize launches it saves.  Off unless
     // D3_LASTBLOCK_FINALIZE=1 (kept for hardware with a coherent L2).
+    // Round 3: per convolution instead of per network -- at the deep levels (a few thousand rows, a few dozen workgroups,
+    // every kernel at the launch floor) the ticket costs nothing measurable and the chain conv -> finalize -> apply loses a
+    // launch: D3_LASTBLOCK_ROWS is the row count up to which a convolution finalizes its own statistics.
     n->lastblock = d3_tune(D3T_LASTBLOCK_FINALIZE) == 1;
-    for (size_t j = 0; n->lastblock && j < n->ops.size(); j++) {
+    n->lb_rows = n->lastblock ? 0x7fffffff : d3_tune(D3T_LASTBLOCK_ROWS);
+    for (size_t j = 0; j < n->ops.size(); j++) {
         OpD &b = n->ops[j];
         if (b.type != OP_BNACT || b.srcs.size() != 1) continue;
         OpD &p = n->ops[b.srcs[0].op];
@@ -806,7 +811,7 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
             if (o.res >= 0) { res = (const float *)tptr(n, arena, input, o.res); ldr = n->T[o.res].ld; }
             float *part = (o.stats && training) ? (float *)(arena + o.part_off) : nullptr;
             int rc;
-            if (part && o.fin_bn >= 0) {
+            if (part && o.fin_bn >= 0 && Mout <= n->lb_rows) {
                 const OpD &b = n->ops[o.fin_bn];
                 float *mean = (float *)(arena + b.state_off), *var = mean + o.Cout;
                 rc = d3_spconv_fwd2_fin(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
@@ -832,7 +837,7 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                     const OpD &p = n->ops[r.op];
                     ss[q] = StatSrc{(const float *)(arena + p.part_off), p.nparts, p.partw, r.c0, r.cn};
                 }
-                if (M > 0 && o.fin_by < 0)
+                if (M > 0 && !(o.fin_by >= 0 && M <= n->lb_rows))
                     un_bn_finalize_kernel<<<(C + 3) / 4, 256, 0, s>>>(ss[0], ss[1], M, C, mean, var,
                                                                    o.rmean >= 0 ? (float *)params[o.rmean] : nullptr,
                                                                    o.rvar >= 0 ? (float *)params[o.rvar] : nullptr, o.momentum);
@@ -899,6 +904,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     hipStream_t ws_stream = use_side ? n->side : s;
     std::map<int, hipEvent_t> pending;   // gradient buffer root -> event after its last side-stream reader
     bool side_used = false;
+    const int side_op_rows = d3_tune(D3T_SIDE_OP_ROWS);     // convolutions with fewer rows keep their weight gradient on the caller's stream
+    bool main_wgrads = false;                               // ... and the batched reduction (side stream) is ordered behind them by one event
     auto wait_pending = [&](int root) {
         if (!use_side) return;
         auto it = pending.find(root);
@@ -913,6 +920,13 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
     // end left its 137 us exposed behind the stem's weight gradient, after the caller's stream had nothing left to do
     auto flush_red = [&]() -> int {
         if (red.empty()) return 0;
+        if (main_wgrads && use_side) {
+            hipEvent_t e = n->next_event();
+            if (!e) return D3_ERR_OVERFLOW;
+            D3_CHECK(hipEventRecord(e, s));
+            D3_CHECK(hipStreamWaitEvent(ws_stream, e, 0));
+            main_wgrads = false;
+        }
         if (red.size() > n->red_cap) {
             D3_CHECK(hipStreamSynchronize(ws_stream));   // (growing: nothing may still read the old tables -- BEFORE they are freed)
             if (n->red_host) hipHostFree(n->red_host);
@@ -956,39 +970,12 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             float *go32 = go;                      // (the residual add below reads the fp32 buffer)
             const int ldgo32 = ldgo;
             if (o.use_shadow && root_o >= 0 && n->gshadow[root_o]) { go = (float *)(garena + n->gshadow_off[root_o]); gobf = 1; ldgo = n->gshadow[root_o]; }   // dense (M, C) bf16
-            // weight gradient on the side stream
-            if (pgrads[o.w] != nullptr) {
-                if (use_side) {
-                    hipEvent_t e1 = n->next_event();
-                    if (!e1) return D3_ERR_OVERFLOW;
-                    D3_CHECK(hipEventRecord(e1, s));
-                    D3_CHECK(hipStreamWaitEvent(n->side, e1, 0));
-                    side_used = true;
-                }
-                const bool xstat = o.Cin > o.Cout;
-                int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_DYBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0);
-                const int *tw = tf;
-                if (xstat) { flags |= D3_CONV_XSTAT | (flip ? D3_CONV_FLIPK : 0); tw = tb; }
-                float *dW = pgrads[o.w];
-                // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
-                char *wpart = garena + o.wpart_off;
-                int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
-                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)ws_stream);
-                if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)
-                    RedJob j;
-                    memset(&j, 0, sizeof(j));
-                    j.part = (const float *)wpart; j.dW = dW; j.n = (long long)o.K * o.CinW * o.Cout; j.R = o.wsplits;
-                    j.accum = paccum[o.w] ? 1 : 0; j.start = red_blocks;
-                    red_blocks += (j.n + 31) / 32;
-                    red.push_back(j);
-                }
-                if (rc) return rc;
-                if (use_side && root_o >= 0 && o.wg_hazard) {
-                    hipEvent_t e2 = n->next_event();
-                    if (!e2) return D3_ERR_OVERFLOW;
-                    D3_CHECK(hipEventRecord(e2, n->side));
-                    pending[root_o] = e2;
-                }
+            const bool op_side = use_side && (Min > Mout ? Min : Mout) >= side_op_rows;
+            hipEvent_t e1 = nullptr;
+            if (pgrads[o.w] != nullptr && op_side) {      // dy is complete here
+                e1 = n->next_event();
+                if (!e1) return D3_ERR_OVERFLOW;
+                D3_CHECK(hipEventRecord(e1, s));
             }
             // data gradient
             if (o.in_grad_mode) {
@@ -999,7 +986,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     const OpD &b = n->ops[o.bn_of_in];
                     const TensorD &tx = n->T[b.in];
                     float *mean = (float *)(arena + b.state_off), *var = mean + tx.C;
-                    if (!n->lastblock)
+                    if (Min > n->lb_rows)
                         rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
                                                   (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
@@ -1020,6 +1007,41 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 const long long total = (long long)Mout * (o.Cout / 4);
                 if (total > 0) un_add_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(gr, ldr, go32, ldgo32, Mout, o.Cout, o.res_mode == 3 ? 1 : 0);
             }
+            // weight gradient on the side stream -- enqueued AFTER the data gradient: at the deep levels the caller's stream runs ~10 us
+            // kernels and the host is the bottleneck (event pair + plan + launches of the weight gradient took ~20 us of host time in
+            // front of every data gradient: profiles/r03_b step gaps); the event is recorded where dy is complete, i.e. before the
+            // data gradient, so the side stream loses nothing
+            if (pgrads[o.w] != nullptr) {
+                if (!op_side) main_wgrads = true;
+                if (op_side) {
+                    D3_CHECK(hipStreamWaitEvent(n->side, e1, 0));
+                    side_used = true;
+                }
+                const bool xstat = o.Cin > o.Cout;
+                int flags = (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (paccum[o.w] ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_DYBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0);
+                const int *tw = tf;
+                if (xstat) { flags |= D3_CONV_XSTAT | (flip ? D3_CONV_FLIPK : 0); tw = tb; }
+                float *dW = pgrads[o.w];
+                // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
+                char *wpart = garena + o.wpart_off;
+                int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
+                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? ws_stream : s));
+                if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)
+                    RedJob j;
+                    memset(&j, 0, sizeof(j));
+                    j.part = (const float *)wpart; j.dW = dW; j.n = (long long)o.K * o.CinW * o.Cout; j.R = o.wsplits;
+                    j.accum = paccum[o.w] ? 1 : 0; j.start = red_blocks;
+                    red_blocks += (j.n + 31) / 32;
+                    red.push_back(j);
+                }
+                if (rc) return rc;
+                if (op_side && root_o >= 0 && o.wg_hazard) {
+                    hipEvent_t e2 = n->next_event();
+                    if (!e2) return D3_ERR_OVERFLOW;
+                    D3_CHECK(hipEventRecord(e2, n->side));
+                    pending[root_o] = e2;
+                }
+            }
         } else if (o.type == OP_BNACT) {
             if (!o.in_grad_mode && pgrads[o.gamma] == nullptr) continue;
             const TensorD &ti = n->T[o.in];
@@ -1031,7 +1053,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
             if (o.fused_by >= 0) {   // reductions (and the ReLU mask) done by the consumer conv's data gradient
-                if (!n->lastblock)
+                if (M > n->lb_rows)
                     un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
                                                                    pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
                 relu = 0;

@@ -54,6 +54,7 @@ class CoordinateManager:
         self.coords = {1: coordinates.contiguous()}
         self._k3 = {}
         self._down = {}
+        self._pending = None      # begin_pyramid() without its build_pyramid() yet
 
     def _ws(self, M):
         return _workspace(_lib.lib().d3_coordmap_ws_bytes(M), self.device, "cm")
@@ -69,30 +70,47 @@ class CoordinateManager:
             self._k3[ts] = nbr
         return self._k3[ts]
 
-    def build_pyramid(self, nlevels):
-        """Coordinates and stride-2 maps of levels 1..nlevels-1 with one host round trip (d3_kmap_pyramid) instead of
-        one per level; afterwards `down(ts)` / `coords[ts]` are cache hits."""
-        if all((1 << l) in self._down for l in range(nlevels - 1)) or 1 in self._down:
+    def begin_pyramid(self, nlevels):
+        """Enqueue the coordinate pyramid of levels 1..nlevels-1 and the copy of its row counts WITHOUT waiting for them
+        (d3_kmap_pyramid_begin): device work enqueued by the caller before `build_pyramid` runs while the host reads the counts."""
+        if self._pending is not None or 1 in self._down:
             return
         c0 = self.coords[1]
         M0 = c0.size(0)
         if M0 == 0 or nlevels < 2:
             return
         dev = self.device
-        L = _lib.lib()
         n1 = nlevels - 1
         cout = torch.empty((n1, M0, 4), dtype=torch.int32, device=dev)
         par = torch.empty((n1, M0), dtype=torch.int32, device=dev)
         kid = torch.empty((n1, M0), dtype=torch.int32, device=dev)
         flg = torch.empty((n1, M0), dtype=torch.int32, device=dev)
         rdev = torch.empty(nlevels, dtype=torch.int32, device=dev)
-        rows = (C.c_int * nlevels)()
         ws = self._ws(M0)
+        ticket = C.c_void_p()
         with _on(dev):
-            check(L.d3_kmap_pyramid(_ptr(c0), M0, nlevels, _ptr(ws), ws.numel(), _ptr(cout), _ptr(par), _ptr(kid), _ptr(flg),
-                                    _ptr(rdev), rows, _stream()), "kmap_pyramid")
+            check(_lib.lib().d3_kmap_pyramid_begin(_ptr(c0), M0, nlevels, _ptr(ws), ws.numel(), _ptr(cout), _ptr(par), _ptr(kid), _ptr(flg),
+                                                  _ptr(rdev), C.byref(ticket), _stream()), "kmap_pyramid_begin")
+        self._pending = (nlevels, ticket, cout, par, kid, flg, rdev, ws)
+
+    def build_pyramid(self, nlevels):
+        """Coordinates and stride-2 maps of levels 1..nlevels-1 with one host round trip (d3_kmap_pyramid_begin / _end) instead
+        of one per level; afterwards `down(ts)` / `coords[ts]` are cache hits."""
+        if self._pending is None:
+            if all((1 << l) in self._down for l in range(nlevels - 1)) or 1 in self._down:
+                return
+            self.begin_pyramid(nlevels)
+            if self._pending is None:
+                return
+        nl, ticket, cout, par, kid, flg, rdev, ws = self._pending
+        self._pending = None
+        dev = self.device
+        L = _lib.lib()
+        rows = (C.c_int * nl)()
+        check(L.d3_kmap_pyramid_end(ticket, rows, nl), "kmap_pyramid_end")
+        with _on(dev):
             ts = 1
-            for l in range(n1):
+            for l in range(nl - 1):
                 M, Mo = rows[l], rows[l + 1]
                 child = torch.empty((Mo, 8), dtype=torch.int32, device=dev)
                 up = torch.empty((M, 8), dtype=torch.int32, device=dev)
@@ -103,6 +121,8 @@ class CoordinateManager:
 
     def down(self, ts):
         """-> (child (Mout,8), up (M,8), Mout); registers the coordinates of stride 2*ts."""
+        if self._pending is not None:
+            self.build_pyramid(self._pending[0])
         if ts not in self._down:
             c = self.coords[ts]
             M = c.size(0)

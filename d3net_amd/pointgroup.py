@@ -160,6 +160,14 @@ class PointGroup(nn.Module):
             self._execs[key] = ex
         return ex
 
+    def _begin_maps(self, name, voxel_locs):
+        """coordinate manager of a U-Net input with its pyramid already enqueued (the native executor's path; None otherwise)"""
+        if not (self.native_unet and voxel_locs.is_cuda and voxel_locs.size(0) > 0) or (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)):
+            return None
+        cm = ME.CoordinateManager(voxel_locs.int().contiguous())
+        cm.begin_pyramid(self._exec(name, exact=ME._EXACT).nlevels)
+        return cm
+
     def _run_unet(self, name, module, x):
         """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""
         if self.native_unet and not (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)) and x.F.size(0) > 0:
@@ -244,8 +252,9 @@ class PointGroup(nn.Module):
         _mark("cv_elementwise")
         voxel_coords, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(clusters_coords, n_clusters, mode)
         _mark("cv_voxelization_idx")
+        cm = self._begin_maps("score_net", voxel_coords)      # (as in feed(): the pooling below runs during the round trip)
         voxel_feats = pointgroup_ops.voxelization(clusters_feats, v2p_map, mode)
-        voxel_feats = ME.SparseTensor(features=voxel_feats, coordinates=voxel_coords.int())
+        voxel_feats = ME.SparseTensor(features=voxel_feats, coordinates=None if cm is not None else voxel_coords.int(), coordinate_manager=cm)
         voxel_feats.v2p_map = v2p_map
         return voxel_feats, p2v_map, (clusters_center, clusters_size)
 
@@ -274,8 +283,10 @@ class PointGroup(nn.Module):
         crop = data_dict["proposal_crop_bbox"]
         keys = ("proposal_feats_batched", "proposal_bbox_batched", "proposal_center_batched", "proposal_sem_cls_batched",
                 "proposal_scores_batched", "proposal_batch_mask")
-        perm = torch.stack([torch.randperm(K) if perms is None else perms[b].cpu() for b in range(batch_size)])   # (:251)
-        perm = _STAGE.put(perm, dev)
+        perm = data_dict.pop("_slot_perm_staged", None) if perms is None else None
+        if perm is None:
+            perm = torch.stack([torch.randperm(K) if perms is None else perms[b].cpu() for b in range(batch_size)])   # (:251)
+            perm = _STAGE.put(perm, dev)
         # one fill + three launches (csrc/heads.hip) when the shapes allow; the library-op form below otherwise
         want_assign = self.cfg.general.task != "test"
         fused = heads.stack_to_batch(pf, data_dict["proposal_objectness_scores"], crop.detach(), data_dict["proposals_batchId"],
@@ -321,7 +332,9 @@ class PointGroup(nn.Module):
     # ------------------------------------------------------------------------------------- forward
     def forward(self, data_dict):
         batch_size = len(data_dict["batch_offsets"]) - 1
-        x = ME.SparseTensor(features=data_dict["voxel_feats"], coordinates=data_dict["voxel_locs"].int())
+        cm = data_dict.pop("_backbone_cm", None)
+        x = ME.SparseTensor(features=data_dict["voxel_feats"], coordinates=None if cm is not None else data_dict["voxel_locs"].int(),
+                            coordinate_manager=cm)
         _mark("voxelize")
         out_feats = self._run_unet("backbone", self.backbone, x)
         _mark("backbone_fwd")
@@ -406,6 +419,13 @@ class PointGroup(nn.Module):
             _mark("cluster_voxelization")
             score_feats = self._run_unet("score_net", self.score_net, proposals_voxel_feats)
             _mark("score_net_fwd")
+            # Host work that does not depend on the proposals goes HERE: the device still has the cluster voxelisation and
+            # ScoreNet queued, so the point losses' ~20 small launches and the slot permutation's CPU draw cost no device time;
+            # after the `nonzero` below the queue is empty and every host microsecond is an idle device microsecond.
+            self._early_point_losses(data_dict)
+            if "slot_perms" not in data_dict:     # (same position in the CPU generator's stream as the reference's draw, :251 --
+                K = self.cfg.model.max_num_proposal   # nothing between here and convert_stack_to_batch draws from it)
+                data_dict["_slot_perm_staged"] = _STAGE.put(torch.stack([torch.randperm(K) for _ in range(batch_size)]), pt_feats.device)
             pt_score_feats = heads.devoxelize(score_feats, proposals_p2v_map, getattr(proposals_voxel_feats, "v2p_map", None))
             proposals_score_feats = pointgroup_ops.roipool(pt_score_feats, proposals_offset)   # (P, m)
             scores = self.score_linear(proposals_score_feats)
@@ -465,15 +485,35 @@ class PointGroup(nn.Module):
         return data_dict
 
     # ---------------------------------------------------------------------------------------- loss
+    def _point_losses(self, semantic_scores, semantic_labels, pt_offsets, coords, instance_info, instance_ids):
+        semantic_loss = heads.cross_entropy(semantic_scores, semantic_labels, ignore_index=self.cfg.data.ignore_label)
+        offset_norm_loss, offset_dir_loss, n_valid = heads.offset_losses(pt_offsets, coords, instance_info, instance_ids,
+                                                                         self.cfg.data.ignore_label)
+        return semantic_loss, offset_norm_loss, offset_dir_loss, n_valid
+
+    def _early_point_losses(self, data_dict):
+        """the semantic / offset losses of `loss()` computed inside forward() (they need only the point heads' outputs and the
+        labels); `loss()` takes them over when it is called with the very same tensors"""
+        if self.mode == "test" or not torch.is_grad_enabled():
+            return
+        need = ("sem_labels", "locs", "instance_info", "instance_ids")
+        if any(k not in data_dict for k in need) or not torch.is_tensor(data_dict["semantic_scores"]):
+            return
+        args = (data_dict["semantic_scores"], data_dict["sem_labels"], data_dict["pt_offsets"], data_dict["locs"],
+                data_dict["instance_info"], data_dict["instance_ids"])
+        data_dict["_point_losses"] = (args, self._point_losses(*args))
+
     def loss(self, data_dict, epoch):
         """semantic CE + offset L1 / direction + soft-IoU score BCE (reference :387-463)."""
         semantic_scores, semantic_labels = data_dict["semantic_scores"]
-        semantic_loss = heads.cross_entropy(semantic_scores, semantic_labels, ignore_index=self.cfg.data.ignore_label)
-        data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
-
         pt_offsets, coords, instance_info, instance_ids = data_dict["pt_offsets"]
-        offset_norm_loss, offset_dir_loss, n_valid = heads.offset_losses(pt_offsets, coords, instance_info, instance_ids,
-                                                                         self.cfg.data.ignore_label)
+        args = (semantic_scores, semantic_labels, pt_offsets, coords, instance_info, instance_ids)
+        early = data_dict.pop("_point_losses", None)
+        if early is not None and len(early[0]) == len(args) and all(a is b for a, b in zip(early[0], args)):
+            semantic_loss, offset_norm_loss, offset_dir_loss, n_valid = early[1]
+        else:
+            semantic_loss, offset_norm_loss, offset_dir_loss, n_valid = self._point_losses(*args)
+        data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
         data_dict["offset_norm_loss"] = (offset_norm_loss, n_valid)
         data_dict["offset_dir_loss"] = (offset_dir_loss, n_valid)
 
@@ -498,6 +538,10 @@ class PointGroup(nn.Module):
         """(reference :466-479)"""
         data_dict["epoch"] = epoch
         f = data_dict["feats"]
+        # The coordinate pyramid of the backbone needs one host round trip (the level sizes).  Its kernels and the copy of
+        # the counts are enqueued BEFORE the input voxelisation, the wait comes after it: the device pools the point features
+        # (~0.27 ms for four scenes) while the host reads the counts and enqueues the kernel-map fills.
+        cm = self._begin_maps("backbone", data_dict["voxel_locs"])
         if self.cfg.model.use_coords and f.is_cuda and f.dtype == torch.float32 and not f.requires_grad:
             # voxelization(cat(feats, locs)) without the concatenated copy (csrc/voxelize.hip: d3_voxelize_fp2)
             data_dict["voxel_feats"] = pointgroup_ops.voxelization_cat(f, data_dict["locs"], data_dict["v2p_map"], self.cfg.data.mode)
@@ -506,6 +550,8 @@ class PointGroup(nn.Module):
                 data_dict["feats"] = torch.cat((data_dict["feats"], data_dict["locs"]), 1)
             data_dict["voxel_feats"] = pointgroup_ops.voxelization(data_dict["feats"].contiguous(), data_dict["v2p_map"],
                                                                    self.cfg.data.mode)
+        if cm is not None:
+            data_dict["_backbone_cm"] = cm
         data_dict = self.forward(data_dict)
         if data_dict["epoch"] > self.prepare_epochs or self.freeze_backbone:
             data_dict = self.convert_stack_to_batch(data_dict, perms=data_dict.get("slot_perms"))

@@ -197,6 +197,12 @@ int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_byte
  * (nlevels-1, M0) (level l at [l*M0], rows of level l); rows_dev: nlevels ints.  ws >= d3_coordmap_ws_bytes(M0). */
 int d3_kmap_pyramid(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out, int *parent,
                     int *kidx, int *flag, int *rows_dev, int *rows_host, void *stream);
+/* The same with the host round trip split in two: _begin enqueues the level kernels and the copy of the row counts and returns
+ * a ticket; _end waits for that copy only (not for work enqueued on the stream in between -- the caller puts independent
+ * device work there: PointGroup.feed the input voxelisation) and returns rows_host.  *ticket == NULL when M0 == 0. */
+int d3_kmap_pyramid_begin(const int *coords0, int M0, int nlevels, void *ws, size_t ws_bytes, int *coords_out, int *parent,
+                          int *kidx, int *flag, int *rows_dev, void **ticket, void *stream);
+int d3_kmap_pyramid_end(void *ticket, int *rows_host, int nlevels);
 int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int *child, int *up, void *stream);
 
 /* Gather-GEMM convolution  out[u,:] = sum_k x[tbl[u,k],:] @ Wk   (tbl == NULL: identity map, K = 1).

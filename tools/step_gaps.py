@@ -68,6 +68,13 @@ def main():
             for e in es:
                 f.write("%9.3f %7.1f %7.1f  %s\n" % ((e[0] - es[0][0]) / 1e6, (e[1] - e[0]) / 1e3, max(0, e[0] - pe) / 1e3, e[2]))
                 pe = max(pe, e[1])
+    if os.environ.get("D3_GAPS_DUMP_ALL"):   # every kernel of the step on every queue in start order (queue, start ms, us, name)
+        with open(os.environ["D3_GAPS_DUMP_ALL"], "w") as f:
+            qend = {}
+            for e in seg:
+                idle = max(0, e[0] - qend.get(e[3], e[0])) / 1e3
+                f.write("q%-2s %9.3f %7.1f %7.1f  %s\n" % (e[3], (e[0] - seg[0][0]) / 1e6, (e[1] - e[0]) / 1e3, idle, e[2]))
+                qend[e[3]] = max(qend.get(e[3], 0), e[1])
     agg = defaultdict(lambda: [0, 0, 0])
     prev_end = es[0][0]
     for e in es:
