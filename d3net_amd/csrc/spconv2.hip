@@ -129,6 +129,7 @@ struct Conv2Args {
     unsigned int inv;           // ceil(65536 / S): i = (s * inv) >> 16 == s / S for s < 4096
     int xbf16, accum, ntiles, NT;   // NT = ceil(Cout / 16)
     int f32;                        // D3_CONV_F32: fp32 weight fragments, v_mfma_f32_16x16x4_f32 (host-side dispatch only)
+    unsigned int xbytes;            // extent of x in bytes for the raw buffer gathers (0: beyond 2 GiB / 2^24 rows, refused for the wave-per-tile kernel)
     unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
     // BatchNorm-backward epilogue (data gradient of a BN -> ReLU -> conv unit): the stored value is g = dy * relu'(bn(x))
     // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
@@ -206,6 +207,9 @@ __device__ __forceinline__ void c2_load_raw(const void *x, long long off, uint4 
     if (XBF) lo = *(const uint4 *)((const unsigned short *)x + off);
     else { lo = *(const uint4 *)((const float *)x + off); hi = *(const uint4 *)((const float *)x + off + 4); }
 }
+typedef unsigned int c2_u32x4 __attribute__((ext_vector_type(4)));
+#define C2_RSRC_FLAGS 0x00020000          // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+__device__ __forceinline__ uint4 c2_from_u32x4(const c2_u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
 template <bool XBF>
 __device__ __forceinline__ bf16x8_t c2_cvt_raw(const uint4 lo, const uint4 hi) {
     if (XBF) return __builtin_bit_cast(bf16x8_t, lo);
@@ -241,7 +245,8 @@ __device__ __forceinline__ void c2_wload(const unsigned short *Wb, int e, uint4 
 }
 
 // LDS use of the wave-per-tile kernel besides the weights
-#define C2_TBL_INTS (16 * C2_MAXK)
+#define C2_TBL_SENT (16 * C2_MAXK)        // one more slot per wave that always holds -1 (steps beyond the reduction read it)
+#define C2_TBL_INTS (16 * C2_MAXK + 16)
 #define C2_WAVE_LDS_BASE(NTV, NWV) ((NWV) * C2_TBL_INTS * 4 + (NWV) * 32 * 4 + (NWV) * 2 * (NTV) * 16 * 4)
 #define C2_WAVE_LDS_BYTES(NTV, NWV) (C2_WAVE_LDS_BASE(NTV, NWV) + (NTV) * 16 * 16)   // + BatchNorm parameters, float4 per channel
 
@@ -265,14 +270,21 @@ __device__ __forceinline__ void c2_wload(const unsigned short *Wb, int e, uint4 
 #define C2_F32_OCCDROP 1
 #endif
 #define C2_OCC(NTV, XB) ((NTV) <= 4 ? ((XB) ? C2_OCC_SMALL : C2_OCC_SMALL - C2_F32_OCCDROP) : (NTV) <= 9 ? ((XB) ? 3 : 2) : 2)
-template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false>
+// KT / ST > 0: kernel size and slots per offset (Cin / 8) known at compile time (round 3: the shapes that carry the step -- K = 27
+// with 16 / 32 / 64 input channels): the reduction loop is fully unrolled and every (offset, channel group) of a step is a
+// constant per lane group -- the ~10 index instructions in front of each gather fold away.
+template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false, int KT = 0, int ST = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
     static_assert(!(F32M && XBF), "fp32 MFMA needs fp32 gathers");
+    static_assert((KT > 0) == (ST > 0), "static shapes fix both the kernel size and the channel groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (16-wave workgroups run at 128 VGPRs: the fp32-input variants keep 4 gathers of 32 B in flight there instead of 8)
-    constexpr int U = (!XBF && NT <= 2) ? (NW == 16 ? 4 : C2_F32_U) : C2_U(NT);
+    // statically shaped, >= 32 input channels: a batch is KB whole offsets of Q = ceil(ST / 4) steps each
+    constexpr int Q = ST >= 4 ? (ST + 3) / 4 : 1;
+    constexpr int KB = ST >= 4 ? (Q >= 5 ? 2 : (8 / Q > 0 ? 8 / Q : 1)) : 1;
+    constexpr int U = ST >= 4 ? KB * Q : (!XBF && NT <= 2) ? (NW == 16 ? 4 : C2_F32_U) : C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
-    const int K = a.K, S = a.S;
+    const int K = KT ? KT : a.K, S = ST ? ST : a.S;
     const size_t wbytes = WLDS ? (size_t)K * S * NT * (F32M ? 512 : 256) : 0;
     int *tblS = (int *)(smem + wbytes) + wave * C2_TBL_INTS;
     float *redS = (float *)(smem + wbytes + NW * C2_TBL_INTS * 4);
@@ -320,6 +332,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
 #pragma unroll
     for (int n = 0; n < NT; n++) { ssum[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int nsteps = (K * S + 3) >> 2;
+    constexpr int NSTEPS_T = (KT * ST + 3) / 4;   // static shapes below 32 channels: steps of a tile
+    const unsigned int xrowb = (unsigned int)a.ldx * (XBF ? 2u : 4u);
+    const int rK = r * K;
+    if (lane == 0) tblS[C2_TBL_SENT] = -1;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, C2_RSRC_FLAGS);
 
     for (int tg = tg0; tg < tg1; tg++) {
         const int tile = tg * NW + wave;
@@ -357,32 +374,62 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
             }                                                                                                 \
         }
         if (HOIST) { C2_EPI_LOAD(0) }
-        for (int m0 = 0; m0 < nsteps; m0 += U) {
+        auto batch = [&](const int m0) __attribute__((always_inline)) {
             uint4 rlo[U], rhi[U];
-            int boff[U];
+            int boff[U], idxv[U], c8v[U];
+            // Round 3 (ISA review): the kernel-map entries of the whole batch are read from LDS back to back and unconditionally
+            // (a clamped slot: a conditional read put an exec-masked branch and a full LDS wait in front of EVERY gather -- eight
+            // serialized LDS round trips per batch), the row offset is one unsigned 32 x 32 -> 64 multiply-add (the signed
+            // long long form took three), and the weight element of slot s is simply s * NT * 16 + r (k * S + c8 == s).
+            int lidx[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int s = 4 * (m0 + u) + g;
-                const int k = (int)(((unsigned int)s * a.inv) >> 16);
-                const int c8 = s - k * S;
-                const bool ok = (m0 + u < nsteps) && (k < K);
-                const int idx = ok ? tblS[r * K + k] : -1;
-                boff[u] = ok ? ((k * S + c8) * NT) * 16 + r : r;      // weight ELEMENT index (16 B bf16 / 32 B fp32 each)
-                rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u];
-                if (idx >= 0) c2_load_raw<XBF>(a.x, (long long)idx * a.ldx + c8 * 8, rlo[u], rhi[u]);
+                int s = 4 * (m0 + u) + g, k;
+                bool ok;
+                if (ST >= 4) {
+                    // static shapes with >= 32 input channels: a step stays inside ONE offset (here m0 is the first OFFSET of the
+                    // batch; the channel group is a constant per lane group; 136 channels run 5 steps per offset, the last one
+                    // with a single live lane group)
+                    k = m0 + u / Q;
+                    c8v[u] = 4 * (u % Q) + g;
+                    ok = (k < KT) && (c8v[u] < ST);
+                    s = k * ST + c8v[u];
+                } else {
+                    k = ST ? s / (ST ? ST : 1) : (int)(__umul24((unsigned int)s, a.inv) >> 16);      // (24-bit multiplies: full rate)
+                    c8v[u] = s - (int)__umul24((unsigned int)k, (unsigned int)S);
+                    ok = (m0 + u < nsteps) && (k < K);
+                }
+                lidx[u] = ok ? rK + k : C2_TBL_SENT;                              // (the sentinel slot holds -1)
+                boff[u] = ok ? s * (NT * 16) + r : r;                 // weight ELEMENT index (16 B bf16 / 32 B fp32 each)
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) idxv[u] = tblS[lidx[u]];
+            // raw buffer gathers: an absent neighbour (-1) lands beyond the buffer's extent and the hardware returns zeros
+            // without a memory request -- no exec-masked branch, no zero fill and no 64-bit address per gather
+            // (inputs beyond 2 GiB are refused by the host: 32-bit offsets, absent rows at offset 2^31)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if ((ST > 0 && ST < 4 && m0 + u >= NSTEPS_T) || (ST >= 4 && m0 + u / Q >= KT)) {   // (folded where m0 is a constant; wave-uniform otherwise)
+                    rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u]; continue;
+                }
+                const unsigned int off = idxv[u] >= 0 ? __umul24((unsigned int)idxv[u], xrowb) + (unsigned int)c8v[u] * (XBF ? 16u : 32u) : 0x80000000u;
+                rlo[u] = c2_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                if (!XBF) rhi[u] = c2_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off + 16u, 0, 0));
+                else rhi[u] = rlo[u];
             }
             if (WLDS || F32M) {
                 __builtin_amdgcn_sched_barrier(0);   // every gather is in flight before the first conversion
+                // (steps beyond nsteps gathered nothing: their products add zero, and without a branch per step the weight
+                // fragments of the batch are read ahead of the products instead of one LDS round trip in front of each)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    if (m0 + u < nsteps) {   // wave-uniform
+                    if ((ST > 0 && ST < 4 && m0 + u >= NSTEPS_T) || (ST >= 4 && m0 + u / Q >= KT)) continue;
 #pragma unroll
-                        for (int n = 0; n < NT; n++) {
-                            uint4 wl, wh;
-                            c2_wload<F32M>(Wb, boff[u] + n * 16, wl, wh);
-                            // transposed product: D[m = channel][n = row] += W^T[channel][k] * X^T[k][row]
-                            acc[n] = c2_mma<XBF, F32M>(acc[n], wl, wh, rlo[u], rhi[u]);
-                        }
+                    for (int n = 0; n < NT; n++) {
+                        uint4 wl, wh;
+                        c2_wload<F32M>(Wb, boff[u] + n * 16, wl, wh);
+                        // transposed product: D[m = channel][n = row] += W^T[channel][k] * X^T[k][row]
+                        acc[n] = c2_mma<XBF, F32M>(acc[n], wl, wh, rlo[u], rhi[u]);
                     }
                 }
             } else {
@@ -428,6 +475,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                     }
                 }
             }
+        };
+        if constexpr (ST >= 4 && KT * Q > 56) {          // (the stem: 135 steps -- unrolled completely it spills)
+#pragma unroll 1
+            for (int k0 = 0; k0 < KT; k0 += KB) batch(k0);
+        } else if constexpr (ST >= 4) {
+#pragma unroll
+            for (int k0 = 0; k0 < KT; k0 += KB) batch(k0);
+        } else if constexpr (ST > 0) {
+#pragma unroll
+            for (int m0 = 0; m0 < NSTEPS_T; m0 += U) batch(m0);
+        } else {
+            for (int m0 = 0; m0 < nsteps; m0 += U) batch(m0);
         }
         // D layout: column (= output row) lane & 15, rows (= channels) (lane >> 4) * 4 + q
 #pragma unroll
@@ -750,9 +809,32 @@ static int launch_fwd2_f32(const Conv2Args &a, const Conv2Plan &p, hipStream_t s
     D3_LAUNCH_CHECK();
     return 0;
 }
+// the statically shaped instances (K = 27, bf16 rows, weights in LDS)
+template <int NT, int NW, int ST>
+static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev))
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST><<<p.grid, 64 * NW, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
 template <int NT>
 static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
     if (a.f32) return launch_fwd2_f32<NT>(a, p, s);
+    if (a.xbf16 && a.K == 27 && p.wlds && d3_tune(D3T_C2_STATIC) != 0) {
+        if constexpr (NT == 1) {
+            if (a.S == 2 && p.nw == 4) return launch_fwd2_static<1, 4, 2>(a, p, s);      // 16 -> 16
+            if (a.S == 4 && p.nw == 16) return launch_fwd2_static<1, 16, 4>(a, p, s);    // 32 -> 16
+            if (a.S == 17 && p.nw == 16) return launch_fwd2_static<1, 16, 17>(a, p, s);  // the stem: 134 (+2) -> 16
+        }
+        if constexpr (NT == 2) {
+            if (a.S == 2 && p.nw == 16) return launch_fwd2_static<2, 16, 2>(a, p, s);    // 16 -> 32
+            if (a.S == 4 && p.nw == 16) return launch_fwd2_static<2, 16, 4>(a, p, s);    // 32 -> 32
+            if (a.S == 8 && p.nw == 16) return launch_fwd2_static<2, 16, 8>(a, p, s);    // 64 -> 32
+        }
+        // (48 -> 48 and 32 -> 64 spill at 128 registers when fully unrolled: they stay on the generic instance)
+    }
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev)) {   // allow more than 64 KB of dynamic LDS
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -824,6 +906,11 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     a.inv = (65536u + a.S - 1) / a.S;
     a.invK = (65536u + K - 1) / K;
     a.xbf16 = xbf16; a.f32 = f32; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
+    {   // the last row of a column view ends after Cin elements; an absent neighbour's offset (2^32 - row bytes + ...) must stay outside
+        const unsigned long long elt = xbf16 ? 2ull : 4ull, rowb = (unsigned long long)ldx * elt;
+        const unsigned long long xb = Min > 0 ? ((unsigned long long)(Min - 1) * ldx + Cin) * elt : 0ull;
+        a.xbytes = (Min > 0 && Min < (1 << 24) && rowb < (1ull << 24) && xb <= 0x7FFFFFFFull) ? (unsigned int)xb : 0u;   // (24-bit row x row-bytes multiply; absent rows address 2 GiB)
+    }
     a.bnx = nullptr; a.bn_mean = a.bn_var = a.bn_gamma = a.bn_beta = nullptr; a.ldbx = 0; a.bn_relu = 0; a.bn_eps = 0.f;
     if (bn) {
         if (bn->ldx & 3) return D3_ERR_ARG;
@@ -836,6 +923,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         a.fin_a = fin->a; a.fin_b = fin->b; a.fin_c = fin->c; a.fin_d = fin->d; a.fin_momentum = fin->momentum;
     }
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout, f32 != 0);
+    if (!p.split && a.xbytes == 0u) return D3_ERR_RANGE;   // the wave-per-tile kernel addresses x through a raw buffer: <= 2 GiB, < 2^24 rows
     const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + (f32 ? 4.0 : 2.0) * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
     void *pr = d3_prof_begin(p.split ? 2 : 0, bytes, 0.0, s);

@@ -34,6 +34,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_BQ_GRID", 1},              // 0: padded ball query by the ordered chunk scan instead of the cell grid
     {"D3_SIDE_OP_ROWS", 0},         // convolutions below this many rows keep their weight gradient on the caller's stream (no event pair)
     {"D3_LASTBLOCK_ROWS", 0},       // convolutions with at most this many output rows finalize the following BatchNorm's statistics themselves
+    {"D3_C2_STATIC", 1},            // 0: never the statically shaped convolution instances (K = 27, 16 / 32 / 48 / 64 input channels)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

@@ -137,6 +137,23 @@ def test_canonical_step_exact_executor_equals_exact_module_path(dev, canonical):
     print("exact executor vs exact module path: gradient rel-L2 median %.2e, worst %.2e (%s)" % (vals[len(vals) // 2], errs[worst], worst))
     # (measured on MI355X: median 3.7e-4, worst 2.0e-3 -- fp32 against fp32 with different reduction orders through ~70 ReLU layers)
     assert vals[len(vals) // 2] < 2e-3 and errs[worst] < 2e-2, (vals[len(vals) // 2], worst, errs[worst])
+    # the bf16 step bench.py times, bounded against THIS path (same kernels' structure, same schedule, fp32 operands): what bf16
+    # MFMA operands alone change.  Direction (cosine) and size (norm ratio) per tensor; ~70 ReLU layers decorrelate single entries,
+    # so the bound is statistical: median cosine > 0.7, 10th percentile > 0.3, none pointing backwards, norms within 2x
+    # (measured on MI355X: median cosine 0.81, norm ratio median 1.00, extremes 0.7 .. 1.4).
+    for p in model.parameters():
+        p.grad = None
+    _hip_step(c, dev, exact=False)
+    cs, ratio = {}, {}
+    for n, p in model.named_parameters():
+        if p.grad is not None and n in g_exec and not _degenerate(n, g_exec[n]):
+            cs[n] = cos(p.grad, g_exec[n])
+            ratio[n] = float(p.grad.double().norm() / (g_exec[n].double().norm() + 1e-30))
+    cv, rv = sorted(cs.values()), sorted(ratio.values())
+    print("bf16 executor vs fp32-MFMA executor: grad cosine median %.4f 10%% %.4f worst %.4f; norm ratio median %.3f min %.3f max %.3f" %
+          (cv[len(cv) // 2], cv[len(cv) // 10], cv[0], rv[len(rv) // 2], rv[0], rv[-1]))
+    assert cv[len(cv) // 2] > 0.7 and cv[len(cv) // 10] > 0.3 and cv[0] > 0.0, (cv[len(cv) // 2], cv[len(cv) // 10], cv[0])
+    assert 0.8 < rv[len(rv) // 2] < 1.25 and rv[0] > 0.4 and rv[-1] < 2.5, (rv[0], rv[len(rv) // 2], rv[-1])
 
 
 def test_canonical_step_bf16_executor_close_to_oracle(dev, canonical):
