@@ -275,7 +275,9 @@ int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
         else hg_gemm_kernel<RTV, true, 4><<<dim3(ctiles, GY, nprobs), 256, 0, s>>>(b);                      \
     } while (0)
     if (maxM <= 32) {            // a decode step: K split over the waves of a workgroup
-        if (maxM <= 16) HG_SPLIT(1, 1); else HG_SPLIT(2, 1);
+        if (maxM <= 16) HG_SPLIT(1, 1);
+        else if (d3_tune(D3T_HG_RT1) != 0) HG_SPLIT(1, 2);     // (one row tile per workgroup: twice the workgroups; 0: two tiles)
+        else HG_SPLIT(2, 1);
     } else {
         const long long tiles16 = (long long)ctiles * ((maxM + 15) / 16);
         if (tiles16 < 2048) {    // few tiles: still split K so that the chip is covered

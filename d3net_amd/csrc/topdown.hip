@@ -172,10 +172,122 @@ __global__ __launch_bounds__(GRU_NW * 64) void td_gru_fwd_kernel(const GruArgs a
     }
 }
 
+// The same cell with the GATES packed into the MFMA columns (round 3): a workgroup owns 4 hidden units and its 16 columns are
+// (r, z, n-input, n-hidden) x 4 units -- a lane's weight row is Wih / Whh row gate * H + unit (no row for the n-hidden column in
+// the input segments and for the n-input column in the recurrent one), ONE accumulator per row tile.  The cell is bound by the
+// fp32 MFMA chain of the few workgroups that hold it (16 units: 12 products per k block and row tile on 32 compute units =
+// 5.5 us of matrix time at N = 32, H = 512); here 128 workgroups issue 4 products per k block, and 16 waves split the k blocks.
+#define GRU4_NW 16
+#ifndef GRU4_U
+#define GRU4_U 3
+#endif
+template <int RT>
+__global__ __launch_bounds__(GRU4_NW * 64) void td_gru4_fwd_kernel(const GruArgs a) {
+    __shared__ float red[GRU4_NW * RT * 256];   // [wave][rt][q][lane]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int ut = blockIdx.x, rg = blockIdx.y, H = a.H;
+    const int gate = i >> 2, unit = ut * 4 + (i & 3);
+    f32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int gkb = 0;
+#pragma unroll
+    for (int seg = 0; seg < 3; seg++) {      // input-side segment(s), then the recurrent one
+        if (seg == 0 && !a.x) continue;
+        if (seg == 1 && !a.xb) continue;
+        const int K = seg == 0 ? a.I : seg == 1 ? a.Ib : H;
+        const float *X = seg == 0 ? a.x : seg == 1 ? a.xb : a.h;
+        const long long ldx = seg == 0 ? a.ldx : seg == 1 ? a.ldxb : a.ldh;
+        const long long ldw = seg == 2 ? (long long)H : (a.ldw ? a.ldw : (long long)a.I);
+        const float *W = seg == 0 ? a.Wih : seg == 1 ? a.Wih + a.I : a.Whh;
+        const int nkb = (K + 15) >> 4;
+        const float *xr[RT];
+        bool xv[RT];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const int row = (rg * RT + r) * 16 + i;
+            xv[r] = row < a.N;
+            xr[r] = X + (long long)(xv[r] ? row : 0) * ldx;
+        }
+        const bool wlive = gate < 2 || (gate == 2 ? seg < 2 : seg == 2);
+        const float *w = W + (long long)((gate == 3 ? 2 : gate) * H + unit) * ldw;
+        const int first = (wave - gkb) & (GRU4_NW - 1);
+        gkb += nkb;
+        constexpr int U = GRU4_U;
+        for (int kb0 = first; kb0 < nkb; kb0 += GRU4_NW * U) {
+            f32x4 xa[U][RT], b[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k0 = (kb0 + GRU4_NW * u) * 16 + g * 4;
+                const bool in = kb0 + GRU4_NW * u < nkb;
+                b[u] = td_load4(w, k0, K, in && wlive);
+#pragma unroll
+                for (int r = 0; r < RT; r++) xa[u][r] = td_load4(xr[r], k0, K, in && xv[r]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (kb0 + GRU4_NW * u < nkb) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][r][q], b[u][q], acc[r], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) red[((wave * RT + r) * 4 + q) * 64 + lane] = acc[r][q];
+    __syncthreads();
+    // D layout: column lane & 15, row (lane >> 4) * 4 + q.  One thread per (row, unit): its four gate sums are columns gate * 4 + unit
+    for (int e = t; e < RT * 64; e += GRU4_NW * 64) {
+        const int r = e >> 6, rt = (e >> 2) & 15, uu = e & 3;
+        const int row = (rg * RT + r) * 16 + rt, c = ut * 4 + uu;
+        float s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ln = (rt >> 2) * 16 + k * 4 + uu, q = rt & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < GRU4_NW; w2++) v += red[((w2 * RT + r) * 4 + q) * 64 + ln];
+            s[k] = v;
+        }
+        if (row >= a.N) continue;
+        const float hp = a.h[(long long)row * a.ldh + c];
+        const long long o = (long long)row * H + c;
+        if (a.lens && a.t_step >= a.lens[row]) {     // finished sequence: carry the state, emit zeros (pad_packed_sequence)
+            a.hout[(long long)row * a.ldo + c] = hp;
+            if (a.hid_out) a.hid_out[(long long)row * a.ldhid + c] = 0.f;
+            if (a.r) { a.r[o] = 0.f; a.z[o] = 1.f; a.n[o] = 0.f; a.ghn[o] = 0.f; }   // identity step for the backward
+            continue;
+        }
+        float gr = s[0], gz = s[1], gn = s[2];
+        if (a.gi_pre) {
+            const float *gi = a.gi_pre + (long long)row * a.ldgi;
+            gr += gi[c]; gz += gi[H + c]; gn += gi[2 * H + c];
+        } else { gr += a.bih[c]; gz += a.bih[H + c]; gn += a.bih[2 * H + c]; }
+        const float rr = 1.f / (1.f + expf(-(gr + a.bhh[c])));
+        const float zz = 1.f / (1.f + expf(-(gz + a.bhh[H + c])));
+        const float gh = s[3] + a.bhh[2 * H + c];
+        const float nv = tanhf(gn + rr * gh);
+        const float hn = (1.f - zz) * nv + zz * hp;
+        a.hout[(long long)row * a.ldo + c] = hn;
+        if (a.hid_out) a.hid_out[(long long)row * a.ldhid + c] = hn;
+        if (a.r) { a.r[o] = rr; a.z[o] = zz; a.n[o] = nv; a.ghn[o] = gh; }
+    }
+}
+
 static int td_gru_fwd(const GruArgs &a, hipStream_t s) {
     if (a.H & 15) return D3_ERR_ARG;
     if (a.N <= 0) return 0;
-    if (a.N <= 16) td_gru_fwd_kernel<1><<<dim3(a.H / 16, 1), GRU_NW * 64, 0, s>>>(a);
+    if (d3_tune(D3T_GRU4) != 0 && a.N <= 256) {   // gate-packed columns: 4 hidden units per workgroup
+        td_gru4_fwd_kernel<1><<<dim3(a.H / 4, (a.N + 15) / 16), GRU4_NW * 64, 0, s>>>(a);
+        D3_LAUNCH_CHECK();
+        return 0;
+    }
+    // (17..64 rows: one 16-row tile per workgroup -- twice the workgroups, half the MFMA chain of each; D3_GRU_RT1=0: two tiles)
+    if (a.N <= 16 || (a.N <= 64 && d3_tune(D3T_GRU_RT1) != 0)) td_gru_fwd_kernel<1><<<dim3(a.H / 16, (a.N + 15) / 16), GRU_NW * 64, 0, s>>>(a);
     else td_gru_fwd_kernel<2><<<dim3(a.H / 16, (a.N + 31) / 32), GRU_NW * 64, 0, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;

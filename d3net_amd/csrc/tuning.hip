@@ -35,6 +35,9 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_SIDE_OP_ROWS", 0},         // convolutions below this many rows keep their weight gradient on the caller's stream (no event pair)
     {"D3_LASTBLOCK_ROWS", 0},       // convolutions with at most this many output rows finalize the following BatchNorm's statistics themselves
     {"D3_C2_STATIC", 1},            // 0: never the statically shaped convolution instances (K = 27, 16 / 32 / 48 / 64 input channels)
+    {"D3_GRU_RT1", 1},              // 0: fused GRU cell with two 16-row tiles per workgroup for 17..64 rows
+    {"D3_HG_RT1", 1},               // 0: K-split GEMM with two 16-row tiles per workgroup for 17..32 rows
+    {"D3_GRU4", 1},                 // 0: fused GRU cell on 16 hidden units x 3 gate tiles per workgroup (rounds 1-2)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;
