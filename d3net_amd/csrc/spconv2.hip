@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                 }
             }
         };
-        if constexpr (ST >= 4 && KT * Q > 56) {          // (the stem: 135 steps -- unrolled completely it spills)
+        if constexpr (ST >= 4 && (KT * Q > 56 || NT >= 3)) {   // (the stem: 135 steps; >= 48 output channels -- unrolled completely they spill)
 #pragma unroll 1
             for (int k0 = 0; k0 < KT; k0 += KB) batch(k0);
         } else if constexpr (ST >= 4) {
@@ -833,7 +833,10 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
             if (a.S == 4 && p.nw == 16) return launch_fwd2_static<2, 16, 4>(a, p, s);    // 32 -> 32
             if (a.S == 8 && p.nw == 16) return launch_fwd2_static<2, 16, 8>(a, p, s);    // 64 -> 32
         }
-        // (48 -> 48 and 32 -> 64 spill at 128 registers when fully unrolled: they stay on the generic instance)
+        if constexpr (NT == 3) {
+            if (a.S == 6 && p.nw == 16) return launch_fwd2_static<3, 16, 6>(a, p, s);    // 48 -> 48 (offset loop kept rolled)
+        }
+        // (32 -> 64 spills at 128 registers even with the rolled loop: generic instance)
     }
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev)) {   // allow more than 64 KB of dynamic LDS

@@ -149,26 +149,42 @@ __global__ void un_bn_finalize_kernel(StatSrc s0, StatSrc s1, int M, int C, floa
 
 // y = [relu]((x - mean) * rsqrt(var + eps) * gamma + beta); x (M, ldx) fp32; y (M, ldy) bf16 or fp32
 template <bool BF16>
-__global__ void un_bn_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ mean,
+__global__ __launch_bounds__(256) void un_bn_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ mean,
                                    const float *__restrict__ var, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, void *__restrict__ y, int ldy, long long M, int C,
                                    float eps, int relu) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels per thread (C % 4 == 0)
-    const int c4 = C >> 2;
-    if (e >= M * c4) return;
-    const long long row = e / c4;
-    const int c = (int)(e - row * c4) * 4;
-    const float4 v = *(const float4 *)(x + row * ldx + c);
-    const float in[4] = {v.x, v.y, v.z, v.w};
-    float o[4];
+    // (row-walking form: see un_bn_bwd_apply_kernel)
+    const int c4 = C >> 2, rpb = 256 / c4, t = threadIdx.x;
+    if (t >= rpb * c4) return;
+    const int rl = t / c4, c = (t - rl * c4) * 4;
+    float inv[4], ga[4], mu[4], be[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float inv = rsqrtf(var[c + j] + eps);
-        const float r = fmaf((in[j] - mean[c + j]) * inv, gamma[c + j], beta[c + j]);
-        o[j] = (relu && r < 0.f) ? 0.f : r;
+    for (int j = 0; j < 4; j++) { inv[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; mu[j] = mean[c + j]; be[j] = beta[c + j]; }
+    const long long rows = (long long)((256 / c4) * 8);
+    const long long r0 = (long long)blockIdx.x * rows, r1 = (r0 + rows < M) ? r0 + rows : M;
+    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long row = rb + (long long)u * rpb;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r1) v[u] = *(const float4 *)(x + row * ldx + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long row = rb + (long long)u * rpb;
+            if (row >= r1) continue;
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float r = fmaf((in[j] - mu[j]) * inv[j], ga[j], be[j]);
+                o[j] = (relu && r < 0.f) ? 0.f : r;
+            }
+            if (BF16) *(uint2 *)((unsigned short *)y + row * ldy + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));
+            else *(float4 *)((float *)y + row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
-    if (BF16) *(uint2 *)((unsigned short *)y + row * ldy + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));
-    else *(float4 *)((float *)y + row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // backward reductions: sum g, sum g*xhat with g = dy * relu'(y) -> fp32 partials [block][2][C]
@@ -225,37 +241,65 @@ __global__ void un_bn_bwd_final_kernel(const float *part, int nparts, int C, flo
 }
 // dx = gamma*inv*(g - mean(g) - xhat*mean(g*xhat)) (+ dx when accum: the second contribution to a residual /
 // concatenated gradient is added here instead of in a separate pass)
+// Round 3: a thread keeps ONE channel quad and walks rows (UN_AP_U rows in flight): the six per-channel parameters are loaded
+// once per thread instead of once per 16 bytes, the row index needs no 64-bit division, and a workgroup streams a contiguous
+// row range.  Arithmetic (expressions and their order) unchanged.
+#define UN_AP_U 4
+__host__ __device__ __forceinline__ int un_ap_rows_per_block(int C) { return (256 / (C >> 2)) * UN_AP_U * 2; }
+// workgroups of a row-walking apply kernel: (256 / (C / 4)) rows per pass, `passes` passes per workgroup
+static inline int un_ap_grid(long long M, int C, int passes) {
+    const long long rows = (long long)(256 / (C >> 2)) * passes;
+    return (int)((M + rows - 1) / rows);
+}
 template <bool OBF>
-__global__ void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ dy, int ldy,
+__global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ dy, int ldy,
                                        const float *__restrict__ mean, const float *__restrict__ var,
                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                        const float *__restrict__ sums, float *__restrict__ dx, int ldo, long long M,
                                        int C, float eps, int relu, int accum, unsigned short *__restrict__ shadow) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels per thread
-    const int c4 = C >> 2;
-    if (e >= M * c4) return;
-    const long long row = e / c4;
-    const int c = (int)(e - row * c4) * 4;
-    const float4 xv = *(const float4 *)(x + row * ldx + c);
-    const float4 gv = *(const float4 *)(dy + row * ldy + c);
-    const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
-    float4 *op = (float4 *)(dx + row * ldo + c);
-    float old[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!OBF && accum) { const float4 ov = *op; old[0] = ov.x; old[1] = ov.y; old[2] = ov.z; old[3] = ov.w; }
+    const int c4 = C >> 2, rpb = 256 / c4, t = threadIdx.x;
+    if (t >= rpb * c4) return;
+    const int rl = t / c4, c = (t - rl * c4) * 4;
     const float invM = 1.f / (float)M;
-    float o[4];
+    float inv[4], ga[4], mu[4], be[4], mg[4], mgx[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const float inv = rsqrtf(var[c + j] + eps), ga = gamma[c + j];
-        const float xh = (xi[j] - mean[c + j]) * inv;
-        float g = gi[j];
-        if (relu && fmaf(xh, ga, beta[c + j]) <= 0.f) g = 0.f;
-        const float mg = sums[c + j] * invM, mgx = sums[C + c + j] * invM;
-        o[j] = old[j] + ga * inv * (g - mg - xh * mgx);
+        inv[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; mu[j] = mean[c + j]; be[j] = beta[c + j];
+        mg[j] = sums[c + j] * invM; mgx[j] = sums[C + c + j] * invM;
     }
-    if (OBF) *(uint2 *)((unsigned short *)dx + row * ldo + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // bf16 gradient buffer
-    else *op = make_float4(o[0], o[1], o[2], o[3]);
-    if (!OBF && shadow) *(uint2 *)(shadow + row * C + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // dense (M, C) bf16 copy
+    const long long rows = (long long)un_ap_rows_per_block(C);
+    const long long r0 = (long long)blockIdx.x * rows, r1 = (r0 + rows < M) ? r0 + rows : M;
+    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * UN_AP_U) {
+        float4 xv[UN_AP_U], gv[UN_AP_U], ov[UN_AP_U];
+#pragma unroll
+        for (int u = 0; u < UN_AP_U; u++) {
+            const long long row = rb + (long long)u * rpb;
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
+            if (row < r1) {
+                xv[u] = *(const float4 *)(x + row * ldx + c);
+                gv[u] = *(const float4 *)(dy + row * ldy + c);
+                if (!OBF && accum) ov[u] = *(const float4 *)(dx + row * ldo + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN_AP_U; u++) {
+            const long long row = rb + (long long)u * rpb;
+            if (row >= r1) continue;
+            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gi[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float xh = (xi[j] - mu[j]) * inv[j];
+                float g = gi[j];
+                if (relu && fmaf(xh, ga[j], be[j]) <= 0.f) g = 0.f;
+                o[j] = old[j] + ga[j] * inv[j] * (g - mg[j] - xh * mgx[j]);
+            }
+            if (OBF) *(uint2 *)((unsigned short *)dx + row * ldo + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // bf16 gradient buffer
+            else *(float4 *)(dx + row * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (!OBF && shadow) *(uint2 *)(shadow + row * C + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));   // dense (M, C) bf16 copy
+        }
+    }
 }
 __global__ void un_add_kernel(float *__restrict__ dst, int ldd, const float *__restrict__ src, int lds, long long M, int C, int copy) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -848,10 +892,10 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
             const long long total = (long long)M * (C / 4);
             if (total > 0) {
                 if (to.dtype == 1)
-                    un_bn_apply_kernel<true><<<(int)((total + 255) / 256), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
+                    un_bn_apply_kernel<true><<<un_ap_grid(M, C, 8), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
                                                                                      tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu);
                 else
-                    un_bn_apply_kernel<false><<<(int)((total + 255) / 256), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
+                    un_bn_apply_kernel<false><<<un_ap_grid(M, C, 8), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
                                                                                       tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu);
             }
         }
@@ -1068,10 +1112,10 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 const long long total = (long long)M * (C / 4);
                 unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
                 if (gibf)
-                    un_bn_bwd_apply_kernel<true><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
+                    un_bn_bwd_apply_kernel<true><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
                                                                                          o.eps, relu, 0, nullptr);
                 else
-                    un_bn_bwd_apply_kernel<false><<<(int)((total + 255) / 256), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
+                    un_bn_bwd_apply_kernel<false><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
                                                                                           o.eps, relu, o.in_grad_mode == 2 ? 1 : 0, sh);
             }
         }
