@@ -53,6 +53,7 @@ struct ClWs {
     int *lcnt;     // n  per-owner counter behind lid
     int *star;     // n  star[o] = 1: the kept cluster of owner o is the seed's own list (no level loop needed)
     int *scalars;  // [0]=changed [1]=nCluster [2]=sumNPoint
+    int4 *ninfo;   // n  (owner or -1 when not in a level-loop cluster, dense id, record start, list length): ONE gather per list entry
     void *temp; size_t temp_bytes;
 };
 
@@ -66,6 +67,7 @@ static bool cl_carve(void *ws, size_t ws_bytes, int n, ClWs &w) {
     w.lid = c.take<int>(nn); w.lcnt = c.take<int>(nn); w.star = c.take<int>(nn);
     w.klen = c.take<int>(nn); w.estart = c.take<int>(nn);
     w.scalars = c.take<int>(64);
+    w.ninfo = c.take<int4>(nn);
     w.temp_bytes = d3_scan_temp_bytes(n);
     w.temp = c.take<char>(w.temp_bytes);
     return ws != nullptr && c.ok();
@@ -75,6 +77,7 @@ extern "C" size_t d3_bfs_cluster_ws_bytes(int n) {
     size_t nn = (size_t)(n > 0 ? n : 1);
     for (int i = 0; i < 18; i++) c.take<int>(nn);
     c.take<int>(64);
+    c.take<int4>(nn);
     c.take<char>(d3_scan_temp_bytes(n));
     return c.off + 256;
 }
@@ -147,10 +150,13 @@ __global__ __launch_bounds__(256) void cl_union_kernel(const int *__restrict__ s
 __global__ void cl_flatten_kernel(int *parent, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // Cached loads (round 3; device-scope loads made every hop a memory-side round trip: 158 us for 600 k nodes): the unions
+    // finished with the previous kernel, a root keeps parent[r] == r for the whole launch, and whatever another thread stores
+    // meanwhile into a non-root entry is that entry's root -- a stale read is an older ancestor, the walk still ends at the root.
     int r = i;
-    for (;;) { int p = ld_dev(&parent[r]); if (p == r) break; r = p; }
+    for (;;) { int p = parent[r]; if (p == r) break; r = p; }
     // every thread only writes its own entry with its root; roots keep parent[r]==r
-    if (r != i) st_dev(&parent[i], r);
+    if (r != i) parent[i] = r;
 }
 
 __device__ __forceinline__ int cl_chase(const int *lab, int l) {
@@ -579,9 +585,14 @@ __global__ void cl_lid_kernel(const int *__restrict__ own, const int *__restrict
 // The records are COMPACT whatever the layout of idx (the padded ball query gives every node a 1000-entry slot: records at
 // the same sparse positions cost 4x the write time and scatter the BFS's loads over 16 KB strides): node i's records
 // start at estart[i], the exclusive scan of the kept nodes' list lengths, and a record carries its target's estart.
+__global__ void cl_ninfo_kernel(const int *__restrict__ own, const int *__restrict__ lid, const int *__restrict__ estart,
+                                const int *__restrict__ start_len, int4 *__restrict__ ninfo, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ninfo[i] = make_int4(own[i], lid[i], estart[i], start_len[i * 2 + 1]);
+}
 __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
                                                      const int *__restrict__ own, const int *__restrict__ flag,
-                                                     const int *__restrict__ star, const int *__restrict__ lid,
+                                                     const int *__restrict__ star, const int4 *__restrict__ ninfo,
                                                      const int *__restrict__ estart, int4 *__restrict__ erec, int n) {
     const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n) return;
@@ -589,18 +600,19 @@ __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ id
     if (!flag[oi] || star[oi]) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     const long long es = estart[i];
-    // four entries per lane per round trip pair (ids; then owner / dense id / record start / length of all four together,
-    // unconditionally): a capped list is 16 passes of three dependent gathers otherwise
+    // four entries per lane per round trip pair (ids; then owner / dense id / record start / length of all four together as ONE
+    // 16-byte record per neighbour -- round 3; four 4-byte gathers per entry before): a capped list is 16 passes otherwise
     for (int e0 = d3_lane(); e0 < ln; e0 += 256) {
-        int j[4], oj[4], lj[4], ej[4], nj[4];
+        int j[4];
+        int4 nj[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int e = e0 + q * 64; j[q] = idx[st + (e < ln ? e : 0)]; }
 #pragma unroll
-        for (int q = 0; q < 4; q++) { oj[q] = own[j[q]]; lj[q] = lid[j[q]]; ej[q] = estart[j[q]]; nj[q] = start_len[j[q] * 2 + 1]; }
+        for (int q = 0; q < 4; q++) nj[q] = ninfo[j[q]];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int e = e0 + q * 64;
-            if (e < ln) erec[es + e] = (oj[q] == oi) ? make_int4(j[q], lj[q], ej[q], nj[q]) : make_int4(-1, 0, 0, 0);
+            if (e < ln) erec[es + e] = (nj[q].x == oi) ? make_int4(j[q], nj[q].y, nj[q].z, nj[q].w) : make_int4(-1, 0, 0, 0);
         }
     }
 }
@@ -891,7 +903,8 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, w.star, start_len, w.lcnt, w.lid, w.klen, n);
         int rc = d3_exclusive_scan_i32(w.klen, w.estart, n, w.temp, w.temp_bytes, s);
         if (rc) return rc;
-        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.lid, w.estart, (int4 *)erec, n);
+        cl_ninfo_kernel<<<nb, T, 0, s>>>(w.own, w.lid, w.estart, start_len, w.ninfo, n);
+        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.ninfo, w.estart, (int4 *)erec, n);
         const bool debug = d3_tune(D3T_BFS_DEBUG) != 0;
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
                                                         w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);

@@ -88,7 +88,12 @@ __global__ __launch_bounds__(NW * 64) void hg_gemm_kernel(const HgBatch batch) {
 #ifndef HG_U16
 #define HG_U16 2
 #endif
-        constexpr int U = RT > 2 ? 2 : (NW == 16 ? HG_U16 : 4);   // (1024-thread workgroups: 128 VGPRs per lane)
+#ifndef HG_U16_RT1
+#define HG_U16_RT1 3
+#endif
+        // (1024-thread workgroups: 128 VGPRs per lane; with ONE row tile a wave's whole share of a 1536-deep reduction -- 6 k blocks --
+        // is a two batches of loads (HG_U16_RT1 = 3; 6 spills))
+        constexpr int U = RT > 2 ? 2 : (NW == 16 ? (RT == 1 ? HG_U16_RT1 : HG_U16) : 4);
         for (int kb0 = first; kb0 < nkb; kb0 += step * U) {
             f32x4 a[U][RT], b[U];
 #pragma unroll

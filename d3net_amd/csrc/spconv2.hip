@@ -833,9 +833,7 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
             if (a.S == 4 && p.nw == 16) return launch_fwd2_static<2, 16, 4>(a, p, s);    // 32 -> 32
             if (a.S == 8 && p.nw == 16) return launch_fwd2_static<2, 16, 8>(a, p, s);    // 64 -> 32
         }
-        if constexpr (NT == 3) {
-            if (a.S == 6 && p.nw == 16) return launch_fwd2_static<3, 16, 6>(a, p, s);    // 48 -> 48 (offset loop kept rolled)
-        }
+        // (48 -> 48 with the offset loop rolled: measured no faster than the generic instance -- 36 k rows are one tile per wave)
         // (32 -> 64 spills at 128 registers even with the rolled loop: generic instance)
     }
     static bool attr_done_dev[64] = {false};
