@@ -373,12 +373,14 @@ def test_backbone_bucket_is_all_reduced_in_chunks_from_inside_backward():
         mp.spawn(_chunk_worker, args=(world, _free_port(), ret, overlap), nprocs=world, join=True)
     for step in range(3):
         a0, a1 = ret[(0, True)][step], ret[(1, True)][step]
-        b0 = ret[(0, False)][step]
+        b0, b1 = ret[(0, False)][step], ret[(1, False)][step]
         assert a0["inside"] == a1["inside"] == (0 if step == 0 else 3), (step, a0["inside"], a1["inside"])
         assert b0["inside"] == 0
         assert a0["views"] and a1["views"]
         assert a0["loss"] == b0["loss"]
-        for g0, g1, l0, l1, gb in zip(a0["avg"], a1["avg"], a0["local"], a1["local"], b0["avg"]):
+        # (the LOCAL gradients are read from the run without overlap -- same seeds, same data: with overlap a collective started
+        # inside backward() may already have rewritten its chunk in place when backward() returns)
+        for g0, g1, l0, l1, gb in zip(a0["avg"], a1["avg"], b0["local"], b1["local"], b0["avg"]):
             assert torch.allclose(g0, g1) and torch.allclose(g0, (l0 + l1) / 2, atol=1e-6) and torch.allclose(g0, gb, atol=1e-7)
 
 
