@@ -90,9 +90,9 @@ __device__ __forceinline__ void st_dev(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void cl_init_kernel(int *parent, int *lab, int *sizes, int *par, int *pushed, int n, int *scalars) {
+__global__ void cl_init_kernel(int *parent, int *lab, int *sizes, int *par, int *pushed, int *lpush, int n, int *scalars) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { parent[i] = i; lab[i] = i; sizes[i] = 0; par[i] = CL_INF; pushed[i] = CL_INF; }
+    if (i < n) { parent[i] = i; lab[i] = i; sizes[i] = 0; par[i] = CL_INF; pushed[i] = CL_INF; lpush[i] = CL_INF; }
     if (i < 8) scalars[i] = 0;
 }
 
@@ -166,18 +166,20 @@ __device__ __forceinline__ int cl_chase(const int *lab, int l) {
 // phase 1b: push labels over all edges; root[] == parent[] after flatten
 __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                      const int *__restrict__ start_len, int n,
-                                                     const int *__restrict__ root, int *lab, int *pushed,
+                                                     const int *__restrict__ root, int *lab, int *pushed, int *lpush,
                                                      int *changed_flag, const int *__restrict__ capped_flag, int ascending, int minima_only) {
-    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (i >= n) return;
     if (*capped_flag == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
+    // (round 3: a bounded grid walks the nodes -- with nothing capped, the common case of the unshifted coordinates, 150 k
+    // workgroups used to start only to read that flag: 3 x 25-85 us per clustering)
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < n; i += nwaves) {
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     // Opening sweep (ascending lists only): just the nodes without a smaller-index neighbour push -- the future seeds.  In a
     // collapsed instance (every list = its first 1000 members) that is ONE node, whose push settles all 1000 labels without
     // contention; the full sweep behind it then finds them settled through its cached filter read.  Without it every member
     // pushed its own index at all later members at once: 500 k contended atomicMin per instance, most of the sweep's time
     // (profiles/r02_q_cluster_timeline.txt: 2.1 ms).  Any sweep order reaches the same fixpoint.
-    if (minima_only && (ln == 0 || idx[st] < i)) return;
+    if (minima_only && (ln == 0 || idx[st] < i)) continue;
     const int si = sem[i];
     const int ri = root[i];
     const int li = cl_chase(lab, ld_dev(&lab[ri]));
@@ -185,8 +187,23 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
     // Worklist: a node pushes again only when its own label got smaller since its last push -- every neighbour's label
     // was <= that value then and labels only decrease.  The verification sweep therefore walks only the lists of the
     // nodes the previous sweep changed (the first 1000 points of a collapsed instance, not all of them).
-    if (pushed[i] == li) return;          // (one wave per node: uniform)
+    if (pushed[i] == li) continue;        // (one wave per node: uniform)
     if (d3_lane() == 0) pushed[i] = li;
+    // Shared lists (round 3): the cell-grid ball query hands every member of a clique cell the SAME list (start = leader *
+    // 1000).  A push of label l over a list by a node of class c settles every target of that class at <= l, so another node
+    // with the same list, the same class and a label >= l has nothing to add -- in an instance collapsed onto its centre that is
+    // all but one of its first 1000 members (each used to walk the 1000 entries: 160 M list entries per clustering, 0.42 ms).
+    // lpush[slot] = smallest label pushed so far over the list starting at slot * 1000 by a node of the slot owner's class.
+    // (Keyed by the exact start: private lists have private keys, whatever the layout.)
+    if (ln > 0 && st % CL_CAP == 0) {
+        const int slot = st / CL_CAP;
+        if (slot < n && sem[slot] == si) {
+            int old = 0;
+            if (d3_lane() == 0) old = atomicMin(&lpush[slot], li);
+            old = __shfl(old, 0);
+            if (old <= li) continue;
+        }
+    }
     bool changed = false;
     // A push can only lower the label of a target j > li: lab[root(j)] <= root(j) <= j at all times (a label starts as the
     // node's own index, a root is the smallest index of its tree, labels only decrease).  The lists are ascending
@@ -231,6 +248,7 @@ __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ se
         }
     }
     if (__any(changed) && d3_lane() == 0) *changed_flag = 1;
+    }
 }
 
 __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *sizes, int n) {
@@ -289,7 +307,7 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
-    cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, n, w.scalars);   // (klen: scratch until the fill)
+    cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, w.qln, n, w.scalars);   // (klen, qln: scratch until the fill)
     cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
@@ -297,13 +315,14 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     // trip: the usual case is one productive sweep plus the sweep that finds nothing left to do (the second one reports
     // through its own flag, scalars[4]); only when both sweeps still changed labels is the tail recomputed after more.
     int h[5] = {0, 0, 0, 0, 0};
+    const int npb = nwb < 4096 ? nwb : 4096;      // label push: a bounded grid of waves walks the nodes
     for (int it = 0;; it += 2) {
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
         if (it == 0 && asc)
-            cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3, asc, 1);
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars, w.scalars + 3, asc, 0);
-        cl_push_kernel<<<nwb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.scalars + 4, w.scalars + 3, asc, 0);
+            cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 1);
+        cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 0);
+        cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars + 4, w.scalars + 3, asc, 0);
         if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
         cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
         cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);

@@ -389,6 +389,9 @@ class PointGroup(nn.Module):
                     fut = _cluster_worker().submit(work)
                     try:
                         first = cluster_branch(coords_, self.cluster_meanActive, True)
+                        # the shifted branch (capped lists: label push) runs ~0.4 ms longer: the point losses, which need
+                        # nothing from the clustering, fill this stream's wait for it
+                        self._early_point_losses(data_dict)
                     finally:
                         shifted = fut.result()      # (an exception of the helper is re-raised here)
                     cur.wait_stream(side)
@@ -498,6 +501,8 @@ class PointGroup(nn.Module):
             return
         need = ("sem_labels", "locs", "instance_info", "instance_ids")
         if any(k not in data_dict for k in need) or not torch.is_tensor(data_dict["semantic_scores"]):
+            return
+        if "_point_losses" in data_dict:
             return
         args = (data_dict["semantic_scores"], data_dict["sem_labels"], data_dict["pt_offsets"], data_dict["locs"],
                 data_dict["instance_info"], data_dict["instance_ids"])

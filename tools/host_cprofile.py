@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""cProfile of the host side of the training step (main thread), 20 steps: top functions by own time."""
+"""cProfile of the host side of the training step (main thread), 20 steps of bench.py's workload: top functions by own time and
+by cumulative time.  usage: python tools/host_cprofile.py [--config speaker|detector|listener]"""
 import cProfile
 import os
 import pstats
@@ -7,25 +8,38 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
 from d3net_amd import pointgroup as PG, synthetic as S  # noqa: E402
 from d3net_amd.config import default_conf  # noqa: E402
 from d3net_amd.optim import FusedAdamW  # noqa: E402
 
+config = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "speaker"
 dev = torch.device("cuda", 0)
-cfg = default_conf()
+torch.cuda.set_device(0)
+cfg = default_conf(bench.CONF[config])
 torch.manual_seed(123)
-model = PG.PointGroup(cfg).to(dev).train()
-model.teacher = True
+scenes = bench.make_scenes(config, 0)
+if config == "detector":
+    model = PG.PointGroup(cfg).to(dev).train()
+    det = model
+else:
+    from d3net_amd.pipeline import PipelineNet
+    model = PipelineNet(cfg, bench.make_dataset(len(scenes), cfg.data.num_des_per_scene, False)).to(dev).train()
+    det = model.detector
+det.teacher = True
 opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=0.002)
-occ, sem, inst, _ = S.occupancy_grid()
-batch = S.make_batch([S.scene_from_grid(occ, sem, inst)], dev)
+batch = S.make_batch(scenes, dev)
+if config != "detector":
+    batch = S.add_language(batch, dev, chunk=cfg.data.num_des_per_scene, vocab=bench.VOCAB)
+    if config == "speaker":
+        batch["lang_len"] = batch["spk_lang_len"]
 
 
 def step():
-    d = dict(batch)
     model.zero_grad(set_to_none=True)
-    loss, d = model.training_step(d)
+    loss, d = model.training_step(dict(batch))
     loss.backward()
     opt.step()
 
@@ -40,4 +54,5 @@ for _ in range(20):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(38)
+st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumulative").print_stats(60)
