@@ -16,6 +16,21 @@ from .pointgroup import PointGroup, _mark
 from .speaker import SpeakerNet
 
 
+class _HostScalars:
+    """a few device scalars on their way to the host: the copy is enqueued at construction (pinned buffer, own event) and
+    waited for only at `.get()` -- by then it has long completed, the stream is not drained"""
+
+    def __init__(self, t):
+        self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self.host.copy_(t, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def get(self):
+        self.ev.synchronize()
+        return self.host.tolist()
+
+
 class PipelineNet(nn.Module):
     def __init__(self, cfg, dataset=None):
         super().__init__()
@@ -96,7 +111,12 @@ class PipelineNet(nn.Module):
         return {k: vec[i] for i, k in enumerate(keys)}
 
     def _detect(self, data_dict):
-        data_dict = self.detector.feed(data_dict, self.current_epoch)
+        keep = self.detector.compact_proposals      # (only for this call: the detector object may be driven directly as well)
+        self.detector.compact_proposals = keep and not self.__dict__.get("_lazy_proposals", False)
+        try:
+            data_dict = self.detector.feed(data_dict, self.current_epoch)
+        finally:
+            self.detector.compact_proposals = keep
         _, data_dict = self.detector.parse_feed_ret(data_dict, self.current_epoch)
         data_dict = self.detector.loss(data_dict, self.current_epoch)
         gb = self.__dict__.get("grad_boundary")
@@ -109,6 +129,13 @@ class PipelineNet(nn.Module):
 
     def training_step(self, data_dict, idx=0):
         self.logged = {}
+        # the heads consume only the batched proposal tensors: no compaction of the kept proposals, hence no host round trip
+        # between ScoreNet and the heads (PointGroup.compact_proposals); the speaker's two host scalars depend only on the
+        # batch's language inputs and are requested now, long before they are needed
+        self._lazy_proposals = True
+        if self.mode in (1, 3) and "lang_len" in data_dict and "annotated" in data_dict and data_dict["lang_len"].is_cuda:
+            data_dict["_spk_host_meta"] = _HostScalars(torch.stack([data_dict["lang_len"].reshape(-1).max().long(),
+                                                                    (data_dict["annotated"].reshape(-1) != 1).sum()]))
         if self.mode == 0:
             data_dict = self._detect(data_dict)
             loss = data_dict["total_loss"][0]
@@ -177,6 +204,7 @@ class PipelineNet(nn.Module):
         from .caption_eval import eval_caption_step
         if self.mode not in (0, 1, 2, 3):
             raise NotImplementedError("GT-proposal modes 4-6 (no_detection) are not on the hot path")
+        self._lazy_proposals = False                # (the evaluation code reads the compact per-proposal tensors)
         data_dict = self._detect(data_dict)
         if self.mode == 0:
             for k, v in data_dict.items():

@@ -107,6 +107,12 @@ class PointGroup(nn.Module):
         self.score_scale = cfg.train.score_scale
         self.score_fullscale = cfg.train.score_fullscale
         self.mode = cfg.train.score_mode
+        # True (the reference's data_dict): the proposals that pass the thresholds are compacted into `proposal_feats`,
+        # `proposals_batchId`, `proposal_objectness_scores`, `proposal_crop_bbox` -- which needs their COUNT on the host, a round
+        # trip in the middle of the step.  False (PipelineNet's training steps, where only the batched tensors are consumed):
+        # convert_stack_to_batch takes the uncompacted rows with the batch id of a rejected proposal set to -1; same batched
+        # tensors, same gradients, no round trip, and the four compact keys are not produced.
+        self.compact_proposals = True
         self.prepare_epochs = cfg.cluster.prepare_epochs
         self.current_epoch = 0
 
@@ -278,9 +284,13 @@ class PointGroup(nn.Module):
         """stacked proposals -> (B,128,.) padded + shuffled tensors (reference :223-263)."""
         batch_size = len(data_dict["batch_offsets"]) - 1
         K = self.cfg.model.max_num_proposal
-        pf = data_dict["proposal_feats"]
+        lazy = data_dict.pop("_stb_inputs", None)
+        if lazy is not None:
+            pf, scores_in, crop, bids_in = lazy
+        else:
+            pf, scores_in, crop, bids_in = (data_dict["proposal_feats"], data_dict["proposal_objectness_scores"],
+                                            data_dict["proposal_crop_bbox"], data_dict["proposals_batchId"])
         dev = pf.device
-        crop = data_dict["proposal_crop_bbox"]
         keys = ("proposal_feats_batched", "proposal_bbox_batched", "proposal_center_batched", "proposal_sem_cls_batched",
                 "proposal_scores_batched", "proposal_batch_mask")
         perm = data_dict.pop("_slot_perm_staged", None) if perms is None else None
@@ -289,8 +299,10 @@ class PointGroup(nn.Module):
             perm = _STAGE.put(perm, dev)
         # one fill + three launches (csrc/heads.hip) when the shapes allow; the library-op form below otherwise
         want_assign = self.cfg.general.task != "test"
-        fused = heads.stack_to_batch(pf, data_dict["proposal_objectness_scores"], crop.detach(), data_dict["proposals_batchId"],
+        fused = heads.stack_to_batch(pf, scores_in, crop.detach(), bids_in,
                                      perm, data_dict["center_label"] if want_assign else None, batch_size, K)
+        if fused is None and lazy is not None:
+            raise RuntimeError("compact_proposals=False needs the fused stack_to_batch (shapes outside its limits)")
         if fused is not None:
             data_dict.update(zip(keys, fused[:6]))
             if want_assign:
@@ -454,6 +466,14 @@ class PointGroup(nn.Module):
             data_dict["proposals_npoint"] = proposals_npoint
             data_dict["proposal_thres_mask"] = thres_mask
             _mark("pr_mask")
+            if (not self.compact_proposals and fused and num_proposals <= 4096 and proposals_score_feats.dtype == torch.float32
+                    and batch_size * self.cfg.model.max_num_proposal <= 8192):
+                # no host round trip: rejected proposals keep their rows and get batch id -1 (heads.stack_to_batch drops them)
+                bids_masked = torch.where(thres_mask, bid_start, torch.full_like(bid_start, -1))
+                data_dict["_stb_inputs"] = (proposals_score_feats, sig, crop, bids_masked)
+                for m_ in ("pr_nonzero", "pr_index", "pr_select"):
+                    _mark(m_)
+                return data_dict
             keep = torch.nonzero(thres_mask).squeeze(1)    # one host round trip for the four selections below
             _mark("pr_nonzero")
             proposals_batchId = bid_start.index_select(0, keep)
@@ -574,10 +594,10 @@ class PointGroup(nn.Module):
             scores, proposals_idx, proposals_offset = data_dict["proposal_scores"]
             preds["score"] = scores
             preds["proposals"] = (proposals_idx, proposals_offset)
-            preds["proposal_crop_bboxes"] = data_dict["proposal_crop_bbox"]
+            preds["proposal_crop_bboxes"] = data_dict.get("proposal_crop_bbox")
             if self.mode != "test":
                 data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset, data_dict["instance_num_point"])
-                if self.cfg.model.crop_bbox:
+                if self.cfg.model.crop_bbox and "proposal_crop_bbox" in data_dict:
                     data_dict["proposal_crop_bboxes"] = data_dict["proposal_crop_bbox"]
         return preds, data_dict
 

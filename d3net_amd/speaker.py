@@ -721,7 +721,8 @@ class TopDownSceneCaptionModule(nn.Module):
         obj_masks = rep(data_dict["proposal_batch_mask"])
         # ONE host round trip for the two scalars the driver needs: the longest description and whether any sample lacks an
         # annotation (the reference reads both separately: des_lens.max(), and a python loop over is_annotated)
-        num_words, n_not_ann = torch.stack([des_lens.max().long(), (is_annotated != 1).sum()]).tolist()
+        meta = data_dict.pop("_spk_host_meta", None)     # (PipelineNet.training_step asked for them at the start of the step)
+        num_words, n_not_ann = meta.get() if meta is not None else torch.stack([des_lens.max().long(), (is_annotated != 1).sum()]).tolist()
 
         target_ids, target_ious, labels = self.select_target(
             data_dict["proposal_batch_mask"], data_dict["proposal_center_batched"], data_dict["proposal_bbox_batched"],
