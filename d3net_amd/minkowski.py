@@ -56,6 +56,17 @@ class CoordinateManager:
         self._down = {}
         self._pending = None      # begin_pyramid() without its build_pyramid() yet
 
+    def __del__(self):
+        # a begin_pyramid() whose build_pyramid() never ran (an exception in between): hand the ticket back to the library's pool
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            self._pending = None
+            try:
+                rows = (C.c_int * pend[0])()
+                _lib.lib().d3_kmap_pyramid_end(pend[1], rows, pend[0])
+            except Exception:
+                pass
+
     def _ws(self, M):
         return _workspace(_lib.lib().d3_coordmap_ws_bytes(M), self.device, "cm")
 
