@@ -115,7 +115,8 @@ def _gt_keys(batch):
                 gt_bbox_label=batch["box_label_mask"].cpu(), sem_cls_label=torch.from_numpy(cls))
 
 
-def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3, seed=0, exact_too=True, verbose=True, with_oracle=True):
+def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3, seed=0, exact_too=True, verbose=True, with_oracle=True,
+               head_lr=None):
     """train on the device, evaluate held-out scenes with the HIP path(s) and the CPU oracle -> dict of metrics"""
     from d3net_amd import synthetic as S, minkowski as ME, evaluator as ev
     from d3net_amd.caption_eval import eval_caption_step, eval_caption_epoch
@@ -143,7 +144,13 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
     torch.manual_seed(seed)
     net = PipelineNet(cfg, {"train": ds, "val": ds}).to(dev).train()
     params = [p for p in net.parameters() if p.requires_grad]
-    opt = FusedAdamW(params, lr=lr, weight_decay=1e-4)
+    if head_lr is None:
+        opt = FusedAdamW(params, lr=lr, weight_decay=1e-4)
+    else:       # the recurrent captioner at its own (smaller) step size
+        det = {id(p) for p in net.detector.parameters()}
+        opt = FusedAdamW([{"params": [p for p in params if id(p) in det], "lr": lr},
+                          {"params": [p for p in params if id(p) not in det], "lr": head_lr}], lr=lr, weight_decay=1e-4)
+    base_lrs = [gr["lr"] for gr in opt.param_groups]
     opt.register_step_pre_hook(lambda *a: net.detector.drop_stale_grads())
     train_batches = [make_lang_batch(train_scenes[i:i + 4], dev, chunk, seed=7 + i, scene_ids=["scene%04d_00" % (i + j) for j in range(4)])[0]
                      for i in range(0, n_train, 4)]
@@ -158,8 +165,8 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
         f[:, :20] = AMP * clean[it % len(train_batches)] + sigma * torch.randn(f.shape[0], 20, device=dev, generator=gen)
         tb["feats"] = f
         if it == steps - 150:        # settle: the last steps at a quarter of the learning rate
-            for gr in opt.param_groups:
-                gr["lr"] = lr / 4
+            for gr, bl in zip(opt.param_groups, base_lrs):
+                gr["lr"] = bl / 4
         loss, d = net.training_step(tb)
         loss.backward()
         opt.step()
@@ -272,7 +279,11 @@ def test_heldout_map_and_cider_parity_with_the_fp32_oracle(dev):
         at most 3 flipped detections' worth of mAP (3 / n_GT relative) and 2 % of CIDEr -- tight enough to catch a broken kernel
         (a wrong neighbour table or BatchNorm statistic moves these by tens of percent), honest about what bf16 is.
     """
-    res = run_parity(dev, n_val=32)
+    # (the captioner trains at 1e-3, the detector at 4e-3: with ONE rate of 4e-3 the GRU captioner collapsed to the unigram
+    # distribution in 3 of 6 seeds -- the recipe, not the kernels; at 1e-3 all of seeds 0-5 reach CIDEr 1.6-2.1.  Measured with the
+    # oracle on seeds 0 / 1 / 2: reference-precision path identical to 4 digits, bf16 mAP identical (0 flipped detections),
+    # bf16 CIDEr within 0.34 / 0.67 / 0.47 %, 187-190 of 192 captions token-identical)
+    res = run_parity(dev, n_val=32, head_lr=1e-3)
     o = res["oracle"]
     n_gt = len(o["cands"])
     assert n_gt >= 150, n_gt
