@@ -438,8 +438,10 @@ def main():
     if world == 1 and not args.no_fp32 and not args.exact:
         ME.set_exact(True)
         try:
-            step(); step(); torch.cuda.synchronize()      # (the fp32 program's own plan / workspaces / code objects)
-            k = 5
+            for _ in range(6):                            # (the fp32 program's own plan / arena / workspaces / code objects; the caching
+                step()                                    # allocator needs a few steps to stop growing)
+            torch.cuda.synchronize()
+            k = 10
             t1 = time.perf_counter()
             for _ in range(k):
                 step()

@@ -25,7 +25,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_WG2_TR", 1},               // 0: first LDS staging scheme of the second-generation weight gradient
     {"D3_LASTBLOCK_FINALIZE", 0},   // 1: last workgroup of a convolution finalizes the BatchNorm statistics
     {"D3_GRAD_BF16", 1},            // 0: every gradient buffer in fp32
-    {"D3_SIDE_PRIO", 1},            // 0: plain (not lowest-priority) weight-gradient stream
+    {"D3_SIDE_PRIO", 0},            // 1: lowest-priority weight-gradient stream (round 2: -0.3 ms; round 3: starved once other streams exist -- +3 ms)
     {"D3_SIDE_MIN_ROWS", 32768},    // level-0 rows from which the weight gradients run on the side stream
     {"D3_RED_TAIL", 5},             // flush the batched weight-gradient reduction when this many convolutions are left
     {"D3_VOX_ROWS", 1},             // 0: thread-per-element input voxelisation

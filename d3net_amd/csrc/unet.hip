@@ -634,8 +634,12 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             }
         }
     }
-    {   // weight gradients are off the critical path: lowest priority, so the data-gradient chain of the caller's stream wins
-        // when both want the machine (D3_SIDE_PRIO=0: plain stream)
+    {   // weight gradients run on their own stream.  Round 2 gave it the lowest priority (the data-gradient chain of the caller's
+        // stream then wins when both want the machine: -0.3 ms).  Round 3 measured what that does once the process owns more
+        // streams (an executor created after others exist; six idle streams created before the executors, as RCCL's would be): the
+        // low-priority queue is starved -- 18.3 -> 21.7 ms per bf16 step, 19 -> 27 ms for the fp32 backward whose weight gradients
+        // ARE the critical path -- while a plain stream measures the same 18.4 ms in both situations.  Plain by default
+        // (D3_SIDE_PRIO=1: lowest priority).
         int lo = 0, hi = 0;
         if (d3_tune(D3T_SIDE_PRIO) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
             hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo);
