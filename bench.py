@@ -294,8 +294,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # D3_DIST_WORLD1=1 (test switch, like D3_DIST_BACKEND / D3_SHARE_DEVICE): ONE rank still initialises the process group and
+    # runs the gradient reducer -- the RCCL plumbing (in-place collectives on the flat buffers, AVG, async handles started inside
+    # backward) on a one-GPU box; a world of one averages nothing, so the loss must equal the plain run's
+    dist_on = world > 1 or os.environ.get("D3_DIST_WORLD1") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         # RCCL over xGMI ("nccl" on ROCm); D3_DIST_BACKEND=gloo + D3_SHARE_DEVICE=1 is a plumbing test of the N>1 path on a
         # one-GPU box (all ranks on cuda:0), not a benchmark configuration
         dist.init_process_group(os.environ.get("D3_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
@@ -332,13 +337,13 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdamW(params, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)
     opt.register_step_pre_hook(lambda *a: detector.drop_stale_grads())
-    if world > 1:  # identical replicas
+    if dist_on:  # identical replicas
         broadcast_module(model)
     # the executors' flat gradient buffers are all-reduced in place (RCCL, sum -> mean); the other parameters share one
     # packed collective; the bucket layout is static (identical on every rank whatever its scenes produce)
     # -- and the speaker / listener heads' bucket starts from inside the backward, as soon as it crosses into the detector
     grad_sync = None
-    if world > 1:
+    if dist_on:
         det_ids = {id(p) for p in detector.parameters()}
         grad_sync = BucketGradAllReduce(params, detector, early=[p for p in params if id(p) not in det_ids])
         if model is not detector:
@@ -393,7 +398,7 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     PROF_STRIDE = 13   # every 13th convolution launch is bracketed by HIP events (coprime with the launches per step)
     L.d3_prof_enable(PROF_STRIDE)
@@ -413,11 +418,11 @@ def main():
         with open(os.environ["D3_BENCH_CPROFILE"], "w") as f:
             pstats.Stats(host_prof, stream=f).sort_stats("cumulative").print_stats(60)
             pstats.Stats(host_prof, stream=f).sort_stats("tottime").print_stats(40)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -435,7 +440,7 @@ def main():
     fp32 = None
     if args.exact:
         ME.set_exact(False)
-    if world == 1 and not args.no_fp32 and not args.exact:
+    if not dist_on and not args.no_fp32 and not args.exact:
         ME.set_exact(True)
         try:
             for _ in range(6):                            # (the fp32 program's own plan / arena / workspaces / code objects; the caching
@@ -491,8 +496,8 @@ def main():
                        "raw_proposals": int(d.get("num_raw_proposals", 0)),
                        "proposals_per_scene": float(d["proposal_batch_mask"].sum() / n_scenes) if "proposal_batch_mask" in d else None,
                        "parallelism": "scene-parallel dp%d" % world,
-                       "world": {"size_seen_by_process_group": dist.get_world_size() if world > 1 else 1,
-                                 "backend": dist.get_backend() if world > 1 else None,
+                       "world": {"size_seen_by_process_group": dist.get_world_size() if dist_on else 1,
+                                 "backend": dist.get_backend() if dist_on else None,
                                  "scaling": "weak: %d scenes per rank per step" % n_scenes if args.scaling == "weak" else
                                             "strong: global batch fixed at %d scenes, %d per rank" % (STRONG_GLOBAL_BATCH, n_scenes)},
                        "precision": ("fp32 storage, exact fp32 products on v_mfma_f32_16x16x4_f32, fp32 accumulate (the reference's precision)" if args.exact else
@@ -526,10 +531,10 @@ def main():
                                           "heads_bucket_started_inside_backward": grad_sync.early_launches,
                                           "executor_chunks": [[hi - lo for lo, hi in it["ranges"]] for it in items],
                                           "executor_chunk_collectives_started_inside_backward": grad_sync.chunk_launches}
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

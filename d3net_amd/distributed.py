@@ -11,6 +11,14 @@ import torch
 import torch.distributed as dist
 
 
+
+def _dist_active():
+    """a process group with more than one rank -- or with ONE rank under D3_DIST_WORLD1=1 (test switch: the RCCL plumbing of the
+    reducers on a one-GPU box; averaging over one rank is the identity)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("D3_DIST_WORLD1") == "1"
+
 class FlatGradAllReduce:
     """Averages the gradients of `params` across ranks with ONE collective on a persistent flat buffer."""
 
@@ -24,7 +32,7 @@ class FlatGradAllReduce:
             off += p.numel()
 
     def __call__(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not _dist_active():
             return
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -119,7 +127,7 @@ class BucketGradAllReduce:
 
     # ---- schedule -------------------------------------------------------------------------------------------------
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return _dist_active()
 
     def _buckets(self):
         if hasattr(self.owner, "static_gradient_buckets"):
@@ -265,7 +273,7 @@ class BucketGradAllReduce:
         self._checked = True
 
     def __call__(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not _dist_active():
             return
         world = dist.get_world_size()
         items = self._items()
