@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONF), default="speaker")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle", type=int, default=SETTLE_STEPS,
+                    help="untimed steps between the dry pass and the --warmup steps (a fresh box reaches its sustained rate after some tens of steps)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the untimed exact-fp32 (reference precision) steps")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
@@ -64,6 +66,7 @@ CPU_THREAD_SWEEP = (8, 16, 32)   # the sweep behind that "8", re-run with every 
 
 
 # ------------------------------------------------------------------------------------------ workloads
+SETTLE_STEPS = 40            # untimed steps between the dry pass and the --warmup steps (see main())
 STRONG_GLOBAL_BATCH = 8
 
 
@@ -378,6 +381,13 @@ def main():
     # loads the code objects, so that a run with a very small --warmup does not time one-off allocations ("setup")
     loss, d = step()
     torch.cuda.synchronize()
+    # ... and a process on a fresh box needs more than a handful of steps to reach its sustained rate (measured on fresh MI355X boxes:
+    # first run 20.8 ms per step with 5 warm-up steps, 18.9 with 60, 18.4 for any later process -- clocks, allocator growth, code
+    # objects): SETTLE_STEPS untimed steps (~1 s), independent of --warmup, before the contract's W warm-up steps
+    settle_steps = max(0, args.settle)   # (a fixed count: every rank issues the same collectives)
+    for _ in range(settle_steps):
+        loss, d = step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         loss, d = step()
     torch.cuda.synchronize()
@@ -502,7 +512,8 @@ def main():
                                             "strong: global batch fixed at %d scenes, %d per rank" % (STRONG_GLOBAL_BATCH, n_scenes)},
                        "precision": ("fp32 storage, exact fp32 products on v_mfma_f32_16x16x4_f32, fp32 accumulate (the reference's precision)" if args.exact else
                                      "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate; heads fp32"),
-                       "setup": "1 untimed dry-run step before the warm-up (workspace allocation, code-object loads)"},
+                       "setup": "1 untimed dry-run step (workspace allocation, code-object loads) + %d untimed settle steps (a fresh "
+                                "box reaches its sustained rate only after some tens of steps) before the --warmup steps" % settle_steps},
             "final_loss": final_loss, "fp32_exact": fp32,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,

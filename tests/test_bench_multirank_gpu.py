@@ -22,7 +22,7 @@ def _env():
 
 
 def _run(extra, env):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--settle", "2", "--small"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
@@ -41,12 +41,14 @@ def test_two_rank_bench_line(dev):
     assert out["config"]["world"]["size_seen_by_process_group"] == 2 and out["config"]["world"]["backend"] == "gloo"
     assert out["config"]["global_batch"] == 8 and out["config"]["scenes_per_gpu"] == 4
     # the heads' bucket starts from inside backward() in every step after the first (which compares the layouts first):
-    # 1 dry-run + 1 warm-up + 1 pyramid-census step + 2 timed steps -> 4 early starts; and it changes nothing in the result
+    # 1 dry-run + 2 settle (--settle 2) + 1 warm-up + 1 pyramid-census step + 2 timed steps -> all but the first start early; and it
+    # changes nothing in the result
+    early = 2 + 1 + 1 + 2
     gs = out["config"]["grad_sync"]
-    assert gs["heads_bucket_floats"] > 0 and gs["heads_bucket_started_inside_backward"] == 4, gs
+    assert gs["heads_bucket_floats"] > 0 and gs["heads_bucket_started_inside_backward"] == early, gs
     # ... and behind it, still inside backward(), the executors' buffers: ScoreNet's in one piece, the backbone's 31 MB in
-    # three tail chunks gated by the events d3_net_backward records (4 collectives x 4 steps)
-    assert [len(c) for c in gs["executor_chunks"]] == [1, 3] and gs["executor_chunk_collectives_started_inside_backward"] == 16, gs
+    # three tail chunks gated by the events d3_net_backward records (4 collectives per step)
+    assert [len(c) for c in gs["executor_chunks"]] == [1, 3] and gs["executor_chunk_collectives_started_inside_backward"] == 4 * early, gs
     late = _run([], dict(_env(), D3_EARLY_ALLREDUCE="0"))
     assert late["config"]["grad_sync"]["heads_bucket_floats"] == 0
     assert late["config"]["grad_sync"]["executor_chunk_collectives_started_inside_backward"] == 0
