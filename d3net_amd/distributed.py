@@ -143,7 +143,8 @@ class BucketGradAllReduce:
                 ranges = [(0, flat.numel())]
                 if ex is not None and self._overlap and hasattr(ex, "set_grad_chunks") and self.chunks > 1:
                     ranges = ex.set_grad_chunks(self.chunks)          # [(lo, hi)] in completion order (tail first)
-                it = dict(flat=flat, params=ps, ex=ex, ranges=ranges, works=[], launched=False, count=-1)
+                it = dict(flat=flat, params=ps, ex=ex, ranges=ranges, works=[], launched=False, count=-1,
+                          base=getattr(ex, "backward_count", 0) if ex is not None else 0)
                 if ex is not None and self._overlap and hasattr(ex, "on_backward"):
                     ex.on_backward = lambda net, it=it: self._exec_ready(it)
                 items.append(it)
@@ -192,11 +193,17 @@ class BucketGradAllReduce:
                 return
             self._launch_early()
             self.early_launches += 1
+        # a step may run the detector more than once (PipelineNet mode 3: the speaker's and the listener's batch): an executor's
+        # buffer is complete when its backward has run once per detector pass of this step -- the passes are counted by the
+        # boundaries the forward passes crossed (`_expected`; no heads, no boundary: one pass)
+        need = max(1, self._expected)
         for it in self._items():
             if it["launched"]:
                 continue
             ex = it["ex"]
             if ex is None or not getattr(ex, "backward_done", False):
+                return
+            if getattr(ex, "backward_count", 0) - it["base"] < need:
                 return
             self._launch_exec(it, inside_backward)
 
@@ -316,6 +323,8 @@ class BucketGradAllReduce:
             if ex is not None and getattr(ex, "backward_count", it["count"]) != it["count"]:
                 stale_exec = ex       # its backward ran again AFTER its buffer went on the wire
             it["works"], it["launched"], it["count"] = [], False, -1
+            if ex is not None:
+                it["base"] = getattr(ex, "backward_count", 0)
             if ex is not None and hasattr(ex, "backward_done"):
                 ex.backward_done = False
         if self.early:

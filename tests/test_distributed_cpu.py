@@ -326,7 +326,7 @@ class _FakeNativeBackward(torch.autograd.Function):
         return grads[0], None
 
 
-def _chunk_worker(rank, world, port, ret, overlap):
+def _chunk_worker(rank, world, port, ret, overlap, passes=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["D3_EARLY_ALLREDUCE"] = "1" if overlap else "0"
@@ -346,10 +346,12 @@ def _chunk_worker(rank, world, port, ret, overlap):
             p.grad = None
         ex.fresh_grads = True
         torch.manual_seed(1000 * step + rank)
-        x = torch.randn(16, 9)
-        f = _FakeNativeBackward.apply(x.requires_grad_(True), ex)
-        fb, = sync.boundary(f)
-        loss = head(fb).pow(2).sum() + point_head(f).pow(2).sum()
+        loss = 0
+        for _ in range(passes):          # (PipelineNet mode 3 runs the detector twice per step: two passes through the SAME executor)
+            x = torch.randn(16, 9)
+            f = _FakeNativeBackward.apply(x.requires_grad_(True), ex)
+            fb, = sync.boundary(f)
+            loss = loss + head(fb).pow(2).sum() + point_head(f).pow(2).sum()
         before = sync.chunk_launches
         loss.backward()
         inside = sync.chunk_launches - before
@@ -357,9 +359,26 @@ def _chunk_worker(rank, world, port, ret, overlap):
         sync()
         out[step] = dict(loss=float(loss), inside=inside, local=local, avg=[p.grad.clone() for p in net.parameters()],
                          views=all(p.grad is v for p, v in zip(ex.params, ex.views)))
-    ret[(rank, overlap)] = out
+    ret[(rank, overlap, passes) if passes != 1 else (rank, overlap)] = out
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_two_detector_passes_per_step_launch_the_chunks_after_the_second_backward():
+    """PipelineNet mode 3 (speaker batch + listener batch): the executor's backward runs twice inside ONE loss.backward(); its
+    chunk collectives must wait for the second run (they used to start after the first, and the reducer then raised 'backward ran
+    again after its buffer had been all-reduced' -- found with `bench.py --config joint` over RCCL)"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    for overlap in (True, False):
+        mp.spawn(_chunk_worker, args=(world, _free_port(), ret, overlap, 2), nprocs=world, join=True)
+    for step in range(3):
+        a0, a1, b0, b1 = (ret[(r, o, 2)][step] for r, o in ((0, True), (1, True), (0, False), (1, False)))
+        assert a0["inside"] == a1["inside"] == (0 if step == 0 else 3), (step, a0["inside"], a1["inside"])
+        assert a0["loss"] == b0["loss"]
+        for g0, g1, l0, l1, gb in zip(a0["avg"], a1["avg"], b0["local"], b1["local"], b0["avg"]):
+            assert torch.allclose(g0, g1) and torch.allclose(g0, (l0 + l1) / 2, atol=1e-6) and torch.allclose(g0, gb, atol=1e-7)
 
 
 def test_backbone_bucket_is_all_reduced_in_chunks_from_inside_backward():
