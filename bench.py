@@ -544,10 +544,24 @@ def main():
                                           "executor_chunk_collectives_started_inside_backward": grad_sync.chunk_launches}
         if not dist_on and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config)
-        print(json.dumps(out), flush=True)
+    # The JSON line must be the LAST thing on stdout: RCCL writes a five-line version banner through C stdio at communicator
+    # set-up, and with stdout on a pipe that text sits in the C buffer of EVERY rank until the process exits -- after the line.
+    # So: every rank flushes its C buffers, all ranks meet, the process group goes away, and only then rank 0 prints.
     if dist_on:
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         dist.barrier()
         dist.destroy_process_group()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
