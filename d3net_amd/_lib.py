@@ -148,6 +148,7 @@ SIGNATURES = {
     "d3_tuning_name": (C.c_char_p, [i32]),
     "d3_prof_collect": (i32, [i32, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
+    "d3_prof_dump": (i32, [i32, C.POINTER(C.c_double), i32, C.POINTER(i32)]),
     "d3_bn_ws_bytes": (sz, [i32]),
     "d3_bn_stats": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "d3_bn_relu_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),

@@ -197,6 +197,7 @@ def _rl_cap_loss(data_dict, loss_opt):
     data_dict["loc_rwd"] = (listener_reward * good).sum() / ngood
     data_dict["ttl_rwd"] = (rewards * good).sum() / ngood
     data_dict["cap_loss"], data_dict["cap_acc"] = cap_loss, cap_acc
+    data_dict["sampled_scores"], data_dict["baseline_scores"] = sampled, baseline      # (the CIDEr-D rewards themselves: parity tests)
     return cap_loss, data_dict
 
 

@@ -26,6 +26,7 @@
 //      written in (parent position, list order) -- which is the FIFO order.
 // All passes stream the neighbour lists: bytes = 4*nActive per pass + 12*n, HBM/L2 bound.
 #include "common.h"
+#include "prof.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -925,8 +926,11 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         cl_ninfo_kernel<<<nb, T, 0, s>>>(w.own, w.lid, w.estart, start_len, w.ninfo, n);
         cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.ninfo, w.estart, (int4 *)erec, n);
         const bool debug = d3_tune(D3T_BFS_DEBUG) != 0;
+        // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S
+        void *pr = d3_prof_begin(5, 4.0 * (double)nActive + 12.0 * (double)n + 8.0 * (double)sumNPoint, 0.0, s);
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
                                                         w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
+        if (pr) { d3_prof_tag(pr, 0, n); d3_prof_tag(pr, 1, nCluster); d3_prof_end(pr, s); }
         if (debug) {
             int h[60 + 160];
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);

@@ -26,6 +26,7 @@
 // Roofline: these GEMMs are latency / launch bound at M = 32 (0.3 GFLOP per decode step); the batched ones (classifier
 // over all time steps: 992 x 512 x 3004) are bound by the fp32 matrix rate.
 #include "common.h"
+#include "prof.h"
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -273,8 +274,19 @@ int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
         for (int q = 0; q < probs[i].nseg; q++) kb += (probs[i].seg[q].K + 15) / 16;
         if (kb > kblocks) kblocks = kb;
     }
+    // launch timing (bench.py): exact-fp32 MFMA GEMM -- flops 2 M N K, bytes = operands + outputs once (SURVEY 8(d) "Heads")
+    double pflops = 0.0, pbytes = 0.0;
+    for (int i = 0; i < nprobs; i++) {
+        long long ksum = 0;
+        for (int q = 0; q < probs[i].nseg; q++) ksum += probs[i].seg[q].K;
+        pflops += 2.0 * (double)probs[i].M * probs[i].N * (double)ksum;
+        pbytes += 4.0 * ((double)probs[i].M * (double)ksum + (double)ksum * probs[i].N + (double)probs[i].M * probs[i].N);
+    }
+    void *pr = d3_prof_begin(3, pbytes, pflops, s);
+    int variant[3] = {0, 0, 0};          // {kernel: 0 hg_gemm_tiled_kernel, 1 hg_gemm_kernel, RT, waves}
 #define HG_SPLIT(RTV, GY)                                                                                  \
     do {                                                                                                   \
+        variant[0] = 1; variant[1] = RTV; variant[2] = kblocks >= 40 ? 16 : (kblocks >= 20 ? 8 : 4);        \
         if (kblocks >= 40) hg_gemm_kernel<RTV, true, 16><<<dim3(ctiles, GY, nprobs), 1024, 0, s>>>(b);      \
         else if (kblocks >= 20) hg_gemm_kernel<RTV, true, 8><<<dim3(ctiles, GY, nprobs), 512, 0, s>>>(b);   \
         else hg_gemm_kernel<RTV, true, 4><<<dim3(ctiles, GY, nprobs), 256, 0, s>>>(b);                      \
@@ -290,10 +302,15 @@ int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
         } else {
             const bool tiled = d3_tune(D3T_HG_TILED) != 0;   // (A/B)
             if (tiled) hg_gemm_tiled_kernel<<<dim3((ctiles * 16 + HT_BN - 1) / HT_BN, (maxM + HT_BM - 1) / HT_BM, nprobs), 256, 0, s>>>(b);
-            else hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b);
+            else { variant[0] = 1; variant[1] = 4; variant[2] = 0; hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b); }
         }
     }
 #undef HG_SPLIT
+    if (pr) {
+        const int tags[7] = {maxM, maxN, kblocks * 16, nprobs, variant[0], variant[1], variant[2]};
+        for (int i = 0; i < 7; i++) d3_prof_tag(pr, i, tags[i]);
+        d3_prof_end(pr, s);
+    }
     D3_LAUNCH_CHECK();
     return 0;
 }

@@ -1,9 +1,13 @@
-// prof.h -- launch timing shared by the convolution kernels (bench.py's `roofline` object): with profiling
-// enabled, a launch is bracketed by two HIP events on its own stream and tagged with its algorithmic bytes.
+// prof.h -- launch timing shared by the hot kernels (bench.py's `roofline` object): with profiling enabled, a sampled launch
+// is bracketed by two HIP events on its own stream and tagged with its algorithmic bytes / flops and its shape.
 #pragma once
 #include <hip/hip_runtime.h>
 // family: 0 = forward / data-gradient convolution, wave-per-tile kernel (big levels); 2 = the same contraction,
-// workgroup-per-tile kernel (few-row levels); 1 = weight-gradient kernels.  Returns an opaque
-// record (NULL when profiling is off) to pass to d3_prof_end after the launch.
+// workgroup-per-tile kernel (few-row levels); 1 = weight-gradient kernels; 3 = hg_gemm* (dense layers of the heads);
+// 4 = td_* (captioner / language-encoder recurrence); 5 = cl_bfs2 (cluster replay); 6 = un_bn_* (BatchNorm passes).
+// Returns an opaque record (NULL when profiling is off or this launch is not sampled) to pass to d3_prof_end after the launch.
+#define D3_PROF_TAGS 12
 void *d3_prof_begin(int family, double bytes, double flops, hipStream_t s);
 void d3_prof_end(void *rec, hipStream_t s);
+// shape / kernel-instance tags of a record (no-op on NULL): convolutions {Min, Mout, K, Cin, Cout, NT, WLDS, XBF, NW, F32M, KT, ST}
+void d3_prof_tag(void *rec, int idx, int value);

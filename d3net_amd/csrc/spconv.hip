@@ -35,7 +35,7 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
 // When enabled, every MFMA convolution launch is bracketed by two HIP events on its own stream and tagged
 // with its algorithmic byte / flop count; d3_prof_collect() resolves them after the timed region.
 #include <deque>
-struct ProfRec { hipEvent_t a, b; int family; double bytes, flops; };
+struct ProfRec { hipEvent_t a, b; int family; double bytes, flops; int tag[D3_PROF_TAGS]; };
 static std::deque<ProfRec> g_prof;   // stable element addresses
 static size_t g_prof_used = 0;
 static int g_prof_on = 0;
@@ -67,12 +67,14 @@ static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s
     }
     ProfRec *r = &g_prof[g_prof_used++];
     r->family = family; r->bytes = bytes; r->flops = flops;
+    for (int i = 0; i < D3_PROF_TAGS; i++) r->tag[i] = 0;
     hipEventRecord(r->a, s);
     return r;
 }
 static void prof_end(ProfRec *r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 void *d3_prof_begin(int family, double bytes, double flops, hipStream_t s) { return prof_begin(family, bytes, flops, s); }
 void d3_prof_end(void *rec, hipStream_t s) { prof_end((ProfRec *)rec, s); }
+void d3_prof_tag(void *rec, int idx, int value) { if (rec && idx >= 0 && idx < D3_PROF_TAGS) ((ProfRec *)rec)->tag[idx] = value; }
 // family: 0 = spconv_fwd2 / spconv_fwd_mfma (forward + data gradient), 1 = weight gradient, 2 = spconv_fwd2_split.
 // The elapsed time of an EMPTY event pair on the same stream (median of 32) is subtracted from every sample: it is the
 // cost of the bracket itself, not of the kernel (rocprofv3's kernel durations carry no such term).
@@ -104,6 +106,42 @@ extern "C" int d3_prof_collect(int family, long long *launches, double *total_ms
         if (d < 0.0005) d = 0.0005;
         *launches += 1; *total_ms += d; *total_bytes += r.bytes; *total_flops += r.flops;
     }
+    return 0;
+}
+
+// every sampled launch of a family: rows of (3 + D3_PROF_TAGS) doubles = {ms (empty event pair subtracted), bytes, flops, tags...};
+// *n = records of the family (rows beyond `cap` are counted, not written).  Synchronises like d3_prof_collect.
+extern "C" int d3_prof_dump(int family, double *rows, int cap, int *n) {
+    D3_CLEAR();
+    hipEvent_t ea, eb;
+    D3_CHECK(hipEventCreate(&ea)); D3_CHECK(hipEventCreate(&eb));
+    float v[32];
+    for (int i = 0; i < 32; i++) {
+        hipEventRecord(ea, 0); hipEventRecord(eb, 0);
+        D3_CHECK(hipEventSynchronize(eb));
+        v[i] = 0.f; hipEventElapsedTime(&v[i], ea, eb);
+    }
+    for (int i = 0; i < 32; i++) for (int j = i + 1; j < 32; j++) if (v[j] < v[i]) { float t = v[i]; v[i] = v[j]; v[j] = t; }
+    const double empty_ms = v[16];
+    hipEventDestroy(ea); hipEventDestroy(eb);
+    int k = 0;
+    const int W = 3 + D3_PROF_TAGS;
+    for (size_t i = 0; i < g_prof_used; i++) {
+        ProfRec &r = g_prof[i];
+        if (r.family != family) continue;
+        if (k < cap && rows) {
+            D3_CHECK(hipEventSynchronize(r.b));
+            float ms = 0.f;
+            D3_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+            double d = (double)ms - empty_ms;
+            if (d < 0.0005) d = 0.0005;
+            double *o = rows + (size_t)k * W;
+            o[0] = d; o[1] = r.bytes; o[2] = r.flops;
+            for (int t = 0; t < D3_PROF_TAGS; t++) o[3 + t] = (double)r.tag[t];
+        }
+        k++;
+    }
+    *n = k;
     return 0;
 }
 

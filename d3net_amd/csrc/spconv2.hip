@@ -792,6 +792,12 @@ static bool c2_attr_needed(bool *done) {
     return true;
 }
 
+// template arguments of the instance the last launch_fwd2* call of this thread ran: {NT, WLDS, XBF, NW, F32M, KT, ST} for
+// spconv_fwd2_kernel, {NTW, XBF, F32M} for spconv_fwd2_split_kernel -- the profiling record names the kernel as rocprofv3 prints it
+static thread_local int g_c2_inst[7];
+static inline void c2_inst(int a0, int a1, int a2, int a3, int a4, int a5, int a6) {
+    g_c2_inst[0] = a0; g_c2_inst[1] = a1; g_c2_inst[2] = a2; g_c2_inst[3] = a3; g_c2_inst[4] = a4; g_c2_inst[5] = a5; g_c2_inst[6] = a6;
+}
 template <int NT>
 static int launch_fwd2_f32(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
     static bool attr_done_dev[64] = {false};
@@ -802,8 +808,9 @@ static int launch_fwd2_f32(const Conv2Args &a, const Conv2Plan &p, hipStream_t s
             D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if constexpr (NT <= C2_NW16_MAXNT) {
-        if (p.nw == 16) { spconv_fwd2_kernel<NT, true, false, 16, true><<<p.grid, 1024, p.lds, s>>>(a); D3_LAUNCH_CHECK(); return 0; }
+        if (p.nw == 16) { c2_inst(NT, 1, 0, 16, 1, 0, 0); spconv_fwd2_kernel<NT, true, false, 16, true><<<p.grid, 1024, p.lds, s>>>(a); D3_LAUNCH_CHECK(); return 0; }
     }
+    c2_inst(NT, p.wlds ? 1 : 0, 0, 4, 1, 0, 0);
     if (p.wlds) spconv_fwd2_kernel<NT, true, false, 4, true><<<p.grid, 256, p.lds, s>>>(a);
     else spconv_fwd2_kernel<NT, false, false, 4, true><<<p.grid, 256, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
@@ -815,6 +822,7 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev))
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c2_inst(NT, 1, 1, NW, 0, 27, ST);
     spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST><<<p.grid, 64 * NW, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
@@ -850,12 +858,14 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
                 D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
+            c2_inst(NT, 1, a.xbf16 ? 1 : 0, 16, 0, 0, 0);
             if (a.xbf16) spconv_fwd2_kernel<NT, true, true, 16><<<p.grid, 1024, p.lds, s>>>(a);
             else spconv_fwd2_kernel<NT, true, false, 16><<<p.grid, 1024, p.lds, s>>>(a);
             D3_LAUNCH_CHECK();
             return 0;
         }
     }
+    c2_inst(NT, p.wlds ? 1 : 0, a.xbf16 ? 1 : 0, 4, 0, 0, 0);
     if (a.xbf16) {
         if (p.wlds) spconv_fwd2_kernel<NT, true, true><<<p.grid, 256, p.lds, s>>>(a);
         else spconv_fwd2_kernel<NT, false, true><<<p.grid, 256, p.lds, s>>>(a);
@@ -873,6 +883,7 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_split_kernel<NTW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     }
+    c2_inst(NTW, a.f32 ? 0 : (a.xbf16 ? 1 : 0), a.f32 ? 1 : 0, -1, 0, 0, 0);
     if (a.f32) {
         static bool attr32_done_dev[64] = {false};
         if (c2_attr_needed(attr32_done_dev))
@@ -928,6 +939,12 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + (f32 ? 4.0 : 2.0) * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
     void *pr = d3_prof_begin(p.split ? 2 : 0, bytes, 0.0, s);
+    auto tag_rec = [&]() {
+        if (!pr) return;
+        const int dims[5] = {Min, Mout, K, Cin, Cout};
+        for (int i = 0; i < 5; i++) d3_prof_tag(pr, i, dims[i]);
+        for (int i = 0; i < 7; i++) d3_prof_tag(pr, 5 + i, g_c2_inst[i]);
+    };
     int rc;
     a.NT = (Cout + 15) / 16;
     if (p.split) {
@@ -940,6 +957,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
             case 6: rc = launch_fwd2_split<6>(a, p, s); break;
             default: rc = launch_fwd2_split<7>(a, p, s); break;
         }
+        tag_rec();
         d3_prof_end(pr, s);
         return rc;
     }
@@ -950,6 +968,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         default: rc = D3_ERR_ARG;
     }
 #undef C2_CASE
+    tag_rec();
     d3_prof_end(pr, s);
     return rc;
 }
@@ -1919,6 +1938,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         f.ngb = ((f.Cg + 15) / 16 + cf.bg - 1) / cf.bg; f.nsb = ((f.Cs + 15) / 16 + cf.bs - 1) / cf.bs;
         const double bytes32 = 4.0 * (double)Min * Cin + 4.0 * (double)Mout * Cout + 4.0 * (double)wn + (tbl ? 4.0 * (double)Ms * K : 0.0);
         void *pr32 = d3_prof_begin(1, bytes32, 0.0, s);
+        { const int dims[6] = {Min, Mout, K, Cin, Cout, 32}; for (int i = 0; i < 6; i++) d3_prof_tag(pr32, i, dims[i]); }
         { const int lrc = launch_wgf(f, cf, p.R, s); if (lrc) return lrc; }
         if (!(flags & D3_CONV_NOREDUCE)) {
             wgrad2_reduce_kernel<<<(int)((wn + 31) / 32), 256, 0, s>>>((const float *)ws, dW, wn, p.R, accum);
@@ -1944,6 +1964,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
     const double bytes = (xbf ? 2.0 : 4.0) * (double)Min * Cin + (dybf ? 2.0 : 4.0) * (double)Mout * Cout + 4.0 * (double)wn +
                          (tbl ? 4.0 * (double)Ms * K : 0.0);
     void *pr = d3_prof_begin(1, bytes, 0.0, s);
+    { const int dims[6] = {Min, Mout, K, Cin, Cout, p.w3 ? 3 : (p.wide ? 1 : 2)}; for (int i = 0; i < 6; i++) d3_prof_tag(pr, i, dims[i]); }
     int rc = D3_ERR_ARG;
     if (p.w3) {
         const Wg3Cfg &c = *p.w3;

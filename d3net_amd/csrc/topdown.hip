@@ -23,6 +23,7 @@
 // Roofline: launch / latency bound (0.3 GFLOP and ~20 MB of L2-resident weights per step); the measure is launches and
 // microseconds per step, reported by bench.py's profile.
 #include "common.h"
+#include "prof.h"
 #include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -282,7 +283,11 @@ static int td_gru_fwd(const GruArgs &a, hipStream_t s) {
     if (a.H & 15) return D3_ERR_ARG;
     if (a.N <= 0) return 0;
     if (d3_tune(D3T_GRU4) != 0 && a.N <= 256) {   // gate-packed columns: 4 hidden units per workgroup
+        // launch timing (bench.py): a GRU cell = two skinny fp32 GEMMs (N x 3H x I, N x 3H x H) + gates; bytes = weights + rows once
+        const int I = a.gi_pre ? 0 : a.I;
+        void *pr = d3_prof_begin(4, 4.0 * (3.0 * a.H * (I + a.H) + (double)a.N * (I + 6.0 * a.H)), 2.0 * a.N * 3.0 * a.H * (I + a.H), s);
         td_gru4_fwd_kernel<1><<<dim3(a.H / 4, (a.N + 15) / 16), GRU4_NW * 64, 0, s>>>(a);
+        if (pr) { d3_prof_tag(pr, 0, 1); d3_prof_tag(pr, 1, a.N); d3_prof_tag(pr, 2, a.H); d3_prof_tag(pr, 3, I); d3_prof_end(pr, s); }
         D3_LAUNCH_CHECK();
         return 0;
     }

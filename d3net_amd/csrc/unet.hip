@@ -367,7 +367,7 @@ struct OpD {
     int use_shadow;                   // CONV: reads its output gradient from the bf16 shadow of that (fp32) gradient buffer
     int write_shadow;                 // BNACT: its backward apply also writes the bf16 shadow of the buffer it finalises
 };
-#define RED_RING 16
+#define RED_RING 32
 struct Net {
     std::vector<TensorD> T;
     std::vector<BufD> B;
@@ -665,7 +665,10 @@ extern "C" void d3_net_destroy(void *h) {
 // op_idx[k] (descending): the backward has finished chunk k's parameters when it has processed op op_idx[k]
 extern "C" int d3_net_set_chunks(void *h, const int *op_idx, int nchunks) {
     Net *n = (Net *)h;
-    if (!n || nchunks < 0 || nchunks > 64) return D3_ERR_ARG;
+    // every chunk boundary may flush the pending reductions through one slot of the pinned staging ring (+ the tail flush and the
+    // final one): a slot must not come round again while its host-to-device copy can still be queued, i.e. within two backward
+    // calls -- 2 * (nchunks + 2) <= RED_RING (64 chunks wrapped the ring inside ONE backward)
+    if (!n || nchunks < 0 || 2 * (nchunks + 2) > RED_RING) return D3_ERR_ARG;
     for (int k = 0; k < nchunks; k++) {
         if (op_idx[k] < 0 || op_idx[k] >= (int)n->ops.size() || (k > 0 && op_idx[k] >= op_idx[k - 1])) return D3_ERR_ARG;
     }
@@ -983,7 +986,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             D3_CHECK(hipHostMalloc((void **)&n->red_host, RED_RING * n->red_cap * sizeof(RedJob)));
             D3_CHECK(hipMalloc((void **)&n->red_dev, RED_RING * n->red_cap * sizeof(RedJob)));
         }
-        n->red_flip = (n->red_flip + 1) % RED_RING;   // a slot is rewritten only RED_RING / 2 backward calls later (no host sync needed in between)
+        n->red_flip = (n->red_flip + 1) % RED_RING;   // <= nchunks + 2 flushes per backward (d3_net_set_chunks bounds nchunks): a slot comes round again >= 2 backward calls later
         RedJob *hj = n->red_host + (size_t)n->red_flip * n->red_cap, *dj = n->red_dev + (size_t)n->red_flip * n->red_cap;
         memcpy(hj, red.data(), red.size() * sizeof(RedJob));
         D3_CHECK(hipMemcpyAsync(dj, hj, red.size() * sizeof(RedJob), hipMemcpyHostToDevice, ws_stream));

@@ -91,9 +91,14 @@ class BucketGradAllReduce:
     `owner`: an object with `static_gradient_buckets()` -> [(flat tensor, [parameters], executor)] (PointGroup), or --
     legacy form used by the CPU tests -- a callable returning ([flat tensors], [covered parameters])."""
 
-    def __init__(self, params, owner, early=(), chunks=3):
+    def __init__(self, params, owner, early=(), chunks=None):
         self.params = [p for p in params if p.requires_grad]
         self.owner = owner
+        if chunks is None:
+            # without per-chunk streams a chunk collective is ordered behind the WHOLE native backward already enqueued on the
+            # caller's stream: k chunks would be k serial collectives with nothing to overlap -- one collective per executor
+            # (ADVICE r3); with D3_CHUNK_STREAMS=1 three tail chunks overlap the rest of the backward
+            chunks = 3 if os.environ.get("D3_CHUNK_STREAMS", "0") == "1" else 1
         self.chunks = int(os.environ.get("D3_GRAD_CHUNKS", chunks))
         self._checked = False
         self._rest = None
@@ -144,7 +149,8 @@ class BucketGradAllReduce:
                 if ex is not None and self._overlap and hasattr(ex, "set_grad_chunks") and self.chunks > 1:
                     ranges = ex.set_grad_chunks(self.chunks)          # [(lo, hi)] in completion order (tail first)
                 it = dict(flat=flat, params=ps, ex=ex, ranges=ranges, works=[], launched=False, count=-1,
-                          base=getattr(ex, "backward_count", 0) if ex is not None else 0)
+                          base=getattr(ex, "backward_count", 0) if ex is not None else 0,
+                          fbase=getattr(ex, "forward_count", None) if ex is not None else None)
                 if ex is not None and self._overlap and hasattr(ex, "on_backward"):
                     ex.on_backward = lambda net, it=it: self._exec_ready(it)
                 items.append(it)
@@ -194,15 +200,17 @@ class BucketGradAllReduce:
             self._launch_early()
             self.early_launches += 1
         # a step may run the detector more than once (PipelineNet mode 3: the speaker's and the listener's batch): an executor's
-        # buffer is complete when its backward has run once per detector pass of this step -- the passes are counted by the
-        # boundaries the forward passes crossed (`_expected`; no heads, no boundary: one pass)
-        need = max(1, self._expected)
+        # buffer is complete when its backward has run once per differentiable FORWARD it ran since the last sync.  The executor
+        # counts those itself (`forward_count`, ADVICE r3: the boundaries crossed are only a proxy -- a pass whose outputs carry
+        # no gradient into the heads places none); executors without the counter (the CPU tests' stand-ins): boundaries, min 1
         for it in self._items():
             if it["launched"]:
                 continue
             ex = it["ex"]
             if ex is None or not getattr(ex, "backward_done", False):
                 return
+            fc = getattr(ex, "forward_count", None)
+            need = max(1, self._expected) if (fc is None or it["fbase"] is None) else max(1, fc - it["fbase"])
             if getattr(ex, "backward_count", 0) - it["base"] < need:
                 return
             self._launch_exec(it, inside_backward)
@@ -325,6 +333,7 @@ class BucketGradAllReduce:
             it["works"], it["launched"], it["count"] = [], False, -1
             if ex is not None:
                 it["base"] = getattr(ex, "backward_count", 0)
+                it["fbase"] = getattr(ex, "forward_count", None)
             if ex is not None and hasattr(ex, "backward_done"):
                 ex.backward_done = False
         if self.early:

@@ -166,6 +166,8 @@ class _AddLayerNorm(Function):
 
 def add_layer_norm(a, b, ln):
     """ln(a + b) (b may be None) for an nn.LayerNorm over the last dimension"""
-    if not _native_ok(a, b, ln.weight, ln.bias) or ln.weight is None or len(ln.normalized_shape) != 1 or a.shape[-1] > 1024:
+    # the kernels index `b` with a's (R, D) shape: a broadcastable b or a LayerNorm over another width takes the library path
+    if (not _native_ok(a, b, ln.weight, ln.bias) or ln.weight is None or len(ln.normalized_shape) != 1 or a.shape[-1] > 1024
+            or ln.normalized_shape[0] != a.shape[-1] or (b is not None and b.shape != a.shape)):
         return ln(a if b is None else a + b)
     return _AddLayerNorm.apply(a, b, ln.weight, ln.bias, ln.eps)

@@ -160,6 +160,7 @@ class NativeUNet:
         self.on_backward = None
         self.backward_done = False   # a native backward ran since the reducer last reset it
         self.backward_count = 0
+        self.forward_count = 0       # differentiable forwards (each one owes a backward before the flat buffer is complete)
         self._chunk_ranges = None
 
     # ------------------------------------------------------------------ lazily created native state
@@ -231,6 +232,7 @@ class NativeUNet:
             offs.append(off)
             off += p.numel() if g else 0
         total = off
+        nchunks = max(1, min(int(nchunks), 14))      # (d3_net_set_chunks: the staging ring covers 2 * (nchunks + 2) <= 32 flushes)
         if total < (1 << 20):                # (a 0.1 MB ScoreNet buffer: one collective)
             nchunks = 1
         first_param = []                     # per op: its first parameter index (ops without parameters: None)
@@ -308,6 +310,8 @@ class NativeUNet:
         # parameters made the engine visit 250 AccumulateGrad nodes with nothing to accumulate: 0.3 ms of host time right
         # before the optimizer)
         anchor = next((p for p, g in zip(ps, self.b.grad_params) if g and p.requires_grad), None)
+        if training and torch.is_grad_enabled() and (anchor is not None or feats.requires_grad):
+            self.forward_count += 1
         return _NetFunction.apply(feats, self, cm, bool(training), *(() if anchor is None else (anchor,)))
 
 

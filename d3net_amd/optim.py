@@ -43,17 +43,14 @@ class FusedAdamW(torch.optim.Optimizer):
                     self.state[p]["step"] = t
 
     def state_dict(self):
-        """torch.optim.AdamW's layout: per-parameter `step` (a float32 scalar tensor), `exp_avg`, `exp_avg_sq`"""
+        """torch.optim.AdamW's layout: per-parameter `step` (a float32 scalar tensor), `exp_avg`, `exp_avg_sq`.  The returned
+        per-parameter dicts are COPIES: `Optimizer.state_dict()` hands out the live `self.state[p]` objects, and this class keeps
+        python-int step counts there (converting in place also rewrote the dict already returned)."""
         self._flush_steps()
-        for st in self.state.values():
-            if "step" in st and not torch.is_tensor(st["step"]):
-                st["step"] = torch.tensor(float(st["step"]))
-        try:
-            return super().state_dict()
-        finally:
-            for st in self.state.values():
-                if torch.is_tensor(st.get("step")):
-                    st["step"] = int(st["step"])
+        sd = super().state_dict()
+        sd["state"] = {k: (dict(st, step=torch.tensor(float(st["step"]))) if "step" in st and not torch.is_tensor(st["step"]) else dict(st))
+                       for k, st in sd["state"].items()}
+        return sd
 
     def load_state_dict(self, state_dict):
         """moments are replaced: the cached device tables (which hold their addresses) are dropped; the step counts come from

@@ -182,11 +182,13 @@ class PointGroup(nn.Module):
 
     def static_gradient_buckets(self):
         """[(flat gradient buffer, its parameters, executor)] for BOTH executors, created eagerly so that every rank of
-        a data-parallel job has the same bucket layout whatever its scenes produce (d3net_amd.distributed)."""
+        a data-parallel job has the same bucket layout whatever its scenes produce (d3net_amd.distributed).  The executors are
+        the ones the current precision mode runs (`minkowski.set_exact`: the fp32 twins own their own flat buffers); a reducer
+        caches the list, so the mode must be chosen before the first gradient sync."""
         out = []
         dev = self.score_linear.weight.device
         for name in ("score_net", "backbone"):      # backward order: ScoreNet's gradients are complete first
-            ex = self._exec(name)
+            ex = self._exec(name, exact=ME._EXACT)
             ex._param_ptrs()
             ex._grads(dev)
             out.append((ex._flat_grad, ex.owned_params(), ex))

@@ -284,6 +284,11 @@ int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int
  * collect() synchronises. */
 int d3_prof_enable(int on);
 int d3_prof_collect(int family, long long *launches, double *total_ms, double *total_bytes, double *total_flops);
+/* every sampled launch of a family as rows of 15 doubles {ms, bytes, flops, 12 tags}; families 3 = hg_gemm* (tags maxM, maxN,
+ * K, problems, kernel 0 tiled / 1 split, row tiles, waves), 4 = td_gru4_fwd (1, N, H, I), 5 = cl_bfs2 (n, clusters), 6 = un_bn_*
+ * (kernel, M, C); convolutions: Min, Mout, K, Cin, Cout + the template arguments of the instance (rocprofv3's kernel name).
+ * *n = records of the family; at most `cap` rows are written.  No reference counterpart (measurement only). */
+int d3_prof_dump(int family, double *rows, int cap, int *n);
 
 /* Measurement / test switches.  The library reads its environment ONCE (csrc/tuning.hip: one
  * table, one parse at first use); these entry points let tests and the A/B tools flip a switch at run time instead of

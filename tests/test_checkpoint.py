@@ -95,3 +95,22 @@ def test_kernel_order_load_hook():
         ME.set_kernel_order("xyz")
     conv.load_state_dict({"kernel": src.clone()})
     assert torch.equal(conv.kernel.detach(), src)
+
+
+def test_fused_adamw_state_dict_is_a_copy_in_torch_layout():
+    """`step` leaves as a float32 scalar tensor (torch.optim.AdamW's layout) while the live optimizer state keeps its
+    python int, and the returned per-parameter dicts are not the live `state[p]` objects."""
+    from d3net_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.zeros(5))
+    opt = FusedAdamW([p], lr=1e-3)
+    opt.state[p] = {"step": 3, "exp_avg": torch.ones(5), "exp_avg_sq": torch.full((5,), 2.0)}
+    sd = opt.state_dict()
+    st = sd["state"][0]
+    assert torch.is_tensor(st["step"]) and st["step"].dtype == torch.float32 and float(st["step"]) == 3.0
+    assert st is not opt.state[p] and opt.state[p]["step"] == 3 and isinstance(opt.state[p]["step"], int)
+    ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(5))], lr=1e-3)
+    ref.load_state_dict(sd)
+    assert float(list(ref.state.values())[0]["step"]) == 3.0
+    opt2 = FusedAdamW([torch.nn.Parameter(torch.zeros(5))], lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert list(opt2.state.values())[0]["step"] == 3

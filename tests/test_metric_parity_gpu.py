@@ -16,9 +16,10 @@ Set-up (no dataset is available offline; SURVEY.md section 7 "metric parity with
     HIP = the product's `validation_step` / `validation_epoch_end` + the device evaluator;
     oracle = PointGroupOracle(training=False) -> speaker_oracle.graph_module -> speaker_oracle.forward_scene_batch, scored by
     the same (golden-pinned, host-side) metric code.
-Bound (BASELINE.json north_star: "mAP@0.5 / CIDEr within 0.5 % of reference"): asserted for the reference-precision path
-(`minkowski.set_exact`, fp32 MFMA); the bf16 path is bounded in flipped detections (see the test), with the oracle's mAP@0.5
-required inside (0.3, 0.95) and its CIDEr@0.5IoU > 0.2 so that equality is not 0 == 0 or 1 == 1.
+Bound (BASELINE.json north_star: "mAP@0.5 / CIDEr within 0.5 % of reference"): asserted for the bf16 path -- the one `bench.py`
+times and reports -- on 128 held-out scenes (768 GT boxes) for three training seeds, and for the reference-precision path
+(`minkowski.set_exact`, fp32 MFMA) on seed 0; the oracle's mAP@0.5 is required inside (0.3, 0.95) and its CIDEr@0.5IoU > 0.2
+so that equality is not 0 == 0 or 1 == 1.
 """
 import types
 
@@ -266,36 +267,34 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
     return res
 
 
-def test_heldout_map_and_cider_parity_with_the_fp32_oracle(dev):
-    """32 held-out scenes (192 GT boxes).  What is asserted, and why it is split:
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_heldout_map_and_cider_parity_with_the_fp32_oracle(dev, seed):
+    """128 held-out scenes (768 GT boxes: one flipped detection moves mAP@0.5 by ~0.13 %, one changed caption moves
+    CIDEr@0.5IoU by ~0.15 %), three training seeds.  BASELINE.json's north-star bound -- mAP@0.5 and CIDEr@0.5IoU within 0.5 % of
+    the reference -- is asserted for the bf16 path, the one `bench.py` reports as `value`, against the fp32 CPU oracle on the same
+    weights and scenes; the reference-precision path (`minkowski.set_exact`, `bench.py --exact` / the line's `fp32_exact`) is
+    held to the same bound on seed 0.
 
-      * the REFERENCE-PRECISION path (minkowski.set_exact: fp32 storage, fp32 MFMA products; what `bench.py --exact` times) must
-        meet the north-star bound: mAP@0.5 and CIDEr@0.5IoU within 0.5 % of the fp32 CPU oracle;
-      * the bf16 path (what `bench.py` times by default) is the same network with operands rounded to 8 mantissa bits: a point
-        whose two best class scores are within ~1 % changes its arg-max, a cluster gains or loses a few points, and a box whose
-        IoU with its GT box sits at 0.5 +- 0.01 changes sides.  On this evaluation set that is 0-1 detections of 96 per run
-        (measured: 0.08 % and 1.4 % of mAP on two builds whose trained weights differed), and mAP moves in quanta of
-        ~1 / (number of GT boxes): one flipped detection of 192 is 0.5 %.  The bf16 bound is therefore stated in detections:
-        at most 3 flipped detections' worth of mAP (3 / n_GT relative) and 2 % of CIDEr -- tight enough to catch a broken kernel
-        (a wrong neighbour table or BatchNorm statistic moves these by tens of percent), honest about what bf16 is.
-    """
-    # (the captioner trains at 1e-3, the detector at 4e-3: with ONE rate of 4e-3 the GRU captioner collapsed to the unigram
-    # distribution in 3 of 6 seeds -- the recipe, not the kernels; at 1e-3 all of seeds 0-5 reach CIDEr 1.6-2.1.  Measured with the
-    # oracle on seeds 0 / 1 / 2: reference-precision path identical to 4 digits, bf16 mAP identical (0 flipped detections),
-    # bf16 CIDEr within 0.34 / 0.67 / 0.47 %, 187-190 of 192 captions token-identical)
-    res = run_parity(dev, n_val=32, head_lr=1e-3)
+    Measured (tools/metric_parity_seeds.py, gpurun_out r04_parity_seeds): bf16 mAP -0.003 / -0.001 / -0.003 %, CIDEr +0.04 /
+    -0.21 / -0.19 %, 757 / 762 / 763 of 768 captions token-identical; fp32 path: mAP identical, CIDEr -0.16 / 0 / 0 %
+    (767 / 768 / 768 captions).  Round 3 evaluated 32 scenes: with 192 captions one changed caption alone was 0.3 - 0.7 %, which
+    is what its looser bound (2 %) was absorbing -- the evaluation set was too small to resolve the bound, not the arithmetic
+    too coarse to meet it.
+    (the captioner trains at 1e-3, the detector at 4e-3: with ONE rate of 4e-3 the GRU captioner collapsed to the unigram
+    distribution in 3 of 6 seeds -- the recipe, not the kernels)"""
+    res = run_parity(dev, n_val=128, head_lr=1e-3, seed=seed, exact_too=(seed == 0), verbose=False)
     o = res["oracle"]
     n_gt = len(o["cands"])
-    assert n_gt >= 150, n_gt
+    assert n_gt >= 750, n_gt
     assert 0.3 < o["mAP"] < 0.95, ("operating point saturated or degenerate", o["mAP"])
     assert o["cider"] > 0.2, o["cider"]
-    e = res["exact"]
-    assert abs(e["mAP"] - o["mAP"]) <= 0.005 * o["mAP"], ("reference precision", "mAP@0.5", e["mAP"], o["mAP"])
-    assert abs(e["cider"] - o["cider"]) <= 0.005 * o["cider"], ("reference precision", "CIDEr@0.5IoU", e["cider"], o["cider"])
-    h = res["bf16"]
-    flips = abs(h["mAP"] - o["mAP"]) / o["mAP"] * n_gt
-    print("bf16 vs fp32 oracle: mAP %.4f vs %.4f = %.2f %% = %.1f detections of %d; CIDEr %.4f vs %.4f = %.2f %%; %d / %d captions identical" %
-          (h["mAP"], o["mAP"], 100 * abs(h["mAP"] - o["mAP"]) / o["mAP"], flips, n_gt, h["cider"], o["cider"],
-           100 * abs(h["cider"] - o["cider"]) / o["cider"], h["same_captions"][0], h["same_captions"][1]))
-    assert flips <= 3.0, ("bf16", "mAP@0.5", h["mAP"], o["mAP"], flips)
-    assert abs(h["cider"] - o["cider"]) <= 0.02 * o["cider"], ("bf16", "CIDEr@0.5IoU", h["cider"], o["cider"])
+    for k in ("bf16", "exact"):
+        if k not in res:
+            continue
+        h = res[k]
+        print("seed %d, %s vs fp32 oracle: mAP@0.5 %.5f vs %.5f = %+.3f %%; CIDEr@0.5IoU %.5f vs %.5f = %+.3f %%; %d / %d captions identical"
+              % (seed, k, h["mAP"], o["mAP"], 100 * (h["mAP"] - o["mAP"]) / o["mAP"], h["cider"], o["cider"],
+                 100 * (h["cider"] - o["cider"]) / o["cider"], h["same_captions"][0], h["same_captions"][1]))
+        assert abs(h["mAP"] - o["mAP"]) <= 0.005 * o["mAP"], (k, "mAP@0.5", h["mAP"], o["mAP"])
+        assert abs(h["cider"] - o["cider"]) <= 0.005 * o["cider"], (k, "CIDEr@0.5IoU", h["cider"], o["cider"])
+        assert h["same_captions"][0] >= 0.97 * h["same_captions"][1], (k, h["same_captions"])
