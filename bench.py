@@ -33,6 +33,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 (exact fp32 in / fp32 accumulate), dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (quoted beside the HBM fraction of the convolutions: the secondary figure of SURVEY 8(d))
+PROF_TAGS = 12
 VOCAB = 3004
 CONF = {"speaker": "pointgroup_captioning.yaml", "detector": "pointgroup.yaml", "listener": "pointgroup_grounding.yaml",
         "joint": "pointgroup_joint.yaml"}
@@ -63,6 +66,7 @@ def parse():
 
 CPU_THREADS = 8            # default thread count of the CPU baseline child (the parent sweeps CPU_THREAD_SWEEP; all 256 hardware threads of the GPU box: 1000x slower)
 CPU_THREAD_SWEEP = (8, 16, 32)   # the sweep behind that "8", re-run with every bench line (the best one is `cpu_baseline.value`)
+CPU_WARMUP_STEPS, CPU_TIMED_STEPS = 1, 3   # per thread count: ~4 x 5 s of CPU work
 
 
 # ------------------------------------------------------------------------------------------ workloads
@@ -158,7 +162,7 @@ def compulsory_bytes(detector, batch):
             nin, nout = rows[lin], rows[lout]
             P = pairs3[mlevel] if kind == netexec.MAP_K3 else (max(nin, nout) if kind in (netexec.MAP_DOWN, netexec.MAP_UP) else nout)
             fwd += 2.0 * (nin * cin + nout * cout) + 2.0 * K * cin * cout + 8.0 * P
-        detail[name] = {"rows": list(rows), "forward_bytes": fwd}
+        detail[name] = {"rows": list(rows), "pairs27": list(pairs3), "forward_bytes": fwd}
         total += 3.0 * fwd
     N, C = batch["feats"].shape[0], batch["feats"].shape[1] + 3
     M, mA1 = batch["v2p_map"].shape
@@ -166,6 +170,106 @@ def compulsory_bytes(detector, batch):
     detail["input_pooling_bytes"] = pool
     return total + pool, detail
 
+
+
+def _b(x):
+    return "true" if x else "false"
+
+
+def prof_kernel_name(fam, t):
+    """the kernel a profiling record timed, named as rocprofv3 prints it (template arguments included where the record has them)"""
+    t = [int(v) for v in t]
+    if fam == 0:
+        nt, wlds, xbf, nw, f32, kt, st = t[5:12]
+        return "spconv_fwd2_kernel<%d, %s, %s, %d, %s, %d, %d>" % (nt, _b(wlds), _b(xbf), nw, _b(f32), kt, st)
+    if fam == 2:
+        return "spconv_fwd2_split_kernel<%d, %s, %s>" % (t[5], _b(t[6]), _b(t[7]))
+    if fam == 1:
+        return {3: "spconv_wgrad3_kernel", 2: "spconv_wgrad2_kernel", 1: "spconv_wgrad2_wide_kernel", 32: "spconv_wgrad_f32_kernel"}.get(t[5], "spconv_wgrad")
+    if fam == 3:
+        return "hg_gemm_tiled_kernel" if t[4] == 0 else "hg_gemm_kernel<%d, %s, %d>" % (t[5], _b(t[6] > 0), max(t[6], 4))
+    if fam == 4:
+        return "td_gru4_fwd_kernel<1>"
+    if fam == 5:
+        return "cl_bfs2_kernel"
+    return "family%d" % fam
+
+
+def conv_bytes_8d(t, pairs27):
+    """Bytes = e*(Nin*Cin + Nout*Cout) + e*K*Cin*Cout + 8*P with e = 2 (bf16 storage) and P = the kernel map's
+    (in, out) pairs: the 27-offset rulebook size of the level for K = 27 (counted from this step's own maps), the fine level's
+    rows for the stride-2 / transposed convolutions (K = 8: every fine row has exactly one parent), Nout for K = 1.
+    FLOPs = 2*P*Cin*Cout.  The weight-gradient launch of a layer is priced like its forward (8(d): backward = 2x the forward)."""
+    Min, Mout, K, Cin, Cout = (int(v) for v in t[:5])
+    if K == 27:
+        P = pairs27.get(Mout)
+        if P is None:
+            P = pairs27.get(Min, 9.3 * Mout)
+    elif K == 8:
+        P = max(Min, Mout)
+    else:
+        P = Mout * K
+    return 2.0 * (Min * Cin + Mout * Cout) + 2.0 * K * Cin * Cout + 8.0 * P, 2.0 * P * Cin * Cout
+
+
+def collect_kernel_rooflines(L, steps, stride, pairs27):
+    """every sampled launch of the timed region (HIP events on its own stream, csrc/prof.h) -> per-kernel records:
+    {name: {family, launches_sampled, launches_per_step, avg_launch_us, ms_per_step, bytes_8d, bytes_design, flops}}"""
+    out = {}
+    W = 3 + PROF_TAGS
+    for fam in (0, 1, 2, 3, 4, 5):
+        n = C.c_int(0)
+        L.d3_prof_dump(fam, None, 0, C.byref(n))
+        if n.value == 0:
+            continue
+        buf = (C.c_double * (W * n.value))()
+        L.d3_prof_dump(fam, buf, n.value, C.byref(n))
+        for i in range(n.value):
+            row = buf[i * W:(i + 1) * W]
+            ms, bdesign, flops, tags = row[0], row[1], row[2], row[3:]
+            name = prof_kernel_name(fam, tags)
+            if fam in (0, 1, 2):
+                b8, flops = conv_bytes_8d(tags, pairs27)
+            else:
+                b8 = bdesign
+            r = out.setdefault(name, dict(family=fam, n=0, ms=0.0, bytes_8d=0.0, bytes_design=0.0, flops=0.0))
+            r["n"] += 1; r["ms"] += ms; r["bytes_8d"] += b8; r["bytes_design"] += bdesign; r["flops"] += flops
+    res = {}
+    for name, r in out.items():
+        n = max(r["n"], 1)
+        res[name] = {"family": r["family"], "launches_sampled": r["n"], "launches_per_step": r["n"] * stride / steps,
+                     "avg_launch_us": 1e3 * r["ms"] / n, "ms_per_step": r["ms"] * stride / steps,
+                     "algorithmic_bytes_per_launch": r["bytes_8d"] / n, "bytes_moved_by_design_per_launch": r["bytes_design"] / n,
+                     "flops_per_launch": r["flops"] / n,
+                     "achieved_gbs": r["bytes_8d"] / max(r["ms"], 1e-9) / 1e6, "achieved_tflops": r["flops"] / max(r["ms"], 1e-9) / 1e9}
+    return res
+
+
+def roofline_object(name, r, traffic_table, stride):
+    """the bench line's `roofline` for kernel `name`: HBM-bound kernels price SURVEY 8(d)'s algorithmic bytes against 8 TB/s; the
+    dense fp32 GEMM of the heads (hg_gemm*) is MFMA-bound work priced against the 157.3 TFLOP/s fp32-MFMA peak, its byte-side
+    fraction quoted beside it"""
+    mfma = r["family"] == 3
+    o = {"bound": "mfma" if mfma else "hbm", "kernel": name,
+         "achieved": r["achieved_tflops"] if mfma else r["achieved_gbs"],
+         "peak": MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s"}
+    o["frac"] = o["achieved"] / o["peak"]
+    t = traffic_table.get(name) or traffic_table.get(name.split("<")[0]) or {}
+    o["traffic"] = t.get("hbm_bytes_per_launch")
+    o["traffic_kernel"] = (name if name in traffic_table else name.split("<")[0]) if t else None
+    o["algorithmic_bytes_per_launch"] = r["algorithmic_bytes_per_launch"]
+    o["traffic_over_algorithmic"] = (o["traffic"] / r["algorithmic_bytes_per_launch"]) if (o["traffic"] and r["algorithmic_bytes_per_launch"]) else None
+    o["bytes_moved_by_design_per_launch"] = r["bytes_moved_by_design_per_launch"]
+    o["flops_per_launch"] = r["flops_per_launch"]
+    o["hbm_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+    o["mfma_frac"] = r["achieved_tflops"] / (MFMA_F32_PEAK_TFLOPS if r["family"] in (3, 4) else MFMA_BF16_PEAK_TFLOPS)
+    o["launches_per_step"] = r["launches_per_step"]; o["avg_launch_us"] = r["avg_launch_us"]; o["launches_sampled"] = r["launches_sampled"]
+    o["ms_per_step"] = r["ms_per_step"]
+    o["timing"] = ("HIP events on the launch's own stream around every %d-th instrumented launch (convolutions, hg_gemm, GRU cell, BFS "
+                   "replay) of the timed region, minus the elapsed time of an empty event pair" % stride)
+    o["bytes"] = ("SURVEY.md 8(d): e*(Nin*Cin + Nout*Cout) + e*K*Cin*Cout + 8*P, e = 2, P from this step's kernel maps" if r["family"] in (0, 1, 2)
+                  else "SURVEY.md 8(d): operands and outputs once (heads) / 4*nActive + 12*n + 8*S (BFS)")
+    return o
 
 def cpu_baseline_child(config, threads=0):
     """`bench.py --cpu-baseline-only`: the oracle (CPU restatement of the reference step) timed on this host, on a bounded
@@ -201,34 +305,42 @@ def cpu_baseline_child(config, threads=0):
     orc.teacher = True
     leaves = [v for v in orc.p.values() if v.requires_grad] + ([v for v in spk.values() if v.requires_grad] if spk is not None else [])
     opt = torch.optim.AdamW(leaves, lr=cfg.train.optim.lr, weight_decay=cfg.train.optim.weight_decay)   # (model/pipeline.py:738-757)
+    what = "detector" if spk is None else "detector + relation graph + captioner (XE)"
+
+    def one_step():
+        opt.zero_grad(set_to_none=True)
+        d = orc.loss(orc.feed(cpu, 0))
+        loss = d["total_loss"]
+        if spk is not None:   # relation graph + top-down captioner (teacher forcing) + cross-entropy, oracle/speaker_oracle.py
+            import torch.nn.functional as F
+            from oracle import speaker_oracle as spo
+            d.update({k: v for k, v in lang.items() if k not in d})
+            d["lang_len"] = lang["lang_len"]
+            g = spo.graph_module({k[len("graph."):]: v for k, v in spk.items() if k.startswith("graph.")}, d, cfg.model.num_graph_steps,
+                                 cfg.model.num_locals)
+            d.update(g)
+            cp = {k[len("caption."):]: v for k, v in spk.items() if k.startswith("caption.")}
+            out = spo.forward_sample_batch(cp, d, cfg, cfg.model.max_num_proposal, cfg.model.num_locals)
+            logits = out["lang_cap"]
+            tgt = d["lang_ids"].reshape(-1, cfg.data.max_spk_len + 2)[:, 1:logits.shape[1] + 1]
+            good = out["good"]
+            if bool(good.any()):
+                loss = loss + F.cross_entropy(logits[good].reshape(-1, logits.shape[-1]), tgt[good].reshape(-1), ignore_index=0)
+        loss.backward()
+        opt.step()
+
+    # steady state (BASELINE.md section 2 / VERDICT r3): untimed warm-up step(s), then the timed steps
+    for _ in range(CPU_WARMUP_STEPS):
+        one_step()
     t0 = time.time()
-    d = orc.loss(orc.feed(cpu, 0))
-    loss = d["total_loss"]
-    what = "detector"
-    if spk is not None:   # relation graph + top-down captioner (teacher forcing) + cross-entropy, oracle/speaker_oracle.py
-        import torch.nn.functional as F
-        from oracle import speaker_oracle as spo
-        d.update({k: v for k, v in lang.items() if k not in d})
-        d["lang_len"] = lang["lang_len"]
-        g = spo.graph_module({k[len("graph."):]: v for k, v in spk.items() if k.startswith("graph.")}, d, cfg.model.num_graph_steps,
-                             cfg.model.num_locals)
-        d.update(g)
-        cp = {k[len("caption."):]: v for k, v in spk.items() if k.startswith("caption.")}
-        out = spo.forward_sample_batch(cp, d, cfg, cfg.model.max_num_proposal, cfg.model.num_locals)
-        logits = out["lang_cap"]
-        tgt = d["lang_ids"].reshape(-1, cfg.data.max_spk_len + 2)[:, 1:logits.shape[1] + 1]
-        good = out["good"]
-        if bool(good.any()):
-            loss = loss + F.cross_entropy(logits[good].reshape(-1, logits.shape[-1]), tgt[good].reshape(-1), ignore_index=0)
-        what = "detector + relation graph + captioner (XE)"
-    loss.backward()
-    opt.step()
-    dt = time.time() - t0
+    for _ in range(CPU_TIMED_STEPS):
+        one_step()
+    dt = (time.time() - t0) / CPU_TIMED_STEPS
     print(json.dumps({"value": 1.0 / dt, "unit": "scenes/sec", "cores": cores, "kind": "port",
-                      "sample": "1 scene (of the step's %d; %d points) x 1 step, forward+loss+backward+AdamW: %s "
+                      "sample": "1 scene (of the step's %d; %d points) x (%d warm-up + %d timed) steps, forward+loss+backward+AdamW: %s "
                                 "through oracle/ (torch-CPU gather-mm sparse conv and the reference's brute-force ball query on %d "
-                                "threads; BFS / segment ops single-threaded): %.1f s" % (1 if config == "detector" else 4,
-                                                                                         cpu["locs"].shape[0], what, cores, dt)}), flush=True)
+                                "threads; BFS / segment ops single-threaded): %.1f s per step" %
+                                (1 if config == "detector" else 4, cpu["locs"].shape[0], CPU_WARMUP_STEPS, CPU_TIMED_STEPS, what, cores, dt)}), flush=True)
 
 
 def cpu_baseline(config, limit_s=420):
@@ -437,12 +549,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel launch durations measured with HIP events on the launch stream during the timed region
-    prof = {}
-    for fam, name in ((0, "spconv_fwd2_kernel"), (2, "spconv_fwd2_split_kernel"), (1, "spconv_wgrad3_kernel")):   # family 1: every weight-gradient launch (wgrad3; wgrad2 / wide for the remaining shapes)
-        n, ms, by, fl = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0)
-        L.d3_prof_collect(fam, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
-        prof[name] = dict(launches=n.value, total_ms=ms.value, bytes=by.value)   # the sampled launches
+    # per-kernel launch durations measured with HIP events on the launch's own stream during the timed region, priced with
+    # SURVEY.md 8(d)'s algorithmic bytes / flops (the kernel maps' pair counts are this step's own)
+    pairs27 = {}
+    for dname, dd in comp_detail.items():
+        if isinstance(dd, dict) and "pairs27" in dd:
+            for r_, p_ in zip(dd["rows"], dd["pairs27"]):
+                pairs27[int(r_)] = int(p_)
+    kernels = collect_kernel_rooflines(L, args.steps, PROF_STRIDE, pairs27)
     L.d3_prof_enable(0)
     final_loss = float(loss.detach())
 
@@ -469,23 +583,20 @@ def main():
             ME.set_exact(False)
 
     if rank == 0:
-        dom = max(prof, key=lambda k: prof[k]["total_ms"])
-        pd = prof[dom]
-        avg_ms = pd["total_ms"] / max(pd["launches"], 1)
-        achieved = (pd["bytes"] / max(pd["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch of the dominant kernel from the PMC counters (cannot be sampled from inside this
-        # process): the committed rocprofv3 --pmc measurement of this same command (tools/gpu_round.sh)
-        traffic, traffic_src, traffic_stale = None, None, None
+        # HBM traffic per launch from the PMC counters (cannot be sampled from inside this process): the committed rocprofv3 --pmc
+        # measurement of this same command (tools/gpu_round.sh -> tools/pmc_traffic.py), per kernel instance
+        traffic_table, traffic_src, traffic_stale = {}, None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             pmc = pmc.get(config, pmc)
-            traffic = pmc[dom]["hbm_bytes_per_launch"]
+            traffic_table = {k: v for k, v in pmc.items() if isinstance(v, dict)}
             measured_on = pmc.get("code_sha")
             traffic_stale = measured_on != code_sha()      # measured on another state of bench.py / csrc: quoted, but flagged
-            traffic_src = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command; (2*FETCH+WRITE)*1024); "
-                           "measured on code %s, this is %s" % (measured_on, code_sha()))
+            traffic_src = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command in separate passes; "
+                           "(2*FETCH+WRITE)*1024 per MI355X_MICROARCH.md); measured on code %s, this is %s" % (measured_on, code_sha()))
         except Exception:
             pass
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         workload = {
             "speaker": "BASELINE configs[2]: PipelineNet mode 1 (PointGroup detector -> relation graph -> top-down captioner, "
                        "XE), conf/pointgroup_captioning.yaml: %d scenes/GPU/step (40-box synthetic ScanNet scenes, 200x150x100 "
@@ -515,19 +626,33 @@ def main():
                        "setup": "1 untimed dry-run step (workspace allocation, code-object loads) + %d untimed settle steps (a fresh "
                                 "box reaches its sustained rate only after some tens of steps) before the --warmup steps" % settle_steps},
             "final_loss": final_loss, "fp32_exact": fp32,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                         "algorithmic_bytes_per_launch": pd["bytes"] / max(pd["launches"], 1),
-                         "launches_per_step": pd["launches"] * PROF_STRIDE / args.steps, "avg_launch_us": avg_ms * 1e3,
-                         "launches_sampled": pd["launches"],
-                         "timing": "HIP events on the launch stream around every %d-th convolution launch of the timed "
-                                   "region, minus the elapsed time of an empty event pair" % PROF_STRIDE,
-                         "share_of_step": pd["total_ms"] * PROF_STRIDE / (1e3 * elapsed),
-                         "other": {k: {"launches_per_step": v["launches"] * PROF_STRIDE / args.steps,
-                                       "avg_launch_us": 1e3 * v["total_ms"] / max(v["launches"], 1),
-                                       "achieved": (v["bytes"] / max(v["total_ms"], 1e-9)) / 1e6}
-                                   for k, v in prof.items() if k != dom}},
         }
+        if dom is not None:
+            rf = roofline_object(dom, kernels[dom], traffic_table, PROF_STRIDE)
+            rf["traffic_source"], rf["traffic_stale"] = traffic_src, traffic_stale
+            rf["share_of_step"] = kernels[dom]["ms_per_step"] / (1e3 * elapsed / args.steps)
+            rf["dominant"] = ("the instrumented kernel (rocprofv3 name) with the most time per step; every other instrumented kernel "
+                              "follows in `per_kernel` with the same pricing, most expensive first")
+            # every instrumented kernel, and the family aggregates (all instances of spconv_fwd2_kernel etc.)
+            order = sorted(kernels, key=lambda k: -kernels[k]["ms_per_step"])
+            rf["per_kernel"] = {k: {kk: vv for kk, vv in roofline_object(k, kernels[k], traffic_table, PROF_STRIDE).items()
+                                    if kk in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac", "mfma_frac", "traffic", "traffic_over_algorithmic",
+                                              "algorithmic_bytes_per_launch", "launches_per_step", "avg_launch_us", "ms_per_step")}
+                                for k in order[:24]}
+            fams = {}
+            for k, r in kernels.items():
+                f = fams.setdefault(k.split("<")[0], dict(ms=0.0, by=0.0, fl=0.0, n=0.0))
+                f["ms"] += r["ms_per_step"]; f["n"] += r["launches_per_step"]
+                f["by"] += r["algorithmic_bytes_per_launch"] * r["launches_per_step"]; f["fl"] += r["flops_per_launch"] * r["launches_per_step"]
+            rf["families"] = {k: {"ms_per_step": f["ms"], "launches_per_step": f["n"], "avg_launch_us": 1e3 * f["ms"] / max(f["n"], 1e-9),
+                                  "algorithmic_bytes_per_launch": f["by"] / max(f["n"], 1e-9),
+                                  "achieved_gbs": f["by"] / max(f["ms"], 1e-9) / 1e6, "hbm_frac": f["by"] / max(f["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                  "achieved_tflops": f["fl"] / max(f["ms"], 1e-9) / 1e9,
+                                  "traffic": (traffic_table.get(k) or {}).get("hbm_bytes_per_launch")}
+                              for k, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
+            out["roofline"] = rf
+        else:
+            out["roofline"] = None
         step_ms = 1e3 * elapsed / args.steps
         out["step_roofline"] = {"bound": "hbm", "compulsory_bytes_per_step": comp_bytes, "achieved": comp_bytes / (step_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": comp_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -131,6 +131,7 @@ struct Conv2Args {
     int f32;                        // D3_CONV_F32: fp32 weight fragments, v_mfma_f32_16x16x4_f32 (host-side dispatch only)
     unsigned int xbytes;            // extent of x in bytes for the raw buffer gathers (0: beyond 2 GiB / 2^24 rows, refused for the wave-per-tile kernel)
     unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
+    int interleave;             // wave-per-tile kernel: the workgroups of an XCD take consecutive tile groups in turn (one moving window per L2)
     // BatchNorm-backward epilogue (data gradient of a BN -> ReLU -> conv unit): the stored value is g = dy * relu'(bn(x))
     // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
     const float *bnx; const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
@@ -293,7 +294,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     const int lb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
     const int ntg = (a.ntiles + NW - 1) / NW;
     const int per = (ntg + nb - 1) / nb;
-    const int tg0 = lb * per, tg1 = min(ntg, tg0 + per);
+    // Round 4: with `interleave` the nb / 8 workgroups of an XCD take the XCD's tile groups IN TURN (iteration i of workgroup j:
+    // group xcd_base + i * (nb / 8) + j) instead of one contiguous range each: at any moment the XCD works on ONE window of
+    // (nb / 8) * NW * 16 consecutive rows plus its neighbourhood, which fits its 4 MB L2, where 32 separate windows do not (the
+    // stem gathers 272-byte rows from +-1 x-slab: measured 1032 MB of HBM-side traffic per launch against 245 MB algorithmic).
+    const bool il = a.interleave && (nb & 7) == 0;
+    const int tstride = il ? (nb >> 3) : 1;
+    const int tg0 = il ? (b & 7) * (nb >> 3) * per + (b >> 3) : lb * per;
+    const int tg1 = il ? min(ntg, ((b & 7) + 1) * (nb >> 3) * per) : min(ntg, tg0 + per);
     int v[7];
 #define C2_LOAD_TBL(TILE)                                                                                     \
     {                                                                                                         \
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     if (lane == 0) tblS[C2_TBL_SENT] = -1;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, C2_RSRC_FLAGS);
 
-    for (int tg = tg0; tg < tg1; tg++) {
+    for (int tg = tg0; tg < tg1; tg += tstride) {
         const int tile = tg * NW + wave;
         if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
         const int row0 = tile * 16;
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
             const int e = lane + it * 64;
             if (e < 16 * K) tblS[e] = v[it];
         }
-        if (C2_PREFETCH && tg + 1 < tg1) C2_LOAD_TBL(tile + NW)
+        if (C2_PREFETCH && tg + tstride < tg1) C2_LOAD_TBL(tile + NW * tstride)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -917,6 +925,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     a.ldx = ldx; a.ldo = ldo; a.ldr = ldr; a.Mout = Mout; a.K = K; a.Cout = Cout; a.S = Cin / 8;
     a.inv = (65536u + a.S - 1) / a.S;
     a.invK = (65536u + K - 1) / K;
+    a.interleave = d3_tune(D3T_C2_INTERLEAVE) != 0 ? 1 : 0;
     a.xbf16 = xbf16; a.f32 = f32; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
     {   // the last row of a column view ends after Cin elements; an absent neighbour's offset (2^32 - row bytes + ...) must stay outside
         const unsigned long long elt = xbf16 ? 2ull : 4ull, rowb = (unsigned long long)ldx * elt;

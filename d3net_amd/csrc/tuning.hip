@@ -38,6 +38,8 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_GRU_RT1", 1},              // 0: fused GRU cell with two 16-row tiles per workgroup for 17..64 rows
     {"D3_HG_RT1", 1},               // 0: K-split GEMM with two 16-row tiles per workgroup for 17..32 rows
     {"D3_GRU4", 1},                 // 0: fused GRU cell on 16 hidden units x 3 gate tiles per workgroup (rounds 1-2)
+    {"D3_C2_INTERLEAVE", 1},        // 0: every convolution workgroup walks its own contiguous tile range (rounds 1-3) instead of the XCD's workgroups sweeping one window together
+    {"D3_BN_FUSED_ROWS", 16384},    // BatchNorm over at most this many rows: finalize + apply (forward) / final + apply (backward) in one launch (0: never)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

@@ -301,6 +301,177 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
         }
     }
 }
+// ---- few-row levels (round 4): finalize + apply in ONE launch.
+// Below ~16 k rows every kernel of the BatchNorm chain sits at the launch floor (~5 us for microseconds of work, + ~1.5 us per
+// dependent boundary): conv -> finalize -> apply was three launches per convolution, 160 finalize launches per step.  Here a
+// handful of workgroups each reduce the producer's partial rows themselves (the table is a few hundred KB at most and L2-resident;
+// G <= 32 workgroups re-read it) and then normalise their slice of the rows.  The reduction is a fixed tree -- thread (slice j,
+// channel c) adds rows j, j + S, ... in fp64, the slices are combined in slice order -- so every workgroup derives bit-identical
+// statistics and the result does not depend on G.  Workgroup 0 stores mean / var (the backward reads them) and updates the
+// running statistics.
+#define UN_FS_T 256
+#define UN_FS_MAXC 256
+__device__ __forceinline__ void un_fs_reduce(const StatSrc &s0, const StatSrc &s1, int C, double *acc /* [2][UN_FS_T] */, double &sa, double &sb) {
+    const int t = threadIdx.x;
+    const int S = UN_FS_T / C > 0 ? UN_FS_T / C : 1;
+    const int c = t % C, j = t / C;
+    double a = 0., b = 0.;
+    if (j < S && c < C) {
+        const bool first = (c >= s0.c0 && c < s0.c0 + s0.cn);
+        const float *part = first ? s0.part : s1.part;
+        const int nparts = first ? s0.nparts : s1.nparts, width = first ? s0.width : s1.width, cc = c - (first ? s0.c0 : s1.c0);
+        int r = j;
+        for (; r + 3 * S < nparts; r += 4 * S) {      // four rows in flight
+            float pa[4], pb[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const size_t o = (size_t)(r + q * S) * 2 * width + cc; pa[q] = part[o]; pb[q] = part[o + width]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { a += (double)pa[q]; b += (double)pb[q]; }
+        }
+        for (; r < nparts; r += S) { const size_t o = (size_t)r * 2 * width + cc; a += (double)part[o]; b += (double)part[o + width]; }
+    }
+    acc[t] = a; acc[UN_FS_T + t] = b;
+    __syncthreads();
+    sa = 0.; sb = 0.;
+    if (t < C) for (int q = 0; q < S; q++) { sa += acc[q * C + t]; sb += acc[UN_FS_T + q * C + t]; }
+}
+template <bool BF16>
+__global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, StatSrc s1, const float *__restrict__ x, int ldx,
+                                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                      void *__restrict__ y, int ldy, int M, int C, float eps, int relu,
+                                                                      float *mean_out, float *var_out, float *running_mean, float *running_var,
+                                                                      float momentum, int rows_per_block) {
+    __shared__ double acc[2 * UN_FS_T];
+    __shared__ float4 prm[UN_FS_MAXC];     // (mean, 1/std, gamma, beta)
+    const int t = threadIdx.x;
+    double sa, sb;
+    un_fs_reduce(s0, s1, C, acc, sa, sb);
+    if (t < C) {
+        const double m = sa / (double)M;
+        double v = sb / (double)M - m * m;
+        if (v < 0.) v = 0.;
+        prm[t] = make_float4((float)m, rsqrtf((float)v + eps), gamma[t], beta[t]);
+        if (blockIdx.x == 0) {
+            mean_out[t] = (float)m; var_out[t] = (float)v;
+            if (running_mean) {
+                running_mean[t] = (1.f - momentum) * running_mean[t] + momentum * (float)m;
+                running_var[t] = (1.f - momentum) * running_var[t] + momentum * (float)(v * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+            }
+        }
+    }
+    __syncthreads();
+    const int c4 = C >> 2, rpb = UN_FS_T / c4;
+    if (t >= rpb * c4) return;
+    const int rl = t / c4, c = (t - rl * c4) * 4;
+    float inv[4], ga[4], mu[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const float4 q = prm[c + j]; mu[j] = q.x; inv[j] = q.y; ga[j] = q.z; be[j] = q.w; }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int rb = r0 + rl; rb < r1; rb += rpb * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = rb + u * rpb;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = rb + u * rpb;
+            if (row >= r1) continue;
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float r = fmaf((in[j] - mu[j]) * inv[j], ga[j], be[j]);
+                o[j] = (relu && r < 0.f) ? 0.f : r;
+            }
+            if (BF16) *(uint2 *)((unsigned short *)y + (long long)row * ldy + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));
+            else *(float4 *)((float *)y + (long long)row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+// backward twin: sum g / sum g*xhat from the data gradient's epilogue partials (width C) -> sums, dgamma / dbeta (workgroup 0),
+// then dx = gamma*inv*(g - mean(g) - xhat*mean(g*xhat)) for this workgroup's rows (the arithmetic of un_bn_bwd_apply_kernel)
+template <bool OBF>
+__global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ x, int ldx,
+                                                                          const float *__restrict__ dy, int ldy, const float *__restrict__ mean,
+                                                                          const float *__restrict__ var, const float *__restrict__ gamma,
+                                                                          const float *__restrict__ beta, float *sums, float *dgamma, float *dbeta,
+                                                                          int paccum, float *__restrict__ dx, int ldo, int M, int C, float eps,
+                                                                          int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block) {
+    __shared__ double acc[2 * UN_FS_T];
+    __shared__ float2 sm[UN_FS_MAXC];
+    const int t = threadIdx.x;
+    double sa, sb;
+    const StatSrc s0{part, nparts, C, 0, C};
+    un_fs_reduce(s0, s0, C, acc, sa, sb);
+    if (t < C) {
+        sm[t] = make_float2((float)sa, (float)sb);
+        if (blockIdx.x == 0) {
+            sums[t] = (float)sa; sums[C + t] = (float)sb;
+            if (dbeta) dbeta[t] = (paccum ? dbeta[t] : 0.f) + (float)sa;
+            if (dgamma) dgamma[t] = (paccum ? dgamma[t] : 0.f) + (float)sb;
+        }
+    }
+    __syncthreads();
+    if (dx == nullptr) return;
+    const int c4 = C >> 2, rpb = UN_FS_T / c4;
+    if (t >= rpb * c4) return;
+    const int rl = t / c4, c = (t - rl * c4) * 4;
+    const float invM = 1.f / (float)M;
+    float inv[4], ga[4], mu[4], be[4], mg[4], mgx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        inv[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; mu[j] = mean[c + j]; be[j] = beta[c + j];
+        mg[j] = sm[c + j].x * invM; mgx[j] = sm[c + j].y * invM;
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int rb = r0 + rl; rb < r1; rb += rpb * UN_AP_U) {
+        float4 xv[UN_AP_U], gv[UN_AP_U], ov[UN_AP_U];
+#pragma unroll
+        for (int u = 0; u < UN_AP_U; u++) {
+            const int row = rb + u * rpb;
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
+            if (row < r1) {
+                xv[u] = *(const float4 *)(x + (long long)row * ldx + c);
+                gv[u] = *(const float4 *)(dy + (long long)row * ldy + c);
+                if (!OBF && accum) ov[u] = *(const float4 *)(dx + (long long)row * ldo + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN_AP_U; u++) {
+            const int row = rb + u * rpb;
+            if (row >= r1) continue;
+            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gi[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float xh = (xi[j] - mu[j]) * inv[j];
+                float g = gi[j];
+                if (relu && fmaf(xh, ga[j], be[j]) <= 0.f) g = 0.f;
+                o[j] = old[j] + ga[j] * inv[j] * (g - mg[j] - xh * mgx[j]);
+            }
+            if (OBF) *(uint2 *)((unsigned short *)dx + (long long)row * ldo + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));
+            else *(float4 *)(dx + (long long)row * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (!OBF && shadow) *(uint2 *)(shadow + (long long)row * C + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));
+        }
+    }
+}
+// workgroups / rows per workgroup of the fused few-row kernels: ~16 k elements per workgroup, at most 32 workgroups
+static inline void un_fs_grid(int M, int C, int &G, int &rows_per_block) {
+    long long g = ((long long)M * C + 16383) / 16384;
+    if (g < 1) g = 1;
+    if (g > 32) g = 32;
+    const int rpb = UN_FS_T / (C >> 2);                   // rows per pass
+    int rows = (int)((M + g - 1) / g);
+    rows = (rows + rpb - 1) / rpb * rpb;
+    if (rows < rpb) rows = rpb;
+    rows_per_block = rows;
+    G = (M + rows - 1) / rows;
+}
+
 __global__ void un_add_kernel(float *__restrict__ dst, int ldd, const float *__restrict__ src, int lds, long long M, int C, int copy) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4 = C >> 2;
@@ -888,6 +1059,19 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                     const OpD &p = n->ops[r.op];
                     ss[q] = StatSrc{(const float *)(arena + p.part_off), p.nparts, p.partw, r.c0, r.cn};
                 }
+                const int fs_rows = d3_tune(D3T_BN_FUSED_ROWS);
+                if (M > 0 && M <= fs_rows && C <= UN_FS_MAXC && !(o.fin_by >= 0 && M <= n->lb_rows)) {
+                    // few rows: statistics + normalisation in one launch (un_bn_fused_small_kernel)
+                    int G, rows_pb; un_fs_grid(M, C, G, rows_pb);
+                    float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
+                    if (to.dtype == 1)
+                        un_bn_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
+                                                                             tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb);
+                    else
+                        un_bn_fused_small_kernel<false><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
+                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb);
+                    continue;
+                }
                 if (M > 0 && !(o.fin_by >= 0 && M <= n->lb_rows))
                     un_bn_finalize_kernel<<<(C + 3) / 4, 256, 0, s>>>(ss[0], ss[1], M, C, mean, var,
                                                                    o.rmean >= 0 ? (float *)params[o.rmean] : nullptr,
@@ -1103,6 +1287,25 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
+            if (o.fused_by >= 0 && M > n->lb_rows && M <= d3_tune(D3T_BN_FUSED_ROWS) && C <= UN_FS_MAXC) {
+                // few rows: the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
+                int G, rows_pb; un_fs_grid(M, C, G, rows_pb);
+                float *gi = nullptr; int ldgi = 0, root_i = -1, gibf = 0;
+                if (o.in_grad_mode) {
+                    gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
+                    if (root_i >= 0) wait_pending(root_i);
+                }
+                unsigned short *sh = (o.in_grad_mode && o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
+                if (!o.in_grad_mode) G = 1;
+                if (gibf)
+                    un_bn_bwd_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, var, gamma, beta,
+                                                                             sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, ldgi, M, C, o.eps, 0, 0, nullptr, rows_pb);
+                else
+                    un_bn_bwd_fused_small_kernel<false><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, var, gamma, beta,
+                                                                              sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, ldgi, M, C, o.eps, 0,
+                                                                              o.in_grad_mode == 2 ? 1 : 0, sh, rows_pb);
+                continue;
+            }
             if (o.fused_by >= 0) {   // reductions (and the ReLU mask) done by the consumer conv's data gradient
                 if (M > n->lb_rows)
                     un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,

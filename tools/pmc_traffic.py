@@ -9,18 +9,22 @@ import sys
 from collections import defaultdict
 
 acc = defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+inst = defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})     # per template instance (rocprofv3's kernel name)
 for path in sys.argv[1:3]:
     for line in list(open(path))[1:]:
         # kernel names contain commas (template arguments): the four numeric / counter fields are the last four
         name, counter, launches, _mean, total = line.rstrip("\n").rsplit(",", 4)
         base = name.split("<")[0].strip('"').replace("void ", "")
+        full = name.strip('"').replace("void ", "")
+        b = inst[full][counter]
+        b[0] += int(launches); b[1] += float(total)
         if base in ("spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel"):   # bench.py's weight-gradient family
             base = "spconv_wgrad3_kernel"
         a = acc[base][counter]
         a[0] += int(launches); a[1] += float(total)
 out = {}
 for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel",
-          "un_bn_bwd_apply_kernel", "hg_gemm_kernel", "cl_push_kernel", "bq_scan_kernel"):
+          "un_bn_bwd_apply_kernel", "hg_gemm_kernel", "hg_gemm_tiled_kernel", "td_gru4_fwd_kernel", "cl_push_kernel", "bq_scan_kernel"):
     if k not in acc:
         continue
     f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
@@ -32,6 +36,16 @@ for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kerne
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_round.sh), bench.py --steps 2 "
                       "--warmup 1 (the bench default workload unless the file name says otherwise); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B "
                       "per 128-B request: MI355X_MICROARCH.md HBM section)"}
+BASES = ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel",
+         "hg_gemm_kernel", "hg_gemm_tiled_kernel", "td_gru4_fwd_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel", "un_bn_bwd_apply_kernel")
+for full, v in inst.items():
+    if full in out or full.split("<")[0] not in BASES:
+        continue
+    f, w = v["FETCH_SIZE"], v["WRITE_SIZE"]
+    if not f[0] or not w[0]:
+        continue
+    fk, wk = f[1] / f[0], w[1] / w[0]
+    out[full] = {"launches_sampled": f[0], "fetch_kib_per_launch": fk, "write_kib_per_launch": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
 # stamp: the state of bench.py + csrc this was measured on (bench.py prints traffic_stale when it differs)
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
