@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--settle", type=int, default=SETTLE_STEPS,
                     help="untimed steps between the dry pass and the --warmup steps (a fresh box reaches its sustained rate after some tens of steps)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the untimed exact-fp32 (reference precision) steps")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the untimed 8-scene / 1-scene steps behind `strong_scaling_ceiling`")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-teacher", action="store_true", help="cluster on the network's own predictions")
@@ -254,9 +255,8 @@ def roofline_object(name, r, traffic_table, stride):
          "achieved": r["achieved_tflops"] if mfma else r["achieved_gbs"],
          "peak": MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s"}
     o["frac"] = o["achieved"] / o["peak"]
-    t = traffic_table.get(name) or traffic_table.get(name.split("<")[0]) or {}
+    t = traffic_table.get(name) or {}          # (exact instance only: a family average next to one instance's bytes would mislead)
     o["traffic"] = t.get("hbm_bytes_per_launch")
-    o["traffic_kernel"] = (name if name in traffic_table else name.split("<")[0]) if t else None
     o["algorithmic_bytes_per_launch"] = r["algorithmic_bytes_per_launch"]
     o["traffic_over_algorithmic"] = (o["traffic"] / r["algorithmic_bytes_per_launch"]) if (o["traffic"] and r["algorithmic_bytes_per_launch"]) else None
     o["bytes_moved_by_design_per_launch"] = r["bytes_moved_by_design_per_launch"]
@@ -582,6 +582,40 @@ def main():
         finally:
             ME.set_exact(False)
 
+    # strong-scaling ceiling of ONE GPU's step: the 8-scene global batch of `--scaling strong` on this GPU
+    # against one scene per step -- what 8 ranks with 1 scene each can gain at best before any link is involved
+    ceiling = None
+    if not dist_on and not args.no_ceiling and not args.exact and config in ("speaker", "listener") and args.scaling == "weak" and not args.small:
+        try:
+            def timed(scene_list, k=10, warm=6):
+                b = S.make_batch(scene_list, dev)
+                b = S.add_language(b, dev, chunk=chunk, vocab=VOCAB)
+                if config in ("speaker", "joint"):
+                    b["lang_len"] = b["spk_lang_len"]
+                l2 = S.add_language(S.make_batch(scene_list, dev), dev, chunk=chunk, vocab=VOCAB, seed=9) if config == "joint" else None
+
+                def one():
+                    model.zero_grad(set_to_none=True)
+                    loss_, _ = model.training_step([dict(b), dict(l2)] if config == "joint" else dict(b))
+                    loss_.backward()
+                    opt.step()
+                for _ in range(warm):
+                    one()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    one()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t1) / k
+            sc8 = make_scenes(config, 0, False, list(range(STRONG_GLOBAL_BATCH)))
+            t8 = timed(sc8)
+            t1s = timed(sc8[:1])
+            ceiling = {"t_8_scenes_ms": t8, "t_1_scene_ms": t1s, "ratio": t8 / t1s,
+                       "what": "ms per step of this config with the strong-scaling global batch (8 scenes) on ONE GPU / with 1 scene: the best "
+                               "speed-up 8 ranks x 1 scene can reach before communication (10 timed steps each after 6 warm-up steps)"}
+        except Exception as e:      # (never lose the bench line over the side measurement)
+            ceiling = {"error": repr(e)[:200]}
+
     if rank == 0:
         # HBM traffic per launch from the PMC counters (cannot be sampled from inside this process): the committed rocprofv3 --pmc
         # measurement of this same command (tools/gpu_round.sh -> tools/pmc_traffic.py), per kernel instance
@@ -625,7 +659,7 @@ def main():
                                      "fp32 residual stream, bf16 BN->ReLU activations and MFMA operands, fp32 accumulate; heads fp32"),
                        "setup": "1 untimed dry-run step (workspace allocation, code-object loads) + %d untimed settle steps (a fresh "
                                 "box reaches its sustained rate only after some tens of steps) before the --warmup steps" % settle_steps},
-            "final_loss": final_loss, "fp32_exact": fp32,
+            "final_loss": final_loss, "fp32_exact": fp32, "strong_scaling_ceiling": ceiling,
         }
         if dom is not None:
             rf = roofline_object(dom, kernels[dom], traffic_table, PROF_STRIDE)

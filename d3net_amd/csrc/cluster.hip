@@ -891,6 +891,8 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     B2_TDUMP
 }
 
+__global__ void cl_prof_total_kernel(const int *estart, const int *klen, int n, double *out) { *out = (double)estart[n - 1] + (double)klen[n - 1]; }
+
 extern "C" size_t d3_bfs_cluster_erec_bytes(long long nActive) { return (size_t)(nActive > 0 ? nActive : 1) * sizeof(int4); }
 
 // d3_bfs_cluster_fill with the record-form level loop; erec: d3_bfs_cluster_erec_bytes(nActive) bytes of scratch
@@ -926,11 +928,15 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         cl_ninfo_kernel<<<nb, T, 0, s>>>(w.own, w.lid, w.estart, start_len, w.ninfo, n);
         cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.ninfo, w.estart, (int4 *)erec, n);
         const bool debug = d3_tune(D3T_BFS_DEBUG) != 0;
-        // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S
-        void *pr = d3_prof_begin(5, 4.0 * (double)nActive + 12.0 * (double)n + 8.0 * (double)sumNPoint, 0.0, s);
+        // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S, nActive = the list entries of the kept
+        // clusters' nodes (what the replay streams; the padded lists' capacity says nothing) -- known on the device only
+        void *pr = d3_prof_begin(5, 12.0 * (double)n + 8.0 * (double)sumNPoint, 0.0, s);
         cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
                                                         w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
-        if (pr) { d3_prof_tag(pr, 0, n); d3_prof_tag(pr, 1, nCluster); d3_prof_end(pr, s); }
+        if (pr) {
+            d3_prof_tag(pr, 0, n); d3_prof_tag(pr, 1, nCluster); d3_prof_end(pr, s);
+            if (double *slot = d3_prof_dev_slot(pr, 4.0)) cl_prof_total_kernel<<<1, 1, 0, s>>>(w.estart, w.klen, n, slot);   // (behind the bracket)
+        }
         if (debug) {
             int h[60 + 160];
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);

@@ -11,3 +11,7 @@ void *d3_prof_begin(int family, double bytes, double flops, hipStream_t s);
 void d3_prof_end(void *rec, hipStream_t s);
 // shape / kernel-instance tags of a record (no-op on NULL): convolutions {Min, Mout, K, Cin, Cout, NT, WLDS, XBF, NW, F32M, KT, ST}
 void d3_prof_tag(void *rec, int idx, int value);
+// a device-side value the record's byte count depends on (BFS: the number of edge records actually streamed is known only on
+// the device): returns a device pointer to one double the caller's kernel fills (NULL: no slot); d3_prof_dump folds
+// `bytes += scale * value` into the record when it resolves it
+double *d3_prof_dev_slot(void *rec, double scale);

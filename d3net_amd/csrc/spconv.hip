@@ -35,12 +35,16 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
 // When enabled, every MFMA convolution launch is bracketed by two HIP events on its own stream and tagged
 // with its algorithmic byte / flop count; d3_prof_collect() resolves them after the timed region.
 #include <deque>
-struct ProfRec { hipEvent_t a, b; int family; double bytes, flops; int tag[D3_PROF_TAGS]; };
+#include <vector>
+struct ProfRec { hipEvent_t a, b; int family; double bytes, flops; int tag[D3_PROF_TAGS]; int dev_slot; double dev_scale; };
 static std::deque<ProfRec> g_prof;   // stable element addresses
 static size_t g_prof_used = 0;
 static int g_prof_on = 0;
 #define PROF_MAX 200000
 
+#define PROF_DEV_SLOTS 4096
+static double *g_prof_dev = nullptr;
+static int g_prof_dev_used = 0;
 static int g_prof_stride = 1;
 static unsigned long long g_prof_seq = 0;
 // on = 0: off; on = n >= 1: bracket every n-th convolution launch (an event pair is a queue barrier plus a timestamp
@@ -52,6 +56,7 @@ extern "C" int d3_prof_enable(int on) {
     g_prof_stride = on > 1 ? on : 1;
     g_prof_used = 0;
     g_prof_seq = 0;
+    g_prof_dev_used = 0;
     return 0;
 }
 #include <mutex>
@@ -68,12 +73,22 @@ static ProfRec *prof_begin(int family, double bytes, double flops, hipStream_t s
     ProfRec *r = &g_prof[g_prof_used++];
     r->family = family; r->bytes = bytes; r->flops = flops;
     for (int i = 0; i < D3_PROF_TAGS; i++) r->tag[i] = 0;
+    r->dev_slot = -1; r->dev_scale = 0.0;
     hipEventRecord(r->a, s);
     return r;
 }
 static void prof_end(ProfRec *r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 void *d3_prof_begin(int family, double bytes, double flops, hipStream_t s) { return prof_begin(family, bytes, flops, s); }
 void d3_prof_end(void *rec, hipStream_t s) { prof_end((ProfRec *)rec, s); }
+double *d3_prof_dev_slot(void *rec, double scale) {
+    if (!rec) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_dev && hipMalloc((void **)&g_prof_dev, PROF_DEV_SLOTS * sizeof(double)) != hipSuccess) { g_prof_dev = nullptr; return nullptr; }
+    if (g_prof_dev_used >= PROF_DEV_SLOTS) return nullptr;
+    ProfRec *r = (ProfRec *)rec;
+    r->dev_slot = g_prof_dev_used++; r->dev_scale = scale;
+    return g_prof_dev + r->dev_slot;
+}
 void d3_prof_tag(void *rec, int idx, int value) { if (rec && idx >= 0 && idx < D3_PROF_TAGS) ((ProfRec *)rec)->tag[idx] = value; }
 // family: 0 = spconv_fwd2 / spconv_fwd_mfma (forward + data gradient), 1 = weight gradient, 2 = spconv_fwd2_split.
 // The elapsed time of an EMPTY event pair on the same stream (median of 32) is subtracted from every sample: it is the
@@ -126,6 +141,8 @@ extern "C" int d3_prof_dump(int family, double *rows, int cap, int *n) {
     hipEventDestroy(ea); hipEventDestroy(eb);
     int k = 0;
     const int W = 3 + D3_PROF_TAGS;
+    std::vector<double> devv((size_t)(g_prof_dev_used > 0 ? g_prof_dev_used : 1), 0.0);
+    if (g_prof_dev && g_prof_dev_used > 0) D3_CHECK(hipMemcpy(devv.data(), g_prof_dev, (size_t)g_prof_dev_used * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < g_prof_used; i++) {
         ProfRec &r = g_prof[i];
         if (r.family != family) continue;
@@ -136,7 +153,7 @@ extern "C" int d3_prof_dump(int family, double *rows, int cap, int *n) {
             double d = (double)ms - empty_ms;
             if (d < 0.0005) d = 0.0005;
             double *o = rows + (size_t)k * W;
-            o[0] = d; o[1] = r.bytes; o[2] = r.flops;
+            o[0] = d; o[1] = r.bytes + (r.dev_slot >= 0 ? r.dev_scale * devv[(size_t)r.dev_slot] : 0.0); o[2] = r.flops;
             for (int t = 0; t < D3_PROF_TAGS; t++) o[3 + t] = (double)r.tag[t];
         }
         k++;
