@@ -133,6 +133,38 @@ extern "C" int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_
     return 0;
 }
 
+// ---- 16-bit form of a K = 27 neighbour table (round 4).  A stride-1 table is read by the forward, the data gradient and the
+// weight gradient of every convolution of its level (33 launches at level 0 of the backbone): 108 bytes per row each time.
+// Neighbours of row u sit near u in any spatially coherent row order, so the entries are stored as int16 deltas nbr - u
+// (54 bytes per row; -32768 = absent).  *ok16 = 1 when every delta fits; otherwise the consumers keep the dense table.
+// nbr16 holds M * 27 shorts (+ 2 pad shorts: the kernels read it in 32-bit words).
+__global__ void cm_pack16_kernel(const int *__restrict__ nbr, long long total, short *__restrict__ nbr16, int *ok16) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (e < total) {
+        const int v = nbr[e];
+        int d = -32768;
+        if (v >= 0) {
+            d = v - (int)(e / 27);
+            if (d < -32767 || d > 32767) { bad = true; d = -32768; }
+        }
+        nbr16[e] = (short)d;
+    } else if (e < total + 2) nbr16[e] = (short)-32768;
+    if (__any(bad) && (threadIdx.x & 63) == 0) *ok16 = 0;
+}
+__global__ void cm_set1_kernel(int *p) { *p = 1; }
+extern "C" int d3_kmap_k3_pack16(const int *nbr, int M, void *nbr16, int *ok16, void *stream) {
+    D3_CLEAR();
+    if (M <= 0) return 0;
+    if (!nbr || !nbr16 || !ok16) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    const long long total = (long long)M * 27;
+    cm_set1_kernel<<<1, 1, 0, s>>>(ok16);
+    cm_pack16_kernel<<<(int)((total + 2 + 255) / 256), 256, 0, s>>>(nbr, total, (short *)nbr16, ok16);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void cm_flag_kernel(const int *first, const int *slot_of, int *flag, int M) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) flag[i] = (first[slot_of[i]] == i) ? 1 : 0;

@@ -132,6 +132,8 @@ struct Conv2Args {
     unsigned int xbytes;            // extent of x in bytes for the raw buffer gathers (0: beyond 2 GiB / 2^24 rows, refused for the wave-per-tile kernel)
     unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
     int interleave;             // wave-per-tile kernel: the workgroups of an XCD take consecutive tile groups in turn (one moving window per L2)
+    const unsigned int *tbl16;  // optional 16-bit delta form of tbl (coordmap.hip cm_pack16_kernel; validated by the caller), read as 32-bit
+                                // words by the T16 instances of the wave-per-tile kernel
     // BatchNorm-backward epilogue (data gradient of a BN -> ReLU -> conv unit): the stored value is g = dy * relu'(bn(x))
     // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
     const float *bnx; const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
@@ -274,8 +276,9 @@ __device__ __forceinline__ void c2_wload(const unsigned short *Wb, int e, uint4 
 // KT / ST > 0: kernel size and slots per offset (Cin / 8) known at compile time (round 3: the shapes that carry the step -- K = 27
 // with 16 / 32 / 64 input channels): the reduction loop is fully unrolled and every (offset, channel group) of a step is a
 // constant per lane group -- the ~10 index instructions in front of each gather fold away.
-template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false, int KT = 0, int ST = 0>
+template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false, int KT = 0, int ST = 0, bool T16 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
+    static_assert(!T16 || KT == 27, "the 16-bit kernel map is read by the statically shaped K = 27 instances");
     static_assert(!(F32M && XBF), "fp32 MFMA needs fp32 gathers");
     static_assert((KT > 0) == (ST > 0), "static shapes fix both the kernel size and the channel groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -303,14 +306,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     const int tg0 = il ? (b & 7) * (nb >> 3) * per + (b >> 3) : lb * per;
     const int tg1 = il ? min(ntg, ((b & 7) + 1) * (nb >> 3) * per) : min(ntg, tg0 + per);
     int v[7];
+    // 16-bit table (round 4): entries (2d, 2d + 1) of the tile travel as ONE 32-bit word d = lane + it * 64 < 8 K; v[0..3] hold the
+    // raw words, the LDS store decodes them (row + delta; 0x8000 = absent).  K is odd: the word that straddles the end of the
+    // table's last row reads one of the two pad entries behind it.
+    constexpr bool t16 = T16;                                  // (the host validated the table: d3_spconv_next_tbl16)
 #define C2_LOAD_TBL(TILE)                                                                                     \
     {                                                                                                         \
         const int tile_ = (TILE);                                                                             \
         const long long base_ = (long long)tile_ * 16 * K, lim_ = (long long)a.Mout * K;                      \
+        if constexpr (t16) {                                                                                  \
+            _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                \
+                const int d = lane + it * 64;                                                                 \
+                v[it] = (int)0x80008000u;                                                                     \
+                if (tile_ < a.ntiles && d < 8 * K && base_ + 2 * d < lim_) v[it] = (int)a.tbl16[(base_ >> 1) + d]; \
+            }                                                                                                 \
+        } else {                                                                                              \
         _Pragma("unroll") for (int it = 0; it < 7; it++) {                                                    \
             const int e = lane + it * 64;                                                                     \
             v[it] = -1;                                                                                       \
             if (tile_ < a.ntiles && e < 16 * K && base_ + e < lim_) v[it] = a.tbl ? a.tbl[base_ + e] : (int)(base_ + e); \
+        }                                                                                                     \
         }                                                                                                     \
     }
     if (C2_PREFETCH) C2_LOAD_TBL(tg0 * NW + wave)
@@ -351,10 +366,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
         if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
         const int row0 = tile * 16;
         if (!C2_PREFETCH) C2_LOAD_TBL(tile)
+        if constexpr (t16) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int d = lane + it * 64;
+                if (d < 8 * K) {
+                    const int e0 = 2 * d, e1 = e0 + 1;
+                    const int lo = (int)(short)(v[it] & 0xFFFF), hi = v[it] >> 16;          // (arithmetic shift: sign-extended)
+                    const int u0 = e0 / (KT ? KT : 1), u1 = e1 / (KT ? KT : 1);
+                    // (entries behind the table's end are absent already: words not loaded are 0x80008000 and the one word
+                    // that straddles the end carries a pad entry, which cm_pack16_kernel wrote as absent)
+                    tblS[e0] = lo == -32768 ? -1 : row0 + u0 + lo;
+                    tblS[e1] = hi == -32768 ? -1 : row0 + u1 + hi;
+                }
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < 7; it++) {
             const int e = lane + it * 64;
             if (e < 16 * K) tblS[e] = v[it];
+        }
         }
         if (C2_PREFETCH && tg + tstride < tg1) C2_LOAD_TBL(tile + NW * tstride)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -800,6 +831,9 @@ static bool c2_attr_needed(bool *done) {
     return true;
 }
 
+#include <atomic>
+static std::atomic<long long> g_t16_launches{0};       // launches that read a 16-bit kernel map (tests: the path really ran)
+extern "C" long long d3_spconv_t16_launches(void) { return g_t16_launches.load(); }
 // template arguments of the instance the last launch_fwd2* call of this thread ran: {NT, WLDS, XBF, NW, F32M, KT, ST} for
 // spconv_fwd2_kernel, {NTW, XBF, F32M} for spconv_fwd2_split_kernel -- the profiling record names the kernel as rocprofv3 prints it
 static thread_local int g_c2_inst[7];
@@ -831,6 +865,15 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
     if (c2_attr_needed(attr_done_dev))
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c2_inst(NT, 1, 1, NW, 0, 27, ST);
+    if (a.tbl16) {
+        static bool attr16_done_dev[64] = {false};
+        if (c2_attr_needed(attr16_done_dev))
+            D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST, true><<<p.grid, 64 * NW, p.lds, s>>>(a);
+        g_t16_launches++;
+        D3_LAUNCH_CHECK();
+        return 0;
+    }
     spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST><<<p.grid, 64 * NW, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
@@ -904,6 +947,10 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
     return 0;
 }
 
+static thread_local const void *g_next_tbl16 = nullptr;
+static thread_local const int *g_next_ok16 = nullptr;
+void d3_spconv_next_tbl16(const void *tbl16, const int *ok16) { g_next_tbl16 = tbl16; g_next_ok16 = ok16; }
+
 struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; };
 struct Conv2Fin { int *counter; int mode, M, accum; float *a, *b, *c, *d; float momentum; };
 
@@ -911,6 +958,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
                      float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, const Conv2Fin *fin,
                      void *stream) {
     D3_CLEAR();
+    const void *tbl16 = g_next_tbl16; const int *ok16 = g_next_ok16;      // the hint belongs to THIS call, whatever it does with it
+    g_next_tbl16 = nullptr; g_next_ok16 = nullptr;
     if (Mout <= 0) return 0;
     if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -926,6 +975,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     a.inv = (65536u + a.S - 1) / a.S;
     a.invK = (65536u + K - 1) / K;
     a.interleave = d3_tune(D3T_C2_INTERLEAVE) != 0 ? 1 : 0;
+    a.tbl16 = (tbl && tbl16 && K == 27 && !f32 && xbf16) ? (const unsigned int *)tbl16 : nullptr;   // (only the static instances launch with it)
+    (void)ok16;
     a.xbf16 = xbf16; a.f32 = f32; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
     {   // the last row of a column view ends after Cin elements; an absent neighbour's offset (2^32 - row bytes + ...) must stay outside
         const unsigned long long elt = xbf16 ? 2ull : 4ull, rowb = (unsigned long long)ldx * elt;
@@ -1433,6 +1484,7 @@ struct Wg3Args {
     int Ms, Cs8, cpw, flipk, Cin, Cout, K;
     unsigned int invs;                     // ceil(65536 / Cs8)
     int rss, dss, imgs;                    // stationary image (wg2_img)
+    const void *tbl16; const int *ok16; unsigned int t16bytes;   // optional 16-bit delta form of tbl (KV = 27; see spconv_fwd2_kernel)
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -1468,7 +1520,9 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
     const int lbg = gs_off + wg2_lane_base(RSBG, DG, r, g), lbs = wg2_lane_base(a.rss, a.dss, r, g);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.G, 0, a.gbytes, WG3_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Sm, 0, a.sbytes, WG3_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)a.tbl, 0, a.tbytes, WG3_RSRC_FLAGS);
+    const bool t16 = KV == 27 && a.tbl16 != nullptr;      // (uniform; validated by the caller)
+    const __amdgpu_buffer_rsrc_t rt = t16 ? __builtin_amdgcn_make_buffer_rsrc((void *)a.tbl16, 0, a.t16bytes, WG3_RSRC_FLAGS)
+                                          : __builtin_amdgcn_make_buffer_rsrc((void *)a.tbl, 0, a.tbytes, WG3_RSRC_FLAGS);
     const int nit = (a.Ms + 32 * S - 1) / (32 * S);
     const int it_begin = blockIdx.x * a.cpw, it_end = min(nit, it_begin + a.cpw);
     const int k0 = blockIdx.y * (NW * OW) + wave;                      // this wave's offsets: k0 + j * NW
@@ -1500,14 +1554,29 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
     for (int q = 0; q < MT; q++) { const int unit = lane + q * 64; g_row[q] = unit / CG8; g_c8[q] = unit - g_row[q] * CG8; }
 
     int tv[TL];
+    int erow[TL];                     // row (inside the iteration's 32 * S rows) of this thread's i-th kernel-map entry
+#pragma unroll
+    for (int i = 0; i < TL; i++) erow[i] = (t + i * NTH) / KV;
     u32x4_t sv[SU][SE];
     auto prefetch = [&](int it) {
         const unsigned int row0 = (unsigned int)it * (32 * S);
+        if (t16) {
+#pragma unroll
+            for (int i = 0; i < TL; i++) {
+                const int e = t + i * NTH;
+                tv[i] = 0;
+                if (TL * NTH == TE || e < TE) {
+                    const int d = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rt, (row0 * KV + e) * 2u, 0, 0);   // (beyond the table: 0)
+                    tv[i] = d == -32768 ? -1 : (int)row0 + erow[i] + d;
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TL; i++) {
             const int e = t + i * NTH;
             tv[i] = 0;
             if (TL * NTH == TE || e < TE) tv[i] = __builtin_amdgcn_raw_buffer_load_b32(rt, (row0 * KV + e) * 4u, 0, 0);
+        }
         }
 #pragma unroll
         for (int i = 0; i < SU; i++) {
@@ -1924,6 +1993,8 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
                                 int Mout, int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes,
                                 void *stream) {
     D3_CLEAR();
+    const void *tbl16 = g_next_tbl16; const int *ok16 = g_next_ok16;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
+    g_next_tbl16 = nullptr; g_next_ok16 = nullptr;
     if (K < 1 || K > C2_MAXK || Cin < 8 || Cout < 8 || (Cin & 7) || (Cout & 7) || Cin > 224 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
     hipStream_t s = d3_stream(stream);
@@ -1983,6 +2054,8 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         Wg3Args b;
         b.G = a.G; b.Sm = a.Sm; b.tbl = tbl; b.dst = (float *)ws;
         b.gbytes = (unsigned int)gb; b.sbytes = (unsigned int)sb; b.tbytes = (unsigned int)((long long)Ms * K * 4);
+        b.tbl16 = (tbl16 && K == 27) ? tbl16 : nullptr; b.ok16 = ok16; b.t16bytes = (unsigned int)((long long)Ms * K * 2);
+        if (b.tbl16) g_t16_launches++;
         b.growb = a.ldg * (a.gbf16 ? 2 : 4); b.srowb = a.lds * (a.sbf16 ? 2 : 4);
         b.Ms = Ms; b.Cs8 = Cs / 8; b.cpw = p.cpw; b.flipk = a.flipk; b.Cin = CinW; b.Cout = Cout; b.K = K;
         b.invs = a.invs; b.rss = p.rss; b.dss = p.dss; b.imgs = p.imgs;

@@ -40,6 +40,8 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_GRU4", 1},                 // 0: fused GRU cell on 16 hidden units x 3 gate tiles per workgroup (rounds 1-2)
     {"D3_C2_INTERLEAVE", 1},        // 0: every convolution workgroup walks its own contiguous tile range (rounds 1-3) instead of the XCD's workgroups sweeping one window together
     {"D3_BN_FUSED_ROWS", 16384},    // BatchNorm over at most this many rows: finalize + apply (forward) / final + apply (backward) in one launch (0: never)
+    {"D3_KMAP16", 1},               // 0: the executor's K = 27 convolutions read the dense int32 kernel maps only
+    {"D3_HG_BF16X3", 1},            // 0: the tall heads GEMMs on exact fp32 MFMA (hg_gemm_tiled_kernel) instead of the bf16 x 3 split (also forced by minkowski.set_exact)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

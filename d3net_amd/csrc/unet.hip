@@ -311,29 +311,51 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
 // running statistics.
 #define UN_FS_T 256
 #define UN_FS_MAXC 256
-__device__ __forceinline__ void un_fs_reduce(const StatSrc &s0, const StatSrc &s1, int C, double *acc /* [2][UN_FS_T] */, double &sa, double &sb) {
+#define UN_FS_MAX_PART_FLOATS 65536      // producer partial tables beyond this (2 * nparts * C floats) keep the separate finalize launch
+// Per-channel fp64 sums of the producer's partial rows, identical in every workgroup: thread (slice j, channel quad q) adds rows
+// j, j + S, ... (16-byte loads, eight rows in flight), the S slices are combined in slice order.  acc: [S][C][2] doubles (16 KB).
+__device__ __forceinline__ void un_fs_reduce(const StatSrc &s0, const StatSrc &s1, int C, double *acc, double &sa, double &sb) {
     const int t = threadIdx.x;
-    const int S = UN_FS_T / C > 0 ? UN_FS_T / C : 1;
-    const int c = t % C, j = t / C;
-    double a = 0., b = 0.;
-    if (j < S && c < C) {
+    const int C4 = C >> 2, S = UN_FS_T / C4;
+    const int q = t % C4, j = t / C4, c = q * 4;
+    double a[4] = {0., 0., 0., 0.}, b[4] = {0., 0., 0., 0.};
+    if (j < S) {
         const bool first = (c >= s0.c0 && c < s0.c0 + s0.cn);
         const float *part = first ? s0.part : s1.part;
         const int nparts = first ? s0.nparts : s1.nparts, width = first ? s0.width : s1.width, cc = c - (first ? s0.c0 : s1.c0);
         int r = j;
-        for (; r + 3 * S < nparts; r += 4 * S) {      // four rows in flight
-            float pa[4], pb[4];
+        for (; r + 7 * S < nparts; r += 8 * S) {
+            float4 pa[8], pb[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const size_t o = (size_t)(r + q * S) * 2 * width + cc; pa[q] = part[o]; pb[q] = part[o + width]; }
+            for (int u = 0; u < 8; u++) { const float *o = part + (size_t)(r + u * S) * 2 * width + cc; pa[u] = *(const float4 *)o; pb[u] = *(const float4 *)(o + width); }
 #pragma unroll
-            for (int q = 0; q < 4; q++) { a += (double)pa[q]; b += (double)pb[q]; }
+            for (int u = 0; u < 8; u++) {
+                a[0] += (double)pa[u].x; a[1] += (double)pa[u].y; a[2] += (double)pa[u].z; a[3] += (double)pa[u].w;
+                b[0] += (double)pb[u].x; b[1] += (double)pb[u].y; b[2] += (double)pb[u].z; b[3] += (double)pb[u].w;
+            }
         }
-        for (; r < nparts; r += S) { const size_t o = (size_t)r * 2 * width + cc; a += (double)part[o]; b += (double)part[o + width]; }
+        {   // tail: up to seven rows, requested together
+            float4 pa[7], pb[7];
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const int rr = r + u * S;
+                const float *o = part + (size_t)(rr < nparts ? rr : 0) * 2 * width + cc;
+                pa[u] = *(const float4 *)o; pb[u] = *(const float4 *)(o + width);
+            }
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                if (r + u * S < nparts) {
+                    a[0] += (double)pa[u].x; a[1] += (double)pa[u].y; a[2] += (double)pa[u].z; a[3] += (double)pa[u].w;
+                    b[0] += (double)pb[u].x; b[1] += (double)pb[u].y; b[2] += (double)pb[u].z; b[3] += (double)pb[u].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { acc[((size_t)j * C + c + k) * 2] = a[k]; acc[((size_t)j * C + c + k) * 2 + 1] = b[k]; }
     }
-    acc[t] = a; acc[UN_FS_T + t] = b;
     __syncthreads();
     sa = 0.; sb = 0.;
-    if (t < C) for (int q = 0; q < S; q++) { sa += acc[q * C + t]; sb += acc[UN_FS_T + q * C + t]; }
+    if (t < C) for (int k = 0; k < S; k++) { sa += acc[((size_t)k * C + t) * 2]; sb += acc[((size_t)k * C + t) * 2 + 1]; }
 }
 template <bool BF16>
 __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, StatSrc s1, const float *__restrict__ x, int ldx,
@@ -341,39 +363,49 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
                                                                       void *__restrict__ y, int ldy, int M, int C, float eps, int relu,
                                                                       float *mean_out, float *var_out, float *running_mean, float *running_var,
                                                                       float momentum, int rows_per_block) {
-    __shared__ double acc[2 * UN_FS_T];
+    __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float4 prm[UN_FS_MAXC];     // (mean, 1/std, gamma, beta)
     const int t = threadIdx.x;
+    const int c4 = C >> 2, rpb = UN_FS_T / c4;
+    const int rl = t / c4, c = (t - rl * c4) * 4;
+    const bool worker = t < rpb * c4;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    // the first rows of this thread do not depend on the statistics: requested before the reduction, they arrive during it
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = r0 + rl + u * rpb;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (worker && row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
+    }
     double sa, sb;
     un_fs_reduce(s0, s1, C, acc, sa, sb);
     if (t < C) {
         const double m = sa / (double)M;
-        double v = sb / (double)M - m * m;
-        if (v < 0.) v = 0.;
-        prm[t] = make_float4((float)m, rsqrtf((float)v + eps), gamma[t], beta[t]);
+        double vv = sb / (double)M - m * m;
+        if (vv < 0.) vv = 0.;
+        prm[t] = make_float4((float)m, rsqrtf((float)vv + eps), gamma[t], beta[t]);
         if (blockIdx.x == 0) {
-            mean_out[t] = (float)m; var_out[t] = (float)v;
+            mean_out[t] = (float)m; var_out[t] = (float)vv;
             if (running_mean) {
                 running_mean[t] = (1.f - momentum) * running_mean[t] + momentum * (float)m;
-                running_var[t] = (1.f - momentum) * running_var[t] + momentum * (float)(v * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+                running_var[t] = (1.f - momentum) * running_var[t] + momentum * (float)(vv * ((double)M / (double)(M > 1 ? M - 1 : 1)));
             }
         }
     }
     __syncthreads();
-    const int c4 = C >> 2, rpb = UN_FS_T / c4;
-    if (t >= rpb * c4) return;
-    const int rl = t / c4, c = (t - rl * c4) * 4;
+    if (!worker) return;
     float inv[4], ga[4], mu[4], be[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const float4 q = prm[c + j]; mu[j] = q.x; inv[j] = q.y; ga[j] = q.z; be[j] = q.w; }
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int j = 0; j < 4; j++) { const float4 p4 = prm[c + j]; mu[j] = p4.x; inv[j] = p4.y; ga[j] = p4.z; be[j] = p4.w; }
     for (int rb = r0 + rl; rb < r1; rb += rpb * 4) {
-        float4 v[4];
+        if (rb != r0 + rl) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int row = rb + u * rpb;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
+            for (int u = 0; u < 4; u++) {
+                const int row = rb + u * rpb;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -400,9 +432,34 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
                                                                           const float *__restrict__ beta, float *sums, float *dgamma, float *dbeta,
                                                                           int paccum, float *__restrict__ dx, int ldo, int M, int C, float eps,
                                                                           int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block) {
-    __shared__ double acc[2 * UN_FS_T];
+    __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float2 sm[UN_FS_MAXC];
     const int t = threadIdx.x;
+    const int c4 = C >> 2, rpb = UN_FS_T / c4;
+    const int rl = t / c4, c = (t - rl * c4) * 4;
+    const bool worker = dx != nullptr && t < rpb * c4;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float4 xv[UN_AP_U], gv[UN_AP_U], ov[UN_AP_U];
+    auto load = [&](int rb) {
+#pragma unroll
+        for (int u = 0; u < UN_AP_U; u++) {
+            const int row = rb + u * rpb;
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
+            if (worker && row < r1) {
+                xv[u] = *(const float4 *)(x + (long long)row * ldx + c);
+                gv[u] = *(const float4 *)(dy + (long long)row * ldy + c);
+                if (!OBF && accum) ov[u] = *(const float4 *)(dx + (long long)row * ldo + c);
+            }
+        }
+    };
+    load(r0 + rl);          // (independent of the sums: in flight during the reduction)
+    float pinv[4], pga[4], pmu[4], pbe[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { pinv[j] = 0.f; pga[j] = 0.f; pmu[j] = 0.f; pbe[j] = 0.f; }
+    if (worker) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pinv[j] = rsqrtf(var[c + j] + eps); pga[j] = gamma[c + j]; pmu[j] = mean[c + j]; pbe[j] = beta[c + j]; }
+    }
     double sa, sb;
     const StatSrc s0{part, nparts, C, 0, C};
     un_fs_reduce(s0, s0, C, acc, sa, sb);
@@ -415,30 +472,13 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
         }
     }
     __syncthreads();
-    if (dx == nullptr) return;
-    const int c4 = C >> 2, rpb = UN_FS_T / c4;
-    if (t >= rpb * c4) return;
-    const int rl = t / c4, c = (t - rl * c4) * 4;
+    if (!worker) return;
     const float invM = 1.f / (float)M;
-    float inv[4], ga[4], mu[4], be[4], mg[4], mgx[4];
+    float mg[4], mgx[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        inv[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; mu[j] = mean[c + j]; be[j] = beta[c + j];
-        mg[j] = sm[c + j].x * invM; mgx[j] = sm[c + j].y * invM;
-    }
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int j = 0; j < 4; j++) { mg[j] = sm[c + j].x * invM; mgx[j] = sm[c + j].y * invM; }
     for (int rb = r0 + rl; rb < r1; rb += rpb * UN_AP_U) {
-        float4 xv[UN_AP_U], gv[UN_AP_U], ov[UN_AP_U];
-#pragma unroll
-        for (int u = 0; u < UN_AP_U; u++) {
-            const int row = rb + u * rpb;
-            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
-            if (row < r1) {
-                xv[u] = *(const float4 *)(x + (long long)row * ldx + c);
-                gv[u] = *(const float4 *)(dy + (long long)row * ldy + c);
-                if (!OBF && accum) ov[u] = *(const float4 *)(dx + (long long)row * ldo + c);
-            }
-        }
+        if (rb != r0 + rl) load(rb);
 #pragma unroll
         for (int u = 0; u < UN_AP_U; u++) {
             const int row = rb + u * rpb;
@@ -448,10 +488,10 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float xh = (xi[j] - mu[j]) * inv[j];
+                const float xh = (xi[j] - pmu[j]) * pinv[j];
                 float g = gi[j];
-                if (relu && fmaf(xh, ga[j], be[j]) <= 0.f) g = 0.f;
-                o[j] = old[j] + ga[j] * inv[j] * (g - mg[j] - xh * mgx[j]);
+                if (relu && fmaf(xh, pga[j], pbe[j]) <= 0.f) g = 0.f;
+                o[j] = old[j] + pga[j] * pinv[j] * (g - mg[j] - xh * mgx[j]);
             }
             if (OBF) *(uint2 *)((unsigned short *)dx + (long long)row * ldo + c) = make_uint2(un_pack2bf(o[0], o[1]), un_pack2bf(o[2], o[3]));
             else *(float4 *)(dx + (long long)row * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -566,6 +606,8 @@ struct Net {
     // processed op chunk_op[k] (ops run in reverse program order, parameters are registered in program order: a chunk is a
     // contiguous tail range); two events per chunk -- side stream (weight-gradient reductions) and caller's stream
     // (BatchNorm parameter gradients) -- let a collective stream start the chunk's all-reduce while the backward goes on
+    std::vector<const void *> k3_16;   // per level: 16-bit delta form of the k3 table for the next forward / backward call (or NULL)
+    std::vector<const int *> ok16;
     std::vector<int> chunk_op;
     std::vector<hipEvent_t> chunk_ev_side, chunk_ev_main;
     RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (ring of RED_RING slots) + device copies of the reduce jobs
@@ -852,6 +894,16 @@ extern "C" int d3_net_set_chunks(void *h, const int *op_idx, int nchunks) {
     }
     return 0;
 }
+extern "C" int d3_net_set_k3_16(void *h, const void *const *k3_16, const int *const *ok16) {
+    Net *n = (Net *)h;
+    if (!n) return D3_ERR_ARG;
+    n->k3_16.assign((size_t)n->nlevels, nullptr);
+    n->ok16.assign((size_t)n->nlevels, nullptr);
+    if (k3_16 && ok16 && d3_tune(D3T_KMAP16) != 0 && !n->f32)
+        for (int l = 0; l < n->nlevels; l++)
+            if (k3_16[l] && ok16[l]) { n->k3_16[(size_t)l] = k3_16[l]; n->ok16[(size_t)l] = ok16[l]; }
+    return 0;
+}
 // make `stream` wait until chunk k of the LAST d3_net_backward call is complete (its events were recorded by that call)
 extern "C" int d3_net_chunk_wait(void *h, int k, void *stream) {
     Net *n = (Net *)h;
@@ -1032,6 +1084,8 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
             const float *res = nullptr; int ldr = 0;
             if (o.res >= 0) { res = (const float *)tptr(n, arena, input, o.res); ldr = n->T[o.res].ld; }
             float *part = (o.stats && training) ? (float *)(arena + o.part_off) : nullptr;
+            if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
+                d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
             int rc;
             if (part && o.fin_bn >= 0 && Mout <= n->lb_rows) {
                 const OpD &b = n->ops[o.fin_bn];
@@ -1060,7 +1114,8 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                     ss[q] = StatSrc{(const float *)(arena + p.part_off), p.nparts, p.partw, r.c0, r.cn};
                 }
                 const int fs_rows = d3_tune(D3T_BN_FUSED_ROWS);
-                if (M > 0 && M <= fs_rows && C <= UN_FS_MAXC && !(o.fin_by >= 0 && M <= n->lb_rows)) {
+                const long long part_floats = 2ll * ss[0].nparts * ss[0].cn + (o.srcs.size() > 1 ? 2ll * ss[1].nparts * ss[1].cn : 0ll);
+                if (M > 0 && M <= fs_rows && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
                     // few rows: statistics + normalisation in one launch (un_bn_fused_small_kernel)
                     int G, rows_pb; un_fs_grid(M, C, G, rows_pb);
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
@@ -1216,6 +1271,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             if (o.in_grad_mode) {
                 int ldgi, root_i; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i);
                 if (root_i >= 0) wait_pending(root_i);
+                const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel];
+                if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
                 int rc;
                 if (o.bn_of_in >= 0) {
                     const OpD &b = n->ops[o.bn_of_in];
@@ -1259,6 +1316,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 float *dW = pgrads[o.w];
                 // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
                 char *wpart = garena + o.wpart_off;
+                if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
+                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
                                           flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? ws_stream : s));
                 if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)
@@ -1287,7 +1346,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
-            if (o.fused_by >= 0 && M > n->lb_rows && M <= d3_tune(D3T_BN_FUSED_ROWS) && C <= UN_FS_MAXC) {
+            if (o.fused_by >= 0 && M > n->lb_rows && M <= d3_tune(D3T_BN_FUSED_ROWS) && C <= UN_FS_MAXC && 2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS) {
                 // few rows: the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
                 int G, rows_pb; un_fs_grid(M, C, G, rows_pb);
                 float *gi = nullptr; int ldgi = 0, root_i = -1, gibf = 0;

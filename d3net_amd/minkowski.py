@@ -35,9 +35,22 @@ _EXACT_FMA = False   # with _EXACT: the one-thread-per-output FMA validation ker
 
 
 def set_exact(flag):
-    """Select the exact-fp32 convolution kernels (slow; for validation) instead of bf16 MFMA."""
-    global _EXACT
+    """Select the reference-precision kernels: exact fp32 convolutions (fp32 MFMA) instead of bf16 MFMA, and the exact fp32 MFMA
+    form of the heads' tall GEMMs instead of the bf16 x 3 split (csrc/hgemm.hip)."""
+    global _EXACT, _HG_X3_DEFAULT
     _EXACT = bool(flag)
+    try:        # (the library may not be built yet when a CPU-only test flips the flag)
+        L = _lib.lib()
+        if _HG_X3_DEFAULT is None:
+            v = C.c_int(1)
+            L.d3_tuning_get(b"D3_HG_BF16X3", C.byref(v))
+            _HG_X3_DEFAULT = int(v.value)
+        L.d3_tuning_set(b"D3_HG_BF16X3", 0 if _EXACT else _HG_X3_DEFAULT)
+    except Exception:
+        pass
+
+
+_HG_X3_DEFAULT = None
 
 
 def _mode_flag():
@@ -53,6 +66,7 @@ class CoordinateManager:
         self.device = coordinates.device
         self.coords = {1: coordinates.contiguous()}
         self._k3 = {}
+        self._k3_16 = {}
         self._down = {}
         self._pending = None      # begin_pyramid() without its build_pyramid() yet
 
@@ -81,6 +95,34 @@ class CoordinateManager:
             self._k3[ts] = nbr
         return self._k3[ts]
 
+    K3_16_MIN_ROWS = 32768     # levels below run the workgroup-per-tile kernels, which read the dense table
+
+    def k3_16(self, ts):
+        """The int16-delta form of k3(ts) (d3_kmap_k3_pack16) IF it is known to be valid, else None.  The validity flag is computed
+        on the device and copied to pinned memory behind the table build; nobody waits for it: a consumer that asks before the
+        copy has landed gets None and reads the dense table (the backbone's level 0 is built inside begin_pyramid(), so its
+        flag arrives with the pyramid's row counts -- before the forward; the deeper levels' flags are there for the backward).
+        Levels below K3_16_MIN_ROWS never build one."""
+        st = self._k3_16.get(ts)
+        if st is None:
+            nbr = self.k3(ts)
+            M = nbr.size(0)
+            if M < self.K3_16_MIN_ROWS:
+                st = self._k3_16[ts] = {"tbl": None, "valid": False}
+            else:
+                n16 = torch.empty(M * 27 + 2, dtype=torch.int16, device=self.device)
+                ok = torch.empty(1, dtype=torch.int32, device=self.device)
+                with _on(self.device):
+                    check(_lib.lib().d3_kmap_k3_pack16(_ptr(nbr), M, _ptr(n16), _ptr(ok), _stream()), "kmap_k3_pack16")
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(ok, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                st = self._k3_16[ts] = {"tbl": n16, "ok": ok, "host": host, "ev": ev, "valid": None}
+        if st["valid"] is None and st["ev"].query():
+            st["valid"] = bool(int(st["host"][0]) == 1)
+        return st["tbl"] if st["valid"] else None
+
     def begin_pyramid(self, nlevels):
         """Enqueue the coordinate pyramid of levels 1..nlevels-1 and the copy of its row counts WITHOUT waiting for them
         (d3_kmap_pyramid_begin): device work enqueued by the caller before `build_pyramid` runs while the host reads the counts."""
@@ -90,6 +132,7 @@ class CoordinateManager:
         M0 = c0.size(0)
         if M0 == 0 or nlevels < 2:
             return
+        self.k3_16(1)      # level 0's table + its 16-bit form go first: the validity flag then lands with the row counts below
         dev = self.device
         n1 = nlevels - 1
         cout = torch.empty((n1, M0, 4), dtype=torch.int32, device=dev)

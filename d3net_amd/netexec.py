@@ -289,11 +289,17 @@ class NativeUNet:
 
     def maps(self, cm):
         k3, child, up, rows, keep = [], [], [], [], []
+        k16, ok16 = [], []
         cm.build_pyramid(self.nlevels)
         ts = 1
         for lev in range(self.nlevels):
             nbr = cm.k3(ts)
             keep.append(nbr); k3.append(nbr.data_ptr()); rows.append(nbr.size(0))
+            t16 = cm.k3_16(ts) if (not self.exact and hasattr(cm, "k3_16")) else None    # (validated; the bf16 wave-per-tile kernels read it)
+            if t16 is not None:
+                keep.append(t16); k16.append(t16.data_ptr()); ok16.append(t16.data_ptr())
+            else:
+                k16.append(0); ok16.append(0)
             if lev + 1 < self.nlevels:
                 ch, u, _ = cm.down(ts)
                 keep += [ch, u]; child.append(ch.data_ptr()); up.append(u.data_ptr())
@@ -301,6 +307,7 @@ class NativeUNet:
                 child.append(0); up.append(0)
             ts *= 2
         n = self.nlevels
+        keep.append(((C.c_void_p * n)(*k16), (C.c_void_p * n)(*ok16)))     # (last element: the 16-bit tables' pointer arrays)
         return ((C.c_void_p * n)(*k3), (C.c_void_p * n)(*child), (C.c_void_p * n)(*up), rows, keep)
 
     def __call__(self, feats, cm, training):
@@ -328,6 +335,7 @@ class _NetFunction(Function):
         arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
         pp = net._param_ptrs()
         with _on(dev):
+            check(L.d3_net_set_k3_16(net._net(), keep[-1][0], keep[-1][1]), "net_set_k3_16")
             check(L.d3_net_forward(net._net(), pp, k3, child, up, C.c_void_p(feats.data_ptr()), C.c_void_p(arena.data_ptr()),
                                    int(training), _stream()), "net_forward")
         if training:
@@ -338,9 +346,10 @@ class _NetFunction(Function):
         if net.debug_keep:
             net.debug_last = (arena, list(rows))
             # kernel-3 pairs per level (entries of the dense neighbour table that exist): bench.py's compulsory-byte count
-            net.debug_pairs = [int((t >= 0).sum()) for t in keep if t.dim() == 2 and t.size(1) == 27]
+            net.debug_pairs = [int((t >= 0).sum()) for t in keep if torch.is_tensor(t) and t.dim() == 2 and t.size(1) == 27]
         ctx.net, ctx.maps, ctx.arena, ctx.feats, ctx.grad_bytes = net, (k3, child, up, keep), arena, feats, grad_bytes
         ctx.rows = rows
+        ctx.cm = cm if hasattr(cm, "k3_16") else None
         ctx.training = training
         return out
 
@@ -375,7 +384,13 @@ class _NetFunction(Function):
         net._plan_for(ctx.rows)   # the arena layout belongs to the forward's level sizes (another forward may have re-planned)
         garena = torch.empty(ctx.grad_bytes, dtype=torch.uint8, device=dev)
         gin = torch.empty_like(ctx.feats) if net.input_needs_grad else None
+        k16 = keep[-1]
+        if ctx.cm is not None and not net.exact:      # the 16-bit tables whose validity flag has landed since the forward
+            n_ = net.nlevels
+            ptrs = [(t.data_ptr() if t is not None else 0) for t in (ctx.cm.k3_16(1 << l) for l in range(n_))]
+            k16 = ((C.c_void_p * n_)(*ptrs), (C.c_void_p * n_)(*ptrs))
         with _on(dev):
+            check(L.d3_net_set_k3_16(net._net(), k16[0], k16[1]), "net_set_k3_16")
             check(L.d3_net_backward(net._net(), net._param_ptrs(), k3, child, up, C.c_void_p(ctx.feats.data_ptr()),
                                     C.c_void_p(ctx.arena.data_ptr()), C.c_void_p(garena.data_ptr()), C.c_void_p(gout.data_ptr()),
                                     pg, acc, C.c_void_p(gin.data_ptr()) if gin is not None else None, _stream()), "net_backward")

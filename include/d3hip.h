@@ -186,6 +186,10 @@ int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_query_idxs, 
  *                   child (Mout,8) for the strided conv, up (M,8) for the transposed conv. */
 size_t d3_coordmap_ws_bytes(int M);
 int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *stream);
+/* 16-bit form of a d3_kmap_k3 table: nbr16 (M*27 + 2 int16) = nbr - row, -32768 = absent; *ok16 (device int) = 1 when every
+ * delta fits, else 0 (the consumers then read the dense table).  MinkowskiEngine keeps one int32 pair list per kernel map
+ * (no counterpart); the executor hands both forms to the convolutions of a level (d3_net_set_k3_16). */
+int d3_kmap_k3_pack16(const int *nbr, int M, void *nbr16, int *ok16, void *stream);
 int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *parent, int *kidx,
                        int *Mout_host, void *stream);
 int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,
@@ -355,6 +359,12 @@ int d3_net_backward(void *net, const void *const *params, const int *const *k3, 
  * d3_net_chunk_wait makes `stream` wait for chunk k of the last backward -- the caller starts that chunk's all-reduce on
  * it while the rest of the backward is still running.  nchunks <= 64; 0 switches the feature off. */
 int d3_net_set_chunks(void *net, const int *op_idx, int nchunks);
+/* per level: the 16-bit form of the k3 table handed to the next d3_net_forward / d3_net_backward call (NULL entries, or a NULL
+ * array, = dense tables only).  The caller passes only tables whose d3_kmap_k3_pack16 flag it has READ as 1 (ok16[l]: any
+ * non-NULL pointer, unused by the kernels).  The arrays are copied; the tables must stay alive like the dense ones.
+ * d3_spconv_t16_launches: launches so far that read a 16-bit table (tests). */
+int d3_net_set_k3_16(void *net, const void *const *k3_16, const int *const *ok16);
+long long d3_spconv_t16_launches(void);
 int d3_net_chunk_wait(void *net, int k, void *stream);
 
 /* ---- point-level heads (csrc/heads.hip) -------------------------------------------------------------

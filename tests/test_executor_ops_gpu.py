@@ -206,3 +206,86 @@ def test_executor_ops_teacher_forced_at_canonical_rows(dev, stem):
     assert len(errs) == sum(1 for p in net.parameters() if p.grad is not None) >= 70
     assert errs[worst] < 2e-2, (worst, errs[worst])
     assert e_in < 2e-2, e_in
+
+
+def _detector_step(dev, scene, seed=0):
+    """one bf16 detector step on `scene` -> (loss, flat backbone gradient, backbone output checksum)"""
+    from d3net_amd import synthetic as S
+    from d3net_amd.config import default_conf
+    from d3net_amd.pointgroup import PointGroup
+    cfg = default_conf("pointgroup.yaml")
+    torch.manual_seed(seed)
+    model = PointGroup(cfg).to(dev).train()
+    model.teacher = True
+    batch = S.make_batch([scene], dev)
+    batch["cluster_rand"] = torch.rand(2, 3, generator=torch.Generator().manual_seed(1))
+    batch["slot_perms"] = [torch.randperm(cfg.model.max_num_proposal, generator=torch.Generator().manual_seed(2))]
+    loss, d = model.training_step(batch)
+    loss.backward()
+    torch.cuda.synchronize()
+    ex = model._execs["backbone"]
+    return float(loss), ex._flat_grad.clone(), d["semantic_scores"][0].detach().clone()
+
+
+def test_int16_kernel_maps_are_bit_identical_to_the_dense_tables(dev):
+    """Round 4: the K = 27 convolutions of the big levels read their kernel map as int16 deltas (csrc/coordmap.hip
+    cm_pack16_kernel; forward / data gradient: the T16 instances of spconv_fwd2_kernel, weight gradient: spconv_wgrad3_kernel).
+    Same neighbours, same order, same arithmetic: a whole detector step (loss, every backbone parameter gradient, the point
+    logits) must be BIT-identical with D3_KMAP16 on and off -- and the 16-bit path must really have run."""
+    from d3net_amd import _lib, synthetic as S
+    L = _lib.lib()
+    occ, sem, inst, _ = S.occupancy_grid()
+    scene = S.scene_from_grid(occ, sem, inst)
+    res = {}
+    for on in (1, 0):
+        assert L.d3_tuning_set(b"D3_KMAP16", on) == 0
+        n0 = L.d3_spconv_t16_launches()
+        res[on] = _detector_step(dev, scene) + (L.d3_spconv_t16_launches() - n0,)
+    L.d3_tuning_set(b"D3_KMAP16", 1)
+    assert res[1][3] >= 20, ("launches that read a 16-bit table", res[1][3])      # level 0: stem + 11 convs forward, their gradients
+    assert res[0][3] == 0
+    assert res[1][0] == res[0][0], (res[1][0], res[0][0])
+    assert torch.equal(res[1][1], res[0][1]), "backbone parameter gradients"
+    assert torch.equal(res[1][2], res[0][2]), "point logits"
+
+
+def test_int16_kernel_map_refuses_far_neighbours(dev):
+    """a row order whose neighbours are more than 32767 rows apart does not fit int16 deltas: the validity flag of
+    d3_kmap_k3_pack16 is 0 and the coordinate manager hands out no 16-bit table (the convolutions keep the dense one)"""
+    from d3net_amd import minkowski as ME, synthetic as S
+    occ, _, _, _ = S.occupancy_grid()
+    vox = np.argwhere(occ)
+    rng = np.random.default_rng(0)
+    vox = vox[rng.permutation(len(vox))]                       # shuffled rows: neighbours anywhere in 0..M
+    coords = torch.from_numpy(np.concatenate([np.zeros((len(vox), 1), np.int64), vox], 1)).int().to(dev)
+    cm = ME.CoordinateManager(coords.contiguous())
+    cm.k3_16(1)
+    torch.cuda.synchronize()
+    assert cm.k3_16(1) is None and cm._k3_16[1]["valid"] is False
+    coords = torch.from_numpy(np.concatenate([np.zeros((len(vox), 1), np.int64), np.argwhere(occ)], 1)).int().to(dev)
+    cm = ME.CoordinateManager(coords.contiguous())             # scan order: fits
+    cm.k3_16(1)
+    torch.cuda.synchronize()
+    t16 = cm.k3_16(1)
+    assert t16 is not None
+    nbr = cm.k3(1).cpu().numpy()
+    d = t16[:-2].view(-1, 27).cpu().numpy().astype(np.int64)
+    rows = np.arange(nbr.shape[0])[:, None]
+    assert np.array_equal(np.where(d == -32768, -1, rows + d), nbr)
+
+
+def test_few_row_batchnorm_in_one_launch_matches_the_separate_kernels(dev):
+    """Round 4: below D3_BN_FUSED_ROWS rows a BatchNorm is one launch per direction (un_bn_fused_small_kernel /
+    un_bn_bwd_fused_small_kernel).  The statistics are reduced by another (fixed) tree than un_bn_finalize_kernel's, so the
+    comparison with the separate kernels is to fp32 rounding, not bit for bit: loss 1e-6, gradients 1e-4 relative L2."""
+    from d3net_amd import _lib, synthetic as S
+    L = _lib.lib()
+    scene = S.small_scene(dims=(64, 48, 32), n_boxes=4, seed=7)
+    res = {}
+    for rows in (16384, 0):
+        assert L.d3_tuning_set(b"D3_BN_FUSED_ROWS", rows) == 0
+        res[rows] = _detector_step(dev, scene)
+    L.d3_tuning_set(b"D3_BN_FUSED_ROWS", 16384)
+    assert abs(res[16384][0] - res[0][0]) <= 1e-5 * abs(res[0][0]), (res[16384][0], res[0][0])
+    assert l2err(res[16384][2], res[0][2]) < 1e-3
+    assert l2err(res[16384][1], res[0][1]) < 5e-2          # (bf16 chains decorrelate: see the module docstring; a wrong kernel gives O(1))
