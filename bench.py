@@ -188,7 +188,9 @@ def prof_kernel_name(fam, t):
     if fam == 1:
         return {3: "spconv_wgrad3_kernel", 2: "spconv_wgrad2_kernel", 1: "spconv_wgrad2_wide_kernel", 32: "spconv_wgrad_f32_kernel"}.get(t[5], "spconv_wgrad")
     if fam == 3:
-        return "hg_gemm_tiled_kernel" if t[4] == 0 else "hg_gemm_kernel<%d, %s, %d>" % (t[5], _b(t[6] > 0), max(t[6], 4))
+        if t[4] in (0, 2):
+            return "hg_gemm_tiled_kernel" if t[4] == 0 else "hg_gemm_tiled3_kernel"
+        return "hg_gemm_kernel<%d, %s, %d>" % (t[5], _b(t[6] > 0), max(t[6], 4))
     if fam == 4:
         return "td_gru4_fwd_kernel<1>"
     if fam == 5:
@@ -251,9 +253,12 @@ def roofline_object(name, r, traffic_table, stride):
     dense fp32 GEMM of the heads (hg_gemm*) is MFMA-bound work priced against the 157.3 TFLOP/s fp32-MFMA peak, its byte-side
     fraction quoted beside it"""
     mfma = r["family"] == 3
+    # hg_gemm_tiled3_kernel: every algorithmic fp32 product is three bf16 MFMA products (hi*hi + hi*lo + lo*hi): its matrix-core
+    # ceiling in ALGORITHMIC flops is a third of the dense bf16 peak
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if name.startswith("hg_gemm_tiled3") else MFMA_F32_PEAK_TFLOPS
     o = {"bound": "mfma" if mfma else "hbm", "kernel": name,
          "achieved": r["achieved_tflops"] if mfma else r["achieved_gbs"],
-         "peak": MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s"}
+         "peak": mfma_peak if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s"}
     o["frac"] = o["achieved"] / o["peak"]
     t = traffic_table.get(name) or {}          # (exact instance only: a family average next to one instance's bytes would mislead)
     o["traffic"] = t.get("hbm_bytes_per_launch")
@@ -262,7 +267,7 @@ def roofline_object(name, r, traffic_table, stride):
     o["bytes_moved_by_design_per_launch"] = r["bytes_moved_by_design_per_launch"]
     o["flops_per_launch"] = r["flops_per_launch"]
     o["hbm_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
-    o["mfma_frac"] = r["achieved_tflops"] / (MFMA_F32_PEAK_TFLOPS if r["family"] in (3, 4) else MFMA_BF16_PEAK_TFLOPS)
+    o["mfma_frac"] = r["achieved_tflops"] / (mfma_peak if r["family"] in (3, 4) else MFMA_BF16_PEAK_TFLOPS)
     o["launches_per_step"] = r["launches_per_step"]; o["avg_launch_us"] = r["avg_launch_us"]; o["launches_sampled"] = r["launches_sampled"]
     o["ms_per_step"] = r["ms_per_step"]
     o["timing"] = ("HIP events on the launch's own stream around every %d-th instrumented launch (convolutions, hg_gemm, GRU cell, BFS "

@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void hg_gemm_tiled_kernel(const HgBatch batch)
 // and a product is three v_mfma_f32_16x16x32_bf16 -- lo*hi + hi*lo + hi*hi, fp32 accumulate: the dropped lo*lo term and the
 // rounding of lo are ~2^-17 relative per product (fp32 itself: 2^-24), i.e. ~1e-5 relative on a dot product -- two orders below
 // the 1e-3 the heads are held to -- at 12 bf16 MFMAs per 64 x 64 x 32 slab and wave instead of 32 fp32 ones (192 vs 1024
-// matrix-core cycles).  D3_HG_BF16X3 = 0 (and minkowski.set_exact: the reference-precision step) keeps the exact kernel.
+// matrix-core cycles).  Measured (profiles/r04): 152 -> 140 us per launch in the joint step, 26 -> 23 us in the speaker step --
+// the 64 x 64 tile moves 16 KB per 262 kFLOP slab and is bound by L2 traffic, not by the matrix rate.  NOT adopted: the switch
+// D3_HG_BF16X3 is off by default (the heads stay exact fp32); minkowski.set_exact forces it off.
 typedef __bf16 hg_bf16x8 __attribute__((ext_vector_type(8)));
 #define HT3_RP (HT_BK + 8)     // LDS row pitch in bf16: 80-byte rows, 16-byte aligned k groups
 __device__ __forceinline__ unsigned short hg_bf16_rne(float x) {

@@ -499,11 +499,13 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
         }
     }
 }
-// workgroups / rows per workgroup of the fused few-row kernels: ~16 k elements per workgroup, at most 32 workgroups
-static inline void un_fs_grid(int M, int C, int &G, int &rows_per_block) {
+// workgroups / rows per workgroup of the fused kernels: ~16 k elements per workgroup, at most `cap` workgroups (32 for the few-row
+// levels; the big levels use up to 512 -- every workgroup re-reads the producer's partial table from L2, so their number is
+// what the fusion costs)
+static inline void un_fs_grid(int M, int C, int &G, int &rows_per_block, int cap = 32) {
     long long g = ((long long)M * C + 16383) / 16384;
     if (g < 1) g = 1;
-    if (g > 32) g = 32;
+    if (g > cap) g = cap;
     const int rpb = UN_FS_T / (C >> 2);                   // rows per pass
     int rows = (int)((M + g - 1) / g);
     rows = (rows + rpb - 1) / rpb * rpb;
@@ -1115,9 +1117,10 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                 }
                 const int fs_rows = d3_tune(D3T_BN_FUSED_ROWS);
                 const long long part_floats = 2ll * ss[0].nparts * ss[0].cn + (o.srcs.size() > 1 ? 2ll * ss[1].nparts * ss[1].cn : 0ll);
-                if (M > 0 && M <= fs_rows && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
-                    // few rows: statistics + normalisation in one launch (un_bn_fused_small_kernel)
-                    int G, rows_pb; un_fs_grid(M, C, G, rows_pb);
+                const int fs_big = d3_tune(D3T_BN_FUSED_BIG);
+                if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
+                    // statistics + normalisation in one launch (un_bn_fused_small_kernel); big levels: up to 512 workgroups
+                    int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows ? 32 : 512);
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
                     if (to.dtype == 1)
                         un_bn_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
@@ -1346,9 +1349,11 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
-            if (o.fused_by >= 0 && M > n->lb_rows && M <= d3_tune(D3T_BN_FUSED_ROWS) && C <= UN_FS_MAXC && 2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS) {
-                // few rows: the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
-                int G, rows_pb; un_fs_grid(M, C, G, rows_pb);
+            const int fs_rows_b = d3_tune(D3T_BN_FUSED_ROWS);
+            if (o.fused_by >= 0 && M > n->lb_rows && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
+                2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS) {
+                // the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
+                int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows_b ? 32 : 512);
                 float *gi = nullptr; int ldgi = 0, root_i = -1, gibf = 0;
                 if (o.in_grad_mode) {
                     gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);

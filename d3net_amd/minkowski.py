@@ -42,7 +42,7 @@ def set_exact(flag):
     try:        # (the library may not be built yet when a CPU-only test flips the flag)
         L = _lib.lib()
         if _HG_X3_DEFAULT is None:
-            v = C.c_int(1)
+            v = C.c_int(0)
             L.d3_tuning_get(b"D3_HG_BF16X3", C.byref(v))
             _HG_X3_DEFAULT = int(v.value)
         L.d3_tuning_set(b"D3_HG_BF16X3", 0 if _EXACT else _HG_X3_DEFAULT)
