@@ -182,7 +182,8 @@ def prof_kernel_name(fam, t):
     t = [int(v) for v in t]
     if fam == 0:
         nt, wlds, xbf, nw, f32, kt, st = t[5:12]
-        return "spconv_fwd2_kernel<%d, %s, %s, %d, %s, %d, %d>" % (nt, _b(wlds), _b(xbf), nw, _b(f32), kt, st)
+        st, t16 = st % 1000, st >= 1000          # (the record packs the T16 template flag into the ST tag: ST + 1000)
+        return "spconv_fwd2_kernel<%d, %s, %s, %d, %s, %d, %d, %s>" % (nt, _b(wlds), _b(xbf), nw, _b(f32), kt, st, _b(t16))
     if fam == 2:
         return "spconv_fwd2_split_kernel<%d, %s, %s>" % (t[5], _b(t[6]), _b(t[7]))
     if fam == 1:
@@ -635,7 +636,23 @@ def main():
                            "(2*FETCH+WRITE)*1024 per MI355X_MICROARCH.md); measured on code %s, this is %s" % (measured_on, code_sha()))
         except Exception:
             pass
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        # families: all template instances of a kernel function (what a profile reader calls "the kernel"); the dominant one is the
+        # family with the most time per step, priced as a whole (sum of its launches' algorithmic bytes / flops over the sum of
+        # their durations); its instances follow in `per_kernel`
+        fam_rec = {}
+        for k, r in kernels.items():
+            f = fam_rec.setdefault(k.split("<")[0], dict(family=r["family"], n=0.0, ms=0.0, b8=0.0, bd=0.0, fl=0.0, samp=0))
+            w = r["launches_per_step"]
+            f["n"] += w; f["ms"] += r["ms_per_step"]; f["samp"] += r["launches_sampled"]
+            f["b8"] += r["algorithmic_bytes_per_launch"] * w; f["bd"] += r["bytes_moved_by_design_per_launch"] * w; f["fl"] += r["flops_per_launch"] * w
+        families = {}
+        for k, f in fam_rec.items():
+            n = max(f["n"], 1e-9)
+            families[k] = {"family": f["family"], "launches_sampled": f["samp"], "launches_per_step": f["n"], "avg_launch_us": 1e3 * f["ms"] / n,
+                           "ms_per_step": f["ms"], "algorithmic_bytes_per_launch": f["b8"] / n, "bytes_moved_by_design_per_launch": f["bd"] / n,
+                           "flops_per_launch": f["fl"] / n, "achieved_gbs": f["b8"] / max(f["ms"], 1e-9) / 1e6,
+                           "achieved_tflops": f["fl"] / max(f["ms"], 1e-9) / 1e9}
+        dom = max(families, key=lambda k: families[k]["ms_per_step"]) if families else None
         workload = {
             "speaker": "BASELINE configs[2]: PipelineNet mode 1 (PointGroup detector -> relation graph -> top-down captioner, "
                        "XE), conf/pointgroup_captioning.yaml: %d scenes/GPU/step (40-box synthetic ScanNet scenes, 200x150x100 "
@@ -667,28 +684,18 @@ def main():
             "final_loss": final_loss, "fp32_exact": fp32, "strong_scaling_ceiling": ceiling,
         }
         if dom is not None:
-            rf = roofline_object(dom, kernels[dom], traffic_table, PROF_STRIDE)
+            rf = roofline_object(dom, families[dom], traffic_table, PROF_STRIDE)
             rf["traffic_source"], rf["traffic_stale"] = traffic_src, traffic_stale
-            rf["share_of_step"] = kernels[dom]["ms_per_step"] / (1e3 * elapsed / args.steps)
-            rf["dominant"] = ("the instrumented kernel (rocprofv3 name) with the most time per step; every other instrumented kernel "
-                              "follows in `per_kernel` with the same pricing, most expensive first")
-            # every instrumented kernel, and the family aggregates (all instances of spconv_fwd2_kernel etc.)
+            rf["share_of_step"] = families[dom]["ms_per_step"] / (1e3 * elapsed / args.steps)
+            rf["dominant"] = ("the instrumented kernel function (all template instances of it; rocprofv3 lists the instances separately) with the "
+                              "most time per step; `per_kernel`: every instance of every instrumented kernel under its rocprofv3 name, `families`: "
+                              "every kernel function -- same pricing, most expensive first")
+            keys = ("bound", "achieved", "peak", "unit", "frac", "hbm_frac", "mfma_frac", "traffic", "traffic_over_algorithmic",
+                    "algorithmic_bytes_per_launch", "launches_per_step", "avg_launch_us", "ms_per_step")
             order = sorted(kernels, key=lambda k: -kernels[k]["ms_per_step"])
-            rf["per_kernel"] = {k: {kk: vv for kk, vv in roofline_object(k, kernels[k], traffic_table, PROF_STRIDE).items()
-                                    if kk in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac", "mfma_frac", "traffic", "traffic_over_algorithmic",
-                                              "algorithmic_bytes_per_launch", "launches_per_step", "avg_launch_us", "ms_per_step")}
-                                for k in order[:24]}
-            fams = {}
-            for k, r in kernels.items():
-                f = fams.setdefault(k.split("<")[0], dict(ms=0.0, by=0.0, fl=0.0, n=0.0))
-                f["ms"] += r["ms_per_step"]; f["n"] += r["launches_per_step"]
-                f["by"] += r["algorithmic_bytes_per_launch"] * r["launches_per_step"]; f["fl"] += r["flops_per_launch"] * r["launches_per_step"]
-            rf["families"] = {k: {"ms_per_step": f["ms"], "launches_per_step": f["n"], "avg_launch_us": 1e3 * f["ms"] / max(f["n"], 1e-9),
-                                  "algorithmic_bytes_per_launch": f["by"] / max(f["n"], 1e-9),
-                                  "achieved_gbs": f["by"] / max(f["ms"], 1e-9) / 1e6, "hbm_frac": f["by"] / max(f["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS,
-                                  "achieved_tflops": f["fl"] / max(f["ms"], 1e-9) / 1e9,
-                                  "traffic": (traffic_table.get(k) or {}).get("hbm_bytes_per_launch")}
-                              for k, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
+            rf["per_kernel"] = {k: {kk: vv for kk, vv in roofline_object(k, kernels[k], traffic_table, PROF_STRIDE).items() if kk in keys} for k in order[:24]}
+            rf["families"] = {k: {kk: vv for kk, vv in roofline_object(k, families[k], traffic_table, PROF_STRIDE).items() if kk in keys}
+                              for k in sorted(families, key=lambda k: -families[k]["ms_per_step"])}
             out["roofline"] = rf
         else:
             out["roofline"] = None

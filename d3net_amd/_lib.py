@@ -57,6 +57,7 @@ SIGNATURES = {
     "d3_coordmap_ws_bytes": (sz, [i32]),
     "d3_kmap_k3": (i32, [vp, i32, i32, vp, sz, vp, vp]),
     "d3_kmap_k3_pack16": (i32, [vp, i32, vp, vp, vp]),
+    "d3_kmap_k3_16": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp]),
     "d3_net_set_k3_16": (i32, [vp, vp, vp]),
     "d3_spconv_t16_launches": (C.c_longlong, []),
     "d3_kmap_down_count": (i32, [vp, i32, i32, vp, sz, vp, vp, pi, vp]),

@@ -66,6 +66,12 @@ __global__ void cm_init_kernel(unsigned long long *keys, int *first, size_t cap,
     if (i < cap) { keys[i] = CM_EMPTY; first[i] = 0x7FFFFFFF; }
     if (i < 8) scalars[i] = 0;
 }
+__global__ void cm_init2_kernel(unsigned long long *keys, int *first, size_t cap, int *scalars, int *ok16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = CM_EMPTY; first[i] = 0x7FFFFFFF; }
+    if (i < 8) scalars[i] = 0;
+    if (i == 0) *ok16 = 1;
+}
 // insert coords[i] quantised to step q (q == 0: as is)
 __global__ void cm_insert_kernel(const int *__restrict__ coords, int M, int q, unsigned long long *keys, int *first,
                                  size_t cap, int *slot_of, int *scalars) {
@@ -97,40 +103,61 @@ __device__ __forceinline__ int cm_lookup(const unsigned long long *keys, const i
 }
 
 // one thread per (row, offset): coalesced table stores
+// nbr16 / ok16 (optional, round 4): the int16-delta form of the table in the same pass (see cm_pack16_kernel below);
+// *ok16 was set to 1 by the hash build's init kernel
 __global__ void cm_k3_kernel(const int *__restrict__ coords, int M, int ts, const unsigned long long *keys,
-                             const int *first, size_t cap, int *__restrict__ nbr) {
+                             const int *first, size_t cap, int *__restrict__ nbr, short *__restrict__ nbr16, int *ok16) {
     long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long long)M * 27) return;
-    const int u = (int)(e / 27), k = (int)(e % 27);
-    const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
-    unsigned long long key;
-    int r = -1;
-    if (cm_pack(coords[u * 4], coords[u * 4 + 1] + ox * ts, coords[u * 4 + 2] + oy * ts, coords[u * 4 + 3] + oz * ts, key))
-        r = cm_lookup(keys, first, cap, key);
-    nbr[e] = r;
+    const long long total = (long long)M * 27;
+    bool bad = false;
+    if (e < total) {
+        const int u = (int)(e / 27), k = (int)(e % 27);
+        const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+        unsigned long long key;
+        int r = -1;
+        if (cm_pack(coords[u * 4], coords[u * 4 + 1] + ox * ts, coords[u * 4 + 2] + oy * ts, coords[u * 4 + 3] + oz * ts, key))
+            r = cm_lookup(keys, first, cap, key);
+        nbr[e] = r;
+        if (nbr16) {
+            int d = -32768;
+            if (r >= 0) { d = r - u; if (d < -32767 || d > 32767) { bad = true; d = -32768; } }
+            nbr16[e] = (short)d;
+        }
+    } else if (nbr16 && e < total + 2) nbr16[e] = (short)-32768;
+    if (nbr16 && __any(bad) && (threadIdx.x & 63) == 0) *ok16 = 0;
 }
 
-static int cm_build_hash(const int *coords, int M, int q, CmWs &w, hipStream_t s) {
+static int cm_build_hash(const int *coords, int M, int q, CmWs &w, hipStream_t s, int *ok16 = nullptr) {
     const int T = 256;
+    if (ok16) cm_init2_kernel<<<(int)((w.cap + T - 1) / T), T, 0, s>>>(w.keys, w.first, w.cap, w.scalars, ok16);
+    else
     cm_init_kernel<<<(int)((w.cap + T - 1) / T), T, 0, s>>>(w.keys, w.first, w.cap, w.scalars);
     cm_insert_kernel<<<(M + T - 1) / T, T, 0, s>>>(coords, M, q, w.keys, w.first, w.cap, w.slot_of, w.scalars);
     D3_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *stream) {
+static int cm_k3_run(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, short *nbr16, int *ok16, void *stream) {
     D3_CLEAR();
     if (M <= 0) return 0;
-    if (ts <= 0) return D3_ERR_ARG;
+    if (ts <= 0 || ((nbr16 == nullptr) != (ok16 == nullptr))) return D3_ERR_ARG;
     CmWs w;
     if (ws == nullptr || cm_layout(ws, ws_bytes, M, w) > ws_bytes) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
-    int rc = cm_build_hash(coords, M, 0, w, s);
+    int rc = cm_build_hash(coords, M, 0, w, s, ok16);
     if (rc) return rc;
-    long long total = (long long)M * 27;
-    cm_k3_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(coords, M, ts, w.keys, w.first, w.cap, nbr);
+    long long total = (long long)M * 27 + (nbr16 ? 2 : 0);
+    cm_k3_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(coords, M, ts, w.keys, w.first, w.cap, nbr, nbr16, ok16);
     D3_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *stream) {
+    return cm_k3_run(coords, M, ts, ws, ws_bytes, nbr, nullptr, nullptr, stream);
+}
+// d3_kmap_k3 + the int16-delta form of the table and its validity flag in the same pass (see d3_kmap_k3_pack16)
+extern "C" int d3_kmap_k3_16(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *nbr16, int *ok16, void *stream) {
+    if (!nbr16 || !ok16) return D3_ERR_ARG;
+    return cm_k3_run(coords, M, ts, ws, ws_bytes, nbr, (short *)nbr16, ok16, stream);
 }
 
 // ---- 16-bit form of a K = 27 neighbour table (round 4).  A stride-1 table is read by the forward, the data gradient and the

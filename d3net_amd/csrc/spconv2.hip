@@ -869,6 +869,7 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
         static bool attr16_done_dev[64] = {false};
         if (c2_attr_needed(attr16_done_dev))
             D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        c2_inst(NT, 1, 1, NW, 0, 27, ST + 1000);     // (+ 1000: the T16 template flag, unpacked by bench.py's kernel naming)
         spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST, true><<<p.grid, 64 * NW, p.lds, s>>>(a);
         g_t16_launches++;
         D3_LAUNCH_CHECK();

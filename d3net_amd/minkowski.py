@@ -91,7 +91,18 @@ class CoordinateManager:
             nbr = torch.empty((M, 27), dtype=torch.int32, device=self.device)
             ws = self._ws(M)
             with _on(self.device):
-                check(_lib.lib().d3_kmap_k3(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _stream()), "kmap_k3")
+                if M >= self.K3_16_MIN_ROWS:      # big level: the 16-bit form and its validity flag in the same pass
+                    n16 = torch.empty(M * 27 + 2, dtype=torch.int16, device=self.device)
+                    ok = torch.empty(1, dtype=torch.int32, device=self.device)
+                    check(_lib.lib().d3_kmap_k3_16(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _ptr(n16), _ptr(ok), _stream()), "kmap_k3_16")
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(ok, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._k3_16[ts] = {"tbl": n16, "ok": ok, "host": host, "ev": ev, "valid": None}
+                else:
+                    check(_lib.lib().d3_kmap_k3(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _stream()), "kmap_k3")
+                    self._k3_16[ts] = {"tbl": None, "valid": False}
             self._k3[ts] = nbr
         return self._k3[ts]
 
@@ -103,22 +114,9 @@ class CoordinateManager:
         copy has landed gets None and reads the dense table (the backbone's level 0 is built inside begin_pyramid(), so its
         flag arrives with the pyramid's row counts -- before the forward; the deeper levels' flags are there for the backward).
         Levels below K3_16_MIN_ROWS never build one."""
-        st = self._k3_16.get(ts)
-        if st is None:
-            nbr = self.k3(ts)
-            M = nbr.size(0)
-            if M < self.K3_16_MIN_ROWS:
-                st = self._k3_16[ts] = {"tbl": None, "valid": False}
-            else:
-                n16 = torch.empty(M * 27 + 2, dtype=torch.int16, device=self.device)
-                ok = torch.empty(1, dtype=torch.int32, device=self.device)
-                with _on(self.device):
-                    check(_lib.lib().d3_kmap_k3_pack16(_ptr(nbr), M, _ptr(n16), _ptr(ok), _stream()), "kmap_k3_pack16")
-                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                host.copy_(ok, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                st = self._k3_16[ts] = {"tbl": n16, "ok": ok, "host": host, "ev": ev, "valid": None}
+        if ts not in self._k3:
+            self.k3(ts)
+        st = self._k3_16[ts]
         if st["valid"] is None and st["ev"].query():
             st["valid"] = bool(int(st["host"][0]) == 1)
         return st["tbl"] if st["valid"] else None

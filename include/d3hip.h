@@ -190,6 +190,8 @@ int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int 
  * delta fits, else 0 (the consumers then read the dense table).  MinkowskiEngine keeps one int32 pair list per kernel map
  * (no counterpart); the executor hands both forms to the convolutions of a level (d3_net_set_k3_16). */
 int d3_kmap_k3_pack16(const int *nbr, int M, void *nbr16, int *ok16, void *stream);
+/* d3_kmap_k3 that writes the 16-bit form and its flag in the same pass (what the coordinate manager calls for big levels) */
+int d3_kmap_k3_16(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *nbr16, int *ok16, void *stream);
 int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *parent, int *kidx,
                        int *Mout_host, void *stream);
 int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,

@@ -18,13 +18,12 @@ for path in sys.argv[1:3]:
         full = name.strip('"').replace("void ", "")
         b = inst[full][counter]
         b[0] += int(launches); b[1] += float(total)
-        if base in ("spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel"):   # bench.py's weight-gradient family
-            base = "spconv_wgrad3_kernel"
         a = acc[base][counter]
         a[0] += int(launches); a[1] += float(total)
 out = {}
-for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel",
-          "un_bn_bwd_apply_kernel", "hg_gemm_kernel", "hg_gemm_tiled_kernel", "td_gru4_fwd_kernel", "cl_push_kernel", "bq_scan_kernel"):
+for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel", "cl_bfs2_kernel",
+          "un_bn_apply_kernel", "un_bn_bwd_apply_kernel", "un_bn_fused_small_kernel", "un_bn_bwd_fused_small_kernel", "hg_gemm_kernel", "hg_gemm_tiled_kernel",
+          "hg_gemm_tiled3_kernel", "td_gru4_fwd_kernel", "cl_push_kernel", "cl_union_kernel", "bqg_query_kernel", "bq_scan_kernel"):
     if k not in acc:
         continue
     f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
@@ -37,7 +36,8 @@ for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kerne
                       "--warmup 1 (the bench default workload unless the file name says otherwise); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B "
                       "per 128-B request: MI355X_MICROARCH.md HBM section)"}
 BASES = ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel",
-         "hg_gemm_kernel", "hg_gemm_tiled_kernel", "td_gru4_fwd_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel", "un_bn_bwd_apply_kernel")
+         "hg_gemm_kernel", "hg_gemm_tiled_kernel", "hg_gemm_tiled3_kernel", "td_gru4_fwd_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel", "un_bn_bwd_apply_kernel",
+         "un_bn_fused_small_kernel", "un_bn_bwd_fused_small_kernel")
 for full, v in inst.items():
     if full in out or full.split("<")[0] not in BASES:
         continue
