@@ -18,7 +18,15 @@ from d3net_amd.optim import FusedAdamW  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 config = args[0]
-switches = [(a.split("=")[0], [int(v) for v in a.split("=")[1].split(",")]) for a in args[1:]]
+# NAME=a,b flips one switch; NAME1+NAME2=a,b flips several together (arm values per switch: a:b pairs joined by '/', e.g.
+# D3_KMAP16+D3_BN_FUSED_ROWS=0/0,1/16384)
+switches = []
+for a in args[1:]:
+    names, vals = a.split("=")
+    names = names.split("+")
+    arms = [[int(x) for x in v.split("/")] for v in vals.split(",")]
+    arms = [arm * len(names) if len(arm) == 1 else arm for arm in arms]
+    switches.append((names, arms))
 block = int(sys.argv[sys.argv.index("--block") + 1]) if "--block" in sys.argv else 20
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 6
 dev = torch.device("cuda", 0)
@@ -58,11 +66,14 @@ for _ in range(40):
 torch.cuda.synchronize()
 import gc
 gc.collect(); gc.freeze()
-for name, vals in switches:
+for names, arms in switches:
+    name = "+".join(names)
+    vals = list(range(len(arms)))
     res = {v: [] for v in vals}
     for r in range(rounds):
         for v in (vals if r % 2 == 0 else vals[::-1]):
-            assert L.d3_tuning_set(name.encode(), v) == 0, name
+            for nm, x in zip(names, arms[v]):
+                assert L.d3_tuning_set(nm.encode(), x) == 0, nm
             for _ in range(4):
                 step()
             torch.cuda.synchronize()
@@ -71,6 +82,7 @@ for name, vals in switches:
                 step()
             torch.cuda.synchronize()
             res[v].append(1e3 * (time.perf_counter() - t0) / block)
-    L.d3_tuning_set(name.encode(), vals[-1])
-    print("%s (%s): " % (name, config) + "   ".join("%d -> %.3f ms (median %.3f, min %.3f)" % (v, statistics.mean(res[v]), statistics.median(res[v]), min(res[v]))
+    for nm, x in zip(names, arms[-1]):
+        L.d3_tuning_set(nm.encode(), x)
+    print("%s (%s): " % (name, config) + "   ".join("%s -> %.3f ms (median %.3f, min %.3f)" % ("/".join(map(str, arms[v])), statistics.mean(res[v]), statistics.median(res[v]), min(res[v]))
                                                     for v in vals), flush=True)
