@@ -16,7 +16,14 @@ from d3net_amd import _lib, synthetic as S  # noqa: E402
 from d3net_amd.config import default_conf  # noqa: E402
 from d3net_amd.optim import FusedAdamW  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args, skip = [], False
+for a in sys.argv[1:]:
+    if skip:
+        skip = False
+    elif a in ("--block", "--rounds"):
+        skip = True
+    elif not a.startswith("--"):
+        args.append(a)
 config = args[0]
 # NAME=a,b flips one switch; NAME1+NAME2=a,b flips several together (arm values per switch: a:b pairs joined by '/', e.g.
 # D3_KMAP16+D3_BN_FUSED_ROWS=0/0,1/16384)
