@@ -220,6 +220,7 @@ def collect_kernel_rooflines(L, steps, stride, pairs27):
     """every sampled launch of the timed region (HIP events on its own stream, csrc/prof.h) -> per-kernel records:
     {name: {family, launches_sampled, launches_per_step, avg_launch_us, ms_per_step, bytes_8d, bytes_design, flops}}"""
     out = {}
+    shapes = {}          # hg_gemm*: (kernel, max M, max N, K, problems) -> [launches sampled, ms]
     W = 3 + PROF_TAGS
     for fam in (0, 1, 2, 3, 4, 5):
         n = C.c_int(0)
@@ -236,6 +237,10 @@ def collect_kernel_rooflines(L, steps, stride, pairs27):
                 b8, flops = conv_bytes_8d(tags, pairs27)
             else:
                 b8 = bdesign
+            if fam == 3:
+                k = (name.split("<")[0], int(tags[0]), int(tags[1]), int(tags[2]), int(tags[3]))
+                sh = shapes.setdefault(k, [0, 0.0, 0.0])
+                sh[0] += 1; sh[1] += ms; sh[2] += flops
             r = out.setdefault(name, dict(family=fam, n=0, ms=0.0, bytes_8d=0.0, bytes_design=0.0, flops=0.0))
             r["n"] += 1; r["ms"] += ms; r["bytes_8d"] += b8; r["bytes_design"] += bdesign; r["flops"] += flops
     res = {}
@@ -246,6 +251,9 @@ def collect_kernel_rooflines(L, steps, stride, pairs27):
                      "algorithmic_bytes_per_launch": r["bytes_8d"] / n, "bytes_moved_by_design_per_launch": r["bytes_design"] / n,
                      "flops_per_launch": r["flops"] / n,
                      "achieved_gbs": r["bytes_8d"] / max(r["ms"], 1e-9) / 1e6, "achieved_tflops": r["flops"] / max(r["ms"], 1e-9) / 1e9}
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:10]
+    res["__hg_shapes__"] = [{"kernel": k[0], "M": k[1], "N": k[2], "K": k[3], "problems": k[4], "launches_per_step": v[0] * stride / steps,
+                             "avg_launch_us": 1e3 * v[1] / v[0], "tflops": v[2] / max(v[1], 1e-9) / 1e9} for k, v in top]
     return res
 
 
@@ -563,6 +571,7 @@ def main():
             for r_, p_ in zip(dd["rows"], dd["pairs27"]):
                 pairs27[int(r_)] = int(p_)
     kernels = collect_kernel_rooflines(L, args.steps, PROF_STRIDE, pairs27)
+    hg_shapes = kernels.pop("__hg_shapes__", [])
     L.d3_prof_enable(0)
     final_loss = float(loss.detach())
 
@@ -696,6 +705,7 @@ def main():
             rf["per_kernel"] = {k: {kk: vv for kk, vv in roofline_object(k, kernels[k], traffic_table, PROF_STRIDE).items() if kk in keys} for k in order[:24]}
             rf["families"] = {k: {kk: vv for kk, vv in roofline_object(k, families[k], traffic_table, PROF_STRIDE).items() if kk in keys}
                               for k in sorted(families, key=lambda k: -families[k]["ms_per_step"])}
+            rf["hg_gemm_shapes"] = hg_shapes       # the heads' GEMM shapes that cost the most time (largest problem of a batched launch)
             out["roofline"] = rf
         else:
             out["roofline"] = None

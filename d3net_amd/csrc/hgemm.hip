@@ -374,8 +374,41 @@ static int hg_check(const d3_gemm_prob &p) {
 }
 
 // host-side launcher shared with topdown.hip / edgeconv.hip (C++ linkage; the C entry point is d3_hgemm)
+// kernel class of ONE problem: 0 = decode step (M <= 32), 1 = few output tiles (K split over the waves of a workgroup),
+// 2 = tall (64 x 64 LDS-tiled kernel)
+static int hg_class(const d3_gemm_prob &p) {
+    if (p.M <= 32) return 0;
+    const long long tiles16 = (long long)((p.N + 15) / 16) * ((p.M + 15) / 16);
+    return tiles16 < 2048 ? 1 : 2;
+}
+
 int hg_launch(const d3_gemm_prob *probs, int nprobs, hipStream_t s) {
     if (nprobs < 1 || nprobs > HG_MAXP) return D3_ERR_ARG;
+    // Round 4: a batch is launched with the kernel its LARGEST problem asks for, which is right for the captioner's homogeneous
+    // batches and very wrong for the listener's backward pairs: (dx = dy W: 4096 x 128 x 128, tall) batched with
+    // (dW = dy^T x: 128 x 128 x 4096) ran the weight gradient on FOUR workgroups of the tiled kernel walking 128 (joint step: 384)
+    // k slabs one after the other -- 212 us (643 us) per launch, 14 % of the listener step.  A mixed batch is split by class:
+    // the deep, few-tile problems go to the K-split kernel (128 x 128 x 4096: ~17 us).
+    if (nprobs > 1 && d3_tune(D3T_HG_CLASS_SPLIT) != 0) {
+        int cls[HG_MAXP], first = -1;
+        bool mixed = false;
+        for (int i = 0; i < nprobs; i++) {
+            int rc = hg_check(probs[i]);
+            if (rc) return rc;
+            cls[i] = probs[i].M > 0 ? hg_class(probs[i]) : -1;
+            if (cls[i] < 0) continue;
+            if (first < 0) first = cls[i]; else if (cls[i] != first) mixed = true;
+        }
+        if (mixed) {
+            for (int c = 0; c < 3; c++) {
+                d3_gemm_prob sub[HG_MAXP];
+                int n = 0;
+                for (int i = 0; i < nprobs; i++) if (cls[i] == c) sub[n++] = probs[i];
+                if (n > 0) { int rc = hg_launch(sub, n, s); if (rc) return rc; }
+            }
+            return 0;
+        }
+    }
     HgBatch b;
     int maxM = 0, maxN = 0;
     for (int i = 0; i < nprobs; i++) {
