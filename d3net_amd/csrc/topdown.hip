@@ -1064,3 +1064,138 @@ extern "C" int d3_gru_seq_backward(const float *x, const int *lens, const float 
     D3_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------ decode-loop selection kernels (round 4)
+// The sampling loops of the self-critical step (beam search + greedy baseline, model/caption_module.py:136-383) ran ~25 library
+// launches per time step around the native decode step -- log_softmax, add, topk (sbtopk::gatherTopK: 45 us), div / mod, three
+// gathers, cat, comparisons, two index_selects of the hidden states: ~7,000 element-wise launches per joint step.  One launch
+// per step instead.
+//
+// d3_beam_select: one workgroup per sample.  logits (N*b, V): row n*b + j = live beam j of sample n (live = 1 at t = 0).
+//   logp[j][v] = (x - max_j) - log(sum_v exp(x - max_j))             (torch's log_softmax expression)
+//   cand[j*V + v] = sums_in[n][j] + logp[j][v]; the b best candidates best first (ties: the lower flat index) give
+//   beam_ix = flat / V, tok = flat % V, chosen = logp, snap = sums_in[beam_ix] + chosen, ended = tok == eos (or `last`),
+//   sums_out = snap - 1000 * ended (caption_module.py:300), seq_out[n][r][:t] = seq_prev[n][beam_ix][:t], seq_out[n][r][t] = tok,
+//   and the two hidden states of row n*b + r are those of row n*b + beam_ix (the re-ordering of :305-307).
+#define BS_T 256
+__global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__restrict__ logits, const float *__restrict__ sums_in, int live, int b, int V,
+                                                             int eos, int last, int t, int Tmax, const long long *__restrict__ seq_prev,
+                                                             long long *__restrict__ seq_out, long long *__restrict__ tok_out,
+                                                             float *__restrict__ snap_out, unsigned char *__restrict__ ended_out,
+                                                             float *__restrict__ sums_out, const float *__restrict__ h1_in,
+                                                             const float *__restrict__ h2_in, float *__restrict__ h1_out,
+                                                             float *__restrict__ h2_out, int H) {
+    __shared__ float red[BS_T];
+    __shared__ int redi[BS_T];
+    __shared__ float s_max[8], s_lse[8], s_sum[8];
+    __shared__ int s_pick[8];
+    __shared__ float s_pickv[8];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    // (a) per live beam: max and log-sum-exp
+    for (int j = 0; j < live; j++) {
+        const float *x = logits + ((long long)n * b + j) * V;
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += BS_T) m = fmaxf(m, x[v]);
+        red[tid] = m; __syncthreads();
+        for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+        m = red[0]; __syncthreads();
+        float sm = 0.f;
+        for (int v = tid; v < V; v += BS_T) sm += expf(x[v] - m);
+        red[tid] = sm; __syncthreads();
+        for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) { s_max[j] = m; s_lse[j] = logf(red[0]); s_sum[j] = sums_in[(long long)n * live + j]; }
+        __syncthreads();
+    }
+    // (b) the b best candidates, best first: b block-wide arg-max passes (a picked candidate is skipped by later passes)
+    for (int r = 0; r < b; r++) {
+        float bv = -INFINITY; int bi = 0x7FFFFFFF;
+        for (int j = 0; j < live; j++) {
+            const float *x = logits + ((long long)n * b + j) * V;
+            const float mj = s_max[j], lj = s_lse[j], sj = s_sum[j];
+            for (int v = tid; v < V; v += BS_T) {
+                const int flat = j * V + v;
+                bool taken = false;
+                for (int q = 0; q < r; q++) taken |= (s_pick[q] == flat);
+                if (taken) continue;
+                const float c = sj + ((x[v] - mj) - lj);
+                if (c > bv || (c == bv && flat < bi)) { bv = c; bi = flat; }
+            }
+        }
+        red[tid] = bv; redi[tid] = bi; __syncthreads();
+        for (int o = BS_T / 2; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float ov = red[tid + o]; const int oi = redi[tid + o];
+                if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) { red[tid] = ov; redi[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { s_pick[r] = redi[0]; s_pickv[r] = red[0]; }
+        __syncthreads();
+    }
+    // (c) outputs
+    if (tid < b) {
+        const int flat = s_pick[tid], j = flat / V, v = flat - j * V;
+        const float chosen = (logits[((long long)n * b + j) * V + v] - s_max[j]) - s_lse[j];
+        const float snap = s_sum[j] + chosen;
+        const bool ended = last || v == eos;
+        const long long o = (long long)n * b + tid;
+        tok_out[o] = v; snap_out[o] = snap; ended_out[o] = ended ? 1 : 0; sums_out[o] = snap - 1000.0f * (ended ? 1.f : 0.f);
+        seq_out[o * Tmax + t] = v;
+    }
+    for (int e = tid; e < b * t; e += BS_T) {          // histories of the chosen beams
+        const int r = e / t, c = e - r * t;
+        const int j = s_pick[r] / V;
+        seq_out[((long long)n * b + r) * Tmax + c] = seq_prev[((long long)n * b + j) * Tmax + c];
+    }
+    if (h1_in) {
+        for (int e = tid; e < b * H; e += BS_T) {
+            const int r = e / H, c = e - r * H;
+            const int j = s_pick[r] / V;
+            h1_out[((long long)n * b + r) * H + c] = h1_in[((long long)n * b + j) * H + c];
+            h2_out[((long long)n * b + r) * H + c] = h2_in[((long long)n * b + j) * H + c];
+        }
+    }
+}
+extern "C" int d3_beam_select(const float *logits, const float *sums_in, int N, int live, int b, int V, int eos, int last, int t, int Tmax,
+                              const long long *seq_prev, long long *seq_out, long long *tok_out, float *snap_out, unsigned char *ended_out,
+                              float *sums_out, const float *h1_in, const float *h2_in, float *h1_out, float *h2_out, int H, void *stream) {
+    D3_CLEAR();
+    if (N <= 0) return 0;
+    if (live < 1 || live > b || b < 1 || b > 8 || V < 1 || t < 0 || t >= Tmax || (t > 0 && !seq_prev)) return D3_ERR_ARG;
+    td_beam_select_kernel<<<N, BS_T, 0, d3_stream(stream)>>>(logits, sums_in, live, b, V, eos, last, t, Tmax, seq_prev, seq_out, tok_out, snap_out, ended_out,
+                                                             sums_out, h1_in, h2_in, h1_out, h2_out, H);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+// greedy step: word = argmax_v logits[n][v] (first maximum), lp = its log-softmax value (caption_module.py:367-371)
+__global__ __launch_bounds__(BS_T) void td_greedy_select_kernel(const float *__restrict__ logits, int V, long long *__restrict__ word, float *__restrict__ lp) {
+    __shared__ float red[BS_T];
+    __shared__ int redi[BS_T];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float *x = logits + (long long)n * V;
+    float m = -INFINITY; int mi = 0x7FFFFFFF;
+    for (int v = tid; v < V; v += BS_T) if (x[v] > m) { m = x[v]; mi = v; }
+    red[tid] = m; redi[tid] = mi; __syncthreads();
+    for (int o = BS_T / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float ov = red[tid + o]; const int oi = redi[tid + o];
+            if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) { red[tid] = ov; redi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    m = red[0]; mi = redi[0]; __syncthreads();
+    float sm = 0.f;
+    for (int v = tid; v < V; v += BS_T) sm += expf(x[v] - m);
+    red[tid] = sm; __syncthreads();
+    for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { word[n] = mi; lp[n] = (x[mi] - m) - logf(red[0]); }
+}
+extern "C" int d3_greedy_select(const float *logits, int N, int V, long long *word, float *lp, void *stream) {
+    D3_CLEAR();
+    if (N <= 0) return 0;
+    if (V < 1) return D3_ERR_ARG;
+    td_greedy_select_kernel<<<N, BS_T, 0, d3_stream(stream)>>>(logits, V, word, lp);
+    D3_LAUNCH_CHECK();
+    return 0;
+}

@@ -482,11 +482,16 @@ class TopDownSceneCaptionModule(nn.Module):
         outs, lps = [], []
         if self.native and target_feats.is_cuda:
             dec = _NativeDecoder(self, target_feats, obj_feats, valid_masks.reshape(N, -1))
-            for _ in range(max_len):
-                logits, _ = dec.step(word)
-                lp, word = F.log_softmax(logits, dim=-1).max(-1)
-                outs.append(word.unsqueeze(1)); lps.append(lp.unsqueeze(1))
-            return self.trim_outputs(torch.cat(outs, 1).unsqueeze(1), torch.cat(lps, 1).unsqueeze(1))
+            # arg-max + its log-softmax value in one launch per step (d3_greedy_select), written straight into the (N, max_len) outputs
+            L = _lib.lib()
+            words = torch.empty(max_len, N, dtype=torch.long, device=target_feats.device)
+            lpa = torch.empty(max_len, N, dtype=torch.float32, device=target_feats.device)
+            with _on(target_feats.device):
+                for t in range(max_len):
+                    logits, _ = dec.step(word)
+                    check(L.d3_greedy_select(_ptr(logits), N, logits.shape[1], _ptr(words[t]), _ptr(lpa[t]), _stream()), "greedy_select")
+                    word = words[t]
+            return self.trim_outputs(words.t().contiguous().unsqueeze(1), lpa.t().contiguous().unsqueeze(1))
         hiddens = (target_feats.new_zeros(N, self.hidden_size), target_feats.new_zeros(N, self.hidden_size))
         proj = self.map_feat(obj_feats)
         for _ in range(max_len):
@@ -579,35 +584,34 @@ class TopDownSceneCaptionModule(nn.Module):
                                  vm.repeat_interleave(b, dim=0), obj_div=b)
             word = torch.full((N * b,), sos, dtype=torch.long, device=dev)
             logits, _ = dec.step(word)
-            logp = F.log_softmax(logits.view(N, b, V)[:, :1], dim=-1)        # t = 0: a single live beam per sample (:176-179)
-            base = torch.arange(N, device=dev).unsqueeze(1) * b
-            sums = target_feats.new_zeros(N, 1)
-            seq = torch.zeros(N, b, 0, dtype=torch.long, device=dev)
+            # One launch per step selects (csrc/topdown.hip d3_beam_select: log_softmax, the b best of live * V candidates best
+            # first -- what the reference's full descending sort keeps (:181-182); an exact tie between two candidates' float scores
+            # is the only way the two could order differently --, token histories, running sums with the -1000 penalty of finished
+            # beams (:300), ended flags, and the re-ordering of the hidden states: rows are (sample, beam slot)); ~25 library
+            # launches per step before round 4.
+            L = _lib.lib()
+            H = dec.h1[0].shape[1]
             allseq = torch.zeros(max_len, N, b, max_len, dtype=torch.long, device=dev)   # every step's beams, zero padded
-            snaps = []
-            for t in range(max_len):
-                live = logp.shape[1]
-                cand = (sums.unsqueeze(-1) + logp).reshape(N, live * V)
-                # the b best of the live*V candidates, best first: what the reference's full descending sort (:181-182) keeps
-                # (an exact tie between two candidates' float scores is the only way the two could order differently)
-                ix = torch.topk(cand, b, dim=-1, largest=True, sorted=True)[1]
-                beam_ix, tok = ix // V, ix % V
-                if t > 0:
-                    seq = seq.gather(1, beam_ix.unsqueeze(-1).expand_as(seq))
-                chosen = logp.reshape(N, live * V).gather(1, ix)
-                seq = torch.cat([seq, tok.unsqueeze(-1)], -1)
-                sums = sums.gather(1, beam_ix) + chosen
-                ended = (tok == eos) if t < max_len - 1 else torch.ones_like(tok, dtype=torch.bool)
-                allseq[t, :, :, :t + 1] = seq
-                snaps.append((None, sums.clone(), ended))
-                sums = sums - 1000.0 * ended.to(sums.dtype)                 # finished beams stay, heavily penalised (:300)
-                if t == max_len - 1:
-                    break
-                state_ix = (base + beam_ix).reshape(-1)                     # rows are (sample, beam slot)
-                dec.h1[0], dec.h2[0] = dec.h1[0].index_select(0, state_ix), dec.h2[0].index_select(0, state_ix)
-                logits, _ = dec.step(tok.reshape(-1))
-                logp = F.log_softmax(logits, dim=-1).view(N, b, V)
-            P = torch.stack([torch.where(e, p_, torch.full_like(p_, float("-inf"))) for (_, p_, e) in snaps], 1).reshape(N, -1)
+            snap_all = torch.empty(max_len, N, b, dtype=torch.float32, device=dev)
+            ended_all = torch.empty(max_len, N, b, dtype=torch.uint8, device=dev)
+            sums = [torch.zeros(N, b, dtype=torch.float32, device=dev), torch.empty(N, b, dtype=torch.float32, device=dev)]
+            tok = torch.empty(N * b, dtype=torch.long, device=dev)
+            h1_sp, h2_sp = torch.empty_like(dec.h1[0]), torch.empty_like(dec.h2[0])
+            live = 1                                                          # t = 0: a single live beam per sample (:176-179)
+            with _on(dev):
+                for t in range(max_len):
+                    lastf = int(t == max_len - 1)
+                    check(L.d3_beam_select(_ptr(logits), _ptr(sums[0]), N, live, b, V, eos, lastf, t, max_len,
+                                           _ptr(allseq[t - 1]) if t > 0 else None, _ptr(allseq[t]), _ptr(tok), _ptr(snap_all[t]), _ptr(ended_all[t]),
+                                           _ptr(sums[1]), _ptr(dec.h1[0]), _ptr(dec.h2[0]), _ptr(h1_sp), _ptr(h2_sp), H, _stream()), "beam_select")
+                    sums.reverse()
+                    dec.h1[0], h1_sp = h1_sp, dec.h1[0]       # (the re-ordered states are the decoder's current ones)
+                    dec.h2[0], h2_sp = h2_sp, dec.h2[0]
+                    live = b
+                    if lastf:
+                        break
+                    logits, _ = dec.step(tok)
+            P = torch.where(ended_all.bool(), snap_all, torch.full_like(snap_all, float("-inf"))).permute(1, 0, 2).reshape(N, -1)
             keep = b if topn is None else min(topn, b)
             order = torch.sort(P, dim=1, descending=True, stable=True)[1][:, :b].cpu()
             Pc = P.cpu()

@@ -551,6 +551,18 @@ int d3_topdown_step(const d3_topdown_args *a, const long long *word, const float
                     const float *h2_in, float *h1_out, float *h2_out, float *logits, float *attn, void *ws, size_t ws_bytes,
                     void *stream);
 
+/* Selection step of the sampling loops around d3_topdown_step (beam search: model/caption_module.py:136-349; greedy: :350-383) in
+ * one launch each: log_softmax, candidate scores sums + logp, the b best of live * V candidates best first (ties: lower flat
+ * index), beam_ix / tok / chosen log-prob / running sums (snapshot and the -1000 penalised continuation, :300) / ended flags, the
+ * token histories of the chosen beams (seq_out[n][r][:t] = seq_prev[n][beam_ix][:t], seq_out[n][r][t] = tok; rows of Tmax int64)
+ * and the re-ordering of the two hidden states (h*_out row n*b + r = h*_in row n*b + beam_ix; h1_in NULL: skipped).
+ * logits (N*b, V): row n*b + j = live beam j of sample n (live = 1 at t = 0); sums_in (N, live).  b <= 8.
+ * d3_greedy_select: word[n] = first arg-max of logits[n], lp[n] = its log-softmax value. */
+int d3_beam_select(const float *logits, const float *sums_in, int N, int live, int b, int V, int eos, int last, int t, int Tmax,
+                   const long long *seq_prev, long long *seq_out, long long *tok_out, float *snap_out, unsigned char *ended_out,
+                   float *sums_out, const float *h1_in, const float *h2_in, float *h1_out, float *h2_out, int H, void *stream);
+int d3_greedy_select(const float *logits, int N, int V, long long *word, float *lp, void *stream);
+
 /* ---- packed-sequence GRU of the language encoder (csrc/topdown.hip) ---------------------------------------
  * nn.GRU(I -> H, batch_first=True) over pack_padded_sequence(x (N,T,I), lens (N)) as LangModule runs it
  * (model/lang_module.py:51-55, 146-150; torch gate order r, z, n): hiddens (N,T,H) zero beyond a sample's length, last (N,H)

@@ -288,3 +288,59 @@ def test_local_context_mask_kernel_equals_topk_scatter(dev):
         assert torch.equal(a * valid_cols, b * valid_cols)            # identical wherever a valid proposal is concerned
         full = (b * valid_cols).sum(-1) == L
         assert torch.equal(a[full], b[full])                           # rows decided without ties: identical masks
+
+
+def test_beam_and_greedy_selection_kernels_match_the_library_formulation(dev):
+    """csrc/topdown.hip d3_beam_select / d3_greedy_select (round 4: one launch per decode step) against the ~25 library ops they
+    replace (log_softmax, candidate sums, the b best of live * V best first, gathers of histories / running sums / hidden states,
+    the -1000 penalty of finished beams: model/caption_module.py:176-307,367-371).  Integers identical; floats to 1e-6."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from d3net_amd import _lib
+    L = _lib.lib()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N, b, V, H, Tmax, eos = 7, 3, 3004, 64, 6, 3
+    g = torch.Generator().manual_seed(4)
+    seq_prev = torch.zeros(N, b, Tmax, dtype=torch.long, device=dev)
+    sums = torch.zeros(N, b, device=dev)
+    for t in range(4):
+        live = 1 if t == 0 else b
+        logits = (torch.randn(N * b, V, generator=g) * 3).to(dev)
+        logits[:, eos] += 6.0 * (t >= 2)                                    # some beams end
+        h1, h2 = torch.randn(N * b, H, generator=g).to(dev), torch.randn(N * b, H, generator=g).to(dev)
+        last = int(t == 3)
+        # library formulation
+        logp = F.log_softmax(logits.view(N, b, V)[:, :live], dim=-1)
+        cand = (sums[:, :live].unsqueeze(-1) + logp).reshape(N, live * V)
+        ix = torch.sort(cand, -1, True, stable=True)[1][:, :b]
+        beam_ix, tok = ix // V, ix % V
+        chosen = logp.reshape(N, live * V).gather(1, ix)
+        snap = sums[:, :live].gather(1, beam_ix) + chosen
+        ended = (tok == eos) if not last else torch.ones_like(tok, dtype=torch.bool)
+        seq = torch.cat([seq_prev[:, :, :t].gather(1, beam_ix.unsqueeze(-1).expand(N, b, t)), tok.unsqueeze(-1)], -1)
+        base = torch.arange(N, device=dev).unsqueeze(1) * b
+        sel = (base + beam_ix).reshape(-1)
+        # kernel
+        seq_out = torch.zeros(N, b, Tmax, dtype=torch.long, device=dev)
+        tok_k = torch.empty(N * b, dtype=torch.long, device=dev)
+        snap_k, sums_k = torch.empty(N, b, device=dev), torch.empty(N, b, device=dev)
+        ended_k = torch.empty(N, b, dtype=torch.uint8, device=dev)
+        h1o, h2o = torch.empty_like(h1), torch.empty_like(h2)
+        sums_in = sums if t > 0 else torch.zeros(N, b, device=dev)
+        rc = L.d3_beam_select(ptr(logits), ptr(sums_in), N, live, b, V, eos, last, t, Tmax, ptr(seq_prev) if t > 0 else None, ptr(seq_out), ptr(tok_k),
+                              ptr(snap_k), ptr(ended_k), ptr(sums_k), ptr(h1), ptr(h2), ptr(h1o), ptr(h2o), H, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(tok_k.view(N, b), tok), t
+        assert torch.equal(seq_out[:, :, :t + 1], seq), t
+        assert torch.equal(ended_k.bool(), ended)
+        assert torch.allclose(snap_k, snap, rtol=1e-6, atol=1e-5)
+        assert torch.allclose(sums_k, snap - 1000.0 * ended.float(), rtol=1e-6, atol=1e-4)
+        assert torch.equal(h1o, h1.index_select(0, sel)) and torch.equal(h2o, h2.index_select(0, sel))
+        seq_prev, sums = seq_out, sums_k
+    logits = (torch.randn(33, V, generator=g) * 2).to(dev)
+    word, lp = torch.empty(33, dtype=torch.long, device=dev), torch.empty(33, device=dev)
+    assert L.d3_greedy_select(ptr(logits), 33, V, ptr(word), ptr(lp), st) == 0
+    rl, rw = F.log_softmax(logits, dim=-1).max(-1)
+    assert torch.equal(word, rw) and torch.allclose(lp, rl, rtol=1e-6, atol=1e-6)
