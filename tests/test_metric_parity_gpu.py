@@ -21,6 +21,7 @@ times and reports -- on 128 held-out scenes (768 GT boxes) for three training se
 (`minkowski.set_exact`, fp32 MFMA) on seed 0; the oracle's mAP@0.5 is required inside (0.3, 0.95) and its CIDEr@0.5IoU > 0.2
 so that equality is not 0 == 0 or 1 == 1.
 """
+import os
 import types
 
 import numpy as np
@@ -240,19 +241,30 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
     orc = PointGroupOracle(cfg, det_sd, training=False)
     calc = ev.APCalculator(0.5)
     cands, nprop = {}, 0
-    torch.set_num_threads(min(16, torch.get_num_threads()))
-    with torch.no_grad():
-        for b in val_batches:
+    # the oracle evaluates the held-out batches on the host: four batches at a time on worker threads (the torch / numpy / C-oracle
+    # calls release the GIL), four intra-op threads each; results are folded in batch order
+    from concurrent.futures import ThreadPoolExecutor
+    torch.set_num_threads(4)
+
+    def oracle_batch(b):
+        with torch.no_grad():
             host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()}
             od = orc.feed(host, 0, rand=host["cluster_rand"], perms=host["slot_perms"])
             od.update(_gt_keys(host))
-            calc.step(ev.parse_predictions(od), ev.parse_groundtruths(od))
-            nprop += int(od["proposal_batch_mask"].sum())
+            parsed = (ev.parse_predictions(od), ev.parse_groundtruths(od))
+            n = int(od["proposal_batch_mask"].sum())
             od.update(spo.graph_module(gp, od, cfg.model.num_graph_steps, cfg.model.num_locals))
             out = spo.forward_scene_batch(cp, od, cfg, cfg.model.max_num_proposal, cfg.model.num_locals, vocab["word2idx"]["sos"])
             od["lang_cap"] = out["lang_cap"]
             od["gt_bbox"] = host["gt_bbox"]          # (the language batch's gt_bbox: same corners, lib/dataset/pipeline.py:300)
-            cands.update(eval_caption_step(od, vocab))
+            return parsed, n, eval_caption_step(od, vocab)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        for parsed, n, cand in pool.map(oracle_batch, val_batches):
+            calc.step(*parsed)
+            nprop += n
+            cands.update(cand)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     spo.TIE_RULE = "topk"
     bleu, cider, rouge, _ = eval_caption_epoch(cands, raw_val, max_len=cfg.eval.max_des_len + 2, min_iou=cfg.eval.min_iou_threshold)
     res["oracle"] = dict(mAP=calc.compute_metrics()["mAP"], cider=float(cider[0]), bleu4=float(bleu[0][3]), proposals=nprop, cands=cands)

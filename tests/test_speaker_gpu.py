@@ -313,7 +313,7 @@ def test_beam_and_greedy_selection_kernels_match_the_library_formulation(dev):
         # library formulation
         logp = F.log_softmax(logits.view(N, b, V)[:, :live], dim=-1)
         cand = (sums[:, :live].unsqueeze(-1) + logp).reshape(N, live * V)
-        ix = torch.sort(cand, -1, True, stable=True)[1][:, :b]
+        ix = torch.sort(cand, dim=-1, descending=True, stable=True)[1][:, :b]
         beam_ix, tok = ix // V, ix % V
         chosen = logp.reshape(N, live * V).gather(1, ix)
         snap = sums[:, :live].gather(1, beam_ix) + chosen
