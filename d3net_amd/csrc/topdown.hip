@@ -1107,20 +1107,20 @@ __global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__res
         if (tid == 0) { s_max[j] = m; s_lse[j] = logf(red[0]); s_sum[j] = sums_in[(long long)n * live + j]; }
         __syncthreads();
     }
-    // (b) the b best candidates, best first: b block-wide arg-max passes (a picked candidate is skipped by later passes)
+    // (b) candidate scores staged in LDS once, then b block-wide arg-max passes over the LDS copy (a picked candidate is struck out)
+    extern __shared__ float cs[];                     // live * V floats
+    for (int j = 0; j < live; j++) {
+        const float *x = logits + ((long long)n * b + j) * V;
+        const float mj = s_max[j], lj = s_lse[j], sj = s_sum[j];
+        for (int v = tid; v < V; v += BS_T) cs[j * V + v] = sj + ((x[v] - mj) - lj);
+    }
+    __syncthreads();
+    const int total = live * V;
     for (int r = 0; r < b; r++) {
         float bv = -INFINITY; int bi = 0x7FFFFFFF;
-        for (int j = 0; j < live; j++) {
-            const float *x = logits + ((long long)n * b + j) * V;
-            const float mj = s_max[j], lj = s_lse[j], sj = s_sum[j];
-            for (int v = tid; v < V; v += BS_T) {
-                const int flat = j * V + v;
-                bool taken = false;
-                for (int q = 0; q < r; q++) taken |= (s_pick[q] == flat);
-                if (taken) continue;
-                const float c = sj + ((x[v] - mj) - lj);
-                if (c > bv || (c == bv && flat < bi)) { bv = c; bi = flat; }
-            }
+        for (int flat = tid; flat < total; flat += BS_T) {
+            const float c = cs[flat];
+            if (c > bv) { bv = c; bi = flat; }            // (ascending flat per thread: the first maximum wins)
         }
         red[tid] = bv; redi[tid] = bi; __syncthreads();
         for (int o = BS_T / 2; o > 0; o >>= 1) {
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__res
             }
             __syncthreads();
         }
-        if (tid == 0) { s_pick[r] = redi[0]; s_pickv[r] = red[0]; }
+        if (tid == 0) { s_pick[r] = redi[0]; s_pickv[r] = red[0]; cs[redi[0]] = -INFINITY; }
         __syncthreads();
     }
     // (c) outputs
@@ -1163,7 +1163,17 @@ extern "C" int d3_beam_select(const float *logits, const float *sums_in, int N, 
     D3_CLEAR();
     if (N <= 0) return 0;
     if (live < 1 || live > b || b < 1 || b > 8 || V < 1 || t < 0 || t >= Tmax || (t > 0 && !seq_prev)) return D3_ERR_ARG;
-    td_beam_select_kernel<<<N, BS_T, 0, d3_stream(stream)>>>(logits, sums_in, live, b, V, eos, last, t, Tmax, seq_prev, seq_out, tok_out, snap_out, ended_out,
+    const size_t lds = (size_t)live * V * sizeof(float);
+    if (lds > 60 * 1024) {        // (b = 8 beams over a 3004-word vocabulary: 94 KB)
+        static bool attr_done[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_done[dev]) {
+            D3_CHECK(hipFuncSetAttribute((const void *)td_beam_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+        if (lds > 150 * 1024) return D3_ERR_ARG;
+    }
+    td_beam_select_kernel<<<N, BS_T, lds, d3_stream(stream)>>>(logits, sums_in, live, b, V, eos, last, t, Tmax, seq_prev, seq_out, tok_out, snap_out, ended_out,
                                                              sums_out, h1_in, h2_in, h1_out, h2_out, H);
     D3_LAUNCH_CHECK();
     return 0;
