@@ -171,13 +171,13 @@ class PointGroup(nn.Module):
         if not (self.native_unet and voxel_locs.is_cuda and voxel_locs.size(0) > 0) or (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)):
             return None
         cm = ME.CoordinateManager(voxel_locs.int().contiguous())
-        cm.begin_pyramid(self._exec(name, exact=ME._EXACT).nlevels)
+        cm.begin_pyramid(self._exec(name, exact=ME.exact_for(self.training)).nlevels)
         return cm
 
     def _run_unet(self, name, module, x):
         """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""
         if self.native_unet and not (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)) and x.F.size(0) > 0:
-            return self._exec(name, exact=ME._EXACT)(x.F, x.coordinate_manager, self.training)
+            return self._exec(name, exact=ME.exact_for(self.training))(x.F, x.coordinate_manager, self.training)
         return module(x).features
 
     def static_gradient_buckets(self):
