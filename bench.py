@@ -694,7 +694,7 @@ def main():
             "metric_parity": {"policy": "training steps (this line's value) run bf16 MFMA operands; evaluation -- every mAP / CIDEr the library reports -- runs "
                                         "the reference-precision kernels (d3net_amd/minkowski.py exact_for; DESIGN.md 5.1)",
                               "asserted": "tests/test_metric_parity_gpu.py: 128 held-out scenes x 3 training seeds, evaluation path within 0.5 % of the fp32 CPU "
-                                          "oracle on mAP@0.5 and CIDEr@0.5IoU; bf16 kernels forced onto evaluation: measured +0.04 / -0.21 / -0.19 / -1.70 % CIDEr "
+                                          "oracle on mAP@0.5 and CIDEr@0.5IoU; bf16 kernels forced onto evaluation: measured +0.04 / -0.21 / -0.19 / -0.12 / -1.70 / +0.12 % CIDEr over six trained models "
                                           "(reported, bound 3 %)",
                               "same_step_at_reference_precision": "fp32_exact"},
         }

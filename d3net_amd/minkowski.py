@@ -56,8 +56,8 @@ _HG_X3_DEFAULT = None
 # EVALUATION (module.eval(): validation_step, forward(), every reported mAP / CIDEr / Acc) runs the reference-precision kernels by
 # default.  Why: a bf16 forward perturbs the 16-dim proposal features by ~1e-2, which flips ~1 % of the greedy caption tokens and an
 # occasional IoU-0.5 decision -- discrete events whose effect on CIDEr@0.5IoU over 768 held-out captions was measured at +0.04 /
-# -0.21 / -0.19 / -1.70 % for four trained models: not inside the north star's 0.5 % with any margin, while the fp32 kernels are
-# (0 / 0 / -0.16 %).  An inference pass has no backward, so fp32 costs ~1.6x a bf16 forward there and nothing in the training step.
+# -0.21 / -0.19 / -0.12 / -1.70 / +0.12 % for six trained models: not inside the north star's 0.5 % with any margin, while the fp32 kernels are
+# (identical metrics on the final tree).  An inference pass has no backward, so fp32 costs ~1.6x a bf16 forward there and nothing in the training step.
 # D3_EVAL_BF16=1 (or set_eval_exact(False)) evaluates with the bf16 kernels.
 import os as _os
 _EVAL_EXACT = _os.environ.get("D3_EVAL_BF16", "0") != "1"

@@ -289,11 +289,11 @@ def test_heldout_map_and_cider_parity_with_the_fp32_oracle(dev, seed):
     Precision policy under test (d3net_amd/minkowski.py `exact_for`): training steps run bf16 MFMA operands; evaluation -- every
     mAP / CIDEr the library reports: `validation_step`, `forward()` under `eval()` -- runs the reference-precision kernels.
       * the evaluation path AS SHIPPED must meet BASELINE.json's bound: mAP@0.5 and CIDEr@0.5IoU within 0.5 % of the fp32 CPU oracle
-        on the same weights and scenes, for every seed (measured: mAP identical; CIDEr 0 / 0 / -0.16 %; 767 - 768 of 768 captions);
+        on the same weights and scenes, for every seed (measured on the final tree: mAP and CIDEr identical to five digits; 766 / 768 / 768 of 768 captions);
       * the bf16 kernels forced onto the evaluation are REPORTED and held to a looser bound (mAP 1 %, CIDEr 3 %): a bf16 forward
         perturbs the 16-dim proposal features by ~1e-2, ~1 % of the greedy captions change a token and an occasional box crosses
-        IoU 0.5 -- discrete events worth 0.15 - 0.4 % of CIDEr each.  Four trained models measured +0.04 / -0.21 / -0.19 / -1.70 %
-        (757 - 763 of 768 captions identical): not inside 0.5 % with any margin, which is why evaluation does not use them.
+        IoU 0.5 -- discrete events worth 0.15 - 0.4 % of CIDEr each.  Six trained models measured +0.04 / -0.21 / -0.19 / -0.12 / -1.70 / +0.12 %
+        (757 - 766 of 768 captions identical): not inside 0.5 % with any margin, which is why evaluation does not use them.
         A broken kernel (wrong neighbour table, wrong BatchNorm statistic) moves these by tens of percent.
     (the captioner trains at 1e-3, the detector at 4e-3: with ONE rate of 4e-3 the GRU captioner collapsed to the unigram
     distribution in 3 of 6 seeds -- the recipe, not the kernels)"""
