@@ -118,8 +118,9 @@ def _gt_keys(batch):
 
 
 def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3, seed=0, exact_too=True, verbose=True, with_oracle=True,
-               head_lr=None):
-    """train on the device, evaluate held-out scenes with the HIP path(s) and the CPU oracle -> dict of metrics"""
+               head_lr=None, train_exact=False):
+    """train on the device, evaluate held-out scenes with the HIP path(s) and the CPU oracle -> dict of metrics
+    (train_exact: the training steps run the reference-precision kernels instead of bf16 -- tools/train_precision_compare.py)"""
     from d3net_amd import synthetic as S, minkowski as ME, evaluator as ev
     from d3net_amd.caption_eval import eval_caption_step, eval_caption_epoch
     from d3net_amd.config import default_conf
@@ -160,6 +161,7 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
     # denoise through its receptive field instead of memorising 16 fixed noise patterns; held-out scenes keep theirs fixed
     clean = [torch.nn.functional.one_hot(b["sem_labels"].clamp(0, 19), 20).float() for b in train_batches]
     gen = torch.Generator(device=dev).manual_seed(seed + 1)
+    ME.set_exact(bool(train_exact))
     for it in range(steps):
         net.zero_grad(set_to_none=True)
         tb = dict(train_batches[it % len(train_batches)])
@@ -179,6 +181,7 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
             print("step %d: loss %.3f (detector %.3f, semantic %.3f, caption %.3f, cap_acc %.3f, object-point acc %.3f)" %
                   (it, float(loss.detach()), float(d["total_loss"][0].detach()), float(d["semantic_loss"][0].detach()), float(d["cap_loss"].detach()),
                    float(d["cap_acc"]), acc))
+    ME.set_exact(False)
     torch.cuda.synchronize()
     if verbose:      # diagnostics: how well does the detector do on the held-out scenes, train-mode vs eval-mode BatchNorm
         saved = {k: v.clone() for k, v in net.named_buffers()}       # (a train-mode forward updates the running statistics)
