@@ -44,6 +44,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_HG_BF16X3", 0},            // 1: the tall heads GEMMs as a bf16 x 3 split (hg_gemm_tiled3_kernel) instead of exact fp32 MFMA -- measured round 4: the 64 x 64 tile is L2-bound, not MFMA-bound (152 -> 140 us per launch in the joint step, 26 -> 23 us in the speaker step): not adopted, the heads stay exact fp32
     {"D3_BN_FUSED_BIG", 1},         // 0: only BatchNorms of at most D3_BN_FUSED_ROWS rows run as one launch; the big levels keep finalize + apply
     {"D3_HG_CLASS_SPLIT", 1},       // 0: a batched heads GEMM launch always runs the kernel its largest problem asks for (rounds 1-3)
+    {"D3_HG_SPLITK", 256},          // largest number of 16 x 16 output tiles of a deep (K >= 8192) heads GEMM whose reduction is cut over 4 workgroups; 0: never
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

@@ -121,6 +121,53 @@ def test_kmajor_operands_and_batched_problems(dev):
     _close(out, a.double() @ Bm.double().t(), V)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 12288), (128, 128, 8195), (256, 128, 8192), (64, 30, 16382)])
+def test_deep_reduction_cut_over_workgroups(dev, M, N, K):
+    """dW = dy^T x of the listener's projections (model/match_module.py:31-47 backward: K = proposals x batch): the reduction
+    is cut into 4 slices + an epilogue launch (D3_HG_SPLITK); the same problem with the switch off is the comparison, and
+    every epilogue option is exercised on the split form (bias, add, ReLU, accumulate, row permutation, batched with a
+    shallow problem in the same call)"""
+    from d3net_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(K)
+    dy, x = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g) / np.sqrt(K)
+    b, add = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    dyd, xd, bd, addd = dy.to(dev), x.to(dev), b.to(dev), add.to(dev)
+    ref = dy.double().t() @ x.double()
+    outs = {}
+    for cap in (0, 256):
+        L.d3_tuning_set(b"D3_HG_SPLITK", cap)
+        try:
+            out = torch.full((M, N), float("nan"), device=dev)
+            small = torch.full((48, N), float("nan"), device=dev)
+            _run([_prob([_seg(dyd, xd, K, a_km=True, b_km=True)], M, N, out, bias=bd, add=addd, relu=True),
+                  _prob([_seg(dyd[:64].t().contiguous()[:48], xd[:64], 64, b_km=True)], 48, N, small)])
+            _close(out, torch.relu(ref + b.double() + add.double()), K)
+            _close(small, dy[:64].double().t()[:48] @ x[:64].double(), 64)
+            acc = addd.clone()
+            _run([_prob([_seg(dyd, xd, K, a_km=True, b_km=True)], M, N, acc, accum=True)])
+            _close(acc, ref + add.double(), K)
+            if M % 4 == 0:
+                pm = torch.full((M, N), float("nan"), device=dev)
+                _run([_prob([_seg(dyd, xd, K, a_km=True, b_km=True)], M, N, pm, perm=(4, M // 4))])
+                _close(pm, ref.view(M // 4, 4, N).transpose(0, 1).reshape(M, N), K)
+            # row-major operands (x W^T over a long feature axis)
+            a2 = dy.t().contiguous().to(dev); b2 = x.t().contiguous().to(dev)
+            o2 = torch.full((M, N), float("nan"), device=dev)
+            _run([_prob([_seg(a2, b2, K)], M, N, o2)])
+            _close(o2, ref, K)
+            outs[cap] = (out.cpu(), o2.cpu())
+        finally:
+            L.d3_tuning_set(b"D3_HG_SPLITK", 256)
+    # two summation orders of the same products
+    assert float((outs[0][0] - outs[256][0]).abs().max()) < 1e-4 * float(ref.abs().max())
+    # deterministic: the slices are added in slice order
+    L.d3_tuning_set(b"D3_HG_SPLITK", 256)
+    again = torch.full((M, N), float("nan"), device=dev)
+    _run([_prob([_seg(dyd, xd, K, a_km=True, b_km=True)], M, N, again, bias=bd, add=addd, relu=True)])
+    assert torch.equal(again.cpu(), outs[256][0])
+
+
 def test_colsum(dev):
     from d3net_amd import _lib
     x = torch.randn(992, 1536)
