@@ -25,7 +25,7 @@ for a in sys.argv[1:]:
     elif not a.startswith("--"):
         args.append(a)
 config = args[0]
-# NAME=a,b flips one switch; NAME1+NAME2=a,b flips several together (arm values per switch: a:b pairs joined by '/', e.g.
+# NAME=a,b flips one switch (py:module.ATTR=a,b a host-side module attribute); NAME1+NAME2=a,b flips several together (arm values per switch: a:b pairs joined by '/', e.g.
 # D3_KMAP16+D3_BN_FUSED_ROWS=0/0,1/16384)
 switches = []
 for a in args[1:]:
@@ -68,6 +68,18 @@ def step():
 
 
 L = _lib.lib()
+
+
+def set_switch(nm, x):
+    """a library switch (D3_*: d3_tuning_set) or a module attribute of the host side (py:d3net_amd.speaker.CONCURRENT_DECODES)"""
+    if nm.startswith("py:"):
+        import importlib
+        mod, attr = nm[3:].rsplit(".", 1)
+        setattr(importlib.import_module(mod), attr, x)
+    else:
+        assert L.d3_tuning_set(nm.encode(), x) == 0, nm
+
+
 for _ in range(40):
     step()
 torch.cuda.synchronize()
@@ -80,7 +92,7 @@ for names, arms in switches:
     for r in range(rounds):
         for v in (vals if r % 2 == 0 else vals[::-1]):
             for nm, x in zip(names, arms[v]):
-                assert L.d3_tuning_set(nm.encode(), x) == 0, nm
+                set_switch(nm, x)
             for _ in range(4):
                 step()
             torch.cuda.synchronize()
@@ -90,6 +102,6 @@ for names, arms in switches:
             torch.cuda.synchronize()
             res[v].append(1e3 * (time.perf_counter() - t0) / block)
     for nm, x in zip(names, arms[-1]):
-        L.d3_tuning_set(nm.encode(), x)
+        set_switch(nm, x)
     print("%s (%s): " % (name, config) + "   ".join("%s -> %.3f ms (median %.3f, min %.3f)" % ("/".join(map(str, arms[v])), statistics.mean(res[v]), statistics.median(res[v]), min(res[v]))
                                                     for v in vals), flush=True)
