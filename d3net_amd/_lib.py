@@ -127,6 +127,9 @@ SIGNATURES = {
     "d3_topdown_step": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "d3_beam_select": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "d3_greedy_select": (i32, [vp, i32, i32, vp, vp, vp]),
+    "d3_topdown_greedy": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp, i32, vp, vp, vp]),
+    "d3_topdown_beam": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, sz, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "d3_topdown_beam_greedy": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, sz, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "d3_gru_seq_ws_bytes": (sz, [i32, i32, i32, i32]),
     "d3_gru_seq_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
     "d3_gru_seq_forward": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),

@@ -1079,7 +1079,7 @@ extern "C" int d3_gru_seq_backward(const float *x, const int *lens, const float 
 //   sums_out = snap - 1000 * ended (caption_module.py:300), seq_out[n][r][:t] = seq_prev[n][beam_ix][:t], seq_out[n][r][t] = tok,
 //   and the two hidden states of row n*b + r are those of row n*b + beam_ix (the re-ordering of :305-307).
 #define BS_T 256
-__global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__restrict__ logits, const float *__restrict__ sums_in, int live, int b, int V,
+__device__ __forceinline__ void td_beam_select_body(const int n, const int rs, const float *__restrict__ logits, const float *__restrict__ sums_in, int live, int b, int V,
                                                              int eos, int last, int t, int Tmax, const long long *__restrict__ seq_prev,
                                                              long long *__restrict__ seq_out, long long *__restrict__ tok_out,
                                                              float *__restrict__ snap_out, unsigned char *__restrict__ ended_out,
@@ -1091,10 +1091,10 @@ __global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__res
     __shared__ float s_max[8], s_lse[8], s_sum[8];
     __shared__ int s_pick[8];
     __shared__ float s_pickv[8];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     // (a) per live beam: max and log-sum-exp
     for (int j = 0; j < live; j++) {
-        const float *x = logits + ((long long)n * b + j) * V;
+        const float *x = logits + ((long long)n * rs + j) * V;
         float m = -INFINITY;
         for (int v = tid; v < V; v += BS_T) m = fmaxf(m, x[v]);
         red[tid] = m; __syncthreads();
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__res
     // (b) candidate scores staged in LDS once, then b block-wide arg-max passes over the LDS copy (a picked candidate is struck out)
     extern __shared__ float cs[];                     // live * V floats
     for (int j = 0; j < live; j++) {
-        const float *x = logits + ((long long)n * b + j) * V;
+        const float *x = logits + ((long long)n * rs + j) * V;
         const float mj = s_max[j], lj = s_lse[j], sj = s_sum[j];
         for (int v = tid; v < V; v += BS_T) cs[j * V + v] = sj + ((x[v] - mj) - lj);
     }
@@ -1136,11 +1136,11 @@ __global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__res
     // (c) outputs
     if (tid < b) {
         const int flat = s_pick[tid], j = flat / V, v = flat - j * V;
-        const float chosen = (logits[((long long)n * b + j) * V + v] - s_max[j]) - s_lse[j];
+        const float chosen = (logits[((long long)n * rs + j) * V + v] - s_max[j]) - s_lse[j];
         const float snap = s_sum[j] + chosen;
         const bool ended = last || v == eos;
         const long long o = (long long)n * b + tid;
-        tok_out[o] = v; snap_out[o] = snap; ended_out[o] = ended ? 1 : 0; sums_out[o] = snap - 1000.0f * (ended ? 1.f : 0.f);
+        tok_out[(long long)n * rs + tid] = v; snap_out[o] = snap; ended_out[o] = ended ? 1 : 0; sums_out[o] = snap - 1000.0f * (ended ? 1.f : 0.f);
         seq_out[o * Tmax + t] = v;
     }
     for (int e = tid; e < b * t; e += BS_T) {          // histories of the chosen beams
@@ -1152,10 +1152,20 @@ __global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__res
         for (int e = tid; e < b * H; e += BS_T) {
             const int r = e / H, c = e - r * H;
             const int j = s_pick[r] / V;
-            h1_out[((long long)n * b + r) * H + c] = h1_in[((long long)n * b + j) * H + c];
-            h2_out[((long long)n * b + r) * H + c] = h2_in[((long long)n * b + j) * H + c];
+            h1_out[((long long)n * rs + r) * H + c] = h1_in[((long long)n * rs + j) * H + c];
+            h2_out[((long long)n * rs + r) * H + c] = h2_in[((long long)n * rs + j) * H + c];
         }
     }
+}
+__global__ __launch_bounds__(BS_T) void td_beam_select_kernel(const float *__restrict__ logits, const float *__restrict__ sums_in, int live, int b, int V,
+                                                             int eos, int last, int t, int Tmax, const long long *__restrict__ seq_prev,
+                                                             long long *__restrict__ seq_out, long long *__restrict__ tok_out,
+                                                             float *__restrict__ snap_out, unsigned char *__restrict__ ended_out,
+                                                             float *__restrict__ sums_out, const float *__restrict__ h1_in,
+                                                             const float *__restrict__ h2_in, float *__restrict__ h1_out,
+                                                             float *__restrict__ h2_out, int H) {
+    td_beam_select_body(blockIdx.x, b, logits, sums_in, live, b, V, eos, last, t, Tmax, seq_prev, seq_out, tok_out, snap_out, ended_out, sums_out, h1_in,
+                        h2_in, h1_out, h2_out, H);
 }
 extern "C" int d3_beam_select(const float *logits, const float *sums_in, int N, int live, int b, int V, int eos, int last, int t, int Tmax,
                               const long long *seq_prev, long long *seq_out, long long *tok_out, float *snap_out, unsigned char *ended_out,
@@ -1179,11 +1189,11 @@ extern "C" int d3_beam_select(const float *logits, const float *sums_in, int N, 
     return 0;
 }
 // greedy step: word = argmax_v logits[n][v] (first maximum), lp = its log-softmax value (caption_module.py:367-371)
-__global__ __launch_bounds__(BS_T) void td_greedy_select_kernel(const float *__restrict__ logits, int V, long long *__restrict__ word, float *__restrict__ lp) {
+__device__ __forceinline__ void td_greedy_select_body(const float *__restrict__ x, int V, long long *__restrict__ word, float *__restrict__ lp,
+                                                      long long *__restrict__ word2) {
     __shared__ float red[BS_T];
     __shared__ int redi[BS_T];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const float *x = logits + (long long)n * V;
+    const int tid = threadIdx.x;
     float m = -INFINITY; int mi = 0x7FFFFFFF;
     for (int v = tid; v < V; v += BS_T) if (x[v] > m) { m = x[v]; mi = v; }
     red[tid] = m; redi[tid] = mi; __syncthreads();
@@ -1199,13 +1209,148 @@ __global__ __launch_bounds__(BS_T) void td_greedy_select_kernel(const float *__r
     for (int v = tid; v < V; v += BS_T) sm += expf(x[v] - m);
     red[tid] = sm; __syncthreads();
     for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) { word[n] = mi; lp[n] = (x[mi] - m) - logf(red[0]); }
+    if (tid == 0) { *word = mi; *lp = (x[mi] - m) - logf(red[0]); if (word2) *word2 = mi; }
+}
+// rows n * rs + off of logits (rs = 1, off = 0: dense); word2 (optional): the token also goes to row n * rs + off of the next step's input
+__global__ __launch_bounds__(BS_T) void td_greedy_select_kernel(const float *__restrict__ logits, int V, long long *__restrict__ word, float *__restrict__ lp,
+                                                               int rs, int off, long long *__restrict__ word2) {
+    const long long row = (long long)blockIdx.x * rs + off;
+    td_greedy_select_body(logits + row * V, V, word + blockIdx.x, lp + blockIdx.x, word2 ? word2 + row : nullptr);
+}
+// one selection launch for the joined decode (d3_topdown_beam_greedy): workgroups [0, N) select the beams of sample n (rows n * rs ..
+// n * rs + b - 1), workgroups [N, 2N) the greedy row n * rs + b, whose hidden states are copied through (its row is not re-ordered)
+__global__ __launch_bounds__(BS_T) void td_beam_greedy_select_kernel(const float *__restrict__ logits, const float *__restrict__ sums_in, int N, int live, int b,
+                                                                    int V, int eos, int last, int t, int Tmax, const long long *__restrict__ seq_prev,
+                                                                    long long *__restrict__ seq_out, long long *__restrict__ tok_out,
+                                                                    float *__restrict__ snap_out, unsigned char *__restrict__ ended_out,
+                                                                    float *__restrict__ sums_out, const float *__restrict__ h1_in,
+                                                                    const float *__restrict__ h2_in, float *__restrict__ h1_out,
+                                                                    float *__restrict__ h2_out, int H, long long *__restrict__ g_word,
+                                                                    float *__restrict__ g_lp) {
+    const int rs = b + 1;
+    if ((int)blockIdx.x < N) {
+        td_beam_select_body(blockIdx.x, rs, logits, sums_in, live, b, V, eos, last, t, Tmax, seq_prev, seq_out, tok_out, snap_out, ended_out, sums_out, h1_in,
+                            h2_in, h1_out, h2_out, H);
+        return;
+    }
+    const int n = blockIdx.x - N;
+    const long long row = (long long)n * rs + b;
+    td_greedy_select_body(logits + row * V, V, g_word + n, g_lp + n, tok_out + row);
+    for (int c = threadIdx.x; c < H; c += BS_T) { h1_out[row * H + c] = h1_in[row * H + c]; h2_out[row * H + c] = h2_in[row * H + c]; }
 }
 extern "C" int d3_greedy_select(const float *logits, int N, int V, long long *word, float *lp, void *stream) {
     D3_CLEAR();
     if (N <= 0) return 0;
     if (V < 1) return D3_ERR_ARG;
-    td_greedy_select_kernel<<<N, BS_T, 0, d3_stream(stream)>>>(logits, V, word, lp);
+    td_greedy_select_kernel<<<N, BS_T, 0, d3_stream(stream)>>>(logits, V, word, lp, 1, 0, nullptr);
     D3_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- whole decodes in one call (round 4).  The loops around d3_topdown_step used to live on the host side of the boundary: two
+// library calls, two tensor allocations and their argument marshalling per time step, ~60 us of interpreter time per step against
+// ~30 us of launches -- and the self-critical step (model/caption_module.py:588-633) walks 61 such steps.  Same launches in the same
+// order, issued from here.
+// greedy (:350-383): h1_a / h2_a hold the initial (zero) states, words / lps are (max_len, N), first_word (N) is the sos row.
+extern "C" int d3_topdown_greedy(const d3_topdown_args *a, const float *fp, int obj_div, float *h1_a, float *h2_a, float *h1_b, float *h2_b,
+                                 float *logits, float *attn, void *ws, size_t ws_bytes, const long long *first_word, int max_len,
+                                 long long *words, float *lps, void *stream) {
+    if (!a || max_len < 1 || !first_word || !words || !lps) return D3_ERR_ARG;
+    const long long *w = first_word;
+    float *i1 = h1_a, *i2 = h2_a, *o1 = h1_b, *o2 = h2_b;
+    for (int t = 0; t < max_len; t++) {
+        int rc = d3_topdown_step(a, w, fp, obj_div, i1, i2, o1, o2, logits, attn, ws, ws_bytes, stream);
+        if (rc) return rc;
+        rc = d3_greedy_select(logits, a->N, a->V, words + (size_t)t * a->N, lps + (size_t)t * a->N, stream);
+        if (rc) return rc;
+        w = words + (size_t)t * a->N;
+        float *x = i1; i1 = o1; o1 = x;
+        x = i2; i2 = o2; o2 = x;
+    }
+    return 0;
+}
+// The two decodes of one self-critical step as ONE chain (model/caption_module.py:588-633: beam search = "sampled", greedy = baseline,
+// same samples, same parameters): a->N = samples * (b + 1) rows, row n * (b + 1) + j = beam j of sample n for j < b and the greedy row
+// for j = b; all rows of a sample share its object block (obj_div = b + 1).  One decode step + one selection launch per time step
+// instead of two of each: the recurrence is a chain of dependent ~7 us launches, so the step costs its length, not its rows.
+// Every row's arithmetic is that of the separate decodes (a row of the step never reads another row).  Beam outputs as
+// d3_topdown_beam; g_words / g_lps (glen, samples), glen >= max_len (the reference decodes max_spk_len + 1 greedy steps).
+static int td_beam_select_lds(size_t lds, const void *kernel) {
+    if (lds > 150 * 1024) return D3_ERR_ARG;
+    if (lds > 60 * 1024) D3_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    return 0;
+}
+extern "C" int d3_topdown_beam_greedy(const d3_topdown_args *a, const float *fp, int b, float *const *h1, float *const *h2, float *logits,
+                                      float *attn, void *ws, size_t ws_bytes, const long long *first_word, int eos, int max_len,
+                                      long long *allseq, float *snap_all, unsigned char *ended_all, float *sums0, float *sums1,
+                                      long long *tok, int glen, long long *g_words, float *g_lps, void *stream) {
+    if (!a || b < 1 || b > 8 || a->N % (b + 1) || max_len < 1 || glen < max_len || !h1 || !h2 || !g_words || !g_lps) return D3_ERR_ARG;
+    const int rs = b + 1, N = a->N / rs, H = a->H, V = a->V;
+    const size_t per = (size_t)N * b;
+    hipStream_t s = d3_stream(stream);
+    int rc = td_beam_select_lds((size_t)b * V * sizeof(float), (const void *)td_beam_greedy_select_kernel);
+    if (rc) return rc;
+    float *P1 = h1[1], *Q1 = h1[2], *R1 = h1[0], *P2 = h2[1], *Q2 = h2[2], *R2 = h2[0];
+    rc = d3_topdown_step(a, first_word, fp, rs, R1, R2, P1, P2, logits, attn, ws, ws_bytes, stream);
+    if (rc) return rc;
+    float *s_in = sums0, *s_out = sums1;
+    int live = 1;
+    for (int t = 0; t < max_len; t++) {
+        const int last = t == max_len - 1;
+        td_beam_greedy_select_kernel<<<2 * N, BS_T, (size_t)live * V * sizeof(float), s>>>(
+            logits, s_in, N, live, b, V, eos, last, t, max_len, t > 0 ? allseq + (size_t)(t - 1) * per * max_len : nullptr,
+            allseq + (size_t)t * per * max_len, tok, snap_all + (size_t)t * per, ended_all + (size_t)t * per, s_out, P1, P2, Q1, Q2, H,
+            g_words + (size_t)t * N, g_lps + (size_t)t * N);
+        D3_LAUNCH_CHECK();
+        float *x = s_in; s_in = s_out; s_out = x;
+        live = b;
+        if (t + 1 >= glen) break;
+        rc = d3_topdown_step(a, tok, fp, rs, Q1, Q2, R1, R2, logits, attn, ws, ws_bytes, stream);
+        if (rc) return rc;
+        x = P1; P1 = R1; R1 = Q1; Q1 = x;
+        x = P2; P2 = R2; R2 = Q2; Q2 = x;
+    }
+    for (int t = max_len; t < glen; t++) {          // the greedy rows' remaining steps (the beam rows ride along, unread)
+        td_greedy_select_kernel<<<N, BS_T, 0, s>>>(logits, V, g_words + (size_t)t * N, g_lps + (size_t)t * N, rs, b, tok);
+        D3_LAUNCH_CHECK();
+        if (t + 1 >= glen) break;
+        rc = d3_topdown_step(a, tok, fp, rs, P1, P2, R1, R2, logits, attn, ws, ws_bytes, stream);
+        if (rc) return rc;
+        float *x = P1; P1 = R1; R1 = x;
+        x = P2; P2 = R2; R2 = x;
+    }
+    return 0;
+}
+// beam search (:136-349) over a->N = samples * b rows (row n * b + j = beam j of sample n; the b rows of a sample share its object
+// block: obj_div = b).  Three buffers per hidden state rotate: latest step output -> (select: re-ordered) -> next step's output;
+// h1[0] / h2[0] hold the initial (zero) states.  allseq (max_len, samples, b, max_len) zero-filled by the caller, snap_all /
+// ended_all (max_len, samples, b), sums0 (samples, b) zero-filled, sums1 / tok scratch: every step's beams are kept, the caller
+// ranks the finished ones (d3net_amd/speaker.py).
+extern "C" int d3_topdown_beam(const d3_topdown_args *a, const float *fp, int b, float *const *h1, float *const *h2, float *logits,
+                               float *attn, void *ws, size_t ws_bytes, const long long *first_word, int eos, int max_len,
+                               long long *allseq, float *snap_all, unsigned char *ended_all, float *sums0, float *sums1,
+                               long long *tok, void *stream) {
+    if (!a || b < 1 || a->N % b || max_len < 1 || !h1 || !h2) return D3_ERR_ARG;
+    const int N = a->N / b, H = a->H;
+    const size_t per = (size_t)N * b;
+    float *P1 = h1[1], *Q1 = h1[2], *R1 = h1[0], *P2 = h2[1], *Q2 = h2[2], *R2 = h2[0];
+    int rc = d3_topdown_step(a, first_word, fp, b, R1, R2, P1, P2, logits, attn, ws, ws_bytes, stream);
+    if (rc) return rc;
+    float *s_in = sums0, *s_out = sums1;
+    int live = 1;                                   // t = 0: a single live beam per sample (:176-179)
+    for (int t = 0; t < max_len; t++) {
+        const int last = t == max_len - 1;
+        rc = d3_beam_select(logits, s_in, N, live, b, a->V, eos, last, t, max_len, t > 0 ? allseq + (size_t)(t - 1) * per * max_len : nullptr,
+                            allseq + (size_t)t * per * max_len, tok, snap_all + (size_t)t * per, ended_all + (size_t)t * per, s_out, P1, P2, Q1, Q2,
+                            H, stream);
+        if (rc) return rc;
+        float *x = s_in; s_in = s_out; s_out = x;
+        live = b;
+        if (last) break;
+        rc = d3_topdown_step(a, tok, fp, b, Q1, Q2, R1, R2, logits, attn, ws, ws_bytes, stream);
+        if (rc) return rc;
+        x = P1; P1 = R1; R1 = Q1; Q1 = x;
+        x = P2; P2 = R2; R2 = Q2; Q2 = x;
+    }
     return 0;
 }

@@ -26,6 +26,8 @@ from . import _lib
 from ._lib import check
 from .pointgroup_ops import _on, _ptr, _stream
 
+JOINED_DECODES = True   # the self-critical step's beam search and greedy baseline as one chain (tools/ab.py py:d3net_amd.speaker.JOINED_DECODES=0,1)
+
 
 # --------------------------------------------------------------------------------------- local context
 def query_locals_all(corners, object_masks, num_locals, include_self, overlay_threshold=0.5, query_mode="corner"):
@@ -482,15 +484,18 @@ class TopDownSceneCaptionModule(nn.Module):
         outs, lps = [], []
         if self.native and target_feats.is_cuda:
             dec = _NativeDecoder(self, target_feats, obj_feats, valid_masks.reshape(N, -1))
-            # arg-max + its log-softmax value in one launch per step (d3_greedy_select), written straight into the (N, max_len) outputs
+            # the whole loop is one library call (d3_topdown_greedy: per step the 8 launches of the decode step + arg-max and its
+            # log-softmax value in one launch, written straight into the (max_len, N) outputs)
             L = _lib.lib()
-            words = torch.empty(max_len, N, dtype=torch.long, device=target_feats.device)
-            lpa = torch.empty(max_len, N, dtype=torch.float32, device=target_feats.device)
-            with _on(target_feats.device):
-                for t in range(max_len):
-                    logits, _ = dec.step(word)
-                    check(L.d3_greedy_select(_ptr(logits), N, logits.shape[1], _ptr(words[t]), _ptr(lpa[t]), _stream()), "greedy_select")
-                    word = words[t]
+            dev = target_feats.device
+            words = torch.empty(max_len, N, dtype=torch.long, device=dev)
+            lpa = torch.empty(max_len, N, dtype=torch.float32, device=dev)
+            logits = torch.empty((N, self.num_vocabs), dtype=torch.float32, device=dev)
+            attn = torch.empty((N, dec.K), dtype=torch.float32, device=dev)
+            with _on(dev):
+                check(L.d3_topdown_greedy(C.byref(dec.args), _ptr(dec.fp), 1, _ptr(dec.h1[0]), _ptr(dec.h2[0]), _ptr(dec.h1[1]), _ptr(dec.h2[1]),
+                                          _ptr(logits), _ptr(attn), _ptr(dec.ws), dec.ws.numel(), _ptr(word), max_len, _ptr(words), _ptr(lpa),
+                                          _stream()), "topdown_greedy")
             return self.trim_outputs(words.t().contiguous().unsqueeze(1), lpa.t().contiguous().unsqueeze(1))
         hiddens = (target_feats.new_zeros(N, self.hidden_size), target_feats.new_zeros(N, self.hidden_size))
         proj = self.map_feat(obj_feats)
@@ -566,7 +571,7 @@ class TopDownSceneCaptionModule(nn.Module):
             done.append(beams)
         return done
 
-    def _beam_decode_native(self, target_feats, obj_feats, valid_masks, beam_size, max_len, topn=None):
+    def _beam_decode_native(self, target_feats, obj_feats, valid_masks, beam_size, max_len, topn=None, greedy_len=0):
         """The same search on the native decode step (csrc/topdown.hip), in two parts:
           1. the search itself runs without autograd on `d3_topdown_step` -- the b beams of a sample are b rows that share the
              sample's object block, a beam re-ordering is a row gather of the two hidden states;
@@ -579,38 +584,41 @@ class TopDownSceneCaptionModule(nn.Module):
         dev = target_feats.device
         sos, eos = int(self.vocabulary["word2idx"]["sos"]), int(self.vocabulary["word2idx"]["eos"])
         vm = valid_masks.reshape(N, -1)
+        rs = b + 1 if greedy_len else b                     # rows per sample: the b beams (+ the greedy row of the joined decode)
         with torch.no_grad():
-            dec = _NativeDecoder(self, target_feats.detach().repeat_interleave(b, dim=0), obj_feats.detach(),
-                                 vm.repeat_interleave(b, dim=0), obj_div=b)
-            word = torch.full((N * b,), sos, dtype=torch.long, device=dev)
-            logits, _ = dec.step(word)
-            # One launch per step selects (csrc/topdown.hip d3_beam_select: log_softmax, the b best of live * V candidates best
-            # first -- what the reference's full descending sort keeps (:181-182); an exact tie between two candidates' float scores
-            # is the only way the two could order differently --, token histories, running sums with the -1000 penalty of finished
-            # beams (:300), ended flags, and the re-ordering of the hidden states: rows are (sample, beam slot)); ~25 library
-            # launches per step before round 4.
+            dec = _NativeDecoder(self, target_feats.detach().repeat_interleave(rs, dim=0), obj_feats.detach(),
+                                 vm.repeat_interleave(rs, dim=0), obj_div=rs)
+            word = torch.full((N * rs,), sos, dtype=torch.long, device=dev)
+            # The search is ONE library call (d3_topdown_beam): per step the decode step's 8 launches and one selection launch
+            # (d3_beam_select: log_softmax, the b best of live * V candidates best first -- what the reference's full descending sort
+            # keeps (:181-182); an exact tie between two candidates' float scores is the only way the two could order differently --,
+            # token histories, running sums with the -1000 penalty of finished beams (:300), ended flags, and the re-ordering of the
+            # hidden states: rows are (sample, beam slot)).  ~25 library launches per step before round 4, then a host loop of two
+            # calls per step, now none.  With `greedy_len` the greedy baseline of the same samples (:350-383) rides in the same chain
+            # as one more row per sample (d3_topdown_beam_greedy).
             L = _lib.lib()
-            H = dec.h1[0].shape[1]
             allseq = torch.zeros(max_len, N, b, max_len, dtype=torch.long, device=dev)   # every step's beams, zero padded
             snap_all = torch.empty(max_len, N, b, dtype=torch.float32, device=dev)
             ended_all = torch.empty(max_len, N, b, dtype=torch.uint8, device=dev)
             sums = [torch.zeros(N, b, dtype=torch.float32, device=dev), torch.empty(N, b, dtype=torch.float32, device=dev)]
-            tok = torch.empty(N * b, dtype=torch.long, device=dev)
-            h1_sp, h2_sp = torch.empty_like(dec.h1[0]), torch.empty_like(dec.h2[0])
-            live = 1                                                          # t = 0: a single live beam per sample (:176-179)
+            tok = torch.empty(N * rs, dtype=torch.long, device=dev)
+            h1 = [dec.h1[0], dec.h1[1], torch.empty_like(dec.h1[0])]
+            h2 = [dec.h2[0], dec.h2[1], torch.empty_like(dec.h2[0])]
+            logits = torch.empty((N * rs, V), dtype=torch.float32, device=dev)
+            attn = torch.empty((N * rs, dec.K), dtype=torch.float32, device=dev)
+            P3 = C.c_void_p * 3
             with _on(dev):
-                for t in range(max_len):
-                    lastf = int(t == max_len - 1)
-                    check(L.d3_beam_select(_ptr(logits), _ptr(sums[0]), N, live, b, V, eos, lastf, t, max_len,
-                                           _ptr(allseq[t - 1]) if t > 0 else None, _ptr(allseq[t]), _ptr(tok), _ptr(snap_all[t]), _ptr(ended_all[t]),
-                                           _ptr(sums[1]), _ptr(dec.h1[0]), _ptr(dec.h2[0]), _ptr(h1_sp), _ptr(h2_sp), H, _stream()), "beam_select")
-                    sums.reverse()
-                    dec.h1[0], h1_sp = h1_sp, dec.h1[0]       # (the re-ordered states are the decoder's current ones)
-                    dec.h2[0], h2_sp = h2_sp, dec.h2[0]
-                    live = b
-                    if lastf:
-                        break
-                    logits, _ = dec.step(tok)
+                if greedy_len:
+                    g_words = torch.empty(greedy_len, N, dtype=torch.long, device=dev)
+                    g_lps = torch.empty(greedy_len, N, dtype=torch.float32, device=dev)
+                    check(L.d3_topdown_beam_greedy(C.byref(dec.args), _ptr(dec.fp), b, P3(*[t.data_ptr() for t in h1]), P3(*[t.data_ptr() for t in h2]),
+                                                   _ptr(logits), _ptr(attn), _ptr(dec.ws), dec.ws.numel(), _ptr(word), eos, max_len, _ptr(allseq),
+                                                   _ptr(snap_all), _ptr(ended_all), _ptr(sums[0]), _ptr(sums[1]), _ptr(tok), greedy_len,
+                                                   _ptr(g_words), _ptr(g_lps), _stream()), "topdown_beam_greedy")
+                else:
+                    check(L.d3_topdown_beam(C.byref(dec.args), _ptr(dec.fp), b, P3(*[t.data_ptr() for t in h1]), P3(*[t.data_ptr() for t in h2]),
+                                            _ptr(logits), _ptr(attn), _ptr(dec.ws), dec.ws.numel(), _ptr(word), eos, max_len, _ptr(allseq),
+                                            _ptr(snap_all), _ptr(ended_all), _ptr(sums[0]), _ptr(sums[1]), _ptr(tok), _stream()), "topdown_beam")
             P = torch.where(ended_all.bool(), snap_all, torch.full_like(snap_all, float("-inf"))).permute(1, 0, 2).reshape(N, -1)
             keep = b if topn is None else min(topn, b)
             order = torch.sort(P, dim=1, descending=True, stable=True)[1][:, :b].cpu()
@@ -623,8 +631,10 @@ class TopDownSceneCaptionModule(nn.Module):
                 t, v = divmod(j, b)
                 picked.append((n, t, v, float(Pc[n, j])))
         done = [[] for _ in range(N)]
+        if greedy_len:
+            greedy = self.trim_outputs(g_words.t().contiguous().unsqueeze(1), g_lps.t().contiguous().unsqueeze(1))
         if not picked:
-            return done
+            return (done, greedy) if greedy_len else done
         # teacher-forced replay of the returned beams: inputs [sos, tok_0 .. tok_{l-2}] predict tok_0 .. tok_{l-1}
         R, S = len(picked), max(t + 1 for _, t, _, _ in picked)
         pk = torch.tensor([(n, t, v) for n, t, v, _ in picked], dtype=torch.long).to(dev)
@@ -637,7 +647,7 @@ class TopDownSceneCaptionModule(nn.Module):
         lp = F.log_softmax(logits, dim=-1).gather(2, toks.unsqueeze(-1)).squeeze(-1)              # (R, S)
         for r, (n, t, v, p_) in enumerate(picked):
             done[n].append({"seq": toks[r, :t + 1], "logps": lp[r, :t + 1], "p": p_})
-        return done
+        return (done, greedy) if greedy_len else done
 
     def trim_outputs(self, raw_word_ids, raw_logprobs):
         """cut every sequence at its first eos / pad_ (:385-414); if none occurs the LAST token is dropped, as the
@@ -753,10 +763,15 @@ class TopDownSceneCaptionModule(nn.Module):
         if use_rl:   # self-critical: sampled = best beams (with gradients), baseline = greedy (:588-633)
             assert beam_opt
             beam_size, topn = beam_opt.get("train_beam_size", 5), beam_opt.get("train_sample_topn", 1)
-            done = self.beam_decode(target_feats, obj_feats, valid_masks, beam_size, self.cfg.data.max_spk_len, topn)
+            if JOINED_DECODES and self.native and target_feats.is_cuda:
+                # both decodes of the step in one chain of launches (csrc/topdown.hip d3_topdown_beam_greedy)
+                done, (greedy, _) = self._beam_decode_native(target_feats, obj_feats, valid_masks, beam_size, self.cfg.data.max_spk_len, topn,
+                                                             greedy_len=self.cfg.data.max_spk_len + 1)
+            else:
+                done = self.beam_decode(target_feats, obj_feats, valid_masks, beam_size, self.cfg.data.max_spk_len, topn)
+                greedy, _ = self.greedy_decode(target_feats, obj_feats, valid_masks, self.cfg.data.max_spk_len + 1)
             lang_cap = [[done[n][k]["seq"] for k in range(topn)] for n in range(N)]
             data_dict["lang_logprob"] = [[done[n][k]["logps"] for k in range(topn)] for n in range(N)]
-            greedy, _ = self.greedy_decode(target_feats, obj_feats, valid_masks, self.cfg.data.max_spk_len + 1)
             data_dict["baseline_cap"] = [[greedy[n][0] for _ in range(topn)] for n in range(N)]
         elif use_tf and self.native and obj_feats.is_cuda:
             # teacher forcing: every input word is known up front -> the whole S-step pass is one native call (csrc/topdown.hip)

@@ -562,6 +562,26 @@ int d3_beam_select(const float *logits, const float *sums_in, int N, int live, i
                    const long long *seq_prev, long long *seq_out, long long *tok_out, float *snap_out, unsigned char *ended_out,
                    float *sums_out, const float *h1_in, const float *h2_in, float *h1_out, float *h2_out, int H, void *stream);
 int d3_greedy_select(const float *logits, int N, int V, long long *word, float *lp, void *stream);
+/* The two decodes as single calls (same launches as the loops over d3_topdown_step + d3_*_select, issued inside the library).
+ * d3_topdown_greedy (model/caption_module.py:350-383): h1_a / h2_a (N,H) = initial (zero) states, h1_b / h2_b scratch, logits (N,V)
+ * and attn (N,K) scratch, first_word (N) = sos; words / lps (max_len, N) written.
+ * d3_topdown_beam (:136-349): a->N = samples * b rows (row n*b + j = beam j of sample n, obj_div = b); h1 / h2: three (N,H) buffers
+ * each, [0] = initial (zero) states; allseq (max_len, samples, b, max_len) zero-filled by the caller, snap_all / ended_all (max_len,
+ * samples, b), sums0 (samples, b) zero-filled, sums1 (samples, b) and tok (a->N) scratch.  Every step's beams are kept (a beam that
+ * ended at step t: ended_all[t] != 0, its score snap_all[t], its tokens allseq[t][..][:t+1]). */
+int d3_topdown_greedy(const d3_topdown_args *a, const float *fp, int obj_div, float *h1_a, float *h2_a, float *h1_b, float *h2_b,
+                      float *logits, float *attn, void *ws, size_t ws_bytes, const long long *first_word, int max_len,
+                      long long *words, float *lps, void *stream);
+int d3_topdown_beam(const d3_topdown_args *a, const float *fp, int b, float *const *h1, float *const *h2, float *logits, float *attn,
+                    void *ws, size_t ws_bytes, const long long *first_word, int eos, int max_len, long long *allseq, float *snap_all,
+                    unsigned char *ended_all, float *sums0, float *sums1, long long *tok, void *stream);
+/* Both decodes of one self-critical step (model/caption_module.py:588-633) as one chain: a->N = samples * (b + 1) rows, row
+ * n*(b+1) + j = beam j of sample n (j < b) / its greedy row (j = b), obj_div = b + 1; beam outputs as d3_topdown_beam, greedy
+ * outputs g_words / g_lps (glen, samples), glen >= max_len.  tok (a->N) scratch.  Row for row the arithmetic of the separate calls. */
+int d3_topdown_beam_greedy(const d3_topdown_args *a, const float *fp, int b, float *const *h1, float *const *h2, float *logits,
+                           float *attn, void *ws, size_t ws_bytes, const long long *first_word, int eos, int max_len,
+                           long long *allseq, float *snap_all, unsigned char *ended_all, float *sums0, float *sums1, long long *tok,
+                           int glen, long long *g_words, float *g_lps, void *stream);
 
 /* ---- packed-sequence GRU of the language encoder (csrc/topdown.hip) ---------------------------------------
  * nn.GRU(I -> H, batch_first=True) over pack_padded_sequence(x (N,T,I), lens (N)) as LangModule runs it

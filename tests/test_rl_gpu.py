@@ -85,6 +85,51 @@ def test_rl_chain_matches_reference_golden(dev):
         assert np.allclose(got, ref, rtol=5e-3, atol=1e-6 + 2e-3 * np.abs(ref).max()), (k, float(np.abs(got - ref).max()))
 
 
+def test_joined_decode_chain_equals_the_two_separate_decodes(dev):
+    """model/caption_module.py:588-633: the beam search and the greedy baseline of one self-critical step decode the same samples
+    with the same parameters; the library runs them as one chain of launches, the greedy sample as one more row per sample
+    (csrc/topdown.hip d3_topdown_beam_greedy; speaker.JOINED_DECODES).  A row of the decode step never reads another row, so
+    captions and baselines must be identical and the log-probabilities equal to the last bits' summation order (the GEMM's tile
+    class may differ with the row count): 1e-5."""
+    from test_oracle_rl import setup
+    from d3net_amd import speaker as SP
+    R, S, g, cfg, vocab, p, lp, d, opt = setup()
+    cap = SP.TopDownSceneCaptionModule(cfg, vocab, S.make_embeddings(), num_proposals=S.K, num_locals=S.L, use_relation=True)
+    cap.load_state_dict(p)
+    cap = cap.to(dev)
+    d = {k: v.to(dev) for k, v in d.items()}
+    d["adjacent_mat"] = SP.query_locals_all(d["proposal_bbox_batched"], d["proposal_batch_mask"], S.L, include_self=False)
+    outs = []
+    old = SP.JOINED_DECODES
+    try:
+        for flag in (False, True, True):
+            SP.JOINED_DECODES = flag
+            random.seed(5)
+            dd = cap(dict(d), use_tf=True, use_rl=True, is_eval=False, beam_opt={"train_beam_size": R.BEAM, "train_sample_topn": R.TOPN})
+            torch.cuda.synchronize()
+            outs.append(([[t.cpu() for t in row] for row in dd["lang_cap"]], [[t.detach().cpu() for t in row] for row in dd["lang_logprob"]],
+                         [[t.cpu() for t in row] for row in dd["baseline_cap"]]))
+    finally:
+        SP.JOINED_DECODES = old
+    for o in outs[1:]:
+        for k, (a, b) in enumerate(zip(outs[0], o)):
+            assert len(a) == len(b)
+            for ra, rb in zip(a, b):
+                assert len(ra) == len(rb)
+                for x, y in zip(ra, rb):
+                    assert x.shape == y.shape and (torch.equal(x, y) if k != 1 else float((x - y).abs().max()) < 1e-5)
+    # greedy-only and beam-only entry points (evaluation paths) still agree with the joined chain's rows
+    si = {k: torch.from_numpy(v).to(dev) for k, v in S.step_inputs().items()}
+    done = cap.beam_decode(si["target"], si["obj"], si["mask"], R.BEAM, S.MAXLEN)
+    gr, glp = cap.greedy_decode(si["target"], si["obj"], si["mask"].unsqueeze(-1) if si["mask"].dim() == 2 else si["mask"], S.MAXLEN + 1)
+    done2, (gr2, glp2) = cap._beam_decode_native(si["target"], si["obj"], si["mask"], R.BEAM, S.MAXLEN, None, greedy_len=S.MAXLEN + 1)
+    for n in range(len(done)):
+        assert len(done[n]) == len(done2[n])
+        for x, y in zip(done[n], done2[n]):
+            assert torch.equal(x["seq"], y["seq"]) and abs(x["p"] - y["p"]) < 1e-4
+        assert torch.equal(gr[n][0], gr2[n][0]) and float((glp[n][0] - glp2[n][0]).abs().max()) < 1e-5
+
+
 def test_pipeline_mode3_runs_and_trains(dev):
     from d3net_amd import synthetic as S
     from d3net_amd.config import default_conf
