@@ -1086,27 +1086,25 @@ __device__ __forceinline__ void td_beam_select_body(const int n, const int rs, c
                                                              float *__restrict__ sums_out, const float *__restrict__ h1_in,
                                                              const float *__restrict__ h2_in, float *__restrict__ h1_out,
                                                              float *__restrict__ h2_out, int H) {
-    __shared__ float red[BS_T];
-    __shared__ int redi[BS_T];
     __shared__ float s_max[8], s_lse[8], s_sum[8];
     __shared__ int s_pick[8];
     __shared__ float s_pickv[8];
-    const int tid = threadIdx.x;
-    // (a) per live beam: max and log-sum-exp
-    for (int j = 0; j < live; j++) {
+    __shared__ float w_v[BS_T / 64];
+    __shared__ int w_i[BS_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (a) per live beam: max and log-sum-exp -- one wave per beam, shuffles only (round 4: block-wide trees of 8 barriers each before,
+    // ~135 barriers per launch, 30 us on a 31-step dependent chain)
+    for (int j = wv; j < live; j += BS_T / 64) {
         const float *x = logits + ((long long)n * rs + j) * V;
         float m = -INFINITY;
-        for (int v = tid; v < V; v += BS_T) m = fmaxf(m, x[v]);
-        red[tid] = m; __syncthreads();
-        for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
-        m = red[0]; __syncthreads();
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         float sm = 0.f;
-        for (int v = tid; v < V; v += BS_T) sm += expf(x[v] - m);
-        red[tid] = sm; __syncthreads();
-        for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-        if (tid == 0) { s_max[j] = m; s_lse[j] = logf(red[0]); s_sum[j] = sums_in[(long long)n * live + j]; }
-        __syncthreads();
+        for (int v = lane; v < V; v += 64) sm += expf(x[v] - m);
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        if (lane == 0) { s_max[j] = m; s_lse[j] = logf(sm); s_sum[j] = sums_in[(long long)n * live + j]; }
     }
+    __syncthreads();
     // (b) candidate scores staged in LDS once, then b block-wide arg-max passes over the LDS copy (a picked candidate is struck out)
     extern __shared__ float cs[];                     // live * V floats
     for (int j = 0; j < live; j++) {
@@ -1122,15 +1120,17 @@ __device__ __forceinline__ void td_beam_select_body(const int n, const int rs, c
             const float c = cs[flat];
             if (c > bv) { bv = c; bi = flat; }            // (ascending flat per thread: the first maximum wins)
         }
-        red[tid] = bv; redi[tid] = bi; __syncthreads();
-        for (int o = BS_T / 2; o > 0; o >>= 1) {
-            if (tid < o) {
-                const float ov = red[tid + o]; const int oi = redi[tid + o];
-                if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) { red[tid] = ov; redi[tid] = oi; }
-            }
-            __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) {                // larger value, then lower flat index
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if (tid == 0) { s_pick[r] = redi[0]; s_pickv[r] = red[0]; cs[redi[0]] = -INFINITY; }
+        if (lane == 0) { w_v[wv] = bv; w_i[wv] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = w_v[0]; int fi = w_i[0];
+            for (int w = 1; w < BS_T / 64; w++) if (w_v[w] > fv || (w_v[w] == fv && w_i[w] < fi)) { fv = w_v[w]; fi = w_i[w]; }
+            s_pick[r] = fi; s_pickv[r] = fv; cs[fi] = -INFINITY;
+        }
         __syncthreads();
     }
     // (c) outputs
@@ -1191,25 +1191,30 @@ extern "C" int d3_beam_select(const float *logits, const float *sums_in, int N, 
 // greedy step: word = argmax_v logits[n][v] (first maximum), lp = its log-softmax value (caption_module.py:367-371)
 __device__ __forceinline__ void td_greedy_select_body(const float *__restrict__ x, int V, long long *__restrict__ word, float *__restrict__ lp,
                                                       long long *__restrict__ word2) {
-    __shared__ float red[BS_T];
-    __shared__ int redi[BS_T];
-    const int tid = threadIdx.x;
+    __shared__ float w_v[BS_T / 64];
+    __shared__ int w_i[BS_T / 64];
+    __shared__ float w_s[BS_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float m = -INFINITY; int mi = 0x7FFFFFFF;
     for (int v = tid; v < V; v += BS_T) if (x[v] > m) { m = x[v]; mi = v; }
-    red[tid] = m; redi[tid] = mi; __syncthreads();
-    for (int o = BS_T / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-            const float ov = red[tid + o]; const int oi = redi[tid + o];
-            if (ov > red[tid] || (ov == red[tid] && oi < redi[tid])) { red[tid] = ov; redi[tid] = oi; }
-        }
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {                    // larger value, then lower index (the first maximum)
+        const float ov = __shfl_xor(m, o); const int oi = __shfl_xor(mi, o);
+        if (ov > m || (ov == m && oi < mi)) { m = ov; mi = oi; }
     }
-    m = red[0]; mi = redi[0]; __syncthreads();
+    if (lane == 0) { w_v[wv] = m; w_i[wv] = mi; }
+    __syncthreads();
+    m = w_v[0]; mi = w_i[0];
+    for (int w = 1; w < BS_T / 64; w++) if (w_v[w] > m || (w_v[w] == m && w_i[w] < mi)) { m = w_v[w]; mi = w_i[w]; }
     float sm = 0.f;
     for (int v = tid; v < V; v += BS_T) sm += expf(x[v] - m);
-    red[tid] = sm; __syncthreads();
-    for (int o = BS_T / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) { *word = mi; *lp = (x[mi] - m) - logf(red[0]); if (word2) *word2 = mi; }
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    if (lane == 0) w_s[wv] = sm;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < BS_T / 64; w++) tot += w_s[w];
+        *word = mi; *lp = (x[mi] - m) - logf(tot); if (word2) *word2 = mi;
+    }
 }
 // rows n * rs + off of logits (rs = 1, off = 0: dense); word2 (optional): the token also goes to row n * rs + off of the next step's input
 __global__ __launch_bounds__(BS_T) void td_greedy_select_kernel(const float *__restrict__ logits, int V, long long *__restrict__ word, float *__restrict__ lp,
