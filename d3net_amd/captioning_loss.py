@@ -53,6 +53,7 @@ class CiderCorpus:
 
 
 _CORPORA = {}
+LOGP_SUM_TENSOR = True     # (tools/ab.py py:d3net_amd.captioning_loss.LOGP_SUM_TENSOR=0,1)
 
 
 def _cider_device(corpus, entry_sets, cands, sample_topn):
@@ -178,7 +179,9 @@ def _rl_cap_loss(data_dict, loss_opt):
     caps, logprobs, base_caps = data_dict["lang_cap"], data_dict["lang_logprob"], data_dict["baseline_cap"]
     good = data_dict["good_bbox_masks"].long()
     annotated = data_dict["annotated"].reshape(-1)
-    logp = torch.stack([lp.sum() for beams in logprobs for lp in beams])
+    logp = data_dict.get("lang_logprob_sum") if LOGP_SUM_TENSOR else None     # (native beam search: the same sums as one tensor)
+    if logp is None or logp.shape[0] != sum(len(beams) for beams in logprobs):
+        logp = torch.stack([lp.sum() for beams in logprobs for lp in beams])
     args = (topn, loss_opt.get("idx2word"), loss_opt.get("train_dataset_data"), loss_opt.get("organized_data"))
     sampled = compute_caption_reward(data_dict, caps, *args).type_as(logp)
     baseline = compute_caption_reward(data_dict, base_caps, *args).type_as(logp)

@@ -24,6 +24,7 @@ import torch.nn as nn
 from . import common
 from . import heads
 from . import minkowski as ME
+from . import nativelinear
 from . import netexec
 from . import pointgroup_ops
 
@@ -445,7 +446,9 @@ class PointGroup(nn.Module):
                 data_dict["_slot_perm_staged"] = _STAGE.put(torch.stack([torch.randperm(K) for _ in range(batch_size)]), pt_feats.device)
             pt_score_feats = heads.devoxelize(score_feats, proposals_p2v_map, getattr(proposals_voxel_feats, "v2p_map", None))
             proposals_score_feats = pointgroup_ops.roipool(pt_score_feats, proposals_offset)   # (P, m)
-            scores = self.score_linear(proposals_score_feats)
+            # (library GEMM on the device: the hipBLASLt call behind nn.Linear costs 50-100 us of host time per call in this host-bound
+            # stretch of the step; CPU tensors take F.linear inside)
+            scores = nativelinear.linear(proposals_score_feats, self.score_linear.weight, self.score_linear.bias)
             data_dict["proposal_scores"] = (scores, proposals_idx, proposals_offset)
 
             _mark("pr_roipool_score")

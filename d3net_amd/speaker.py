@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import nativelinear
 from ._lib import check
 from .pointgroup_ops import _on, _ptr, _stream
 
@@ -198,7 +199,7 @@ class GraphModule(nn.Module):
             edge_feats = _GatherRowsPad.apply(msg, e["feat_src"].view(-1)).view(B, K, L, self.out_size)
             m = self.edge_layer.map_edge
             _, last = EdgeConvFunction.apply(node, m[0].weight, m[0].bias, m[2].weight, m[2].bias, e)
-            pred = self.edge_predict(last)
+            pred = nativelinear.linear(last, self.edge_predict.weight, self.edge_predict.bias)
             edge_preds = _GatherRowsPad.apply(pred, e["pred_src"].view(-1)).view(B, K * L, self.num_bins + 1)
             edge_indices = e["edge_index"]
             num_sources, num_targets = e["cnt"][:, 1].long(), e["cnt"][:, 2].long()
@@ -218,7 +219,7 @@ class GraphModule(nn.Module):
         return data_dict
 
     def forward(self, data_dict):
-        obj_feats = self.map_input(data_dict["proposal_feats_batched"])           # (B,K,out)
+        obj_feats = nativelinear.linear(data_dict["proposal_feats_batched"], self.map_input.weight, self.map_input.bias)   # (B,K,out)
         object_masks = data_dict["proposal_batch_mask"]
         B, K, _ = obj_feats.shape
         adjacent_mat = query_locals_all(data_dict["proposal_bbox_batched"], object_masks, self.num_locals,
@@ -270,6 +271,17 @@ _TD_KEYS = {"W_td": "map_topdown.weight", "b_td": "map_topdown.bias", "Wih1": "r
             "b_lang": "map_lang.bias", "Wih2": "recurrent_cell_2.weight_ih", "Whh2": "recurrent_cell_2.weight_hh",
             "bih2": "recurrent_cell_2.bias_ih", "bhh2": "recurrent_cell_2.bias_hh", "Wc0": "classifier.0.weight",
             "bc0": "classifier.0.bias", "Wc2": "classifier.2.weight", "bc2": "classifier.2.bias"}
+_TD_GETTERS = None
+
+
+def _td_params(cap):
+    """the captioner's parameters in csrc/topdown.hip's argument order (attribute walks: `dict(named_parameters())` per call cost
+    ~50 us of interpreter time in a host-bound stretch of the step)"""
+    global _TD_GETTERS
+    if _TD_GETTERS is None:
+        import operator
+        _TD_GETTERS = [operator.attrgetter(_TD_KEYS[k]) for k in _lib.TOPDOWN_PARAMS]
+    return [g(cap) for g in _TD_GETTERS]
 
 
 class TopDownXEFunction(torch.autograd.Function):
@@ -328,6 +340,13 @@ class TopDownXEFunction(torch.autograd.Function):
         return (None, None, None, None, dobj, dtarget) + tuple(grads)
 
 
+class _BeamResult(list):
+    """beam_decode's per-sample lists + (native search only) `logp_sums`: the summed log-probability of every returned beam, one
+    tensor on the autograd graph, rows in the order of the flattened lists"""
+    logp_sums = None
+    rows = None
+
+
 class _NativeDecoder:
     """Inference-time decode loop state for csrc/topdown.hip's d3_topdown_step: map_feat(obj) computed once, hidden states
     double-buffered on the device, 8 launches per step.  obj_feats: (N / obj_div, K, F) -- `obj_div` consecutive samples share
@@ -340,8 +359,7 @@ class _NativeDecoder:
         N, F_ = self.target.shape
         nblk, K, _ = self.obj.shape
         assert nblk * obj_div == N and self.mask.shape == (N, K)
-        sd = dict(cap.named_parameters())
-        self.params = [sd[_TD_KEYS[k]].detach().contiguous() for k in _lib.TOPDOWN_PARAMS]
+        self.params = [p.detach().contiguous() for p in _td_params(cap)]
         self.emb = cap.embeddings
         V, E = self.emb.shape
         H = cap.hidden_size
@@ -630,7 +648,7 @@ class TopDownSceneCaptionModule(nn.Module):
                     break
                 t, v = divmod(j, b)
                 picked.append((n, t, v, float(Pc[n, j])))
-        done = [[] for _ in range(N)]
+        done = _BeamResult([] for _ in range(N))
         if greedy_len:
             greedy = self.trim_outputs(g_words.t().contiguous().unsqueeze(1), g_lps.t().contiguous().unsqueeze(1))
         if not picked:
@@ -641,10 +659,13 @@ class TopDownSceneCaptionModule(nn.Module):
         rows = pk[:, 0]
         toks = allseq[pk[:, 1], pk[:, 0], pk[:, 2], :S]                      # (R, S), zero behind a beam's own length
         word_ids = torch.cat([torch.full((R, 1), sos, dtype=torch.long, device=dev), toks], 1)   # (R, S + 1)
-        sd = dict(self.named_parameters())
         logits, _ = TopDownXEFunction.apply(self.embeddings, word_ids, vm.index_select(0, rows), S, obj_feats.index_select(0, rows),
-                                            target_feats.index_select(0, rows), *[sd[_TD_KEYS[k]] for k in _lib.TOPDOWN_PARAMS])
+                                            target_feats.index_select(0, rows), *_td_params(self))
         lp = F.log_softmax(logits, dim=-1).gather(2, toks.unsqueeze(-1)).squeeze(-1)              # (R, S)
+        # every returned beam's summed log-probability in one masked reduction, rows in (sample, rank) order: what the self-critical
+        # loss needs (loss_helper.py:128-131 sums each list entry: one slice + one reduction + their backward launches per caption)
+        done.logp_sums = (lp * (torch.arange(S, device=dev).unsqueeze(0) <= pk[:, 1].unsqueeze(1)).to(lp.dtype)).sum(1)
+        done.rows = [(n, t) for n, t, _, _ in picked]
         for r, (n, t, v, p_) in enumerate(picked):
             done[n].append({"seq": toks[r, :t + 1], "logps": lp[r, :t + 1], "p": p_})
         return (done, greedy) if greedy_len else done
@@ -772,13 +793,14 @@ class TopDownSceneCaptionModule(nn.Module):
                 greedy, _ = self.greedy_decode(target_feats, obj_feats, valid_masks, self.cfg.data.max_spk_len + 1)
             lang_cap = [[done[n][k]["seq"] for k in range(topn)] for n in range(N)]
             data_dict["lang_logprob"] = [[done[n][k]["logps"] for k in range(topn)] for n in range(N)]
+            sums = getattr(done, "logp_sums", None)
+            if sums is not None and sums.shape[0] == N * topn and all(len(done[n]) == topn for n in range(N)):
+                data_dict["lang_logprob_sum"] = sums          # == [lp.sum() for beams in lang_logprob for lp in beams], one reduction
             data_dict["baseline_cap"] = [[greedy[n][0] for _ in range(topn)] for n in range(N)]
         elif use_tf and self.native and obj_feats.is_cuda:
             # teacher forcing: every input word is known up front -> the whole S-step pass is one native call (csrc/topdown.hip)
-            sd = dict(self.named_parameters())
             lang_cap, data_dict["topdown_attn"] = TopDownXEFunction.apply(
-                self.embeddings, word_ids, valid_masks.squeeze(-1), max(num_words, 2) - 1, obj_feats, target_feats,
-                *[sd[_TD_KEYS[k]] for k in _lib.TOPDOWN_PARAMS])
+                self.embeddings, word_ids, valid_masks.squeeze(-1), max(num_words, 2) - 1, obj_feats, target_feats, *_td_params(self))
         else:
             hiddens = (obj_feats.new_zeros(N, self.hidden_size), obj_feats.new_zeros(N, self.hidden_size))
             proj = self.map_feat(obj_feats)
