@@ -128,6 +128,7 @@ struct Conv2Args {
     int Mout, K, Cout, S;       // S = Cin / 8 slots per offset
     unsigned int inv;           // ceil(65536 / S): i = (s * inv) >> 16 == s / S for s < 4096
     int xbf16, accum, ntiles, NT;   // NT = ceil(Cout / 16)
+    int obf16;                      // D3_CONV_OUTBF16: out is (Mout, ldo) bf16
     int f32;                        // D3_CONV_F32: fp32 weight fragments, v_mfma_f32_16x16x4_f32 (host-side dispatch only)
     unsigned int xbytes;            // extent of x in bytes for the raw buffer gathers (0: beyond 2 GiB / 2^24 rows, refused for the wave-per-tile kernel)
     unsigned int invK;          // ceil(65536 / K): e / K for e < 16*27
@@ -549,10 +550,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                             xh[q] = (e_bnx[j][q] - bp.x) * bp.y;
                             if (a.bn_relu && fmaf(xh[q], bp.z, bp.w) <= 0.f) vv[q] = 0.f;
                         }
-                        *o = vv;
+                        if (a.obf16) *(uint2 *)((unsigned short *)a.out + (long long)urow * a.ldo + col) = make_uint2(pack2bf2(vv[0], vv[1]), pack2bf2(vv[2], vv[3]));
+                        else *o = vv;
                         ssum[n] += vv; ssq[n] += vv * xh;
                     } else {
-                        *o = vv;
+                        if (a.obf16) *(uint2 *)((unsigned short *)a.out + (long long)urow * a.ldo + col) = make_uint2(pack2bf2(vv[0], vv[1]), pack2bf2(vv[2], vv[3]));
+                        else *o = vv;
                         ssum[n] += vv; ssq[n] += vv * vv;
                     }
                 }
@@ -743,7 +746,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
                 if (a.bn_relu && fmaf(xh, e_gam[i], e_bet[i]) <= 0.f) v = 0.f;
                 w2 = v * xh;
             } else w2 = v * v;
-            a.out[(long long)u * a.ldo + col] = v;
+            if (a.obf16) ((unsigned short *)a.out)[(long long)u * a.ldo + col] = (unsigned short)(pack2bf2(v, 0.f) & 0xFFFFu);
+            else a.out[(long long)u * a.ldo + col] = v;
         } else { v = 0.f; w2 = 0.f; }
         finS[e] = v; fin2S[e] = w2;
     }
@@ -979,6 +983,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     a.tbl16 = (tbl && tbl16 && K == 27 && !f32 && xbf16) ? (const unsigned int *)tbl16 : nullptr;   // (only the static instances launch with it)
     (void)ok16;
     a.xbf16 = xbf16; a.f32 = f32; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
+    a.obf16 = (flags & D3_CONV_OUTBF16) ? 1 : 0;
+    if (a.obf16 && (a.accum || res || f32)) return D3_ERR_ARG;
     {   // the last row of a column view ends after Cin elements; an absent neighbour's offset (2^32 - row bytes + ...) must stay outside
         const unsigned long long elt = xbf16 ? 2ull : 4ull, rowb = (unsigned long long)ldx * elt;
         const unsigned long long xb = Min > 0 ? ((unsigned long long)(Min - 1) * ldx + Cin) * elt : 0ull;
@@ -997,7 +1003,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     }
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout, f32 != 0);
     if (!p.split && a.xbytes == 0u) return D3_ERR_RANGE;   // the wave-per-tile kernel addresses x through a raw buffer: <= 2 GiB, < 2^24 rows
-    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + 4.0 * (double)Mout * Cout + (f32 ? 4.0 : 2.0) * (double)K * Cin * Cout +
+    const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + (a.obf16 ? 2.0 : 4.0) * (double)Mout * Cout + (f32 ? 4.0 : 2.0) * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
     void *pr = d3_prof_begin(p.split ? 2 : 0, bytes, 0.0, s);
     auto tag_rec = [&]() {

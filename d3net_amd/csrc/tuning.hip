@@ -45,6 +45,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_BN_FUSED_BIG", 1},         // 0: only BatchNorms of at most D3_BN_FUSED_ROWS rows run as one launch; the big levels keep finalize + apply
     {"D3_HG_CLASS_SPLIT", 1},       // 0: a batched heads GEMM launch always runs the kernel its largest problem asks for (rounds 1-3)
     {"D3_HG_SPLITK", 256},          // largest number of 16 x 16 output tiles of a deep (K >= 8192) heads GEMM whose reduction is cut over 4 workgroups; 0: never
+    {"D3_ACT_GRAD_BF16", 0},        // 1: gradients of BatchNorm->ReLU activations (one convolution reader) stored as bf16 (unet.hip Net::gabf): measured neutral, off
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

@@ -37,6 +37,11 @@ __device__ __forceinline__ unsigned int un_pack2bf(float lo, float hi) {
     return (a >> 16) | (b & 0xFFFF0000u);
 }
 
+// one element of a gradient row stored as fp32 or (bf != 0) bf16
+__device__ __forceinline__ float un_ld1(const float *p, long long idx, int bf) {
+    return bf ? __uint_as_float((unsigned int)((const unsigned short *)p)[idx] << 16) : p[idx];
+}
+
 struct PackJob { const float *W; size_t dst_off; int K, S, CinW, Cout, NT, flipk, transw, Cin, f32; long long start; };
 
 // all convolution weights of a network -> bf16 MFMA fragment order (layout of spconv2.hip's spconv_pack_kernel)
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(UN_T) void un_bn_bwd_reduce_kernel(const float *__r
                                                                const float *__restrict__ dy, int ldy,
                                                                const float *__restrict__ mean, const float *__restrict__ var,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                               int M, int C, float eps, int relu, float *part) {
+                                                               int M, int C, float eps, int relu, float *part, int dybf) {
     __shared__ float s1[UN_T], s2[UN_T];
     const int t = threadIdx.x;
     const int active = (UN_T / C) * C, rpp = active / C;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(UN_T) void un_bn_bwd_reduce_kernel(const float *__r
         const float mu = mean[c], inv = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
         for (long long r = (long long)blockIdx.x * rpp + t / C; r < M; r += (long long)gridDim.x * rpp) {
             const float xh = (x[r * ldx + c] - mu) * inv;
-            float g = dy[r * ldy + c];
+            float g = un_ld1(dy, r * ldy + c, dybf);
             if (relu && fmaf(xh, ga, be) <= 0.f) g = 0.f;
             a += g; b = fmaf(g, xh, b);
         }
@@ -251,7 +256,21 @@ static inline int un_ap_grid(long long M, int C, int passes) {
     const long long rows = (long long)(256 / (C >> 2)) * passes;
     return (int)((M + rows - 1) / rows);
 }
-template <bool OBF>
+// raw 16 / 8 bytes of four consecutive gradient elements (fp32 / bf16: GBF), converted where they are used so that the loads of a
+// batch of rows are issued back to back (a conversion right behind each load made every load wait for its own data)
+template <bool GBF>
+__device__ __forceinline__ float4 un_ldraw4(const float *p, long long idx) {
+    if (GBF) { const uint2 v = *(const uint2 *)((const unsigned short *)p + idx); return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f); }
+    return *(const float4 *)(p + idx);
+}
+template <bool GBF>
+__device__ __forceinline__ void un_cvt4(const float4 r, float *g) {
+    if (GBF) {
+        const unsigned int a = __float_as_uint(r.x), b = __float_as_uint(r.y);
+        g[0] = __uint_as_float(a << 16); g[1] = __uint_as_float(a & 0xFFFF0000u); g[2] = __uint_as_float(b << 16); g[3] = __uint_as_float(b & 0xFFFF0000u);
+    } else { g[0] = r.x; g[1] = r.y; g[2] = r.z; g[3] = r.w; }
+}
+template <bool OBF, bool GBF>
 __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ dy, int ldy,
                                        const float *__restrict__ mean, const float *__restrict__ var,
                                        const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
             if (row < r1) {
                 xv[u] = *(const float4 *)(x + row * ldx + c);
-                gv[u] = *(const float4 *)(dy + row * ldy + c);
+                gv[u] = un_ldraw4<GBF>(dy, row * ldy + c);
                 if (!OBF && accum) ov[u] = *(const float4 *)(dx + row * ldo + c);
             }
         }
@@ -285,7 +304,9 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
         for (int u = 0; u < UN_AP_U; u++) {
             const long long row = rb + (long long)u * rpb;
             if (row >= r1) continue;
-            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gi[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float gi[4];
+            un_cvt4<GBF>(gv[u], gi);
             const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
             float o[4];
 #pragma unroll
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
 }
 // backward twin: sum g / sum g*xhat from the data gradient's epilogue partials (width C) -> sums, dgamma / dbeta (workgroup 0),
 // then dx = gamma*inv*(g - mean(g) - xhat*mean(g*xhat)) for this workgroup's rows (the arithmetic of un_bn_bwd_apply_kernel)
-template <bool OBF>
+template <bool OBF, bool GBF>
 __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ x, int ldx,
                                                                           const float *__restrict__ dy, int ldy, const float *__restrict__ mean,
                                                                           const float *__restrict__ var, const float *__restrict__ gamma,
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
             if (worker && row < r1) {
                 xv[u] = *(const float4 *)(x + (long long)row * ldx + c);
-                gv[u] = *(const float4 *)(dy + (long long)row * ldy + c);
+                gv[u] = un_ldraw4<GBF>(dy, (long long)row * ldy + c);
                 if (!OBF && accum) ov[u] = *(const float4 *)(dx + (long long)row * ldo + c);
             }
         }
@@ -483,7 +504,9 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
         for (int u = 0; u < UN_AP_U; u++) {
             const int row = rb + u * rpb;
             if (row >= r1) continue;
-            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gi[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float gi[4];
+            un_cvt4<GBF>(gv[u], gi);
             const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
             float o[4];
 #pragma unroll
@@ -589,6 +612,7 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
+    std::vector<int> gabf;            // per buffer: the gradient of an activation buffer (one BatchNorm writer, one convolution reader) is stored as bf16
     std::vector<int> gshadow;         // per buffer: width of the bf16 shadow of (a column window of) its fp32 gradient, 0 = none
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
@@ -802,6 +826,41 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             if (ok && nprod == 1 && ncons == 1) n->gbf[b] = 1;
         }
     }
+    // Round 4: the same for the gradient of an ACTIVATION buffer (BatchNorm -> ReLU output, bf16 in the forward): written once by
+    // the data gradient of the one convolution that reads the activation, read once by that BatchNorm's backward.  The convolution's
+    // epilogue takes the BatchNorm-backward partial sums from the unrounded values and stores bf16 (D3_CONV_OUTBF16); the apply pass
+    // reads 2 bytes per element instead of 4.  MEASURED, NOT ADOPTED (D3_ACT_GRAD_BF16 = 0 by default): the gradient arena of the bench batch
+    // shrinks 1.99 -> 1.62 GB, i.e. 0.74 GB less traffic per backward, and the step does not move (19.07 vs 19.00 ms over three
+    // alternating runs; rocprofv3: data-gradient kernels -2 %, the BatchNorm backward unchanged -- at these sizes it is bound by
+    // its per-workgroup reduction of the partial table and by latency, not by the 2 of 16 bytes per element).  fp32 stays.
+    n->gabf.assign(n->B.size(), 0);
+    {
+        const bool on = d3_tune(D3T_ACT_GRAD_BF16) != 0 && !n->f32;
+        for (size_t b = 0; on && b < n->B.size(); b++) {
+            if (n->galias[b] >= 0 || n->gbf[b]) continue;
+            if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
+            bool ok = n->B[b].dtype == 1;
+            for (size_t x = 0; x < n->B.size(); x++)
+                if (n->galias[x] >= 0 && n->T[n->galias[x]].buf == (int)b) ok = false;
+            int nprod = 0, ncons = 0;
+            for (auto &o : n->ops) {
+                if (o.type == OP_PADCAST && n->T[o.out].buf == (int)b) ok = false;
+                if (o.type == OP_STATS) continue;
+                if (o.type == OP_CONV && o.res >= 0 && n->T[o.res].buf == (int)b) ok = false;
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.out].buf == (int)b) {
+                    const TensorD &t = n->T[o.out];
+                    nprod++;
+                    if (o.type != OP_BNACT || t.coff != 0 || t.C != n->B[b].width || (t.C & 7)) ok = false;
+                }
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.in].buf == (int)b) {
+                    const TensorD &t = n->T[o.in];
+                    ncons++;
+                    if (o.type != OP_CONV || o.in_grad_mode != 1 || t.coff != 0 || t.C != n->B[b].width || o.CinW != t.C) ok = false;
+                }
+            }
+            if (ok && nprod == 1 && ncons == 1) n->gabf[b] = 1;
+        }
+    }
     // Residual-stream gradients stay fp32 (they are accumulated in place and feed fp32 consumers), but the convolution that
     // reads one as ITS output gradient uses it as a bf16 MFMA operand, gathered 27 times per row.  Where the last kernel to
     // touch the buffer before that read is a BatchNorm backward apply over the whole buffer (the first BatchNorm of the next
@@ -936,7 +995,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     for (auto &b : n->B) {
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
         const size_t bi = &b - &n->B[0];
-        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[bi] ? 2 : 4));
+        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * ((n->gbf[bi] || n->gabf[bi]) ? 2 : 4));
         if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * n->gshadow[bi] * 2); }
     }
     size_t bnscr = 0, wgws = 16;
@@ -1168,7 +1227,7 @@ static float *gptr(const Net *n, char *garena, const float *gout, float *gin, in
     }
     ld = n->B[t->buf].width;
     root = t->buf;
-    if (n->gbf[t->buf]) {          // (whole-buffer views only: coff == 0)
+    if (n->gbf[t->buf] || n->gabf[t->buf]) {          // (whole-buffer views only: coff == 0)
         if (bf16) *bf16 = 1;
         return (float *)(garena + n->B[t->buf].goff);
     }
@@ -1272,7 +1331,8 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             }
             // data gradient
             if (o.in_grad_mode) {
-                int ldgi, root_i; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i);
+                int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
+                const int obf = gibf ? D3_CONV_OUTBF16 : 0;          // (activation gradients with one writer and one reader: Net::gabf)
                 if (root_i >= 0) wait_pending(root_i);
                 const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel];
                 if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
@@ -1284,15 +1344,15 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                     if (Min > n->lb_rows)
                         rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
                     else
                     rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
                                                   (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
-                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
-                                        (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+                                        (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
                 }
                 if (rc) return rc;
             }
@@ -1346,7 +1406,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             if (M <= 0) continue;
             float *mean = (float *)(arena + o.state_off), *var = mean + C, *sums = var + C;
             const float *gamma = (const float *)params[o.gamma], *beta = (const float *)params[o.beta];
-            int ldgo, root_o; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o);
+            int ldgo, root_o, gobf; float *go = gptr(n, garena, gout, gin, o.out, ldgo, root_o, &gobf);
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
             const int fs_rows_b = d3_tune(D3T_BN_FUSED_ROWS);
@@ -1361,13 +1421,14 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 }
                 unsigned short *sh = (o.in_grad_mode && o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
                 if (!o.in_grad_mode) G = 1;
-                if (gibf)
-                    un_bn_bwd_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, var, gamma, beta,
-                                                                             sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, ldgi, M, C, o.eps, 0, 0, nullptr, rows_pb);
-                else
-                    un_bn_bwd_fused_small_kernel<false><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, var, gamma, beta,
-                                                                              sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, ldgi, M, C, o.eps, 0,
-                                                                              o.in_grad_mode == 2 ? 1 : 0, sh, rows_pb);
+#define UN_FSB(OBFV, GBFV, RELU_, ACC_, SH_)                                                                                          \
+                un_bn_bwd_fused_small_kernel<OBFV, GBFV><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, \
+                                                                              var, gamma, beta, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, \
+                                                                              ldgi, M, C, o.eps, RELU_, ACC_, SH_, rows_pb)
+                if (gibf) { if (gobf) UN_FSB(true, true, 0, 0, nullptr); else UN_FSB(true, false, 0, 0, nullptr); }
+                else if (gobf) UN_FSB(false, true, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
+                else UN_FSB(false, false, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
+#undef UN_FSB
                 continue;
             }
             if (o.fused_by >= 0) {   // reductions (and the ReLU mask) done by the consumer conv's data gradient
@@ -1377,7 +1438,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 relu = 0;
             } else {
                 const int nb = bn_blocks2(M, C);
-                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr);
+                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr, gobf);
                 un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>(bnscr, nb, C, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
             }
             if (o.in_grad_mode) {
@@ -1385,12 +1446,13 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
                 if (root_i >= 0) wait_pending(root_i);
                 const long long total = (long long)M * (C / 4);
                 unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
-                if (gibf)
-                    un_bn_bwd_apply_kernel<true><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
-                                                                                         o.eps, relu, 0, nullptr);
-                else
-                    un_bn_bwd_apply_kernel<false><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C,
-                                                                                          o.eps, relu, o.in_grad_mode == 2 ? 1 : 0, sh);
+#define UN_APB(OBFV, GBFV, ACC_, SH_)                                                                                                     \
+                un_bn_bwd_apply_kernel<OBFV, GBFV><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C, \
+                                                                                              o.eps, relu, ACC_, SH_)
+                if (gibf) { if (gobf) UN_APB(true, true, 0, nullptr); else UN_APB(true, false, 0, nullptr); }
+                else if (gobf) UN_APB(false, true, o.in_grad_mode == 2 ? 1 : 0, sh);
+                else UN_APB(false, false, o.in_grad_mode == 2 ? 1 : 0, sh);
+#undef UN_APB
             }
         }
     }

@@ -224,6 +224,8 @@ int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int 
 #define D3_CONV_ACCUM 16
 #define D3_CONV_XBF16 32   /* x is stored as bf16 (ushort), Cin % 8 == 0; not with D3_CONV_EXACT */
 #define D3_CONV_DYBF16 64  /* dy is stored as bf16 (d3_spconv_wgrad2 only) */
+#define D3_CONV_OUTBF16 512 /* d3_spconv_fwd2*: `out` is stored as bf16 (ushort, ldo in elements); not with D3_CONV_ACCUM, a residual or
+                            * D3_CONV_F32.  BatchNorm partials are taken from the unrounded values. */
 #define D3_CONV_F32 256    /* d3_spconv_pack / d3_spconv_fwd2* / d3_spconv_wgrad2: the REFERENCE'S PRECISION on the matrix cores -- fp32
                             * operands (x, dy fp32; weights packed as fp32 fragments: d3_spconv_pack_bytes_ex), exact fp32 products on
                             * v_mfma_f32_16x16x4_f32, fp32 accumulation.  Not with D3_CONV_XBF16 / D3_CONV_DYBF16. */

@@ -289,3 +289,24 @@ def test_few_row_batchnorm_in_one_launch_matches_the_separate_kernels(dev):
     assert abs(res[16384][0] - res[0][0]) <= 1e-5 * abs(res[0][0]), (res[16384][0], res[0][0])
     assert l2err(res[16384][2], res[0][2]) < 1e-3
     assert l2err(res[16384][1], res[0][1]) < 5e-2          # (bf16 chains decorrelate: see the module docstring; a wrong kernel gives O(1))
+
+
+def test_bf16_activation_gradients_stay_at_the_bf16_noise_floor(dev):
+    """Round 4 (csrc/unet.hip Net::gabf, D3_ACT_GRAD_BF16): the gradient of a BatchNorm -> ReLU activation that one convolution reads
+    is stored as bf16 between that convolution's data gradient (which takes the BatchNorm-backward sums from the unrounded values)
+    and the BatchNorm's backward apply.  Same forward (loss identical); the backward differs by one bf16 rounding per element per
+    layer: parameter gradients within the bf16-chain bound of this module (5e-2; a wrong stride or dtype gives O(1)).  The switch
+    is off by default (measured neutral on the step: DESIGN.md 9); this keeps its code path honest."""
+    from d3net_amd import _lib, synthetic as S
+    L = _lib.lib()
+    scene = S.small_scene(dims=(64, 48, 32), n_boxes=4, seed=7)
+    res = {}
+    try:
+        for on in (1, 0):
+            assert L.d3_tuning_set(b"D3_ACT_GRAD_BF16", on) == 0
+            res[on] = _detector_step(dev, scene)
+    finally:
+        L.d3_tuning_set(b"D3_ACT_GRAD_BF16", 0)
+    assert res[1][0] == res[0][0], (res[1][0], res[0][0])
+    assert l2err(res[1][2], res[0][2]) < 2e-2
+    assert l2err(res[1][1], res[0][1]) < 5e-2
