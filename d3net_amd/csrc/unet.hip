@@ -526,7 +526,8 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
 // levels; the big levels use up to 512 -- every workgroup re-reads the producer's partial table from L2, so their number is
 // what the fusion costs)
 static inline void un_fs_grid(int M, int C, int &G, int &rows_per_block, int cap = 32) {
-    long long g = ((long long)M * C + 16383) / 16384;
+    const long long per = cap > 512 ? (16384ll * 512) / cap : 16384ll;          // (experiments: caps beyond 512 also shrink the slice)
+    long long g = ((long long)M * C + per - 1) / per;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     const int rpb = UN_FS_T / (C >> 2);                   // rows per pass
@@ -1179,7 +1180,7 @@ extern "C" int d3_net_forward(void *h, const void *const *params, const int *con
                 const int fs_big = d3_tune(D3T_BN_FUSED_BIG);
                 if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
                     // statistics + normalisation in one launch (un_bn_fused_small_kernel); big levels: up to 512 workgroups
-                    int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows ? 32 : 512);
+                    int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows ? 32 : (fs_big > 1 ? fs_big : 512));
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
                     if (to.dtype == 1)
                         un_bn_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
@@ -1413,7 +1414,7 @@ extern "C" int d3_net_backward(void *h, const void *const *params, const int *co
             if (o.fused_by >= 0 && M > n->lb_rows && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
                 2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS) {
                 // the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
-                int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows_b ? 32 : 512);
+                int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows_b ? 32 : (d3_tune(D3T_BN_FUSED_BIG) > 1 ? d3_tune(D3T_BN_FUSED_BIG) : 512));
                 float *gi = nullptr; int ldgi = 0, root_i = -1, gibf = 0;
                 if (o.in_grad_mode) {
                     gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
