@@ -330,7 +330,9 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
 // channel c) adds rows j, j + S, ... in fp64, the slices are combined in slice order -- so every workgroup derives bit-identical
 // statistics and the result does not depend on G.  Workgroup 0 stores mean / var (the backward reads them) and updates the
 // running statistics.
+#ifndef UN_FS_T
 #define UN_FS_T 256
+#endif
 #define UN_FS_MAXC 256
 #define UN_FS_MAX_PART_FLOATS 65536      // producer partial tables beyond this (2 * nparts * C floats) keep the separate finalize launch
 // Per-channel fp64 sums of the producer's partial rows, identical in every workgroup: thread (slice j, channel quad q) adds rows
