@@ -130,6 +130,29 @@ def test_joined_decode_chain_equals_the_two_separate_decodes(dev):
         assert torch.equal(gr[n][0], gr2[n][0]) and float((glp[n][0] - glp2[n][0]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("b,extra", [(1, 0), (2, 3), (4, 1), (8, 0)])
+def test_joined_decode_chain_at_other_beam_widths_and_lengths(dev, b, extra):
+    """d3_topdown_beam_greedy's contract (include/d3hip.h): any 1 <= b <= 8, greedy length >= beam length (the greedy rows go on alone
+    once the beams have ended, or stop with them).  Against the two separate library loops on three samples."""
+    from test_oracle_rl import setup
+    from d3net_amd import speaker as SP
+    R, S, g, cfg, vocab, p, lp, d, opt = setup()
+    cap = SP.TopDownSceneCaptionModule(cfg, vocab, S.make_embeddings(), num_proposals=S.K, num_locals=S.L, use_relation=True)
+    cap.load_state_dict(p)
+    cap = cap.to(dev)
+    si = {k: torch.from_numpy(v).to(dev)[:3].contiguous() for k, v in S.step_inputs().items()}
+    T = 7
+    done = cap.beam_decode(si["target"], si["obj"], si["mask"], b, T)
+    gr, glp = cap.greedy_decode(si["target"], si["obj"], si["mask"], T + extra)
+    done2, (gr2, glp2) = cap._beam_decode_native(si["target"], si["obj"], si["mask"], b, T, None, greedy_len=T + extra)
+    for n in range(3):
+        assert len(done[n]) == len(done2[n]) >= 1
+        for x, y in zip(done[n], done2[n]):
+            assert torch.equal(x["seq"], y["seq"]) and abs(x["p"] - y["p"]) < 1e-4
+            assert float((x["logps"] - y["logps"]).abs().max()) < 1e-5
+        assert torch.equal(gr[n][0], gr2[n][0]) and float((glp[n][0] - glp2[n][0]).abs().max()) < 1e-5
+
+
 def test_pipeline_mode3_runs_and_trains(dev):
     from d3net_amd import synthetic as S
     from d3net_amd.config import default_conf
