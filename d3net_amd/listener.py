@@ -165,11 +165,24 @@ class LangModule(nn.Module):
         B, Cn, T, _ = word_embs.shape
         embs = word_embs.reshape(-1, T, self.emb_size)
         lens = lang_len.reshape(-1)
-        if self.native and embs.is_cuda and not self.use_bidir:
+        if self.native and embs.is_cuda:
             # one native call: no host copy of the lengths, no packing / unpacking, hiddens already zero-padded to T (:67-68)
             g = self.gru
             pad, last = GRUSeqFunction.apply(embs.float(), lens, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
-            masks = (torch.arange(T, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)).float()
+            steps = torch.arange(T, device=lens.device).unsqueeze(0)
+            if self.use_bidir:
+                # the reverse direction (:15-24, 58-61) is the same recurrence over every description read backwards: position t of
+                # sample n <-> position len_n - 1 - t (padding stays where it is); its final state is the one at the first word.
+                # The two directions are averaged, as the reference does.
+                L_ = lens.unsqueeze(1).to(steps.dtype)
+                rev = torch.where(steps < L_, L_ - 1 - steps, steps)                       # (N, T), an involution
+                gidx = rev.unsqueeze(-1)
+                e_rev = embs.float().gather(1, gidx.expand(-1, -1, self.emb_size))
+                pad_r, last_r = GRUSeqFunction.apply(e_rev, lens, g.weight_ih_l0_reverse, g.weight_hh_l0_reverse, g.bias_ih_l0_reverse,
+                                                     g.bias_hh_l0_reverse)
+                pad = (pad + pad_r.gather(1, gidx.expand(-1, -1, self.hidden_size))) / 2
+                last = (last + last_r) / 2
+            masks = (steps < lens.unsqueeze(1)).float()
             scores = self.lang_cls(last) if self.use_lang_classifier else None
             return pad, last, masks, scores
         packed = pack_padded_sequence(embs, lens.cpu(), batch_first=True, enforce_sorted=False)

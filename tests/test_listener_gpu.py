@@ -81,14 +81,17 @@ def test_listener_matches_reference_golden(dev, mode):
                 assert np.allclose(got, ref, rtol=5e-3, atol=1e-5 + 2e-3 * np.abs(ref).max()), (k, float(np.abs(got - ref).max()))
 
 
-def test_native_packed_gru_matches_library_gru_at_config_shape(dev):
-    """csrc/topdown.hip's packed-sequence GRU (one GEMM for all input gates + one fused launch per step) against nn.GRU over
+@pytest.mark.parametrize("bidir", [False, True], ids=["forward", "bidirectional"])
+def test_native_packed_gru_matches_library_gru_at_config_shape(dev, bidir):
+    """(bidirectional: model/lang_module.py:15-24,58-61 -- the reverse direction is the native recurrence over the descriptions read
+    backwards, the two directions averaged.)
+    csrc/topdown.hip's packed-sequence GRU (one GEMM for all input gates + one fused launch per step) against nn.GRU over
     pack_padded_sequence on the same parameters: batch 32, T = 128, lengths 1..128 (conf/pointgroup_grounding.yaml shape).
     Outputs 1e-5, parameter gradients 1e-3 of their scale (128 sequential steps, summation order)."""
     import types
     from d3net_amd.listener import LangModule
     torch.manual_seed(3)
-    cfg = types.SimpleNamespace(model=types.SimpleNamespace(num_bbox_class=18, use_lang_classifier=True, use_bidir=False))
+    cfg = types.SimpleNamespace(model=types.SimpleNamespace(num_bbox_class=18, use_lang_classifier=True, use_bidir=bidir))
     lm = LangModule(cfg).to(dev)
     for m in lm.modules():
         if isinstance(m, torch.nn.Dropout):
