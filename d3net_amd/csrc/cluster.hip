@@ -318,8 +318,10 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     int h[5] = {0, 0, 0, 0, 0};
     const int npb = nwb < 4096 ? nwb : 4096;      // label push: a bounded grid of waves walks the nodes
     for (int it = 0;; it += 2) {
-        D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
-        D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
+        if (it > 0) {          // (the first pair of sweeps finds both flags zeroed by cl_init_kernel: two 4-byte fill launches less per clustering)
+            D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
+            D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
+        }
         if (it == 0 && asc)
             cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 1);
         cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 0);
@@ -342,10 +344,13 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     return 0;
 }
 
+// z0 / z1 (optional, n ints each): zeroed here instead of by two fill launches in front of the record pass (3 MB each at the bench
+// batch: 13 + 29 us of fill kernels and their launch gaps on the clustering's critical path)
 __global__ void cl_seed_kernel(const int *flag, const int *cid, const int *koff, int n, int *seeds,
-                               int *cluster_offsets, int nCluster, int sumNPoint) {
+                               int *cluster_offsets, int nCluster, int sumNPoint, int *z0, int *z1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cluster_offsets[nCluster] = sumNPoint;
+    if (i < n && z0) { z0[i] = 0; z1[i] = 0; }
     if (i >= n || !flag[i]) return;
     seeds[cid[i]] = i;
     cluster_offsets[cid[i]] = koff[i];
@@ -503,7 +508,7 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T;
-    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
+    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint, nullptr, nullptr);
     if (nCluster > 0)
         cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
                                                          w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, 0);
@@ -907,7 +912,7 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
     if (erec == nullptr || erec_bytes < d3_bfs_cluster_erec_bytes(nActive)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
-    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint);
+    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint, nCluster > 0 ? w.lcnt : nullptr, w.star);
     if (nCluster > 0) {
         static bool attr_done_dev[64] = {false};   // the attribute is per device
         const size_t lds = (size_t)B2_LDS_INTS * sizeof(int);
@@ -916,8 +921,6 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
             D3_CHECK(hipFuncSetAttribute((const void *)cl_bfs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (dev_id >= 0 && dev_id < 64) attr_done_dev[dev_id] = true;
         }
-        D3_CHECK(hipMemsetAsync(w.lcnt, 0, (size_t)n * sizeof(int), s));
-        D3_CHECK(hipMemsetAsync(w.star, 0, (size_t)n * sizeof(int), s));
         const bool no_star = d3_tune(D3T_BFS_NO_STAR) != 0;   // (tests: force the level loop for every cluster)
         if (!no_star)
             cl_star_kernel<<<(nCluster + 3) / 4, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.seeds, w.koff, w.sizes, nCluster, w.star,
