@@ -26,6 +26,7 @@ def _run(extra, env):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
+    assert len(lines[0]) < 4096, len(lines[0])          # the driver keeps only the tail of stdout
     return json.loads(lines[0])
 
 
@@ -40,6 +41,12 @@ def test_two_rank_bench_line(dev):
     assert "bench.py itself: 2 child ranks" in out["config"]["launched_by"] and out["config"]["launched_by"].endswith("rc 0")
     assert out["config"]["world"]["size_seen_by_process_group"] == 2 and out["config"]["world"]["backend"] == "gloo"
     assert out["config"]["global_batch"] == 8 and out["config"]["scenes_per_gpu"] == 4
+    # per-rank clocks, ranks the backend saw, bytes of every collective of a step
+    pr = out["config"]["per_rank_ms_per_step"]
+    assert len(pr) == 2 and abs(max(pr) - out["ms_per_step"]) < 0.02 * out["ms_per_step"] + 0.01, (pr, out["ms_per_step"])
+    gs0 = out["config"]["grad_sync"]
+    assert gs0["ranks_seen_by_backend"] == 2 and len(gs0["bytes_per_collective"]) == gs0["collectives_per_step"], gs0
+    assert os.path.exists(os.path.join(ROOT, out["detail"]))
     # the heads' bucket starts from inside backward() in every step after the first (which compares the layouts first):
     # 1 dry-run + 2 settle (--settle 2) + 1 warm-up + 1 pyramid-census step + 2 timed steps -> all but the first start early; and it
     # changes nothing in the result

@@ -15,7 +15,8 @@ if [ "$SKIP" != "skip-tests" ]; then
   timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 2>&1 | tail -40 > $OUT/pytest_gpu.log
   timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -2 > $OUT/smoke.log
 fi
-timeout 900 python bench.py $BARGS 2> $OUT/bench.err | grep '^{' > $OUT/bench.json
+timeout 1200 python bench.py $BARGS 2> $OUT/bench.err | grep '^{' > $OUT/bench.json
+cp gpurun_out/bench_detail_speaker.json $OUT/bench_detail.json 2>/dev/null
 timeout 300 python bench.py --exact --no-cpu-baseline $BARGS 2> $OUT/bench_exact.err | grep '^{' > $OUT/bench_exact.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fp32 --no-ceiling $BARGS > $OUT/bench_under_rocprof.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv") $OUT/kernel_stats.csv
@@ -32,6 +33,7 @@ python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT
 timeout 300 python tools/phase_times.py 10 > $OUT/phases.txt 2>&1
 for CFG in detector listener joint; do
   timeout 400 python bench.py --config $CFG --no-fp32 --no-cpu-baseline 2> $OUT/bench_$CFG.err | grep '^{' > $OUT/bench_$CFG.json
+  cp gpurun_out/bench_detail_$CFG.json $OUT/bench_detail_$CFG.json 2>/dev/null
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$CFG -o bench -- python3 bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-ceiling > $OUT/bench_${CFG}_under_rocprof.log 2>&1
   cp $(find /tmp/prof_${TAG}_$CFG -name "*kernel_stats.csv") $OUT/kernel_stats_$CFG.csv
   for CTR in FETCH_SIZE WRITE_SIZE; do
