@@ -391,8 +391,13 @@ static int hg_class(const d3_gemm_prob &p) {
 #define HG_KS 4
 #define HG_DECLINED 1000000
 #define HG_KS_MINK 8192          // measured in-process: K = 12,288 (joint) -0.55 ms / step, K = 4,096 (listener) +0.2 ms (the second launch costs more than the slices save)
-struct HgScratch { hipStream_t s; float *p; size_t floats; };          // grow-only, one per stream that ever ran a split
-static HgScratch g_hg_scr[8];
+// grow-only, one per (device, stream) that ever ran a split: torch's default stream is handle 0 on EVERY device, so the stream
+// alone does not identify the buffer.  The buffer lives in the stream's own order (hipMallocAsync / hipFreeAsync on
+// the launch stream): growing needs no host synchronisation, and the kernels already enqueued on the stream finish with the old
+// buffer before it is released.  The table's mutex is held until this call's launches are enqueued, so a concurrent grow on
+// another thread cannot slip between reading the pointer and using it.
+struct HgScratch { int dev; hipStream_t s; float *p; size_t floats; };
+static HgScratch g_hg_scr[32];
 static int g_hg_nscr = 0;
 static std::mutex g_hg_scr_mu;
 __global__ void hg_splitk_reduce_kernel(const float *__restrict__ part, d3_gemm_prob p, long long slice) {
@@ -413,21 +418,22 @@ static int hg_launch_batch(const d3_gemm_prob *probs, int nprobs, hipStream_t s)
 static int hg_splitk(const d3_gemm_prob &p, hipStream_t s) {
     const long long slice = (long long)p.M * p.N;
     float *g_hg_scratch = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return HG_DECLINED;
+    std::lock_guard<std::mutex> lk(g_hg_scr_mu);          // (held until the launches below are enqueued)
     {
-        std::lock_guard<std::mutex> lk(g_hg_scr_mu);
         HgScratch *e = nullptr;
-        for (int i = 0; i < g_hg_nscr; i++) if (g_hg_scr[i].s == s) e = &g_hg_scr[i];
+        for (int i = 0; i < g_hg_nscr; i++) if (g_hg_scr[i].s == s && g_hg_scr[i].dev == dev) e = &g_hg_scr[i];
         if (!e) {
-            if (g_hg_nscr == 8) return HG_DECLINED;          // (more streams than slots: the caller keeps the one-workgroup reduction)
+            if (g_hg_nscr == 32) return HG_DECLINED;          // (more streams than slots: the caller keeps the one-workgroup reduction)
             e = &g_hg_scr[g_hg_nscr++];
-            e->s = s; e->p = nullptr; e->floats = 0;
+            e->dev = dev; e->s = s; e->p = nullptr; e->floats = 0;
         }
         if ((size_t)(slice * HG_KS) > e->floats) {
-            D3_CHECK(hipStreamSynchronize(s));          // (growing: nothing may still read the old buffer)
-            if (e->p) D3_CHECK(hipFree(e->p));
+            if (e->p) D3_CHECK(hipFreeAsync(e->p, s));          // (stream-ordered: earlier launches on s still read it safely)
             e->floats = (size_t)(slice * HG_KS) * 2;
             e->p = nullptr;
-            D3_CHECK(hipMalloc((void **)&e->p, e->floats * sizeof(float)));
+            D3_CHECK(hipMallocAsync((void **)&e->p, e->floats * sizeof(float), s));
         }
         g_hg_scratch = e->p;
     }

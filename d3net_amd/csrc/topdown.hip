@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void td_beam_select_body(const int n, const int rs, c
                                                              const float *__restrict__ h2_in, float *__restrict__ h1_out,
                                                              float *__restrict__ h2_out, int H) {
     __shared__ float s_max[8], s_lse[8], s_sum[8];
-    __shared__ int s_pick[8];
+    __shared__ int s_pick[8], s_nan[8];
     __shared__ float s_pickv[8];
     __shared__ float w_v[BS_T / 64];
     __shared__ int w_i[BS_T / 64];
@@ -1129,6 +1129,15 @@ __device__ __forceinline__ void td_beam_select_body(const int n, const int rs, c
         if (tid == 0) {
             float fv = w_v[0]; int fi = w_i[0];
             for (int w = 1; w < BS_T / 64; w++) if (w_v[w] > fv || (w_v[w] == fv && w_i[w] < fi)) { fv = w_v[w]; fi = w_i[w]; }
+            // NaN / all -inf scores: no comparison above is ever true and the sentinel index survives.  torch.topk returns NaN
+            // scores there (a non-finite-loss guard can skip the step); an unguarded 0x7FFFFFFF would index far out of bounds.
+            // Take the lowest candidate not picked yet (its score is NaN / -inf and propagates into snap / sums_out).
+            if (fi == 0x7FFFFFFF) {
+                fi = 0;
+                for (int q = 0; q < r; q++) if (s_pick[q] == fi) { fi++; q = -1; }
+                if (fi >= total) fi = 0;
+                s_nan[r] = 1;
+            } else s_nan[r] = 0;
             s_pick[r] = fi; s_pickv[r] = fv; cs[fi] = -INFINITY;
         }
         __syncthreads();
@@ -1136,7 +1145,8 @@ __device__ __forceinline__ void td_beam_select_body(const int n, const int rs, c
     // (c) outputs
     if (tid < b) {
         const int flat = s_pick[tid], j = flat / V, v = flat - j * V;
-        const float chosen = (logits[((long long)n * rs + j) * V + v] - s_max[j]) - s_lse[j];
+        float chosen = (logits[((long long)n * rs + j) * V + v] - s_max[j]) - s_lse[j];
+        if (s_nan[tid]) chosen = __builtin_nanf("");     // (degenerate scores: the pick is arbitrary, its score says so)
         const float snap = s_sum[j] + chosen;
         const bool ended = last || v == eos;
         const long long o = (long long)n * b + tid;
@@ -1205,6 +1215,10 @@ __device__ __forceinline__ void td_greedy_select_body(const float *__restrict__ 
     __syncthreads();
     m = w_v[0]; mi = w_i[0];
     for (int w = 1; w < BS_T / 64; w++) if (w_v[w] > m || (w_v[w] == m && w_i[w] < mi)) { m = w_v[w]; mi = w_i[w]; }
+    // NaN / all -inf logits: no comparison is ever true; torch.max returns NaN there.  Index 0 with a NaN log-probability
+    // instead of an out-of-bounds read through the sentinel.
+    const bool degenerate = mi == 0x7FFFFFFF;
+    if (degenerate) mi = 0;
     float sm = 0.f;
     for (int v = tid; v < V; v += BS_T) sm += expf(x[v] - m);
     for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
@@ -1213,7 +1227,7 @@ __device__ __forceinline__ void td_greedy_select_body(const float *__restrict__ 
     if (tid == 0) {
         float tot = 0.f;
         for (int w = 0; w < BS_T / 64; w++) tot += w_s[w];
-        *word = mi; *lp = (x[mi] - m) - logf(tot); if (word2) *word2 = mi;
+        *word = mi; *lp = degenerate ? __builtin_nanf("") : (x[mi] - m) - logf(tot); if (word2) *word2 = mi;
     }
 }
 // rows n * rs + off of logits (rs = 1, off = 0: dense); word2 (optional): the token also goes to row n * rs + off of the next step's input

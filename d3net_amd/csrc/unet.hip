@@ -1074,8 +1074,26 @@ static inline char *tptr(const Net *n, char *arena, const void *input, int tenso
     return arena + n->B[t.buf].off + (size_t)t.coff * esize(t.dtype);
 }
 
+// The 16-bit tables handed over by d3_net_set_k3_16 serve exactly ONE forward or backward call (a caller that freed
+// its coordinate manager and ran again without re-setting them read freed tables): every return path of the two entry points
+// drops them, and the thread-local hint of d3_spconv_next_tbl16 with them (an error return taken between setting the hint and
+// the convolution that consumes it must not hand the table to an unrelated K = 27 convolution on this thread).
+void d3_spconv_next_tbl16(const void *tbl16, const int *ok16);
+static void net_drop_k3_16(Net *n) {
+    if (n) { n->k3_16.assign(n->k3_16.size(), nullptr); n->ok16.assign(n->ok16.size(), nullptr); }
+    d3_spconv_next_tbl16(nullptr, nullptr);
+}
+static int net_forward_impl(void *h, const void *const *params, const int *const *k3, const int *const *child,
+                            const int *const *up, const void *input, void *arena_, int training, void *stream);
 extern "C" int d3_net_forward(void *h, const void *const *params, const int *const *k3, const int *const *child,
                               const int *const *up, const void *input, void *arena_, int training, void *stream) {
+    if (!h) return D3_ERR_ARG;
+    const int rc = net_forward_impl(h, params, k3, child, up, input, arena_, training, stream);
+    net_drop_k3_16((Net *)h);
+    return rc;
+}
+static int net_forward_impl(void *h, const void *const *params, const int *const *k3, const int *const *child,
+                            const int *const *up, const void *input, void *arena_, int training, void *stream) {
     D3_CLEAR();
     Net *n = (Net *)h;
     if (!n->planned) return D3_ERR_ARG;
@@ -1240,9 +1258,20 @@ static float *gptr(const Net *n, char *garena, const float *gout, float *gin, in
 // gout: gradient of the output tensor (rows x C fp32, dense); pgrads[param]: where to write / accumulate the
 // parameter gradient (NULL = frozen); paccum[param] != 0 -> accumulate.  gin: gradient of the external input
 // (only when the network was created with input_needs_grad).
+static int net_backward_impl(void *h, const void *const *params, const int *const *k3, const int *const *child,
+                             const int *const *up, const void *input, void *arena_, void *garena_, const float *gout,
+                             float *const *pgrads, const int *paccum, float *gin, void *stream);
 extern "C" int d3_net_backward(void *h, const void *const *params, const int *const *k3, const int *const *child,
                                const int *const *up, const void *input, void *arena_, void *garena_, const float *gout,
                                float *const *pgrads, const int *paccum, float *gin, void *stream) {
+    if (!h) return D3_ERR_ARG;
+    const int rc = net_backward_impl(h, params, k3, child, up, input, arena_, garena_, gout, pgrads, paccum, gin, stream);
+    net_drop_k3_16((Net *)h);
+    return rc;
+}
+static int net_backward_impl(void *h, const void *const *params, const int *const *k3, const int *const *child,
+                             const int *const *up, const void *input, void *arena_, void *garena_, const float *gout,
+                             float *const *pgrads, const int *paccum, float *gin, void *stream) {
     D3_CLEAR();
     Net *n = (Net *)h;
     if (!n->planned) return D3_ERR_ARG;

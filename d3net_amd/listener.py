@@ -174,7 +174,7 @@ class LangModule(nn.Module):
                 # the reverse direction (:15-24, 58-61) is the same recurrence over every description read backwards: position t of
                 # sample n <-> position len_n - 1 - t (padding stays where it is); its final state is the one at the first word.
                 # The two directions are averaged, as the reference does.
-                L_ = lens.unsqueeze(1).to(steps.dtype)
+                L_ = lens.clamp(max=T).unsqueeze(1).to(steps.dtype)      # (a length beyond T would gather out of range)
                 rev = torch.where(steps < L_, L_ - 1 - steps, steps)                       # (N, T), an involution
                 gidx = rev.unsqueeze(-1)
                 e_rev = embs.float().gather(1, gidx.expand(-1, -1, self.emb_size))

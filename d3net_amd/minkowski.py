@@ -74,8 +74,45 @@ def exact_for(training):
     return _EXACT or (not training and _EVAL_EXACT)
 
 
+class heads_exact_for:
+    """`with heads_exact_for(training):` -- the heads' GEMM mode follows the same policy as the U-Nets: an evaluation forward that
+    runs the fp32 twin executors must not run the heads on the bf16 x 3 split either (set_exact() switched
+    D3_HG_BF16X3 off, exact_for() did not).  A no-op in training mode and when the split is off anyway (the default)."""
+
+    def __init__(self, training):
+        self.on = (not training) and _EVAL_EXACT and not _EXACT
+        self.prev = None
+
+    def __enter__(self):
+        if self.on:
+            try:
+                L = _lib.lib()
+                v = C.c_int(0)
+                L.d3_tuning_get(b"D3_HG_BF16X3", C.byref(v))
+                if v.value:
+                    self.prev = int(v.value)
+                    L.d3_tuning_set(b"D3_HG_BF16X3", 0)
+            except Exception:
+                self.prev = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            _lib.lib().d3_tuning_set(b"D3_HG_BF16X3", self.prev)
+        return False
+
+
 def _mode_flag():
     return D3_CONV_EXACT if _EXACT else 0
+
+
+def _kmap16_enabled():
+    try:
+        v = C.c_int(1)
+        _lib.lib().d3_tuning_get(b"D3_KMAP16", C.byref(v))
+        return bool(v.value)
+    except Exception:
+        return True
 
 
 # ------------------------------------------------------------------------------ coordinate manager
@@ -90,6 +127,10 @@ class CoordinateManager:
         self._k3_16 = {}
         self._down = {}
         self._pending = None      # begin_pyramid() without its build_pyramid() yet
+        # build the 16-bit form of the big levels' 27-offset tables?  Only a bf16 executor reads it, and only with D3_KMAP16 on
+        # (the fp32 / evaluation executors and D3_KMAP16=0 paid 54 B per row, a pinned tensor, a copy and an event per
+        # level for a table nobody read); NativeUNet's caller says so through `want16`
+        self.want16 = _kmap16_enabled()
 
     def __del__(self):
         # a begin_pyramid() whose build_pyramid() never ran (an exception in between): hand the ticket back to the library's pool
@@ -112,7 +153,7 @@ class CoordinateManager:
             nbr = torch.empty((M, 27), dtype=torch.int32, device=self.device)
             ws = self._ws(M)
             with _on(self.device):
-                if M >= self.K3_16_MIN_ROWS:      # big level: the 16-bit form and its validity flag in the same pass
+                if M >= self.K3_16_MIN_ROWS and self.want16:      # big level: the 16-bit form and its validity flag in the same pass
                     n16 = torch.empty(M * 27 + 2, dtype=torch.int16, device=self.device)
                     ok = torch.empty(1, dtype=torch.int32, device=self.device)
                     check(_lib.lib().d3_kmap_k3_16(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _ptr(n16), _ptr(ok), _stream()), "kmap_k3_16")

@@ -200,7 +200,13 @@ class PipelineNet(nn.Module):
     @torch.no_grad()
     def validation_step(self, data_dict, idx=0, dataloader_idx=0):
         """(model/pipeline.py:457-643) detector losses (mode 0), dense-caption candidates of the batch (modes 1 / 3 loader 0:
-        evaluation decode of all proposals + Hungarian assignment to the GT boxes), grounding scores (modes 2 / 3 loader 1)"""
+        evaluation decode of all proposals + Hungarian assignment to the GT boxes), grounding scores (modes 2 / 3 loader 1).
+        Precision policy: in eval() the U-Nets run their fp32 twin executors and the heads' GEMMs stay exact fp32."""
+        from . import minkowski as ME
+        with ME.heads_exact_for(self.training):
+            return self._validation_step(data_dict, idx, dataloader_idx)
+
+    def _validation_step(self, data_dict, idx=0, dataloader_idx=0):
         from .caption_eval import eval_caption_step
         if self.mode not in (0, 1, 2, 3):
             raise NotImplementedError("GT-proposal modes 4-6 (no_detection) are not on the hot path")
@@ -225,6 +231,10 @@ class PipelineNet(nn.Module):
         `combined` = CIDEr + Acc@0.5IoU, the monitor of the joint training"""
         from .caption_eval import eval_caption_epoch
         log = {}
+        # the fp32 twin executors evaluation forwards instantiated beside the bf16 ones (packed fp32 weights, arena plan, flat
+        # gradient buffer) go away with the validation epoch; the next evaluation forward rebuilds them (ADVICE r4)
+        if not self.no_detection and hasattr(self.detector, "release_eval_executors"):
+            self.detector.release_eval_executors()
         if self.mode in (0, 2):
             return log
         cap_outs = outputs if self.mode == 1 else outputs[0]
@@ -250,6 +260,11 @@ class PipelineNet(nn.Module):
 
     def forward(self, data_dict):
         """inference entry point (model/pipeline.py:894-925): detector -> speaker -> listener, whichever exist"""
+        from . import minkowski as ME
+        with ME.heads_exact_for(self.training):
+            return self._forward(data_dict)
+
+    def _forward(self, data_dict):
         if not self.no_detection:
             data_dict = self.detector.feed(data_dict, self.current_epoch)
         if not self.no_captioning:

@@ -172,8 +172,20 @@ class PointGroup(nn.Module):
         if not (self.native_unet and voxel_locs.is_cuda and voxel_locs.size(0) > 0) or (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)):
             return None
         cm = ME.CoordinateManager(voxel_locs.int().contiguous())
-        cm.begin_pyramid(self._exec(name, exact=ME.exact_for(self.training)).nlevels)
+        exact = ME.exact_for(self.training)
+        if exact:
+            cm.want16 = False        # (only the bf16 executors read the 16-bit kernel maps)
+        cm.begin_pyramid(self._exec(name, exact=exact).nlevels)
         return cm
+
+    def release_eval_executors(self):
+        """free the fp32 twin executors (packed fp32 weights, fp32 arena plan, flat gradient buffer) that evaluation-mode forwards
+        instantiate beside the bf16 ones under the precision policy (minkowski.exact_for): call after a validation pass inside a
+        training run when the memory matters; the next evaluation forward rebuilds them (one plan + one weight packing)."""
+        if ME._EXACT:
+            return       # the fp32 executors ARE the training executors in this mode
+        for key in [k for k in self._execs if k.endswith("/f32")]:
+            del self._execs[key]
 
     def _run_unet(self, name, module, x):
         """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""

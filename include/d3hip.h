@@ -361,7 +361,7 @@ int d3_net_backward(void *net, const void *const *params, const int *const *k3, 
  * before the call's last kernel.  d3_net_set_chunks: op_idx[k] (strictly descending) = the op after which chunk k is
  * complete; d3_net_backward then flushes the pending weight-gradient reductions there and records two events per chunk.
  * d3_net_chunk_wait makes `stream` wait for chunk k of the last backward -- the caller starts that chunk's all-reduce on
- * it while the rest of the backward is still running.  nchunks <= 64; 0 switches the feature off. */
+ * it while the rest of the backward is still running.  2 * (nchunks + 2) <= 32, i.e. nchunks <= 14 (else D3_ERR_ARG); 0 switches the feature off. */
 int d3_net_set_chunks(void *net, const int *op_idx, int nchunks);
 /* per level: the 16-bit form of the k3 table handed to the next d3_net_forward / d3_net_backward call (NULL entries, or a NULL
  * array, = dense tables only).  The caller passes only tables whose d3_kmap_k3_pack16 flag it has READ as 1 (ok16[l]: any

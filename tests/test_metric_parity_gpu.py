@@ -293,7 +293,7 @@ def test_heldout_map_and_cider_parity_with_the_fp32_oracle(dev, seed):
     mAP / CIDEr the library reports: `validation_step`, `forward()` under `eval()` -- runs the reference-precision kernels.
       * the evaluation path AS SHIPPED must meet BASELINE.json's bound: mAP@0.5 and CIDEr@0.5IoU within 0.5 % of the fp32 CPU oracle
         on the same weights and scenes, for every seed (measured on the final tree: mAP and CIDEr identical to five digits; 766 / 768 / 768 of 768 captions);
-      * the bf16 kernels forced onto the evaluation are REPORTED and held to a looser bound (mAP 1 %, CIDEr 3 %): a bf16 forward
+      * the bf16 kernels forced onto the evaluation are REPORTED and held to a looser bound (mAP 1 %, CIDEr 2 % -- round 3's bound, not loosened: ADVICE r4): a bf16 forward
         perturbs the 16-dim proposal features by ~1e-2, ~1 % of the greedy captions change a token and an occasional box crosses
         IoU 0.5 -- discrete events worth 0.15 - 0.4 % of CIDEr each.  Six trained models measured +0.04 / -0.21 / -0.19 / -0.12 / -1.70 / +0.12 %
         (757 - 766 of 768 captions identical): not inside 0.5 % with any margin, which is why evaluation does not use them.
@@ -307,7 +307,7 @@ def test_heldout_map_and_cider_parity_with_the_fp32_oracle(dev, seed):
     assert 0.3 < o["mAP"] < 0.95, ("operating point saturated or degenerate", o["mAP"])
     assert o["cider"] > 0.2, o["cider"]
     for k, name, b_map, b_cider, b_same in (("exact", "evaluation path as shipped (reference-precision kernels)", 0.005, 0.005, 0.99),
-                                            ("bf16", "bf16 kernels forced onto the evaluation", 0.01, 0.03, 0.97)):
+                                            ("bf16", "bf16 kernels forced onto the evaluation", 0.01, 0.02, 0.97)):
         h = res[k]
         print("seed %d, %s vs fp32 oracle: mAP@0.5 %.5f vs %.5f = %+.3f %%; CIDEr@0.5IoU %.5f vs %.5f = %+.3f %%; %d / %d captions identical"
               % (seed, name, h["mAP"], o["mAP"], 100 * (h["mAP"] - o["mAP"]) / o["mAP"], h["cider"], o["cider"],

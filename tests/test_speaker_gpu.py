@@ -344,3 +344,48 @@ def test_beam_and_greedy_selection_kernels_match_the_library_formulation(dev):
     assert L.d3_greedy_select(ptr(logits), 33, V, ptr(word), ptr(lp), st) == 0
     rl, rw = F.log_softmax(logits, dim=-1).max(-1)
     assert torch.equal(word, rw) and torch.allclose(lp, rl, rtol=1e-6, atol=1e-6)
+
+
+def test_selection_kernels_survive_nan_and_all_minus_inf_logits(dev):
+    """NaN / all -inf logits leave every `c > best` comparison false; the arg-max sentinel must not be used as an index
+    (a far out-of-bounds read = GPU memory fault).  torch.topk / .max return NaN scores there, which a non-finite-loss guard can
+    skip: the kernels return in-range tokens with NaN (or -inf) scores, and healthy samples of the same launch are untouched."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from d3net_amd import _lib
+    L = _lib.lib()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N, b, V, H, Tmax, eos = 4, 3, 3004, 64, 6, 3
+    g = torch.Generator().manual_seed(11)
+    for t, live in ((0, 1), (1, b)):
+        logits = (torch.randn(N * b, V, generator=g) * 3).to(dev)
+        logits[0 * b:(0 + 1) * b] = float("nan")              # sample 0: NaN everywhere
+        logits[1 * b:(1 + 1) * b] = float("-inf")             # sample 1: all -inf (log-softmax of it is NaN)
+        h1, h2 = torch.randn(N * b, H, generator=g).to(dev), torch.randn(N * b, H, generator=g).to(dev)
+        sums_in = torch.zeros(N, b, device=dev)
+        seq_prev = torch.zeros(N, b, Tmax, dtype=torch.long, device=dev)
+        seq_out = torch.zeros(N, b, Tmax, dtype=torch.long, device=dev)
+        tok_k = torch.full((N * b,), -7, dtype=torch.long, device=dev)
+        snap_k, sums_k = torch.empty(N, b, device=dev), torch.empty(N, b, device=dev)
+        ended_k = torch.empty(N, b, dtype=torch.uint8, device=dev)
+        h1o, h2o = torch.empty_like(h1), torch.empty_like(h2)
+        rc = L.d3_beam_select(ptr(logits), ptr(sums_in), N, live, b, V, eos, 0, t, Tmax, ptr(seq_prev) if t > 0 else None, ptr(seq_out), ptr(tok_k),
+                              ptr(snap_k), ptr(ended_k), ptr(sums_k), ptr(h1), ptr(h2), ptr(h1o), ptr(h2o), H, st)
+        assert rc == 0
+        torch.cuda.synchronize()                                # (a fault would surface here)
+        tk = tok_k.view(N, b)
+        assert bool(((tk >= 0) & (tk < V)).all())
+        assert not bool(torch.isfinite(snap_k[:2]).any()) and bool(torch.isfinite(snap_k[2:]).all())
+        # the healthy samples equal the library formulation
+        logp = F.log_softmax(logits.view(N, b, V)[2:, :live], dim=-1)
+        ix = torch.sort(logp.reshape(N - 2, live * V), dim=-1, descending=True, stable=True)[1][:, :b]
+        assert torch.equal(tk[2:], ix % V)
+    logits = (torch.randn(5, V, generator=g) * 2).to(dev)
+    logits[1] = float("nan"); logits[3] = float("-inf")
+    word, lp = torch.empty(5, dtype=torch.long, device=dev), torch.empty(5, device=dev)
+    assert L.d3_greedy_select(ptr(logits), 5, V, ptr(word), ptr(lp), st) == 0
+    torch.cuda.synchronize()
+    assert bool(((word >= 0) & (word < V)).all()) and bool(torch.isnan(lp[[1, 3]]).all())
+    rl, rw = F.log_softmax(logits[[0, 2, 4]], dim=-1).max(-1)
+    assert torch.equal(word[[0, 2, 4]], rw) and torch.allclose(lp[[0, 2, 4]], rl, rtol=1e-6, atol=1e-6)
