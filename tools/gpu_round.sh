@@ -4,6 +4,7 @@
 # the same command; then bench line + kernel stats of the other three configs.
 # usage: tools/gpu_round.sh <tag> [skip-tests] [bench args...]  -> everything lands under gpurun_out/<tag>/ ; every step is bounded.
 set -u
+ulimit -c 0      # (a faulting process must not fill the box's disk with a multi-GB core file)
 TAG=${1:-r03}
 SKIP=${2:-}
 shift; shift
