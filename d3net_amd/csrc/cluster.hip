@@ -121,6 +121,30 @@ __device__ __forceinline__ void cl_union(int *parent, int a, int b) {
     }
 }
 
+// phase 1a, opening move (round 5; the initialisation of ECL-CC, Jaiganesh & Burtscher 2018): every node hooks itself under ONE
+// smaller-index neighbour across a mutual edge before any union runs -- no atomics (a thread writes only its own entry), parent < child
+// keeps the forest acyclic and every tree inside a true component.  On surfaces in scan order that alone builds most of each tree; the
+// union pass below then finds most edges already inside one tree (two short walks, no atomic) instead of hooking root by root.
+// Lists need not be sorted: any of the first CL_HOOK_TRY entries that qualifies will do (in ascending lists the smallest come first).
+#define CL_HOOK_TRY 4
+__global__ __launch_bounds__(256) void cl_hook_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
+                                                     const int *__restrict__ start_len, int n, int *parent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
+    if (ln >= CL_CAP) return;                      // a capped list's edges need not be mutual: left to the label push
+    const int si = sem[i];
+    int j[CL_HOOK_TRY];
+#pragma unroll
+    for (int e = 0; e < CL_HOOK_TRY; e++) j[e] = e < ln ? idx[st + e] : i;
+    int sj[CL_HOOK_TRY], lj[CL_HOOK_TRY];
+#pragma unroll
+    for (int e = 0; e < CL_HOOK_TRY; e++) { sj[e] = sem[j[e]]; lj[e] = start_len[j[e] * 2 + 1]; }
+#pragma unroll
+    for (int e = 0; e < CL_HOOK_TRY; e++)
+        if (j[e] < i && sj[e] == si && lj[e] < CL_CAP) { parent[i] = j[e]; return; }
+}
+
 // phase 1a: eight lanes per node walk its (complete, hence short) list, four edges per lane in flight: every edge is a
 // chain of dependent gathers (neighbour id -> its label / list length -> the two finds), and a thread per node walked
 // that chain once per edge.  scalars[3] is raised when any list is capped: only then does phase 1b have work.
@@ -268,11 +292,14 @@ __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *
         todo &= ~grp;
     }
 }
-__global__ void cl_keep_kernel(const int *sizes, int *flag, int *ksz, int n, int threshold) {
+// scalars[5] <- 1 when some list is longer than cl_bfs3_kernel's key can number (B3_MAXLIST entries; the reference's ball query
+// stops at 1000): read back with the counts, the fill then keeps the edge-parallel replay
+__global__ void cl_keep_kernel(const int *sizes, int *flag, int *ksz, int n, int threshold, const int *__restrict__ start_len, int *scalars) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int k = sizes[i] >= threshold && sizes[i] > 0;
     flag[i] = k; ksz[i] = k ? sizes[i] : 0;
+    if (start_len[i * 2 + 1] > 2047) scalars[5] = 1;
 }
 __global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz, const int *koff, int n,
                                  int *scalars) {
@@ -284,6 +311,11 @@ __global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz
 
 static int cl_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold, void *ws,
                     size_t ws_bytes, int *sumNPoint_host, int *nCluster_host, int flags, void *stream);
+// The count phase reads back, with the counts, whether every list fits cl_bfs3_kernel's key (<= 2047 entries).  The fill uses
+// that replay only for a workspace this thread's last count vouched for; anything else (a fill on another thread, a count that
+// saw a longer list) keeps cl_bfs2_kernel, which has no such limit.
+static thread_local const void *g_cl_checked_ws = nullptr;
+static thread_local bool g_cl_short_lists = false;
 
 extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
                                     int n, int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host,
@@ -309,13 +341,14 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
     cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, w.qln, n, w.scalars);   // (klen, qln: scratch until the fill)
+    if (d3_tune(D3T_CL_HOOK) != 0) cl_hook_kernel<<<nb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
     cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
     cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
     D3_LAUNCH_CHECK();
     // Label pushes in pairs, and the sizes / ids / offsets computed right behind them, all read back with ONE host round
     // trip: the usual case is one productive sweep plus the sweep that finds nothing left to do (the second one reports
     // through its own flag, scalars[4]); only when both sweeps still changed labels is the tail recomputed after more.
-    int h[5] = {0, 0, 0, 0, 0};
+    int h[6] = {0, 0, 0, 0, 0, 0};
     const int npb = nwb < 4096 ? nwb : 4096;      // label push: a bounded grid of waves walks the nodes
     for (int it = 0;; it += 2) {
         if (it > 0) {          // (the first pair of sweeps finds both flags zeroed by cl_init_kernel: two 4-byte fill launches less per clustering)
@@ -328,7 +361,7 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
         cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars + 4, w.scalars + 3, asc, 0);
         if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
         cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
-        cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold);
+        cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold, start_len, w.scalars);
         int rc = d3_exclusive_scan_i32(w.flag, w.cid, n, w.temp, w.temp_bytes, s);
         if (rc) return rc;
         rc = d3_exclusive_scan_i32(w.ksz, w.koff, n, w.temp, w.temp_bytes, s);
@@ -341,6 +374,8 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     }
     *nCluster_host = h[1];
     *sumNPoint_host = h[2];
+    // what the fill may assume about THIS workspace's lists (same thread: count and fill are one operator call)
+    g_cl_checked_ws = ws; g_cl_short_lists = h[5] == 0;
     return 0;
 }
 
@@ -696,7 +731,7 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                                                             const int *__restrict__ lid, const int *__restrict__ seeds,
                                                             const int *__restrict__ koff, const int *__restrict__ sizes,
                                                             const int *__restrict__ star, int *qst_all, int *qln_all,
-                                                            int *cluster_idxs, int *dbg) {
+                                                            int *cluster_idxs, int *dbg, int min_size) {
     extern __shared__ __attribute__((aligned(16))) int b2_smem[];
     int n_levels = 0, n_batches = 0;
 #ifdef B2_TIMING
@@ -712,6 +747,7 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     const int c = blockIdx.x, tid = threadIdx.x;
     const int s = seeds[c], base = koff[s], size = sizes[s];
     if (size > B2_MAXSIZE) return;                                  // left to cl_bfs_kernel
+    if (size <= min_size) return;                                   // written by cl_bfs3_kernel
     if (star[s]) return;                                            // written by cl_star_kernel
     int *qst = qst_all + base, *qln = qln_all + base;
     const int words = (size + 31) >> 5;
@@ -896,6 +932,241 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     B2_TDUMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// phase 3, third form (round 5): a 16-lane GROUP per frontier ENTRY, discovery keys in an LDS array over the dense ids.
+// Both level loops of this file are bound by VALU issue on ONE compute unit: cl_bfs2_kernel spends ~14,000 cycles per level of the
+// canonical floor (~300 nodes / ~2,700 edges per level, 192 levels; cycle counters, gpurun_out r04_j20) = ~800 instructions per
+// wave per level on the flat-edge -> owner search, the CAS / probe / atomicMin hash that elects the first discoverer, hint tables,
+// their clean-up and a (count, list length) block scan.  What a level needs per edge is much less:
+//   * a frontier ENTRY is (record start, <= 16 records): a node with a longer list is queued as consecutive entries of 16.
+//     Group g of pass p owns entry a = p * 32 + g, lane l its record l: one contiguous 256-byte read per group, no owner search,
+//     no list-offset prefix;
+//   * the election is ONE LDS atomic per edge: disc[dense id] = min(disc, key), key = batch number : entry : lane (19 + 9 + 4
+//     bits).  A word claimed by an earlier batch is smaller than every key of this one (= visited), 0xFFFFFFFF = never seen;
+//     after the barrier the edge whose key is still there is the FIFO discoverer (entries and lanes are in (parent position,
+//     list position) order) -- no bitmap, no hash, no clean-up;
+//   * inside a wave-pass that order IS the lane order, so a winner's rank is mbcnt(ballot) and the wave's total a scalar
+//     popcount; the (pass, wave) totals go through a 128-entry LDS table that every wave scans for itself and reads back with
+//     v_readlane.  Winners with more than 16 records (rare) add their extra entries through six more ballots (bit planes of the
+//     chunk count).  Three LDS-only barriers per batch; records / outputs through raw buffer instructions (32-bit offsets).
+// Earlier attempts of this round, both bit-exact and both SLOWER than cl_bfs2_kernel (944 us): one THREAD per frontier node
+// (1,460 us: 64 lanes x 16-byte loads from 64 different lines per instruction, lists beyond eight records walked with dependent
+// loads) and this layout with per-group masks / cross-lane reads and 64-bit addressing (1,500 us: ~100 instructions per
+// wave-pass, ~80 wave-passes per level).  A wave-pass here is ~35 instructions.
+// disc needs 4 B per node: clusters up to B3_MAXNODES; larger ones, inputs with a list beyond 2,047 entries (the reference's ball
+// query stops at 1,000: lib/pointgroup_ops/src/bfs_cluster/bfs_cluster.cu:45) and record arrays beyond 4 GiB keep
+// cl_bfs2_kernel.  Same outputs as the other forms, bit for bit.
+#ifndef B3_T
+#define B3_T 512
+#endif
+#define B3_G 16                                // lanes per frontier entry = records per entry
+#define B3_NG (B3_T / B3_G)                    // entries per pass
+#define B3_FMAX 512                            // frontier entries per batch (= kept in LDS)
+#define B3_P (B3_FMAX / B3_NG)                 // passes per batch
+#define B3_NW (B3_T / 64)
+#define B3_MAXNODES 37632                      // 147 KB of discovery words
+#define B3_QMAX 0x7FFFFu
+#define B3_LDS_INTS (B3_MAXNODES + 2 * 2 * B3_FMAX + 2 * B3_P * B3_NW + 64 + 64)
+#define B3_RSRC_FLAGS 0x00020000               // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+static_assert(B3_P * B3_NW == 128, "the (pass, wave) tables are scanned as two entries per lane");
+typedef unsigned int b3_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int b3_u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(B3_T) void cl_bfs3_kernel(const int4 *__restrict__ erec, unsigned int erec_bytes,
+                                                      const int *__restrict__ start_len, const int *__restrict__ estart,
+                                                      const int *__restrict__ lid, const int *__restrict__ seeds,
+                                                      const int *__restrict__ koff, const int *__restrict__ sizes,
+                                                      const int *__restrict__ star, int *qst_all, int *qln_all, int *cluster_idxs,
+                                                      int *dbg) {
+    extern __shared__ __attribute__((aligned(16))) int b3_smem[];
+    unsigned int *disc = (unsigned int *)b3_smem;                      // B3_MAXNODES
+    int2 *ftab = (int2 *)(b3_smem + B3_MAXNODES);                      // 2 x B3_FMAX: (first record, records <= 16) per frontier entry
+    int *wtabN = (int *)(ftab + 2 * B3_FMAX);                          // B3_P x B3_NW: winners (nodes) per (pass, wave)
+    int *wtabE = wtabN + B3_P * B3_NW;                                 // ... and their frontier entries
+    int *misc = wtabE + B3_P * B3_NW;                                  // [0..1]: cut of a read-back batch (nodes, entries); [8..]: block scan
+    // landing zone of the list prefetches: a winner's first record line is pulled towards this XCD's L2 by a load that writes to
+    // LDS (no register to keep alive across the level's barriers; the values are never read, every wave shares the 256 bytes)
+    __attribute__((address_space(3))) void *pfz = (__attribute__((address_space(3))) void *)(misc + 64);
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = tid / B3_G, l = tid % B3_G;
+    const int s = seeds[c], base = koff[s], size = sizes[s];
+    if (size > B3_MAXNODES) return;                                    // left to cl_bfs2_kernel
+    if (star[s]) return;                                               // written by cl_star_kernel
+    const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc((void *)erec, 0, erec_bytes, B3_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(cluster_idxs + (size_t)base * 2), 0, (unsigned int)size * 8u, B3_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rqs = __builtin_amdgcn_make_buffer_rsrc((void *)(qst_all + base), 0, (unsigned int)size * 4u, B3_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rql = __builtin_amdgcn_make_buffer_rsrc((void *)(qln_all + base), 0, (unsigned int)size * 4u, B3_RSRC_FLAGS);
+    int *qst = qst_all + base, *qln = qln_all + base;
+    for (int w = tid; w < size; w += B3_T) disc[w] = 0xFFFFFFFFu;
+    __syncthreads();
+    int ne = 0;                                                        // entries of the current frontier held in LDS
+    {
+        const int sl = start_len[s * 2 + 1], es = estart[s];
+        ne = (sl + B3_G - 1) / B3_G;
+        if (tid == 0) { disc[lid[s]] = 0u; cluster_idxs[(size_t)base * 2] = c; cluster_idxs[(size_t)base * 2 + 1] = s; qst[0] = es; qln[0] = sl; }
+        if (tid < ne && tid < B3_FMAX) ftab[tid] = make_int2(es + tid * B3_G, min(B3_G, sl - tid * B3_G));
+    }
+    __syncthreads();
+    int lo = 0, hi = 1, cur = 0, n_levels = 0, n_batches = 0;
+    unsigned int q = 1u;                                               // batch number (the key's high field)
+#ifdef B3_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_readcyclecounter();
+#define B3_TICK(k) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; }
+#define B3_TDUMP if (dbg && tid == 0 && c < 20) for (int k = 0; k < 8; k++) dbg[60 + c * 8 + k] = (int)(tacc[k] >> 4);
+#else
+#define B3_TICK(k)
+#define B3_TDUMP
+#endif
+    while (lo < hi && hi < size) {
+        const bool in_lds = ne <= B3_FMAX;                             // the frontier's entry table was written by the previous level
+        int tail = hi, etail = 0;                                      // nodes queued / entries of the next frontier so far
+        int2 *ntab = ftab + (cur ^ 1) * B3_FMAX;
+        int2 *ctab = ftab + cur * B3_FMAX;
+        for (int fb = lo; fb < hi;) {
+            int nb;                                                    // entries of this batch
+            if (in_lds) { nb = ne; fb = hi; }
+            else {
+                // frontier beyond the LDS window: node records (first record, list length) come back from the global queue and are
+                // cut into entries again -- as many whole nodes as fit B3_FMAX entries
+                __syncthreads();                                       // (queue records written by other waves: full barrier)
+                const int NB = min(B3_FMAX, hi - fb);
+                int st = 0, ln = 0;
+                if (tid < NB) { st = ld_dev(&qst[fb + tid]); ln = ld_dev(&qln[fb + tid]); }
+                const int nch = (ln + B3_G - 1) / B3_G;
+                if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+                int tot_;
+                const int eoff = cl_blk_scan(nch, misc + 8, tot_);     // (block scan: __syncthreads inside)
+                const bool fits = tid < NB && eoff + nch <= B3_FMAX;
+                if (fits) { atomicMax(&misc[0], tid + 1); atomicMax(&misc[1], eoff + nch); }
+                if (fits) for (int j = 0; j < nch; j++) ctab[eoff + j] = make_int2(st + j * B3_G, min(B3_G, ln - j * B3_G));
+                __syncthreads();
+                nb = misc[1]; fb += misc[0];
+                __syncthreads();                                       // (misc is rewritten by the next read-back batch)
+            }
+            const int npass = (nb + B3_NG - 1) / B3_NG;
+            b3_u32x4 rec[B3_P];
+            int rk[B3_P];                                              // winner: node rank | entry rank << 8 inside the wave-pass; else -1
+            const unsigned int kthread = (q << 13) | ((unsigned int)g << 4) | (unsigned int)l;
+            // ---- claim: every record bids for its target with (batch, entry, lane)
+#pragma unroll
+            for (int p = 0; p < B3_P; p++) {
+                rec[p] = (b3_u32x4){0xFFFFFFFFu, 0u, 0u, 0u};
+                if (p < npass) {
+                    const int a = p * B3_NG + g;
+                    if (a < nb) {
+                        const int2 me = ctab[a];
+                        if (l < me.y) rec[p] = __builtin_amdgcn_raw_buffer_load_b128(rrec, (unsigned int)(me.x + l) * 16u, 0, 0);
+                    }
+                }
+            }
+            B3_TICK(0)
+            __builtin_amdgcn_sched_barrier(0);                         // (all record loads issued before the first use)
+#ifdef B3_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            B3_TICK(1)
+#endif
+#pragma unroll
+            for (int p = 0; p < B3_P; p++)
+                if (p < npass && (int)rec[p].x >= 0) atomicMin(&disc[rec[p].y], kthread + (unsigned int)(p * B3_NG << 4));
+            B3_TICK(2)
+            b2_barrier();
+            B3_TICK(3)
+            // ---- check: the bid that is still there discovered the node first; lane order = FIFO order inside a wave-pass
+            int tvN = 0, tvE = 0;                                      // lane p: this wave's totals of pass p
+#pragma unroll
+            for (int p = 0; p < B3_P; p++) {
+                rk[p] = -1;
+                if (p < npass) {
+                    const bool w0 = (int)rec[p].x >= 0 && disc[rec[p].y] == kthread + (unsigned int)(p * B3_NG << 4);
+                    const unsigned long long bal = __ballot(w0);
+                    const int nrank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0u));
+                    int erank = nrank, ecount = (int)__popcll(bal);
+                    const int ncount = ecount;
+                    const unsigned long long balL = __ballot(w0 && rec[p].w > (unsigned int)B3_G);
+                    if (balL != 0ull) {                                // some winner brings more than one entry: bit planes of (entries - 1)
+                        const unsigned int x = w0 ? (rec[p].w + B3_G - 1) / B3_G - 1u : 0u;
+#pragma unroll
+                        for (int bit = 0; bit < 7; bit++) {
+                            const unsigned long long bb = __ballot((x >> bit) & 1u);
+                            erank += (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bb, 0u)) << bit;
+                            ecount += (int)__popcll(bb) << bit;
+                        }
+                    }
+                    if (w0) rk[p] = nrank | (erank << 8);
+                    if (lane == p) { tvN = ncount; tvE = ecount; }
+                }
+            }
+            if (lane < npass) { wtabN[lane * B3_NW + wv] = tvN; wtabE[lane * B3_NW + wv] = tvE; }
+            B3_TICK(4)
+            b2_barrier();
+            // ---- ranks: every wave scans the (pass, wave) totals for itself (128 entries, two per lane), nodes and entries
+            int totN, totE, exN0, exN1, exE0, exE1;
+            {
+                const int npw = npass * B3_NW;
+                const int2 vn = (2 * lane < npw) ? *(const int2 *)&wtabN[2 * lane] : make_int2(0, 0);      // (npw is even)
+                const int2 ve = (2 * lane < npw) ? *(const int2 *)&wtabE[2 * lane] : make_int2(0, 0);
+                int xn = vn.x + vn.y, xe = ve.x + ve.y;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int yn = __shfl_up(xn, o), ye = __shfl_up(xe, o);
+                    if (lane >= o) { xn += yn; xe += ye; }
+                }
+                totN = __builtin_amdgcn_readlane(xn, 63); totE = __builtin_amdgcn_readlane(xe, 63);
+                exN0 = xn - vn.x - vn.y; exN1 = exN0 + vn.x;
+                exE0 = xe - ve.x - ve.y; exE1 = exE0 + ve.x;
+            }
+            B3_TICK(5)
+            // ---- enqueue in (parent position, list position) order
+#pragma unroll
+            for (int p = 0; p < B3_P; p++) {
+                if (p < npass) {
+                    // base of (pass p, this wave): table entry p * NW + wv sits in lane (p * NW + wv) / 2 -- a wave-uniform lane
+                    const int ti = p * B3_NW + wv;
+                    const int bN = (ti & 1) ? __builtin_amdgcn_readlane(exN1, ti >> 1) : __builtin_amdgcn_readlane(exN0, ti >> 1);
+                    const int bE = (ti & 1) ? __builtin_amdgcn_readlane(exE1, ti >> 1) : __builtin_amdgcn_readlane(exE0, ti >> 1);
+                    if (rk[p] >= 0) {
+                        const int pos = tail + bN + (rk[p] & 0xFF);    // queue position of the node
+                        const int e0 = etail + bE + (rk[p] >> 8);      // its first entry in the next frontier
+                        __builtin_amdgcn_raw_buffer_store_b64((b3_u32x2){(unsigned int)c, rec[p].x}, rout, (unsigned int)pos * 8u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(rec[p].z, rqs, (unsigned int)pos * 4u, 0, 0);      // (plain stores: the only reader is this
+                        __builtin_amdgcn_raw_buffer_store_b32(rec[p].w, rql, (unsigned int)pos * 4u, 0, 0);      //  workgroup, through ld_dev)
+                        if (rec[p].w <= (unsigned int)B3_G) { if (e0 < B3_FMAX) ntab[e0] = make_int2((int)rec[p].z, (int)rec[p].w); }
+                        else {
+                            const int nch = ((int)rec[p].w + B3_G - 1) / B3_G;
+                            for (int j = 0; j < nch && e0 + j < B3_FMAX; j++) ntab[e0 + j] = make_int2((int)rec[p].z + j * B3_G, min(B3_G, (int)rec[p].w - j * B3_G));
+                        }
+#ifndef B3_NO_PREFETCH
+                        // the winner's own records start travelling now (8 per line)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, pfz, 4, rec[p].z * 16u, 0, 0, 0);
+                        if (rec[p].w > 8u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, pfz, 4, rec[p].z * 16u + 128u, 0, 0, 0);
+#endif
+                    }
+                }
+            }
+            tail += totN; etail += totE;
+            q++; n_batches++;
+            B3_TICK(6)
+            b2_barrier();
+            B3_TICK(7)
+            if (tail >= size) {   // every node of the component is queued: the remaining edges cannot discover anything
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no LDS-landing load may outlive the workgroup's LDS allocation)
+                if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels + 1; dbg[c * 3 + 2] = n_batches; }
+                B3_TDUMP
+                return;
+            }
+            if (q == B3_QMAX) {   // batch numbers wrap: every visited word becomes "batch 0"
+                for (int w = tid; w < size; w += B3_T) if (disc[w] != 0xFFFFFFFFu) disc[w] = 0u;
+                q = 1u;
+                b2_barrier();
+            }
+        }
+        lo = hi; hi = tail; ne = etail; cur ^= 1; n_levels++;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; }
+    B3_TDUMP
+}
+
 __global__ void cl_prof_total_kernel(const int *estart, const int *klen, int n, double *out) { *out = (double)estart[n - 1] + (double)klen[n - 1]; }
 
 extern "C" size_t d3_bfs_cluster_erec_bytes(long long nActive) { return (size_t)(nActive > 0 ? nActive : 1) * sizeof(int4); }
@@ -934,8 +1205,24 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
         // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S, nActive = the list entries of the kept
         // clusters' nodes (what the replay streams; the padded lists' capacity says nothing) -- known on the device only
         void *pr = d3_prof_begin(5, 12.0 * (double)n + 8.0 * (double)sumNPoint, 0.0, s);
-        cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
-                                                        w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr);
+        // round 5: clusters whose discovery words fit the LDS (<= B3_MAXNODES nodes) replay on the thread-per-frontier-node kernel;
+        // larger ones (and everything with D3_BFS3=0) on the edge-parallel hash form
+        const bool use3 = d3_tune(D3T_BFS3) != 0 && g_cl_checked_ws == ws && g_cl_short_lists &&
+                          (unsigned long long)(nActive > 0 ? nActive : 1) * sizeof(int4) < 0xFFFFFFFFull;      // (32-bit record offsets)
+        if (use3) {
+            static bool attr3_done_dev[64] = {false};
+            const size_t lds3 = (size_t)B3_LDS_INTS * sizeof(int);
+            if (dev_id < 0 || dev_id >= 64 || !attr3_done_dev[dev_id]) {
+                D3_CHECK(hipFuncSetAttribute((const void *)cl_bfs3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+                if (dev_id >= 0 && dev_id < 64) attr3_done_dev[dev_id] = true;
+            }
+            cl_bfs3_kernel<<<nCluster, B3_T, lds3, s>>>((const int4 *)erec, (unsigned int)((size_t)(nActive > 0 ? nActive : 1) * sizeof(int4)), start_len,
+                                                       w.estart, w.lid, w.seeds, w.koff, w.sizes, w.star, w.fcnt, w.qln, cluster_idxs,
+                                                       debug ? w.lcnt : nullptr);
+        }
+        if (!use3 || sumNPoint > B3_MAXNODES)
+            cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
+                                                            w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr, use3 ? B3_MAXNODES : 0);
         if (pr) {
             d3_prof_tag(pr, 0, n); d3_prof_tag(pr, 1, nCluster); d3_prof_end(pr, s);
             if (double *slot = d3_prof_dev_slot(pr, 4.0)) cl_prof_total_kernel<<<1, 1, 0, s>>>(w.estart, w.klen, n, slot);   // (behind the bracket)
@@ -945,8 +1232,8 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);
             for (int c = 0; c < nCluster && c < 20; c++) {
                 fprintf(stderr, "bfs2 cluster %d size %d levels %d batches %d", c, h[c * 3], h[c * 3 + 1], h[c * 3 + 2]);
-#ifdef B2_TIMING
-                for (int k = 0; k < 7; k++) fprintf(stderr, " t%d=%d", k, h[60 + c * 8 + k] * 16);
+#if defined(B2_TIMING) || defined(B3_TIMING)
+                for (int k = 0; k < 8; k++) fprintf(stderr, " t%d=%d", k, h[60 + c * 8 + k] * 16);
 #endif
                 fprintf(stderr, "\n");
             }

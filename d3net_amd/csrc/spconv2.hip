@@ -116,6 +116,13 @@ extern "C" int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout
     return 0;
 }
 
+// Second-level BatchNorm partials (round 5).  Every BatchNorm launch used to reduce its producer's whole partial table (one row per
+// convolution workgroup: ~1000 rows at the big levels) IN EVERY ONE of its <= 512 workgroups before it could touch a row: 8 - 19 us
+// of dependent L2 round trips per launch, ~155 launches per step -- more than the normalisation passes themselves.  The producer
+// now also adds its row into a 16-row fp64 table (hardware fp64 atomics, row = workgroup % 16: <= 64 adds per address); the
+// consumer's reduction is ONE round trip over 16 rows.  Every addend is an fp32 value, so the fp64 sums are exact -- independent of
+// the order the atomics land in -- unless the addends of one channel span more than 2^29 in magnitude (then: 2^-53 relative).
+#define C2_P2_ROWS 16
 // ------------------------------------------------------------------------------ forward / data gradient
 struct Conv2Args {
     const void *x;              // (Min, ldx) fp32 or bf16
@@ -124,6 +131,8 @@ struct Conv2Args {
     float *out;                 // (Mout, ldo)
     const float *res;           // optional residual (Mout, ldr), added before the store
     float *part;                // optional BatchNorm partials: [nparts][2][NT*16] (sum, sum of squares per column)
+    double *part2;              // optional (round 5): second-level table [C2_P2_ROWS][2][NT*16] of fp64 accumulators; workgroup b adds its
+                                // partial row to row b % C2_P2_ROWS (zeroed by the caller), so a consumer reads 16 rows instead of ~1000
     int ldx, ldo, ldr;
     int Mout, K, Cout, S;       // S = Cin / 8 slots per offset
     unsigned int inv;           // ceil(65536 / S): i = (s * inv) >> 16 == s / S for s < 4096
@@ -583,6 +592,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
             for (int w = 0; w < NW; w++) s += redS[w * 2 * NT * 16 + t];
             if (a.fin_counter) c2_part_store(&a.part[(long long)b * 2 * NT * 16 + t], s);
             else a.part[(long long)b * 2 * NT * 16 + t] = s;
+            if (a.part2) unsafeAtomicAdd(&a.part2[(b % C2_P2_ROWS) * 2 * NT * 16 + t], (double)s);
         }
         if (a.fin_counter)   // (flag word: the spare LDS behind the statistics rows; no static LDS in front of the dynamic region)
             c2_last_block_finalize(a, (int)gridDim.x, (int)gridDim.x, (int *)(redS + NW * 2 * NT * 16));
@@ -761,6 +771,7 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             if (n0 * 16 + cl < a.NT * 16) {
                 float *pp = &a.part[(long long)blockIdx.x * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl];
                 if (a.fin_counter) c2_part_store(pp, s); else *pp = s;
+                if (a.part2) unsafeAtomicAdd(&a.part2[(long long)(blockIdx.x % C2_P2_ROWS) * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl], (double)s);
             }
         }
         if (a.fin_counter) c2_last_block_finalize(a, (int)(gridDim.x * gridDim.y), (int)gridDim.x, (int *)(kmaskS + 1));
@@ -955,6 +966,10 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
 static thread_local const void *g_next_tbl16 = nullptr;
 static thread_local const int *g_next_ok16 = nullptr;
 void d3_spconv_next_tbl16(const void *tbl16, const int *ok16) { g_next_tbl16 = tbl16; g_next_ok16 = ok16; }
+// second-level partial table of the NEXT forward / data-gradient call of this thread (same hand-over as the 16-bit map hint):
+// [C2_P2_ROWS][2][ceil(Cout / 16) * 16] doubles, zeroed by the caller; ignored when the call takes no partials
+static thread_local double *g_next_part2 = nullptr;
+void d3_spconv_next_part2(double *part2) { g_next_part2 = part2; }
 
 struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; };
 struct Conv2Fin { int *counter; int mode, M, accum; float *a, *b, *c, *d; float momentum; };
@@ -965,6 +980,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     D3_CLEAR();
     const void *tbl16 = g_next_tbl16; const int *ok16 = g_next_ok16;      // the hint belongs to THIS call, whatever it does with it
     g_next_tbl16 = nullptr; g_next_ok16 = nullptr;
+    double *part2 = g_next_part2;
+    g_next_part2 = nullptr;
     if (Mout <= 0) return 0;
     if (K < 1 || K > C2_MAXK || Cin < 8 || (Cin & 7) || Cout < 1 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -976,6 +993,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     hipStream_t s = d3_stream(stream);
     Conv2Args a;
     a.x = x; a.tbl = tbl; a.Wp = (const unsigned short *)Wp; a.out = out; a.res = res; a.part = part;
+    a.part2 = part ? part2 : nullptr;
     a.ldx = ldx; a.ldo = ldo; a.ldr = ldr; a.Mout = Mout; a.K = K; a.Cout = Cout; a.S = Cin / 8;
     a.inv = (65536u + a.S - 1) / a.S;
     a.invK = (65536u + K - 1) / K;

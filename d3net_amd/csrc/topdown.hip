@@ -375,8 +375,15 @@ __global__ __launch_bounds__(TD_PREP_T) void td_attn_prep_kernel(const float *__
     }
 }
 
+#ifndef TD_ATT_T
+#define TD_ATT_T 1024          // threads of the per-sample attention workgroups (256: rounds 2-4)
+#endif
+static inline size_t td_attn_bwd_rsum_floats(int H) { const int CT = H < TD_ATT_T ? H : TD_ATT_T, RS = TD_ATT_T / CT; return RS > 1 ? (size_t)RS * 2 * H : 0; }
 // one workgroup per sample; attn_out: (N, K, S) slice t of `topdown_attn` (NULL: not wanted)
-__global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
+// NTH threads (round 5: 1024 -- the N <= 32 workgroups of a step are all the kernel has, and a sample's na x H tanh evaluations on
+// four waves were 9.6 us of a 31-step dependent chain; sixteen waves split the proposals: same expressions, same summation order)
+template <int NTH>
+__global__ __launch_bounds__(NTH) void td_attn_fwd_kernel(const float *__restrict__ fp, const float *__restrict__ q, long long ldq,
                                                           const float *__restrict__ watt, const float *__restrict__ obj,
                                                           const int *__restrict__ act, const int *__restrict__ nact,
                                                           const float *__restrict__ msum, float *__restrict__ a_out,
@@ -389,9 +396,9 @@ __global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restric
     const long long ns = n / obj_div;      // obj / fp row block of this sample (evaluation: the K targets of a scene share it)
     const int na = nact[n], nm = K - na;
     const int *al = act + (long long)n * K;
-    for (int c = t; c < H; c += 256) { qs[c] = q[(long long)n * ldq + c]; ws[c] = watt[c]; }
+    for (int c = t; c < H; c += NTH) { qs[c] = q[(long long)n * ldq + c]; ws[c] = watt[c]; }
     __syncthreads();
-    for (int j = wave; j < na; j += 4) {
+    for (int j = wave; j < na; j += NTH / 64) {
         const float *row = fp + (ns * K + al[j]) * H;
         float s = 0.f;
         for (int c = lane * 4; c < H; c += 256) {
@@ -418,11 +425,11 @@ __global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restric
     }
     __syncthreads();
     const float am = am_s;
-    for (int k = t; k < K; k += 256) ak[k] = am;
+    for (int k = t; k < K; k += NTH) ak[k] = am;
     __syncthreads();
-    for (int j = t; j < na; j += 256) ak[al[j]] = sc[j];
+    for (int j = t; j < na; j += NTH) ak[al[j]] = sc[j];
     __syncthreads();
-    for (int k = t; k < K; k += 256) {
+    for (int k = t; k < K; k += NTH) {
         a_out[(long long)n * K + k] = ak[k];
         if (attn_out) attn_out[((long long)n * K + k) * S + t_step] = ak[k];
     }
@@ -440,7 +447,10 @@ __global__ __launch_bounds__(256) void td_attn_fwd_kernel(const float *__restric
 
 // backward of one step: datt (N,F) -> dq (N,H), dfp rows of the active proposals +=, dwpart row (H); datt is also copied to
 // dattS (N,F) for the accumulation of dobj after the time loop
-__global__ __launch_bounds__(256) void td_attn_bwd_kernel(const float *__restrict__ datt, long long lddatt, const float *__restrict__ a_in,
+// NTH threads: CT = min(H, NTH) column threads x RS = NTH / CT row slices (slice r takes the row quads r, r + RS, ...; the slices'
+// dq / dw sums are added in slice order through LDS: deterministic; NTH = 256 is the rounds-2-4 kernel)
+template <int NTH>
+__global__ __launch_bounds__(NTH) void td_attn_bwd_kernel(const float *__restrict__ datt, long long lddatt, const float *__restrict__ a_in,
                                                           const float *__restrict__ att, long long ldatt, const float *__restrict__ fp,
                                                           const float *__restrict__ q, long long ldq, const float *__restrict__ watt,
                                                           const float *__restrict__ obj, const int *__restrict__ act,
@@ -448,21 +458,21 @@ __global__ __launch_bounds__(256) void td_attn_bwd_kernel(const float *__restric
                                                           float *__restrict__ dfp, float *__restrict__ dwpart, float *__restrict__ dattS,
                                                           int K, int H, int F) {
     extern __shared__ float sm[];
-    float *dat = sm, *dss = dat + F, *red = dss + K;   // red: 4
+    float *dat = sm, *dss = dat + F, *red = dss + K, *rsum = red + 4;   // red: 4; rsum: (RS - 1) * 2 * H (row-slice partials)
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int na = nact[n];
     const int *al = act + (long long)n * K;
     float pd = 0.f;
-    for (int c = t; c < F; c += 256) {
+    for (int c = t; c < F; c += NTH) {
         const float v = datt[(long long)n * lddatt + c];
         dat[c] = v; dattS[(long long)n * F + c] = v;
         pd += v * att[(long long)n * ldatt + c];
     }
     for (int o = 32; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
-    if (lane == 0) red[wave] = pd;
+    if (lane == 0 && wave < 4) red[wave] = pd;      // (F <= 256: the waves beyond hold no element)
     __syncthreads();
     const float dot = (red[0] + red[1]) + (red[2] + red[3]);      // sum_k a[k] da[k] = datt . attended
-    for (int j = wave; j < na; j += 4) {
+    for (int j = wave; j < na; j += NTH / 64) {
         const int k = al[j];
         float s = 0.f;
         for (int c = lane; c < F; c += 64) s += dat[c] * obj[((long long)n * K + k) * F + c];
@@ -470,10 +480,11 @@ __global__ __launch_bounds__(256) void td_attn_bwd_kernel(const float *__restric
         if (lane == 0) dss[j] = a_in[(long long)n * K + k] * (s - dot);
     }
     __syncthreads();
-    for (int c = t; c < H; c += 256) {
+    const int CT = H < NTH ? H : NTH, RS = NTH / CT, rs = t / CT;
+    for (int c = t - rs * CT; c < H && rs < RS; c += CT) {
         const float qc = q[(long long)n * ldq + c], wc = watt[c];
         float dqa = 0.f, dwa = 0.f;
-        for (int j0 = 0; j0 < na; j0 += 4) {          // four rows' loads in flight
+        for (int j0 = rs * 4; j0 < na; j0 += 4 * RS) {          // four rows' loads in flight
             float fv[4], dv[4];
             long long o[4];
 #pragma unroll
@@ -493,8 +504,18 @@ __global__ __launch_bounds__(256) void td_attn_bwd_kernel(const float *__restric
                 }
             }
         }
-        dq[(long long)n * lddq + c] = dqa;
-        dwpart[(long long)n * H + c] = dwa;
+        if (rs == 0 && RS == 1) { dq[(long long)n * lddq + c] = dqa; dwpart[(long long)n * H + c] = dwa; }
+        else if (rs > 0) { rsum[((rs - 1) * 2) * H + c] = dqa; rsum[((rs - 1) * 2 + 1) * H + c] = dwa; }
+        else { rsum[(RS - 1) * 2 * H + c] = dqa; rsum[(RS - 1) * 2 * H + H + c] = dwa; }      // (slice 0 parks its sums behind the others')
+    }
+    if (RS > 1) {
+        __syncthreads();
+        for (int c = t; c < H; c += NTH) {
+            float dqa = rsum[(RS - 1) * 2 * H + c], dwa = rsum[(RS - 1) * 2 * H + H + c];
+            for (int r = 1; r < RS; r++) { dqa += rsum[((r - 1) * 2) * H + c]; dwa += rsum[((r - 1) * 2 + 1) * H + c]; }
+            dq[(long long)n * lddq + c] = dqa;
+            dwpart[(long long)n * H + c] = dwa;
+        }
     }
 }
 
@@ -670,7 +691,7 @@ extern "C" int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream) {
             p.nseg = 1; p.seg[0] = td_seg(h1n, H, a->W_hidd, H, H);
             if ((rc = hg_launch(&p, 1, s))) return rc;
         }
-        td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, act, nact, msum, av + rN * K,
+        td_attn_fwd_kernel<TD_ATT_T><<<N, TD_ATT_T, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q + rN * H, H, a->w_att, a->obj, act, nact, msum, av + rN * K,
                                                                              att + rN * F, F, a->attn, t, S, K, H, F, 1);
         {
             GruArgs g{att + rN * F, F, F, h2p, H, Wa, a->Whh2, bc2, a->bhh2, h2n, H,
@@ -804,7 +825,7 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
             p[2].nseg = 1; p[2].seg[0] = td_seg(dgi2 + rN * 3 * H, 3 * H, a->Wih2, E, 3 * H, nullptr, 0, 1);
             if ((rc = hg_launch(p, 3, s))) return rc;
         }
-        td_attn_bwd_kernel<<<N, 256, (size_t)(F + K + 4) * 4, s>>>(tmpL, F + H, av + rN * K, att + rN * F, F, fp, q + rN * H, H, a->w_att,
+        td_attn_bwd_kernel<TD_ATT_T><<<N, TD_ATT_T, (size_t)(F + K + 4 + td_attn_bwd_rsum_floats(H)) * 4, s>>>(tmpL, F + H, av + rN * K, att + rN * F, F, fp, q + rN * H, H, a->w_att,
                                                                  a->obj, act, nact, dq + rN * H, H, dfp, dwp + rN * H, dattS + rN * F, K, H, F);
         {   // dh1 (through map_hidd) = dq W_hidd
             d3_gemm_prob p = td_prob(N, H, dh1q, H);
@@ -940,7 +961,7 @@ extern "C" int d3_topdown_step(const d3_topdown_args *a, const long long *word, 
         p.nseg = 1; p.seg[0] = td_seg(h1_out, H, a->W_hidd, H, H);
         if ((rc = hg_launch(&p, 1, s))) return rc;
     }
-    td_attn_fwd_kernel<<<N, 256, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q, H, a->w_att, a->obj, act, nact, msum, attn, att, F, nullptr, 0, 1, K, H,
+    td_attn_fwd_kernel<TD_ATT_T><<<N, TD_ATT_T, (size_t)(2 * H + 2 * K + 2 * F) * 4, s>>>(fp, q, H, a->w_att, a->obj, act, nact, msum, attn, att, F, nullptr, 0, 1, K, H,
                                                                          F, obj_div);
     {
         d3_gemm_prob p = td_prob(N, E, x2, E);

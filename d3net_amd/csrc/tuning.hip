@@ -45,6 +45,9 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_BN_FUSED_BIG", 1},         // 0: only BatchNorms of at most D3_BN_FUSED_ROWS rows run as one launch; the big levels keep finalize + apply
     {"D3_HG_CLASS_SPLIT", 1},       // 0: a batched heads GEMM launch always runs the kernel its largest problem asks for (rounds 1-3)
     {"D3_HG_SPLITK", 256},          // largest number of 16 x 16 output tiles of a deep (K >= 8192) heads GEMM whose reduction is cut over 4 workgroups; 0: never
+    {"D3_BFS3", 0},                 // 1: BFS replay of clusters <= 37,632 nodes on the lane-group-per-frontier-entry form (cl_bfs3_kernel, round 5: bit-exact, measured SLOWER than the edge-parallel hash form cl_bfs2_kernel -- 1,270 vs 925 us on the canonical scene -- so off)
+    {"D3_BN_PART2", 1},             // 0: BatchNorm launches reduce the producer's whole per-workgroup partial table (rounds 1-4) instead of the 16-row fp64 second-level table
+    {"D3_CL_HOOK", 1},              // 0: the clustering's union-find starts from singletons (rounds 1-4) instead of one hook per node under a smaller-index neighbour
     {"D3_ACT_GRAD_BF16", 0},        // 1: gradients of BatchNorm->ReLU activations (one convolution reader) stored as bf16 (unet.hip Net::gabf): measured neutral, off
 };
 std::atomic<int> g_val[D3T_COUNT];

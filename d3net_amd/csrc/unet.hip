@@ -95,7 +95,8 @@ __global__ void un_padcast_kernel(const float *__restrict__ x, unsigned short *_
 
 #define UN_T 256
 // per-channel sum / sum of squares of x (M, ld) -> partials [block][2][C] (fp32; summed in fp64 by the finalize)
-__global__ __launch_bounds__(UN_T) void un_stats_parts_kernel(const float *__restrict__ x, int ld, int M, int C, float *part) {
+#define UN_P2_ROWS 16      // rows of a second-level fp64 partial table (== C2_P2_ROWS of spconv2.hip: the producers add row = workgroup % 16)
+__global__ __launch_bounds__(UN_T) void un_stats_parts_kernel(const float *__restrict__ x, int ld, int M, int C, float *part, double *part2) {
     __shared__ float s1[UN_T], s2[UN_T];
     const int t = threadIdx.x;
     const int active = (UN_T / C) * C, rpp = active / C;
@@ -114,10 +115,15 @@ __global__ __launch_bounds__(UN_T) void un_stats_parts_kernel(const float *__res
         for (int k = t; k < active; k += C) { da += s1[k]; db += s2[k]; }
         part[(size_t)blockIdx.x * 2 * C + t] = da;
         part[(size_t)blockIdx.x * 2 * C + C + t] = db;
+        if (part2) {
+            unsafeAtomicAdd(&part2[(size_t)(blockIdx.x % UN_P2_ROWS) * 2 * C + t], (double)da);
+            unsafeAtomicAdd(&part2[(size_t)(blockIdx.x % UN_P2_ROWS) * 2 * C + C + t], (double)db);
+        }
     }
 }
 
-struct StatSrc { const float *part; int nparts, width, c0, cn; };
+// p2 (optional): the producer's second-level table [UN_P2_ROWS][2][width] of fp64 sums (spconv2.hip C2_P2_ROWS)
+struct StatSrc { const float *part; int nparts, width, c0, cn; const double *p2; };
 
 // mean / biased variance of C channels from up to two partial sets (a concatenated input has two producers), and
 // the running-statistics update of nn.BatchNorm1d in training mode.  One wave per channel, fp64, fixed order.
@@ -380,6 +386,27 @@ __device__ __forceinline__ void un_fs_reduce(const StatSrc &s0, const StatSrc &s
     sa = 0.; sb = 0.;
     if (t < C) for (int k = 0; k < S; k++) { sa += acc[((size_t)k * C + t) * 2]; sb += acc[((size_t)k * C + t) * 2 + 1]; }
 }
+// The same sums from the producers' second-level tables (round 5): UN_P2_ROWS rows per source, ONE round trip -- thread `col` of
+// the 2 C columns (sum | sum of squares) requests its 16 values together and adds them in row order.  acc: >= 2 C doubles.
+__device__ __forceinline__ void un_fs_reduce2(const StatSrc &s0, const StatSrc &s1, int C, double *acc, double &sa, double &sb) {
+    const int t = threadIdx.x;
+    for (int col = t; col < 2 * C; col += UN_FS_T) {
+        const int st = col >= C ? 1 : 0, c = col - st * C;
+        const bool first = (c >= s0.c0 && c < s0.c0 + s0.cn);
+        const StatSrc &src = first ? s0 : s1;
+        const double *p = src.p2 + (size_t)st * src.width + (c - src.c0);
+        double v[UN_P2_ROWS];
+#pragma unroll
+        for (int r = 0; r < UN_P2_ROWS; r++) v[r] = p[(size_t)r * 2 * src.width];
+        double a = 0.;
+#pragma unroll
+        for (int r = 0; r < UN_P2_ROWS; r++) a += v[r];
+        acc[col] = a;
+    }
+    __syncthreads();
+    sa = 0.; sb = 0.;
+    if (t < C) { sa = acc[t]; sb = acc[C + t]; }
+}
 template <bool BF16>
 __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, StatSrc s1, const float *__restrict__ x, int ldx,
                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -402,7 +429,8 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
         if (worker && row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
     }
     double sa, sb;
-    un_fs_reduce(s0, s1, C, acc, sa, sb);
+    if (s0.p2) un_fs_reduce2(s0, s1, C, acc, sa, sb);
+    else un_fs_reduce(s0, s1, C, acc, sa, sb);
     if (t < C) {
         const double m = sa / (double)M;
         double vv = sb / (double)M - m * m;
@@ -454,7 +482,8 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
                                                                           const float *__restrict__ var, const float *__restrict__ gamma,
                                                                           const float *__restrict__ beta, float *sums, float *dgamma, float *dbeta,
                                                                           int paccum, float *__restrict__ dx, int ldo, int M, int C, float eps,
-                                                                          int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block) {
+                                                                          int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block,
+                                                                          const double *__restrict__ part2) {
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float2 sm[UN_FS_MAXC];
     const int t = threadIdx.x;
@@ -484,8 +513,9 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
         for (int j = 0; j < 4; j++) { pinv[j] = rsqrtf(var[c + j] + eps); pga[j] = gamma[c + j]; pmu[j] = mean[c + j]; pbe[j] = beta[c + j]; }
     }
     double sa, sb;
-    const StatSrc s0{part, nparts, C, 0, C};
-    un_fs_reduce(s0, s0, C, acc, sa, sb);
+    const StatSrc s0{part, nparts, (C + 15) / 16 * 16, 0, C, part2};      // (the data gradient's partial rows are ceil(C / 16) * 16 wide)
+    if (part2) un_fs_reduce2(s0, s0, C, acc, sa, sb);
+    else un_fs_reduce(s0, s0, C, acc, sa, sb);
     if (t < C) {
         sm[t] = make_float2((float)sa, (float)sb);
         if (blockIdx.x == 0) {
@@ -598,6 +628,7 @@ struct OpD {
     int bn_of_in;                     // CONV: index of the BNACT op that produced `in` (-1: none) -> fused BN-backward dgrad
     int fused_by;                     // BNACT: index of the CONV whose dgrad epilogue already did this op's reductions
     size_t bpart_off; int bparts;     // BNACT: gradient-arena offset / count of those partials
+    size_t part2_off, bpart2_off;     // second-level fp64 tables (UN_P2_ROWS rows; inside the per-call zeroed regions): producer ops / BNACT backward
     int wg_hazard;                    // CONV: its output gradient buffer is accumulated into in place later in the backward
     int fin_bn;                       // CONV: BNACT whose batch statistics this conv's last workgroup finalizes (-1: none)
     int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
@@ -692,7 +723,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.part2_off = 0; o.bpart2_off = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -1039,10 +1070,20 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     for (auto &o : n->ops) if (o.type == OP_CONV) { o.wpart_off = goff; goff += o.wpart_bytes; }
     n->cnt_off0 = off;
     for (auto &o : n->ops) if (o.type == OP_CONV) { o.cnt_off = off; off += 4; }
-    off = d3_align(off); n->cnt_bytes = off - n->cnt_off0;
+    off = d3_align(off);
+    // second-level partial tables (round 5) live in the same zeroed-once-per-call region as the ticket counters: no extra fill launch
+    for (auto &o : n->ops)
+        if ((o.type == OP_CONV || o.type == OP_STATS) && o.nparts > 0) { o.part2_off = off; off += d3_align((size_t)UN_P2_ROWS * 2 * o.partw * 8); }
+    n->cnt_bytes = off - n->cnt_off0;
     n->bcnt_off0 = goff;
     for (auto &o : n->ops) if (o.type == OP_BNACT) { o.bcnt_off = goff; goff += 4; }
-    goff = d3_align(goff); n->bcnt_bytes = goff - n->bcnt_off0;
+    goff = d3_align(goff);
+    for (auto &o : n->ops) {
+        if (o.type != OP_BNACT || o.fused_by < 0) continue;
+        const OpD &cv = n->ops[o.fused_by];
+        o.bpart2_off = goff; goff += d3_align((size_t)UN_P2_ROWS * 2 * ((cv.CinW + 15) / 16 * 16) * 8);
+    }
+    n->bcnt_bytes = goff - n->bcnt_off0;
     n->arena_bytes = off;
     n->bnscr_off = goff; goff += d3_align(bnscr); n->bnscr_bytes = bnscr;
     n->wgws_off = goff; goff += d3_align(wgws); n->wgws_bytes = wgws;
@@ -1082,6 +1123,7 @@ void d3_spconv_next_tbl16(const void *tbl16, const int *ok16);
 static void net_drop_k3_16(Net *n) {
     if (n) { n->k3_16.assign(n->k3_16.size(), nullptr); n->ok16.assign(n->ok16.size(), nullptr); }
     d3_spconv_next_tbl16(nullptr, nullptr);
+    d3_spconv_next_part2(nullptr);
 }
 static int net_forward_impl(void *h, const void *const *params, const int *const *k3, const int *const *child,
                             const int *const *up, const void *input, void *arena_, int training, void *stream);
@@ -1101,6 +1143,7 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
     char *arena = (char *)arena_;
     Maps maps{k3, child, up};
     if (training && n->cnt_bytes) D3_CHECK(hipMemsetAsync(arena + n->cnt_off0, 0, n->cnt_bytes, s));
+    const bool use_p2 = training && d3_tune(D3T_BN_PART2) != 0;      // second-level fp64 partial tables (zeroed with the counters above)
     // ---- all weights -> bf16 fragment order, one launch
     {
         std::vector<PackJob> jobs;
@@ -1158,7 +1201,8 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
             if (!training) continue;
             const TensorD &t = n->T[o.in];
             const int M = n->rows[t.level];
-            if (M > 0) un_stats_parts_kernel<<<o.nparts, UN_T, 0, s>>>((const float *)tptr(n, arena, input, o.in), t.ld, M, t.C, (float *)(arena + o.part_off));
+            if (M > 0) un_stats_parts_kernel<<<o.nparts, UN_T, 0, s>>>((const float *)tptr(n, arena, input, o.in), t.ld, M, t.C, (float *)(arena + o.part_off),
+                                                                       use_p2 ? (double *)(arena + o.part2_off) : nullptr);
         } else if (o.type == OP_CONV) {
             const TensorD &ti = n->T[o.in], &to = n->T[o.out];
             int Min, Mout; conv_dims(n, o, Min, Mout);
@@ -1168,6 +1212,7 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
             float *part = (o.stats && training) ? (float *)(arena + o.part_off) : nullptr;
             if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
                 d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
+            if (part && use_p2) d3_spconv_next_part2((double *)(arena + o.part2_off));
             int rc;
             if (part && o.fin_bn >= 0 && Mout <= n->lb_rows) {
                 const OpD &b = n->ops[o.fin_bn];
@@ -1193,10 +1238,11 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                 for (size_t q = 0; q < 2; q++) {
                     const SrcRef &r = o.srcs[q < o.srcs.size() ? q : 0];
                     const OpD &p = n->ops[r.op];
-                    ss[q] = StatSrc{(const float *)(arena + p.part_off), p.nparts, p.partw, r.c0, r.cn};
+                    ss[q] = StatSrc{(const float *)(arena + p.part_off), p.nparts, p.partw, r.c0, r.cn, use_p2 ? (const double *)(arena + p.part2_off) : nullptr};
                 }
                 const int fs_rows = d3_tune(D3T_BN_FUSED_ROWS);
-                const long long part_floats = 2ll * ss[0].nparts * ss[0].cn + (o.srcs.size() > 1 ? 2ll * ss[1].nparts * ss[1].cn : 0ll);
+                // (with the second-level tables the reduction is 16 rows whatever the producer's grid was: no size limit)
+                const long long part_floats = use_p2 ? 0ll : 2ll * ss[0].nparts * ss[0].cn + (o.srcs.size() > 1 ? 2ll * ss[1].nparts * ss[1].cn : 0ll);
                 const int fs_big = d3_tune(D3T_BN_FUSED_BIG);
                 if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
                     // statistics + normalisation in one launch (un_bn_fused_small_kernel); big levels: up to 512 workgroups
@@ -1296,6 +1342,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
         if (it != pending.end()) { hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
     };
     if (n->bcnt_bytes) D3_CHECK(hipMemsetAsync(garena + n->bcnt_off0, 0, n->bcnt_bytes, s));
+    const bool use_p2 = d3_tune(D3T_BN_PART2) != 0;
     float *bnscr = (float *)(garena + n->bnscr_off);
     std::vector<RedJob> red;
     long long red_blocks = 0;
@@ -1373,6 +1420,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                     const OpD &b = n->ops[o.bn_of_in];
                     const TensorD &tx = n->T[b.in];
                     float *mean = (float *)(arena + b.state_off), *var = mean + tx.C;
+                    if (use_p2) d3_spconv_next_part2((double *)(garena + b.bpart2_off));
                     if (Min > n->lb_rows)
                         rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
@@ -1443,7 +1491,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             int relu = o.relu;
             const int fs_rows_b = d3_tune(D3T_BN_FUSED_ROWS);
             if (o.fused_by >= 0 && M > n->lb_rows && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
-                2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS) {
+                (use_p2 || 2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS)) {
                 // the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
                 int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows_b ? 32 : (d3_tune(D3T_BN_FUSED_BIG) > 1 ? d3_tune(D3T_BN_FUSED_BIG) : 512));
                 float *gi = nullptr; int ldgi = 0, root_i = -1, gibf = 0;
@@ -1456,7 +1504,8 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
 #define UN_FSB(OBFV, GBFV, RELU_, ACC_, SH_)                                                                                          \
                 un_bn_bwd_fused_small_kernel<OBFV, GBFV><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, \
                                                                               var, gamma, beta, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, \
-                                                                              ldgi, M, C, o.eps, RELU_, ACC_, SH_, rows_pb)
+                                                                              ldgi, M, C, o.eps, RELU_, ACC_, SH_, rows_pb, \
+                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr)
                 if (gibf) { if (gobf) UN_FSB(true, true, 0, 0, nullptr); else UN_FSB(true, false, 0, 0, nullptr); }
                 else if (gobf) UN_FSB(false, true, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
                 else UN_FSB(false, false, 0, o.in_grad_mode == 2 ? 1 : 0, sh);

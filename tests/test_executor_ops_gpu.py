@@ -310,3 +310,26 @@ def test_bf16_activation_gradients_stay_at_the_bf16_noise_floor(dev):
     assert res[1][0] == res[0][0], (res[1][0], res[0][0])
     assert l2err(res[1][2], res[0][2]) < 2e-2
     assert l2err(res[1][1], res[0][1]) < 5e-2
+
+
+def test_second_level_batchnorm_partials_match_the_full_table_reduction(dev):
+    """Round 5 (csrc/spconv2.hip C2_P2_ROWS, csrc/unet.hip un_fs_reduce2, D3_BN_PART2): every producer workgroup also adds its
+    BatchNorm partial row into a 16-row fp64 table (hardware fp64 atomics, row = workgroup % 16) and the BatchNorm launches
+    reduce those 16 rows instead of the producer's whole per-workgroup table.  Both paths add the SAME fp32 partial values in fp64;
+    such sums are exact (hence order-independent) unless one channel's addends span more than 2^29 in magnitude, so the two
+    paths agree to the last bit almost everywhere and a bf16 step stays far inside its noise floor: loss 1e-6, logits 1e-4,
+    parameter gradients 1e-3 relative L2 -- and two runs of the atomics path reproduce each other (loss identical, gradients 1e-6)."""
+    from d3net_amd import _lib, synthetic as S
+    L = _lib.lib()
+    scene = S.small_scene(dims=(64, 48, 32), n_boxes=4, seed=7)
+    res = {}
+    try:
+        for key, on in (("on", 1), ("off", 0), ("again", 1)):
+            assert L.d3_tuning_set(b"D3_BN_PART2", on) == 0
+            res[key] = _detector_step(dev, scene)
+    finally:
+        L.d3_tuning_set(b"D3_BN_PART2", 1)
+    assert abs(res["on"][0] - res["off"][0]) <= 1e-6 * abs(res["off"][0]), (res["on"][0], res["off"][0])
+    assert l2err(res["on"][2], res["off"][2]) < 1e-4
+    assert l2err(res["on"][1], res["off"][1]) < 1e-3
+    assert res["on"][0] == res["again"][0] and l2err(res["on"][1], res["again"][1]) < 1e-6

@@ -365,6 +365,45 @@ def test_bfs_cluster_capped_chain(dev, order):
         assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), asc
 
 
+def test_bfs_replay_forms_agree_with_the_oracle(dev):
+    """Round 5: cl_bfs3_kernel (thread per frontier node, key election in LDS words; D3_BFS3=1, the default) and the edge-parallel hash
+    form (cl_bfs2_kernel, D3_BFS3=0) against the sequential oracle on inputs that reach every path of the new kernel: a 190 x 190
+    sheet in shuffled order (36,100 nodes: fits the discovery words; square wavefronts of > 512 nodes -> frontiers read back from the
+    global queue in several batches), a 200 x 200 sheet (40,000 nodes: beyond the words -> stays on cl_bfs2_kernel inside the same
+    call), a loose 3-d blob (lists of 100 - 400 entries: the beyond-registers part of a list) and a dense blob with capped lists
+    (512 x 1000 entries per chunk -> the 64-nodes-at-a-time sub-batches)."""
+    from d3net_amd import pointgroup_ops as P
+    from d3net_amd import _lib
+    rng = np.random.default_rng(85)
+
+    def sheet(nx, ny, z):
+        g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij"), -1).reshape(-1, 2).astype(np.float32) * 0.02
+        return np.concatenate([g, np.full((len(g), 1), z, np.float32)], 1)
+    parts = [sheet(190, 190, 0.0), sheet(200, 200, 1.0),
+             rng.normal(0, 0.03, (3000, 3)).astype(np.float32) + np.array([8.0, 0, 3.0], np.float32),
+             rng.normal(0, 0.006, (2500, 3)).astype(np.float32) + np.array([12.0, 0, 5.0], np.float32)]
+    xyz = np.concatenate(parts)
+    sem = np.concatenate([np.full(len(p), 2 + k, np.int32) for k, p in enumerate(parts)])
+    perm = rng.permutation(len(xyz))
+    xyz, sem = xyz[perm], sem[perm]
+    n = len(xyz)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = P.ballquery_batch_p(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, 300)
+    idx, sl = N(idx), N(sl)
+    rci, rco = o.bfs_cluster(sem, idx, sl, 50)
+    sizes = np.diff(rco)
+    assert 36100 in sizes and 40000 in sizes and (sl[:, 1] >= 1000).sum() > 500 and ((sl[:, 1] > 100) & (sl[:, 1] < 1000)).sum() > 500
+    try:
+        for form in (1, 0):
+            assert _lib.lib().d3_tuning_set(b"D3_BFS3", form) == 0
+            for asc in (False, True):
+                ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, asc)
+                assert np.array_equal(N(co), rco), (form, asc)
+                assert np.array_equal(N(ci), rci), (form, asc, int((N(ci) != rci).any(1).argmax()))
+    finally:
+        _lib.lib().d3_tuning_set(b"D3_BFS3", 0)
+
+
 def test_bfs_cluster_no_clusters(dev):
     from d3net_amd import pointgroup_ops as P
     sem = np.array([1, 2, 3], np.int32); idx = np.array([0, 1, 2], np.int32)
