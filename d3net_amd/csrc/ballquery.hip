@@ -21,6 +21,7 @@
 // caller allocate the exact output (the reference guesses n*meanActive and retries).
 // HBM bound: bytes = 12*n (coords) + 8*n (start_len) + 4*nActive (lists); box tables are L2-resident.
 #include "common.h"
+#include <string.h>
 
 #define BQ_CHUNK 64
 #define BQ_SUPER 64
@@ -254,6 +255,16 @@ __global__ void bq_pack_kernel(const int *len, const int *start, int *start_len,
     if (i == n - 1) total[0] = start[i] + len[i];
 }
 
+// 64-bit total of the list lengths (only launched when n * 1000 could pass INT_MAX): total[2..3] as one unsigned long long.
+// The reference's nActive is an int (lib/pointgroup_ops/src/bfs_cluster/bfs_cluster.cpp:17-22); past 2^31 - 1 entries the compact
+// form has no representation -- the count then reports D3_ERR_RANGE instead of scanning a wrapped prefix.
+__global__ __launch_bounds__(256) void bq_total64_kernel(const int *__restrict__ len, int n, unsigned long long *total64) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = i < n ? (unsigned long long)len[i] : 0ull;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (d3_lane() == 0 && v) atomicAdd(total64, v);
+}
+
 static int bq_boxes(const float *xyz, int n, BqWs &w, hipStream_t s) {
     bq_chunk_box_kernel<<<(w.nchunks + 3) / 4, 256, 0, s>>>(xyz, n, w.clo, w.chi, w.nchunks);
     bq_super_box_kernel<<<(w.nsuper + 3) / 4, 256, 0, s>>>(w.clo, w.chi, w.nchunks, w.slo, w.shi, w.nsuper);
@@ -282,9 +293,21 @@ extern "C" int d3_ballquery_count(const float *xyz, const int *batch_idxs, const
     rc = d3_exclusive_scan_i32(w.len, w.start, n, w.temp, w.temp_bytes, s);
     if (rc) return rc;
     bq_pack_kernel<<<(n + 255) / 256, 256, 0, s>>>(w.len, w.start, start_len, n, w.total);
+    const bool may_wrap = (long long)n * BQ_CAP > 0x7FFFFFFFll;          // (lists are capped at BQ_CAP entries)
+    if (may_wrap) {
+        D3_CHECK(hipMemsetAsync(w.total + 2, 0, sizeof(unsigned long long), s));
+        bq_total64_kernel<<<(n + 255) / 256, 256, 0, s>>>(w.len, n, (unsigned long long *)(w.total + 2));
+    }
     D3_LAUNCH_CHECK();
-    D3_CHECK(hipMemcpyAsync(nActive_host, w.total, sizeof(int), hipMemcpyDeviceToHost, s));
+    int h[4] = {0, 0, 0, 0};
+    D3_CHECK(hipMemcpyAsync(h, w.total, may_wrap ? sizeof(h) : sizeof(int), hipMemcpyDeviceToHost, s));
     D3_CHECK(hipStreamSynchronize(s));
+    if (may_wrap) {
+        unsigned long long t64;
+        memcpy(&t64, h + 2, sizeof(t64));
+        if (t64 > 0x7FFFFFFFull) return D3_ERR_RANGE;      // nActive does not fit the reference's int
+    }
+    *nActive_host = h[0];
     return 0;
 }
 

@@ -29,6 +29,8 @@
 #include "prof.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 #define CL_CAP 1000
 #define CL_BFS_THREADS 1024
@@ -330,6 +332,43 @@ extern "C" int d3_bfs_cluster_count_ex(const int *semantic_label, const int *bal
     return cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, sumNPoint_host, nCluster_host, flags, stream);
 }
 
+// One iteration of the count phase, enqueued only: a pair of label-push sweeps (it == 0: also the union-find in front of them), owners,
+// sizes, kept flags, cluster ids / offsets, and the copy of the scalars to `h` (6 ints; pinned memory for the asynchronous form).
+static int cl_count_enqueue(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold, ClWs &w,
+                            int asc, int it, int *h, hipStream_t s) {
+    const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
+    if (it == 0) {
+        cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, w.qln, n, w.scalars);   // (klen, qln: scratch until the fill)
+        if (d3_tune(D3T_CL_HOOK) != 0) cl_hook_kernel<<<nb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
+        cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
+        cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
+        D3_LAUNCH_CHECK();
+    }
+    // Label pushes in pairs, and the sizes / ids / offsets computed right behind them, all read back with ONE host round
+    // trip: the usual case is one productive sweep plus the sweep that finds nothing left to do (the second one reports
+    // through its own flag, scalars[4]); only when both sweeps still changed labels is the tail recomputed after more.
+    const int npb = nwb < 4096 ? nwb : 4096;      // label push: a bounded grid of waves walks the nodes
+    if (it > 0) {          // (the first pair of sweeps finds both flags zeroed by cl_init_kernel: two 4-byte fill launches less per clustering)
+        D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
+        D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
+    }
+    if (it == 0 && asc)
+        cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 1);
+    cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 0);
+    cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars + 4, w.scalars + 3, asc, 0);
+    if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
+    cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
+    cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold, start_len, w.scalars);
+    int rc = d3_exclusive_scan_i32(w.flag, w.cid, n, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    rc = d3_exclusive_scan_i32(w.ksz, w.koff, n, w.temp, w.temp_bytes, s);
+    if (rc) return rc;
+    cl_totals_kernel<<<1, 64, 0, s>>>(w.flag, w.cid, w.ksz, w.koff, n, w.scalars);
+    D3_LAUNCH_CHECK();
+    D3_CHECK(hipMemcpyAsync(h, w.scalars, 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
 static int cl_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold, void *ws,
                     size_t ws_bytes, int *sumNPoint_host, int *nCluster_host, int flags, void *stream) {
     D3_CLEAR();
@@ -339,36 +378,10 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     ClWs w;
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
-    const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
-    cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, w.qln, n, w.scalars);   // (klen, qln: scratch until the fill)
-    if (d3_tune(D3T_CL_HOOK) != 0) cl_hook_kernel<<<nb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
-    cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
-    cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
-    D3_LAUNCH_CHECK();
-    // Label pushes in pairs, and the sizes / ids / offsets computed right behind them, all read back with ONE host round
-    // trip: the usual case is one productive sweep plus the sweep that finds nothing left to do (the second one reports
-    // through its own flag, scalars[4]); only when both sweeps still changed labels is the tail recomputed after more.
     int h[6] = {0, 0, 0, 0, 0, 0};
-    const int npb = nwb < 4096 ? nwb : 4096;      // label push: a bounded grid of waves walks the nodes
     for (int it = 0;; it += 2) {
-        if (it > 0) {          // (the first pair of sweeps finds both flags zeroed by cl_init_kernel: two 4-byte fill launches less per clustering)
-            D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
-            D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
-        }
-        if (it == 0 && asc)
-            cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 1);
-        cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars, w.scalars + 3, asc, 0);
-        cl_push_kernel<<<npb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.lab, w.klen, w.qln, w.scalars + 4, w.scalars + 3, asc, 0);
-        if (it > 0) D3_CHECK(hipMemsetAsync(w.sizes, 0, (size_t)n * sizeof(int), s));   // (cl_owner_kernel accumulates)
-        cl_owner_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.own, w.sizes, n);
-        cl_keep_kernel<<<nb, T, 0, s>>>(w.sizes, w.flag, w.ksz, n, threshold, start_len, w.scalars);
-        int rc = d3_exclusive_scan_i32(w.flag, w.cid, n, w.temp, w.temp_bytes, s);
+        int rc = cl_count_enqueue(semantic_label, ball_query_idxs, start_len, n, threshold, w, asc, it, h, s);
         if (rc) return rc;
-        rc = d3_exclusive_scan_i32(w.ksz, w.koff, n, w.temp, w.temp_bytes, s);
-        if (rc) return rc;
-        cl_totals_kernel<<<1, 64, 0, s>>>(w.flag, w.cid, w.ksz, w.koff, n, w.scalars);
-        D3_LAUNCH_CHECK();
-        D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
         D3_CHECK(hipStreamSynchronize(s));
         if (!h[0] || !h[4] || it >= n + 2) break;
     }
@@ -381,10 +394,12 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
 
 // z0 / z1 (optional, n ints each): zeroed here instead of by two fill launches in front of the record pass (3 MB each at the bench
 // batch: 13 + 29 us of fill kernels and their launch gaps on the clustering's critical path)
+// cnt (optional): the count phase's device scalars ([1] = nCluster, [2] = sumNPoint) -- the speculative fill of d3_bfs_cluster_run is
+// enqueued before the host has read them
 __global__ void cl_seed_kernel(const int *flag, const int *cid, const int *koff, int n, int *seeds,
-                               int *cluster_offsets, int nCluster, int sumNPoint, int *z0, int *z1) {
+                               int *cluster_offsets, int nCluster, int sumNPoint, int *z0, int *z1, const int *__restrict__ cnt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) cluster_offsets[nCluster] = sumNPoint;
+    if (i == 0) cluster_offsets[cnt ? cnt[1] : nCluster] = cnt ? cnt[2] : sumNPoint;
     if (i < n && z0) { z0[i] = 0; z1[i] = 0; }
     if (i >= n || !flag[i]) return;
     seeds[cid[i]] = i;
@@ -543,7 +558,7 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T;
-    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint, nullptr, nullptr);
+    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint, nullptr, nullptr, nullptr);
     if (nCluster > 0)
         cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
                                                          w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, 0);
@@ -588,9 +603,9 @@ extern "C" int d3_bfs_cluster_fill(const int *semantic_label, const int *ball_qu
 __global__ __launch_bounds__(256) void cl_star_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
                                                      const int *__restrict__ own, const int *__restrict__ seeds,
                                                      const int *__restrict__ koff, const int *__restrict__ sizes, int nCluster,
-                                                     int *__restrict__ star, int *__restrict__ cluster_idxs) {
+                                                     int *__restrict__ star, int *__restrict__ cluster_idxs, const int *__restrict__ dcnt) {
     const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = d3_lane();
-    if (c >= nCluster) return;
+    if (c >= (dcnt ? dcnt[1] : nCluster)) return;
     const int s = seeds[c], st = start_len[s * 2], ln = start_len[s * 2 + 1], size = sizes[s];
     int cnt = 0;
     for (int e0 = 0; e0 < ln; e0 += 64) {
@@ -731,8 +746,9 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
                                                             const int *__restrict__ lid, const int *__restrict__ seeds,
                                                             const int *__restrict__ koff, const int *__restrict__ sizes,
                                                             const int *__restrict__ star, int *qst_all, int *qln_all,
-                                                            int *cluster_idxs, int *dbg, int min_size) {
+                                                            int *cluster_idxs, int *dbg, int min_size, const int *__restrict__ cnt, int c0) {
     extern __shared__ __attribute__((aligned(16))) int b2_smem[];
+    if (cnt && (int)blockIdx.x + c0 >= cnt[1]) return;       // (speculative launch on an upper-bound grid: no such cluster)
     int n_levels = 0, n_batches = 0;
 #ifdef B2_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_readcyclecounter();
@@ -744,7 +760,7 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     int *foff = fst + 2 * B2_FMAX;                                  // 2 * (B2_FMAX + 8): exclusive prefix of their lengths
     unsigned short *hint = (unsigned short *)(foff + 2 * (B2_FMAX + 8));   // 2 * B2_HINTS
     int *s_w = (int *)(hint + 2 * B2_HINTS);                        // 128
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.x + c0, tid = threadIdx.x;
     const int s = seeds[c], base = koff[s], size = sizes[s];
     if (size > B2_MAXSIZE) return;                                  // left to cl_bfs_kernel
     if (size <= min_size) return;                                   // written by cl_bfs3_kernel
@@ -1167,23 +1183,30 @@ __global__ __launch_bounds__(B3_T) void cl_bfs3_kernel(const int4 *__restrict__ 
     B3_TDUMP
 }
 
-__global__ void cl_prof_total_kernel(const int *estart, const int *klen, int n, double *out) { *out = (double)estart[n - 1] + (double)klen[n - 1]; }
+// (cnt: the speculative fill does not know sumNPoint on the host -- its 8 S bytes are added here, in units of the slot's factor 4)
+__global__ void cl_prof_total_kernel(const int *estart, const int *klen, int n, double *out, const int *cnt) {
+    *out = (double)estart[n - 1] + (double)klen[n - 1] + (cnt ? 2.0 * (double)cnt[2] : 0.0);
+}
 
 extern "C" size_t d3_bfs_cluster_erec_bytes(long long nActive) { return (size_t)(nActive > 0 ? nActive : 1) * sizeof(int4); }
 
 // d3_bfs_cluster_fill with the record-form level loop; erec: d3_bfs_cluster_erec_bytes(nActive) bytes of scratch
 // (nActive = length of ball_query_idxs).  Same outputs, bit for bit.
-extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
-                                    int n, void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive,
-                                    int *cluster_idxs, int *cluster_offsets, int sumNPoint, int nCluster, void *stream) {
-    D3_CLEAR();
+// dev_counts: the sizes are read on the device (w.scalars, written by the count kernels enqueued in front); sumNPoint / nCluster are
+// then UPPER BOUNDS for the grids (the star pass and the replay walk `nCluster` slots and find the real count on the device), and
+// the generic level loop for clusters beyond the LDS bitmap is left to the caller, who launches it once it knows sumNPoint.
+static int cl_fill2_impl(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
+                         int n, void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive,
+                         int *cluster_idxs, int *cluster_offsets, int sumNPoint, int nCluster, bool dev_counts, int c0, void *stream) {
     if (n <= 0) return 0;
     ClWs w;
     if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
     if (erec == nullptr || erec_bytes < d3_bfs_cluster_erec_bytes(nActive)) return D3_ERR_WORKSPACE;
     hipStream_t s = d3_stream(stream);
     const int T = 256, nb = (n + T - 1) / T, nwb = (n + 3) / 4;
-    cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint, nCluster > 0 ? w.lcnt : nullptr, w.star);
+    const int *cnt = dev_counts ? w.scalars : nullptr;
+    if (c0 == 0)
+        cl_seed_kernel<<<nb, T, 0, s>>>(w.flag, w.cid, w.koff, n, w.seeds, cluster_offsets, nCluster, sumNPoint, nCluster > 0 ? w.lcnt : nullptr, w.star, cnt);
     if (nCluster > 0) {
         static bool attr_done_dev[64] = {false};   // the attribute is per device
         const size_t lds = (size_t)B2_LDS_INTS * sizeof(int);
@@ -1193,21 +1216,23 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
             if (dev_id >= 0 && dev_id < 64) attr_done_dev[dev_id] = true;
         }
         const bool no_star = d3_tune(D3T_BFS_NO_STAR) != 0;   // (tests: force the level loop for every cluster)
+        if (c0 == 0) {      // (c0 > 0: a second replay launch for the clusters beyond the speculative grid -- the tables are built)
         if (!no_star)
             cl_star_kernel<<<(nCluster + 3) / 4, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.seeds, w.koff, w.sizes, nCluster, w.star,
-                                                           cluster_idxs);
+                                                           cluster_idxs, cnt);
         cl_lid_kernel<<<nb, T, 0, s>>>(w.own, w.flag, w.star, start_len, w.lcnt, w.lid, w.klen, n);
         int rc = d3_exclusive_scan_i32(w.klen, w.estart, n, w.temp, w.temp_bytes, s);
         if (rc) return rc;
         cl_ninfo_kernel<<<nb, T, 0, s>>>(w.own, w.lid, w.estart, start_len, w.ninfo, n);
         cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.ninfo, w.estart, (int4 *)erec, n);
+        }
         const bool debug = d3_tune(D3T_BFS_DEBUG) != 0;
         // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S, nActive = the list entries of the kept
         // clusters' nodes (what the replay streams; the padded lists' capacity says nothing) -- known on the device only
-        void *pr = d3_prof_begin(5, 12.0 * (double)n + 8.0 * (double)sumNPoint, 0.0, s);
+        void *pr = d3_prof_begin(5, 12.0 * (double)n + (dev_counts ? 0.0 : 8.0 * (double)sumNPoint), 0.0, s);
         // round 5: clusters whose discovery words fit the LDS (<= B3_MAXNODES nodes) replay on the thread-per-frontier-node kernel;
         // larger ones (and everything with D3_BFS3=0) on the edge-parallel hash form
-        const bool use3 = d3_tune(D3T_BFS3) != 0 && g_cl_checked_ws == ws && g_cl_short_lists &&
+        const bool use3 = !dev_counts && c0 == 0 && d3_tune(D3T_BFS3) != 0 && g_cl_checked_ws == ws && g_cl_short_lists &&
                           (unsigned long long)(nActive > 0 ? nActive : 1) * sizeof(int4) < 0xFFFFFFFFull;      // (32-bit record offsets)
         if (use3) {
             static bool attr3_done_dev[64] = {false};
@@ -1221,13 +1246,13 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
                                                        debug ? w.lcnt : nullptr);
         }
         if (!use3 || sumNPoint > B3_MAXNODES)
-            cl_bfs2_kernel<<<nCluster, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
-                                                            w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr, use3 ? B3_MAXNODES : 0);
+            cl_bfs2_kernel<<<nCluster - c0, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
+                                                            w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr, use3 ? B3_MAXNODES : 0, cnt, c0);
         if (pr) {
             d3_prof_tag(pr, 0, n); d3_prof_tag(pr, 1, nCluster); d3_prof_end(pr, s);
-            if (double *slot = d3_prof_dev_slot(pr, 4.0)) cl_prof_total_kernel<<<1, 1, 0, s>>>(w.estart, w.klen, n, slot);   // (behind the bracket)
+            if (double *slot = d3_prof_dev_slot(pr, 4.0)) cl_prof_total_kernel<<<1, 1, 0, s>>>(w.estart, w.klen, n, slot, cnt);   // (behind the bracket)
         }
-        if (debug) {
+        if (debug && !dev_counts) {
             int h[60 + 160];
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);
             for (int c = 0; c < nCluster && c < 20; c++) {
@@ -1239,10 +1264,106 @@ extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_q
             }
         }
         // clusters beyond the LDS bitmap: the generic level loop (none can exist when all kept points together fit)
-        if (sumNPoint > B2_MAXSIZE)
+        if (!dev_counts && c0 == 0 && sumNPoint > B2_MAXSIZE)
             cl_bfs_kernel<<<nCluster, CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds,
                                                          w.koff, w.sizes, w.par, w.queue, w.fcnt, w.qln, cluster_idxs, B2_MAXSIZE);
     }
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
+                                    int n, void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive,
+                                    int *cluster_idxs, int *cluster_offsets, int sumNPoint, int nCluster, void *stream) {
+    D3_CLEAR();
+    return cl_fill2_impl(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs, cluster_offsets,
+                         sumNPoint, nCluster, false, 0, stream);
+}
+
+// count + fill as ONE native call (round 5): the caller hands in outputs at their upper bounds (cluster_idxs: cap_points x 2 ints,
+// cluster_offsets: cap_clusters + 1 ints) and reads back how much of them was written.  Between the two phases the two-call form
+// goes back to its caller for the output allocation; when that caller is a Python thread next to another busy one (the two
+// clustering branches of PointGroup.forward), re-acquiring the interpreter lock there cost 80 - 470 us of idle queue per branch
+// (gpurun_out/r05_j11/cluster_timeline.txt).  Same results as count_ex + fill2: it IS count_ex + fill2.
+// A pinned landing buffer + event per in-flight count (pooled; the clustering branches run on two host threads)
+struct ClTicket { int *pinned; hipEvent_t ev; };
+static std::mutex g_clt_mu;
+static std::vector<ClTicket *> g_clt_free;
+#define CL_SPEC_GRID 2048      // cluster slots of the speculative replay launch (more kept clusters: a second launch once the count is known)
+
+extern "C" int d3_bfs_cluster_run(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
+                                  void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
+                                  int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
+                                  int *sumNPoint_host, int *nCluster_host, void *stream) {
+    if (!sumNPoint_host || !nCluster_host) return D3_ERR_ARG;
+    if (n <= 0 || d3_tune(D3T_CL_SPEC) == 0 || d3_tune(D3T_BFS3) != 0 || d3_tune(D3T_BFS_DEBUG) != 0 || cap_points < n) {
+        int rc = cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, sumNPoint_host, nCluster_host, flags, stream);
+        if (rc) return rc;
+        if (n <= 0) return 0;
+        if ((long long)*sumNPoint_host > cap_points || (long long)*nCluster_host > cap_clusters) return D3_ERR_WORKSPACE;
+        return d3_bfs_cluster_fill2(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs,
+                                    cluster_offsets, *sumNPoint_host, *nCluster_host, stream);
+    }
+    // Speculative form: the count kernels, the copy of their scalars and an event are enqueued, then the WHOLE fill with its sizes
+    // read on the device (upper-bound grids), and only then the host waits -- for the event, not for the stream: while it reads the
+    // counts the record pass and the level replay are already running.  The two-call form left the stream empty from the count's
+    // synchronisation until the fill's seven launches had been issued (40 - 70 us each next to another launching thread:
+    // gpurun_out/r05_j12/cluster_timeline.txt).  Should the label push not have converged in its first pair of sweeps (both sweeps
+    // still changed labels: capped lists in a chain, never seen in the bench workloads), the speculative fill's output is
+    // overwritten by the regular path below.
+    D3_CLEAR();
+    *sumNPoint_host = 0; *nCluster_host = 0;
+    if (erec == nullptr || erec_bytes < d3_bfs_cluster_erec_bytes(nActive)) return D3_ERR_WORKSPACE;
+    const int asc = (flags & D3_BFS_ASCENDING) ? 1 : 0;
+    ClWs w;
+    if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    ClTicket *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_clt_mu);
+        if (!g_clt_free.empty()) { t = g_clt_free.back(); g_clt_free.pop_back(); }
+    }
+    if (!t) {
+        t = new ClTicket{nullptr, nullptr};
+        hipError_t he = hipHostMalloc((void **)&t->pinned, 8 * sizeof(int));
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&t->ev, hipEventDisableTiming);
+        if (he != hipSuccess) { delete t; return (int)he; }
+    }
+    struct Back { ClTicket *t; ~Back() { std::lock_guard<std::mutex> lk(g_clt_mu); g_clt_free.push_back(t); } } back{t};
+    int rc = cl_count_enqueue(semantic_label, ball_query_idxs, start_len, n, threshold, w, asc, 0, t->pinned, s);
+    if (rc) return rc;
+    D3_CHECK(hipEventRecord(t->ev, s));
+    const int slots = (int)(cap_clusters < CL_SPEC_GRID ? cap_clusters : CL_SPEC_GRID);
+    // (cluster_offsets has cap_clusters + 1 entries and cluster_idxs n rows: whatever the device counts turn out to be, they fit)
+    rc = cl_fill2_impl(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs, cluster_offsets,
+                       n, slots > 0 ? slots : 1, true, 0, stream);
+    if (rc) return rc;
+    D3_CHECK(hipEventSynchronize(t->ev));
+    int h[6];
+    for (int k = 0; k < 6; k++) h[k] = t->pinned[k];
+    if (h[0] && h[4]) {      // not converged: more sweeps, then the regular fill over the speculative one
+        for (int it = 2;; it += 2) {
+            rc = cl_count_enqueue(semantic_label, ball_query_idxs, start_len, n, threshold, w, asc, it, h, s);
+            if (rc) return rc;
+            D3_CHECK(hipStreamSynchronize(s));
+            if (!h[0] || !h[4] || it >= n + 2) break;
+        }
+        *nCluster_host = h[1]; *sumNPoint_host = h[2];
+        g_cl_checked_ws = ws; g_cl_short_lists = h[5] == 0;
+        if ((long long)h[2] > cap_points || (long long)h[1] > cap_clusters) return D3_ERR_WORKSPACE;
+        return d3_bfs_cluster_fill2(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs,
+                                    cluster_offsets, h[2], h[1], stream);
+    }
+    *nCluster_host = h[1]; *sumNPoint_host = h[2];
+    g_cl_checked_ws = ws; g_cl_short_lists = h[5] == 0;
+    if ((long long)h[1] > cap_clusters) return D3_ERR_WORKSPACE;      // (cannot happen for cap_clusters >= n / threshold: kept clusters have >= threshold points)
+    if (h[1] > slots)        // kept clusters beyond the speculative grid: their replay now, on the tables the first launch built
+        rc = cl_fill2_impl(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs, cluster_offsets,
+                           h[2], h[1], false, slots, stream);
+    if (rc) return rc;
+    if (h[2] > B2_MAXSIZE && h[1] > 0)      // clusters beyond the LDS bitmap: the generic level loop (none can exist when all kept points together fit)
+        cl_bfs_kernel<<<h[1], CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds, w.koff, w.sizes, w.par, w.queue,
+                                                     w.fcnt, w.qln, cluster_idxs, B2_MAXSIZE);
     D3_LAUNCH_CHECK();
     return 0;
 }

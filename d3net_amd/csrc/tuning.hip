@@ -49,6 +49,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_BN_PART2", 1},             // 0: BatchNorm launches reduce the producer's whole per-workgroup partial table (rounds 1-4) instead of the 16-row fp64 second-level table
     {"D3_CL_HOOK", 1},              // 0: the clustering's union-find starts from singletons (rounds 1-4) instead of one hook per node under a smaller-index neighbour
     {"D3_ACT_GRAD_BF16", 0},        // 1: gradients of BatchNorm->ReLU activations (one convolution reader) stored as bf16 (unet.hip Net::gabf): measured neutral, off
+    {"D3_CL_SPEC", 1},              // 0: d3_bfs_cluster_run waits for the cluster counts before it enqueues the fill (count_ex + fill2); 1: the fill is enqueued behind the count kernels with its sizes read on the device, the host waits for the counts while the fill already runs
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

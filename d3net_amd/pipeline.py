@@ -143,7 +143,9 @@ class PipelineNet(nn.Module):
                 if "loss" in k:
                     self.log("train/{}".format(k), v[0])
         elif self.mode == 1:
-            data_dict = self.speaker(self._detect(data_dict))
+            data_dict = self._detect(data_dict)
+            self.detector._kick_prefetch("caption")      # (input prefetch, if set to start under the captioner's recurrence)
+            data_dict = self.speaker(data_dict)
             _mark("speaker")
             _, data_dict = get_captioning_loss(data_dict, caption=not self.no_captioning, orientation=self.cfg.model.use_orientation,
                                                num_bins=self.cfg.data.num_ori_bins, loss_opt=self.loss_opt)

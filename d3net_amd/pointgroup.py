@@ -77,6 +77,50 @@ def _cluster_worker():
     return _WORKER
 
 
+_PF_WORKER = None
+
+
+def _prefetch_worker():
+    """ONE persistent helper thread per process for the input prefetch (its own per-thread operator workspaces, like the clustering helper)"""
+    global _PF_WORKER
+    if _PF_WORKER is None:
+        import concurrent.futures
+        _PF_WORKER = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="d3-prefetch")
+    return _PF_WORKER
+
+
+class _Prefetch:
+    """ticket of PointGroup.prefetch(): the weight-independent input stage of a LATER step (voxel features, the backbone's coordinate
+    pyramid and kernel maps) built on a side stream while the current step runs"""
+    __slots__ = ("inputs", "future", "cm", "voxel_feats", "event", "error")
+
+    def __init__(self, inputs):
+        self.inputs, self.future, self.cm, self.voxel_feats, self.event, self.error = inputs, None, None, None, None, None
+
+
+PREFETCH_MODE = 3   # InputPrefetcher: 0 off; where in the current step the next batch's input stage starts: 1 clustering begins, 2 at once,
+                    # 3 the first clustering branch is enqueued (its single-workgroup BFS replay leaves the chip idle: measured best,
+                    # speaker step 17.49 -> 16.84 ms, detector 8.30 -> 7.86 ms in-process, gpurun_out/r05_j8), 4 behind ScoreNet, 5 at the captioner
+
+
+class InputPrefetcher:
+    """The training loop's batch source with one batch of look-ahead: `next()` hands out the batch of this step and announces the
+    following one to the detector (PointGroup.prefetch), whose input stage then overlaps this step.  `make()` -> a data_dict (or a
+    list of them for PipelineNet's joint step: the first one is prefetched)."""
+
+    def __init__(self, detector, make):
+        self.detector, self.make, self.ahead = detector, make, None
+
+    def next(self):
+        cur = self.ahead if self.ahead is not None else self.make()
+        self.ahead = None
+        if PREFETCH_MODE:
+            self.detector.prefetch_at = {1: "cluster", 2: "start", 3: "bfs", 4: "scorenet", 5: "caption"}[PREFETCH_MODE]
+            self.ahead = self.make()
+            self.detector.prefetch(self.ahead[0] if isinstance(self.ahead, (list, tuple)) else self.ahead)
+        return cur
+
+
 PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
 
 
@@ -146,6 +190,13 @@ class PointGroup(nn.Module):
         self.native_unet = True
         self.native_exact = True      # minkowski.set_exact(True) also runs through the native executor (False: module by module)
         self.__dict__["_execs"] = {}
+        # input prefetch (prefetch()): the pending ticket, where in the step its work is started ("cluster": when the main stream
+        # reaches the latency-bound clustering stage; "start": at once), and the two newest consumed tickets (kept alive: their
+        # tensors live in the side stream's allocator pool and must not return to it while this step still reads them)
+        self.__dict__["_pf_pending"] = None
+        self.__dict__["_pf_live"] = [None, None]
+        self.__dict__["_pf_inflight"] = None
+        self.prefetch_at = "bfs"
 
     def _side_stream(self, device):
         key = (device.index, threading.get_ident())
@@ -186,6 +237,102 @@ class PointGroup(nn.Module):
             return       # the fp32 executors ARE the training executors in this mode
         for key in [k for k in self._execs if k.endswith("/f32")]:
             del self._execs[key]
+
+    # ------------------------------------------------------------------------------------- input prefetch
+    def _input_stage(self, data_dict):
+        """voxel features + the backbone's coordinate manager (pyramid enqueued) of one batch -> (cm or None, voxel_feats).
+        Nothing here depends on a parameter: model/pointgroup.py:466-474 (`feed`: the input voxelisation) and the coordinate maps
+        MinkowskiEngine builds on first use inside the backbone."""
+        f = data_dict["feats"]
+        # The coordinate pyramid of the backbone needs one host round trip (the level sizes).  Its kernels and the copy of
+        # the counts are enqueued BEFORE the input voxelisation, the wait comes after it: the device pools the point features
+        # (~0.27 ms for four scenes) while the host reads the counts and enqueues the kernel-map fills.
+        cm = self._begin_maps("backbone", data_dict["voxel_locs"])
+        if self.cfg.model.use_coords and f.is_cuda and f.dtype == torch.float32 and not f.requires_grad:
+            # voxelization(cat(feats, locs)) without the concatenated copy (csrc/voxelize.hip: d3_voxelize_fp2)
+            vf = pointgroup_ops.voxelization_cat(f, data_dict["locs"], data_dict["v2p_map"], self.cfg.data.mode)
+        else:
+            if self.cfg.model.use_coords:
+                f = torch.cat((f, data_dict["locs"]), 1)
+                data_dict["feats"] = f
+            vf = pointgroup_ops.voxelization(f.contiguous(), data_dict["v2p_map"], self.cfg.data.mode)
+        return cm, vf
+
+    def prefetch(self, data_dict):
+        """Announce the batch of a LATER training step: its input stage (`_input_stage` + every level's kernel map) is built on a side
+        stream from a helper thread while the current step runs -- the device-side counterpart of the reference's DataLoader workers,
+        which voxelise the next batch on the CPU during the step (data/scannet/dataset.py collate).  The work starts
+        when the current step's main stream reaches the clustering stage (single-workgroup BFS levels, union-find: most of the chip
+        idle; `prefetch_at`: "cluster" / "bfs" / "scorenet" / "caption" name the point) or, with `prefetch_at = "start"`, at once; `feed()` of that batch waits for it (or runs the stage inline when it never
+        started).  Same kernels, same results; one ticket may be pending at a time."""
+        v = data_dict.get("voxel_locs")
+        f = data_dict.get("feats")
+        if not (torch.is_tensor(v) and v.is_cuda and self.native_unet and v.size(0) > 0) or "_prefetch" in data_dict:
+            return data_dict
+        if not (self.cfg.model.use_coords and torch.is_tensor(f) and f.dtype == torch.float32 and not f.requires_grad):
+            return data_dict
+        t = _Prefetch({k: data_dict[k] for k in ("feats", "locs", "v2p_map", "voxel_locs")})
+        data_dict["_prefetch"] = t
+        self._pf_pending = t
+        if self.prefetch_at == "start":
+            self._kick_prefetch()
+        return data_dict
+
+    def _kick_prefetch(self, at=None):
+        t = self._pf_pending
+        if t is None or t.future is not None or (at is not None and at != self.prefetch_at):
+            return
+        self._pf_pending = None
+        dev = t.inputs["voxel_locs"].device
+        cur = torch.cuda.current_stream(dev)
+        # every block the side stream's pool holds was last read by work enqueued before this point (the tickets in _pf_live are the
+        # only side-pool tensors this stream still reads, and they are released at a later feed()): the helper's first act is to wait here
+        gate = torch.cuda.Event()
+        gate.record(cur)
+        training = self.training
+
+        def work():
+            try:
+                with torch.cuda.device(dev):
+                    key = (dev.index, threading.get_ident())
+                    if key not in self._streams:
+                        self._streams[key] = torch.cuda.Stream(device=dev)
+                    side = self._streams[key]
+                    with torch.cuda.stream(side):
+                        side.wait_event(gate)
+                        cm, vf = self._input_stage(t.inputs)
+                        if cm is not None:
+                            self._exec("backbone", exact=ME.exact_for(training)).maps(cm)   # pyramid counts (host round trip) + all kernel maps
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    t.cm, t.voxel_feats, t.event = cm, vf, ev
+            except BaseException as e:      # re-raised by the consumer
+                t.error = e
+        t.future = _prefetch_worker().submit(work)
+        self._pf_inflight = t.future
+
+    def _take_prefetch(self, t, data_dict):
+        """-> (cm, voxel_feats) of ticket t for THIS data_dict, or None (never started, or built from other tensors)"""
+        if self._pf_pending is t:
+            self._pf_pending = None
+        same = t.inputs is not None and all(t.inputs.get(k) is data_dict.get(k) for k in ("feats", "locs", "v2p_map", "voxel_locs"))
+        if t.future is None:            # never started (no clustering stage since prefetch()): the caller runs the stage inline
+            t.inputs = None
+            return None
+        t.future.result()
+        t.inputs = None
+        if t.error is not None:
+            raise t.error
+        # The ticket before the previous one is released here.  Its blocks go back to the side stream's pool, so no helper whose gate
+        # was recorded before that ticket's last use may still be allocating: the newest helper (the only one that can be running) is
+        # waited for first -- it finished long ago unless two detector passes per step are prefetched back to back.
+        if self._pf_inflight is not None:
+            self._pf_inflight.result()
+        self._pf_live = [self._pf_live[1], t]
+        if not same or t.voxel_feats is None:
+            return None
+        torch.cuda.current_stream(t.voxel_feats.device).wait_event(t.event)
+        return t.cm, t.voxel_feats
 
     def _run_unet(self, name, module, x):
         """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""
@@ -405,6 +552,7 @@ class PointGroup(nn.Module):
                 # one runs on a side stream from a helper thread (ctypes releases the GIL inside libd3hip), so its count
                 # phases, which synchronise their own stream, overlap the other branch instead of serialising with it.
                 _mark("cl_prepare")
+                self._kick_prefetch("cluster")          # (a pending input prefetch starts here: the clustering leaves most of the chip idle)
                 cur = torch.cuda.current_stream()
                 if self.concurrent_clustering:
                     side = self._side_stream(coords_.device)
@@ -416,6 +564,7 @@ class PointGroup(nn.Module):
                     fut = _cluster_worker().submit(work)
                     try:
                         first = cluster_branch(coords_, self.cluster_meanActive, True)
+                        self._kick_prefetch("bfs")
                         # the shifted branch (capped lists: label push) runs ~0.4 ms longer: the point losses, which need
                         # nothing from the clustering, fill this stream's wait for it
                         self._early_point_losses(data_dict)
@@ -449,6 +598,7 @@ class PointGroup(nn.Module):
             _mark("cluster_voxelization")
             score_feats = self._run_unet("score_net", self.score_net, proposals_voxel_feats)
             _mark("score_net_fwd")
+            self._kick_prefetch("scorenet")
             # Host work that does not depend on the proposals goes HERE: the device still has the cluster voxelisation and
             # ScoreNet queued, so the point losses' ~20 small launches and the slot permutation's CPU draw cost no device time;
             # after the `nonzero` below the queue is empty and every host microsecond is an idle device microsecond.
@@ -579,19 +729,11 @@ class PointGroup(nn.Module):
     def feed(self, data_dict, epoch=0):
         """(reference :466-479)"""
         data_dict["epoch"] = epoch
-        f = data_dict["feats"]
-        # The coordinate pyramid of the backbone needs one host round trip (the level sizes).  Its kernels and the copy of
-        # the counts are enqueued BEFORE the input voxelisation, the wait comes after it: the device pools the point features
-        # (~0.27 ms for four scenes) while the host reads the counts and enqueues the kernel-map fills.
-        cm = self._begin_maps("backbone", data_dict["voxel_locs"])
-        if self.cfg.model.use_coords and f.is_cuda and f.dtype == torch.float32 and not f.requires_grad:
-            # voxelization(cat(feats, locs)) without the concatenated copy (csrc/voxelize.hip: d3_voxelize_fp2)
-            data_dict["voxel_feats"] = pointgroup_ops.voxelization_cat(f, data_dict["locs"], data_dict["v2p_map"], self.cfg.data.mode)
-        else:
-            if self.cfg.model.use_coords:
-                data_dict["feats"] = torch.cat((data_dict["feats"], data_dict["locs"]), 1)
-            data_dict["voxel_feats"] = pointgroup_ops.voxelization(data_dict["feats"].contiguous(), data_dict["v2p_map"],
-                                                                   self.cfg.data.mode)
+        t = data_dict.pop("_prefetch", None)
+        got = self._take_prefetch(t, data_dict) if t is not None else None
+        if got is None:
+            got = self._input_stage(data_dict)
+        cm, data_dict["voxel_feats"] = got
         if cm is not None:
             data_dict["_backbone_cm"] = cm
         data_dict = self.forward(data_dict)

@@ -282,15 +282,19 @@ class BFSCluster(Function):
         with _on(dev):
             ws = _workspace(L.d3_bfs_cluster_ws_bytes(N), dev, "cl")
             S, P = C.c_int(0), C.c_int(0)
-            check(L.d3_bfs_cluster_count_ex(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(),
-                                            C.byref(S), C.byref(P), 1 if ascending else 0, _stream()), "bfs_cluster_count")
-            S, P = S.value, P.value
-            cluster_idxs = torch.empty((S, 2), dtype=torch.int32, device=dev)
-            cluster_offsets = torch.empty(P + 1, dtype=torch.int32, device=dev)
             nact = int(idx.numel())
             rec = _workspace(L.d3_bfs_cluster_erec_bytes(nact), dev, "clrec")
-            check(L.d3_bfs_cluster_fill2(_ptr(sem), _ptr(idx), _ptr(sl), N, _ptr(ws), ws.numel(), _ptr(rec), rec.numel(), nact,
-                                         _ptr(cluster_idxs), _ptr(cluster_offsets), S, P, _stream()), "bfs_cluster_fill2")
+            # ONE native call for count + fill: outputs at their upper bounds (N points, N / threshold + 1 clusters), sliced below --
+            # going back to the interpreter between the phases costs the interpreter lock when the other clustering branch is busy
+            capP, capC = max(N, 1), N // max(int(threshold), 1) + 1
+            cluster_idxs = torch.empty((capP, 2), dtype=torch.int32, device=dev)
+            cluster_offsets = torch.empty(capC + 1, dtype=torch.int32, device=dev)
+            check(L.d3_bfs_cluster_run(_ptr(sem), _ptr(idx), _ptr(sl), N, int(threshold), _ptr(ws), ws.numel(), _ptr(rec), rec.numel(), nact,
+                                       1 if ascending else 0, _ptr(cluster_idxs), capP, _ptr(cluster_offsets), capC,
+                                       C.byref(S), C.byref(P), _stream()), "bfs_cluster_run")
+            cluster_idxs, cluster_offsets = cluster_idxs[:S.value], cluster_offsets[:P.value + 1]
+            if N == 0:
+                cluster_offsets.zero_()
         if on_cpu:
             return cluster_idxs.cpu(), cluster_offsets.cpu()
         return cluster_idxs, cluster_offsets

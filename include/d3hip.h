@@ -172,6 +172,16 @@ int d3_bfs_cluster_fill2(const int *semantic_label, const int *ball_query_idxs, 
                          size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int *cluster_idxs,
                          int *cluster_offsets, int sumNPoint, int nCluster, void *stream);
 
+/* d3_bfs_cluster_count_ex + d3_bfs_cluster_fill2 as one call: outputs at their upper bounds (cluster_idxs: cap_points x 2
+ * ints, cap_points >= sumNPoint -- n always suffices; cluster_offsets: cap_clusters + 1 ints -- n / max(threshold, 1) + 1
+ * suffices), the used sizes come back in *sumNPoint_host / *nCluster_host.  D3_ERR_WORKSPACE when a bound is too small.
+ * Replaces the pair bfs_cluster.cpp:28-112 is called through (functions/pointgroup_ops.py:203-231) without the return to
+ * the caller between the phases (a Python caller re-acquires its interpreter lock there: idle device time). */
+int d3_bfs_cluster_run(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
+                       void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
+                       int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
+                       int *sumNPoint_host, int *nCluster_host, void *stream);
+
 /* ---- sparse 3-D convolution (MinkowskiEngine subset) ---------------------------------- */
 /* Coordinates are (M,4) int32 rows [batch, x, y, z] (ME.SparseTensor(coordinates=...),
  * reference: model/pointgroup.py:176,268).  Key range as for voxelize_idx.

@@ -365,6 +365,40 @@ def test_bfs_cluster_capped_chain(dev, order):
         assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), asc
 
 
+@pytest.mark.parametrize("spec", [1, 0])
+def test_bfs_cluster_run_speculative_fill_and_many_clusters(dev, spec):
+    """d3_bfs_cluster_run: the fill enqueued behind the count kernels with its sizes read on the device (D3_CL_SPEC=1, the default)
+    equals the count -> host -> fill order (D3_CL_SPEC=0) and the oracle -- also with more kept clusters than the speculative replay
+    launch has slots (2048: the rest replays in a second launch), with and without the star shortcut."""
+    from d3net_amd import pointgroup_ops as P, _lib
+    rng = np.random.default_rng(84)
+    # 3000 isolated triples (clusters of 3) + one 600-point rod (a real level loop) in index order after them
+    ncl = 3000
+    base = np.stack([np.arange(ncl) % 60, (np.arange(ncl) // 60) % 60, np.zeros(ncl)], 1).astype(np.float32) * 0.2
+    tri = (base[:, None, :] + rng.normal(0, 0.004, (ncl, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    rod = np.stack([np.linspace(0, 6.0, 600), np.full(600, 20.0), np.zeros(600)], 1).astype(np.float32)
+    xyz = np.concatenate([tri, rod]).astype(np.float32)
+    n = xyz.shape[0]
+    sem = np.ones(n, np.int32)
+    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
+    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 50)
+    rci, rco = o.bfs_cluster(sem, idx, sl, 3)
+    assert len(rco) - 1 > 2048 + 500
+    L = _lib.lib()
+    try:
+        assert L.d3_tuning_set(b"D3_CL_SPEC", spec) == 0
+        for no_star in (0, 1):
+            assert L.d3_tuning_set(b"D3_BFS_NO_STAR", no_star) == 0
+            ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 3, True)
+            assert np.array_equal(N(co), rco) and np.array_equal(N(ci), rci), (spec, no_star)
+        # nothing kept at all: offsets == [0]
+        ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 100000, True)
+        assert N(co).tolist() == [0] and ci.shape[0] == 0
+    finally:
+        L.d3_tuning_set(b"D3_CL_SPEC", 1)
+        L.d3_tuning_set(b"D3_BFS_NO_STAR", 0)
+
+
 def test_bfs_replay_forms_agree_with_the_oracle(dev):
     """Round 5: cl_bfs3_kernel (thread per frontier node, key election in LDS words; D3_BFS3=1, the default) and the edge-parallel hash
     form (cl_bfs2_kernel, D3_BFS3=0) against the sequential oracle on inputs that reach every path of the new kernel: a 190 x 190

@@ -60,9 +60,13 @@ if config != "detector":
         lis = S.add_language(S.make_batch(scenes, dev), dev, chunk=chunk, vocab=bench.VOCAB, seed=9)
 
 
+from d3net_amd.pointgroup import InputPrefetcher  # noqa: E402
+feeder = InputPrefetcher(det, (lambda: [dict(batch), dict(lis)]) if config == "joint" else (lambda: dict(batch)))
+
+
 def step():
     model.zero_grad(set_to_none=True)
-    loss, d = model.training_step([dict(batch), dict(lis)] if config == "joint" else dict(batch))
+    loss, d = model.training_step(feeder.next())
     loss.backward()
     opt.step()
 

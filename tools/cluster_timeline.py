@@ -6,13 +6,9 @@ import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:40], r.get("Queue_Id", "?")) for r in rows]
-ends = [i for i, e in enumerate(ev) if e[2].startswith("sec_mean")]
+ends = [i for i, e in enumerate(ev) if e[2].startswith("cp_merge")]
 last = ends[-1]
-start = last
-while start > 0 and not ev[start][2].startswith("ce_fwd") and not ev[start][2].startswith("multi_tensor"):
-    start -= 1
-# first ball-query kernel after `start`
-first = next(i for i in range(start, last) if ev[i][2].startswith("bq_"))
+first = next(i for i in range(max(last - 400, 0), last) if (ev[i][2].startswith("bq_") or ev[i][2].startswith("bqg_")))
 first = max(first - 12, 0)
 t0 = ev[first][0]
 prev_end = {}
