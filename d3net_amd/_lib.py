@@ -175,7 +175,10 @@ class GemmSeg(C.Structure):
 class GemmProb(C.Structure):
     """d3_gemm_prob (include/d3hip.h)"""
     _fields_ = [("seg", GemmSeg * 3), ("nseg", i32), ("M", i32), ("N", i32), ("C", vp), ("ldc", i64), ("bias", vp), ("add", vp),
-                ("ldadd", i64), ("relu", i32), ("accum", i32), ("perm_nb", i32), ("perm_s", i32)]
+                ("ldadd", i64), ("relu", i32), ("accum", i32), ("perm_nb", i32), ("perm_s", i32),
+                ("gru", i32), ("gru_H", i32), ("g_d0", vp), ("g_ld0", i64), ("g_d1", vp), ("g_ld1", i64),
+                ("g_r", vp), ("g_z", vp), ("g_n", vp), ("g_ghn", vp), ("g_hp", vp), ("g_ldh", i64),
+                ("g_dgi", vp), ("g_lddgi", i64), ("g_dgh", vp), ("g_dhp", vp)]
 
 
 TOPDOWN_PARAMS = ("W_td", "b_td", "Wih1", "Whh1", "bih1", "bhh1", "W_feat", "W_hidd", "w_att", "W_lang", "b_lang",

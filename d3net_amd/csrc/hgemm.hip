@@ -127,6 +127,25 @@ __global__ __launch_bounds__(NW * 64) void hg_gemm_kernel(const HgBatch batch) {
         if (p.relu && v < 0.f) v = 0.f;
         const long long orow = p.perm_nb > 0 ? (long long)(row % p.perm_nb) * p.perm_s + row / p.perm_nb : (long long)row;
         float *o = p.C + orow * p.ldc + c;
+        if (p.gru) {      // GRUCell gate backward on the finished element (d3hip.h; same expressions as topdown.hip's td_gru_bwd_gates_kernel)
+            const float tot = p.accum ? *o + v : v;
+            const int H = p.gru_H;
+            const long long e = (long long)row * H + c;
+            float dh = 0.f;
+            if (p.g_d0) dh += p.g_d0[(long long)row * p.g_ld0 + c];
+            if (p.g_d1) dh += p.g_d1[(long long)row * p.g_ld1 + c];
+            dh += tot;
+            const float rr = p.g_r[e], zz = p.g_z[e], nv = p.g_n[e];
+            const float dn = dh * (1.f - zz), dz = dh * (p.g_hp[(long long)row * p.g_ldh + c] - nv);
+            const float dnp = dn * (1.f - nv * nv);
+            const float drp = dnp * p.g_ghn[e] * rr * (1.f - rr);
+            const float dzp = dz * zz * (1.f - zz);
+            const long long og = (long long)row * 3 * H + c, oi = (long long)row * p.g_lddgi + c;
+            p.g_dgi[oi] = drp; p.g_dgi[oi + H] = dzp; p.g_dgi[oi + 2 * H] = dnp;
+            p.g_dgh[og] = drp; p.g_dgh[og + H] = dzp; p.g_dgh[og + 2 * H] = dnp * rr;
+            p.g_dhp[e] = dh * zz;
+            return;
+        }
         *o = p.accum ? *o + v : v;
     };
     if (KSPLIT) {
@@ -369,6 +388,8 @@ __global__ __launch_bounds__(256) void hg_gemm_tiled3_kernel(const HgBatch batch
 
 static int hg_check(const d3_gemm_prob &p) {
     if (p.nseg < 1 || p.nseg > 3 || p.M < 0 || p.N < 1 || !p.C) return D3_ERR_ARG;
+    if (p.gru && (p.M > 32 || p.N != p.gru_H || p.perm_nb > 0 || p.relu || !p.g_r || !p.g_z || !p.g_n || !p.g_ghn || !p.g_hp || !p.g_dgi ||
+                  !p.g_dgh || !p.g_dhp)) return D3_ERR_ARG;      // (the gate epilogue lives in the decode-step kernels only)
     for (int s = 0; s < p.nseg; s++)
         if (!p.seg[s].A || !p.seg[s].B || p.seg[s].K < 1) return D3_ERR_ARG;
     return 0;
@@ -524,6 +545,8 @@ static int hg_launch_batch(const d3_gemm_prob *probs, int nprobs, hipStream_t s)
     }
     for (int i = nprobs; i < HG_MAXP; i++) b.p[i] = probs[0];
     if (maxM == 0) return 0;
+    for (int i = 0; i < nprobs; i++)
+        if (probs[i].gru && maxM > 32) return D3_ERR_ARG;      // (a gate epilogue batched with a tall problem: the tiled kernels do not carry it)
     const int ctiles = (maxN + 15) / 16;
     int kblocks = 0;             // deepest reduction of the batch, in 16-wide k blocks
     for (int i = 0; i < nprobs; i++) {

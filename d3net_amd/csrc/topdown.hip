@@ -809,12 +809,25 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
     //   dh2 carry        += (dgi1 Wih1) W_td[:, h2] = dgi1 Wb,  Wb = Wih1 W_td[:, E:E+H] (3H x H)
     // so dx2 / dx1 (still needed, for the weight gradients batched over time) leave the critical path: 8 -> 6 launches per step.
     const int nh = (N * H + 255) / 256;
+    // Round 5: the two gate kernels of a step ride in the epilogues of the GEMMs that complete their input (d3_gemm_prob.gru): GRU-1's
+    // gates behind dq W_hidd (the last of dh1's three contributions), GRU-2's gates of step t-1 behind dgi1 Wb (the last update of
+    // the carried dh2) -- 6 -> 4 dependent launches per step; only the first step's GRU-2 gates keep a launch of their own.
+    const bool fuse = d3_tune(D3T_TD_FUSE_GATES) != 0;
+    auto gates_epi = [&](d3_gemm_prob &p, const float *d0, long long ld0, const float *d1, long long ld1, const float *g, size_t rN,
+                         const float *hp, float *dgi, float *dgh, float *dhp) {
+        p.gru = 1; p.gru_H = H;
+        p.g_d0 = d0; p.g_ld0 = ld0; p.g_d1 = d1; p.g_ld1 = ld1;
+        p.g_r = g + rN * H; p.g_z = g + RH + rN * H; p.g_n = g + 2 * RH + rN * H; p.g_ghn = g + 3 * RH + rN * H;
+        p.g_hp = hp; p.g_ldh = H;
+        p.g_dgi = dgi; p.g_lddgi = 3 * H; p.g_dgh = dgh; p.g_dhp = dhp;
+    };
     for (int t = S - 1; t >= 0; t--) {
         const size_t rN = (size_t)t * N;
         float *h1p = H1 + rN * H, *h2p = H2 + rN * H;
         // GRU2 gates: dh2[t+1] = classifier part + carry from step t+1
-        td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dH2 + rN * H, H, dh2c, H, nullptr, 0, g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H,
-                                                   g2 + 3 * RH + rN * H, h2p, H, dgi2 + rN * 3 * H, 3 * H, dgh2 + rN * 3 * H, dh2c, N, H, nullptr, 0);
+        if (!fuse || t == S - 1)
+            td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dH2 + rN * H, H, dh2c, H, nullptr, 0, g2 + rN * H, g2 + RH + rN * H, g2 + 2 * RH + rN * H,
+                                                       g2 + 3 * RH + rN * H, h2p, H, dgi2 + rN * 3 * H, 3 * H, dgh2 + rN * 3 * H, dh2c, N, H, nullptr, 0);
         {   // dh2c += dgh2 Whh2 ; [datt | dh1 part] = dgi2 Wa ; dx2 = dgi2 Wih2 (off the chain)   (one launch)
             d3_gemm_prob p[3];
             p[0] = td_prob(N, H, dh2c, H);
@@ -827,19 +840,25 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         }
         td_attn_bwd_kernel<TD_ATT_T><<<N, TD_ATT_T, (size_t)(F + K + 4 + td_attn_bwd_rsum_floats(H)) * 4, s>>>(tmpL, F + H, av + rN * K, att + rN * F, F, fp, q + rN * H, H, a->w_att,
                                                                  a->obj, act, nact, dq + rN * H, H, dfp, dwp + rN * H, dattS + rN * F, K, H, F);
-        {   // dh1 (through map_hidd) = dq W_hidd
+        {   // dh1 (through map_hidd) = dq W_hidd  [+ GRU1 gates on dh1 = carry + map_lang part + this]
             d3_gemm_prob p = td_prob(N, H, dh1q, H);
             p.nseg = 1; p.seg[0] = td_seg(dq + rN * H, H, a->W_hidd, H, H, nullptr, 0, 1);
+            if (fuse) gates_epi(p, dh1c, H, tmpL + F, F + H, g1, rN, h1p, dgi1 + rN * 3 * H, dgh1 + rN * 3 * H, dh1c);
             if ((rc = hg_launch(&p, 1, s))) return rc;
         }
-        td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dh1c, H, tmpL + F, F + H, dh1q, H, g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H,
-                                                   g1 + 3 * RH + rN * H, h1p, H, dgi1 + rN * 3 * H, 3 * H, dgh1 + rN * 3 * H, dh1c, N, H, nullptr, 0);
-        {   // dh1c += dgh1 Whh1 ; dh2c += dgi1 Wb ; dx1 = dgi1 Wih1 (off the chain)
+        if (!fuse)
+            td_gru_bwd_gates_kernel<<<nh, 256, 0, s>>>(dh1c, H, tmpL + F, F + H, dh1q, H, g1 + rN * H, g1 + RH + rN * H, g1 + 2 * RH + rN * H,
+                                                       g1 + 3 * RH + rN * H, h1p, H, dgi1 + rN * 3 * H, 3 * H, dgh1 + rN * 3 * H, dh1c, N, H, nullptr, 0);
+        {   // dh1c += dgh1 Whh1 ; dh2c += dgi1 Wb  [+ GRU2 gates of step t-1 on dh2 = classifier part + this carry] ; dx1 = dgi1 Wih1 (off the chain)
             d3_gemm_prob p[3];
             p[0] = td_prob(N, H, dh1c, H);
             p[0].nseg = 1; p[0].seg[0] = td_seg(dgh1 + rN * 3 * H, 3 * H, a->Whh1, H, 3 * H, nullptr, 0, 1); p[0].accum = 1;
             p[1] = td_prob(N, H, dh2c, H);
             p[1].nseg = 1; p[1].seg[0] = td_seg(dgi1 + rN * 3 * H, 3 * H, Wb, H, 3 * H, nullptr, 0, 1); p[1].accum = 1;
+            if (fuse && t > 0) {
+                const size_t rP = (size_t)(t - 1) * N;
+                gates_epi(p[1], dH2 + rP * H, H, nullptr, 0, g2, rP, H2 + rP * H, dgi2 + rP * 3 * H, dgh2 + rP * 3 * H, dh2c);
+            }
             p[2] = td_prob(N, E, dx1 + rN * E, E);
             p[2].nseg = 1; p[2].seg[0] = td_seg(dgi1 + rN * 3 * H, 3 * H, a->Wih1, E, 3 * H, nullptr, 0, 1);
             if ((rc = hg_launch(p, 3, s))) return rc;

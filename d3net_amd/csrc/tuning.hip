@@ -50,6 +50,9 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_CL_HOOK", 1},              // 0: the clustering's union-find starts from singletons (rounds 1-4) instead of one hook per node under a smaller-index neighbour
     {"D3_ACT_GRAD_BF16", 0},        // 1: gradients of BatchNorm->ReLU activations (one convolution reader) stored as bf16 (unet.hip Net::gabf): measured neutral, off
     {"D3_CL_SPEC", 1},              // 0: d3_bfs_cluster_run waits for the cluster counts before it enqueues the fill (count_ex + fill2); 1: the fill is enqueued behind the count kernels with its sizes read on the device, the host waits for the counts while the fill already runs
+    {"D3_TD_FUSE_GATES", 1},        // 0: the captioner's backward step keeps its two GRU gate kernels (rounds 2-4: 6 dependent launches per step) instead of running them as epilogues of the GEMMs that complete their input (4 launches)
+    {"D3_UNSAFE_NO_HAZARD_WAIT", 0}, // 1 (MEASUREMENT ONLY, results undefined): the executor's backward does not wait for the side stream's weight gradients before it accumulates into a gradient buffer they read -- prices those waits
+    {"D3_SIDE2", 2},                // 1: weight gradients whose dy buffer is later accumulated into in place (the caller's stream has to wait for them) run on a SECOND side stream: they no longer queue behind the other weight gradients; 2 (default): all weight gradients alternate between the two streams (speaker step 17.71 -> 17.49 ms in-process, mode 1: 17.57; detector step inside the noise: gpurun_out/r05_j17); 0: one side stream (rounds 1-4)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

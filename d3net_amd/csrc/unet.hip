@@ -660,6 +660,7 @@ struct Net {
     size_t jobs_cap = 0;
     long long pack_total = 0;
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;      // second weight-gradient stream (D3_SIDE2)
     std::vector<hipEvent_t> ev;       // pool
     size_t ev_used = 0;
     // gradient chunks (data-parallel overlap): chunk k of the flat parameter-gradient buffer is complete once the backward has
@@ -953,6 +954,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo);
         else
             hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
+        hipStreamCreateWithFlags(&n->side2, hipStreamNonBlocking);
     }
     return n;
 }
@@ -967,6 +969,7 @@ extern "C" void d3_net_destroy(void *h) {
     for (auto e : n->chunk_ev_side) hipEventDestroy(e);
     for (auto e : n->chunk_ev_main) hipEventDestroy(e);
     if (n->side) hipStreamDestroy(n->side);
+    if (n->side2) hipStreamDestroy(n->side2);
     delete n;
 }
 
@@ -1339,7 +1342,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
     auto wait_pending = [&](int root) {
         if (!use_side) return;
         auto it = pending.find(root);
-        if (it != pending.end()) { hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
+        if (it != pending.end()) { if (d3_tune(D3T_UNSAFE_NO_HAZARD_WAIT) == 0) hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
     };
     if (n->bcnt_bytes) D3_CHECK(hipMemsetAsync(garena + n->bcnt_off0, 0, n->bcnt_bytes, s));
     const bool use_p2 = d3_tune(D3T_BN_PART2) != 0;
@@ -1349,8 +1352,21 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
     // row-split partials -> dW in batched launches on the weight-gradient stream: one when only the last few convolutions of
     // the backward (the first of the network: level 0, small weights) are left, one at the very end -- a single launch at the
     // end left its 137 us exposed behind the stem's weight gradient, after the caller's stream had nothing left to do
+    const int side2_mode = (use_side && n->side2) ? d3_tune(D3T_SIDE2) : 0;
+    bool side2_dirty = false;                               // side2 holds weight gradients the batched reduction / the join has not been ordered behind yet
+    int side2_flip = 0;
+    auto join_side2 = [&]() -> int {                        // ws_stream waits for everything enqueued on side2
+        if (!side2_dirty) return 0;
+        hipEvent_t e = n->next_event();
+        if (!e) return D3_ERR_OVERFLOW;
+        D3_CHECK(hipEventRecord(e, n->side2));
+        D3_CHECK(hipStreamWaitEvent(ws_stream, e, 0));
+        side2_dirty = false;
+        return 0;
+    };
     auto flush_red = [&]() -> int {
         if (red.empty()) return 0;
+        { int jrc = join_side2(); if (jrc) return jrc; }
         if (main_wgrads && use_side) {
             hipEvent_t e = n->next_event();
             if (!e) return D3_ERR_OVERFLOW;
@@ -1383,6 +1399,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
     auto chunk_done = [&](int i) -> int {      // op i has been processed: close every chunk that ends here
         while (next_chunk < n->chunk_op.size() && n->chunk_op[next_chunk] >= i) {
             int frc = flush_red(); if (frc) return frc;
+            frc = join_side2(); if (frc) return frc;       // (weight gradients written straight to dW on the second side stream)
             D3_CHECK(hipEventRecord(n->chunk_ev_side[next_chunk], ws_stream));
             D3_CHECK(hipEventRecord(n->chunk_ev_main[next_chunk], s));
             next_chunk++;
@@ -1448,8 +1465,10 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             // data gradient, so the side stream loses nothing
             if (pgrads[o.w] != nullptr) {
                 if (!op_side) main_wgrads = true;
+                hipStream_t wst = ws_stream;                 // the stream of THIS weight gradient
                 if (op_side) {
-                    D3_CHECK(hipStreamWaitEvent(n->side, e1, 0));
+                    if (side2_mode == 2 ? (side2_flip++ & 1) : (side2_mode == 1 && root_o >= 0 && o.wg_hazard)) { wst = n->side2; side2_dirty = true; }
+                    D3_CHECK(hipStreamWaitEvent(wst, e1, 0));
                     side_used = true;
                 }
                 const bool xstat = o.Cin > o.Cout;
@@ -1462,7 +1481,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
                     d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
-                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? ws_stream : s));
+                                          flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? wst : s));
                 if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)
                     RedJob j;
                     memset(&j, 0, sizeof(j));
@@ -1475,7 +1494,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 if (op_side && root_o >= 0 && o.wg_hazard) {
                     hipEvent_t e2 = n->next_event();
                     if (!e2) return D3_ERR_OVERFLOW;
-                    D3_CHECK(hipEventRecord(e2, n->side));
+                    D3_CHECK(hipEventRecord(e2, wst));
                     pending[root_o] = e2;
                 }
             }
@@ -1539,6 +1558,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
     }
     { int frc = flush_red(); if (frc) return frc; }
     { int crc = chunk_done(0); if (crc) return crc; }
+    { int jrc = join_side2(); if (jrc) return jrc; }
     // join: the caller's stream waits for the last weight gradient
     if (side_used) {
         hipEvent_t e = n->next_event();

@@ -511,6 +511,17 @@ typedef struct {
     float *C; long long ldc;
     const float *bias; const float *add; long long ldadd;
     int relu, accum, perm_nb, perm_s;
+    /* Optional epilogue, gru != 0 (round 5; N == gru_H, decode-step problems M <= 32 and the K-split kernels only): the finished
+     * element v (after bias / add / accumulate) is the last contribution to dh', the gradient of a GRUCell's NEW state, and the
+     * cell's gate backward (torch.nn.GRUCell's autograd as model/caption_module.py:72-133 uses it) runs on it in place of a
+     * launch of its own:   dh' = g_d0 + g_d1 + v  (NULL = absent);  dn = dh'(1-z), dz = dh'(hp-n), dn_pre = dn(1-n^2),
+     *   g_dgi[row] = [dn_pre ghn r(1-r), dz z(1-z), dn_pre],  g_dgh[row] = [same, same, dn_pre r],  g_dhp = dh' z.
+     * r / z / n / ghn: the cell's saved gates (M, gru_H); hp: its previous state (row stride g_ldh).  C is read (accumulate) but NOT
+     * written in this mode: the carried gradient goes to g_dhp, which may alias C. */
+    int gru, gru_H;
+    const float *g_d0; long long g_ld0; const float *g_d1; long long g_ld1;
+    const float *g_r, *g_z, *g_n, *g_ghn, *g_hp; long long g_ldh;
+    float *g_dgi; long long g_lddgi; float *g_dgh; float *g_dhp;
 } d3_gemm_prob;
 int d3_hgemm(const d3_gemm_prob *probs, int nprobs, void *stream);
 /* out[c] (+)= sum_r x[r*ld + c], r < R, c < C (bias gradients; two-stage, fixed summation order); ws >= d3_colsum_ws_bytes(C) */

@@ -121,6 +121,61 @@ def test_kmajor_operands_and_batched_problems(dev):
     _close(out, a.double() @ Bm.double().t(), V)
 
 
+@pytest.mark.parametrize("M,K,accum", [(32, 512, False), (32, 1536, True), (13, 1536, True)])
+def test_gru_gate_backward_epilogue(dev, M, K, accum):
+    """d3_gemm_prob.gru: the GRUCell gate backward on the finished element (the captioner's backward step: model/caption_module.py:72-133
+    through torch.nn.GRUCell's autograd) against the same arithmetic in fp64 -- beside a plain problem in the same launch; the
+    carried gradient goes to g_dhp (aliasing C when the problem accumulates), C itself is not written."""
+    g = torch.Generator().manual_seed(M * 7 + K)
+    H = 512
+    r = lambda *sh: torch.randn(*sh, generator=g)
+    A, W = r(M, K), r(K, H) / np.sqrt(K)              # dy W with W k-major (the data-gradient form)
+    d0, d1full = r(M, H), r(M, 128 + H)
+    rr, zz, nn_, ghn, hp = torch.sigmoid(r(M, H)), torch.sigmoid(r(M, H)), torch.tanh(r(M, H)), r(M, H), r(M, H)
+    carry = r(M, H)
+    D = lambda t: t.to(dev).contiguous()
+    Ad, Wd, d0d, d1d, rd, zd, nd, gd, hpd = map(D, (A, W, d0, d1full, rr, zz, nn_, ghn, hp))
+    Cbuf = D(carry) if accum else torch.full((M, H), float("nan"), device=dev)
+    dgi = torch.full((M, 3 * H), float("nan"), device=dev)
+    dgh = torch.full((M, 3 * H), float("nan"), device=dev)
+    dhp = Cbuf if accum else torch.full((M, H), float("nan"), device=dev)
+    p = _prob([_seg(Ad, Wd, K, b_km=True)], M, H, Cbuf, accum=accum)
+    p.gru, p.gru_H = 1, H
+    p.g_d0, p.g_ld0 = d0d.data_ptr(), H
+    p.g_d1, p.g_ld1 = d1d[:, 128:].data_ptr(), 128 + H
+    p.g_r, p.g_z, p.g_n, p.g_ghn = rd.data_ptr(), zd.data_ptr(), nd.data_ptr(), gd.data_ptr()
+    p.g_hp, p.g_ldh = hpd.data_ptr(), H
+    p.g_dgi, p.g_lddgi, p.g_dgh, p.g_dhp = dgi.data_ptr(), 3 * H, dgh.data_ptr(), dhp.data_ptr()
+    # a plain problem in the same launch (the step's other GEMMs share it)
+    x2, W2 = r(M, 300), r(512, 300) / 17
+    x2d, W2d = D(x2), D(W2)
+    out2 = torch.full((M, 512), float("nan"), device=dev)
+    _run([_prob([_seg(x2d, W2d, 300)], M, 512, out2), p])
+    _close(out2, x2.double() @ W2.double().t(), 300)
+    v = A.double() @ W.double() + (carry.double() if accum else 0)
+    dh = d0.double() + d1full[:, 128:].double() + v
+    R, Z, Nn = rr.double(), zz.double(), nn_.double()
+    dn, dz = dh * (1 - Z), dh * (hp.double() - Nn)
+    dnp = dn * (1 - Nn * Nn)
+    drp, dzp = dnp * ghn.double() * R * (1 - R), dz * Z * (1 - Z)
+    _close(dgi, torch.cat([drp, dzp, dnp], 1), K)
+    _close(dgh, torch.cat([drp, dzp, dnp * R], 1), K)
+    _close(dhp, dh * Z, K)
+    if not accum:
+        assert bool(torch.isnan(Cbuf).all())       # C is not written in this mode
+
+
+def test_gru_gate_epilogue_is_refused_outside_the_decode_step_kernels(dev):
+    x, W = torch.randn(64, 64, device=dev), torch.randn(512, 64, device=dev)
+    out = torch.zeros(64, 512, device=dev)
+    from d3net_amd import _lib
+    from d3net_amd._lib import GemmProb
+    p = _prob([_seg(x, W, 64)], 64, 512, out)
+    p.gru, p.gru_H = 1, 512
+    arr = (GemmProb * 1)(p)
+    assert _lib.lib().d3_hgemm(arr, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 12288), (128, 128, 8195), (256, 128, 8192), (64, 30, 16382)])
 def test_deep_reduction_cut_over_workgroups(dev, M, N, K):
     """dW = dy^T x of the listener's projections (model/match_module.py:31-47 backward: K = proposals x batch): the reduction

@@ -92,8 +92,11 @@ def test_graph_module_vs_oracle(dev):
     assert int(ref["num_edge_source"][0]) == 37 and int(ref["num_edge_target"][0]) == G.L
 
 
-def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev):
-    """csrc/topdown.hip (one native call for the S-step teacher-forced pass, one for its backward) against the same module
+@pytest.mark.parametrize("fuse_gates", [1, 0])
+def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev, fuse_gates):
+    """(fuse_gates: the backward step's GRU gate kernels as epilogues of the GEMMs that complete their input -- D3_TD_FUSE_GATES, the
+    default -- or as launches of their own, rounds 2-4)
+    csrc/topdown.hip (one native call for the S-step teacher-forced pass, one for its backward) against the same module
     run step by step through library ops, at the shape of conf/pointgroup_captioning.yaml: batch 4 x 8 descriptions,
     K = 128 proposals, V = 3004, up to 31 steps.  fp32 both ways: logits / attention 1e-4, every parameter gradient and
     the gradients w.r.t. the object and target features 2e-3 of their scale (summation order over 31 steps)."""
@@ -137,14 +140,18 @@ def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev):
     ref_dobj, ref_dtgt = obj.grad.clone(), tgt.grad.clone()
     cap.zero_grad(); obj.grad = None; tgt.grad = None
     # native
+    assert _lib.lib().d3_tuning_set(b"D3_TD_FUSE_GATES", fuse_gates) == 0
     sd = dict(cap.named_parameters())
     logits, attn = TopDownXEFunction.apply(cap.embeddings, words, masks, Ssteps, obj, tgt, *[sd[_TD_KEYS[k]] for k in _lib.TOPDOWN_PARAMS])
     assert logits.shape == (N, Ssteps, V) and attn.shape == (N, K, Ssteps)
     scale = float(ref_logits.abs().max())
     assert float((logits - ref_logits).abs().max()) < 1e-4 * scale, float((logits - ref_logits).abs().max())
     assert float((attn - ref_attn).abs().max()) < 1e-5
-    loss_of(logits).backward()
-    torch.cuda.synchronize()
+    try:
+        loss_of(logits).backward()
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().d3_tuning_set(b"D3_TD_FUSE_GATES", 1)
     for k, p in cap.named_parameters():
         err = float((p.grad - ref[k]).abs().max()) / (float(ref[k].abs().max()) + 1e-12)
         assert err < 2e-3, (k, err)
