@@ -123,6 +123,7 @@ SIGNATURES = {
     "d3_topdown_bwd_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "d3_topdown_xe_forward": (i32, [vp, vp]),
     "d3_topdown_xe_backward": (i32, [vp, vp, vp]),
+    "d3_topdown_xe_backward_ex": (i32, [vp, vp, vp, vp]),
     "d3_topdown_step_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "d3_topdown_feat_proj": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "d3_topdown_step": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

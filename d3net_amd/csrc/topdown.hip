@@ -750,12 +750,30 @@ extern "C" size_t d3_topdown_bwd_ws_bytes(int N, int K, int S, int V, int H, int
 }
 
 // dlogits (N,S,V) -> every parameter gradient (written), dobj (N,K,F) and dtarget (N,F) (written).
+// side (optional, round 5): a second stream for everything that only feeds PARAMETER gradients (the weight-gradient GEMMs batched over
+// time, the bias column sums, the classifier's two weight gradients: ~0.3 ms of throughput-bound launches) -- the caller's stream
+// then carries just the chain the rest of the backward waits for (dc0, dH2, the S-step recurrence, dobj / dtarget).  The function
+// forks `side` off the caller's stream itself (events); JOINING is the caller's job: `side` must be waited for before anything reads
+// a parameter gradient, and every buffer of `a` / `gd` must stay alive until then.
+extern "C" int d3_topdown_xe_backward_ex(const d3_topdown_args *a, const d3_topdown_grads *gd, void *stream, void *side);
 extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown_grads *gd, void *stream) {
+    return d3_topdown_xe_backward_ex(a, gd, stream, nullptr);
+}
+extern "C" int d3_topdown_xe_backward_ex(const d3_topdown_args *a, const d3_topdown_grads *gd, void *stream, void *side) {
     D3_CLEAR();
     int rc = td_check(a);
     if (rc) return rc;
     if (!gd || !gd->dlogits || !gd->ws) return D3_ERR_ARG;
     hipStream_t s = d3_stream(stream);
+    hipStream_t sp = side ? (hipStream_t)side : s;          // the stream of the parameter-gradient work
+    static thread_local hipEvent_t fork_ev[2] = {nullptr, nullptr};
+    auto fork = [&](int k) -> int {                          // sp continues behind everything enqueued on s so far
+        if (sp == s) return 0;
+        if (!fork_ev[k]) D3_CHECK(hipEventCreateWithFlags(&fork_ev[k], hipEventDisableTiming));
+        D3_CHECK(hipEventRecord(fork_ev[k], s));
+        D3_CHECK(hipStreamWaitEvent(sp, fork_ev[k], 0));
+        return 0;
+    };
     const int N = a->N, K = a->K, S = a->S, V = a->V, H = a->H, E = a->E, F = a->F, R = S * N;
     const TdLayout L = td_layout(N, K, S, H, E, F);
     const TdBwdLayout B = td_bwd_layout(N, K, S, V, H, E, F);
@@ -782,10 +800,11 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         if ((rc = hg_launch(&p, 1, s))) return rc;
         td_relu_mask_kernel<<<(int)((RH + 255) / 256), 256, 0, s>>>(dc0, c0, (long long)RH);
     }
+    if ((rc = fork(0))) return rc;
     {
         // time-major copy of dlogits for the k-major weight gradient (both operands must walk the rows in the same order)
         const long long tot = (long long)R * V;
-        td_gather_rows_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(gd->dlogits, bidx, dlog, R, V);
+        td_gather_rows_kernel<<<(int)((tot + 255) / 256), 256, 0, sp>>>(gd->dlogits, bidx, dlog, R, V);
         d3_gemm_prob p[3];
         p[0] = td_prob(V, H, gd->dWc2, H);
         p[0].nseg = 1; p[0].seg[0] = td_seg(dlog, V, c0, H, R, nullptr, 1, 1);
@@ -793,12 +812,12 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         p[1].nseg = 1; p[1].seg[0] = td_seg(dc0, H, H2 + (size_t)N * H, H, R, nullptr, 1, 1);
         p[2] = td_prob(R, H, dH2, H);
         p[2].nseg = 1; p[2].seg[0] = td_seg(dc0, H, a->Wc0, H, H, nullptr, 0, 1);
-        if ((rc = hg_launch(&p[0], 1, s))) return rc;
-        if ((rc = hg_launch(&p[1], 1, s))) return rc;
-        if ((rc = hg_launch(&p[2], 1, s))) return rc;
+        if ((rc = hg_launch(&p[2], 1, s))) return rc;          // (the recurrence waits for dH2: first, on the caller's stream)
+        if ((rc = hg_launch(&p[0], 1, sp))) return rc;
+        if ((rc = hg_launch(&p[1], 1, sp))) return rc;
         const float *cx[2] = {dlog, dc0}; const long long cl[2] = {V, H}; const int cr[2] = {R, R}, cc[2] = {V, H};
         float *co[2] = {gd->dbc2, gd->dbc0};
-        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 2, bw + B.cs, B.cs_bytes, s))) return rc;
+        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 2, bw + B.cs, B.cs_bytes, sp))) return rc;
     }
     D3_CHECK(hipMemsetAsync(dh1c, 0, (size_t)N * H * 4, s));
     D3_CHECK(hipMemsetAsync(dh2c, 0, (size_t)N * H * 4, s));
@@ -864,7 +883,21 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
             if ((rc = hg_launch(p, 3, s))) return rc;
         }
     }
-    // ---- weight gradients, batched over time (k-major operands, K = R rows)
+    // ---- what the rest of the backward waits for, on the caller's stream: dtarget and dobj
+    td_sum_time_kernel<<<(N * E + 255) / 256, 256, 0, s>>>(dx1, dx1s, S, N, E);      // (sum_t dx1[t]: the target feature is constant in t)
+    if ((rc = fork(1))) return rc;
+    {
+        d3_gemm_prob p = td_prob(N, F, gd->dtarget, F);       // dtarget = dx1s W_td[:, E+H:]
+        p.nseg = 1; p.seg[0] = td_seg(dx1s, E, a->W_td + E + H, ldtd, E, nullptr, 0, 1);
+        if ((rc = hg_launch(&p, 1, s))) return rc;
+        // dobj = sum_t a_t (x) datt_t (the attention's weighted sum), then += dfp W_feat (through map_feat)
+        const int SC = S < 32 ? S : 32;
+        td_dobj_kernel<<<dim3(N, K >= 64 ? 8 : 1), 256, (size_t)SC * (K + F) * 4, s>>>(av, dattS, gd->dobj, S, N, K, F, SC);
+        d3_gemm_prob po = td_prob(N * K, F, gd->dobj, F);
+        po.nseg = 1; po.seg[0] = td_seg(dfp, H, a->W_feat, F, H, nullptr, 0, 1); po.accum = 1;
+        if ((rc = hg_launch(&po, 1, s))) return rc;
+    }
+    // ---- weight gradients, batched over time (k-major operands, K = R rows): the parameter-gradient stream
     {
         d3_gemm_prob p[4];
         // GRU cells
@@ -872,13 +905,13 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         p[1] = td_prob(3 * H, H, gd->dWhh2, H); p[1].nseg = 1; p[1].seg[0] = td_seg(dgh2, 3 * H, H2, H, R, nullptr, 1, 1);
         p[2] = td_prob(3 * H, E, gd->dWih1, E); p[2].nseg = 1; p[2].seg[0] = td_seg(dgi1, 3 * H, x1, E, R, nullptr, 1, 1);
         p[3] = td_prob(3 * H, H, gd->dWhh1, H); p[3].nseg = 1; p[3].seg[0] = td_seg(dgh1, 3 * H, H1, H, R, nullptr, 1, 1);
-        if ((rc = hg_launch(p, 4, s))) return rc;
+        if ((rc = hg_launch(p, 4, sp))) return rc;
         // all remaining bias gradients (and the attention vector's) in one two-stage column sum
         const float *cx[7] = {dgi2, dgh2, dgi1, dgh1, dx2, dx1, dwp};
         const long long cl[7] = {3 * H, 3 * H, 3 * H, 3 * H, E, E, H};
         const int cr[7] = {R, R, R, R, R, R, R}, cc[7] = {3 * H, 3 * H, 3 * H, 3 * H, E, E, H};
         float *co[7] = {gd->dbih2, gd->dbhh2, gd->dbih1, gd->dbhh1, gd->db_lang, gd->db_td, gd->dw_att};
-        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 7, bw + B.cs, B.cs_bytes, s))) return rc;
+        if ((rc = hg_colsum_multi(cx, cl, cr, cc, co, nullptr, 7, bw + B.cs, B.cs_bytes, sp))) return rc;
     }
     {
         // map_lang: dW (E, F+H) = dx2^T [att | h1[1:]] ; map_hidd: dW = dq^T h1[1:] ; map_topdown: dW (E, E+H+F) = dx1^T [emb[w] | h2[:-1] | target]
@@ -887,36 +920,26 @@ extern "C" int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown
         p[1] = td_prob(E, H, gd->dW_lang + F, ldlang); p[1].nseg = 1; p[1].seg[0] = td_seg(dx2, E, H1 + (size_t)N * H, H, R, nullptr, 1, 1);
         p[2] = td_prob(H, H, gd->dW_hidd, H); p[2].nseg = 1; p[2].seg[0] = td_seg(dq, H, H1 + (size_t)N * H, H, R, nullptr, 1, 1);
         p[3] = td_prob(E, H, gd->dW_td + E, ldtd); p[3].nseg = 1; p[3].seg[0] = td_seg(dx1, E, H2, H, R, nullptr, 1, 1);
-        if ((rc = hg_launch(p, 4, s))) return rc;
+        if ((rc = hg_launch(p, 4, sp))) return rc;
     }
     {
-        // embedding / target parts of map_topdown need gathered k-major rows: materialise the two gathered matrices once
-        // (R x E and the time-sum trick for the target: sum_t dx1[t] is enough because the target feature is constant in t)
-        td_sum_time_kernel<<<(N * E + 255) / 256, 256, 0, s>>>(dx1, dx1s, S, N, E);
-        d3_gemm_prob p[3];
+        d3_gemm_prob p[2];
         // dW_td[:, E+H:] = dx1s^T target  (K = N rows)
         p[0] = td_prob(E, F, gd->dW_td + E + H, ldtd); p[0].nseg = 1; p[0].seg[0] = td_seg(dx1s, E, a->target, F, N, nullptr, 1, 1);
-        // dtarget = dx1s W_td[:, E+H:]
-        p[1] = td_prob(N, F, gd->dtarget, F); p[1].nseg = 1; p[1].seg[0] = td_seg(dx1s, E, a->W_td + E + H, ldtd, E, nullptr, 0, 1);
         // map_feat: dW_feat (H, F) = dfp^T obj (K = N*K rows)
-        p[2] = td_prob(H, F, gd->dW_feat, F); p[2].nseg = 1; p[2].seg[0] = td_seg(dfp, H, a->obj, F, N * K, nullptr, 1, 1);
-        if ((rc = hg_launch(p, 3, s))) return rc;
-        // dobj = sum_t a_t (x) datt_t (the attention's weighted sum), then += dfp W_feat (through map_feat)
-        const int SC = S < 32 ? S : 32;
-        td_dobj_kernel<<<dim3(N, K >= 64 ? 8 : 1), 256, (size_t)SC * (K + F) * 4, s>>>(av, dattS, gd->dobj, S, N, K, F, SC);
-        d3_gemm_prob po = td_prob(N * K, F, gd->dobj, F);
-        po.nseg = 1; po.seg[0] = td_seg(dfp, H, a->W_feat, F, H, nullptr, 0, 1); po.accum = 1;
-        if ((rc = hg_launch(&po, 1, s))) return rc;
+        p[1] = td_prob(H, F, gd->dW_feat, F); p[1].nseg = 1; p[1].seg[0] = td_seg(dfp, H, a->obj, F, N * K, nullptr, 1, 1);
+        if ((rc = hg_launch(p, 2, sp))) return rc;
     }
     {
         // dW_td[:, :E] = dx1^T emb[words]: k-major B with gathered rows is not a GEMM operand form; the embedding rows of the
-        // R tokens are gathered into x-space first (R x E floats, reusing the dlog buffer which is dead by now)
+        // R tokens are gathered into x-space first (R x E floats, reusing the dlog buffer which is dead by now: its readers ran on
+        // this same stream)
         float *embg = dlog;
         const long long tot = (long long)R * E;
-        td_gather_rows_kernel<<<(int)((tot + 255) / 256), 256, 0, s>>>(a->emb, widx, embg, R, E);
+        td_gather_rows_kernel<<<(int)((tot + 255) / 256), 256, 0, sp>>>(a->emb, widx, embg, R, E);
         d3_gemm_prob p = td_prob(E, E, gd->dW_td, ldtd);
         p.nseg = 1; p.seg[0] = td_seg(dx1, E, embg, E, R, nullptr, 1, 1);
-        if ((rc = hg_launch(&p, 1, s))) return rc;
+        if ((rc = hg_launch(&p, 1, sp))) return rc;
     }
     D3_LAUNCH_CHECK();
     return 0;

@@ -121,6 +121,7 @@ class InputPrefetcher:
         return cur
 
 
+EARLY_POINT_GRADS = 1   # (A/B switch of tools/ab.py; the per-model switch is PointGroup.early_point_grads)
 PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
 
 
@@ -129,6 +130,23 @@ def _mark(name):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         PHASES.append((name, ev))
+
+
+class _PointLossGraft(torch.autograd.Function):
+    """The weighted point-level loss with its gradient ALREADY computed (PointGroup._early_point_losses): forward hands out the value,
+    backward scales the stored gradients by the incoming one.  inputs: (point features, value, n stored gradients, n tensors they
+    belong to: the point features first, then the two heads' parameters)."""
+
+    @staticmethod
+    def forward(ctx, value, n, *rest):
+        ctx.n = n
+        ctx.save_for_backward(*rest[:n])
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        grads = ctx.saved_tensors
+        return (None, None) + (None,) * ctx.n + tuple(g * go for g in grads)
 
 
 class PointGroup(nn.Module):
@@ -197,6 +215,10 @@ class PointGroup(nn.Module):
         self.__dict__["_pf_live"] = [None, None]
         self.__dict__["_pf_inflight"] = None
         self.prefetch_at = "bfs"
+        # the semantic / offset losses' BACKWARD (both point heads down to the gradient of the backbone's point features) runs inside
+        # forward() as well, right behind the losses themselves: in the clustering stage the chip is mostly idle, in the backward these
+        # ~15 launches sit on the critical path between ScoreNet's and the backbone's backward (0.35 ms of the 4-scene step)
+        self.early_point_grads = True
 
     def _side_stream(self, device):
         key = (device.index, threading.get_ident())
@@ -518,6 +540,7 @@ class PointGroup(nn.Module):
         semantic_scores, semantic_preds, pt_offsets = heads.point_heads(self.sem_seg, self.offset_net, pt_feats)
         data_dict["semantic_scores"] = semantic_scores
         data_dict["pt_offsets"] = pt_offsets
+        data_dict["_pt_feats"] = pt_feats
 
         _mark("heads")
         if data_dict["epoch"] > self.prepare_epochs or self.freeze_backbone:
@@ -693,7 +716,21 @@ class PointGroup(nn.Module):
             return
         args = (data_dict["semantic_scores"], data_dict["sem_labels"], data_dict["pt_offsets"], data_dict["locs"],
                 data_dict["instance_info"], data_dict["instance_ids"])
-        data_dict["_point_losses"] = (args, self._point_losses(*args))
+        losses = self._point_losses(*args)
+        graft = None
+        pf = data_dict.pop("_pt_feats", None)
+        if EARLY_POINT_GRADS and self.early_point_grads and pf is not None and all(torch.is_tensor(l) and l.requires_grad for l in losses[:3]):
+            # d(w0 sem + w1 norm + w2 dir) / d(point features, head parameters) NOW; loss() then builds the total loss on a graft that
+            # carries these gradients (scaled by whatever arrives in the backward) -- same arithmetic, earlier in the step
+            w = self.cfg.train.loss_weight
+            value = w[0] * losses[0] + w[1] * losses[1] + w[2] * losses[2]
+            wrt = [t for t in [pf] + list(self.sem_seg.parameters()) + list(self.offset_net.parameters()) if t.requires_grad]
+            grads = torch.autograd.grad(value, wrt, allow_unused=True)
+            keep = [(t, g) for t, g in zip(wrt, grads) if g is not None]
+            if keep:
+                graft = _PointLossGraft.apply(value.detach(), len(keep), *[g for _, g in keep], *[t for t, _ in keep])
+                losses = tuple(l.detach() for l in losses[:3]) + tuple(losses[3:])
+        data_dict["_point_losses"] = (args, losses, graft)
 
     def loss(self, data_dict, epoch):
         """semantic CE + offset L1 / direction + soft-IoU score BCE (reference :387-463)."""
@@ -701,16 +738,21 @@ class PointGroup(nn.Module):
         pt_offsets, coords, instance_info, instance_ids = data_dict["pt_offsets"]
         args = (semantic_scores, semantic_labels, pt_offsets, coords, instance_info, instance_ids)
         early = data_dict.pop("_point_losses", None)
+        graft = None
         if early is not None and len(early[0]) == len(args) and all(a is b for a, b in zip(early[0], args)):
             semantic_loss, offset_norm_loss, offset_dir_loss, n_valid = early[1]
+            graft = early[2] if len(early) > 2 else None
         else:
+            if early is not None and len(early) > 2 and early[2] is not None:
+                raise RuntimeError("PointGroup.loss: the point losses were computed (and back-propagated) inside forward() for other tensors "
+                                   "than the ones passed to loss(); set early_point_grads = False to recompute them here")
             semantic_loss, offset_norm_loss, offset_dir_loss, n_valid = self._point_losses(*args)
         data_dict["semantic_loss"] = (semantic_loss, semantic_scores.shape[0])
         data_dict["offset_norm_loss"] = (offset_norm_loss, n_valid)
         data_dict["offset_dir_loss"] = (offset_dir_loss, n_valid)
 
         w = self.cfg.train.loss_weight
-        loss = w[0] * semantic_loss + w[1] * offset_norm_loss + w[2] * offset_dir_loss
+        loss = graft if graft is not None else w[0] * semantic_loss + w[1] * offset_norm_loss + w[2] * offset_dir_loss
         if epoch > self.cfg.cluster.prepare_epochs:
             scores, proposals_idx, proposals_offset, instance_pointnum = data_dict["proposal_scores"]
             if scores.shape[0] > 0:

@@ -335,9 +335,48 @@ class TopDownXEFunction(torch.autograd.Function):
         dobj, dtarget = torch.empty_like(obj_feats), torch.empty_like(target_feats)
         ws2 = torch.empty(L.d3_topdown_bwd_ws_bytes(a.N, a.K, a.S, a.V, a.H, a.E, a.F), dtype=torch.uint8, device=dev)
         g.dobj, g.dtarget, g.ws, g.ws_bytes = dobj.data_ptr(), dtarget.data_ptr(), ws2.data_ptr(), ws2.numel()
+        side = _param_grad_stream(dev, params)
+        if side is None:
+            with _on(dev):
+                check(L.d3_topdown_xe_backward(C.byref(a), C.byref(g), _stream()), "topdown_xe_backward")
+            return (None, None, None, None, dobj, dtarget) + tuple(grads)
+        # Parameter-gradient work on a second stream (csrc/topdown.hip: d3_topdown_xe_backward_ex): the caller's stream goes on with
+        # the relation graph's / ScoreNet's / the backbone's backward as soon as dobj / dtarget are enqueued.  The join -- and the
+        # release of every buffer the side stream reads -- happens when the autograd engine finishes this backward pass.
+        main = torch.cuda.current_stream(dev)
         with _on(dev):
-            check(L.d3_topdown_xe_backward(C.byref(a), C.byref(g), _stream()), "topdown_xe_backward")
+            check(L.d3_topdown_xe_backward_ex(C.byref(a), C.byref(g), C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream)),
+                  "topdown_xe_backward_ex")
+        done = torch.cuda.Event()
+        done.record(side)
+        # (NOT the gradient tensors: autograd's AccumulateGrad adopts a gradient only while nobody else holds it and would otherwise
+        # copy it on the caller's stream at once -- before the side stream has written it; adopted, p.grad keeps it alive)
+        keep = [ctx.keep, dlogits, ws2, a, g]
+
+        def join():
+            main.wait_event(done)
+            keep.clear()
+        torch.autograd.Variable._execution_engine.queue_callback(join)
         return (None, None, None, None, dobj, dtarget) + tuple(grads)
+
+
+PARAM_GRAD_STREAM = 0     # 1: the captioner's parameter-gradient GEMMs on a second stream (d3_topdown_xe_backward_ex; measured neutral on the 4-scene step -- 17.18 vs 17.21 ms, gpurun_out/r05_j19: the caller's stream is host-bound behind the captioner -- so off)
+_PG_STREAMS = {}
+
+
+def _param_grad_stream(dev, params):
+    """the side stream of TopDownXEFunction.backward, or None when the overlap is not safe: a parameter that already holds a gradient
+    (accumulation reads the new one at once, on the caller's stream) or a data-parallel job (the heads' gradient bucket is all-reduced
+    from inside the backward: distributed.BucketGradAllReduce.boundary)"""
+    if not PARAM_GRAD_STREAM or any(p.grad is not None for p in params):
+        return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None
+    key = dev.index
+    if key not in _PG_STREAMS:
+        _PG_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _PG_STREAMS[key]
 
 
 class _BeamResult(list):

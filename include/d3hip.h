@@ -564,6 +564,10 @@ size_t d3_topdown_ws_bytes(int N, int K, int S, int H, int E, int F);
 size_t d3_topdown_bwd_ws_bytes(int N, int K, int S, int V, int H, int E, int F);
 int d3_topdown_xe_forward(const d3_topdown_args *a, void *stream);
 int d3_topdown_xe_backward(const d3_topdown_args *a, const d3_topdown_grads *g, void *stream);
+/* the same with the parameter-gradient work (weight-gradient GEMMs batched over time, bias column sums: nothing the rest of the
+ * backward waits for) on a second stream `side` (NULL: everything on `stream`).  The call forks `side` off `stream`; the caller joins:
+ * `side` must be waited for before a parameter gradient is read, and every buffer of `a` / `g` must stay alive until then. */
+int d3_topdown_xe_backward_ex(const d3_topdown_args *a, const d3_topdown_grads *g, void *stream, void *side);
 /* One decode step for the greedy / evaluation decodes (model/caption_module.py:350-383, 689-770), inference only: uses N, K,
  * V, H, E, F, emb, target, obj, mask and the parameters of `a`.  word (N) int64 -> logits (N,V), attn (N,K); hidden states
  * h1_in / h2_in (N,H) -> h1_out / h2_out (distinct buffers).  fp = map_feat(obj) from d3_topdown_feat_proj (rows = number of
