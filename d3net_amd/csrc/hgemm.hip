@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void hg_gemm_tiled3_kernel(const HgBatch batch
 
 static int hg_check(const d3_gemm_prob &p) {
     if (p.nseg < 1 || p.nseg > 3 || p.M < 0 || p.N < 1 || !p.C) return D3_ERR_ARG;
-    if (p.gru && (p.M > 32 || p.N != p.gru_H || p.perm_nb > 0 || p.relu || !p.g_r || !p.g_z || !p.g_n || !p.g_ghn || !p.g_hp || !p.g_dgi ||
+    if (p.gru && (p.N != p.gru_H || p.perm_nb > 0 || p.relu || !p.g_r || !p.g_z || !p.g_n || !p.g_ghn || !p.g_hp || !p.g_dgi ||
                   !p.g_dgh || !p.g_dhp)) return D3_ERR_ARG;      // (the gate epilogue lives in the decode-step kernels only)
     for (int s = 0; s < p.nseg; s++)
         if (!p.seg[s].A || !p.seg[s].B || p.seg[s].K < 1) return D3_ERR_ARG;
@@ -545,8 +545,8 @@ static int hg_launch_batch(const d3_gemm_prob *probs, int nprobs, hipStream_t s)
     }
     for (int i = nprobs; i < HG_MAXP; i++) b.p[i] = probs[0];
     if (maxM == 0) return 0;
-    for (int i = 0; i < nprobs; i++)
-        if (probs[i].gru && maxM > 32) return D3_ERR_ARG;      // (a gate epilogue batched with a tall problem: the tiled kernels do not carry it)
+    for (int i = 0; i < nprobs; i++)      // (the 64 x 64 tiled kernels do not carry the gate epilogue: only hg_gemm_kernel's variants do)
+        if (probs[i].gru && maxM > 32 && (long long)((maxN + 15) / 16) * ((maxM + 15) / 16) >= 2048) return D3_ERR_ARG;
     const int ctiles = (maxN + 15) / 16;
     int kblocks = 0;             // deepest reduction of the batch, in 16-wide k blocks
     for (int i = 0; i < nprobs; i++) {

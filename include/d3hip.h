@@ -511,7 +511,7 @@ typedef struct {
     float *C; long long ldc;
     const float *bias; const float *add; long long ldadd;
     int relu, accum, perm_nb, perm_s;
-    /* Optional epilogue, gru != 0 (round 5; N == gru_H, decode-step problems M <= 32 and the K-split kernels only): the finished
+    /* Optional epilogue, gru != 0 (round 5; N == gru_H; the wave-per-tile / K-split kernels only: fewer than 2048 16 x 16 output tiles): the finished
      * element v (after bias / add / accumulate) is the last contribution to dh', the gradient of a GRUCell's NEW state, and the
      * cell's gate backward (torch.nn.GRUCell's autograd as model/caption_module.py:72-133 uses it) runs on it in place of a
      * launch of its own:   dh' = g_d0 + g_d1 + v  (NULL = absent);  dn = dh'(1-z), dz = dh'(hp-n), dn_pre = dn(1-n^2),

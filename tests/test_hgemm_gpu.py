@@ -121,7 +121,7 @@ def test_kmajor_operands_and_batched_problems(dev):
     _close(out, a.double() @ Bm.double().t(), V)
 
 
-@pytest.mark.parametrize("M,K,accum", [(32, 512, False), (32, 1536, True), (13, 1536, True)])
+@pytest.mark.parametrize("M,K,accum", [(32, 512, False), (32, 1536, True), (13, 1536, True), (64, 1536, True), (100, 512, False)])
 def test_gru_gate_backward_epilogue(dev, M, K, accum):
     """d3_gemm_prob.gru: the GRUCell gate backward on the finished element (the captioner's backward step: model/caption_module.py:72-133
     through torch.nn.GRUCell's autograd) against the same arithmetic in fp64 -- beside a plain problem in the same launch; the
@@ -166,11 +166,11 @@ def test_gru_gate_backward_epilogue(dev, M, K, accum):
 
 
 def test_gru_gate_epilogue_is_refused_outside_the_decode_step_kernels(dev):
-    x, W = torch.randn(64, 64, device=dev), torch.randn(512, 64, device=dev)
-    out = torch.zeros(64, 512, device=dev)
+    x, W = torch.randn(1024, 64, device=dev), torch.randn(512, 64, device=dev)      # 64 x 32 = 2048 output tiles: the tiled kernel's class
+    out = torch.zeros(1024, 512, device=dev)
     from d3net_amd import _lib
     from d3net_amd._lib import GemmProb
-    p = _prob([_seg(x, W, 64)], 64, 512, out)
+    p = _prob([_seg(x, W, 64)], 1024, 512, out)
     p.gru, p.gru_H = 1, 512
     arr = (GemmProb * 1)(p)
     assert _lib.lib().d3_hgemm(arr, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0

@@ -92,8 +92,8 @@ def test_graph_module_vs_oracle(dev):
     assert int(ref["num_edge_source"][0]) == 37 and int(ref["num_edge_target"][0]) == G.L
 
 
-@pytest.mark.parametrize("fuse_gates", [1, 0])
-def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev, fuse_gates):
+@pytest.mark.parametrize("fuse_gates,N,V", [(1, 32, 3004), (0, 32, 3004), (1, 72, 600), (1, 13, 600)])
+def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev, fuse_gates, N, V):
     """(fuse_gates: the backward step's GRU gate kernels as epilogues of the GEMMs that complete their input -- D3_TD_FUSE_GATES, the
     default -- or as launches of their own, rounds 2-4)
     csrc/topdown.hip (one native call for the S-step teacher-forced pass, one for its backward) against the same module
@@ -103,8 +103,10 @@ def test_native_topdown_pass_matches_step_by_step_at_config_shape(dev, fuse_gate
     import types
     from d3net_amd.speaker import TopDownSceneCaptionModule, TopDownXEFunction, _TD_KEYS
     from d3net_amd import _lib, synthetic as S
+    # (N = 72: the 8-scene batch of bench.py's strong-scaling ceiling and the joint step run more than 32 sequences -- the gate
+    # epilogue then rides in the K-split kernel's two-row-tile variant; N = 13: a ragged single tile)
     torch.manual_seed(11)
-    V, N, K, L = 3004, 32, 128, 10
+    K, L = 128, 10
     cfg = types.SimpleNamespace(data=types.SimpleNamespace(max_spk_len=30, min_iou_threshold=0.25))
     emb = np.random.default_rng(3).standard_normal((V, 300)).astype(np.float32)
     cap = TopDownSceneCaptionModule(cfg, S.make_vocabulary(V), emb, num_proposals=K, num_locals=L, use_relation=True).to(dev)
