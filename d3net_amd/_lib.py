@@ -29,6 +29,8 @@ SIGNATURES = {
     "d3_cluster_merge": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "d3_proposal_prepare": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "d3_cluster_coords_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
+    "d3_cluster_coords_stats_ws_bytes": (sz, [i64]),
+    "d3_cluster_coords_stats2": (i32, [vp, vp, vp, i64, vp, vp, vp, i32, vp, sz, vp]),
     "d3_cluster_transform": (i32, [vp, vp, vp, vp, vp, vp, i64, vp]),
     "d3_cluster_norm_params": (i32, [vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "d3_roipool_fp": (i32, [vp, vp, vp, vp, i32, i32, vp]),

@@ -88,79 +88,132 @@ __global__ __launch_bounds__(SEG_THREADS) void sec_mean_kernel(const float *__re
 // ~40 instructions per element) and stage the chunks of the NEXT round in LDS.  The workgroup-per-segment kernel
 // above idles 253 of 256 lanes during the chain and the chain during the staging.
 #define MEANW_CHUNK 1024   // floats per chunk (16 per producer lane)
-#define MEANW_PROD 3       // producer waves = chunks per round
+#define MEANW_PB 16        // elements of a producer lane's 16 whose loads are in flight together (the 512-thread instance has 256 registers per lane: no spills; at 1024 threads / 128 registers every variant spilled, and a spill's reload waits on vmcnt(0), i.e. for the loads in flight)
+// waves of an instance: the chain wave + NPROD producers; beyond 3 producers the waves that would share the chain wave's SIMD
+// (wave % 4 == 0: the hardware deals a workgroup's waves round the four SIMDs) stay idle -- the chain owns its SIMD's issue slots
+#define MEANW_WAVES(NP) ((NP) <= 3 ? (NP) + 1 : (NP) + 1 + ((NP) - 1) / 3)
+#define MEANW_PROD 3       // producer waves = chunks per round (the 256-thread instance; the 1024-thread one runs 15)
 // The chunk is staged TRANSPOSED (channel-major, rows padded to a multiple of 4), so the chain lane of a channel reads
 // four consecutive rows with one ds_read_b128 and keeps 32 rows in flight behind the 32 dependent adds: the chain runs
 // at the issue rate of v_add_f32 instead of waiting for LDS.
 // gidx != nullptr: row r of the input is inp[gidx[2r + 1]] (the (cluster, point) pairs of `clusters_idx`: the mean of the
 // clusters' point coordinates without materialising the gathered (S, 3) copy)
-__global__ __launch_bounds__(256) void sec_mean_pc_kernel(const float *__restrict__ inp, const int *__restrict__ offsets,
-                                                         float *__restrict__ out, int nProposal, int C, const int *__restrict__ gidx) {
-    __shared__ __attribute__((aligned(16))) float stage[2][MEANW_PROD][MEANW_CHUNK];
+// NPROD (round 5): with 3 producers a round is bound by the PRODUCERS' latency (two dependent gathers + IEEE divisions: ~11 us for
+// the ~1020 rows the chain then adds in ~2 us -- 370 us for the 33,721-point floor of the canonical scene, on the step's critical
+// path); 6 producer waves (512 threads, 48 KB of LDS) with all 16 elements of a lane in flight stage ~1,900 rows per round, which the
+// chain adds in ~5 us -- more than the producers' two memory round trips + divisions -- on a SIMD of its own.  The chain itself:
+// tools/probes/addchain.hip measures 2.4 ns per dependent v_add_f32 from registers (~80 us for 33 k rows: the floor of this kernel).
+template <int NPROD>
+__global__ __launch_bounds__(MEANW_WAVES(NPROD) * 64) void sec_mean_pc_kernel(const float *__restrict__ inp, const int *__restrict__ offsets,
+                                                         float *__restrict__ out, int nProposal, int C, const int *__restrict__ gidx, int prediv) {
+    extern __shared__ __attribute__((aligned(16))) float meanw_smem[];
+    float (*stage)[NPROD][MEANW_CHUNK] = (float (*)[NPROD][MEANW_CHUNK])meanw_smem;      // [2][NPROD][MEANW_CHUNK]
+    constexpr int MEANW_PROD_ = NPROD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = blockIdx.x;
     const int start = offsets[p], end = offsets[p + 1];
     const float count = (float)(end - start);
-    const int rpc = (MEANW_CHUNK / C) & ~3, cf = rpc * C;   // rows / floats per chunk (rows: a multiple of 4, or 0)
+    // rows / floats per chunk: a multiple of 256 rows where a chunk holds that many (the chain's straight-line turn takes 256
+    // rows; the 20-row tail of a 340-row chunk at C = 3 ran one LDS round trip per row and cost more than the 320 rows in front
+    // of it), else of 64, else of 4 (or 0)
+    const int rpc0 = MEANW_CHUNK / C, rpc = rpc0 >= 256 ? (rpc0 & ~255) : (rpc0 >= 64 ? (rpc0 & ~63) : (rpc0 & ~3)), cf = rpc * C;
     if (rpc == 0) return;                                    // (C <= 64 on this path: rpc >= 16)
     const long long base = (long long)start * C, total = (long long)(end - start) * C;
     const int nchunk = (int)((total + cf - 1) / cf);
-    const int nround = (nchunk + MEANW_PROD - 1) / MEANW_PROD;
+    const int nround = (nchunk + MEANW_PROD_ - 1) / MEANW_PROD;
     const unsigned int invC = (65536u + C - 1) / C;          // f / C for f < 1024 (exact: f * invC < 2^26, C <= 64)
     float mean = 0.f;
+    if (NPROD > 3 && wave == 0) __builtin_amdgcn_s_setprio(3);
+    const int pslot = NPROD <= 3 ? wave - 1 : ((wave & 3) ? wave - 1 - (wave >> 2) : -1);      // producer slot of this wave (-1: chain / idle)
     for (int rd = 0; rd <= nround; rd++) {
-        if (wave > 0) {   // produce chunk (rd, wave-1) of round rd into buffer rd & 1
-            const int k = rd * MEANW_PROD + wave - 1;
+        if (pslot >= 0) {   // produce chunk (rd, pslot) of round rd into buffer rd & 1
+            const int k = rd * MEANW_PROD_ + pslot;
             if (rd < nround && k < nchunk) {
-                float *st = stage[rd & 1][wave - 1];
+                float *st = stage[rd & 1][pslot];
                 const long long cb = (long long)k * cf;
-                float v[16];
+                // Branch-free, every load of a stage issued before the first use (round 5: written with a branch per element the
+                // compiler emitted, per element, index load -> wait -> value load -> wait: 32 dependent memory round trips per
+                // chunk and producer wave, ~30 us -- the whole kernel was bound by it, whatever the number of producers)
+                // (batches of MEANW_PB elements: 16 x (index, 64-bit address, value) spilled at the 128 registers of a 1024-thread block;
+                // `lz` = lane behind an opaque move: the row / channel of an element are loop invariants the compiler otherwise
+                // hoists out of the round loop -- 48 registers held across it, spilled, and every reload's s_waitcnt vmcnt(0)
+                // serialised the global loads again)
+                int lz;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(lz) : "v"(lane));
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const long long f = j * 64 + lane;
-                    v[j] = 0.f;
-                    if (f < cf && cb + f < total) {
-                        if (gidx) {
-                            const int row = (int)(((unsigned int)f * invC) >> 16), c = (int)f - row * C;
-                            v[j] = inp[(long long)gidx[((long long)start + (long long)k * rpc + row) * 2 + 1] * C + c];
-                        } else v[j] = inp[base + cb + f];
+                for (int hf = 0; hf < 16 / MEANW_PB; hf++) {
+                    float v[MEANW_PB];
+                    int rowj[MEANW_PB], cj[MEANW_PB];
+                    bool okj[MEANW_PB];
+                    unsigned int src[MEANW_PB];
+#pragma unroll
+                    for (int j = 0; j < MEANW_PB; j++) {
+                        const int f = (hf * MEANW_PB + j) * 64 + lz;
+                        okj[j] = f < cf && cb + f < total;
+                        rowj[j] = (int)(((unsigned int)f * invC) >> 16); cj[j] = f - rowj[j] * C;
+                    }
+                    if (gidx) {
+                        int pt[MEANW_PB];
+                        const int *gi = gidx + ((long long)start + (long long)k * rpc) * 2 + 1;
+#pragma unroll
+                        for (int j = 0; j < MEANW_PB; j++) pt[j] = gi[(okj[j] ? rowj[j] : 0) * 2];      // (row 0 of a chunk always exists)
+#pragma unroll
+                        for (int j = 0; j < MEANW_PB; j++) src[j] = (unsigned int)pt[j] * (unsigned int)C + (unsigned int)cj[j];
+#pragma unroll
+                        for (int j = 0; j < MEANW_PB; j++) v[j] = inp[src[j]];
+                    } else {
+                        const float *ib = inp + base + cb;
+#pragma unroll
+                        for (int j = 0; j < MEANW_PB; j++) v[j] = ib[okj[j] ? (hf * MEANW_PB + j) * 64 + lz : 0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < MEANW_PB; j++) {
+                        const int f = (hf * MEANW_PB + j) * 64 + lz;
+                        if (f < cf) st[cj[j] * rpc + rowj[j]] = okj[j] ? (prediv ? v[j] : __fdiv_rn(v[j], count)) : 0.f;
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int f = j * 64 + lane;
-                    if (f < cf) { const int row = (int)(((unsigned int)f * invC) >> 16), c = f - row * C; st[c * rpc + row] = __fdiv_rn(v[j], count); }
-                }
             }
-        } else if (rd > 0) {   // consume round rd-1
-            for (int q = 0; q < MEANW_PROD; q++) {
-                const int k = (rd - 1) * MEANW_PROD + q;
+        } else if (wave == 0 && rd > 0) {   // consume round rd-1
+            for (int q = 0; q < MEANW_PROD_; q++) {
+                const int k = (rd - 1) * MEANW_PROD_ + q;
                 if (k >= nchunk) break;
                 const float *st = stage[(rd - 1) & 1][q] + lane * rpc;
                 const long long left = total - (long long)k * cf;
                 const int rows = (int)((left < cf ? left : cf) / C);
                 if (lane < C) {
                     int r = 0;
-                    float4 w0[8], w1[8];
-                    if (rows >= 32) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) w0[j] = *(const float4 *)(st + j * 4);
+                    // two register sets with FIXED roles (rows r .. r+31 / r+32 .. r+63 of the current 64): a set is reloaded
+                    // for the next turn right behind the adds that read it -- no rotation, hence no register copies in the
+                    // chain wave's issue stream (round 5: the rotating form spent a third of its VALU slots on v_mov)
+                    // 256 rows per turn as STRAIGHT-LINE code: eight groups of 32 rows, group g + 2 requested from LDS behind the
+                    // adds of group g (scheduling barriers pin that order) -- no register set lives across the loop's back edge.
+                    // (Round 5: both software-pipelined loop forms made the compiler copy every prefetched register at the back
+                    // edge -- 64 moves per 64 adds -- and wait for LDS with nothing in flight: 6 ns per row against 2.4 ns for the
+                    // bare dependent-add chain, tools/probes/addchain.hip.)
+#define MEANW_LD(W, R0)  _Pragma("unroll") for (int j = 0; j < 8; j++) W[j] = *(const float4 *)(st + (R0) + j * 4)
+#define MEANW_ADD(W)     _Pragma("unroll") for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, W[j].x); mean = __fadd_rn(mean, W[j].y); mean = __fadd_rn(mean, W[j].z); mean = __fadd_rn(mean, W[j].w); }
+                    for (; r + 256 <= rows; r += 256) {
+                        float4 g0[8], g1[8], g2[8], g3[8], g4[8], g5[8], g6[8], g7[8];
+                        MEANW_LD(g0, r); MEANW_LD(g1, r + 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g0); __builtin_amdgcn_sched_barrier(0); MEANW_LD(g2, r + 64); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g1); __builtin_amdgcn_sched_barrier(0); MEANW_LD(g3, r + 96); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g2); __builtin_amdgcn_sched_barrier(0); MEANW_LD(g4, r + 128); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g3); __builtin_amdgcn_sched_barrier(0); MEANW_LD(g5, r + 160); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g4); __builtin_amdgcn_sched_barrier(0); MEANW_LD(g6, r + 192); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g5); __builtin_amdgcn_sched_barrier(0); MEANW_LD(g7, r + 224); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g6); __builtin_amdgcn_sched_barrier(0);
+                        MEANW_ADD(g7); __builtin_amdgcn_sched_barrier(0);
                     }
-                    for (; r + 64 <= rows; r += 64) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) w1[j] = *(const float4 *)(st + r + 32 + j * 4);
-#pragma unroll
-                        for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, w0[j].x); mean = __fadd_rn(mean, w0[j].y); mean = __fadd_rn(mean, w0[j].z); mean = __fadd_rn(mean, w0[j].w); }
-                        if (r + 96 <= rows) {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) w0[j] = *(const float4 *)(st + r + 64 + j * 4);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, w1[j].x); mean = __fadd_rn(mean, w1[j].y); mean = __fadd_rn(mean, w1[j].z); mean = __fadd_rn(mean, w1[j].w); }
+                    for (; r + 32 <= rows; r += 32) {
+                        float4 g0[8];
+                        MEANW_LD(g0, r);
+                        MEANW_ADD(g0);
                     }
-                    if (r + 32 <= rows) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) { mean = __fadd_rn(mean, w0[j].x); mean = __fadd_rn(mean, w0[j].y); mean = __fadd_rn(mean, w0[j].z); mean = __fadd_rn(mean, w0[j].w); }
-                        r += 32;
+#undef MEANW_LD
+#undef MEANW_ADD
+                    for (; r + 4 <= rows; r += 4) {      // (the tail of a segment's last chunk: its real rows only, four per LDS read)
+                        const float4 w = *(const float4 *)(st + r);
+                        mean = __fadd_rn(mean, w.x); mean = __fadd_rn(mean, w.y); mean = __fadd_rn(mean, w.z); mean = __fadd_rn(mean, w.w);
                     }
                     for (; r < rows; r++) mean = __fadd_rn(mean, st[r]);
                 }
@@ -526,7 +579,7 @@ extern "C" int d3_sec_mean(const float *inp, const int *offsets, float *out, int
     D3_CLEAR();
     if (nProposal <= 0) return 0;
     if (C <= 0 || C > SEG_THREADS) return D3_ERR_ARG;
-    if (C <= 64) sec_mean_pc_kernel<<<nProposal, 256, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C, nullptr);
+    if (C <= 64) sec_mean_pc_kernel<MEANW_PROD><<<nProposal, 256, 2 * MEANW_PROD * MEANW_CHUNK * sizeof(float) + 256, d3_stream(stream)>>>(inp, offsets, out, nProposal, C, nullptr, 0);
     else sec_mean_kernel<<<seg_grid(nProposal), SEG_THREADS, 0, d3_stream(stream)>>>(inp, offsets, out, nProposal, C);
     D3_LAUNCH_CHECK();
     return 0;
@@ -589,12 +642,67 @@ extern "C" int d3_get_iou(const int *proposals_idx, const int *proposals_offset,
 // ---- cluster normalisation helpers of PointGroup.clusters_voxelization (model/pointgroup.py:125-178): the three passes over
 // the S (cluster, point) pairs without the gathered / subtracted / scaled (S, 3) temporaries of the library-op form.
 // clusters_idx (S,2) int32 [cluster, point]; offsets (P+1); coords (N,3).
+// q[e, ch] = coords[point of pair e, ch] / (points of e's cluster): the addends of the clusters' mean chains, gathered and divided
+// (IEEE) by the whole chip -- the chain kernel then streams contiguous rows.  Gathering inside it (round 3: "without the (S, 3)
+// copy") made its few workgroups wait for their compute unit's miss queue: a chunk of 320 rows is 320 scattered 12-byte reads, ~15 us
+// per round of six chunks against the ~5 us the chain needs for them (258 -> ~130 us per launch for the canonical 33 k-point floors).
+__global__ void cluster_quot_kernel(const float *__restrict__ coords, const int *__restrict__ clusters_idx, const int *__restrict__ offsets,
+                                    float *__restrict__ q, long long S, int nProposal) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * 3) return;
+    const long long e = t / 3;
+    const int ch = (int)(t - e * 3);
+    const int pt = clusters_idx[e * 2 + 1];
+    int lo = 0, hi = nProposal;                    // the segment of pair e: largest c with offsets[c] <= e (the offsets define the
+    while (hi - lo > 1) { const int m = (lo + hi) >> 1; if ((long long)offsets[m] <= e) lo = m; else hi = m; }      // segments, as for sec_mean)
+    const int c = lo;
+    const float count = (float)(offsets[c + 1] - offsets[c]);
+    q[t] = __fdiv_rn(coords[(long long)pt * 3 + ch], count);
+}
+
+static int cluster_mean_launch(const float *inp, const int *offsets, float *mean, int nProposal, const int *gidx, int prediv, hipStream_t s) {
+    // (segments of tens of thousands of points -- a floor, a wall -- set this launch's time: the 6-producer instance: 8 waves, wave 4 idle)
+    constexpr int NP = 6;
+    const size_t lds = (size_t)2 * NP * MEANW_CHUNK * sizeof(float) + 256;
+    static bool attr_done[64] = {false};
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64 || !attr_done[dev_id]) {
+        D3_CHECK(hipFuncSetAttribute((const void *)sec_mean_pc_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev_id >= 0 && dev_id < 64) attr_done[dev_id] = true;
+    }
+    sec_mean_pc_kernel<NP><<<nProposal, MEANW_WAVES(NP) * 64, lds, s>>>(inp, offsets, mean, nProposal, 3, gidx, prediv);
+    return 0;
+}
+
+static int cluster_minmax_launch(const float *coords, const int *clusters_idx, const int *offsets, float *cmin, float *cmax, int nProposal, hipStream_t s);
+
 extern "C" int d3_cluster_coords_stats(const float *coords, const int *clusters_idx, const int *offsets, float *mean, float *cmin,
                                        float *cmax, int nProposal, void *stream) {
     D3_CLEAR();
     if (nProposal <= 0) return 0;
     hipStream_t s = d3_stream(stream);
-    sec_mean_pc_kernel<<<nProposal, 256, 0, s>>>(coords, offsets, mean, nProposal, 3, clusters_idx);
+    int rc = cluster_mean_launch(coords, offsets, mean, nProposal, clusters_idx, 0, s);
+    if (rc) return rc;
+    return cluster_minmax_launch(coords, clusters_idx, offsets, cmin, cmax, nProposal, s);
+}
+
+// the same with S = the number of (cluster, point) pairs and S * 3 floats of scratch: the chains' addends are staged by
+// cluster_quot_kernel (bit-identical results: the same IEEE quotients added in the same order)
+extern "C" size_t d3_cluster_coords_stats_ws_bytes(long long S) { return (size_t)(S > 0 ? S : 1) * 3 * sizeof(float); }
+extern "C" int d3_cluster_coords_stats2(const float *coords, const int *clusters_idx, const int *offsets, long long S, float *mean, float *cmin,
+                                        float *cmax, int nProposal, void *ws, size_t ws_bytes, void *stream) {
+    D3_CLEAR();
+    if (nProposal <= 0) return 0;
+    if (S < 0 || ws == nullptr || ws_bytes < d3_cluster_coords_stats_ws_bytes(S)) return D3_ERR_WORKSPACE;
+    hipStream_t s = d3_stream(stream);
+    float *q = (float *)ws;
+    if (S > 0) cluster_quot_kernel<<<(int)((S * 3 + 255) / 256), 256, 0, s>>>(coords, clusters_idx, offsets, q, S, nProposal);
+    int rc = cluster_mean_launch(q, offsets, mean, nProposal, nullptr, 1, s);
+    if (rc) return rc;
+    return cluster_minmax_launch(coords, clusters_idx, offsets, cmin, cmax, nProposal, s);
+}
+
+static int cluster_minmax_launch(const float *coords, const int *clusters_idx, const int *offsets, float *cmin, float *cmax, int nProposal, hipStream_t s) {
     const long long n = (long long)nProposal * 3;
     seg_init_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(cmin, nullptr, n, INFINITY, 0);
     seg_init_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(cmax, nullptr, n, -INFINITY, 0);

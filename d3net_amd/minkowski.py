@@ -69,9 +69,19 @@ def set_eval_exact(flag):
     _EVAL_EXACT = bool(flag)
 
 
-def exact_for(training):
-    """does a forward in this mode run the reference-precision program?"""
-    return _EXACT or (not training and _EVAL_EXACT)
+_EVAL_EXACT_ONLY = frozenset()      # with set_eval_exact(False): the U-Nets ("backbone" / "score_net") that keep the reference precision anyway
+
+
+def set_eval_exact_only(names):
+    """module-wise ablation of the evaluation precision (tools/bf16_ablation.py): with the bf16 kernels forced onto the evaluation
+    (set_eval_exact(False)), the named U-Nets still run their reference-precision twins"""
+    global _EVAL_EXACT_ONLY
+    _EVAL_EXACT_ONLY = frozenset(names or ())
+
+
+def exact_for(training, name=None):
+    """does a forward in this mode (of the U-Net `name`) run the reference-precision program?"""
+    return _EXACT or (not training and (_EVAL_EXACT or (name is not None and name in _EVAL_EXACT_ONLY)))
 
 
 class heads_exact_for:

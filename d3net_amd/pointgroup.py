@@ -245,7 +245,7 @@ class PointGroup(nn.Module):
         if not (self.native_unet and voxel_locs.is_cuda and voxel_locs.size(0) > 0) or (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)):
             return None
         cm = ME.CoordinateManager(voxel_locs.int().contiguous())
-        exact = ME.exact_for(self.training)
+        exact = ME.exact_for(self.training, name)
         if exact:
             cm.want16 = False        # (only the bf16 executors read the 16-bit kernel maps)
         cm.begin_pyramid(self._exec(name, exact=exact).nlevels)
@@ -324,7 +324,7 @@ class PointGroup(nn.Module):
                         side.wait_event(gate)
                         cm, vf = self._input_stage(t.inputs)
                         if cm is not None:
-                            self._exec("backbone", exact=ME.exact_for(training)).maps(cm)   # pyramid counts (host round trip) + all kernel maps
+                            self._exec("backbone", exact=ME.exact_for(training, "backbone")).maps(cm)   # pyramid counts (host round trip) + all kernel maps
                         ev = torch.cuda.Event()
                         ev.record(side)
                     t.cm, t.voxel_feats, t.event = cm, vf, ev
@@ -359,7 +359,7 @@ class PointGroup(nn.Module):
     def _run_unet(self, name, module, x):
         """x: ME.SparseTensor -> (M, m) features of `module` (backbone / score_net)"""
         if self.native_unet and not (ME._EXACT and (ME._EXACT_FMA or not self.native_exact)) and x.F.size(0) > 0:
-            return self._exec(name, exact=ME.exact_for(self.training))(x.F, x.coordinate_manager, self.training)
+            return self._exec(name, exact=ME.exact_for(self.training, name))(x.F, x.coordinate_manager, self.training)
         return module(x).features
 
     def static_gradient_buckets(self):

@@ -480,9 +480,12 @@ def cluster_coords_stats(coords, clusters_idx, clusters_offset):
     assert clusters_idx.dtype == torch.int32 and clusters_idx.is_contiguous() and clusters_offset.dtype == torch.int32
     P = clusters_offset.numel() - 1
     out = torch.empty((3, P, 3), dtype=torch.float32, device=coords.device)
+    L = _lib.lib()
+    S = int(clusters_idx.shape[0])
     with _on(coords.device):
-        check(_lib.lib().d3_cluster_coords_stats(_ptr(coords), _ptr(clusters_idx), _ptr(clusters_offset), _ptr(out[0]), _ptr(out[1]),
-                                                 _ptr(out[2]), P, _stream()), "cluster_coords_stats")
+        ws = _workspace(L.d3_cluster_coords_stats_ws_bytes(S), coords.device, "ccs")     # the mean chains' staged addends
+        check(L.d3_cluster_coords_stats2(_ptr(coords), _ptr(clusters_idx), _ptr(clusters_offset.contiguous()), S, _ptr(out[0]), _ptr(out[1]),
+                                         _ptr(out[2]), P, _ptr(ws), ws.numel(), _stream()), "cluster_coords_stats2")
     return out[0], out[1], out[2]
 
 

@@ -67,6 +67,12 @@ int d3_proposal_prepare(const float *sig, const int *offsets, const int *batch_i
  *                 each fp32 operation rounded separately (:141-166). */
 int d3_cluster_coords_stats(const float *coords, const int *clusters_idx, const int *offsets, float *mean, float *cmin, float *cmax,
                             int nProposal, void *stream);
+/* the same with S = number of (cluster, point) pairs and d3_cluster_coords_stats_ws_bytes(S) bytes of scratch: the addends of the
+ * clusters' mean chains (coords / count, IEEE) are gathered by a chip-wide pass first and the serial chains stream them
+ * (bit-identical results; 258 -> ~130 us for the 4-scene batch, whose 33 k-point floors set the launch time). */
+size_t d3_cluster_coords_stats_ws_bytes(long long S);
+int d3_cluster_coords_stats2(const float *coords, const int *clusters_idx, const int *offsets, long long S, float *mean, float *cmin,
+                             float *cmax, int nProposal, void *ws, size_t ws_bytes, void *stream);
 int d3_cluster_transform(const float *coords, const int *clusters_idx, const float *mean, const float *scale, const float *offset,
                          long long *out, long long S, void *stream);
 /* The per-cluster arithmetic between the two (model/pointgroup.py:146-165): size = cmax - cmin, center = (cmax + cmin) / 2 + mean

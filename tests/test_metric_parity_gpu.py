@@ -118,7 +118,7 @@ def _gt_keys(batch):
 
 
 def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3, seed=0, exact_too=True, verbose=True, with_oracle=True,
-               head_lr=None, train_exact=False):
+               head_lr=None, train_exact=False, ablate=()):
     """train on the device, evaluate held-out scenes with the HIP path(s) and the CPU oracle -> dict of metrics
     (train_exact: the training steps run the reference-precision kernels instead of bf16 -- tools/train_precision_compare.py)"""
     from d3net_amd import synthetic as S, minkowski as ME, evaluator as ev
@@ -209,12 +209,14 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
     res = {}
 
     # ---- HIP: the product's validation hooks + the evaluator
-    def hip_eval(bf16):
+    def hip_eval(bf16, exact_only=()):
         """bf16 False: the library's evaluation path as shipped (eval mode -> reference-precision kernels, minkowski.exact_for);
-        True: the training step's bf16 kernels forced onto the evaluation (minkowski.set_eval_exact(False))"""
+        True: the training step's bf16 kernels forced onto the evaluation (minkowski.set_eval_exact(False)) -- except the U-Nets named
+        in exact_only (module-wise ablation: tools/bf16_ablation.py)"""
         calc = ev.APCalculator(0.5)
         outs, nprop = [], 0
         ME.set_eval_exact(not bf16)
+        ME.set_eval_exact_only(exact_only)
         try:
             for b in val_batches:
                 outs.append(net.validation_step(dict(b), 0))
@@ -225,6 +227,7 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
                 nprop += int(d["proposal_batch_mask"].sum())
         finally:
             ME.set_eval_exact(True)
+            ME.set_eval_exact_only(())
         log = net.validation_epoch_end(outs)
         cands = {}
         for o in outs:
@@ -232,6 +235,8 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
         return dict(mAP=calc.compute_metrics()["mAP"], cider=float(log["cider"]), bleu4=float(log["bleu-4"]), proposals=nprop, cands=cands)
 
     res["bf16"] = hip_eval(True)
+    for names in ablate:
+        res["bf16+exact:" + "+".join(names)] = hip_eval(True, names)
     if exact_too:
         res["exact"] = hip_eval(False)
 
@@ -273,7 +278,7 @@ def run_parity(dev, sigma=1.0, steps=600, n_train=16, n_val=16, chunk=4, lr=4e-3
     spo.TIE_RULE = "topk"
     bleu, cider, rouge, _ = eval_caption_epoch(cands, raw_val, max_len=cfg.eval.max_des_len + 2, min_iou=cfg.eval.min_iou_threshold)
     res["oracle"] = dict(mAP=calc.compute_metrics()["mAP"], cider=float(cider[0]), bleu4=float(bleu[0][3]), proposals=nprop, cands=cands)
-    for k in ("bf16", "exact"):
+    for k in [k for k in res if k != "oracle"]:
         if k in res:
             same = sum(1 for key, v in res[k]["cands"].items() if key in cands and v["caption"] == cands[key]["caption"])
             res[k]["same_captions"] = (same, len(cands))
