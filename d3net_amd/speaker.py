@@ -446,6 +446,7 @@ class _CaptionInputs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, base, edge, adj, locals_, target_ids, per_scene):
+        ctx.set_materialize_grads(False)      # (an output nobody differentiates through arrives as None, not as a zero tensor: one fill launch less each)
         B, K, Fd = base.shape
         N = target_ids.numel()
         dev = base.device
