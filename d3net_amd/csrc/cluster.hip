@@ -665,28 +665,34 @@ __global__ void cl_ninfo_kernel(const int *__restrict__ own, const int *__restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ninfo[i] = make_int4(own[i], lid[i], estart[i], start_len[i * 2 + 1]);
 }
+// Round 5: EIGHT lanes per node (a wave per node left 55 of 64 lanes idle on the ~9-entry lists of a surface and cost one wave
+// launch + three dependent round trips per node: 200 - 260 us for the 600 k nodes of the 4-scene batch); a node's lanes take its
+// entries 8 apart, four per lane in flight, so a list of up to 32 entries is one pass and the eight 16-byte records of a pass are
+// one contiguous 128-byte store.
+#define CL_EG 8
 __global__ __launch_bounds__(256) void cl_erec_kernel(const int *__restrict__ idx, const int *__restrict__ start_len,
                                                      const int *__restrict__ own, const int *__restrict__ flag,
                                                      const int *__restrict__ star, const int4 *__restrict__ ninfo,
                                                      const int *__restrict__ estart, int4 *__restrict__ erec, int n) {
-    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(gid / CL_EG), sub = (int)(gid % CL_EG);
     if (i >= n) return;
     const int oi = own[i];
     if (!flag[oi] || star[oi]) return;
     const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
     const long long es = estart[i];
     // four entries per lane per round trip pair (ids; then owner / dense id / record start / length of all four together as ONE
-    // 16-byte record per neighbour -- round 3; four 4-byte gathers per entry before): a capped list is 16 passes otherwise
-    for (int e0 = d3_lane(); e0 < ln; e0 += 256) {
+    // 16-byte record per neighbour -- round 3; four 4-byte gathers per entry before)
+    for (int e0 = sub; e0 < ln; e0 += 4 * CL_EG) {
         int j[4];
         int4 nj[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int e = e0 + q * 64; j[q] = idx[st + (e < ln ? e : 0)]; }
+        for (int q = 0; q < 4; q++) { const int e = e0 + q * CL_EG; j[q] = idx[st + (e < ln ? e : 0)]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) nj[q] = ninfo[j[q]];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int e = e0 + q * 64;
+            const int e = e0 + q * CL_EG;
             if (e < ln) erec[es + e] = (nj[q].x == oi) ? make_int4(j[q], nj[q].y, nj[q].z, nj[q].w) : make_int4(-1, 0, 0, 0);
         }
     }
@@ -1224,7 +1230,7 @@ static int cl_fill2_impl(const int *semantic_label, const int *ball_query_idxs, 
         int rc = d3_exclusive_scan_i32(w.klen, w.estart, n, w.temp, w.temp_bytes, s);
         if (rc) return rc;
         cl_ninfo_kernel<<<nb, T, 0, s>>>(w.own, w.lid, w.estart, start_len, w.ninfo, n);
-        cl_erec_kernel<<<nwb, T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.ninfo, w.estart, (int4 *)erec, n);
+        cl_erec_kernel<<<(int)(((long long)n * CL_EG + T - 1) / T), T, 0, s>>>(ball_query_idxs, start_len, w.own, w.flag, w.star, w.ninfo, w.estart, (int4 *)erec, n);
         }
         const bool debug = d3_tune(D3T_BFS_DEBUG) != 0;
         // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S, nActive = the list entries of the kept
