@@ -608,8 +608,24 @@ __device__ __forceinline__ bool bqg_test(const BqProbe &r, int t, const int *pre
     return live && d2 < radius2;
 }
 
-// sparse pass: one wave per query; followers of a clique leader and queries with <= 64 candidates finish here, the others
-// are queued for the dense pass (which needs an 8 KB hit buffer per wave -- kept out of this kernel's occupancy)
+// one query on one wave: followers of a clique leader and queries with <= 64 candidates finish here, the others are queued for the
+// dense pass (which needs an 8 KB hit buffer per wave -- kept out of this kernel's occupancy)
+__device__ __forceinline__ void bqg_query_one(int q, const float *__restrict__ xyz, const int *__restrict__ batch_idxs, float radius, float inv,
+                                              const int *__restrict__ sidx, const float *__restrict__ sxyz, const BqSlot *__restrict__ tbl,
+                                              const int *__restrict__ tlead, size_t mask, int *__restrict__ leader_of,
+                                              int *__restrict__ len_out, int *__restrict__ idx, int *dense, int *scal, int lane, int *preS, int *cstS) {
+    const BqProbe r = bqg_probe(xyz, batch_idxs, q, inv, tbl, tlead, mask, lane, preS, cstS);
+    if (r.leader >= 0 && r.leader != q) { if (lane == 0) leader_of[q] = r.leader; return; }   // shares the leader's list
+    if (lane == 0) leader_of[q] = q;
+    if (r.T > 64) { if (lane == 0) dense[atomicAdd(&scal[1], 1)] = q; return; }
+    int k;
+    const bool hit = bqg_test(r, lane, preS, cstS, sidx, sxyz, __fmul_rn(radius, radius), k);
+    const int v = bqg_bitonic64(hit ? k : 0x7FFFFFFF, lane);
+    const int cnt = (int)__popcll(__ballot(hit));
+    if (lane < cnt) idx[(long long)q * BQ_CAP + lane] = v;
+    if (lane == 0) len_out[q] = cnt;
+}
+// sparse pass, one wave per query (rounds 3 - 4; D3_BQ_HALF=0)
 __global__ __launch_bounds__(256) void bqg_query_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n,
                                                        float radius, float inv, const int *__restrict__ sidx,
                                                        const float *__restrict__ sxyz, const BqSlot *__restrict__ tbl,
@@ -619,16 +635,121 @@ __global__ __launch_bounds__(256) void bqg_query_kernel(const float *__restrict_
     const int q = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (q >= n) return;                      // (whole waves: no workgroup barrier below)
     const int lane = d3_lane(), wave = (int)(threadIdx.x >> 6);
-    const BqProbe r = bqg_probe(xyz, batch_idxs, q, inv, tbl, tlead, mask, lane, preS[wave], cstS[wave]);
-    if (r.leader >= 0 && r.leader != q) { if (lane == 0) leader_of[q] = r.leader; return; }   // shares the leader's list
-    if (lane == 0) leader_of[q] = q;
-    if (r.T > 64) { if (lane == 0) dense[atomicAdd(&scal[1], 1)] = q; return; }
-    int k;
-    const bool hit = bqg_test(r, lane, preS[wave], cstS[wave], sidx, sxyz, __fmul_rn(radius, radius), k);
-    const int v = bqg_bitonic64(hit ? k : 0x7FFFFFFF, lane);
-    const int cnt = (int)__popcll(__ballot(hit));
-    if (lane < cnt) idx[(long long)q * BQ_CAP + lane] = v;
-    if (lane == 0) len_out[q] = cnt;
+    bqg_query_one(q, xyz, batch_idxs, radius, inv, sidx, sxyz, tbl, tlead, mask, leader_of, len_out, idx, dense, scal, lane, preS[wave], cstS[wave]);
+}
+// Round 5 -- TWO queries per wave.  The wave-per-query kernel is bound by waves x latency (600 k waves of four dependent round trips
+// at full occupancy: ~390 us for the 4-scene batch) and a query of a surface has ~25 candidates in its 27 cells: 32 lanes hold the 27
+// probes, up to 32 candidates and a 32-lane bitonic network.  A half owns lanes [32 h, 32 h + 32); every cross-lane step is
+// width-limited to it.  33..64 candidates: a second element per lane; more -> the dense queue.  Same lists, same order.
+__device__ __forceinline__ int bqg_bitonic32(int v, int sub) {     // ascending across the 32 lanes of a half
+#pragma unroll
+    for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int o = __shfl_xor(v, j, 32);
+            const bool up = (sub & k) == 0, lower = (sub & j) == 0;
+            v = (lower == up) ? min(v, o) : max(v, o);
+        }
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void bqg_query32_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs, int n,
+                                                         float radius, float inv, const int *__restrict__ sidx,
+                                                         const float *__restrict__ sxyz, const BqSlot *__restrict__ tbl,
+                                                         const int *__restrict__ tlead, size_t mask, int *__restrict__ leader_of,
+                                                         int *__restrict__ len_out, int *__restrict__ idx, int *dense, int *scal) {
+    __shared__ int preS[8][32], cstS[8][32];
+    const int gw = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (gw * 2 >= n) return;                 // (whole waves)
+    const int lane = d3_lane(), half = lane >> 5, sub = lane & 31, hs = (int)(threadIdx.x >> 6) * 2 + half;
+    const int q = gw * 2 + half;
+    const bool live = q < n;
+    const int qq = live ? q : n - 1;
+    // ---- probe (bqg_probe on 32 lanes)
+    BqProbe r;
+    r.ox = xyz[qq * 3 + 0]; r.oy = xyz[qq * 3 + 1]; r.oz = xyz[qq * 3 + 2];
+    const int b = batch_idxs[qq];
+    const int cx = bqg_cell(r.ox, inv) + BQG_BIAS, cy = bqg_cell(r.oy, inv) + BQG_BIAS, cz = bqg_cell(r.oz, inv) + BQG_BIAS;
+    int rs = 0, rn = 0, ld = -1;
+    if (sub < 27) {
+        const int nx = cx + sub / 9 - 1, ny = cy + (sub / 3) % 3 - 1, nz = cz + sub % 3 - 1;
+        if (nx >= 0 && ny >= 0 && nz >= 0 && nx <= 0x7FFF && ny <= 0x7FFF && nz <= 0x7FFF) {
+            const unsigned long long nk = ((unsigned long long)(unsigned)(b & 0x7FFFF) << 45) | ((unsigned long long)nx << 30) |
+                                          ((unsigned long long)ny << 15) | (unsigned long long)nz;
+            size_t slot = bqg_hash(nk) & mask;
+            int4 raw = *(const int4 *)&tbl[slot];
+            int l0 = tlead[slot];
+            for (;;) {
+                const unsigned long long k = ((unsigned long long)(unsigned)raw.y << 32) | (unsigned)raw.x;
+                if (k == nk) { rs = raw.z; rn = raw.w; ld = l0; break; }
+                if (k == BQG_EMPTY) break;
+                slot = (slot + 1) & mask;
+                raw = *(const int4 *)&tbl[slot];
+                l0 = tlead[slot];
+            }
+        }
+    }
+    r.leader = __shfl(ld, 13, 32);
+    int pre = rn;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(pre, o, 32); if (sub >= o) pre += t; }
+    r.T = __shfl(pre, 26, 32);
+    pre -= rn;
+    preS[hs][sub] = sub < 27 ? pre : 0x7FFFFFFF;
+    cstS[hs][sub] = sub < 27 ? rs : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- classify
+    const bool follower = r.leader >= 0 && r.leader != q;
+    if (live && sub == 0) {
+        leader_of[q] = follower ? r.leader : q;
+        if (!follower && r.T > 64) dense[atomicAdd(&scal[1], 1)] = q;
+    }
+    const bool active = live && !follower && r.T <= 64;
+    // (a wave of followers / queued queries is done here -- and an inactive half must not run the test either: its 32 lanes would all
+    // read candidate 0, and a collapsed instance is tens of thousands of such halves hammering ONE cache line's L2 channel)
+    if (!__any(active)) return;
+    const float radius2 = __fmul_rn(radius, radius);
+    // ---- test, order, store.  Candidates 32..63 of a half are a second element per lane (a queue for them -- one atomic per
+    // query on one counter -- cost more than the whole kernel: 40 % of a surface's queries have 33..64 candidates)
+    int k0 = 0, k1 = 0;
+    bool h0 = false, h1 = false;
+    if (active) h0 = bqg_test(r, sub, preS[hs], cstS[hs], sidx, sxyz, radius2, k0);
+    const bool two = __any(active && r.T > 32);          // wave-uniform
+    if (two && active && r.T > 32) h1 = bqg_test(r, sub + 32, preS[hs], cstS[hs], sidx, sxyz, radius2, k1);
+    int v0 = h0 ? k0 : 0x7FFFFFFF, v1 = h1 ? k1 : 0x7FFFFFFF;
+    const unsigned long long b0 = __ballot(h0);
+    int cnt = (int)__popc((unsigned int)(b0 >> (half * 32)));
+    if (!two) {
+        v0 = bqg_bitonic32(v0, sub);
+    } else {
+        const unsigned long long b1 = __ballot(h1);
+        cnt += (int)__popc((unsigned int)(b1 >> (half * 32)));
+        // bitonic network over the 64 elements e = 32 r + sub of a half (r = register): partner e ^ j is the other lane for j < 32,
+        // the other register for j = 32
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                if (j == 32) {
+                    const int lo = min(v0, v1), hi = max(v0, v1);      // (kk = 64: ascending everywhere)
+                    v0 = lo; v1 = hi;
+                } else {
+                    const int o0 = __shfl_xor(v0, j, 32), o1 = __shfl_xor(v1, j, 32);
+                    const bool lower = (sub & j) == 0;
+                    const bool up0 = (sub & kk) == 0, up1 = ((sub + 32) & kk) == 0;
+                    v0 = (lower == up0) ? min(v0, o0) : max(v0, o0);
+                    v1 = (lower == up1) ? min(v1, o1) : max(v1, o1);
+                }
+            }
+        }
+    }
+    if (active) {
+        if (sub < cnt) idx[(long long)q * BQ_CAP + sub] = v0;
+        if (sub + 32 < cnt) idx[(long long)q * BQ_CAP + sub + 32] = v1;
+        if (sub == 0) len_out[q] = cnt;
+    }
 }
 // dense pass: persistent waves over the queued queries
 __global__ __launch_bounds__(256) void bqg_dense_kernel(const float *__restrict__ xyz, const int *__restrict__ batch_idxs,
@@ -703,6 +824,10 @@ static int bqg_padded(const float *xyz, const int *batch_idxs, int n, float radi
     bqg_cellbox_kernel<<<(n + 3) / 4, 256, 0, s>>>(g.cstart, g.cslot, g.scal, g.sxyz, g.tbl, g.cbox);          // (<= n cells)
     bqg_clique_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, g.cstart, g.cslot, g.scal, g.tbl, g.cap - 1, g.cbox,
                                                      radius * radius, g.tlead);
+    if (d3_tune(D3T_BQ_HALF) != 0) {
+        bqg_query32_kernel<<<(n + 7) / 8, 256, 0, s>>>(xyz, batch_idxs, n, radius, inv, g.sidx, g.sxyz, g.tbl, g.tlead, g.cap - 1,
+                                                      g.leader_of, w.len, idx_padded, g.dense, g.scal);
+    } else
     bqg_query_kernel<<<(n + 3) / 4, 256, 0, s>>>(xyz, batch_idxs, n, radius, inv, g.sidx, g.sxyz, g.tbl, g.tlead, g.cap - 1,
                                                 g.leader_of, w.len, idx_padded, g.dense, g.scal);
     // dense pass: as many workgroups as the chip holds (LDS: 5 per CU), each wave walks the queue

@@ -54,6 +54,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_UNSAFE_NO_HAZARD_WAIT", 0}, // 1 (MEASUREMENT ONLY, results undefined): the executor's backward does not wait for the side stream's weight gradients before it accumulates into a gradient buffer they read -- prices those waits
     {"D3_SIDE2", 2},                // 1: weight gradients whose dy buffer is later accumulated into in place (the caller's stream has to wait for them) run on a SECOND side stream: they no longer queue behind the other weight gradients; 2 (default): all weight gradients alternate between the two streams (speaker step 17.71 -> 17.49 ms in-process, mode 1: 17.57; detector step inside the noise: gpurun_out/r05_j17); 0: one side stream (rounds 1-4)
     {"D3_SORT_ONESWEEP_MIN", 65536}, // pair sorts of at least this many items take rocPRIM's Onesweep radix path (requested bits only, 8 per pass) instead of its default block sort + merge passes (~35 launches up to 2^20 items whatever the key width); 0x7fffffff: never
+    {"D3_BQ_HALF", 1},              // 0: the cell-grid ball query runs one WAVE per query point (rounds 3-4); 1: two queries per wave (32 lanes each: 27 probes, up to 64 candidates as two elements per lane, bitonic order inside the half)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;
