@@ -191,91 +191,140 @@ __device__ __forceinline__ int cl_chase(const int *lab, int l) {
 }
 
 // phase 1b: push labels over all edges; root[] == parent[] after flatten
+// Round 5: the FILTERS run one THREAD per node, the list walks one WAVE per surviving node.  A wave per node (rounds 1-4) spent a
+// wave launch and five dependent round trips (list extent, class, root, label chase, last pushed label) on every node only to find
+// that almost none has anything to push -- the second and third sweep of a collapsed instance: 240 + 111 us for 600 k nodes.
+#define CL_PUSH_SHORT 48
 __global__ __launch_bounds__(256) void cl_push_kernel(const int *__restrict__ sem, const int *__restrict__ idx,
                                                      const int *__restrict__ start_len, int n,
                                                      const int *__restrict__ root, int *lab, int *pushed, int *lpush,
                                                      int *changed_flag, const int *__restrict__ capped_flag, int ascending, int minima_only) {
     if (*capped_flag == 0) return;   // no capped list: every edge is mutual and already united, the labels stay the roots
-    // (round 3: a bounded grid walks the nodes -- with nothing capped, the common case of the unshifted coordinates, 150 k
-    // workgroups used to start only to read that flag: 3 x 25-85 us per clustering)
-    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
-    for (int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < n; i += nwaves) {
-    const int st = start_len[i * 2], ln = start_len[i * 2 + 1];
-    // Opening sweep (ascending lists only): just the nodes without a smaller-index neighbour push -- the future seeds.  In a
-    // collapsed instance (every list = its first 1000 members) that is ONE node, whose push settles all 1000 labels without
-    // contention; the full sweep behind it then finds them settled through its cached filter read.  Without it every member
-    // pushed its own index at all later members at once: 500 k contended atomicMin per instance, most of the sweep's time
-    // (profiles/r02_q_cluster_timeline.txt: 2.1 ms).  Any sweep order reaches the same fixpoint.
-    if (minima_only && (ln == 0 || idx[st] < i)) continue;
-    const int si = sem[i];
-    const int ri = root[i];
-    const int li = cl_chase(lab, ld_dev(&lab[ri]));
-    if (li < ld_dev(&lab[ri])) atomicMin(&lab[ri], li);
-    // Worklist: a node pushes again only when its own label got smaller since its last push -- every neighbour's label
-    // was <= that value then and labels only decrease.  The verification sweep therefore walks only the lists of the
-    // nodes the previous sweep changed (the first 1000 points of a collapsed instance, not all of them).
-    if (pushed[i] == li) continue;        // (one wave per node: uniform)
-    if (d3_lane() == 0) pushed[i] = li;
-    // Shared lists (round 3): the cell-grid ball query hands every member of a clique cell the SAME list (start = leader *
-    // 1000).  A push of label l over a list by a node of class c settles every target of that class at <= l, so another node
-    // with the same list, the same class and a label >= l has nothing to add -- in an instance collapsed onto its centre that is
-    // all but one of its first 1000 members (each used to walk the 1000 entries: 160 M list entries per clustering, 0.42 ms).
-    // lpush[slot] = smallest label pushed so far over the list starting at slot * 1000 by a node of the slot owner's class.
-    // (Keyed by the exact start: private lists have private keys, whatever the layout.)
-    if (ln > 0 && st % CL_CAP == 0) {
-        const int slot = st / CL_CAP;
-        if (slot < n && sem[slot] == si) {
-            int old = 0;
-            if (d3_lane() == 0) old = atomicMin(&lpush[slot], li);
-            old = __shfl(old, 0);
-            if (old <= li) continue;
-        }
-    }
+    const int lane = d3_lane();
+    const int nthreads = (int)(gridDim.x * blockDim.x);
     bool changed = false;
-    // A push can only lower the label of a target j > li: lab[root(j)] <= root(j) <= j at all times (a label starts as the
-    // node's own index, a root is the smallest index of its tree, labels only decrease).  The lists are ascending
-    // (ball query order), so the useless targets j <= li are a PREFIX: found with two 64-way probes instead of walked --
-    // in a collapsed instance of m points whose lists all are its first 1000 members, a member's own rank of them.
-    int e_first = 0;
-    if (ascending && ln > 0) {      // (the caller vouches for ascending lists: D3_BFS_ASCENDING)
-        const int lane = d3_lane();
-        const int p = (int)(((long long)lane * ln) >> 6);               // 64 probes, probe 0 = entry 0
-        const unsigned long long gt = __ballot(idx[st + p] > li);
-        if (gt == 0ull) {                                               // every probe <= li: only the tail behind the last probe is left
-            const int p63 = (int)((63ll * ln) >> 6);
-            const int q = p63 + lane;
-            const unsigned long long g2 = __ballot(q < ln && idx[st + (q < ln ? q : 0)] > li);
-            // (the last segment is at most ln/64 + 1 <= 17 entries long)
-            e_first = g2 ? p63 + (int)__builtin_ctzll(g2) : ln;
-        } else {
-            const int f = (int)__builtin_ctzll(gt);                     // first probe > li; the boundary lies in (probe f-1, probe f]
-            const int lo = f == 0 ? 0 : (int)(((long long)(f - 1) * ln) >> 6);
-            const int hi = (int)(((long long)f * ln) >> 6);
-            const int q = lo + lane;
-            const unsigned long long g2 = __ballot(q <= hi && idx[st + (q <= hi ? q : lo)] > li);
-            e_first = g2 ? lo + (int)__builtin_ctzll(g2) : hi;
+    for (int base = (int)(blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {      // (wave-uniform)
+        const int i = base + lane;
+        // ---- filters, one node per lane
+        bool want = false, cand = false;
+        int st = 0, ln = 0, si = 0, ri = 0, li = 0, slot = 0;
+        if (i < n) {
+            st = start_len[i * 2]; ln = start_len[i * 2 + 1];
+            // Opening sweep (ascending lists only): just the nodes without a smaller-index neighbour push -- the future seeds.  In a
+            // collapsed instance (every list = its first 1000 members) that is ONE node, whose push settles all 1000 labels without
+            // contention; the full sweep behind it then finds them settled through its cached filter read.  Without it every member
+            // pushed its own index at all later members at once: 500 k contended atomicMin per instance, most of the sweep's time
+            // (profiles/r02_q_cluster_timeline.txt: 2.1 ms).  Any sweep order reaches the same fixpoint.
+            const bool skip = minima_only && (ln == 0 || idx[st] < i);
+            if (!skip) {
+                si = sem[i];
+                ri = root[i];
+                li = cl_chase(lab, ld_dev(&lab[ri]));
+                if (li < ld_dev(&lab[ri])) atomicMin(&lab[ri], li);
+                // Worklist: a node pushes again only when its own label got smaller since its last push -- every neighbour's label
+                // was <= that value then and labels only decrease.  The verification sweep therefore walks only the lists of the
+                // nodes the previous sweep changed (the first 1000 points of a collapsed instance, not all of them).
+                if (pushed[i] != li) {
+                    pushed[i] = li;
+                    want = true;
+                    // Shared lists (round 3): the cell-grid ball query hands every member of a clique cell the SAME list (start =
+                    // leader * 1000).  A push of label l over a list by a node of class c settles every target of that class at <= l,
+                    // so another node with the same list, the same class and a label >= l has nothing to add -- in an instance
+                    // collapsed onto its centre that is all but one of its first 1000 members.  lpush[slot] = smallest label pushed
+                    // so far over the list starting at slot * 1000 by a node of the slot owner's class.  (Keyed by the exact start:
+                    // private lists have private keys, whatever the layout.)
+                    if (ln > 0 && st % CL_CAP == 0) {
+                        slot = st / CL_CAP;
+                        cand = slot < n && sem[slot] == si;
+                    }
+                }
+            }
+        }
+        // (the shared-list filter's atomic, aggregated: consecutive members of a collapsed instance carry the same (list, class, label)
+        // -- the first group of equal lanes sends ONE lane to the counter; its other members would find its label there and skip, so
+        // they skip.  64 same-address atomics per wave instruction on ~160 hot words were most of the productive sweep's time.)
+        {
+            const unsigned long long cm = __ballot(cand);
+            if (cm) {
+                const int L = (int)__builtin_ctzll(cm);
+                const int ls = __shfl(slot, L), ll = __shfl(li, L), ss = __shfl(si, L);
+                if (cand && slot == ls && li == ll && si == ss) {
+                    if (lane == L) { if (atomicMin(&lpush[slot], li) <= li) want = false; }
+                    else want = false;
+                    cand = false;
+                }
+            }
+            if (cand && atomicMin(&lpush[slot], li) <= li) want = false;
+        }
+        // ---- short lists (a surface's ~9 entries): every surviving lane walks its own, four entries in flight -- 64 nodes at once.
+        // (One after the other on the whole wave, the 135 k floor nodes of the first full sweep cost 64 x three dependent round trips
+        // per wave: 184 us.)  A target j <= li cannot be lowered whatever the list order (see below): checked per entry here.
+        if (want && ln <= CL_PUSH_SHORT) {
+            for (int e0 = 0; e0 < ln; e0 += 4) {
+                int j[4], rj[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { ok[q] = e0 + q < ln; j[q] = ok[q] ? idx[st + e0 + q] : 0; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { ok[q] = ok[q] && j[q] > li && sem[j[q]] == si; rj[q] = ok[q] ? root[j[q]] : ri; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (!ok[q] || rj[q] == ri) continue;
+                    if (lab[rj[q]] > li) { if (atomicMin(&lab[rj[q]], li) > li) changed = true; }
+                }
+            }
+            want = false;
+        }
+        // ---- the surviving nodes' long lists (capped: 1000 entries), one after the other, on the whole wave
+        unsigned long long todo = __ballot(want);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int wst = __shfl(st, src), wln = __shfl(ln, src), wsi = __shfl(si, src), wri = __shfl(ri, src), wli = __shfl(li, src);
+            // A push can only lower the label of a target j > li: lab[root(j)] <= root(j) <= j at all times (a label starts as the
+            // node's own index, a root is the smallest index of its tree, labels only decrease).  The lists are ascending
+            // (ball query order), so the useless targets j <= li are a PREFIX: found with two 64-way probes instead of walked --
+            // in a collapsed instance of m points whose lists all are its first 1000 members, a member's own rank of them.
+            int e_first = 0;
+            if (ascending && wln > 0) {      // (the caller vouches for ascending lists: D3_BFS_ASCENDING)
+                const int p = (int)(((long long)lane * wln) >> 6);               // 64 probes, probe 0 = entry 0
+                const unsigned long long gt = __ballot(idx[wst + p] > wli);
+                if (gt == 0ull) {                                               // every probe <= li: only the tail behind the last probe is left
+                    const int p63 = (int)((63ll * wln) >> 6);
+                    const int q = p63 + lane;
+                    const unsigned long long g2 = __ballot(q < wln && idx[wst + (q < wln ? q : 0)] > wli);
+                    // (the last segment is at most ln/64 + 1 <= 17 entries long)
+                    e_first = g2 ? p63 + (int)__builtin_ctzll(g2) : wln;
+                } else {
+                    const int f = (int)__builtin_ctzll(gt);                     // first probe > li; the boundary lies in (probe f-1, probe f]
+                    const int lo = f == 0 ? 0 : (int)(((long long)(f - 1) * wln) >> 6);
+                    const int hi = (int)(((long long)f * wln) >> 6);
+                    const int q = lo + lane;
+                    const unsigned long long g2 = __ballot(q <= hi && idx[wst + (q <= hi ? q : lo)] > wli);
+                    e_first = g2 ? lo + (int)__builtin_ctzll(g2) : hi;
+                }
+            }
+            // four edges per lane in flight: every edge is a chain of three dependent gathers (neighbour id -> its root ->
+            // the root's label) and a capped list is 16 passes long
+            for (int e0 = e_first + lane; e0 < wln; e0 += 256) {
+                int j[4], rj[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int e = e0 + q * 64; ok[q] = e < wln; j[q] = ok[q] ? idx[wst + e] : 0; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { ok[q] = ok[q] && sem[j[q]] == wsi; rj[q] = ok[q] ? root[j[q]] : wri; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (!ok[q] || rj[q] == wri) continue;
+                    // The filter reads through the cache: labels only ever decrease, so a stale (larger) value can at worst let an
+                    // atomicMin through that changes nothing -- it can never hide a needed update.  (An L2-bypassing load here,
+                    // once per edge of a capped list, was most of this kernel's time.)
+                    if (lab[rj[q]] > wli) { if (atomicMin(&lab[rj[q]], wli) > wli) changed = true; }
+                }
+            }
         }
     }
-    // four edges per lane in flight: every edge is a chain of three dependent gathers (neighbour id -> its root ->
-    // the root's label) and a capped list is 16 passes long
-    for (int e0 = e_first + d3_lane(); e0 < ln; e0 += 256) {
-        int j[4], rj[4];
-        bool ok[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const int e = e0 + q * 64; ok[q] = e < ln; j[q] = ok[q] ? idx[st + e] : 0; }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { ok[q] = ok[q] && sem[j[q]] == si; rj[q] = ok[q] ? root[j[q]] : ri; }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (!ok[q] || rj[q] == ri) continue;
-            // The filter reads through the cache: labels only ever decrease, so a stale (larger) value can at worst let an
-            // atomicMin through that changes nothing -- it can never hide a needed update.  (An L2-bypassing load here,
-            // once per edge of a capped list, was most of this kernel's time.)
-            if (lab[rj[q]] > li) { if (atomicMin(&lab[rj[q]], li) > li) changed = true; }
-        }
-    }
-    if (__any(changed) && d3_lane() == 0) *changed_flag = 1;
-    }
+    if (__any(changed) && lane == 0) *changed_flag = 1;
 }
 
 __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *sizes, int n) {
@@ -347,7 +396,7 @@ static int cl_count_enqueue(const int *semantic_label, const int *ball_query_idx
     // Label pushes in pairs, and the sizes / ids / offsets computed right behind them, all read back with ONE host round
     // trip: the usual case is one productive sweep plus the sweep that finds nothing left to do (the second one reports
     // through its own flag, scalars[4]); only when both sweeps still changed labels is the tail recomputed after more.
-    const int npb = nwb < 4096 ? nwb : 4096;      // label push: a bounded grid of waves walks the nodes
+    const int npb = nb < 2048 ? nb : 2048;        // label push: a bounded grid, one thread per node for the filters, a wave per surviving list
     if (it > 0) {          // (the first pair of sweeps finds both flags zeroed by cl_init_kernel: two 4-byte fill launches less per clustering)
         D3_CHECK(hipMemsetAsync(w.scalars, 0, sizeof(int), s));
         D3_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(int), s));
