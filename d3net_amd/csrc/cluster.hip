@@ -389,6 +389,7 @@ static int cl_count_enqueue(const int *semantic_label, const int *ball_query_idx
     if (it == 0) {
         cl_init_kernel<<<nb, T, 0, s>>>(w.parent, w.lab, w.sizes, w.par, w.klen, w.qln, n, w.scalars);   // (klen, qln: scratch until the fill)
         if (d3_tune(D3T_CL_HOOK) != 0) cl_hook_kernel<<<nb, T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent);
+        if (d3_tune(D3T_CL_HOOK) == 2) cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);      // (trees flattened before the unions: most edges then compare two roots without a walk)
         cl_union_kernel<<<(int)(((long long)n * CL_UG + T - 1) / T), T, 0, s>>>(semantic_label, ball_query_idxs, start_len, n, w.parent, w.scalars);
         cl_flatten_kernel<<<nb, T, 0, s>>>(w.parent, n);
         D3_LAUNCH_CHECK();

@@ -47,7 +47,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_HG_SPLITK", 256},          // largest number of 16 x 16 output tiles of a deep (K >= 8192) heads GEMM whose reduction is cut over 4 workgroups; 0: never
     {"D3_BFS3", 0},                 // 1: BFS replay of clusters <= 37,632 nodes on the lane-group-per-frontier-entry form (cl_bfs3_kernel, round 5: bit-exact, measured SLOWER than the edge-parallel hash form cl_bfs2_kernel -- 1,270 vs 925 us on the canonical scene -- so off)
     {"D3_BN_PART2", 1},             // 0: BatchNorm launches reduce the producer's whole per-workgroup partial table (rounds 1-4) instead of the 16-row fp64 second-level table
-    {"D3_CL_HOOK", 1},              // 0: the clustering's union-find starts from singletons (rounds 1-4) instead of one hook per node under a smaller-index neighbour
+    {"D3_CL_HOOK", 2},              // 0: the clustering's union-find starts from singletons (rounds 1-4); 1: one hook per node under a smaller-index neighbour first (ECL-CC init); 2 (default): + the hooked trees flattened before the unions, so that most edges find parent[i] == parent[j] with two loads and no walk (speaker step 16.59 -> 16.42 ms in-process, gpurun_out/r05_j32)
     {"D3_ACT_GRAD_BF16", 0},        // 1: gradients of BatchNorm->ReLU activations (one convolution reader) stored as bf16 (unet.hip Net::gabf): measured neutral, off
     {"D3_CL_SPEC", 1},              // 0: d3_bfs_cluster_run waits for the cluster counts before it enqueues the fill (count_ex + fill2); 1: the fill is enqueued behind the count kernels with its sizes read on the device, the host waits for the counts while the fill already runs
     {"D3_TD_FUSE_GATES", 1},        // 0: the captioner's backward step keeps its two GRU gate kernels (rounds 2-4: 6 dependent launches per step) instead of running them as epilogues of the GEMMs that complete their input (4 launches)
