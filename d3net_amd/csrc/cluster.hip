@@ -161,15 +161,19 @@ __global__ __launch_bounds__(256) void cl_union_kernel(const int *__restrict__ s
     if (!live || ln >= CL_CAP) return;
     const int si = sem[i];
     for (int e0 = sub; e0 < ln; e0 += 4 * CL_UG) {
-        int j[4], sj[4], lj[4];
+        int j[4], sj[4], lj[4], pj[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int e = e0 + q * CL_UG; j[q] = e < ln ? idx[st + e] : i; }
+        // (the neighbours' parent entries travel with their class / list length: after the hook + flatten opening almost every
+        // edge joins two nodes that already point at the same root -- two equal words, no walk, no atomic.  Equal parents are the same
+        // tree whatever other threads do meanwhile: an entry only ever moves to another ancestor of its node.)
+        const int pi = parent[i];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { sj[q] = sem[j[q]]; lj[q] = start_len[j[q] * 2 + 1]; }
+        for (int q = 0; q < 4; q++) { sj[q] = sem[j[q]]; lj[q] = start_len[j[q] * 2 + 1]; pj[q] = parent[j[q]]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             // the edge is mutual (both lists complete): handle it once, from its smaller endpoint
-            if (j[q] <= i || sj[q] != si || lj[q] >= CL_CAP) continue;
+            if (j[q] <= i || sj[q] != si || lj[q] >= CL_CAP || pj[q] == pi) continue;
             cl_union(parent, i, j[q]);
         }
     }
