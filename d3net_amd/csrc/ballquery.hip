@@ -471,23 +471,52 @@ __global__ void bqg_cells_kernel(const int *__restrict__ skey, const int *__rest
     tbl[slot].start = i; cslot[c] = slot;
     (void)mask;
 }
-// one wave per cell: point count into its hash slot, bounding box of its points (stored at the cell's first sorted position)
+// point count into the cell's hash slot, bounding box of its points (stored at the cell's first sorted position).
+// Round 5: EIGHT lanes per cell (a surface's cells hold ~4 points: a wave per cell idled 60 lanes and the launch covered n waves for
+// ~n / 4 cells: 104 -> 29 us); a cell of more than 64 points (a collapsed instance: tens of thousands) is then taken by the whole wave.
+// (The same treatment of bqg_clique_kernel -- 32 lanes per cell, one probe each -- measured no gain: 94 -> 104 us; not kept.)
+#define BQG_CB 8
 __global__ __launch_bounds__(256) void bqg_cellbox_kernel(const int *__restrict__ cstart, const int *__restrict__ cslot,
                                                          const int *__restrict__ scal, const float *__restrict__ sxyz,
                                                          BqSlot *tbl, float *cbox) {
-    const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (c >= scal[0]) return;
-    const int s0 = cstart[c], s1 = cstart[c + 1];
-    float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
-    for (int i = s0 + d3_lane(); i < s1; i += 64) {
-        const float a = sxyz[i * 3 + 0], b = sxyz[i * 3 + 1], d = sxyz[i * 3 + 2];
-        x = fminf(x, a); X = fmaxf(X, a); y = fminf(y, b); Y = fmaxf(Y, b); z = fminf(z, d); Z = fmaxf(Z, d);
+    const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = d3_lane(), sub = lane & (BQG_CB - 1);
+    const int c = gid / BQG_CB, ncell = scal[0];
+    if ((gid - lane) / BQG_CB >= ncell) return;               // (whole waves)
+    const bool live = c < ncell;
+    const int s0 = live ? cstart[c] : 0, s1 = live ? cstart[c + 1] : 0;
+    const bool big = s1 - s0 > 64;
+    if (live && !big) {
+        float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
+        for (int i = s0 + sub; i < s1; i += BQG_CB) {
+            const float a = sxyz[i * 3 + 0], b = sxyz[i * 3 + 1], d = sxyz[i * 3 + 2];
+            x = fminf(x, a); X = fmaxf(X, a); y = fminf(y, b); Y = fmaxf(Y, b); z = fminf(z, d); Z = fmaxf(Z, d);
+        }
+#pragma unroll
+        for (int o = BQG_CB / 2; o > 0; o >>= 1) {
+            x = fminf(x, __shfl_xor(x, o, BQG_CB)); y = fminf(y, __shfl_xor(y, o, BQG_CB)); z = fminf(z, __shfl_xor(z, o, BQG_CB));
+            X = fmaxf(X, __shfl_xor(X, o, BQG_CB)); Y = fmaxf(Y, __shfl_xor(Y, o, BQG_CB)); Z = fmaxf(Z, __shfl_xor(Z, o, BQG_CB));
+        }
+        if (sub == 0) {
+            float *o = cbox + (size_t)s0 * 6; o[0] = x; o[1] = y; o[2] = z; o[3] = X; o[4] = Y; o[5] = Z;
+            tbl[cslot[c]].count = s1 - s0;
+        }
     }
-    if (s1 - s0 > 1) { x = wave_min(x); y = wave_min(y); z = wave_min(z); X = wave_max(X); Y = wave_max(Y); Z = wave_max(Z); }
-    else { x = __shfl(x, 0); y = __shfl(y, 0); z = __shfl(z, 0); X = x; Y = y; Z = z; }
-    if (d3_lane() == 0) {
-        float *o = cbox + (size_t)s0 * 6; o[0] = x; o[1] = y; o[2] = z; o[3] = X; o[4] = Y; o[5] = Z;
-        tbl[cslot[c]].count = s1 - s0;
+    unsigned long long todo = __ballot(live && big && sub == 0);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int b0 = __shfl(s0, src), b1 = __shfl(s1, src), bc = __shfl(c, src);
+        float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
+        for (int i = b0 + lane; i < b1; i += 64) {
+            const float a = sxyz[i * 3 + 0], b = sxyz[i * 3 + 1], d = sxyz[i * 3 + 2];
+            x = fminf(x, a); X = fmaxf(X, a); y = fminf(y, b); Y = fmaxf(Y, b); z = fminf(z, d); Z = fmaxf(Z, d);
+        }
+        x = wave_min(x); y = wave_min(y); z = wave_min(z); X = wave_max(X); Y = wave_max(Y); Z = wave_max(Z);
+        if (lane == 0) {
+            float *o = cbox + (size_t)b0 * 6; o[0] = x; o[1] = y; o[2] = z; o[3] = X; o[4] = Y; o[5] = Z;
+            tbl[cslot[bc]].count = b1 - b0;
+        }
     }
 }
 // one thread per cell: candidates and bounding box of its 27-cell neighbourhood -> leader (smallest member) of a clique cell
@@ -821,7 +850,7 @@ static int bqg_padded(const float *xyz, const int *batch_idxs, int n, float radi
     rc = d3_exclusive_scan_i32(g.head, g.rid, n, g.temp, g.temp_bytes, s);
     if (rc) return rc;
     bqg_cells_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.head, g.rid, n, g.cstart, g.cslot, g.tbl, g.cap - 1, g.scal);
-    bqg_cellbox_kernel<<<(n + 3) / 4, 256, 0, s>>>(g.cstart, g.cslot, g.scal, g.sxyz, g.tbl, g.cbox);          // (<= n cells)
+    bqg_cellbox_kernel<<<(int)(((long long)n * BQG_CB + 255) / 256), 256, 0, s>>>(g.cstart, g.cslot, g.scal, g.sxyz, g.tbl, g.cbox);          // (<= n cells)
     bqg_clique_kernel<<<(n + 255) / 256, 256, 0, s>>>(g.skey, g.sidx, g.cstart, g.cslot, g.scal, g.tbl, g.cap - 1, g.cbox,
                                                      radius * radius, g.tlead);
     if (d3_tune(D3T_BQ_HALF) != 0) {
