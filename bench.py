@@ -801,8 +801,8 @@ def main():
                                         "no loss scaling; the reference itself trains fp32)" if config == "joint" else "")),
                        "setup": "1 untimed dry-run step (workspace allocation, code-object loads) + %d untimed settle steps (a fresh "
                                 "box reaches its sustained rate only after some tens of steps) before the --warmup steps" % settle_steps,
-                       "input_prefetch": ("mode %d: step i+1's input stage (voxel features + backbone coordinate maps, parameter-free) is built on a side "
-                                          "stream inside step i; K builds in the K timed steps" % PG_MOD.PREFETCH_MODE) if PG_MOD.PREFETCH_MODE else "off"},
+                       "input_prefetch": ("mode %d: the next step's parameter-free input stage is built on a side stream inside the step "
+                                          "(K builds in the K timed steps)" % PG_MOD.PREFETCH_MODE) if PG_MOD.PREFETCH_MODE else "off"},
             "final_loss": final_loss, "fp32_exact": fp32, "strong_scaling_ceiling": ceiling,
             "eval_program": "value = the bf16 TRAINING step; eval()/mAP/CIDEr run another program (fp32 twin executors, minkowski.exact_for; DESIGN 5.1)",
             "metric_parity": {"policy": "training steps (this line's value) run bf16 MFMA operands; evaluation -- every mAP / CIDEr the library reports -- runs "

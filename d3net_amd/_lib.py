@@ -62,6 +62,9 @@ SIGNATURES = {
     "d3_kmap_k3_pack16": (i32, [vp, i32, vp, vp, vp]),
     "d3_kmap_k3_16": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp]),
     "d3_net_set_k3_16": (i32, [vp, vp, vp]),
+    "d3_net_padded_channels": (i32, [vp]),
+    "d3_net_padcast": (i32, [vp, vp, vp, i64, vp]),
+    "d3_net_set_padded_input": (i32, [vp, vp]),
     "d3_spconv_t16_launches": (C.c_longlong, []),
     "d3_kmap_down_count": (i32, [vp, i32, i32, vp, sz, vp, vp, pi, vp]),
     "d3_kmap_down_fill": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, i32, vp]),

@@ -667,6 +667,9 @@ struct Net {
     // processed op chunk_op[k] (ops run in reverse program order, parameters are registered in program order: a chunk is a
     // contiguous tail range); two events per chunk -- side stream (weight-gradient reductions) and caller's stream
     // (BatchNorm parameter gradients) -- let a collective stream start the chunk's all-reduce while the backward goes on
+    int xp_op = -1;                    // index of the PADCAST op of the stem input (there is at most one)
+    int xp_tensor = -1;                // the PADCAST op's output tensor (the stem's zero-padded bf16 input), -1: none
+    const void *xp_ext = nullptr;      // its values prepared by the caller (d3_net_padcast) for the next forward / backward call, or NULL
     std::vector<const void *> k3_16;   // per level: 16-bit delta form of the k3 table for the next forward / backward call (or NULL)
     std::vector<const int *> ok16;
     std::vector<int> chunk_op;
@@ -735,6 +738,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         } else if (o.type == OP_STATS) {
             o.stats = 1;
         }
+        if (o.type == OP_PADCAST && n->xp_op < 0 && n->T[(size_t)o.in].buf < 0) { n->xp_op = (int)n->ops.size(); n->xp_tensor = o.out; }
         n->ops.push_back(o);
     }
     // statistics sources of every BNACT: producers whose columns lie inside the BN input's column range
@@ -1002,6 +1006,32 @@ extern "C" int d3_net_set_k3_16(void *h, const void *const *k3_16, const int *co
             if (k3_16[l] && ok16[l]) { n->k3_16[(size_t)l] = k3_16[l]; n->ok16[(size_t)l] = ok16[l]; }
     return 0;
 }
+// Round 5 (input prefetch): the stem's zero-padded bf16 input prepared OUTSIDE the forward -- d3_net_padcast writes it (M rows x
+// d3_net_padded_channels() bf16) from the fp32 voxel features, d3_net_set_padded_input hands it to the NEXT d3_net_forward /
+// d3_net_backward call (like the 16-bit tables: one call, then dropped), which skips its own PADCAST launch and reads the stem's
+// operand from there.  bf16 executors with a stem only (padded channels 0 otherwise).
+extern "C" int d3_net_padded_channels(void *h) {
+    Net *n = (Net *)h;
+    if (!n || n->f32 || n->xp_tensor < 0 || n->T[(size_t)n->xp_tensor].dtype != 1) return 0;
+    return n->T[(size_t)n->xp_tensor].C;
+}
+extern "C" int d3_net_padcast(void *h, const void *input, void *out, long long M, void *stream) {
+    D3_CLEAR();
+    Net *n = (Net *)h;
+    const int Cd = d3_net_padded_channels(h);
+    if (!n || Cd <= 0 || !input || !out || M < 0) return D3_ERR_ARG;
+    const int Cs = n->T[(size_t)n->ops[(size_t)n->xp_op].in].C;
+    const long long total = M * (Cd / 2);
+    if (total > 0) un_padcast_kernel<<<(int)((total + 255) / 256), 256, 0, d3_stream(stream)>>>((const float *)input, (unsigned short *)out, M, Cs, Cd);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int d3_net_set_padded_input(void *h, const void *xp) {
+    Net *n = (Net *)h;
+    if (!n) return D3_ERR_ARG;
+    n->xp_ext = d3_net_padded_channels(h) > 0 ? xp : nullptr;
+    return 0;
+}
 // make `stream` wait until chunk k of the LAST d3_net_backward call is complete (its events were recorded by that call)
 extern "C" int d3_net_chunk_wait(void *h, int k, void *stream) {
     Net *n = (Net *)h;
@@ -1115,6 +1145,7 @@ static void conv_tables(const OpD &o, const Maps &m, const int *&tf, const int *
 static inline char *tptr(const Net *n, char *arena, const void *input, int tensor) {
     const TensorD &t = n->T[tensor];
     if (t.buf < 0) return (char *)input;
+    if (tensor == n->xp_tensor && n->xp_ext) return (char *)n->xp_ext;      // (prepared outside the call: d3_net_set_padded_input)
     return arena + n->B[t.buf].off + (size_t)t.coff * esize(t.dtype);
 }
 
@@ -1124,7 +1155,7 @@ static inline char *tptr(const Net *n, char *arena, const void *input, int tenso
 // the convolution that consumes it must not hand the table to an unrelated K = 27 convolution on this thread).
 void d3_spconv_next_tbl16(const void *tbl16, const int *ok16);
 static void net_drop_k3_16(Net *n) {
-    if (n) { n->k3_16.assign(n->k3_16.size(), nullptr); n->ok16.assign(n->ok16.size(), nullptr); }
+    if (n) { n->k3_16.assign(n->k3_16.size(), nullptr); n->ok16.assign(n->ok16.size(), nullptr); n->xp_ext = nullptr; }
     d3_spconv_next_tbl16(nullptr, nullptr);
     d3_spconv_next_part2(nullptr);
 }
@@ -1191,6 +1222,7 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
     }
     for (auto &o : n->ops) {
         if (o.type == OP_PADCAST) {
+            if (n->xp_ext && n->xp_tensor >= 0 && &o == &n->ops[(size_t)n->xp_op]) continue;      // (the caller prepared it: input prefetch)
             const TensorD &to = n->T[o.out];
             const long long M = n->rows[to.level];
             const int Cs = n->T[o.in].C;

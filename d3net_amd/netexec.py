@@ -287,6 +287,18 @@ class NativeUNet:
                     v.copy_(p.grad)
                 p.grad = v
 
+    def pad_input(self, feats):
+        """the stem's zero-padded bf16 operand of `feats` (M, in_channels) fp32, prepared outside the forward (the input prefetch: the
+        launch the forward would issue first), or None when this executor has no such operand (no stem / reference precision)"""
+        L = _lib.lib()
+        cp = L.d3_net_padded_channels(self._net())
+        if cp <= 0 or not (feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous() and feats.size(1) == self.in_channels):
+            return None
+        xp = torch.empty((feats.size(0), cp), dtype=torch.bfloat16, device=feats.device)
+        with _on(feats.device):
+            check(L.d3_net_padcast(self._net(), C.c_void_p(feats.data_ptr()), C.c_void_p(xp.data_ptr()), feats.size(0), _stream()), "net_padcast")
+        return xp
+
     def maps(self, cm):
         k3, child, up, rows, keep = [], [], [], [], []
         k16, ok16 = [], []
@@ -334,8 +346,15 @@ class _NetFunction(Function):
         arena_bytes, grad_bytes, out_off = net._plan_for(rows)
         arena = torch.empty(arena_bytes, dtype=torch.uint8, device=dev)
         pp = net._param_ptrs()
+        # (input prefetch: the stem's padded bf16 operand was prepared with the coordinate maps -- NativeUNet.pad_input)
+        xp = getattr(cm, "padded_input", None)
+        if xp is not None and not (torch.is_tensor(xp) and xp.is_cuda and xp.dtype == torch.bfloat16 and xp.is_contiguous() and
+                                   xp.size(0) == feats.size(0) and xp.size(1) == L.d3_net_padded_channels(net._net())):
+            xp = None
         with _on(dev):
             check(L.d3_net_set_k3_16(net._net(), keep[-1][0], keep[-1][1]), "net_set_k3_16")
+            if xp is not None:
+                check(L.d3_net_set_padded_input(net._net(), C.c_void_p(xp.data_ptr())), "net_set_padded_input")
             check(L.d3_net_forward(net._net(), pp, k3, child, up, C.c_void_p(feats.data_ptr()), C.c_void_p(arena.data_ptr()),
                                    int(training), _stream()), "net_forward")
         if training:
@@ -349,6 +368,7 @@ class _NetFunction(Function):
             net.debug_pairs = [int((t >= 0).sum()) for t in keep if torch.is_tensor(t) and t.dim() == 2 and t.size(1) == 27]
         ctx.net, ctx.maps, ctx.arena, ctx.feats, ctx.grad_bytes = net, (k3, child, up, keep), arena, feats, grad_bytes
         ctx.rows = rows
+        ctx.xp = xp
         ctx.cm = cm if hasattr(cm, "k3_16") else None
         ctx.training = training
         return out
@@ -391,6 +411,8 @@ class _NetFunction(Function):
             k16 = ((C.c_void_p * n_)(*ptrs), (C.c_void_p * n_)(*ptrs))
         with _on(dev):
             check(L.d3_net_set_k3_16(net._net(), k16[0], k16[1]), "net_set_k3_16")
+            if ctx.xp is not None:
+                check(L.d3_net_set_padded_input(net._net(), C.c_void_p(ctx.xp.data_ptr())), "net_set_padded_input")
             check(L.d3_net_backward(net._net(), net._param_ptrs(), k3, child, up, C.c_void_p(ctx.feats.data_ptr()),
                                     C.c_void_p(ctx.arena.data_ptr()), C.c_void_p(garena.data_ptr()), C.c_void_p(gout.data_ptr()),
                                     pg, acc, C.c_void_p(gin.data_ptr()) if gin is not None else None, _stream()), "net_backward")

@@ -121,6 +121,7 @@ class InputPrefetcher:
         return cur
 
 
+PREFETCH_PADCAST = 1    # (A/B switch: the prefetch stage also prepares the stem's padded bf16 operand)
 EARLY_POINT_GRADS = 1   # (A/B switch of tools/ab.py; the per-model switch is PointGroup.early_point_grads)
 PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
 
@@ -324,7 +325,10 @@ class PointGroup(nn.Module):
                         side.wait_event(gate)
                         cm, vf = self._input_stage(t.inputs)
                         if cm is not None:
-                            self._exec("backbone", exact=ME.exact_for(training, "backbone")).maps(cm)   # pyramid counts (host round trip) + all kernel maps
+                            ex = self._exec("backbone", exact=ME.exact_for(training, "backbone"))
+                            ex.maps(cm)   # pyramid counts (host round trip) + all kernel maps
+                            if PREFETCH_PADCAST:
+                                cm.padded_input = ex.pad_input(vf)      # the stem's zero-padded bf16 operand (the forward's first launch)
                         ev = torch.cuda.Event()
                         ev.record(side)
                     t.cm, t.voxel_feats, t.event = cm, vf, ev

@@ -384,6 +384,14 @@ int d3_net_set_chunks(void *net, const int *op_idx, int nchunks);
  * non-NULL pointer, unused by the kernels).  The arrays are copied; the tables must stay alive like the dense ones.
  * d3_spconv_t16_launches: launches so far that read a 16-bit table (tests). */
 int d3_net_set_k3_16(void *net, const void *const *k3_16, const int *const *ok16);
+/* Round 5 (input prefetch): the stem's zero-padded bf16 input prepared outside the forward.  d3_net_padded_channels: its width (0: this
+ * executor has no such operand -- no stem, or the reference-precision program).  d3_net_padcast: (M, C_in) fp32 voxel features -> (M,
+ * padded) bf16, the launch d3_net_forward would issue first.  d3_net_set_padded_input: hands the prepared buffer to the NEXT
+ * d3_net_forward / d3_net_backward call (one call, then dropped), which reads the stem's operand from it.  No reference counterpart
+ * (MinkowskiEngine convolves the fp32 features directly, model/pointgroup.py:70). */
+int d3_net_padded_channels(void *net);
+int d3_net_padcast(void *net, const void *input, void *out, long long M, void *stream);
+int d3_net_set_padded_input(void *net, const void *xp);
 long long d3_spconv_t16_launches(void);
 int d3_net_chunk_wait(void *net, int k, void *stream);
 

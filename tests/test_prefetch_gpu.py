@@ -63,6 +63,9 @@ def test_prefetched_step_equals_inline(dev, setup, at):
     model.load_state_dict(state)
     loss, d, grads = _step(model, b)
     assert ticket.cm is not None and d["voxel_feats"] is ticket.voxel_feats          # the prefetched tensors were the ones consumed
+    xp = getattr(ticket.cm, "padded_input", None)                                    # ... incl. the stem's padded bf16 operand
+    assert xp is not None and xp.dtype == torch.bfloat16 and xp.shape[0] == ticket.voxel_feats.shape[0] and xp.shape[1] % 8 == 0
+    assert torch.equal(xp[:, :ticket.voxel_feats.shape[1]].float(), ticket.voxel_feats.to(torch.bfloat16).float()) and bool((xp[:, ticket.voxel_feats.shape[1]:] == 0).all())
     rl, rd, rg = ref[1]
     assert torch.equal(d["voxel_feats"], rd["voxel_feats"])
     assert torch.equal(d["proposal_scores"][1], rd["proposal_scores"][1]) and torch.equal(d["proposal_scores"][2], rd["proposal_scores"][2])
