@@ -121,6 +121,7 @@ class InputPrefetcher:
         return cur
 
 
+PREFETCH_TIMEOUT_S = 120
 PREFETCH_PADCAST = 1    # (A/B switch: the prefetch stage also prepares the stem's padded bf16 operand)
 EARLY_POINT_GRADS = 1   # (A/B switch of tools/ab.py; the per-model switch is PointGroup.early_point_grads)
 PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
@@ -345,7 +346,11 @@ class PointGroup(nn.Module):
         if t.future is None:            # never started (no clustering stage since prefetch()): the caller runs the stage inline
             t.inputs = None
             return None
-        t.future.result()
+        try:
+            t.future.result(timeout=PREFETCH_TIMEOUT_S)
+        except Exception as e:      # (concurrent.futures.TimeoutError: fail loudly instead of hanging the step for ever)
+            raise RuntimeError("PointGroup: the input prefetch of this batch did not finish within %d s (helper thread stuck?); "
+                               "pointgroup.PREFETCH_MODE = 0 disables the look-ahead" % PREFETCH_TIMEOUT_S) from e
         t.inputs = None
         if t.error is not None:
             raise t.error
@@ -353,7 +358,7 @@ class PointGroup(nn.Module):
         # was recorded before that ticket's last use may still be allocating: the newest helper (the only one that can be running) is
         # waited for first -- it finished long ago unless two detector passes per step are prefetched back to back.
         if self._pf_inflight is not None:
-            self._pf_inflight.result()
+            self._pf_inflight.result(timeout=PREFETCH_TIMEOUT_S)
         self._pf_live = [self._pf_live[1], t]
         if not same or t.voxel_feats is None:
             return None
