@@ -57,6 +57,8 @@ SIGNATURES = {
     "d3_bfs_cluster_erec_bytes": (sz, [i64]),
     "d3_bfs_cluster_fill2": (i32, [vp, vp, vp, i32, vp, sz, vp, sz, i64, vp, vp, i32, i32, vp]),
     "d3_bfs_cluster_run": (i32, [vp, vp, vp, i32, i32, vp, sz, vp, sz, i64, i32, vp, i64, vp, i64, pi, pi, vp]),
+    "d3_bfs_cluster_begin": (i32, [vp, vp, vp, i32, i32, vp, sz, vp, sz, i64, i32, vp, i64, vp, i64, C.POINTER(vp), vp]),
+    "d3_bfs_cluster_end": (i32, [vp, pi, pi]),
     "d3_coordmap_ws_bytes": (sz, [i32]),
     "d3_kmap_k3": (i32, [vp, i32, i32, vp, sz, vp, vp]),
     "d3_kmap_k3_pack16": (i32, [vp, i32, vp, vp, vp]),

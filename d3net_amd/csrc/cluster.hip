@@ -1351,32 +1351,48 @@ static std::mutex g_clt_mu;
 static std::vector<ClTicket *> g_clt_free;
 #define CL_SPEC_GRID 2048      // cluster slots of the speculative replay launch (more kept clusters: a second launch once the count is known)
 
-extern "C" int d3_bfs_cluster_run(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
-                                  void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
-                                  int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
-                                  int *sumNPoint_host, int *nCluster_host, void *stream) {
-    if (!sumNPoint_host || !nCluster_host) return D3_ERR_ARG;
+// begin / end (round 5): d3_bfs_cluster_run cut at its one host wait.  `begin` enqueues the count kernels, the copy of their scalars,
+// an event and the whole speculative fill, and returns a ticket; `end` waits for the event and finishes (the rare cases: more label
+// sweeps, kept clusters beyond the speculative grid, clusters beyond the LDS bitmap).  ONE host thread can so keep two clusterings
+// (PointGroup's shifted and unshifted branch, on two streams) in flight: begin, begin, end, end -- no helper thread whose wake-up
+// sits on the step's critical path (on a slow host the wait for the helper's branch grew from 0.5 to 0.8 ms: profiles r05_d vs r05_e).
+// When the speculative form is not available (D3_CL_SPEC=0, debug, cap_points < n) `begin` runs the whole blocking call.
+struct ClRun {
+    const int *sem, *idx, *start_len; int n, threshold; void *ws; size_t ws_bytes; void *erec; size_t erec_bytes; long long nActive; int flags;
+    int *cluster_idxs; long long cap_points; int *cluster_offsets; long long cap_clusters; void *stream;
+    ClTicket *t; int slots; int done; int rc; int sumNPoint, nCluster;
+};
+extern "C" int d3_bfs_cluster_end(void *ticket, int *sumNPoint_host, int *nCluster_host);
+extern "C" int d3_bfs_cluster_begin(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
+                                    void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
+                                    int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
+                                    void **ticket, void *stream) {
+    if (!ticket) return D3_ERR_ARG;
+    *ticket = nullptr;
+    ClRun *r = new ClRun{semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, erec, erec_bytes, nActive, flags,
+                         cluster_idxs, cap_points, cluster_offsets, cap_clusters, stream, nullptr, 0, 0, 0, 0, 0};
     if (n <= 0 || d3_tune(D3T_CL_SPEC) == 0 || d3_tune(D3T_BFS3) != 0 || d3_tune(D3T_BFS_DEBUG) != 0 || cap_points < n) {
-        int rc = cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, sumNPoint_host, nCluster_host, flags, stream);
-        if (rc) return rc;
-        if (n <= 0) return 0;
-        if ((long long)*sumNPoint_host > cap_points || (long long)*nCluster_host > cap_clusters) return D3_ERR_WORKSPACE;
-        return d3_bfs_cluster_fill2(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs,
-                                    cluster_offsets, *sumNPoint_host, *nCluster_host, stream);
+        int S = 0, P = 0;
+        int rc = cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, &S, &P, flags, stream);
+        if (!rc && n > 0) {
+            if ((long long)S > cap_points || (long long)P > cap_clusters) rc = D3_ERR_WORKSPACE;
+            else rc = d3_bfs_cluster_fill2(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs,
+                                           cluster_offsets, S, P, stream);
+        }
+        r->done = 1; r->rc = rc; r->sumNPoint = S; r->nCluster = P;
+        *ticket = r;
+        return rc;
     }
     // Speculative form: the count kernels, the copy of their scalars and an event are enqueued, then the WHOLE fill with its sizes
-    // read on the device (upper-bound grids), and only then the host waits -- for the event, not for the stream: while it reads the
-    // counts the record pass and the level replay are already running.  The two-call form left the stream empty from the count's
-    // synchronisation until the fill's seven launches had been issued (40 - 70 us each next to another launching thread:
-    // gpurun_out/r05_j12/cluster_timeline.txt).  Should the label push not have converged in its first pair of sweeps (both sweeps
-    // still changed labels: capped lists in a chain, never seen in the bench workloads), the speculative fill's output is
-    // overwritten by the regular path below.
+    // read on the device (upper-bound grids); the host waits later (`end`) -- for the event, not for the stream: while it reads the
+    // counts the record pass and the level replay are already running.  Should the label push not have converged in its first pair
+    // of sweeps (both sweeps still changed labels: capped lists in a chain), the speculative fill's output is overwritten by the
+    // regular path in `end`.
     D3_CLEAR();
-    *sumNPoint_host = 0; *nCluster_host = 0;
-    if (erec == nullptr || erec_bytes < d3_bfs_cluster_erec_bytes(nActive)) return D3_ERR_WORKSPACE;
-    const int asc = (flags & D3_BFS_ASCENDING) ? 1 : 0;
+    int rc = 0;
     ClWs w;
-    if (!cl_carve(ws, ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    if (erec == nullptr || erec_bytes < d3_bfs_cluster_erec_bytes(nActive) || !cl_carve(ws, ws_bytes, n, w)) { delete r; return D3_ERR_WORKSPACE; }
+    const int asc = (flags & D3_BFS_ASCENDING) ? 1 : 0;
     hipStream_t s = d3_stream(stream);
     ClTicket *t = nullptr;
     {
@@ -1387,43 +1403,72 @@ extern "C" int d3_bfs_cluster_run(const int *semantic_label, const int *ball_que
         t = new ClTicket{nullptr, nullptr};
         hipError_t he = hipHostMalloc((void **)&t->pinned, 8 * sizeof(int));
         if (he == hipSuccess) he = hipEventCreateWithFlags(&t->ev, hipEventDisableTiming);
-        if (he != hipSuccess) { delete t; return (int)he; }
+        if (he != hipSuccess) { delete t; delete r; return (int)he; }
     }
-    struct Back { ClTicket *t; ~Back() { std::lock_guard<std::mutex> lk(g_clt_mu); g_clt_free.push_back(t); } } back{t};
-    int rc = cl_count_enqueue(semantic_label, ball_query_idxs, start_len, n, threshold, w, asc, 0, t->pinned, s);
-    if (rc) return rc;
-    D3_CHECK(hipEventRecord(t->ev, s));
-    const int slots = (int)(cap_clusters < CL_SPEC_GRID ? cap_clusters : CL_SPEC_GRID);
+    r->t = t;
+    auto fail = [&](int code) { { std::lock_guard<std::mutex> lk(g_clt_mu); g_clt_free.push_back(t); } delete r; return code; };
+    rc = cl_count_enqueue(semantic_label, ball_query_idxs, start_len, n, threshold, w, asc, 0, t->pinned, s);
+    if (rc) return fail(rc);
+    if (hipEventRecord(t->ev, s) != hipSuccess) return fail(D3_ERR_ARG);
+    r->slots = (int)(cap_clusters < CL_SPEC_GRID ? cap_clusters : CL_SPEC_GRID);
     // (cluster_offsets has cap_clusters + 1 entries and cluster_idxs n rows: whatever the device counts turn out to be, they fit)
     rc = cl_fill2_impl(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs, cluster_offsets,
-                       n, slots > 0 ? slots : 1, true, 0, stream);
-    if (rc) return rc;
-    D3_CHECK(hipEventSynchronize(t->ev));
+                       n, r->slots > 0 ? r->slots : 1, true, 0, stream);
+    if (rc) return fail(rc);
+    *ticket = r;
+    return 0;
+}
+extern "C" int d3_bfs_cluster_end(void *ticket, int *sumNPoint_host, int *nCluster_host) {
+    if (!ticket || !sumNPoint_host || !nCluster_host) return D3_ERR_ARG;
+    ClRun *r = (ClRun *)ticket;
+    struct Free { ClRun *r; ~Free() { if (r->t) { std::lock_guard<std::mutex> lk(g_clt_mu); g_clt_free.push_back(r->t); } delete r; } } fr{r};
+    *sumNPoint_host = 0; *nCluster_host = 0;
+    if (r->done) { *sumNPoint_host = r->sumNPoint; *nCluster_host = r->nCluster; return r->rc; }
+    D3_CLEAR();
+    const int n = r->n;
+    hipStream_t s = d3_stream(r->stream);
+    ClWs w;
+    if (!cl_carve(r->ws, r->ws_bytes, n, w)) return D3_ERR_WORKSPACE;
+    const int asc = (r->flags & D3_BFS_ASCENDING) ? 1 : 0;
+    D3_CHECK(hipEventSynchronize(r->t->ev));
     int h[6];
-    for (int k = 0; k < 6; k++) h[k] = t->pinned[k];
+    for (int k = 0; k < 6; k++) h[k] = r->t->pinned[k];
+    int rc = 0;
     if (h[0] && h[4]) {      // not converged: more sweeps, then the regular fill over the speculative one
         for (int it = 2;; it += 2) {
-            rc = cl_count_enqueue(semantic_label, ball_query_idxs, start_len, n, threshold, w, asc, it, h, s);
+            rc = cl_count_enqueue(r->sem, r->idx, r->start_len, n, r->threshold, w, asc, it, h, s);
             if (rc) return rc;
             D3_CHECK(hipStreamSynchronize(s));
             if (!h[0] || !h[4] || it >= n + 2) break;
         }
         *nCluster_host = h[1]; *sumNPoint_host = h[2];
-        g_cl_checked_ws = ws; g_cl_short_lists = h[5] == 0;
-        if ((long long)h[2] > cap_points || (long long)h[1] > cap_clusters) return D3_ERR_WORKSPACE;
-        return d3_bfs_cluster_fill2(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs,
-                                    cluster_offsets, h[2], h[1], stream);
+        g_cl_checked_ws = r->ws; g_cl_short_lists = h[5] == 0;
+        if ((long long)h[2] > r->cap_points || (long long)h[1] > r->cap_clusters) return D3_ERR_WORKSPACE;
+        return d3_bfs_cluster_fill2(r->sem, r->idx, r->start_len, n, r->ws, r->ws_bytes, r->erec, r->erec_bytes, r->nActive, r->cluster_idxs,
+                                    r->cluster_offsets, h[2], h[1], r->stream);
     }
     *nCluster_host = h[1]; *sumNPoint_host = h[2];
-    g_cl_checked_ws = ws; g_cl_short_lists = h[5] == 0;
-    if ((long long)h[1] > cap_clusters) return D3_ERR_WORKSPACE;      // (cannot happen for cap_clusters >= n / threshold: kept clusters have >= threshold points)
-    if (h[1] > slots)        // kept clusters beyond the speculative grid: their replay now, on the tables the first launch built
-        rc = cl_fill2_impl(semantic_label, ball_query_idxs, start_len, n, ws, ws_bytes, erec, erec_bytes, nActive, cluster_idxs, cluster_offsets,
-                           h[2], h[1], false, slots, stream);
+    g_cl_checked_ws = r->ws; g_cl_short_lists = h[5] == 0;
+    if ((long long)h[1] > r->cap_clusters) return D3_ERR_WORKSPACE;      // (cannot happen for cap_clusters >= n / threshold: kept clusters have >= threshold points)
+    if (h[1] > r->slots)        // kept clusters beyond the speculative grid: their replay now, on the tables the first launch built
+        rc = cl_fill2_impl(r->sem, r->idx, r->start_len, n, r->ws, r->ws_bytes, r->erec, r->erec_bytes, r->nActive, r->cluster_idxs, r->cluster_offsets,
+                           h[2], h[1], false, r->slots, r->stream);
     if (rc) return rc;
     if (h[2] > B2_MAXSIZE && h[1] > 0)      // clusters beyond the LDS bitmap: the generic level loop (none can exist when all kept points together fit)
-        cl_bfs_kernel<<<h[1], CL_BFS_THREADS, 0, s>>>(semantic_label, ball_query_idxs, start_len, w.own, w.seeds, w.koff, w.sizes, w.par, w.queue,
-                                                     w.fcnt, w.qln, cluster_idxs, B2_MAXSIZE);
+        cl_bfs_kernel<<<h[1], CL_BFS_THREADS, 0, s>>>(r->sem, r->idx, r->start_len, w.own, w.seeds, w.koff, w.sizes, w.par, w.queue,
+                                                     w.fcnt, w.qln, r->cluster_idxs, B2_MAXSIZE);
     D3_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int d3_bfs_cluster_run(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
+                                  void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
+                                  int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
+                                  int *sumNPoint_host, int *nCluster_host, void *stream) {
+    if (!sumNPoint_host || !nCluster_host) return D3_ERR_ARG;
+    void *ticket = nullptr;
+    const int rc = d3_bfs_cluster_begin(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, erec, erec_bytes, nActive, flags,
+                                        cluster_idxs, cap_points, cluster_offsets, cap_clusters, &ticket, stream);
+    if (!ticket) { *sumNPoint_host = 0; *nCluster_host = 0; return rc; }
+    const int rc2 = d3_bfs_cluster_end(ticket, sumNPoint_host, nCluster_host);
+    return rc ? rc : rc2;
 }

@@ -121,6 +121,7 @@ class InputPrefetcher:
         return cur
 
 
+CLUSTER_THREAD = 0      # 1: the shifted clustering branch on a helper thread (rounds 2-4); 0: both branches from the step's thread (begin / end)
 PREFETCH_TIMEOUT_S = 120
 PREFETCH_PADCAST = 1    # (A/B switch: the prefetch stage also prepares the stem's padded bf16 operand)
 EARLY_POINT_GRADS = 1   # (A/B switch of tools/ab.py; the per-model switch is PointGroup.early_point_grads)
@@ -586,7 +587,32 @@ class PointGroup(nn.Module):
                 _mark("cl_prepare")
                 self._kick_prefetch("cluster")          # (a pending input prefetch starts here: the clustering leaves most of the chip idle)
                 cur = torch.cuda.current_stream()
-                if self.concurrent_clustering:
+                if self.concurrent_clustering and not CLUSTER_THREAD:
+                    # Round 5: BOTH branches from this thread -- begin (everything enqueued: ball query, count kernels, the fill with
+                    # its sizes read on the device), begin, then the two ends (each waits for its count's event only).  The helper
+                    # thread of rounds 2-4 sat on the critical path with its wake-ups and interpreter-lock hand-overs.
+                    side = self._side_stream(coords_.device)
+                    side.wait_stream(cur)
+
+                    def begin(xyz, mean_active, tag):
+                        padded = pointgroup_ops.ballquery_batch_p_padded(xyz, batch_idxs_, batch_offsets_, self.cluster_radius, ws_tag=tag)
+                        if padded is None:
+                            return None
+                        return pointgroup_ops.bfs_cluster_begin(semantic_preds_, padded[0], padded[1], self.cluster_npoint_thre, True, ws_tag=tag)
+                    with torch.cuda.stream(side):
+                        hs = begin(shifted_xyz, self.cluster_shift_meanActive, "s")       # (the longer chain first)
+                    hm = begin(coords_, self.cluster_meanActive, "m")
+                    _mark("cl_ballquery")
+                    self._kick_prefetch("bfs")
+                    self._early_point_losses(data_dict)
+                    first = pointgroup_ops.bfs_cluster_end(hm) if hm is not None else cluster_branch(coords_, self.cluster_meanActive)
+                    _mark("cl_bfs")
+                    with torch.cuda.stream(side):
+                        shifted = pointgroup_ops.bfs_cluster_end(hs) if hs is not None else cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
+                    cur.wait_stream(side)
+                    for t in shifted:
+                        t.record_stream(cur)
+                elif self.concurrent_clustering:
                     side = self._side_stream(coords_.device)
                     side.wait_stream(cur)
 

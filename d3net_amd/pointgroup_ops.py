@@ -233,7 +233,7 @@ class BallQueryBatchP(Function):
 ballquery_batch_p = BallQueryBatchP.apply
 
 
-def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=2 << 30):
+def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=2 << 30, ws_tag=""):
     """Sync-free ball query for callers that hand the result straight to `bfs_cluster`: every point owns a fixed slot
     of `cap` entries (start_len[q] = (s * cap, len) with s = q, or the leader of q's clique cell whose list q shares:
     csrc/ballquery.hip), so there is no nActive to fetch, no scan and no compaction.  Same
@@ -251,7 +251,7 @@ def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_byte
     with _on(dev):
         start_len = torch.empty((n, 2), dtype=torch.int32, device=dev)
         idx = torch.empty(n * cap, dtype=torch.int32, device=dev)
-        ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bqp")
+        ws = _workspace(L.d3_ballquery_ws_bytes(n), dev, "bqp" + ws_tag)      # (ws_tag: two clusterings driven by ONE thread need two workspaces)
         check(L.d3_ballquery_padded(_ptr(coords), _ptr(batch_idxs), _ptr(batch_offsets), n, float(radius), _ptr(start_len),
                                     _ptr(ws), ws.numel(), _ptr(idx), _stream()), "ballquery_padded")
     return idx, start_len
@@ -305,6 +305,51 @@ class BFSCluster(Function):
 
 
 bfs_cluster = BFSCluster.apply
+
+
+class _ClusterRun:
+    """an enqueued clustering (d3_bfs_cluster_begin): its buffers stay referenced until bfs_cluster_end"""
+    __slots__ = ("ticket", "keep", "cluster_idxs", "cluster_offsets", "N", "dev")
+
+
+def bfs_cluster_begin(semantic_label, ball_query_idxs, start_len, threshold, ascending=False, ws_tag=""):
+    """`bfs_cluster` cut at its one host wait (d3_bfs_cluster_begin / _end): everything is enqueued on the current stream here, the
+    cluster counts are read by `bfs_cluster_end`.  One thread keeps several clusterings in flight on different streams (begin, begin,
+    end, end); ws_tag separates their cached workspaces.  Device tensors only."""
+    N = start_len.size(0)
+    assert semantic_label.is_cuda and semantic_label.is_contiguous() and semantic_label.dtype == torch.int32
+    assert ball_query_idxs.is_contiguous() and ball_query_idxs.dtype == torch.int32
+    assert start_len.is_contiguous() and start_len.dtype == torch.int32
+    dev = semantic_label.device
+    idx = ball_query_idxs if ball_query_idxs.numel() > 0 else torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    r = _ClusterRun()
+    with _on(dev):
+        ws = _workspace(L.d3_bfs_cluster_ws_bytes(N), dev, "cl" + ws_tag)
+        nact = int(idx.numel())
+        rec = _workspace(L.d3_bfs_cluster_erec_bytes(nact), dev, "clrec" + ws_tag)
+        capP, capC = max(N, 1), N // max(int(threshold), 1) + 1
+        r.cluster_idxs = torch.empty((capP, 2), dtype=torch.int32, device=dev)
+        r.cluster_offsets = torch.empty(capC + 1, dtype=torch.int32, device=dev)
+        tk = C.c_void_p()
+        check(L.d3_bfs_cluster_begin(_ptr(semantic_label), _ptr(idx), _ptr(start_len), N, int(threshold), _ptr(ws), ws.numel(), _ptr(rec),
+                                     rec.numel(), nact, 1 if ascending else 0, _ptr(r.cluster_idxs), capP, _ptr(r.cluster_offsets), capC,
+                                     C.byref(tk), _stream()), "bfs_cluster_begin")
+    r.ticket, r.keep, r.N, r.dev = tk, (semantic_label, idx, start_len, ws, rec), N, dev
+    return r
+
+
+def bfs_cluster_end(r):
+    """-> (cluster_idxs (sumNPoint, 2), cluster_offsets (nCluster + 1)) of a `bfs_cluster_begin`"""
+    S, P = C.c_int(0), C.c_int(0)
+    tk, r.ticket = r.ticket, None
+    with _on(r.dev):
+        check(_lib.lib().d3_bfs_cluster_end(tk, C.byref(S), C.byref(P)), "bfs_cluster_end")
+    ci, co = r.cluster_idxs[:S.value], r.cluster_offsets[:P.value + 1]
+    if r.N == 0:
+        co.zero_()
+    r.keep = None
+    return ci, co
 
 
 class RoiPool(Function):

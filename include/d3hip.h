@@ -187,6 +187,15 @@ int d3_bfs_cluster_run(const int *semantic_label, const int *ball_query_idxs, co
                        void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
                        int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
                        int *sumNPoint_host, int *nCluster_host, void *stream);
+/* d3_bfs_cluster_run cut at its one host wait: `begin` enqueues everything (count kernels, the copy of their scalars + an event,
+ * the fill with its sizes read on the device) and returns a ticket; `end` waits for the event, finishes the rare cases and
+ * returns the sizes (the ticket is consumed whatever it returns).  One host thread keeps several clusterings in flight on
+ * different streams: begin, begin, end, end.  The buffers handed to `begin` must stay alive until `end`. */
+int d3_bfs_cluster_begin(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold,
+                         void *ws, size_t ws_bytes, void *erec, size_t erec_bytes, long long nActive, int flags,
+                         int *cluster_idxs, long long cap_points, int *cluster_offsets, long long cap_clusters,
+                         void **ticket, void *stream);
+int d3_bfs_cluster_end(void *ticket, int *sumNPoint_host, int *nCluster_host);
 
 /* ---- sparse 3-D convolution (MinkowskiEngine subset) ---------------------------------- */
 /* Coordinates are (M,4) int32 rows [batch, x, y, z] (ME.SparseTensor(coordinates=...),
