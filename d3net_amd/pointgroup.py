@@ -635,7 +635,7 @@ class PointGroup(nn.Module):
                 _mark("cl_prepare")
                 self._kick_prefetch("cluster")          # (a pending input prefetch starts here: the clustering leaves most of the chip idle)
                 cur = torch.cuda.current_stream()
-                if self.concurrent_clustering and not CLUSTER_THREAD:
+                if self.concurrent_clustering and not CLUSTER_THREAD and pointgroup_ops.ballquery_padded_fits(coords_.shape[0]):
                     # Round 5: BOTH branches from this thread -- begin (everything enqueued: ball query, count kernels, the fill with
                     # its sizes read on the device), begin, then the two ends (each waits for its count's event only).  The helper
                     # thread of rounds 2-4 sat on the critical path with its wake-ups and interpreter-lock hand-overs.
@@ -644,8 +644,6 @@ class PointGroup(nn.Module):
 
                     def begin(xyz, mean_active, tag):
                         padded = pointgroup_ops.ballquery_batch_p_padded(xyz, batch_idxs_, batch_offsets_, self.cluster_radius, ws_tag=tag)
-                        if padded is None:
-                            return None
                         return pointgroup_ops.bfs_cluster_begin(semantic_preds_, padded[0], padded[1], self.cluster_npoint_thre, True, ws_tag=tag)
                     with torch.cuda.stream(side):
                         hs = begin(shifted_xyz, self.cluster_shift_meanActive, "s")       # (the longer chain first)
@@ -653,14 +651,14 @@ class PointGroup(nn.Module):
                     _mark("cl_ballquery")
                     self._kick_prefetch("bfs")
                     self._early_point_losses(data_dict)
-                    first = pointgroup_ops.bfs_cluster_end(hm) if hm is not None else cluster_branch(coords_, self.cluster_meanActive)
+                    first = pointgroup_ops.bfs_cluster_end(hm)
                     _mark("cl_bfs")
                     with torch.cuda.stream(side):
-                        shifted = pointgroup_ops.bfs_cluster_end(hs) if hs is not None else cluster_branch(shifted_xyz, self.cluster_shift_meanActive)
+                        shifted = pointgroup_ops.bfs_cluster_end(hs)
                     cur.wait_stream(side)
                     for t in shifted:
                         t.record_stream(cur)
-                elif self.concurrent_clustering:
+                elif self.concurrent_clustering:      # (also: batches beyond the padded lists' range, whose compact form has a host wait per branch)
                     side = self._side_stream(coords_.device)
                     side.wait_stream(cur)
 

@@ -42,9 +42,13 @@ def _ptr(t):
 
 
 def _workspace(nbytes, device, tag):
-    """A cached, growing device scratch buffer per (device, tag)."""
-    # per host thread: the two clustering branches of PointGroup.forward run concurrently on their own streams
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, threading.get_ident())
+    """A cached, growing device scratch buffer per (device, tag, host thread, current stream)."""
+    # per host thread AND per stream: the two clustering branches of PointGroup.forward run concurrently on their own streams, from
+    # two threads (CLUSTER_THREAD) or from one -- and a call may return with kernels that read its workspace still in flight
+    # (d3_bfs_cluster_run's speculative fill), so one thread driving two streams must never hand both the same buffer (r05_f: the
+    # 16-scene batch, whose lists go the compact way, faulted exactly so)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, threading.get_ident(),
+           (_stream().value or 0) if device.type == "cuda" else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -233,16 +237,25 @@ class BallQueryBatchP(Function):
 ballquery_batch_p = BallQueryBatchP.apply
 
 
-def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=2 << 30, ws_tag=""):
+def ballquery_padded_fits(n, max_bytes=None):
+    """does `ballquery_batch_p_padded` take n points?  (n * cap slots must stay inside the int range of start_len -- the library's own
+    bound, d3_ballquery_padded -- and, when given, inside `max_bytes`)"""
+    cap = _lib.lib().d3_ballquery_cap()
+    return n > 0 and n * cap <= 0x7FFFFFFF and (max_bytes is None or n * cap * 4 <= max_bytes)
+
+
+def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=None, ws_tag=""):
     """Sync-free ball query for callers that hand the result straight to `bfs_cluster`: every point owns a fixed slot
     of `cap` entries (start_len[q] = (s * cap, len) with s = q, or the leader of q's clique cell whose list q shares:
     csrc/ballquery.hip), so there is no nActive to fetch, no scan and no compaction.  Same
     neighbours in the same order as `ballquery_batch_p` (lib/pointgroup_ops/functions/pointgroup_ops.py:143-180);
-    returns None when the padded buffer would exceed `max_bytes` (the caller then uses `ballquery_batch_p`)."""
+    returns None when the padded buffer cannot be addressed (`ballquery_padded_fits`: n * cap beyond the int range, ~2.1 M points -- up
+    to round 4 the bound was 2 GiB of slots, a quarter of that, and the 8-scene strong-scaling batch fell back to the compact form with
+    its host round trip) or would exceed `max_bytes` (the caller then uses `ballquery_batch_p`)."""
     n = coords.size(0)
     L = _lib.lib()
     cap = L.d3_ballquery_cap()
-    if n == 0 or n * cap * 4 > max_bytes:
+    if not ballquery_padded_fits(n, max_bytes):
         return None
     assert coords.is_contiguous() and coords.is_cuda and coords.dtype == torch.float32
     assert batch_idxs.is_contiguous() and batch_idxs.is_cuda and batch_idxs.dtype == torch.int32

@@ -185,6 +185,71 @@ def test_ballquery_padded_matches_compact_and_feeds_bfs(dev):
     assert P.ballquery_batch_p_padded(T(xyz, dev), T(bi, dev), T(bo, dev), 0.03, max_bytes=1024) is None
 
 
+def test_padded_lists_beyond_2_gib_of_slots(dev):
+    """Up to round 4 the padded form refused more than 2 GiB of slots (536 k points) although the library addresses n * cap up to the
+    int range (2.1 M points): the 8-scene strong-scaling batch (852 k object points) fell back to the compact form.  600 k points
+    (2.4 GB of slots): the padded lists equal the compact ones -- every list, compared on the device -- and so do the clusters."""
+    from d3net_amd import pointgroup_ops as P
+    g = torch.Generator().manual_seed(73)
+    B, per = 4, 150_000
+    n = B * per
+    assert not P.ballquery_padded_fits(n, max_bytes=2 << 30) and P.ballquery_padded_fits(n)
+    assert not P.ballquery_padded_fits(2_200_000) and not P.ballquery_padded_fits(0)
+    xyz = (torch.rand((n, 3), generator=g) * 0.85).to(dev).contiguous()      # ~32 neighbours per 3 cm ball
+    # one dense blob per scene (capped lists, clique cells) among the sparse points
+    for b in range(B):
+        xyz[b * per:b * per + 3000] = 0.4 + 0.004 * torch.randn((3000, 3), generator=g).to(dev)
+    bi = torch.arange(B, dtype=torch.int32).repeat_interleave(per).to(dev)
+    bo = torch.arange(0, n + 1, per, dtype=torch.int32).to(dev)
+    sem = (1 + (xyz[:, 0] * 5).int() % 2).int().contiguous()
+    cidx, csl = P.ballquery_batch_p(xyz, bi, bo, 0.03, 50)
+    pidx, psl = P.ballquery_batch_p_padded(xyz, bi, bo, 0.03)
+    assert pidx.numel() * 4 > (2 << 30)
+    assert torch.equal(psl[:, 1], csl[:, 1]) and int(csl[:, 1].max()) == 1000
+    ln = csl[:, 1].long()
+    within = torch.arange(int(ln.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(ln, 0) - ln, ln)
+    ppos = torch.repeat_interleave(psl[:, 0].long(), ln) + within
+    assert torch.equal(pidx[ppos], cidx)
+    del ppos, within
+    a = P.bfs_cluster(sem, cidx, csl, 30, True)
+    b_ = P.bfs_cluster(sem, pidx, psl, 30, True)
+    assert a[1].numel() > 1 + B and torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1])
+
+
+def test_workspaces_are_per_stream(dev):
+    """One host thread driving two streams gets two workspaces: d3_bfs_cluster_run returns with its fill still in flight, and the
+    next clustering on ANOTHER stream must not write into the buffer that fill reads (r05_f: the 16-scene batch faulted)."""
+    from d3net_amd import pointgroup_ops as P
+    side = torch.cuda.Stream(device=dev)
+    a = P._workspace(1 << 20, torch.device(dev), "cl")
+    with torch.cuda.stream(side):
+        b = P._workspace(1 << 20, torch.device(dev), "cl")
+        b2 = P._workspace(1 << 10, torch.device(dev), "cl")
+    assert a.data_ptr() != b.data_ptr() and b2.data_ptr() == b.data_ptr()
+    assert P._workspace(1 << 10, torch.device(dev), "cl").data_ptr() == a.data_ptr()
+    # ... and the two-stream sequence itself: compact lists, branch 1 on the current stream, branch 2 on the side stream right behind
+    rng = np.random.default_rng(74)
+    n = 60000
+    xyz = (rng.random((n, 3)) * np.array([1.5, 1.5, 0.3])).astype(np.float32)
+    xyz2 = (xyz + rng.normal(0, 0.01, xyz.shape)).astype(np.float32)
+    bi = T(np.zeros(n, np.int32), dev); bo = T(np.array([0, n], np.int32), dev)
+    sem = T(np.ones(n, np.int32), dev)
+
+    def branch(x):
+        idx, sl = P.ballquery_batch_p(x, bi, bo, 0.03, 50)
+        return P.bfs_cluster(sem, idx, sl, 10, True)
+    x1, x2 = T(xyz, dev), T(xyz2, dev)
+    ref1, ref2 = branch(x1), branch(x2)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        side.wait_stream(torch.cuda.current_stream())
+        r1 = branch(x1)
+        with torch.cuda.stream(side):
+            r2 = branch(x2)
+        torch.cuda.synchronize()
+        assert all(torch.equal(u, v) for u, v in zip(r1 + r2, ref1 + ref2))
+
+
 def _padded_lists_equal(pidx, psl, ridx, rsl, qs):
     for q in qs:
         a = pidx[psl[q, 0]:psl[q, 0] + psl[q, 1]]
