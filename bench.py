@@ -179,12 +179,24 @@ def _b(x):
     return "true" if x else "false"
 
 
+def kernel_family(name):
+    """the kernel function a rocprofv3 name belongs to; the entry points that share spconv_fwd2_body (csrc/spconv2.hip: the
+    wave-per-tile forward / data-gradient convolution) count as ONE function, under the name the earlier rounds' records carry"""
+    base = name.split("<")[0].replace("void ", "").strip('" ')
+    return "spconv_fwd2_kernel" if base in ("spconv_fwd2_c_kernel", "spconv_fwd2_ks_kernel") else base
+
+
 def prof_kernel_name(fam, t):
     """the kernel a profiling record timed, named as rocprofv3 prints it (template arguments included where the record has them)"""
     t = [int(v) for v in t]
     if fam == 0:
         nt, wlds, xbf, nw, f32, kt, st = t[5:12]
-        st, t16 = st % 1000, st >= 1000          # (the record packs the T16 template flag into the ST tag: ST + 1000)
+        st, fl = st % 1000, st // 1000            # (the record packs flags into the ST tag: + 1000 the T16 template flag, + 2000 / + 4000 the kernel)
+        t16 = bool(fl & 1)
+        if fl & 4:
+            return "spconv_fwd2_c_kernel<%d, %d, %d, %s>" % (nt, nw, st, _b(t16))
+        if fl & 2:
+            return "spconv_fwd2_ks_kernel<%d, %s, 4>" % (st, _b(t16))
         return "spconv_fwd2_kernel<%d, %s, %s, %d, %s, %d, %d, %s>" % (nt, _b(wlds), _b(xbf), nw, _b(f32), kt, st, _b(t16))
     if fam == 2:
         return "spconv_fwd2_split_kernel<%d, %s, %s>" % (t[5], _b(t[6]), _b(t[7]))
@@ -758,7 +770,7 @@ def main():
         # their durations); its instances follow in `per_kernel`
         fam_rec = {}
         for k, r in kernels.items():
-            f = fam_rec.setdefault(k.split("<")[0], dict(family=r["family"], n=0.0, ms=0.0, b8=0.0, bd=0.0, fl=0.0, samp=0))
+            f = fam_rec.setdefault(kernel_family(k), dict(family=r["family"], n=0.0, ms=0.0, b8=0.0, bd=0.0, fl=0.0, samp=0))
             w = r["launches_per_step"]
             f["n"] += w; f["ms"] += r["ms_per_step"]; f["samp"] += r["launches_sampled"]
             f["b8"] += r["algorithmic_bytes_per_launch"] * w; f["bd"] += r["bytes_moved_by_design_per_launch"] * w; f["fl"] += r["flops_per_launch"] * w

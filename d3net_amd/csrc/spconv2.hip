@@ -286,9 +286,25 @@ __device__ __forceinline__ void c2_wload(const unsigned short *Wb, int e, uint4 
 // KT / ST > 0: kernel size and slots per offset (Cin / 8) known at compile time (round 3: the shapes that carry the step -- K = 27
 // with 16 / 32 / 64 input channels): the reduction loop is fully unrolled and every (offset, channel group) of a step is a
 // constant per lane group -- the ~10 index instructions in front of each gather fold away.
-template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false, int KT = 0, int ST = 0, bool T16 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
+// KS > 1 (round 5, the stem): KS waves share one tile and split its 27 offsets; the NW / KS tiles of a workgroup's turn -- and with
+// them the XCD's window of rows in flight -- shrink by KS.  The stem's window was (32 workgroups x 16 tiles x 16 rows) = 8192 rows
+// plus a +-1 x-slab halo of 272-byte rows, ~2.7 MB beside the table and the outputs in a 4 MB L2 with the workgroups a turn apart:
+// measured 990 MB of L2-miss traffic per launch against 249 MB algorithmic.  Sibling waves hand their partial accumulator to the
+// tile's first wave through their own (by then dead) kernel-map slot in LDS; flags in LDS, no workgroup barrier.
+__device__ __forceinline__ void c2_lds_wait_eq(int *p, int v) {
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
+}
+// CMP (round 5, the statically shaped instances): the offsets NO row of the tile has are dropped before the reduction loop.  The
+// kernel is bound by the dependent round trips of a wave (table -> gathers -> products, one per batch), not by a throughput: with
+// the rows in raster order a 16-row tile of the 2 cm level uses 15.9 of the 27 offsets on average (a planar patch: 9), so the
+// batches of a tile shrink from 14 to ~8 (stem) / from 2 to mostly 1 (16 -> 16).  One 27-lane pass over the tile's table in LDS
+// gives the mask; the live offsets are then taken from it with scalar instructions (no list in memory).
+template <int NT, bool WLDS, bool XBF, int NW, bool F32M, int KT, int ST, bool T16, int KS, bool CMP = false>
+__device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
+    static_assert(!CMP || (KT == 27 && (ST == 2 || ST >= 4) && KS == 1), "offset compaction: the statically shaped instances");
     static_assert(!T16 || KT == 27, "the 16-bit kernel map is read by the statically shaped K = 27 instances");
+    static_assert(KS == 1 || (KS == 4 && NT == 1 && KT == 27 && ST >= 4 && NW == 16), "the offset split is built for the stem");
+    constexpr int NWT = NW / KS;        // tiles of a workgroup's turn
     static_assert(!(F32M && XBF), "fp32 MFMA needs fp32 gathers");
     static_assert((KT > 0) == (ST > 0), "static shapes fix both the kernel size and the channel groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -298,14 +314,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     constexpr int KB = ST >= 4 ? (Q >= 5 ? 2 : (8 / Q > 0 ? 8 / Q : 1)) : 1;
     constexpr int U = ST >= 4 ? KB * Q : (!XBF && NT <= 2) ? (NW == 16 ? 4 : C2_F32_U) : C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
+    const int slot = KS > 1 ? wave / KS : wave, kpart = KS > 1 ? wave % KS : 0;
     const int K = KT ? KT : a.K, S = ST ? ST : a.S;
     const size_t wbytes = WLDS ? (size_t)K * S * NT * (F32M ? 512 : 256) : 0;
     int *tblS = (int *)(smem + wbytes) + wave * C2_TBL_INTS;
     float *redS = (float *)(smem + wbytes + NW * C2_TBL_INTS * 4);
+    // (offset split) ready[wave]: the iteration whose partial accumulator sits in that wave's table slot; done[slot]: the iteration
+    // the tile's first wave has consumed -- in the spare words behind the statistics rows (word 0 there is the finalize flag)
+    int *readyS = (int *)(redS + NW * 2 * NT * 16) + 4, *doneS = readyS + NW;
     const unsigned short *Wb = WLDS ? (const unsigned short *)smem : a.Wp;
     const int nb = gridDim.x, b = blockIdx.x;
     const int lb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-    const int ntg = (a.ntiles + NW - 1) / NW;
+    const int ntg = (a.ntiles + NWT - 1) / NWT;
     const int per = (ntg + nb - 1) / nb;
     // Round 4: with `interleave` the nb / 8 workgroups of an XCD take the XCD's tile groups IN TURN (iteration i of workgroup j:
     // group xcd_base + i * (nb / 8) + j) instead of one contiguous range each: at any moment the XCD works on ONE window of
@@ -338,7 +358,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
         }                                                                                                     \
         }                                                                                                     \
     }
-    if (C2_PREFETCH) C2_LOAD_TBL(tg0 * NW + wave)
+    if (C2_PREFETCH) C2_LOAD_TBL(tg0 * NWT + slot)
+    if (KS > 1 && t < NW + NWT) readyS[t] = 0;
     float4 *bnS = (float4 *)(smem + wbytes + C2_WAVE_LDS_BASE(NT, NW));   // (mean, 1/std, gamma, beta) per channel
     if (a.bnx && t < NT * 16) {
         float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -371,11 +392,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     if (lane == 0) tblS[C2_TBL_SENT] = -1;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, C2_RSRC_FLAGS);
 
+    int kiter = 0;
     for (int tg = tg0; tg < tg1; tg += tstride) {
-        const int tile = tg * NW + wave;
-        if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
+        const int tile = tg * NWT + slot;
+        if (tile >= a.ntiles) continue;   // wave-uniform (and the same for the KS waves of a tile); there is no workgroup barrier inside this loop
         const int row0 = tile * 16;
         if (!C2_PREFETCH) C2_LOAD_TBL(tile)
+        if (KS > 1) {
+            if (kpart != 0 && kiter > 0) c2_lds_wait_eq(&doneS[slot], kiter);     // my previous partial has been read: the slot is mine again
+            kiter++;
+        }
         if constexpr (t16) {
 #pragma unroll
             for (int it = 0; it < 4; it++) {
@@ -397,10 +423,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
             if (e < 16 * K) tblS[e] = v[it];
         }
         }
-        if (C2_PREFETCH && tg + tstride < tg1) C2_LOAD_TBL(tile + NW * tstride)
+        if (C2_PREFETCH && tg + tstride < tg1) C2_LOAD_TBL(tile + NWT * tstride)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned int kmask = 0u;
+        if constexpr (CMP) {      // bit k: some row of the tile has offset k (absent entries are -1: the AND of a column keeps the sign bit)
+            int av = -1;
+            if (lane < KT) {
+#pragma unroll
+                for (int rr = 0; rr < 16; rr++) av &= tblS[rr * KT + lane];
+            }
+            kmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)__ballot(lane < KT && av >= 0));
+        }
 
         f32x4 acc[NT];
 #pragma unroll
@@ -422,8 +457,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                 if (a.bnx) e_bnx[j] = *(const f32x4 *)(a.bnx + (long long)urow * a.ldbx + col);               \
             }                                                                                                 \
         }
-        if (HOIST) { C2_EPI_LOAD(0) }
-        auto batch = [&](const int m0) __attribute__((always_inline)) {
+        if (HOIST && (KS == 1 || kpart == 0)) { C2_EPI_LOAD(0) }
+        // (CMP: ko[] = the live offsets of this batch, taken from the mask; KT = none)
+        constexpr int NKO = !CMP ? 1 : (ST >= 4 ? KB : 2 * U);
+        auto batch = [&](const int m0, const int (&ko)[NKO]) __attribute__((always_inline)) {
             uint4 rlo[U], rhi[U];
             int boff[U], idxv[U], c8v[U];
             // Round 3 (ISA review): the kernel-map entries of the whole batch are read from LDS back to back and unconditionally
@@ -435,11 +472,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
             for (int u = 0; u < U; u++) {
                 int s = 4 * (m0 + u) + g, k;
                 bool ok;
-                if (ST >= 4) {
+                if constexpr (CMP && ST < 4) {
+                    // 16 input channels: a step is two live offsets (lane groups 0-1 the first, 2-3 the second)
+                    k = (g >> 1) ? ko[(2 * u + 1) % NKO] : ko[(2 * u) % NKO];
+                    c8v[u] = g & 1;
+                    ok = k < KT;
+                    s = k * ST + c8v[u];
+                } else if (ST >= 4) {
                     // static shapes with >= 32 input channels: a step stays inside ONE offset (here m0 is the first OFFSET of the
                     // batch; the channel group is a constant per lane group; 136 channels run 5 steps per offset, the last one
                     // with a single live lane group)
-                    k = m0 + u / Q;
+                    k = CMP ? ko[(u / Q) % NKO] : m0 + u / Q;
                     c8v[u] = 4 * (u % Q) + g;
                     ok = (k < KT) && (c8v[u] < ST);
                     s = k * ST + c8v[u];
@@ -458,7 +501,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
             // (inputs beyond 2 GiB are refused by the host: 32-bit offsets, absent rows at offset 2^31)
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if ((ST > 0 && ST < 4 && m0 + u >= NSTEPS_T) || (ST >= 4 && m0 + u / Q >= KT)) {   // (folded where m0 is a constant; wave-uniform otherwise)
+                if (CMP ? (ko[(ST >= 4 ? u / Q : 2 * u) % NKO] >= KT)
+                        : ((ST > 0 && ST < 4 && m0 + u >= NSTEPS_T) || (ST >= 4 && m0 + u / Q >= KT))) {   // (folded where m0 is a constant; wave-uniform otherwise)
                     rlo[u] = make_uint4(0u, 0u, 0u, 0u); rhi[u] = rlo[u]; continue;
                 }
                 const unsigned int off = idxv[u] >= 0 ? __umul24((unsigned int)idxv[u], xrowb) + (unsigned int)c8v[u] * (XBF ? 16u : 32u) : 0x80000000u;
@@ -472,7 +516,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                 // fragments of the batch are read ahead of the products instead of one LDS round trip in front of each)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    if ((ST > 0 && ST < 4 && m0 + u >= NSTEPS_T) || (ST >= 4 && m0 + u / Q >= KT)) continue;
+                    if (CMP ? (ko[(ST >= 4 ? u / Q : 2 * u) % NKO] >= KT)
+                            : ((ST > 0 && ST < 4 && m0 + u >= NSTEPS_T) || (ST >= 4 && m0 + u / Q >= KT))) continue;
 #pragma unroll
                     for (int n = 0; n < NT; n++) {
                         uint4 wl, wh;
@@ -525,17 +570,44 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
                 }
             }
         };
-        if constexpr (ST >= 4 && (KT * Q > 56 || NT >= 3)) {   // (the stem: 135 steps; >= 48 output channels -- unrolled completely they spill)
+        const int ko0[NKO] = {0};
+        if constexpr (CMP) {
+            unsigned int m = kmask;
 #pragma unroll 1
-            for (int k0 = 0; k0 < KT; k0 += KB) batch(k0);
+            while (m) {      // (wave-uniform: the mask lives in scalar registers)
+                int ko[NKO];
+#pragma unroll
+                for (int j = 0; j < NKO; j++) { ko[j] = m ? (int)__builtin_ctz(m) : KT; m &= m - 1u; }
+                batch(0, ko);
+            }
+        } else if constexpr (KS > 1) {
+            // offsets [0, 8), [8, 14), [14, 20), [20, 27) (KB = 2 offsets per batch: 4 / 3 / 3 / 3.5 batches)
+            static_assert(KB == 2, "offset ranges of the split are whole batches");
+            const int kb = kpart == 0 ? 0 : 2 + 6 * kpart, ke = kpart == 0 ? 8 : kpart == 3 ? KT : 8 + 6 * kpart;
+#pragma unroll 1
+            for (int k0 = kb; k0 < ke; k0 += KB) batch(k0, ko0);
+            if (kpart != 0) {      // the partial accumulator into my own table slot (its entries are in registers or consumed)
+                ((f32x4 *)tblS)[lane] = acc[0];
+                __hip_atomic_store(&readyS[wave], kiter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+#pragma unroll
+            for (int p = 1; p < KS; p++) {      // fixed order: deterministic
+                c2_lds_wait_eq(&readyS[wave + p], kiter);
+                acc[0] += ((const f32x4 *)(tblS + p * C2_TBL_INTS))[lane];
+            }
+            __hip_atomic_store(&doneS[slot], kiter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if constexpr (ST >= 4 && (KT * Q > 56 || NT >= 3)) {   // (the stem: 135 steps; >= 48 output channels -- unrolled completely they spill)
+#pragma unroll 1
+            for (int k0 = 0; k0 < KT; k0 += KB) batch(k0, ko0);
         } else if constexpr (ST >= 4) {
 #pragma unroll
-            for (int k0 = 0; k0 < KT; k0 += KB) batch(k0);
+            for (int k0 = 0; k0 < KT; k0 += KB) batch(k0, ko0);
         } else if constexpr (ST > 0) {
 #pragma unroll
-            for (int m0 = 0; m0 < NSTEPS_T; m0 += U) batch(m0);
+            for (int m0 = 0; m0 < NSTEPS_T; m0 += U) batch(m0, ko0);
         } else {
-            for (int m0 = 0; m0 < nsteps; m0 += U) batch(m0);
+            for (int m0 = 0; m0 < nsteps; m0 += U) batch(m0, ko0);
         }
         // D layout: column (= output row) lane & 15, rows (= channels) (lane >> 4) * 4 + q
 #pragma unroll
@@ -597,6 +669,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
         if (a.fin_counter)   // (flag word: the spare LDS behind the statistics rows; no static LDS in front of the dynamic region)
             c2_last_block_finalize(a, (int)gridDim.x, (int)gridDim.x, (int *)(redS + NW * 2 * NT * 16));
     }
+}
+template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false, int KT = 0, int ST = 0, bool T16 = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
+    spconv_fwd2_body<NT, WLDS, XBF, NW, F32M, KT, ST, T16, 1>(a);
+}
+// the statically shaped instances (K = 27, bf16 rows, weights in LDS) with the tile's dead offsets dropped (CMP above)
+template <int NT, int NW, int ST, bool T16>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, true) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_c_kernel(const Conv2Args a) {
+    spconv_fwd2_body<NT, true, true, NW, false, 27, ST, T16, 1, true>(a);
+}
+// the offset-split form (K = 27, bf16 rows, weights in LDS, one column tile, 16 waves: the stem)
+template <int ST, bool T16, int KS>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void spconv_fwd2_ks_kernel(const Conv2Args a) {
+    spconv_fwd2_body<1, true, true, 16, false, 27, ST, T16, KS>(a);
 }
 
 // Workgroup-per-tile kernel (few-row levels): grid = (16-row tiles, column groups of NTW 16-wide tiles).  The
@@ -879,6 +965,22 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev))
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // the tile's dead offsets dropped (spconv_fwd2_c_kernel): 1 = the stem only (5 steps per offset: 266 -> 231 us at 649 k rows), 2 = every
+    // statically shaped instance (measured SLOWER below 64 input channels -- 16 -> 16: 34.5 -> 50.4 us, 32 -> 32: 68.5 -> 73 us: the
+    // mask pass and the run-time offsets cost more than the dropped steps save; gpurun_out/r05_j44)
+    const int cmp_mode = d3_tune(D3T_C2_COMPACT);
+    if (cmp_mode >= 2 || (cmp_mode == 1 && ST == 17)) {
+        static bool attrc_done_dev[64] = {false};
+        if (c2_attr_needed(attrc_done_dev)) {
+            D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_c_kernel<NT, NW, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_c_kernel<NT, NW, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        c2_inst(NT, 1, 1, NW, 0, 27, ST + (a.tbl16 ? 1000 : 0) + 4000);     // (+ 4000: spconv_fwd2_c_kernel, see bench.py's kernel naming)
+        if (a.tbl16) { spconv_fwd2_c_kernel<NT, NW, ST, true><<<p.grid, 64 * NW, p.lds, s>>>(a); g_t16_launches++; }
+        else spconv_fwd2_c_kernel<NT, NW, ST, false><<<p.grid, 64 * NW, p.lds, s>>>(a);
+        D3_LAUNCH_CHECK();
+        return 0;
+    }
     c2_inst(NT, 1, 1, NW, 0, 27, ST);
     if (a.tbl16) {
         static bool attr16_done_dev[64] = {false};
@@ -894,6 +996,19 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
     D3_LAUNCH_CHECK();
     return 0;
 }
+template <int ST>
+static int launch_fwd2_ks(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev)) {
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_ks_kernel<ST, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_ks_kernel<ST, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    c2_inst(1, 1, 1, 16, 0, 27, ST + (a.tbl16 ? 1000 : 0) + 2000);     // (+ 2000: the offset-split kernel, see bench.py's kernel naming)
+    if (a.tbl16) { spconv_fwd2_ks_kernel<ST, true, 4><<<p.grid, 1024, p.lds, s>>>(a); g_t16_launches++; }
+    else spconv_fwd2_ks_kernel<ST, false, 4><<<p.grid, 1024, p.lds, s>>>(a);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
 template <int NT>
 static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
     if (a.f32) return launch_fwd2_f32<NT>(a, p, s);
@@ -901,6 +1016,7 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
         if constexpr (NT == 1) {
             if (a.S == 2 && p.nw == 4) return launch_fwd2_static<1, 4, 2>(a, p, s);      // 16 -> 16
             if (a.S == 4 && p.nw == 16) return launch_fwd2_static<1, 16, 4>(a, p, s);    // 32 -> 16
+            if (a.S == 17 && p.nw == 16 && d3_tune(D3T_C2_KSPLIT) != 0) return launch_fwd2_ks<17>(a, p, s);   // the stem, offsets split over 4 waves
             if (a.S == 17 && p.nw == 16) return launch_fwd2_static<1, 16, 17>(a, p, s);  // the stem: 134 (+2) -> 16
         }
         if constexpr (NT == 2) {

@@ -55,6 +55,8 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_SIDE2", 2},                // 1: weight gradients whose dy buffer is later accumulated into in place (the caller's stream has to wait for them) run on a SECOND side stream: they no longer queue behind the other weight gradients; 2 (default): all weight gradients alternate between the two streams (speaker step 17.71 -> 17.49 ms in-process, mode 1: 17.57; detector step inside the noise: gpurun_out/r05_j17); 0: one side stream (rounds 1-4)
     {"D3_SORT_ONESWEEP_MIN", 65536}, // pair sorts of at least this many items take rocPRIM's Onesweep radix path (requested bits only, 8 per pass) instead of its default block sort + merge passes (~35 launches up to 2^20 items whatever the key width); 0x7fffffff: never
     {"D3_BQ_HALF", 1},              // 0: the cell-grid ball query runs one WAVE per query point (rounds 3-4); 1: two queries per wave (32 lanes each: 27 probes, up to 64 candidates as two elements per lane, bitonic order inside the half)
+    {"D3_C2_KSPLIT", 0},            // 1: the stem convolution (K = 27, 136 -> 16) runs spconv_fwd2_ks_kernel -- 4 waves per 16-row tile, each a quarter of the offsets, partial sums through LDS: the XCD's window of rows in flight shrinks 4x.  Measured: L2-miss traffic 990 -> 660 MB per launch, time 268 -> 286 us (the kernel is not bound by that traffic): off
+    {"D3_C2_COMPACT", 1},           // the statically shaped forward / data-gradient convolutions (K = 27, bf16 rows) drop the offsets no row of a 16-row tile has before the reduction loop (spconv_fwd2_c_kernel; raster-ordered rows of the 2 cm level: 15.9 of 27 offsets live per tile): 1 (default) the stem only (266 -> 231 us), 2 every static instance (slower: 16 -> 16 34.5 -> 50.4 us), 0 never (rounds 2-4)
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

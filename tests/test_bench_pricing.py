@@ -30,6 +30,12 @@ def test_kernel_names_are_rocprofv3_names():
     assert bench.prof_kernel_name(0, tags) == "spconv_fwd2_kernel<1, true, true, 4, false, 27, 2, false>"
     tags[11] = 1002                                         # the T16 template flag travels in the ST tag
     assert bench.prof_kernel_name(0, tags) == "spconv_fwd2_kernel<1, true, true, 4, false, 27, 2, true>"
+    # round 5: the other entry points of the same kernel body (+ 4000 offset compaction, + 2000 offset split), one family
+    assert bench.prof_kernel_name(0, [0, 0, 27, 136, 16, 1, 1, 1, 16, 0, 27, 5017]) == "spconv_fwd2_c_kernel<1, 16, 17, true>"
+    assert bench.prof_kernel_name(0, [0, 0, 27, 136, 16, 1, 1, 1, 16, 0, 27, 4017]) == "spconv_fwd2_c_kernel<1, 16, 17, false>"
+    assert bench.prof_kernel_name(0, [0, 0, 27, 136, 16, 1, 1, 1, 16, 0, 27, 3017]) == "spconv_fwd2_ks_kernel<17, true, 4>"
+    assert bench.kernel_family("spconv_fwd2_c_kernel<1, 16, 17, true>") == "spconv_fwd2_kernel" == bench.kernel_family("void spconv_fwd2_ks_kernel<17, true, 4>")
+    assert bench.kernel_family("spconv_fwd2_split_kernel<4, true, false>") == "spconv_fwd2_split_kernel" and bench.kernel_family("cl_bfs2_kernel") == "cl_bfs2_kernel"
     assert bench.prof_kernel_name(2, [0, 0, 27, 64, 64, 4, 1, 0, -1, 0, 0, 0]) == "spconv_fwd2_split_kernel<4, true, false>"
     assert bench.prof_kernel_name(3, [4096, 128, 128, 1, 0, 0, 0, 0, 0, 0, 0, 0]) == "hg_gemm_tiled_kernel"
     assert bench.prof_kernel_name(3, [32, 512, 512, 1, 1, 1, 16, 0, 0, 0, 0, 0]) == "hg_gemm_kernel<1, true, 16>"

@@ -15,6 +15,8 @@ for path in sys.argv[1:3]:
         # kernel names contain commas (template arguments): the four numeric / counter fields are the last four
         name, counter, launches, _mean, total = line.rstrip("\n").rsplit(",", 4)
         base = name.split("<")[0].strip('"').replace("void ", "")
+        if base in ("spconv_fwd2_c_kernel", "spconv_fwd2_ks_kernel"):      # (entry points of one kernel body: bench.kernel_family)
+            base = "spconv_fwd2_kernel"
         full = name.strip('"').replace("void ", "")
         b = inst[full][counter]
         b[0] += int(launches); b[1] += float(total)
@@ -39,7 +41,7 @@ BASES = ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel
          "hg_gemm_kernel", "hg_gemm_tiled_kernel", "hg_gemm_tiled3_kernel", "td_gru4_fwd_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel", "un_bn_bwd_apply_kernel",
          "un_bn_fused_small_kernel", "un_bn_bwd_fused_small_kernel")
 for full, v in inst.items():
-    if full in out or full.split("<")[0] not in BASES:
+    if full in out or full.split("<")[0] not in BASES + ("spconv_fwd2_c_kernel", "spconv_fwd2_ks_kernel"):
         continue
     f, w = v["FETCH_SIZE"], v["WRITE_SIZE"]
     if not f[0] or not w[0]:
