@@ -464,6 +464,54 @@ def test_bfs_cluster_run_speculative_fill_and_many_clusters(dev, spec):
         L.d3_tuning_set(b"D3_BFS_NO_STAR", 0)
 
 
+@pytest.mark.parametrize("spec", [1, 0])
+def test_bfs_cluster_begin_end_two_in_flight(dev, spec):
+    """d3_bfs_cluster_begin / _end (round 5): ONE host thread keeps two clusterings in flight on two streams -- begin, begin, end, end,
+    the order PointGroup.forward uses -- and gets what the one-call form and the oracle return: padded and compact lists, a
+    threshold nothing passes, an empty input; with D3_CL_SPEC=0 `begin` runs the whole blocking call and `end` only hands over."""
+    from d3net_amd import pointgroup_ops as P, _lib
+    rng = np.random.default_rng(86)
+    n = 9000
+    xyz1 = (rng.random((n, 3)) * np.array([1.0, 1.0, 0.25])).astype(np.float32)
+    xyz1[rng.permutation(n)[:1500]] = np.array([0.3, 0.6, 0.1], np.float32) + rng.normal(0, 0.003, (1500, 3)).astype(np.float32)   # capped lists
+    xyz2 = (xyz1 + rng.normal(0, 0.006, xyz1.shape)).astype(np.float32)
+    bi = np.concatenate([np.zeros(5000, np.int32), np.ones(n - 5000, np.int32)]); bo = np.array([0, 5000, n], np.int32)
+    sem = (1 + (xyz1[:, 1] * 4).astype(np.int32) % 3).astype(np.int32)
+    refs = []
+    for x in (xyz1, xyz2):
+        idx, sl = o.ballquery_batch_p(x, bi, bo, 0.03, 50)
+        refs.append(o.bfs_cluster(sem, idx, sl, 15))
+    L = _lib.lib()
+    side = torch.cuda.Stream(device=dev)
+    semd, bid, bod = T(sem, dev), T(bi, dev), T(bo, dev)
+    x1, x2 = T(xyz1, dev), T(xyz2, dev)
+    try:
+        assert L.d3_tuning_set(b"D3_CL_SPEC", spec) == 0
+        for padded in (True, False):
+            for rep in range(3):
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    i2, s2 = P.ballquery_batch_p_padded(x2, bid, bod, 0.03, ws_tag="s") if padded else P.ballquery_batch_p(x2, bid, bod, 0.03, 50)
+                    h2 = P.bfs_cluster_begin(semd, i2, s2, 15, True, ws_tag="s")
+                i1, s1 = P.ballquery_batch_p_padded(x1, bid, bod, 0.03, ws_tag="m") if padded else P.ballquery_batch_p(x1, bid, bod, 0.03, 50)
+                h1 = P.bfs_cluster_begin(semd, i1, s1, 15, True, ws_tag="m")
+                r1 = P.bfs_cluster_end(h1)
+                with torch.cuda.stream(side):
+                    r2 = P.bfs_cluster_end(h2)
+                torch.cuda.synchronize()
+                for got, want in ((r1, refs[0]), (r2, refs[1])):
+                    assert np.array_equal(N(got[1]), want[1]) and np.array_equal(N(got[0]), want[0]), (spec, padded, rep)
+        # nothing kept / nothing there
+        i1, s1 = P.ballquery_batch_p_padded(x1, bid, bod, 0.03)
+        ci, co = P.bfs_cluster_end(P.bfs_cluster_begin(semd, i1, s1, 1000000, True))
+        assert N(co).tolist() == [0] and ci.shape[0] == 0
+        e = torch.zeros(0, dtype=torch.int32, device=dev)
+        ci, co = P.bfs_cluster_end(P.bfs_cluster_begin(e, e, torch.zeros((0, 2), dtype=torch.int32, device=dev), 10, True))
+        assert N(co).tolist() == [0] and ci.shape[0] == 0
+    finally:
+        L.d3_tuning_set(b"D3_CL_SPEC", 1)
+
+
 def test_bfs_replay_forms_agree_with_the_oracle(dev):
     """Round 5: cl_bfs3_kernel (thread per frontier node, key election in LDS words; D3_BFS3=1, the default) and the edge-parallel hash
     form (cl_bfs2_kernel, D3_BFS3=0) against the sequential oracle on inputs that reach every path of the new kernel: a 190 x 190
