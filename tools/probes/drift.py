@@ -19,6 +19,9 @@ config = sys.argv[1] if len(sys.argv) > 1 else "speaker"
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 saved = sys.argv
 sys.argv = ["ab.py", config]
+from d3net_amd import _lib  # noqa: E402
+if os.environ.get("D3_SO"):          # (a variant build of tools/probes/build_variant.sh)
+    _lib.SO_PATH = os.path.abspath(os.environ["D3_SO"])
 import runpy  # noqa: E402
 ns = runpy.run_path(os.path.join(ROOT, "tools", "ab.py"))          # builds model / feeder / step(), runs its 40 settle steps, no switches
 step = ns["step"]
