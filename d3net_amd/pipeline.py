@@ -15,6 +15,8 @@ from .listener import ListenerNet, get_grounding_loss, get_lobjcls_loss
 from .pointgroup import PointGroup, _mark
 from .speaker import SpeakerNet
 
+DEFER_DETECT_LOSS = 1   # (A/B switch, tools/ab.py py:d3net_amd.pipeline.DEFER_DETECT_LOSS=0,1) training_step mode 1: the detector's losses are built after the captioner's forward has been enqueued (speaker step 16.23 -> 16.17 ms, r05_j52)
+
 
 class _HostScalars:
     """a few device scalars on their way to the host: the copy is enqueued at construction (pinned buffer, own event) and
@@ -110,7 +112,8 @@ class PipelineNet(nn.Module):
         vec /= dist.get_world_size()
         return {k: vec[i] for i, k in enumerate(keys)}
 
-    def _detect(self, data_dict):
+    def _detect(self, data_dict, defer_loss=False):
+        """defer_loss: the caller runs `self.detector.loss` itself, AFTER it has enqueued the heads (DEFER_DETECT_LOSS)"""
         keep = self.detector.compact_proposals      # (only for this call: the detector object may be driven directly as well)
         self.detector.compact_proposals = keep and not self.__dict__.get("_lazy_proposals", False)
         try:
@@ -118,7 +121,8 @@ class PipelineNet(nn.Module):
         finally:
             self.detector.compact_proposals = keep
         _, data_dict = self.detector.parse_feed_ret(data_dict, self.current_epoch)
-        data_dict = self.detector.loss(data_dict, self.current_epoch)
+        if not defer_loss:
+            data_dict = self.detector.loss(data_dict, self.current_epoch)
         gb = self.__dict__.get("grad_boundary")
         if gb is not None and torch.is_tensor(data_dict.get("proposal_feats_batched")):
             # multi-GPU: everything the heads hand back to the detector comes through the proposal features; when the
@@ -143,10 +147,16 @@ class PipelineNet(nn.Module):
                 if "loss" in k:
                     self.log("train/{}".format(k), v[0])
         elif self.mode == 1:
-            data_dict = self._detect(data_dict)
+            # the detector's score loss (IoU table, BCE: a handful of small launches and their interpreter time) needs nothing from the
+            # heads and the heads nothing from it: it is enqueued BEHIND the captioner's recurrence, whose ~300 launches keep the device
+            # busy for longer than the host needs to issue them -- between ScoreNet and the relation graph the device waits for the host
+            defer = bool(DEFER_DETECT_LOSS)
+            data_dict = self._detect(data_dict, defer_loss=defer)
             self.detector._kick_prefetch("caption")      # (input prefetch, if set to start under the captioner's recurrence)
             data_dict = self.speaker(data_dict)
             _mark("speaker")
+            if defer:
+                data_dict = self.detector.loss(data_dict, self.current_epoch)
             _, data_dict = get_captioning_loss(data_dict, caption=not self.no_captioning, orientation=self.cfg.model.use_orientation,
                                                num_bins=self.cfg.data.num_ori_bins, loss_opt=self.loss_opt)
             loss = data_dict["total_loss"][0] + data_dict["cap_loss"] + 0.1 * data_dict["ori_loss"]
@@ -156,6 +166,7 @@ class PipelineNet(nn.Module):
                          "pred_ious": data_dict["pred_ious"]}.items():
                 self.log("train_{}/{}".format("loss" if "loss" in k else "score", k), v)
         elif self.mode == 2:
+            # (the deferred detector loss of mode 1 measured no gain behind the listener's forward: 18.90 vs 19.03 ms, r05_j52)
             data_dict = self._ground(self.listener(self._detect(data_dict)), False)
             loss = data_dict["total_loss"][0] + data_dict["ref_loss"] + data_dict["lang_loss"]
             for k, v in {"loss": loss, "detect_loss": data_dict["total_loss"][0], "grounding_loss": data_dict["ref_loss"],
