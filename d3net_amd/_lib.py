@@ -26,6 +26,7 @@ SIGNATURES = {
     "d3_sec_min": (i32, [vp, vp, vp, i32, i32, vp]),
     "d3_sec_max": (i32, [vp, vp, vp, i32, i32, vp]),
     "d3_cluster_select": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "d3_cluster_select2": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "d3_cluster_merge": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "d3_proposal_prepare": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]),
     "d3_cluster_coords_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),

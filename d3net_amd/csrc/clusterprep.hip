@@ -10,13 +10,24 @@
 // integer copies: bit-exact by construction (tests/test_pg_ops_gpu.py compares with the library-op chain).
 #include "common.h"
 
+// boff (optional, nb + 1 ints): the offsets of the object points' batch ids (model/pointgroup.py:110-122 get_batch_offsets: boff[b] =
+// points with a batch id below b) written at the boundaries of the id column -- which the reference's callers hand over SORTED (the
+// batch is a concatenation of scenes, and ballquery_batch_p reads [boff[b], boff[b+1]) as THE points of scene b).  For a column that
+// steps down the boundaries are not the reference's counts: such a caller keeps PointGroup.get_batch_offsets
 __global__ void cp_select_kernel(const float *__restrict__ locs, const float *__restrict__ offs, const long long *__restrict__ sem,
                                  const int *__restrict__ batch, const long long *__restrict__ obj, int n, int *__restrict__ batch_o,
-                                 float *__restrict__ coords_o, float *__restrict__ shifted_o, int *__restrict__ sem_o) {
+                                 float *__restrict__ coords_o, float *__restrict__ shifted_o, int *__restrict__ sem_o,
+                                 int *__restrict__ boff, int nb) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const long long o = obj[r];
-    batch_o[r] = batch[o];
+    const int bi = batch[o];
+    batch_o[r] = bi;
+    if (boff) {
+        const int bp = r > 0 ? batch[obj[r - 1]] : -1;
+        for (int b = max(bp + 1, 0); b <= bi && b <= nb; b++) boff[b] = r;          // first point with an id >= b
+        if (r == n - 1) for (int b = max(bi + 1, 0); b <= nb; b++) boff[b] = n;
+    }
     sem_o[r] = (int)sem[o];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -33,7 +44,19 @@ extern "C" int d3_cluster_select(const float *locs, const float *pt_offsets, con
     if (n <= 0) return 0;
     cp_select_kernel<<<(n + 255) / 256, 256, 0, d3_stream(stream)>>>(locs, pt_offsets, (const long long *)semantic_preds, batch_idxs,
                                                                     (const long long *)object_idxs, n, batch_out, coords_out, shifted_out,
-                                                                    semantic_out);
+                                                                    semantic_out, nullptr, 0);
+    D3_LAUNCH_CHECK();
+    return 0;
+}
+// + batch_offsets_out (batch_size + 1 ints, see cp_select_kernel); n >= 1
+extern "C" int d3_cluster_select2(const float *locs, const float *pt_offsets, const int64_t *semantic_preds, const int *batch_idxs,
+                                  const int64_t *object_idxs, int n, int batch_size, int *batch_out, float *coords_out, float *shifted_out,
+                                  int *semantic_out, int *batch_offsets_out, void *stream) {
+    D3_CLEAR();
+    if (n <= 0 || batch_size < 1 || !batch_offsets_out) return D3_ERR_ARG;
+    hipStream_t s = d3_stream(stream);
+    cp_select_kernel<<<(n + 255) / 256, 256, 0, s>>>(locs, pt_offsets, (const long long *)semantic_preds, batch_idxs, (const long long *)object_idxs, n,
+                                                    batch_out, coords_out, shifted_out, semantic_out, batch_offsets_out, batch_size);
     D3_LAUNCH_CHECK();
     return 0;
 }

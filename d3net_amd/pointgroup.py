@@ -133,6 +133,7 @@ PREFETCH_THREAD = 1     # 1: the input prefetch on a helper thread; 0: from the 
 CLUSTER_THREAD = 0      # 1: the shifted clustering branch on a helper thread (rounds 2-4); 0: both branches from the step's thread (begin / end)
 PREFETCH_TIMEOUT_S = 120
 PREFETCH_PADCAST = 1    # (A/B switch: the prefetch stage also prepares the stem's padded bf16 operand)
+SELECT_WITH_OFFSETS = 1  # (A/B switch) the object points' batch offsets come out of the cluster_select launch (0: six library launches behind it)
 EARLY_POINT_GRADS = 1   # (A/B switch of tools/ab.py; the per-model switch is PointGroup.early_point_grads)
 PHASES = None   # tools/phase_times.py: list of (name, cuda event) marks on the current stream when not None
 
@@ -613,9 +614,14 @@ class PointGroup(nn.Module):
             if not self.requires_gt_mask:
                 object_idxs = torch.nonzero(semantic_preds > 0, as_tuple=False).view(-1)   # ">0" as in the reference (:288)
                 # the object points' batch ids / coordinates / shifted coordinates / classes in one pass (csrc/clusterprep.hip)
-                batch_idxs_, coords_, shifted_xyz, semantic_preds_ = pointgroup_ops.cluster_select(
-                    data_dict["locs"], cluster_offsets.detach(), semantic_preds, batch_idxs, object_idxs)
-                batch_offsets_ = self.get_batch_offsets(batch_idxs_, batch_size)
+                # (+ the object points' batch offsets, :296 get_batch_offsets, off the boundaries of the sorted id column in the same launch)
+                if SELECT_WITH_OFFSETS:
+                    batch_idxs_, coords_, shifted_xyz, semantic_preds_, batch_offsets_ = pointgroup_ops.cluster_select(
+                        data_dict["locs"], cluster_offsets.detach(), semantic_preds, batch_idxs, object_idxs, batch_size=batch_size)
+                else:
+                    batch_idxs_, coords_, shifted_xyz, semantic_preds_ = pointgroup_ops.cluster_select(
+                        data_dict["locs"], cluster_offsets.detach(), semantic_preds, batch_idxs, object_idxs)
+                    batch_offsets_ = self.get_batch_offsets(batch_idxs_, batch_size)
 
                 def cluster_branch(xyz, mean_active, marks=False):
                     # (padded lists: same neighbours, no host round trip for nActive; bfs_cluster reads either form)

@@ -499,9 +499,10 @@ def voxelization_cat(feats_a, feats_b, map_rule, mode=4):
     return out
 
 
-def cluster_select(locs, pt_offsets, semantic_preds, batch_idxs, object_idxs):
+def cluster_select(locs, pt_offsets, semantic_preds, batch_idxs, object_idxs, batch_size=None):
     """-> batch_idxs_ (n) int32, coords_ (n,3), shifted (n,3) = coords_ + offsets_, semantic_preds_ (n) int32 of the object points
-    (d3_cluster_select: model/pointgroup.py:288-296 in one pass)"""
+    (d3_cluster_select: model/pointgroup.py:288-296 in one pass); with batch_size also their (batch_size + 1) batch offsets
+    (:296 get_batch_offsets, for the SORTED id column the collate function builds: d3_cluster_select2) as a fifth value"""
     locs, pt_offsets = locs.contiguous(), pt_offsets.contiguous()
     assert locs.dtype == torch.float32 and pt_offsets.dtype == torch.float32 and semantic_preds.dtype == torch.int64
     assert batch_idxs.dtype == torch.int32 and object_idxs.dtype == torch.int64
@@ -509,10 +510,19 @@ def cluster_select(locs, pt_offsets, semantic_preds, batch_idxs, object_idxs):
     b = torch.empty(n, dtype=torch.int32, device=dev)
     sem = torch.empty(n, dtype=torch.int32, device=dev)
     xyz = torch.empty((2, n, 3), dtype=torch.float32, device=dev)
+    if batch_size is not None and n > 0:
+        boff = torch.empty(int(batch_size) + 1, dtype=torch.int32, device=dev)
+        with _on(dev):
+            check(_lib.lib().d3_cluster_select2(_ptr(locs), _ptr(pt_offsets), _ptr(semantic_preds.contiguous()), _ptr(batch_idxs.contiguous()),
+                                                _ptr(object_idxs.contiguous()), n, int(batch_size), _ptr(b), _ptr(xyz[0]), _ptr(xyz[1]), _ptr(sem),
+                                                _ptr(boff), _stream()), "cluster_select2")
+        return b, xyz[0], xyz[1], sem, boff
     with _on(dev):
         check(_lib.lib().d3_cluster_select(_ptr(locs), _ptr(pt_offsets), _ptr(semantic_preds.contiguous()), _ptr(batch_idxs.contiguous()),
                                            _ptr(object_idxs.contiguous()), n, _ptr(b), _ptr(xyz[0]), _ptr(xyz[1]), _ptr(sem), _stream()),
               "cluster_select")
+    if batch_size is not None:
+        return b, xyz[0], xyz[1], sem, torch.zeros(int(batch_size) + 1, dtype=torch.int32, device=dev)
     return b, xyz[0], xyz[1], sem
 
 

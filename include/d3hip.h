@@ -50,6 +50,11 @@ int d3_sec_max(const float *inp, const int *offsets, float *out, int nProposal, 
 int d3_cluster_select(const float *locs, const float *pt_offsets, const int64_t *semantic_preds, const int *batch_idxs,
                       const int64_t *object_idxs, int n, int *batch_out, float *coords_out, float *shifted_out, int *semantic_out,
                       void *stream);
+/* select + the batch offsets of the object points (model/pointgroup.py:110-122 get_batch_offsets, :296): batch_offsets_out[b] = object
+ * points with a batch id below b, b = 0..batch_size, read off the boundaries of the (sorted) id column in the same pass; n >= 1 */
+int d3_cluster_select2(const float *locs, const float *pt_offsets, const int64_t *semantic_preds, const int *batch_idxs,
+                       const int64_t *object_idxs, int n, int batch_size, int *batch_out, float *coords_out, float *shifted_out,
+                       int *semantic_out, int *batch_offsets_out, void *stream);
 int d3_cluster_merge(const int *idx1, int S1, const int *off1, int P1, const int *idx2, int S2, const int *off2, int P2,
                      const int64_t *object_idxs, const int *batch_idxs, int *out_idx, int *out_off, int *out_bid, void *stream);
 /* Per-proposal bookkeeping between the score head and the proposal selection (model/pointgroup.py:338-372): npoint (P) = points

@@ -675,6 +675,18 @@ def test_cluster_select_and_merge_equal_the_library_op_chain(dev):
     b_, c_, sh_, s_ = P.cluster_select(locs, offs, sem, batch, obj)
     assert torch.equal(b_, batch[obj]) and torch.equal(c_, locs[obj]) and torch.equal(s_, sem[obj].int())
     assert torch.equal(sh_, locs[obj] + offs[obj])
+    # ... and with the batch offsets of the object points (get_batch_offsets, model/pointgroup.py:110-122) from the same launch: every
+    # pattern of scenes WITHOUT object points (first, middle, last, all but one), a single object point
+    from d3net_amd.pointgroup import PointGroup
+    for B, present in ((4, (0, 1, 2, 3)), (6, (1, 2, 4)), (6, (0, 5)), (5, (3,)), (3, (0, 1, 2))):
+        bt = torch.from_numpy(np.sort(rng.choice(np.array(present), N)).astype(np.int32)).to(dev)
+        for ob in (obj, obj[7:8]):
+            got = P.cluster_select(locs, offs, sem, bt, ob, batch_size=B)
+            assert len(got) == 5 and torch.equal(got[0], bt[ob]) and torch.equal(got[2], locs[ob] + offs[ob])
+            want = PointGroup.get_batch_offsets(bt[ob], B)
+            assert got[4].dtype == torch.int32 and torch.equal(got[4], want), (B, present, got[4].tolist(), want.tolist())
+    e = P.cluster_select(locs, offs, sem, batch, obj[:0], batch_size=4)
+    assert e[0].numel() == 0 and e[4].tolist() == [0, 0, 0, 0, 0]
     n = obj.numel()
 
     def fake(nc, lo, hi):
