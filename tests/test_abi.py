@@ -41,6 +41,11 @@ def test_host_side_constants(built_lib):
     assert l.d3_adamw_chunk() == 4096
     assert l.d3_bfs_cluster_erec_bytes(10) == 160
     assert l.d3_bfs_cluster_ws_bytes(1000) > 17 * 4 * 1000
+    # the padded lists' range (round 5): n * cap slots inside start_len's int range -- the library's own bound, not 2 GiB of slots
+    from d3net_amd import pointgroup_ops as P
+    assert P.ballquery_padded_fits(1) and P.ballquery_padded_fits(852_000) and P.ballquery_padded_fits(2_147_483)
+    assert not P.ballquery_padded_fits(2_147_484) and not P.ballquery_padded_fits(0)
+    assert P.ballquery_padded_fits(536_870, max_bytes=2 << 30) and not P.ballquery_padded_fits(536_871, max_bytes=2 << 30)
 
 
 def test_product_never_imports_oracle():
