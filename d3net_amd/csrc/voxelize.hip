@@ -308,22 +308,32 @@ __global__ void vi_init_kernel(unsigned long long *keys, int *first, size_t cap,
 
 __global__ void vi_insert_kernel(const int64_t *__restrict__ coords, int n, int ncols, unsigned long long *keys,
                                  int *first, size_t cap, int *slot_of, int *scalars) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long key;
-    if (!vi_pack(coords + (size_t)i * ncols, ncols, key)) { scalars[2] = 1; key &= ~(1ull << 63); }
-    size_t slot = vi_hash(key) & (cap - 1);
-    for (size_t probe = 0; probe < cap; probe++) {
-        unsigned long long prev = atomicCAS(&keys[slot], VI_EMPTY, key);
-        if (prev == VI_EMPTY || prev == key) {
-            atomicMin(&first[slot], i);
-            slot_of[i] = (int)slot;
-            return;
+    // Round 5: points of one voxel often follow each other (cluster members arrive in BFS order, scene points in scan order): only the
+    // FIRST lane of a run of equal keys inside the wave probes the table -- its index is the run's smallest, so first[] gets the same
+    // minimum -- and hands the slot to the rest of the run by a shuffle (~4x fewer CAS / atomicMin pairs on the same cache lines).
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = i < n;
+    unsigned long long key = VI_EMPTY;
+    if (live && !vi_pack(coords + (size_t)i * ncols, ncols, key)) { scalars[2] = 1; key &= ~(1ull << 63); }
+    const unsigned long long pk = __shfl_up(key, 1);
+    const bool head = live && (lane == 0 || pk != key);
+    const unsigned long long heads = __ballot(head);
+    int myslot = 0;
+    if (head) {
+        size_t slot = vi_hash(key) & (cap - 1);
+        bool done = false;
+        for (size_t probe = 0; probe < cap; probe++) {
+            unsigned long long prev = atomicCAS(&keys[slot], VI_EMPTY, key);
+            if (prev == VI_EMPTY || prev == key) { atomicMin(&first[slot], i); myslot = (int)slot; done = true; break; }
+            slot = (slot + 1) & (cap - 1);
         }
-        slot = (slot + 1) & (cap - 1);
+        if (!done) scalars[2] = 2;  // table full (cannot happen with cap >= 2n)
     }
-    scalars[2] = 2;  // table full (cannot happen with cap >= 2n)
-    slot_of[i] = 0;
+    // the head of my run: the highest head lane at or below mine (a dead lane's key is VI_EMPTY, which no live key equals)
+    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int hl = below ? 63 - __builtin_clzll(below) : lane;
+    myslot = __shfl(myslot, hl);
+    if (live) slot_of[i] = myslot;
 }
 
 __global__ void vi_flag_kernel(const int *first, const int *slot_of, int *flag, int n) {
@@ -355,13 +365,17 @@ __global__ void vi_p2v_kernel(const int *slot_of, const int *slot_vid, int *inpu
     }
     (void)scalars;
 }
-// maxActive = the largest voxel population (after vi_p2v_kernel): every voxel's first point reads its counter
-__global__ void vi_max_kernel(const int *flag, const int *slot_of, const int *slot_vid, const int *cnt, int n, int *scalars) {
+// maxActive = the largest voxel population: the maximum of cnt[0 .. M) once vi_p2v_kernel has counted and vi_total_kernel has written
+// M (scalars[0]) -- one contiguous read per voxel (round 5: up to round 4 every voxel's FIRST POINT chased flag -> slot -> voxel id ->
+// count, four dependent random reads per point: 92 us for 400 k points, on the critical path).  One word for the whole launch: a
+// wave whose maximum is not above the word's current value (read at device scope) has nothing to add.
+__global__ void vi_max_kernel(const int *__restrict__ cnt, int n, int *scalars) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    int c = 0;
-    if (i < n && flag[i]) c = cnt[slot_vid[slot_of[i]]];
+    const int M = scalars[0];
+    if ((int)(blockIdx.x * blockDim.x) >= M) return;
+    int c = (i < M && i < n) ? cnt[i] : 0;
     for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
-    if (lane == 0 && c > 0) atomicMax(&scalars[1], c);
+    if (lane == 0 && c > 0 && c > __hip_atomic_load(&scalars[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&scalars[1], c);
 }
 __global__ void vi_total_kernel(const int *flag, const int *scan, int n, int *scalars) {
     if (threadIdx.x == 0 && blockIdx.x == 0) scalars[0] = n > 0 ? scan[n - 1] + flag[n - 1] : 0;
@@ -387,8 +401,8 @@ extern "C" int d3_voxelize_idx_count(const int64_t *coords, int n, int ncols, in
     if (rc) return rc;
     vi_assign_kernel<<<nb, T, 0, s>>>(w.flag, w.scan, w.slot_of, w.slot_vid, n);
     vi_p2v_kernel<<<nb, T, 0, s>>>(w.slot_of, w.slot_vid, input_map, w.cnt, n, w.scalars);
-    vi_max_kernel<<<nb, T, 0, s>>>(w.flag, w.slot_of, w.slot_vid, w.cnt, n, w.scalars);
     vi_total_kernel<<<1, 64, 0, s>>>(w.flag, w.scan, n, w.scalars);
+    vi_max_kernel<<<nb, T, 0, s>>>(w.cnt, n, w.scalars);
     D3_LAUNCH_CHECK();
     int h[3];
     D3_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -400,20 +414,27 @@ extern "C" int d3_voxelize_idx_count(const int64_t *coords, int n, int ncols, in
     return 0;
 }
 
-// one thread per element of the (M, maxActive+1) rule table: coalesced stores
-__global__ void vi_rules_kernel(int mode, const int *__restrict__ cnt, const int *__restrict__ vstart,
-                                const int *__restrict__ sorted_pts, int *__restrict__ out_map, long long total,
-                                int maxActive) {
-    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int w = maxActive + 1;
-    const int v = (int)(e / w), j = (int)(e % w);
+// The (M, maxActive + 1) rule table: a GROUP of G lanes per voxel row (G = the power of two that covers the row, at most 64), the
+// group's lanes stride over the row -- the voxel's count and list start are read once per row, the point ids and the stores are
+// contiguous.  (Round 5: one thread per ELEMENT with a 64-bit e / w, e % w per thread took 102 us for the 2 M elements of the
+// cluster voxelisation -- on the critical path between the clustering and ScoreNet.)
+__global__ __launch_bounds__(256) void vi_rules_kernel(int mode, const int *__restrict__ cnt, const int *__restrict__ vstart,
+                                                       const int *__restrict__ sorted_pts, int *__restrict__ out_map, int M,
+                                                       int maxActive, int gshift) {
+    const int G = 1 << gshift, w = maxActive + 1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long v = t >> gshift;
+    if (v >= M) return;
+    const int j0 = (int)(t & (G - 1));
     const int c = cnt[v];
     const int *pts = sorted_pts + vstart[v];
-    int val;
-    if (mode == 3 || mode == 4) val = (j == 0) ? c : (j - 1 < c ? pts[j - 1] : 0);  // zero padded (voxelize.cpp:151)
-    else val = (j == 0) ? 1 : ((mode == 2) ? pts[c - 1] : pts[0]);  // mode 1: front(), mode 2: back() (:130-140)
-    out_map[e] = val;
+    int *row = out_map + v * w;
+    for (int j = j0; j < w; j += G) {
+        int val;
+        if (mode == 3 || mode == 4) val = (j == 0) ? c : (j - 1 < c ? pts[j - 1] : 0);  // zero padded (voxelize.cpp:151)
+        else val = (j == 0) ? 1 : ((mode == 2) ? pts[c - 1] : pts[0]);  // mode 1: front(), mode 2: back() (:130-140)
+        row[j] = val;
+    }
 }
 // voxel coordinate = coordinate row of the first listed point (voxelize_outputmap, voxelize.cpp:34-49)
 __global__ void vi_coords_kernel(const int64_t *__restrict__ coords, int ncols, int mode,
@@ -448,9 +469,9 @@ extern "C" int d3_voxelize_idx_fill(const int64_t *coords, int n, int ncols, int
     int bits = 1; while ((1ll << bits) < (long long)M && bits < 31) bits++;
     rc = d3_sort_pairs_i32(input_map, w.sorted_keys, w.flag, w.sorted_pts, n, bits, w.temp, w.temp_bytes, s);
     if (rc) return rc;
-    long long total = (long long)M * (maxActive + 1);
-    vi_rules_kernel<<<(int)((total + T - 1) / T), T, 0, s>>>(mode, w.cnt, w.vstart, w.sorted_pts, output_map, total,
-                                                           maxActive);
+    int gshift = 0; while ((1 << gshift) < maxActive + 1 && gshift < 6) gshift++;
+    const long long rthreads = (long long)M << gshift;
+    vi_rules_kernel<<<(int)((rthreads + T - 1) / T), T, 0, s>>>(mode, w.cnt, w.vstart, w.sorted_pts, output_map, M, maxActive, gshift);
     vi_coords_kernel<<<(M * ncols + T - 1) / T, T, 0, s>>>(coords, ncols, mode, w.cnt, w.vstart, w.sorted_pts,
                                                          output_coords, M);
     D3_LAUNCH_CHECK();
