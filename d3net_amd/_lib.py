@@ -65,6 +65,12 @@ SIGNATURES = {
     "d3_kmap_k3_pack16": (i32, [vp, i32, vp, vp, vp]),
     "d3_kmap_k3_16": (i32, [vp, i32, i32, vp, sz, vp, vp, vp, vp]),
     "d3_net_set_k3_16": (i32, [vp, vp, vp]),
+    "d3_kmap_k3_q16_bytes": (sz, [i32]),
+    "d3_kmap_k3_packq": (i32, [vp, i32, vp, vp, vp]),
+    "d3_spconv_fwd3_nparts": (i32, [i32, i32, i32]),
+    "d3_spconv_fwd3": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "d3_spconv_fwd3_bnbwd": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, vp]),
+    "d3_spconv_fwd3_launches": (i64, []),
     "d3_net_padded_channels": (i32, [vp]),
     "d3_net_padcast": (i32, [vp, vp, vp, i64, vp]),
     "d3_net_set_padded_input": (i32, [vp, vp]),

@@ -222,6 +222,12 @@ int d3_kmap_k3(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int 
 int d3_kmap_k3_pack16(const int *nbr, int M, void *nbr16, int *ok16, void *stream);
 /* d3_kmap_k3 that writes the 16-bit form and its flag in the same pass (what the coordinate manager calls for big levels) */
 int d3_kmap_k3_16(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *nbr16, int *ok16, void *stream);
+/* LANE TABLE of a d3_kmap_k3 table (round 6; read by d3_spconv_fwd3*): per 16-row tile 64 lanes x 8 uint16 -- lane (r = lane & 15,
+ * g = lane >> 4), slot q < 7 = nbr[tile*16 + r][4q + g] - tile*16 + 32768 (0xFFFF: absent; offset 27 and slot 7 are pads): the
+ * order in which a wave of the convolution kernel consumes the map, one 16-byte load per lane and tile.  d3_kmap_k3_q16_bytes(M)
+ * bytes; *okq (device int) = 1 when every entry fits, else 0 (the consumers then read the dense table). */
+size_t d3_kmap_k3_q16_bytes(int M);
+int d3_kmap_k3_packq(const int *nbr, int M, void *tq, int *okq, void *stream);
 int d3_kmap_down_count(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *parent, int *kidx,
                        int *Mout_host, void *stream);
 int d3_kmap_down_fill(const int *coords, int M, int ts, void *ws, size_t ws_bytes, const int *parent,
@@ -309,6 +315,20 @@ int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void 
                              const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                              const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma, float *dbeta,
                              int accum, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
+/* Third-generation K = 27 forward / data-gradient kernel (round 6, csrc/spconv3.hip; replaces MinkowskiConvolution forward and
+ * its data gradient at the stride-1 kernel-3 layers: model/common.py:38,41,66; model/pointgroup.py:70): x (Min, ldx) bf16,
+ * tq = the level's lane table (d3_kmap_k3_packq), Wp = d3_spconv_pack fragments (K = 27), out (Mout, ldo) fp32 or bf16
+ * (D3_CONV_OUTBF16), optional fp32 residual, optional BatchNorm partials part [d3_spconv_fwd3_nparts()][2][Cout] (+ part2
+ * [16][2][Cout] fp64, zeroed by the caller).  Shapes with an instance: Cin/Cout in {16/16, 16/32, 32/16, 32/32, 32/64, 48/48,
+ * 64/32}; others return D3_ERR_ARG (d3_spconv_fwd3_nparts() == 0).  _bnbwd: as d3_spconv_fwd2_bnbwd; bnx is fp32, or bf16 with
+ * D3_CONV_XBF16 in flags.  d3_spconv_fwd3_launches(): launches so far (tests: the path really ran). */
+int d3_spconv_fwd3_nparts(int Mout, int Cin, int Cout);
+int d3_spconv_fwd3(const void *x, int ldx, const void *tq, const void *Wp, void *out, int ldo, const float *res, int ldr,
+                   float *part, double *part2, int Min, int Mout, int Cin, int Cout, int flags, void *stream);
+int d3_spconv_fwd3_bnbwd(const void *x, int ldx, const void *tq, const void *Wp, void *out, int ldo, float *part, double *part2,
+                         const void *bnx, int ldbx, const float *mean, const float *var, const float *gamma, const float *beta,
+                         float eps, int relu, int Min, int Mout, int Cin, int Cout, int flags, void *stream);
+long long d3_spconv_fwd3_launches(void);
 /* flags of the two queries: the D3_CONV_XSTAT / D3_CONV_XBF16 / D3_CONV_DYBF16 bits of the d3_spconv_wgrad2 call they size
  * (the kernel, and with it the number of row splits, depends on the operand types) */
 size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
