@@ -71,6 +71,7 @@ SIGNATURES = {
     "d3_spconv_fwd3": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_fwd3_bnbwd": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_fwd3_launches": (i64, []),
+    "d3_spconv_last_nparts": (i32, []),
     "d3_net_padded_channels": (i32, [vp]),
     "d3_net_padcast": (i32, [vp, vp, vp, i64, vp]),
     "d3_net_set_padded_input": (i32, [vp, vp]),

@@ -906,12 +906,18 @@ static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout, bool f32 = false
     return p;
 }
 
+extern "C" int d3_spconv_fwd3_nparts(int Mout, int Cin, int Cout);
+// rows of the BatchNorm partial table a forward / data-gradient call may write: the larger of the two kernels that can serve the
+// shape (which one runs depends on the tables the call is handed); d3_spconv_last_nparts() says how many the call did write
 extern "C" int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout) {
-    return conv2_plan(Mout, K, Cin, Cout).grid;
+    const int g2 = conv2_plan(Mout, K, Cin, Cout).grid, g3 = K == 27 ? d3_spconv_fwd3_nparts(Mout, Cin, Cout) : 0;
+    return g2 > g3 ? g2 : g3;
 }
 // flags: D3_CONV_F32 changes the weight footprint and with it the workgroup shape
 extern "C" int d3_spconv_fwd2_nparts_ex(int Mout, int K, int Cin, int Cout, int flags) {
-    return conv2_plan(Mout, K, Cin, Cout, (flags & D3_CONV_F32) != 0).grid;
+    const int g2 = conv2_plan(Mout, K, Cin, Cout, (flags & D3_CONV_F32) != 0).grid;
+    const int g3 = (K == 27 && !(flags & D3_CONV_F32)) ? d3_spconv_fwd3_nparts(Mout, Cin, Cout) : 0;
+    return g2 > g3 ? g2 : g3;
 }
 
 // which kernel d3_spconv_fwd2* runs for this shape: out[6] = {split (1: spconv_fwd2_split_kernel), waves per workgroup,
@@ -1080,8 +1086,16 @@ static int launch_fwd2_split(const Conv2Args &a, const Conv2Plan &p, hipStream_t
 }
 
 static thread_local const void *g_next_tbl16 = nullptr;
-static thread_local const int *g_next_ok16 = nullptr;
-void d3_spconv_next_tbl16(const void *tbl16, const int *ok16) { g_next_tbl16 = tbl16; g_next_ok16 = ok16; }
+static thread_local const void *g_next_tblq = nullptr;
+void d3_spconv_next_tbl16(const void *tbl16, const void *tblq) { g_next_tbl16 = tbl16; g_next_tblq = tblq; }
+static thread_local int g_last_nparts = 0;
+extern "C" int d3_spconv_last_nparts(void) { return g_last_nparts; }
+void d3_spconv_set_last_nparts(int n) { g_last_nparts = n; }
+// spconv3.hip
+struct Conv3Bn { const void *x; const float *mean, *var, *gamma, *beta; int ldx, relu, xbf16; float eps; };
+int d3_conv3_run(const void *x, int ldx, const void *tq, const void *Wp, void *out, int ldo, const float *res, int ldr, float *part,
+                 double *part2, int Min, int Mout, int Cin, int Cout, int obf16, const Conv3Bn *bn, int *nparts_out, hipStream_t s);
+extern "C" int d3_spconv_fwd3_nparts(int Mout, int Cin, int Cout);
 // second-level partial table of the NEXT forward / data-gradient call of this thread (same hand-over as the 16-bit map hint):
 // [C2_P2_ROWS][2][ceil(Cout / 16) * 16] doubles, zeroed by the caller; ignored when the call takes no partials
 static thread_local double *g_next_part2 = nullptr;
@@ -1094,8 +1108,8 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
                      float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, const Conv2Fin *fin,
                      void *stream) {
     D3_CLEAR();
-    const void *tbl16 = g_next_tbl16; const int *ok16 = g_next_ok16;      // the hint belongs to THIS call, whatever it does with it
-    g_next_tbl16 = nullptr; g_next_ok16 = nullptr;
+    const void *tbl16 = g_next_tbl16, *tblq = g_next_tblq;      // the hints belong to THIS call, whatever it does with them
+    g_next_tbl16 = nullptr; g_next_tblq = nullptr;
     double *part2 = g_next_part2;
     g_next_part2 = nullptr;
     if (Mout <= 0) return 0;
@@ -1107,6 +1121,16 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     if ((xbf16 && (ldx & 7)) || (!xbf16 && (ldx & 3)) || ldx < Cin || ldo < Cout) return D3_ERR_ARG;
     if ((Cout & 3) || (ldo & 3) || (res && (ldr & 3))) return D3_ERR_ARG;   // float4 epilogue
     hipStream_t s = d3_stream(stream);
+    // round 6: the big levels' K = 27 layers on the lane table (spconv3.hip) -- bf16 rows, no accumulate-into, no in-launch finalize
+    if (tblq && tbl && K == 27 && xbf16 && !f32 && !(flags & D3_CONV_ACCUM) && !fin && d3_tune(D3T_C3) != 0 &&
+        Mout >= d3_tune(D3T_C2_GRIDCAP) * 16 && d3_spconv_fwd3_nparts(Mout, Cin, Cout) > 0 && !(bn && res)) {
+        Conv3Bn b3;
+        if (bn) b3 = Conv3Bn{bn->x, bn->mean, bn->var, bn->gamma, bn->beta, bn->ldx, bn->relu, 0, bn->eps};
+        int np = 0;
+        const int rc3 = d3_conv3_run(x, ldx, tblq, Wp, out, ldo, res, ldr, part, part ? part2 : nullptr, Min, Mout, Cin, Cout,
+                                     (flags & D3_CONV_OUTBF16) ? 1 : 0, bn ? &b3 : nullptr, &np, s);
+        if (rc3 != D3_ERR_ARG) { g_last_nparts = np; return rc3; }
+    }
     Conv2Args a;
     a.x = x; a.tbl = tbl; a.Wp = (const unsigned short *)Wp; a.out = out; a.res = res; a.part = part;
     a.part2 = part ? part2 : nullptr;
@@ -1115,7 +1139,6 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     a.invK = (65536u + K - 1) / K;
     a.interleave = d3_tune(D3T_C2_INTERLEAVE) != 0 ? 1 : 0;
     a.tbl16 = (tbl && tbl16 && K == 27 && !f32 && xbf16) ? (const unsigned int *)tbl16 : nullptr;   // (only the static instances launch with it)
-    (void)ok16;
     a.xbf16 = xbf16; a.f32 = f32; a.accum = (flags & D3_CONV_ACCUM) ? 1 : 0; a.ntiles = (Mout + 15) / 16;
     a.obf16 = (flags & D3_CONV_OUTBF16) ? 1 : 0;
     if (a.obf16 && (a.accum || res || f32)) return D3_ERR_ARG;
@@ -1136,6 +1159,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         a.fin_a = fin->a; a.fin_b = fin->b; a.fin_c = fin->c; a.fin_d = fin->d; a.fin_momentum = fin->momentum;
     }
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout, f32 != 0);
+    g_last_nparts = p.grid;
     if (!p.split && a.xbytes == 0u) return D3_ERR_RANGE;   // the wave-per-tile kernel addresses x through a raw buffer: <= 2 GiB, < 2^24 rows
     const double bytes = (xbf16 ? 2.0 : 4.0) * (double)Min * Cin + (a.obf16 ? 2.0 : 4.0) * (double)Mout * Cout + (f32 ? 4.0 : 2.0) * (double)K * Cin * Cout +
                          (tbl ? 4.0 * (double)Mout * K : 0.0) + (res ? 4.0 * (double)Mout * Cout : 0.0);
@@ -2134,8 +2158,8 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
                                 int Mout, int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes,
                                 void *stream) {
     D3_CLEAR();
-    const void *tbl16 = g_next_tbl16; const int *ok16 = g_next_ok16;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
-    g_next_tbl16 = nullptr; g_next_ok16 = nullptr;
+    const void *tbl16 = g_next_tbl16; const int *ok16 = nullptr;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
+    g_next_tbl16 = nullptr; g_next_tblq = nullptr;
     if (K < 1 || K > C2_MAXK || Cin < 8 || Cout < 8 || (Cin & 7) || (Cout & 7) || Cin > 224 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
     hipStream_t s = d3_stream(stream);

@@ -57,6 +57,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_BQ_HALF", 1},              // 0: the cell-grid ball query runs one WAVE per query point (rounds 3-4); 1: two queries per wave (32 lanes each: 27 probes, up to 64 candidates as two elements per lane, bitonic order inside the half)
     {"D3_C2_KSPLIT", 0},            // 1: the stem convolution (K = 27, 136 -> 16) runs spconv_fwd2_ks_kernel -- 4 waves per 16-row tile, each a quarter of the offsets, partial sums through LDS: the XCD's window of rows in flight shrinks 4x.  Measured: L2-miss traffic 990 -> 660 MB per launch, time 268 -> 286 us (the kernel is not bound by that traffic): off
     {"D3_C2_COMPACT", 1},           // the statically shaped forward / data-gradient convolutions (K = 27, bf16 rows) drop the offsets no row of a 16-row tile has before the reduction loop (spconv_fwd2_c_kernel; raster-ordered rows of the 2 cm level: 15.9 of 27 offsets live per tile): 1 (default) the stem only (266 -> 231 us), 2 every static instance (slower: 16 -> 16 34.5 -> 50.4 us), 0 never (rounds 2-4)
+    {"D3_C3", 1},                   // 0: the K = 27 convolutions of the big levels never run spconv_fwd3_kernel (lane table, round 6) -- A/B against spconv_fwd2_kernel
 };
 std::atomic<int> g_val[D3T_COUNT];
 std::once_flag g_once;

@@ -671,7 +671,7 @@ struct Net {
     int xp_tensor = -1;                // the PADCAST op's output tensor (the stem's zero-padded bf16 input), -1: none
     const void *xp_ext = nullptr;      // its values prepared by the caller (d3_net_padcast) for the next forward / backward call, or NULL
     std::vector<const void *> k3_16;   // per level: 16-bit delta form of the k3 table for the next forward / backward call (or NULL)
-    std::vector<const int *> ok16;
+    std::vector<const void *> ok16;    // per level: the lane table (spconv3.hip) for the next forward / backward call (or NULL)
     std::vector<int> chunk_op;
     std::vector<hipEvent_t> chunk_ev_side, chunk_ev_main;
     RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (ring of RED_RING slots) + device copies of the reduce jobs
@@ -1001,9 +1001,11 @@ extern "C" int d3_net_set_k3_16(void *h, const void *const *k3_16, const int *co
     if (!n) return D3_ERR_ARG;
     n->k3_16.assign((size_t)n->nlevels, nullptr);
     n->ok16.assign((size_t)n->nlevels, nullptr);
-    if (k3_16 && ok16 && d3_tune(D3T_KMAP16) != 0 && !n->f32)
-        for (int l = 0; l < n->nlevels; l++)
-            if (k3_16[l] && ok16[l]) { n->k3_16[(size_t)l] = k3_16[l]; n->ok16[(size_t)l] = ok16[l]; }
+    if (d3_tune(D3T_KMAP16) != 0 && !n->f32)
+        for (int l = 0; l < n->nlevels; l++) {
+            if (k3_16 && k3_16[l]) n->k3_16[(size_t)l] = k3_16[l];
+            if (ok16 && ok16[l]) n->ok16[(size_t)l] = (const void *)ok16[l];      // (second array: the lane tables, round 6)
+        }
     return 0;
 }
 // Round 5 (input prefetch): the stem's zero-padded bf16 input prepared OUTSIDE the forward -- d3_net_padcast writes it (M rows x
@@ -1153,7 +1155,6 @@ static inline char *tptr(const Net *n, char *arena, const void *input, int tenso
 // its coordinate manager and ran again without re-setting them read freed tables): every return path of the two entry points
 // drops them, and the thread-local hint of d3_spconv_next_tbl16 with them (an error return taken between setting the hint and
 // the convolution that consumes it must not hand the table to an unrelated K = 27 convolution on this thread).
-void d3_spconv_next_tbl16(const void *tbl16, const int *ok16);
 static void net_drop_k3_16(Net *n) {
     if (n) { n->k3_16.assign(n->k3_16.size(), nullptr); n->ok16.assign(n->ok16.size(), nullptr); n->xp_ext = nullptr; }
     d3_spconv_next_tbl16(nullptr, nullptr);
@@ -1245,8 +1246,8 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
             const float *res = nullptr; int ldr = 0;
             if (o.res >= 0) { res = (const float *)tptr(n, arena, input, o.res); ldr = n->T[o.res].ld; }
             float *part = (o.stats && training) ? (float *)(arena + o.part_off) : nullptr;
-            if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
-                d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
+            if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && (n->k3_16[(size_t)o.mlevel] || n->ok16[(size_t)o.mlevel]))
+                d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], use_p2 || !part ? n->ok16[(size_t)o.mlevel] : nullptr);
             if (part && use_p2) d3_spconv_next_part2((double *)(arena + o.part2_off));
             int rc;
             if (part && o.fin_bn >= 0 && Mout <= n->lb_rows) {
@@ -1261,6 +1262,7 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                                     res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
             }
             if (rc) return rc;
+            if (part) o.nparts = d3_spconv_last_nparts();      // (rows actually written: the kernel depends on the tables at hand)
         } else if (o.type == OP_BNACT) {
             const TensorD &ti = n->T[o.in], &to = n->T[o.out];
             const int M = n->rows[ti.level], C = ti.C;
@@ -1462,8 +1464,8 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
                 const int obf = gibf ? D3_CONV_OUTBF16 : 0;          // (activation gradients with one writer and one reader: Net::gabf)
                 if (root_i >= 0) wait_pending(root_i);
-                const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel];
-                if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
+                const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && (n->k3_16[(size_t)o.mlevel] || n->ok16[(size_t)o.mlevel]);
+                if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], (use_p2 || o.bn_of_in < 0) ? n->ok16[(size_t)o.mlevel] : nullptr);
                 int rc;
                 if (o.bn_of_in >= 0) {
                     const OpD &b = n->ops[o.bn_of_in];
@@ -1479,6 +1481,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
                                                   (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
                                                   pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
+                    if (!rc) n->ops[o.bn_of_in].bparts = d3_spconv_last_nparts();
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
                                         (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
@@ -1511,7 +1514,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
                 char *wpart = garena + o.wpart_off;
                 if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
-                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
+                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], nullptr);
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
                                           flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? wst : s));
                 if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)

@@ -164,14 +164,18 @@ class CoordinateManager:
             ws = self._ws(M)
             with _on(self.device):
                 if M >= self.K3_16_MIN_ROWS and self.want16:      # big level: the 16-bit form and its validity flag in the same pass
+                    L = _lib.lib()
                     n16 = torch.empty(M * 27 + 2, dtype=torch.int16, device=self.device)
-                    ok = torch.empty(1, dtype=torch.int32, device=self.device)
-                    check(_lib.lib().d3_kmap_k3_16(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _ptr(n16), _ptr(ok), _stream()), "kmap_k3_16")
-                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    ok = torch.empty(2, dtype=torch.int32, device=self.device)      # validity flags: [16-bit table, lane table]
+                    check(L.d3_kmap_k3_16(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _ptr(n16), _ptr(ok), _stream()), "kmap_k3_16")
+                    # the lane table of the level (round 6: what spconv_fwd3_kernel reads -- csrc/spconv3.hip)
+                    tq = torch.empty(L.d3_kmap_k3_q16_bytes(M), dtype=torch.uint8, device=self.device)
+                    check(L.d3_kmap_k3_packq(_ptr(nbr), M, _ptr(tq), C.c_void_p(ok.data_ptr() + 4), _stream()), "kmap_k3_packq")
+                    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
                     host.copy_(ok, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
-                    self._k3_16[ts] = {"tbl": n16, "ok": ok, "host": host, "ev": ev, "valid": None}
+                    self._k3_16[ts] = {"tbl": n16, "tq": tq, "ok": ok, "host": host, "ev": ev, "valid": None, "validq": None}
                 else:
                     check(_lib.lib().d3_kmap_k3(_ptr(c), M, ts, _ptr(ws), ws.numel(), _ptr(nbr), _stream()), "kmap_k3")
                     self._k3_16[ts] = {"tbl": None, "valid": False}
@@ -191,7 +195,15 @@ class CoordinateManager:
         st = self._k3_16[ts]
         if st["valid"] is None and st["ev"].query():
             st["valid"] = bool(int(st["host"][0]) == 1)
+            st["validq"] = bool(int(st["host"][1]) == 1)
         return st["tbl"] if st["valid"] else None
+
+    def k3_q(self, ts):
+        """The lane table of k3(ts) (d3_kmap_k3_packq: the kernel map in the order the waves of spconv_fwd3_kernel consume it) IF its
+        validity flag has been read as 1, else None -- same protocol as k3_16()."""
+        self.k3_16(ts)
+        st = self._k3_16[ts]
+        return st.get("tq") if st.get("validq") else None
 
     def begin_pyramid(self, nlevels):
         """Enqueue the coordinate pyramid of levels 1..nlevels-1 and the copy of its row counts WITHOUT waiting for them

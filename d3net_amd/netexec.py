@@ -308,10 +308,15 @@ class NativeUNet:
             nbr = cm.k3(ts)
             keep.append(nbr); k3.append(nbr.data_ptr()); rows.append(nbr.size(0))
             t16 = cm.k3_16(ts) if (not self.exact and hasattr(cm, "k3_16")) else None    # (validated; the bf16 wave-per-tile kernels read it)
+            tq = cm.k3_q(ts) if (not self.exact and hasattr(cm, "k3_q")) else None        # (validated lane table: spconv_fwd3_kernel)
             if t16 is not None:
-                keep.append(t16); k16.append(t16.data_ptr()); ok16.append(t16.data_ptr())
+                keep.append(t16); k16.append(t16.data_ptr())
             else:
-                k16.append(0); ok16.append(0)
+                k16.append(0)
+            if tq is not None:
+                keep.append(tq); ok16.append(tq.data_ptr())
+            else:
+                ok16.append(0)
             if lev + 1 < self.nlevels:
                 ch, u, _ = cm.down(ts)
                 keep += [ch, u]; child.append(ch.data_ptr()); up.append(u.data_ptr())
@@ -319,7 +324,7 @@ class NativeUNet:
                 child.append(0); up.append(0)
             ts *= 2
         n = self.nlevels
-        keep.append(((C.c_void_p * n)(*k16), (C.c_void_p * n)(*ok16)))     # (last element: the 16-bit tables' pointer arrays)
+        keep.append(((C.c_void_p * n)(*k16), (C.c_void_p * n)(*ok16)))     # (last element: the pointer arrays of the 16-bit tables and of the lane tables)
         return ((C.c_void_p * n)(*k3), (C.c_void_p * n)(*child), (C.c_void_p * n)(*up), rows, keep)
 
     def __call__(self, feats, cm, training):
@@ -408,7 +413,8 @@ class _NetFunction(Function):
         if ctx.cm is not None and not net.exact:      # the 16-bit tables whose validity flag has landed since the forward
             n_ = net.nlevels
             ptrs = [(t.data_ptr() if t is not None else 0) for t in (ctx.cm.k3_16(1 << l) for l in range(n_))]
-            k16 = ((C.c_void_p * n_)(*ptrs), (C.c_void_p * n_)(*ptrs))
+            qptrs = [(t.data_ptr() if t is not None else 0) for t in (ctx.cm.k3_q(1 << l) for l in range(n_))]
+            k16 = ((C.c_void_p * n_)(*ptrs), (C.c_void_p * n_)(*qptrs))
         with _on(dev):
             check(L.d3_net_set_k3_16(net._net(), k16[0], k16[1]), "net_set_k3_16")
             if ctx.xp is not None:

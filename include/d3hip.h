@@ -224,7 +224,8 @@ int d3_kmap_k3_pack16(const int *nbr, int M, void *nbr16, int *ok16, void *strea
 int d3_kmap_k3_16(const int *coords, int M, int ts, void *ws, size_t ws_bytes, int *nbr, void *nbr16, int *ok16, void *stream);
 /* LANE TABLE of a d3_kmap_k3 table (round 6; read by d3_spconv_fwd3*): per 16-row tile 64 lanes x 8 uint16 -- lane (r = lane & 15,
  * g = lane >> 4), slot q < 7 = nbr[tile*16 + r][4q + g] - tile*16 + 32768 (0xFFFF: absent; offset 27 and slot 7 are pads): the
- * order in which a wave of the convolution kernel consumes the map, one 16-byte load per lane and tile.  d3_kmap_k3_q16_bytes(M)
+ * order in which a wave of the convolution kernel consumes the map, one 16-byte load per lane and tile (round 6b: the tile's
+ * LIVE offsets first, listed in a 32-byte record per tile behind the lane tables: csrc/spconv3.hip).  d3_kmap_k3_q16_bytes(M)
  * bytes; *okq (device int) = 1 when every entry fits, else 0 (the consumers then read the dense table). */
 size_t d3_kmap_k3_q16_bytes(int M);
 int d3_kmap_k3_packq(const int *nbr, int M, void *tq, int *okq, void *stream);
@@ -292,6 +293,9 @@ size_t d3_spconv_pack_bytes_ex(int K, int Cin, int Cout, int flags);   /* flags 
 int d3_spconv_pack(const float *W, void *Wp, int K, int Cin, int Cout, int flags, void *stream);
 int d3_spconv_fwd2_nparts(int Mout, int K, int Cin, int Cout);
 int d3_spconv_fwd2_nparts_ex(int Mout, int K, int Cin, int Cout, int flags);   /* flags & D3_CONV_F32: that call's partial rows */
+/* both are UPPER BOUNDS since round 6 (the kernel that serves a K = 27 shape depends on the tables the call is handed);
+ * d3_spconv_last_nparts(): the partial rows the last d3_spconv_fwd2* / d3_spconv_fwd3* call of this thread wrote */
+int d3_spconv_last_nparts(void);
 /* which kernel fwd2 runs for a shape (tests assert the variant they mean to cover): out[6] = {split (1 = the few-row
  * spconv_fwd2_split_kernel, 0 = the persistent wave-per-tile spconv_fwd2_kernel), waves per workgroup, grid.x,
  * weights resident in LDS, column tiles per workgroup, grid.y} */
@@ -413,11 +417,12 @@ int d3_net_backward(void *net, const void *const *params, const int *const *k3, 
  * d3_net_chunk_wait makes `stream` wait for chunk k of the last backward -- the caller starts that chunk's all-reduce on
  * it while the rest of the backward is still running.  2 * (nchunks + 2) <= 32, i.e. nchunks <= 14 (else D3_ERR_ARG); 0 switches the feature off. */
 int d3_net_set_chunks(void *net, const int *op_idx, int nchunks);
-/* per level: the 16-bit form of the k3 table handed to the next d3_net_forward / d3_net_backward call (NULL entries, or a NULL
- * array, = dense tables only).  The caller passes only tables whose d3_kmap_k3_pack16 flag it has READ as 1 (ok16[l]: any
- * non-NULL pointer, unused by the kernels).  The arrays are copied; the tables must stay alive like the dense ones.
- * d3_spconv_t16_launches: launches so far that read a 16-bit table (tests). */
-int d3_net_set_k3_16(void *net, const void *const *k3_16, const int *const *ok16);
+/* per level: the compact forms of the k3 table handed to the next d3_net_forward / d3_net_backward call -- k3_16[l]: the 16-bit
+ * delta table (d3_kmap_k3_pack16; read by the weight-gradient kernels), k3_q[l]: the lane table (d3_kmap_k3_packq; read by
+ * spconv_fwd3_kernel, the forward / data-gradient kernel of the big levels).  NULL entries, or NULL arrays, = dense tables only.
+ * The caller passes only tables whose validity flag it has READ as 1.  The arrays are copied; the tables must stay alive like the
+ * dense ones.  d3_spconv_t16_launches / d3_spconv_fwd3_launches: launches so far that read one (tests). */
+int d3_net_set_k3_16(void *net, const void *const *k3_16, const int *const *k3_q);
 /* Round 5 (input prefetch): the stem's zero-padded bf16 input prepared outside the forward.  d3_net_padded_channels: its width (0: this
  * executor has no such operand -- no stem, or the reference-precision program).  d3_net_padcast: (M, C_in) fp32 voxel features -> (M,
  * padded) bf16, the launch d3_net_forward would issue first.  d3_net_set_padded_input: hands the prepared buffer to the NEXT

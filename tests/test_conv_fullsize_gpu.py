@@ -128,12 +128,14 @@ def test_fwd2_big_kernel_forward_and_epilogues(dev, canon, level, kind, cin, cou
     assert relerr(out, refb) < 1e-4, relerr(out, refb)
     assert relerr(out, ref32) < 2e-2, relerr(out, ref32)
     # (2) bf16 input + residual + BatchNorm partials + strided output (second half of a concatenated buffer)
-    nparts = L.d3_spconv_fwd2_nparts(Mout, K, cin, cout)
-    assert nparts == p["grid"]
+    nparts = L.d3_spconv_fwd2_nparts(Mout, K, cin, cout)      # (an upper bound since round 6: the lane-table kernel's grid may be larger)
+    assert nparts >= p["grid"]
     pw = (cout + 15) // 16 * 16
     part = torch.full((nparts, 2, pw), float("nan"), device=dev)
     wide = torch.full((Mout, 2 * cout), -7.0, device=dev)
     _fwd2(L, xq.to(dev), tbl_f, wp, wide, Mout, K, cin, cout, flags=XBF16, res=resd, part=part, col0=cout)
+    assert L.d3_spconv_last_nparts() == p["grid"]
+    part = part[:p["grid"]]
     got = wide[:, cout:]
     want = refq + res
     assert relerr(got, want) < 1e-4, relerr(got, want)
@@ -170,7 +172,7 @@ def test_fwd2_offset_compaction_and_offset_split_equal_the_plain_kernel(dev, can
         part = torch.full((nparts, 2, pw), float("nan"), device=dev)
         _fwd2(L, x, tbl_f, wp, out, Mout, K, cin, cout, flags=XBF16, res=res, part=part)
         torch.cuda.synchronize()
-        return out, part[:, :, :cout].clone()
+        return out, part[:L.d3_spconv_last_nparts(), :, :cout].clone()
     try:
         assert L.d3_tuning_set(b"D3_C2_KSPLIT", 0) == 0 and L.d3_tuning_set(b"D3_C2_COMPACT", 0) == 0
         o0, p0 = run()
@@ -232,6 +234,7 @@ def test_fwd2_big_kernel_data_gradient_and_bn_backward_epilogue(dev, canon, leve
                                 _ptr(bnxd), cin, _ptr(meand), _ptr(vard), _ptr(gammad), _ptr(betad),
                                 eps, 1, Mout, Min, K, cout, cin, 0, _stream())
     assert rc == 0
+    part = part[:L.d3_spconv_last_nparts()]
     o2 = out2.cpu().double()
     assert float(((o2 - g).abs() * sure).max() / g.abs().max()) < 1e-4
     assert int((~sure).sum()) < 256

@@ -237,16 +237,44 @@ def test_int16_kernel_maps_are_bit_identical_to_the_dense_tables(dev):
     occ, sem, inst, _ = S.occupancy_grid()
     scene = S.scene_from_grid(occ, sem, inst)
     res = {}
-    for on in (1, 0):
-        assert L.d3_tuning_set(b"D3_KMAP16", on) == 0
-        n0 = L.d3_spconv_t16_launches()
-        res[on] = _detector_step(dev, scene) + (L.d3_spconv_t16_launches() - n0,)
-    L.d3_tuning_set(b"D3_KMAP16", 1)
+    assert L.d3_tuning_set(b"D3_C3", 0) == 0      # (round 6: the lane-table kernel would take the big levels' forward / data gradients)
+    try:
+        for on in (1, 0):
+            assert L.d3_tuning_set(b"D3_KMAP16", on) == 0
+            n0 = L.d3_spconv_t16_launches()
+            res[on] = _detector_step(dev, scene) + (L.d3_spconv_t16_launches() - n0,)
+    finally:
+        L.d3_tuning_set(b"D3_KMAP16", 1); L.d3_tuning_set(b"D3_C3", 1)
     assert res[1][3] >= 20, ("launches that read a 16-bit table", res[1][3])      # level 0: stem + 11 convs forward, their gradients
     assert res[0][3] == 0
     assert res[1][0] == res[0][0], (res[1][0], res[0][0])
     assert torch.equal(res[1][1], res[0][1]), "backbone parameter gradients"
     assert torch.equal(res[1][2], res[0][2]), "point logits"
+
+
+def test_lane_table_kernel_equals_the_dense_table_kernels_to_fp32_rounding(dev):
+    """Round 6: the K = 27 forward / data-gradient convolutions of the big levels run spconv_fwd3_kernel on the lane table
+    (csrc/spconv3.hip): same bf16 operands and fp32 accumulation as spconv_fwd2_kernel, another summation order (per tile the live
+    offsets first).  A whole detector step with D3_C3 on and off: loss to 1e-5 relative, flat backbone gradient to 2e-3 relative L2,
+    point logits to 1e-3 -- and the lane-table path must really have run (level 0: >= 20 launches)."""
+    from d3net_amd import _lib, synthetic as S
+    L = _lib.lib()
+    occ, sem, inst, _ = S.occupancy_grid()
+    scene = S.scene_from_grid(occ, sem, inst)
+    res = {}
+    try:
+        for on in (1, 0):
+            assert L.d3_tuning_set(b"D3_C3", on) == 0
+            n0 = L.d3_spconv_fwd3_launches()
+            res[on] = _detector_step(dev, scene) + (L.d3_spconv_fwd3_launches() - n0,)
+    finally:
+        L.d3_tuning_set(b"D3_C3", 1)
+    assert res[1][3] >= 20, ("lane-table launches", res[1][3])      # level 0: 11 convolutions forward + their data gradients (the deeper levels' flags may land after the forward)
+    assert res[0][3] == 0
+    assert abs(res[1][0] - res[0][0]) <= 1e-5 * abs(res[0][0]), (res[1][0], res[0][0])
+    g1, g0 = res[1][1].double(), res[0][1].double()
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-3
+    assert float((res[1][2] - res[0][2]).abs().max() / res[0][2].abs().max()) < 1e-3
 
 
 def test_int16_kernel_map_refuses_far_neighbours(dev):

@@ -55,6 +55,9 @@ def main():
         okq = torch.zeros(1, dtype=torch.int32, device=dev)
         assert L.d3_kmap_k3_packq(_ptr(nbr), M, _ptr(tq), _ptr(okq), _stream()) == 0
         assert int(okq[0]) == 1 and int(ok16[0]) == 1
+        nt = (M + 15) // 16
+        recs = tq[nt * 1024:].view(torch.int32).view(nt, 8)
+        print("level %d: %d rows, present fraction %.3f, live gather groups per tile %.2f of 7" % (lev, M, float((nbr >= 0).float().mean()), float(recs[:, 7].float().mean())), flush=True)
         for cin, cout in shapes[lev]:
             torch.manual_seed(lev)
             xb = torch.randn(M, cin, device=dev).to(torch.bfloat16)
@@ -69,7 +72,7 @@ def main():
             np3 = L.d3_spconv_fwd3_nparts(M, cin, cout)
             assert np3 > 0
             part2 = torch.empty(np2, 2, (cout + 15) // 16 * 16, device=dev)
-            part3 = torch.empty(np3, 2, cout, device=dev)
+            part3 = torch.zeros(np3, 2, cout, device=dev)
             o2, o3 = torch.empty(M, cout, device=dev), torch.empty(M, cout, device=dev)
 
             def f2(r=None, t16=False):
@@ -101,38 +104,24 @@ def main():
             rels = []
             t["f2"] = timeit(f2, iters)
             f3()
-            rels.append(max(rel(o3, o2), rel(part3.sum(0), part2.sum(0)[:, :cout])))
+            rels.append(max(rel(o3, o2), rel(part3[:L.d3_spconv_last_nparts()].sum(0), part2.sum(0)[:, :cout])))
             t["f3"] = timeit(f3, iters)
-            if (cin, cout) == (16, 16) and hasattr(L, "d3x_c3_planar_probe"):
-                xpl = xb.view(M, 2, 8).permute(1, 0, 2).contiguous()      # [c8][row][8]: one 16-byte piece per row and plane
-                o3p = torch.empty_like(o3)
-
-                def f3p():
-                    L.d3x_c3_planar_probe(1)
-                    rc = L.d3_spconv_fwd3(_ptr(xpl), cin, _ptr(tq), _ptr(wp), _ptr(o3p), cout, None, cout, _ptr(part3), None, M, M, cin, cout, 0, _stream())
-                    L.d3x_c3_planar_probe(0)
-                    assert rc == 0, rc
-                f3p()
-                o3m = torch.empty_like(o3)
-
-                def f3m():
-                    L.d3x_c3_planar_probe(2)
-                    rc = L.d3_spconv_fwd3(_ptr(xb), cin, _ptr(tq), _ptr(wp), _ptr(o3m), cout, None, cout, _ptr(part3), None, M, M, cin, cout, 0, _stream())
-                    L.d3x_c3_planar_probe(0)
-                    assert rc == 0, rc
-                f3m()
-                print("masked probe 16->16: %.1f us, maxrel %.1e; present fraction %.3f" % (timeit(f3m, iters), rel(o3m, o2), float((nbr >= 0).float().mean())), flush=True)
-                print("planar probe 16->16: %.1f us (interleaved %.1f), maxrel %.1e" % (timeit(f3p, iters), t["f3"], rel(o3p, o2)), flush=True)
             t["f2r"] = timeit(lambda: f2(res), iters)
             f3(res)
-            rels.append(max(rel(o3, o2), rel(part3.sum(0), part2.sum(0)[:, :cout])))
+            rels.append(max(rel(o3, o2), rel(part3[:L.d3_spconv_last_nparts()].sum(0), part2.sum(0)[:, :cout])))
             t["f3r"] = timeit(lambda: f3(res), iters)
             t["b2"] = timeit(b2, iters)
             b3()
-            rels.append(max(rel(o3, o2), rel(part3.sum(0), part2.sum(0)[:, :cout])))
+            rels.append(max(rel(o3, o2), rel(part3[:L.d3_spconv_last_nparts()].sum(0), part2.sum(0)[:, :cout])))
             t["b3"] = timeit(b3, iters)
-            print("%-16s %8d | %9.1f %9s %9.1f | %9.1f %9.1f | %9.1f %9.1f | %.1e %.1e %.1e" %
-                  ("L%d %d->%d" % (lev, cin, cout), M, t["f2"], "-", t["f3"], t["f2r"], t["f3r"], t["b2"], t["b3"], *rels), flush=True)
+            print("%-16s %8d | %9.1f %9s %9.1f | %9.1f %9.1f | %9.1f %9.1f | %.1e %.1e %.1e  (grid %d)" %
+                  ("L%d %d->%d" % (lev, cin, cout), M, t["f2"], "-", t["f3"], t["f2r"], t["f3r"], t["b2"], t["b3"], *rels, L.d3_spconv_last_nparts()), flush=True)
+            if (cin, cout) == (32, 32) and hasattr(L, "d3x_c3_variant"):
+                L.d3x_c3_variant(1)
+                f2()
+                f3()
+                print("   variant 1 (chunked, 2 workgroups per CU): %.1f us, maxrel %.1e (grid %d)" % (timeit(f3, iters), rel(o3, o2), L.d3_spconv_last_nparts()), flush=True)
+                L.d3x_c3_variant(0)
         if lev < 2:
             cm.down(ts)      # creates the next coordinate level
         ts *= 2
