@@ -350,7 +350,7 @@ static int c3_ncu() {
 }
 // one row per instantiated shape: ST = Cin / 8, NT = Cout / 16, waves per workgroup, gather groups per chunk
 struct Conv3Shape { int st, nt, nw, qc; };
-#define C3_SHAPES(X) X(2, 1, 4, 7) X(2, 2, 8, 7) X(4, 1, 8, 7) X(4, 2, 8, 7) X(4, 2, 8, 2) X(4, 4, 16, 2) X(6, 3, 16, 1) X(8, 2, 16, 1)
+#define C3_SHAPES(X) X(2, 1, 4, 7) X(2, 1, 8, 7) X(2, 2, 8, 7) X(4, 1, 8, 2) X(4, 1, 8, 7) X(4, 2, 8, 2) X(4, 2, 8, 7) X(4, 4, 16, 2) X(6, 3, 16, 1) X(8, 2, 16, 1)
 #define C3_ROW(STV, NTV, NWV, QCV) {STV, NTV, NWV, QCV},
 static const Conv3Shape c3_shapes[] = {C3_SHAPES(C3_ROW)};
 static int g_c3_variant = 0;                     // (measurements) which of several rows of one (ST, NT) runs: 0 = the first

@@ -71,7 +71,7 @@ def main():
             np2 = L.d3_spconv_fwd2_nparts(M, 27, cin, cout)
             np3 = L.d3_spconv_fwd3_nparts(M, cin, cout)
             assert np3 > 0
-            part2 = torch.empty(np2, 2, (cout + 15) // 16 * 16, device=dev)
+            part2 = torch.zeros(np2, 2, (cout + 15) // 16 * 16, device=dev)
             part3 = torch.zeros(np3, 2, cout, device=dev)
             o2, o3 = torch.empty(M, cout, device=dev), torch.empty(M, cout, device=dev)
 
@@ -103,24 +103,27 @@ def main():
             t = {}
             rels = []
             t["f2"] = timeit(f2, iters)
+            part2.zero_(); f2()
             f3()
             rels.append(max(rel(o3, o2), rel(part3[:L.d3_spconv_last_nparts()].sum(0), part2.sum(0)[:, :cout])))
             t["f3"] = timeit(f3, iters)
             t["f2r"] = timeit(lambda: f2(res), iters)
+            part2.zero_(); f2(res)
             f3(res)
             rels.append(max(rel(o3, o2), rel(part3[:L.d3_spconv_last_nparts()].sum(0), part2.sum(0)[:, :cout])))
             t["f3r"] = timeit(lambda: f3(res), iters)
             t["b2"] = timeit(b2, iters)
+            part2.zero_(); b2()
             b3()
             rels.append(max(rel(o3, o2), rel(part3[:L.d3_spconv_last_nparts()].sum(0), part2.sum(0)[:, :cout])))
             t["b3"] = timeit(b3, iters)
             print("%-16s %8d | %9.1f %9s %9.1f | %9.1f %9.1f | %9.1f %9.1f | %.1e %.1e %.1e  (grid %d)" %
                   ("L%d %d->%d" % (lev, cin, cout), M, t["f2"], "-", t["f3"], t["f2r"], t["f3r"], t["b2"], t["b3"], *rels, L.d3_spconv_last_nparts()), flush=True)
-            if (cin, cout) == (32, 32) and hasattr(L, "d3x_c3_variant"):
+            if (cin, cout) in ((32, 32), (16, 16), (32, 16)) and hasattr(L, "d3x_c3_variant"):
                 L.d3x_c3_variant(1)
                 f2()
                 f3()
-                print("   variant 1 (chunked, 2 workgroups per CU): %.1f us, maxrel %.1e (grid %d)" % (timeit(f3, iters), rel(o3, o2), L.d3_spconv_last_nparts()), flush=True)
+                print("   variant 1: %.1f us, maxrel %.1e (grid %d)" % (timeit(f3, iters), rel(o3, o2), L.d3_spconv_last_nparts()), flush=True)
                 L.d3x_c3_variant(0)
         if lev < 2:
             cm.down(ts)      # creates the next coordinate level
