@@ -148,6 +148,7 @@ struct Conv2Args {
     // and the partials are (sum g, sum g * xhat) -- the two reductions of the BatchNorm backward, fused here
     const float *bnx; const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
     int ldbx, bn_relu; float bn_eps;
+    int bnx_bf16;               // D3_CONV_BNXBF16: bnx is stored as bf16 (a single-consumer convolution output, round 6)
     // last-workgroup finalize of the partials (no separate reduction launch): fin_mode 1 = forward batch statistics
     // (mean, biased var, running update), 2 = BatchNorm-backward sums (+ dgamma / dbeta)
     int *fin_counter; int fin_mode, fin_M, fin_accum;
@@ -454,7 +455,11 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
             if ((N0) + j < NT && urow < a.Mout && col < a.Cout) {                                             \
                 if (a.res) e_res[j] = *(const f32x4 *)(a.res + (long long)urow * a.ldr + col);                \
                 if (a.accum) e_out[j] = *(const f32x4 *)(a.out + (long long)urow * a.ldo + col);              \
-                if (a.bnx) e_bnx[j] = *(const f32x4 *)(a.bnx + (long long)urow * a.ldbx + col);               \
+                if (a.bnx) {                                                                                  \
+                    if (a.bnx_bf16) { const uint2 b2 = *(const uint2 *)((const unsigned short *)a.bnx + (long long)urow * a.ldbx + col); \
+                        e_bnx[j] = (f32x4){__uint_as_float(b2.x << 16), __uint_as_float(b2.x & 0xFFFF0000u), __uint_as_float(b2.y << 16), __uint_as_float(b2.y & 0xFFFF0000u)}; } \
+                    else e_bnx[j] = *(const f32x4 *)(a.bnx + (long long)urow * a.ldbx + col);                 \
+                }                                                                                             \
             }                                                                                                 \
         }
         if (HOIST && (KS == 1 || kpart == 0)) { C2_EPI_LOAD(0) }
@@ -719,7 +724,8 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             if (a.res) e_res[i] = a.res[(long long)u * a.ldr + col];                                          \
             if (a.accum) e_out[i] = a.out[(long long)u * a.ldo + col];                                        \
             if (a.bnx) {                                                                                      \
-                e_bnx[i] = a.bnx[(long long)u * a.ldbx + col]; e_mean[i] = a.bn_mean[col]; e_var[i] = a.bn_var[col]; \
+                e_bnx[i] = a.bnx_bf16 ? __uint_as_float((unsigned int)((const unsigned short *)a.bnx)[(long long)u * a.ldbx + col] << 16) : a.bnx[(long long)u * a.ldbx + col]; \
+                e_mean[i] = a.bn_mean[col]; e_var[i] = a.bn_var[col]; \
                 if (a.bn_relu) { e_gam[i] = a.bn_gamma[col]; e_bet[i] = a.bn_beta[col]; }                     \
             }                                                                                                 \
         }                                                                                                     \
@@ -1101,7 +1107,7 @@ extern "C" int d3_spconv_fwd3_nparts(int Mout, int Cin, int Cout);
 static thread_local double *g_next_part2 = nullptr;
 void d3_spconv_next_part2(double *part2) { g_next_part2 = part2; }
 
-struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; };
+struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; int xbf16; };
 struct Conv2Fin { int *counter; int mode, M, accum; float *a, *b, *c, *d; float momentum; };
 
 static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res, int ldr,
@@ -1123,9 +1129,10 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     hipStream_t s = d3_stream(stream);
     // round 6: the big levels' K = 27 layers on the lane table (spconv3.hip) -- bf16 rows, no accumulate-into, no in-launch finalize
     if (tblq && tbl && K == 27 && xbf16 && !f32 && !(flags & D3_CONV_ACCUM) && !fin && d3_tune(D3T_C3) != 0 &&
+        (d3_tune(D3T_C3) == 1 || (d3_tune(D3T_C3) == 2 && !bn) || (d3_tune(D3T_C3) == 3 && bn) || (d3_tune(D3T_C3) == 4 && !bn && !res) || (d3_tune(D3T_C3) == 5 && res)) &&      // (2 .. 5: debugging -- forward only / data gradients only / plain forward / residual forward)
         Mout >= d3_tune(D3T_C2_GRIDCAP) * 16 && d3_spconv_fwd3_nparts(Mout, Cin, Cout) > 0 && !(bn && res)) {
         Conv3Bn b3;
-        if (bn) b3 = Conv3Bn{bn->x, bn->mean, bn->var, bn->gamma, bn->beta, bn->ldx, bn->relu, 0, bn->eps};
+        if (bn) b3 = Conv3Bn{bn->x, bn->mean, bn->var, bn->gamma, bn->beta, bn->ldx, bn->relu, bn->xbf16, bn->eps};
         int np = 0;
         const int rc3 = d3_conv3_run(x, ldx, tblq, Wp, out, ldo, res, ldr, part, part ? part2 : nullptr, Min, Mout, Cin, Cout,
                                      (flags & D3_CONV_OUTBF16) ? 1 : 0, bn ? &b3 : nullptr, &np, s);
@@ -1147,11 +1154,11 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         const unsigned long long xb = Min > 0 ? ((unsigned long long)(Min - 1) * ldx + Cin) * elt : 0ull;
         a.xbytes = (Min > 0 && Min < (1 << 24) && rowb < (1ull << 24) && xb <= 0x7FFFFFFFull) ? (unsigned int)xb : 0u;   // (24-bit row x row-bytes multiply; absent rows address 2 GiB)
     }
-    a.bnx = nullptr; a.bn_mean = a.bn_var = a.bn_gamma = a.bn_beta = nullptr; a.ldbx = 0; a.bn_relu = 0; a.bn_eps = 0.f;
+    a.bnx = nullptr; a.bn_mean = a.bn_var = a.bn_gamma = a.bn_beta = nullptr; a.ldbx = 0; a.bn_relu = 0; a.bn_eps = 0.f; a.bnx_bf16 = 0;
     if (bn) {
         if (bn->ldx & 3) return D3_ERR_ARG;
         a.bnx = bn->x; a.bn_mean = bn->mean; a.bn_var = bn->var; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
-        a.ldbx = bn->ldx; a.bn_relu = bn->relu; a.bn_eps = bn->eps;
+        a.ldbx = bn->ldx; a.bn_relu = bn->relu; a.bn_eps = bn->eps; a.bnx_bf16 = bn->xbf16;
     }
     a.fin_counter = nullptr; a.fin_mode = 0; a.fin_M = 0; a.fin_accum = 0; a.fin_a = a.fin_b = a.fin_c = a.fin_d = nullptr; a.fin_momentum = 0.f;
     if (fin && part) {
@@ -1212,7 +1219,7 @@ extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, cons
                                     const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                                     const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
                                     int flags, void *stream) {
-    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps};
+    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps, (flags & D3_CONV_BNXBF16) ? 1 : 0};
     return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, nullptr, stream);
 }
 
@@ -1232,7 +1239,7 @@ extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, 
                                         const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma,
                                         float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
                                         void *stream) {
-    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps};
+    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps, (flags & D3_CONV_BNXBF16) ? 1 : 0};
     Conv2Fin fin{counter, 2, Mout, accum, sums, dgamma, dbeta, nullptr, 0.f};
     return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, &fin, stream);
 }

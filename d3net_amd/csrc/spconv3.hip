@@ -467,13 +467,13 @@ extern "C" int d3_spconv_fwd3(const void *x, int ldx, const void *tq, const void
     return rc;
 }
 // data gradient of a BatchNorm -> ReLU -> convolution unit (as d3_spconv_fwd2_bnbwd); bnx: the BatchNorm input, fp32, or bf16 with
-// D3_CONV_XBF16 in flags
+// D3_CONV_BNXBF16 in flags
 extern "C" int d3_spconv_fwd3_bnbwd(const void *x, int ldx, const void *tq, const void *Wp, void *out, int ldo, float *part, double *part2,
                                     const void *bnx, int ldbx, const float *mean, const float *var, const float *gamma, const float *beta,
                                     float eps, int relu, int Min, int Mout, int Cin, int Cout, int flags, void *stream) {
     D3_CLEAR();
     if (Mout <= 0) return 0;
-    Conv3Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, (flags & D3_CONV_XBF16) ? 1 : 0, eps};
+    Conv3Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, (flags & D3_CONV_BNXBF16) ? 1 : 0, eps};
     int np = 0;
     const int rc = d3_conv3_run(x, ldx, tq, Wp, out, ldo, nullptr, 0, part, part2, Min, Mout, Cin, Cout, (flags & D3_CONV_OUTBF16) ? 1 : 0, &bn, &np, d3_stream(stream));
     d3_spconv_set_last_nparts(np);

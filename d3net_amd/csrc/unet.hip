@@ -41,6 +41,14 @@ __device__ __forceinline__ unsigned int un_pack2bf(float lo, float hi) {
 __device__ __forceinline__ float un_ld1(const float *p, long long idx, int bf) {
     return bf ? __uint_as_float((unsigned int)((const unsigned short *)p)[idx] << 16) : p[idx];
 }
+// four consecutive elements of a BatchNorm input row: fp32, or bf16 (round 6: single-consumer convolution outputs) widened here
+__device__ __forceinline__ float4 un_ldx4(const float *x, long long idx, int xbf) {
+    if (xbf) {
+        const uint2 v = *(const uint2 *)((const unsigned short *)x + idx);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+    }
+    return *(const float4 *)(x + idx);
+}
 
 struct PackJob { const float *W; size_t dst_off; int K, S, CinW, Cout, NT, flipk, transw, Cin, f32; long long start; };
 
@@ -163,7 +171,7 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void un_bn_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ mean,
                                    const float *__restrict__ var, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, void *__restrict__ y, int ldy, long long M, int C,
-                                   float eps, int relu) {
+                                   float eps, int relu, int xbf) {
     // (row-walking form: see un_bn_bwd_apply_kernel)
     const int c4 = C >> 2, rpb = 256 / c4, t = threadIdx.x;
     if (t >= rpb * c4) return;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void un_bn_apply_kernel(const float *__restric
         for (int u = 0; u < 4; u++) {
             const long long row = rb + (long long)u * rpb;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < r1) v[u] = *(const float4 *)(x + row * ldx + c);
+            if (row < r1) v[u] = un_ldx4(x, row * ldx + c, xbf);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(UN_T) void un_bn_bwd_reduce_kernel(const float *__r
                                                                const float *__restrict__ dy, int ldy,
                                                                const float *__restrict__ mean, const float *__restrict__ var,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                               int M, int C, float eps, int relu, float *part, int dybf) {
+                                                               int M, int C, float eps, int relu, float *part, int dybf, int xbf) {
     __shared__ float s1[UN_T], s2[UN_T];
     const int t = threadIdx.x;
     const int active = (UN_T / C) * C, rpp = active / C;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(UN_T) void un_bn_bwd_reduce_kernel(const float *__r
         const int c = t % C;
         const float mu = mean[c], inv = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
         for (long long r = (long long)blockIdx.x * rpp + t / C; r < M; r += (long long)gridDim.x * rpp) {
-            const float xh = (x[r * ldx + c] - mu) * inv;
+            const float xh = (un_ld1(x, r * ldx + c, xbf) - mu) * inv;
             float g = un_ld1(dy, r * ldy + c, dybf);
             if (relu && fmaf(xh, ga, be) <= 0.f) g = 0.f;
             a += g; b = fmaf(g, xh, b);
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
                                        const float *__restrict__ mean, const float *__restrict__ var,
                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                        const float *__restrict__ sums, float *__restrict__ dx, int ldo, long long M,
-                                       int C, float eps, int relu, int accum, unsigned short *__restrict__ shadow) {
+                                       int C, float eps, int relu, int accum, unsigned short *__restrict__ shadow, int xbf) {
     const int c4 = C >> 2, rpb = 256 / c4, t = threadIdx.x;
     if (t >= rpb * c4) return;
     const int rl = t / c4, c = (t - rl * c4) * 4;
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
             const long long row = rb + (long long)u * rpb;
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
             if (row < r1) {
-                xv[u] = *(const float4 *)(x + row * ldx + c);
+                xv[u] = un_ldx4(x, row * ldx + c, xbf);
                 gv[u] = un_ldraw4<GBF>(dy, row * ldy + c);
                 if (!OBF && accum) ov[u] = *(const float4 *)(dx + row * ldo + c);
             }
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                       void *__restrict__ y, int ldy, int M, int C, float eps, int relu,
                                                                       float *mean_out, float *var_out, float *running_mean, float *running_var,
-                                                                      float momentum, int rows_per_block) {
+                                                                      float momentum, int rows_per_block, int xbf) {
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float4 prm[UN_FS_MAXC];     // (mean, 1/std, gamma, beta)
     const int t = threadIdx.x;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
     for (int u = 0; u < 4; u++) {
         const int row = r0 + rl + u * rpb;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (worker && row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
+        if (worker && row < r1) v[u] = un_ldx4(x, (long long)row * ldx + c, xbf);
     }
     double sa, sb;
     if (s0.p2) un_fs_reduce2(s0, s1, C, acc, sa, sb);
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
             for (int u = 0; u < 4; u++) {
                 const int row = rb + u * rpb;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
+                if (row < r1) v[u] = un_ldx4(x, (long long)row * ldx + c, xbf);
             }
         }
 #pragma unroll
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
                                                                           const float *__restrict__ beta, float *sums, float *dgamma, float *dbeta,
                                                                           int paccum, float *__restrict__ dx, int ldo, int M, int C, float eps,
                                                                           int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block,
-                                                                          const double *__restrict__ part2) {
+                                                                          const double *__restrict__ part2, int xbf) {
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float2 sm[UN_FS_MAXC];
     const int t = threadIdx.x;
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
             const int row = rb + u * rpb;
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
             if (worker && row < r1) {
-                xv[u] = *(const float4 *)(x + (long long)row * ldx + c);
+                xv[u] = un_ldx4(x, (long long)row * ldx + c, xbf);
                 gv[u] = un_ldraw4<GBF>(dy, (long long)row * ldy + c);
                 if (!OBF && accum) ov[u] = *(const float4 *)(dx + (long long)row * ldo + c);
             }
@@ -1256,10 +1264,10 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                 rc = d3_spconv_fwd2_fin(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
                                         res, ldr, part, (int *)(arena + o.cnt_off), mean, var,
                                         b.rmean >= 0 ? (float *)params[b.rmean] : nullptr, b.rvar >= 0 ? (float *)params[b.rvar] : nullptr,
-                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | (to.dtype == 1 ? D3_CONV_OUTBF16 : 0), stream);
             } else {
                 rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
-                                    res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+                                    res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | (to.dtype == 1 ? D3_CONV_OUTBF16 : 0), stream);
             }
             if (rc) return rc;
             if (part) o.nparts = d3_spconv_last_nparts();      // (rows actually written: the kernel depends on the tables at hand)
@@ -1287,10 +1295,10 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
                     if (to.dtype == 1)
                         un_bn_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
-                                                                             tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb);
+                                                                             tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
                     else
                         un_bn_fused_small_kernel<false><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
-                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb);
+                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
                     continue;
                 }
                 if (M > 0 && !(o.fin_by >= 0 && M <= n->lb_rows))
@@ -1305,10 +1313,10 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
             if (total > 0) {
                 if (to.dtype == 1)
                     un_bn_apply_kernel<true><<<un_ap_grid(M, C, 8), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
-                                                                                     tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu);
+                                                                                     tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, ti.dtype == 1 ? 1 : 0);
                 else
                     un_bn_apply_kernel<false><<<un_ap_grid(M, C, 8), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
-                                                                                      tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu);
+                                                                                      tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, ti.dtype == 1 ? 1 : 0);
             }
         }
     }
@@ -1475,12 +1483,12 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                     if (Min > n->lb_rows)
                         rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
+                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf | (tx.dtype == 1 ? D3_CONV_BNXBF16 : 0), stream);
                     else
                     rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
                                                   (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
                                                   (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
-                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
+                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf | (tx.dtype == 1 ? D3_CONV_BNXBF16 : 0), stream);
                     if (!rc) n->ops[o.bn_of_in].bparts = d3_spconv_last_nparts();
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
@@ -1559,7 +1567,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 un_bn_bwd_fused_small_kernel<OBFV, GBFV><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, \
                                                                               var, gamma, beta, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, \
                                                                               ldgi, M, C, o.eps, RELU_, ACC_, SH_, rows_pb, \
-                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr)
+                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr, ti.dtype == 1 ? 1 : 0)
                 if (gibf) { if (gobf) UN_FSB(true, true, 0, 0, nullptr); else UN_FSB(true, false, 0, 0, nullptr); }
                 else if (gobf) UN_FSB(false, true, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
                 else UN_FSB(false, false, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
@@ -1573,7 +1581,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 relu = 0;
             } else {
                 const int nb = bn_blocks2(M, C);
-                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr, gobf);
+                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr, gobf, ti.dtype == 1 ? 1 : 0);
                 un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>(bnscr, nb, C, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
             }
             if (o.in_grad_mode) {
@@ -1583,7 +1591,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
 #define UN_APB(OBFV, GBFV, ACC_, SH_)                                                                                                     \
                 un_bn_bwd_apply_kernel<OBFV, GBFV><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C, \
-                                                                                              o.eps, relu, ACC_, SH_)
+                                                                                              o.eps, relu, ACC_, SH_, ti.dtype == 1 ? 1 : 0)
                 if (gibf) { if (gobf) UN_APB(true, true, 0, nullptr); else UN_APB(true, false, 0, nullptr); }
                 else if (gobf) UN_APB(false, true, o.in_grad_mode == 2 ? 1 : 0, sh);
                 else UN_APB(false, false, o.in_grad_mode == 2 ? 1 : 0, sh);

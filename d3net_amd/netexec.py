@@ -22,6 +22,8 @@ from .pointgroup_ops import _on, _stream
 OP_CONV, OP_BNACT, OP_PADCAST, OP_STATS = 1, 2, 3, 4
 MAP_K1, MAP_K3, MAP_DOWN, MAP_UP = 0, 1, 2, 3
 F32, BF16 = 0, 1
+import os as _os
+SINGLE_READER_BF16 = _os.environ.get("D3X_T_F32", "") == ""     # (A/B, tools/jobs: D3X_T_F32=1 keeps every convolution output in fp32, rounds 1-5)
 
 
 def _fbits(x):
@@ -76,7 +78,7 @@ class _Builder:
         self.bns.append(bn)
         return y
 
-    def conv(self, x, conv, level_out, out=None, res=-1, stats=True, cin_w=None):
+    def conv(self, x, conv, level_out, out=None, res=-1, stats=True, cin_w=None, out_dtype=F32):
         if isinstance(conv, ME.MinkowskiConvolutionTranspose):
             kind, mlevel = MAP_UP, level_out
         elif conv.kernel_size == 3:
@@ -86,7 +88,7 @@ class _Builder:
         else:
             kind, mlevel = MAP_K1, level_out
         if out is None:
-            out = self.new(level_out, conv.out_channels, F32)
+            out = self.new(level_out, conv.out_channels, out_dtype)
         assert self.C(out) == conv.out_channels
         self.op(OP_CONV, x, out, res, self.param(conv.kernel, True), kind, mlevel, conv.kernel_volume,
                 conv.in_channels if cin_w is None else cin_w, int(stats))
@@ -98,7 +100,10 @@ class _Builder:
         if isinstance(blk, common.ResidualBlock):
             skip = x if blk.downsample is None else self.conv(x, blk.downsample[0], level, stats=False)
             cb = blk.conv_branch
-            t = self.conv(self.bnact(x, cb[0]), cb[2], level)
+            # (round 6) the first convolution's output has ONE reader -- the BatchNorm behind it (forward apply, backward apply and the
+            # data gradient's ReLU mask) -- and is stored in the activation type: bf16 in the training program (statistics are still
+            # taken from the unrounded accumulators), fp32 in the reference-precision program
+            t = self.conv(self.bnact(x, cb[0]), cb[2], level, out_dtype=self.act_dtype if SINGLE_READER_BF16 else F32)
             return self.conv(self.bnact(t, cb[3]), cb[5], level, out=out, res=skip)
         cl = blk.conv_layers   # VGGBlock
         return self.conv(self.bnact(x, cl[0]), cl[2], level, out=out)

@@ -263,6 +263,7 @@ int d3_kmap_down_fill2(int M, int Mout, const int *parent, const int *kidx, int 
 #define D3_CONV_DYBF16 64  /* dy is stored as bf16 (d3_spconv_wgrad2 only) */
 #define D3_CONV_OUTBF16 512 /* d3_spconv_fwd2*: `out` is stored as bf16 (ushort, ldo in elements); not with D3_CONV_ACCUM, a residual or
                             * D3_CONV_F32.  BatchNorm partials are taken from the unrounded values. */
+#define D3_CONV_BNXBF16 1024 /* d3_spconv_fwd2_bnbwd* / d3_spconv_fwd3_bnbwd: bnx (the BatchNorm input re-read by the epilogue) is stored as bf16 */
 #define D3_CONV_F32 256    /* d3_spconv_pack / d3_spconv_fwd2* / d3_spconv_wgrad2: the REFERENCE'S PRECISION on the matrix cores -- fp32
                             * operands (x, dy fp32; weights packed as fp32 fragments: d3_spconv_pack_bytes_ex), exact fp32 products on
                             * v_mfma_f32_16x16x4_f32, fp32 accumulation.  Not with D3_CONV_XBF16 / D3_CONV_DYBF16. */
@@ -325,7 +326,7 @@ int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void 
  * (D3_CONV_OUTBF16), optional fp32 residual, optional BatchNorm partials part [d3_spconv_fwd3_nparts()][2][Cout] (+ part2
  * [16][2][Cout] fp64, zeroed by the caller).  Shapes with an instance: Cin/Cout in {16/16, 16/32, 32/16, 32/32, 32/64, 48/48,
  * 64/32}; others return D3_ERR_ARG (d3_spconv_fwd3_nparts() == 0).  _bnbwd: as d3_spconv_fwd2_bnbwd; bnx is fp32, or bf16 with
- * D3_CONV_XBF16 in flags.  d3_spconv_fwd3_launches(): launches so far (tests: the path really ran). */
+ * D3_CONV_BNXBF16 in flags.  d3_spconv_fwd3_launches(): launches so far (tests: the path really ran). */
 int d3_spconv_fwd3_nparts(int Mout, int Cin, int Cout);
 int d3_spconv_fwd3(const void *x, int ldx, const void *tq, const void *Wp, void *out, int ldo, const float *res, int ldr,
                    float *part, double *part2, int Min, int Mout, int Cin, int Cout, int flags, void *stream);

@@ -17,7 +17,7 @@ from oracle import sparse_oracle as so
 
 pytestmark = pytest.mark.gpu
 
-FLIPK, TRANSW, XBF16, OUTBF16 = 1, 2, 32, 512
+FLIPK, TRANSW, XBF16, OUTBF16, BNXBF16 = 1, 2, 32, 512, 1024
 
 
 def relerr(a, b):
@@ -219,7 +219,7 @@ def test_fwd3_data_gradient_with_bn_backward_epilogue(dev, canon, level, cin, co
         bnxd = (bnx.bfloat16() if bxbf else bnx).to(dev)
         meand, vard, gammad, betad = (t.to(dev) for t in (mean, var, gamma, beta))
         rc = L.d3_spconv_fwd3_bnbwd(_ptr(dyd), cout, _ptr(g["tq"]), _ptr(wp), _ptr(out), cin, _ptr(part), None, _ptr(bnxd), cin, _ptr(meand), _ptr(vard),
-                                    _ptr(gammad), _ptr(betad), eps, 1, M, M, cout, cin, XBF16 if bxbf else 0, _stream())
+                                    _ptr(gammad), _ptr(betad), eps, 1, M, M, cout, cin, BNXBF16 if bxbf else 0, _stream())
         assert rc == 0, rc
         n = L.d3_spconv_last_nparts()
         o2 = out.cpu().double()

@@ -115,7 +115,7 @@ def test_executor_ops_teacher_forced_at_canonical_rows(dev, stem):
             return lambda xx, W: so.mm(xx, W)
 
         # ---------------- forward, op by op on the executor's activations
-        n_conv = n_bn = 0
+        n_conv = n_bn = n_conv_bf16 = 0
         worst_conv = 0.0
         for op in b.ops:
             if op[0] == OP_PADCAST:
@@ -128,9 +128,18 @@ def test_executor_ops_teacher_forced_at_canonical_rows(dev, stem):
                     ref = conv_fn(op)(tensor(xi), params[w])
                     if res >= 0:
                         ref = ref + tensor(res)
-                e = relerr(tensor(oi), ref)
-                worst_conv = max(worst_conv, e)
-                assert e < 1e-4, ("CONV", op[:10], e)
+                if b.tensors[oi][4] == 1:
+                    # bf16 output (round 6: a convolution output with one reader, the BatchNorm behind it): the fp32 result rounded
+                    # to nearest even -- one ulp, and almost always the same rounding as the oracle's
+                    y, refq = tensor(oi), ref.bfloat16().float()
+                    diff = (y - refq).abs()
+                    assert float((diff > 0).double().mean()) < 1e-2, ("CONV rounding", float((diff > 0).double().mean()))
+                    assert bool((diff <= refq.abs() * 2.0 ** -7 + 1e-6).all()), "bf16 CONV output differs by more than one bf16 ulp"
+                    n_conv_bf16 += 1
+                else:
+                    e = relerr(tensor(oi), ref)
+                    worst_conv = max(worst_conv, e)
+                    assert e < 1e-4, ("CONV", op[:10], e)
                 n_conv += 1
             elif op[0] == OP_BNACT:
                 xi, oi = op[1], op[2]
@@ -145,14 +154,18 @@ def test_executor_ops_teacher_forced_at_canonical_rows(dev, stem):
                 if b.tensors[oi][4] == 1:      # bf16 output: one ulp, and almost always the same rounding
                     refq = ref.float().bfloat16().float()
                     diff = (y - refq).abs()
-                    assert float((diff > 0).double().mean()) < 1e-3, ("BNACT rounding", float((diff > 0).double().mean()))
+                    # (a bf16 INPUT: the executor's statistics come from the producer's unrounded accumulators, the oracle's from
+                    # the stored values -- ~1e-5 relative apart instead of 1e-7)
+                    lim = 2e-2 if b.tensors[xi][4] == 1 else 1e-3
+                    assert float((diff > 0).double().mean()) < lim, ("BNACT rounding", float((diff > 0).double().mean()))
                     # (one bf16 ulp; next to the ReLU threshold the executor's 1e-7 different statistics may leave a value of
                     # rounding size where the oracle has 0)
-                    assert bool((diff <= refq.abs() * 2.0 ** -7 + 1e-5).all()), "BNACT differs by more than one bf16 ulp"
+                    slack = 2e-4 if b.tensors[xi][4] == 1 else 1e-5
+                    assert bool((diff <= refq.abs() * 2.0 ** -7 + slack).all()), "BNACT differs by more than one bf16 ulp"
                 else:
                     assert relerr(y, ref) < 1e-5
                 n_bn += 1
-        assert n_conv >= (25 if stem else 24) and n_bn >= 23
+        assert n_conv >= (25 if stem else 24) and n_bn >= 23 and n_conv_bf16 >= 10
 
         # ---------------- backward: the oracle back-propagates the same gradient through the executor's activations
         nb = len(b.bufs)
@@ -255,13 +268,15 @@ def test_int16_kernel_maps_are_bit_identical_to_the_dense_tables(dev):
 def test_lane_table_kernel_equals_the_dense_table_kernels_to_fp32_rounding(dev):
     """Round 6: the K = 27 forward / data-gradient convolutions of the big levels run spconv_fwd3_kernel on the lane table
     (csrc/spconv3.hip): same bf16 operands and fp32 accumulation as spconv_fwd2_kernel, another summation order (per tile the live
-    offsets first).  A whole detector step with D3_C3 on and off: loss to 1e-5 relative, flat backbone gradient to 2e-3 relative L2,
-    point logits to 1e-3 -- and the lane-table path must really have run (level 0: >= 20 launches)."""
-    from d3net_amd import _lib, synthetic as S
+    offsets first).  A whole detector step with D3_C3 on and off agrees like two bf16 runs (bounds below) -- and the lane-table path
+    must really have run (level 0: >= 20 launches)."""
+    from d3net_amd import _lib, netexec, synthetic as S
     L = _lib.lib()
     occ, sem, inst, _ = S.occupancy_grid()
     scene = S.scene_from_grid(occ, sem, inst)
     res = {}
+    keep = netexec.SINGLE_READER_BF16
+    netexec.SINGLE_READER_BF16 = False      # (fp32 between the two convolutions of a block: a bf16 store would turn a 1e-7 difference into an ulp flip)
     try:
         for on in (1, 0):
             assert L.d3_tuning_set(b"D3_C3", on) == 0
@@ -269,12 +284,20 @@ def test_lane_table_kernel_equals_the_dense_table_kernels_to_fp32_rounding(dev):
             res[on] = _detector_step(dev, scene) + (L.d3_spconv_fwd3_launches() - n0,)
     finally:
         L.d3_tuning_set(b"D3_C3", 1)
+        netexec.SINGLE_READER_BF16 = keep
     assert res[1][3] >= 20, ("lane-table launches", res[1][3])      # level 0: 11 convolutions forward + their data gradients (the deeper levels' flags may land after the forward)
     assert res[0][3] == 0
-    assert abs(res[1][0] - res[0][0]) <= 1e-5 * abs(res[0][0]), (res[1][0], res[0][0])
+    # (every BatchNorm output is stored as bf16: a 1e-7 difference in front of a store is now and then a flipped ulp behind it, and 30
+    # normalised layers carry it on -- the two programs agree like two bf16 runs do, tests/test_fullsize_step_gpu.py's bounds against
+    # the fp32 oracle: loss 2e-2, logits 3e-2; the kernel-level parity is tests/test_conv3_gpu.py's 1e-4 against the oracle)
+    assert abs(res[1][0] - res[0][0]) <= 5e-3 * abs(res[0][0]), (res[1][0], res[0][0])
+    assert float((res[1][2] - res[0][2]).abs().max() / res[0][2].abs().max()) < 3e-2
+    # gradients: ~70 BatchNorm / ReLU layers double a perturbation every other layer (measured op by op: 4e-8 behind the first
+    # convolution, 2e-6 behind its bf16 store, 1e-3 at level 1, 1.5e-2 at level 6), so two bf16 programs agree in direction and size,
+    # not entry by entry -- the bound of tests/test_fullsize_step_gpu.py for bf16 against fp32 operands: cosine of the flat gradient
     g1, g0 = res[1][1].double(), res[0][1].double()
-    assert float((g1 - g0).norm() / g0.norm()) < 2e-3
-    assert float((res[1][2] - res[0][2]).abs().max() / res[0][2].abs().max()) < 1e-3
+    cosine = float((g1 * g0).sum() / (g1.norm() * g0.norm()))
+    assert cosine > 0.7 and 0.8 < float(g1.norm() / g0.norm()) < 1.25, (cosine, float(g1.norm() / g0.norm()))
 
 
 def test_int16_kernel_map_refuses_far_neighbours(dev):
