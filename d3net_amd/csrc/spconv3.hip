@@ -350,11 +350,9 @@ static int c3_ncu() {
 }
 // one row per instantiated shape: ST = Cin / 8, NT = Cout / 16, waves per workgroup, gather groups per chunk
 struct Conv3Shape { int st, nt, nw, qc; };
-#define C3_SHAPES(X) X(2, 1, 4, 7) X(2, 1, 8, 7) X(2, 2, 8, 7) X(4, 1, 8, 2) X(4, 1, 8, 7) X(4, 2, 8, 2) X(4, 2, 8, 7) X(4, 4, 16, 2) X(6, 3, 16, 1) X(8, 2, 16, 1)
+#define C3_SHAPES(X) X(2, 1, 4, 7) X(2, 2, 8, 7) X(4, 1, 8, 2) X(4, 2, 8, 2) X(4, 4, 16, 2) X(6, 3, 16, 1) X(8, 2, 16, 1)
 #define C3_ROW(STV, NTV, NWV, QCV) {STV, NTV, NWV, QCV},
 static const Conv3Shape c3_shapes[] = {C3_SHAPES(C3_ROW)};
-static int g_c3_variant = 0;                     // (measurements) which of several rows of one (ST, NT) runs: 0 = the first
-extern "C" void d3x_c3_variant(int v) { g_c3_variant = v; }
 
 struct Conv3Plan { int ok, nw, qc, maxgrid; size_t lds; };
 static size_t c3_lds_bytes(int ST, int NT, int nw) { return (size_t)28 * ST * NT * 256 + (size_t)nw * 2 * NT * 16 * 4 + (size_t)NT * 16 * 16; }
@@ -363,10 +361,9 @@ static Conv3Plan conv3_plan(int Mout, int Cin, int Cout) {
     Conv3Plan p{0, 4, 7, 1, 0};
     if (Mout <= 0 || (Cin & 7) || (Cout & 15)) return p;
     const int ST = Cin / 8, NT = Cout / 16;
-    int seen = 0;
     const Conv3Shape *pick = nullptr;
     for (const Conv3Shape &c : c3_shapes)
-        if (c.st == ST && c.nt == NT) { if (!pick || seen == g_c3_variant) pick = &c; seen++; }
+        if (c.st == ST && c.nt == NT && !pick) pick = &c;
     if (!pick) return p;
     p.nw = pick->nw; p.qc = pick->qc; p.lds = c3_lds_bytes(ST, NT, p.nw);
     if (p.lds > 160 * 1024) return p;
@@ -394,7 +391,7 @@ static int c3_launch_inst(const Conv3Args &a, const Conv3Plan &p, int *grid_out,
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd3_kernel<ST, NT, EPI, OBF, BXBF, NW, QC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int nblk = 0;
         D3_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void *)spconv_fwd3_kernel<ST, NT, EPI, OBF, BXBF, NW, QC>, NW * 64, p.lds));
-        occ_dev[dev] = nblk < 1 ? 1 : (nblk > 16 / NW ? 16 / NW : nblk);
+        occ_dev[dev] = nblk < 1 ? 1 : (nblk > 16 / NW ? 16 / NW : nblk);      // (measured: 16 -> 16 at five waves per SIMD runs no faster than at four -- 23.7 vs 23.5 us)
     }
     // persistent workgroups: every resident slot of the chip once, fewer when there are fewer tile groups
     const int ntg = (a.ntiles + NW - 1) / NW;

@@ -41,13 +41,18 @@ __device__ __forceinline__ unsigned int un_pack2bf(float lo, float hi) {
 __device__ __forceinline__ float un_ld1(const float *p, long long idx, int bf) {
     return bf ? __uint_as_float((unsigned int)((const unsigned short *)p)[idx] << 16) : p[idx];
 }
-// four consecutive elements of a BatchNorm input row: fp32, or bf16 (round 6: single-consumer convolution outputs) widened here
+// four consecutive elements of a BatchNorm input row: fp32, or bf16 (round 6: single-consumer convolution outputs).  The load is RAW
+// (bf16: 8 bytes in .x / .y) and un_cvx4 widens it where the values are used -- a conversion right behind the load would make every
+// load of a batch wait for its own data instead of all of them being in flight together
 __device__ __forceinline__ float4 un_ldx4(const float *x, long long idx, int xbf) {
-    if (xbf) {
-        const uint2 v = *(const uint2 *)((const unsigned short *)x + idx);
-        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
-    }
+    if (xbf) { const uint2 v = *(const uint2 *)((const unsigned short *)x + idx); return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f); }
     return *(const float4 *)(x + idx);
+}
+__device__ __forceinline__ void un_cvx4(const float4 r, int xbf, float *o) {
+    if (xbf) {
+        const unsigned int a = __float_as_uint(r.x), b = __float_as_uint(r.y);
+        o[0] = __uint_as_float(a << 16); o[1] = __uint_as_float(a & 0xFFFF0000u); o[2] = __uint_as_float(b << 16); o[3] = __uint_as_float(b & 0xFFFF0000u);
+    } else { o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
 }
 
 struct PackJob { const float *W; size_t dst_off; int K, S, CinW, Cout, NT, flipk, transw, Cin, f32; long long start; };
@@ -193,7 +198,8 @@ __global__ __launch_bounds__(256) void un_bn_apply_kernel(const float *__restric
         for (int u = 0; u < 4; u++) {
             const long long row = rb + (long long)u * rpb;
             if (row >= r1) continue;
-            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float in[4];
+            un_cvx4(v[u], xbf, in);
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -318,7 +324,8 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
         for (int u = 0; u < UN_AP_U; u++) {
             const long long row = rb + (long long)u * rpb;
             if (row >= r1) continue;
-            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float xi[4];
+            un_cvx4(xv[u], xbf, xi);
             float gi[4];
             un_cvt4<GBF>(gv[u], gi);
             const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
@@ -470,7 +477,8 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
         for (int u = 0; u < 4; u++) {
             const int row = rb + u * rpb;
             if (row >= r1) continue;
-            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float in[4];
+            un_cvx4(v[u], xbf, in);
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -544,7 +552,8 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
         for (int u = 0; u < UN_AP_U; u++) {
             const int row = rb + u * rpb;
             if (row >= r1) continue;
-            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float xi[4];
+            un_cvx4(xv[u], xbf, xi);
             float gi[4];
             un_cvt4<GBF>(gv[u], gi);
             const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};

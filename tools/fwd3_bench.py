@@ -119,12 +119,6 @@ def main():
             t["b3"] = timeit(b3, iters)
             print("%-16s %8d | %9.1f %9s %9.1f | %9.1f %9.1f | %9.1f %9.1f | %.1e %.1e %.1e  (grid %d)" %
                   ("L%d %d->%d" % (lev, cin, cout), M, t["f2"], "-", t["f3"], t["f2r"], t["f3r"], t["b2"], t["b3"], *rels, L.d3_spconv_last_nparts()), flush=True)
-            if (cin, cout) in ((32, 32), (16, 16), (32, 16)) and hasattr(L, "d3x_c3_variant"):
-                L.d3x_c3_variant(1)
-                f2()
-                f3()
-                print("   variant 1: %.1f us, maxrel %.1e (grid %d)" % (timeit(f3, iters), rel(o3, o2), L.d3_spconv_last_nparts()), flush=True)
-                L.d3x_c3_variant(0)
         if lev < 2:
             cm.down(ts)      # creates the next coordinate level
         ts *= 2
