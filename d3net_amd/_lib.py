@@ -92,9 +92,6 @@ SIGNATURES = {
     "d3_spconv_fwd2_plan": (i32, [i32, i32, i32, i32, pi]),
     "d3_spconv_fwd2": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_fwd2_bnbwd": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "d3_spconv_fwd2_fin": (i32, [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, vp]),
-    "d3_spconv_fwd2_bnbwd_fin": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, i32,
-                                       i32, i32, i32, i32, i32, i32, vp]),
     "d3_spconv_wgrad2_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "d3_spconv_wgrad2_splits": (i32, [i32, i32, i32, i32, i32, i32]),
     "d3_spconv_wgrad2": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),

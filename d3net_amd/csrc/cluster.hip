@@ -347,14 +347,11 @@ __global__ void cl_owner_kernel(const int *root, const int *lab, int *own, int *
         todo &= ~grp;
     }
 }
-// scalars[5] <- 1 when some list is longer than cl_bfs3_kernel's key can number (B3_MAXLIST entries; the reference's ball query
-// stops at 1000): read back with the counts, the fill then keeps the edge-parallel replay
 __global__ void cl_keep_kernel(const int *sizes, int *flag, int *ksz, int n, int threshold, const int *__restrict__ start_len, int *scalars) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int k = sizes[i] >= threshold && sizes[i] > 0;
     flag[i] = k; ksz[i] = k ? sizes[i] : 0;
-    if (start_len[i * 2 + 1] > 2047) scalars[5] = 1;
 }
 __global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz, const int *koff, int n,
                                  int *scalars) {
@@ -366,11 +363,6 @@ __global__ void cl_totals_kernel(const int *flag, const int *cid, const int *ksz
 
 static int cl_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len, int n, int threshold, void *ws,
                     size_t ws_bytes, int *sumNPoint_host, int *nCluster_host, int flags, void *stream);
-// The count phase reads back, with the counts, whether every list fits cl_bfs3_kernel's key (<= 2047 entries).  The fill uses
-// that replay only for a workspace this thread's last count vouched for; anything else (a fill on another thread, a count that
-// saw a longer list) keeps cl_bfs2_kernel, which has no such limit.
-static thread_local const void *g_cl_checked_ws = nullptr;
-static thread_local bool g_cl_short_lists = false;
 
 extern "C" int d3_bfs_cluster_count(const int *semantic_label, const int *ball_query_idxs, const int *start_len,
                                     int n, int threshold, void *ws, size_t ws_bytes, int *sumNPoint_host,
@@ -441,8 +433,6 @@ static int cl_count(const int *semantic_label, const int *ball_query_idxs, const
     }
     *nCluster_host = h[1];
     *sumNPoint_host = h[2];
-    // what the fill may assume about THIS workspace's lists (same thread: count and fill are one operator call)
-    g_cl_checked_ws = ws; g_cl_short_lists = h[5] == 0;
     return 0;
 }
 
@@ -823,7 +813,7 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     const int c = blockIdx.x + c0, tid = threadIdx.x;
     const int s = seeds[c], base = koff[s], size = sizes[s];
     if (size > B2_MAXSIZE) return;                                  // left to cl_bfs_kernel
-    if (size <= min_size) return;                                   // written by cl_bfs3_kernel
+    if (size <= min_size) return;                                   // (caller-side cut: clusters another kernel writes)
     if (star[s]) return;                                            // written by cl_star_kernel
     int *qst = qst_all + base, *qln = qln_all + base;
     const int words = (size + 31) >> 5;
@@ -1008,240 +998,6 @@ __global__ __launch_bounds__(B2_THREADS) void cl_bfs2_kernel(const int4 *__restr
     B2_TDUMP
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// phase 3, third form (round 5): a 16-lane GROUP per frontier ENTRY, discovery keys in an LDS array over the dense ids.
-// Both level loops of this file are bound by VALU issue on ONE compute unit: cl_bfs2_kernel spends ~14,000 cycles per level of the
-// canonical floor (~300 nodes / ~2,700 edges per level, 192 levels; cycle counters, gpurun_out r04_j20) = ~800 instructions per
-// wave per level on the flat-edge -> owner search, the CAS / probe / atomicMin hash that elects the first discoverer, hint tables,
-// their clean-up and a (count, list length) block scan.  What a level needs per edge is much less:
-//   * a frontier ENTRY is (record start, <= 16 records): a node with a longer list is queued as consecutive entries of 16.
-//     Group g of pass p owns entry a = p * 32 + g, lane l its record l: one contiguous 256-byte read per group, no owner search,
-//     no list-offset prefix;
-//   * the election is ONE LDS atomic per edge: disc[dense id] = min(disc, key), key = batch number : entry : lane (19 + 9 + 4
-//     bits).  A word claimed by an earlier batch is smaller than every key of this one (= visited), 0xFFFFFFFF = never seen;
-//     after the barrier the edge whose key is still there is the FIFO discoverer (entries and lanes are in (parent position,
-//     list position) order) -- no bitmap, no hash, no clean-up;
-//   * inside a wave-pass that order IS the lane order, so a winner's rank is mbcnt(ballot) and the wave's total a scalar
-//     popcount; the (pass, wave) totals go through a 128-entry LDS table that every wave scans for itself and reads back with
-//     v_readlane.  Winners with more than 16 records (rare) add their extra entries through six more ballots (bit planes of the
-//     chunk count).  Three LDS-only barriers per batch; records / outputs through raw buffer instructions (32-bit offsets).
-// Earlier attempts of this round, both bit-exact and both SLOWER than cl_bfs2_kernel (944 us): one THREAD per frontier node
-// (1,460 us: 64 lanes x 16-byte loads from 64 different lines per instruction, lists beyond eight records walked with dependent
-// loads) and this layout with per-group masks / cross-lane reads and 64-bit addressing (1,500 us: ~100 instructions per
-// wave-pass, ~80 wave-passes per level).  A wave-pass here is ~35 instructions.
-// disc needs 4 B per node: clusters up to B3_MAXNODES; larger ones, inputs with a list beyond 2,047 entries (the reference's ball
-// query stops at 1,000: lib/pointgroup_ops/src/bfs_cluster/bfs_cluster.cu:45) and record arrays beyond 4 GiB keep
-// cl_bfs2_kernel.  Same outputs as the other forms, bit for bit.
-#ifndef B3_T
-#define B3_T 512
-#endif
-#define B3_G 16                                // lanes per frontier entry = records per entry
-#define B3_NG (B3_T / B3_G)                    // entries per pass
-#define B3_FMAX 512                            // frontier entries per batch (= kept in LDS)
-#define B3_P (B3_FMAX / B3_NG)                 // passes per batch
-#define B3_NW (B3_T / 64)
-#define B3_MAXNODES 37632                      // 147 KB of discovery words
-#define B3_QMAX 0x7FFFFu
-#define B3_LDS_INTS (B3_MAXNODES + 2 * 2 * B3_FMAX + 2 * B3_P * B3_NW + 64 + 64)
-#define B3_RSRC_FLAGS 0x00020000               // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
-static_assert(B3_P * B3_NW == 128, "the (pass, wave) tables are scanned as two entries per lane");
-typedef unsigned int b3_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int b3_u32x2 __attribute__((ext_vector_type(2)));
-
-__global__ __launch_bounds__(B3_T) void cl_bfs3_kernel(const int4 *__restrict__ erec, unsigned int erec_bytes,
-                                                      const int *__restrict__ start_len, const int *__restrict__ estart,
-                                                      const int *__restrict__ lid, const int *__restrict__ seeds,
-                                                      const int *__restrict__ koff, const int *__restrict__ sizes,
-                                                      const int *__restrict__ star, int *qst_all, int *qln_all, int *cluster_idxs,
-                                                      int *dbg) {
-    extern __shared__ __attribute__((aligned(16))) int b3_smem[];
-    unsigned int *disc = (unsigned int *)b3_smem;                      // B3_MAXNODES
-    int2 *ftab = (int2 *)(b3_smem + B3_MAXNODES);                      // 2 x B3_FMAX: (first record, records <= 16) per frontier entry
-    int *wtabN = (int *)(ftab + 2 * B3_FMAX);                          // B3_P x B3_NW: winners (nodes) per (pass, wave)
-    int *wtabE = wtabN + B3_P * B3_NW;                                 // ... and their frontier entries
-    int *misc = wtabE + B3_P * B3_NW;                                  // [0..1]: cut of a read-back batch (nodes, entries); [8..]: block scan
-    // landing zone of the list prefetches: a winner's first record line is pulled towards this XCD's L2 by a load that writes to
-    // LDS (no register to keep alive across the level's barriers; the values are never read, every wave shares the 256 bytes)
-    __attribute__((address_space(3))) void *pfz = (__attribute__((address_space(3))) void *)(misc + 64);
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int g = tid / B3_G, l = tid % B3_G;
-    const int s = seeds[c], base = koff[s], size = sizes[s];
-    if (size > B3_MAXNODES) return;                                    // left to cl_bfs2_kernel
-    if (star[s]) return;                                               // written by cl_star_kernel
-    const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc((void *)erec, 0, erec_bytes, B3_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(cluster_idxs + (size_t)base * 2), 0, (unsigned int)size * 8u, B3_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rqs = __builtin_amdgcn_make_buffer_rsrc((void *)(qst_all + base), 0, (unsigned int)size * 4u, B3_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rql = __builtin_amdgcn_make_buffer_rsrc((void *)(qln_all + base), 0, (unsigned int)size * 4u, B3_RSRC_FLAGS);
-    int *qst = qst_all + base, *qln = qln_all + base;
-    for (int w = tid; w < size; w += B3_T) disc[w] = 0xFFFFFFFFu;
-    __syncthreads();
-    int ne = 0;                                                        // entries of the current frontier held in LDS
-    {
-        const int sl = start_len[s * 2 + 1], es = estart[s];
-        ne = (sl + B3_G - 1) / B3_G;
-        if (tid == 0) { disc[lid[s]] = 0u; cluster_idxs[(size_t)base * 2] = c; cluster_idxs[(size_t)base * 2 + 1] = s; qst[0] = es; qln[0] = sl; }
-        if (tid < ne && tid < B3_FMAX) ftab[tid] = make_int2(es + tid * B3_G, min(B3_G, sl - tid * B3_G));
-    }
-    __syncthreads();
-    int lo = 0, hi = 1, cur = 0, n_levels = 0, n_batches = 0;
-    unsigned int q = 1u;                                               // batch number (the key's high field)
-#ifdef B3_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_readcyclecounter();
-#define B3_TICK(k) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[k] += t_ - tprev; tprev = t_; }
-#define B3_TDUMP if (dbg && tid == 0 && c < 20) for (int k = 0; k < 8; k++) dbg[60 + c * 8 + k] = (int)(tacc[k] >> 4);
-#else
-#define B3_TICK(k)
-#define B3_TDUMP
-#endif
-    while (lo < hi && hi < size) {
-        const bool in_lds = ne <= B3_FMAX;                             // the frontier's entry table was written by the previous level
-        int tail = hi, etail = 0;                                      // nodes queued / entries of the next frontier so far
-        int2 *ntab = ftab + (cur ^ 1) * B3_FMAX;
-        int2 *ctab = ftab + cur * B3_FMAX;
-        for (int fb = lo; fb < hi;) {
-            int nb;                                                    // entries of this batch
-            if (in_lds) { nb = ne; fb = hi; }
-            else {
-                // frontier beyond the LDS window: node records (first record, list length) come back from the global queue and are
-                // cut into entries again -- as many whole nodes as fit B3_FMAX entries
-                __syncthreads();                                       // (queue records written by other waves: full barrier)
-                const int NB = min(B3_FMAX, hi - fb);
-                int st = 0, ln = 0;
-                if (tid < NB) { st = ld_dev(&qst[fb + tid]); ln = ld_dev(&qln[fb + tid]); }
-                const int nch = (ln + B3_G - 1) / B3_G;
-                if (tid == 0) { misc[0] = 0; misc[1] = 0; }
-                int tot_;
-                const int eoff = cl_blk_scan(nch, misc + 8, tot_);     // (block scan: __syncthreads inside)
-                const bool fits = tid < NB && eoff + nch <= B3_FMAX;
-                if (fits) { atomicMax(&misc[0], tid + 1); atomicMax(&misc[1], eoff + nch); }
-                if (fits) for (int j = 0; j < nch; j++) ctab[eoff + j] = make_int2(st + j * B3_G, min(B3_G, ln - j * B3_G));
-                __syncthreads();
-                nb = misc[1]; fb += misc[0];
-                __syncthreads();                                       // (misc is rewritten by the next read-back batch)
-            }
-            const int npass = (nb + B3_NG - 1) / B3_NG;
-            b3_u32x4 rec[B3_P];
-            int rk[B3_P];                                              // winner: node rank | entry rank << 8 inside the wave-pass; else -1
-            const unsigned int kthread = (q << 13) | ((unsigned int)g << 4) | (unsigned int)l;
-            // ---- claim: every record bids for its target with (batch, entry, lane)
-#pragma unroll
-            for (int p = 0; p < B3_P; p++) {
-                rec[p] = (b3_u32x4){0xFFFFFFFFu, 0u, 0u, 0u};
-                if (p < npass) {
-                    const int a = p * B3_NG + g;
-                    if (a < nb) {
-                        const int2 me = ctab[a];
-                        if (l < me.y) rec[p] = __builtin_amdgcn_raw_buffer_load_b128(rrec, (unsigned int)(me.x + l) * 16u, 0, 0);
-                    }
-                }
-            }
-            B3_TICK(0)
-            __builtin_amdgcn_sched_barrier(0);                         // (all record loads issued before the first use)
-#ifdef B3_TIMING
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            B3_TICK(1)
-#endif
-#pragma unroll
-            for (int p = 0; p < B3_P; p++)
-                if (p < npass && (int)rec[p].x >= 0) atomicMin(&disc[rec[p].y], kthread + (unsigned int)(p * B3_NG << 4));
-            B3_TICK(2)
-            b2_barrier();
-            B3_TICK(3)
-            // ---- check: the bid that is still there discovered the node first; lane order = FIFO order inside a wave-pass
-            int tvN = 0, tvE = 0;                                      // lane p: this wave's totals of pass p
-#pragma unroll
-            for (int p = 0; p < B3_P; p++) {
-                rk[p] = -1;
-                if (p < npass) {
-                    const bool w0 = (int)rec[p].x >= 0 && disc[rec[p].y] == kthread + (unsigned int)(p * B3_NG << 4);
-                    const unsigned long long bal = __ballot(w0);
-                    const int nrank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0u));
-                    int erank = nrank, ecount = (int)__popcll(bal);
-                    const int ncount = ecount;
-                    const unsigned long long balL = __ballot(w0 && rec[p].w > (unsigned int)B3_G);
-                    if (balL != 0ull) {                                // some winner brings more than one entry: bit planes of (entries - 1)
-                        const unsigned int x = w0 ? (rec[p].w + B3_G - 1) / B3_G - 1u : 0u;
-#pragma unroll
-                        for (int bit = 0; bit < 7; bit++) {
-                            const unsigned long long bb = __ballot((x >> bit) & 1u);
-                            erank += (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bb, 0u)) << bit;
-                            ecount += (int)__popcll(bb) << bit;
-                        }
-                    }
-                    if (w0) rk[p] = nrank | (erank << 8);
-                    if (lane == p) { tvN = ncount; tvE = ecount; }
-                }
-            }
-            if (lane < npass) { wtabN[lane * B3_NW + wv] = tvN; wtabE[lane * B3_NW + wv] = tvE; }
-            B3_TICK(4)
-            b2_barrier();
-            // ---- ranks: every wave scans the (pass, wave) totals for itself (128 entries, two per lane), nodes and entries
-            int totN, totE, exN0, exN1, exE0, exE1;
-            {
-                const int npw = npass * B3_NW;
-                const int2 vn = (2 * lane < npw) ? *(const int2 *)&wtabN[2 * lane] : make_int2(0, 0);      // (npw is even)
-                const int2 ve = (2 * lane < npw) ? *(const int2 *)&wtabE[2 * lane] : make_int2(0, 0);
-                int xn = vn.x + vn.y, xe = ve.x + ve.y;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int yn = __shfl_up(xn, o), ye = __shfl_up(xe, o);
-                    if (lane >= o) { xn += yn; xe += ye; }
-                }
-                totN = __builtin_amdgcn_readlane(xn, 63); totE = __builtin_amdgcn_readlane(xe, 63);
-                exN0 = xn - vn.x - vn.y; exN1 = exN0 + vn.x;
-                exE0 = xe - ve.x - ve.y; exE1 = exE0 + ve.x;
-            }
-            B3_TICK(5)
-            // ---- enqueue in (parent position, list position) order
-#pragma unroll
-            for (int p = 0; p < B3_P; p++) {
-                if (p < npass) {
-                    // base of (pass p, this wave): table entry p * NW + wv sits in lane (p * NW + wv) / 2 -- a wave-uniform lane
-                    const int ti = p * B3_NW + wv;
-                    const int bN = (ti & 1) ? __builtin_amdgcn_readlane(exN1, ti >> 1) : __builtin_amdgcn_readlane(exN0, ti >> 1);
-                    const int bE = (ti & 1) ? __builtin_amdgcn_readlane(exE1, ti >> 1) : __builtin_amdgcn_readlane(exE0, ti >> 1);
-                    if (rk[p] >= 0) {
-                        const int pos = tail + bN + (rk[p] & 0xFF);    // queue position of the node
-                        const int e0 = etail + bE + (rk[p] >> 8);      // its first entry in the next frontier
-                        __builtin_amdgcn_raw_buffer_store_b64((b3_u32x2){(unsigned int)c, rec[p].x}, rout, (unsigned int)pos * 8u, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(rec[p].z, rqs, (unsigned int)pos * 4u, 0, 0);      // (plain stores: the only reader is this
-                        __builtin_amdgcn_raw_buffer_store_b32(rec[p].w, rql, (unsigned int)pos * 4u, 0, 0);      //  workgroup, through ld_dev)
-                        if (rec[p].w <= (unsigned int)B3_G) { if (e0 < B3_FMAX) ntab[e0] = make_int2((int)rec[p].z, (int)rec[p].w); }
-                        else {
-                            const int nch = ((int)rec[p].w + B3_G - 1) / B3_G;
-                            for (int j = 0; j < nch && e0 + j < B3_FMAX; j++) ntab[e0 + j] = make_int2((int)rec[p].z + j * B3_G, min(B3_G, (int)rec[p].w - j * B3_G));
-                        }
-#ifndef B3_NO_PREFETCH
-                        // the winner's own records start travelling now (8 per line)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, pfz, 4, rec[p].z * 16u, 0, 0, 0);
-                        if (rec[p].w > 8u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, pfz, 4, rec[p].z * 16u + 128u, 0, 0, 0);
-#endif
-                    }
-                }
-            }
-            tail += totN; etail += totE;
-            q++; n_batches++;
-            B3_TICK(6)
-            b2_barrier();
-            B3_TICK(7)
-            if (tail >= size) {   // every node of the component is queued: the remaining edges cannot discover anything
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no LDS-landing load may outlive the workgroup's LDS allocation)
-                if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels + 1; dbg[c * 3 + 2] = n_batches; }
-                B3_TDUMP
-                return;
-            }
-            if (q == B3_QMAX) {   // batch numbers wrap: every visited word becomes "batch 0"
-                for (int w = tid; w < size; w += B3_T) if (disc[w] != 0xFFFFFFFFu) disc[w] = 0u;
-                q = 1u;
-                b2_barrier();
-            }
-        }
-        lo = hi; hi = tail; ne = etail; cur ^= 1; n_levels++;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (dbg && tid == 0 && c < 20) { dbg[c * 3] = size; dbg[c * 3 + 1] = n_levels; dbg[c * 3 + 2] = n_batches; }
-    B3_TDUMP
-}
 
 // (cnt: the speculative fill does not know sumNPoint on the host -- its 8 S bytes are added here, in units of the slot's factor 4)
 __global__ void cl_prof_total_kernel(const int *estart, const int *klen, int n, double *out, const int *cnt) {
@@ -1290,24 +1046,8 @@ static int cl_fill2_impl(const int *semantic_label, const int *ball_query_idxs, 
         // launch timing (bench.py): SURVEY 8(d) "BFS/CC" bytes = 4 nActive + 12 n + 8 S, nActive = the list entries of the kept
         // clusters' nodes (what the replay streams; the padded lists' capacity says nothing) -- known on the device only
         void *pr = d3_prof_begin(5, 12.0 * (double)n + (dev_counts ? 0.0 : 8.0 * (double)sumNPoint), 0.0, s);
-        // round 5: clusters whose discovery words fit the LDS (<= B3_MAXNODES nodes) replay on the thread-per-frontier-node kernel;
-        // larger ones (and everything with D3_BFS3=0) on the edge-parallel hash form
-        const bool use3 = !dev_counts && c0 == 0 && d3_tune(D3T_BFS3) != 0 && g_cl_checked_ws == ws && g_cl_short_lists &&
-                          (unsigned long long)(nActive > 0 ? nActive : 1) * sizeof(int4) < 0xFFFFFFFFull;      // (32-bit record offsets)
-        if (use3) {
-            static bool attr3_done_dev[64] = {false};
-            const size_t lds3 = (size_t)B3_LDS_INTS * sizeof(int);
-            if (dev_id < 0 || dev_id >= 64 || !attr3_done_dev[dev_id]) {
-                D3_CHECK(hipFuncSetAttribute((const void *)cl_bfs3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-                if (dev_id >= 0 && dev_id < 64) attr3_done_dev[dev_id] = true;
-            }
-            cl_bfs3_kernel<<<nCluster, B3_T, lds3, s>>>((const int4 *)erec, (unsigned int)((size_t)(nActive > 0 ? nActive : 1) * sizeof(int4)), start_len,
-                                                       w.estart, w.lid, w.seeds, w.koff, w.sizes, w.star, w.fcnt, w.qln, cluster_idxs,
-                                                       debug ? w.lcnt : nullptr);
-        }
-        if (!use3 || sumNPoint > B3_MAXNODES)
-            cl_bfs2_kernel<<<nCluster - c0, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
-                                                            w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr, use3 ? B3_MAXNODES : 0, cnt, c0);
+        cl_bfs2_kernel<<<nCluster - c0, B2_THREADS, lds, s>>>((const int4 *)erec, start_len, w.estart, w.lid, w.seeds, w.koff, w.sizes,
+                                                        w.star, w.fcnt, w.qln, cluster_idxs, debug ? w.lcnt : nullptr, 0, cnt, c0);
         if (pr) {
             d3_prof_tag(pr, 0, n); d3_prof_tag(pr, 1, nCluster); d3_prof_end(pr, s);
             if (double *slot = d3_prof_dev_slot(pr, 4.0)) cl_prof_total_kernel<<<1, 1, 0, s>>>(w.estart, w.klen, n, slot, cnt);   // (behind the bracket)
@@ -1317,7 +1057,7 @@ static int cl_fill2_impl(const int *semantic_label, const int *ball_query_idxs, 
             hipMemcpyAsync(h, w.lcnt, sizeof(h), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);
             for (int c = 0; c < nCluster && c < 20; c++) {
                 fprintf(stderr, "bfs2 cluster %d size %d levels %d batches %d", c, h[c * 3], h[c * 3 + 1], h[c * 3 + 2]);
-#if defined(B2_TIMING) || defined(B3_TIMING)
+#if defined(B2_TIMING)
                 for (int k = 0; k < 8; k++) fprintf(stderr, " t%d=%d", k, h[60 + c * 8 + k] * 16);
 #endif
                 fprintf(stderr, "\n");
@@ -1371,7 +1111,7 @@ extern "C" int d3_bfs_cluster_begin(const int *semantic_label, const int *ball_q
     *ticket = nullptr;
     ClRun *r = new ClRun{semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, erec, erec_bytes, nActive, flags,
                          cluster_idxs, cap_points, cluster_offsets, cap_clusters, stream, nullptr, 0, 0, 0, 0, 0};
-    if (n <= 0 || d3_tune(D3T_CL_SPEC) == 0 || d3_tune(D3T_BFS3) != 0 || d3_tune(D3T_BFS_DEBUG) != 0 || cap_points < n) {
+    if (n <= 0 || d3_tune(D3T_CL_SPEC) == 0 || d3_tune(D3T_BFS_DEBUG) != 0 || cap_points < n) {
         int S = 0, P = 0;
         int rc = cl_count(semantic_label, ball_query_idxs, start_len, n, threshold, ws, ws_bytes, &S, &P, flags, stream);
         if (!rc && n > 0) {
@@ -1442,13 +1182,11 @@ extern "C" int d3_bfs_cluster_end(void *ticket, int *sumNPoint_host, int *nClust
             if (!h[0] || !h[4] || it >= n + 2) break;
         }
         *nCluster_host = h[1]; *sumNPoint_host = h[2];
-        g_cl_checked_ws = r->ws; g_cl_short_lists = h[5] == 0;
         if ((long long)h[2] > r->cap_points || (long long)h[1] > r->cap_clusters) return D3_ERR_WORKSPACE;
         return d3_bfs_cluster_fill2(r->sem, r->idx, r->start_len, n, r->ws, r->ws_bytes, r->erec, r->erec_bytes, r->nActive, r->cluster_idxs,
                                     r->cluster_offsets, h[2], h[1], r->stream);
     }
     *nCluster_host = h[1]; *sumNPoint_host = h[2];
-    g_cl_checked_ws = r->ws; g_cl_short_lists = h[5] == 0;
     if ((long long)h[1] > r->cap_clusters) return D3_ERR_WORKSPACE;      // (cannot happen for cap_clusters >= n / threshold: kept clusters have >= threshold points)
     if (h[1] > r->slots)        // kept clusters beyond the speculative grid: their replay now, on the tables the first launch built
         rc = cl_fill2_impl(r->sem, r->idx, r->start_len, n, r->ws, r->ws_bytes, r->erec, r->erec_bytes, r->nActive, r->cluster_idxs, r->cluster_offsets,

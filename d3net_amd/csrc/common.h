@@ -46,9 +46,9 @@ __device__ __forceinline__ unsigned long long d3_lanemask_lt() {
 }
 
 // measurement / test switches: ONE table parsed once from the environment (tuning.hip); launch paths read a slot
-enum D3Tune { D3T_ATTN_SCALAR, D3T_BFS_NO_STAR, D3T_BFS_DEBUG, D3T_EC_KSPLIT, D3T_HG_TILED, D3T_C2_GRIDCAP, D3T_WG3, D3T_WG3_R, D3T_WG3_S,
-              D3T_WG2_TR, D3T_LASTBLOCK_FINALIZE, D3T_GRAD_BF16, D3T_SIDE_PRIO, D3T_SIDE_MIN_ROWS, D3T_RED_TAIL, D3T_VOX_ROWS,
-              D3T_C2_WLDS_KB, D3T_C2_NW16_KB, D3T_BQ_GRID, D3T_SIDE_OP_ROWS, D3T_LASTBLOCK_ROWS, D3T_C2_STATIC, D3T_GRU_RT1, D3T_HG_RT1, D3T_GRU4, D3T_C2_INTERLEAVE, D3T_BN_FUSED_ROWS, D3T_KMAP16, D3T_HG_BF16X3, D3T_BN_FUSED_BIG, D3T_HG_CLASS_SPLIT, D3T_HG_SPLITK, D3T_BFS3, D3T_BN_PART2, D3T_CL_HOOK, D3T_ACT_GRAD_BF16, D3T_CL_SPEC, D3T_TD_FUSE_GATES, D3T_UNSAFE_NO_HAZARD_WAIT, D3T_SIDE2, D3T_SORT_ONESWEEP_MIN, D3T_BQ_HALF, D3T_C2_KSPLIT, D3T_C2_COMPACT, D3T_C3, D3T_COUNT };
+enum D3Tune { D3T_ATTN_SCALAR, D3T_BFS_NO_STAR, D3T_BFS_DEBUG, D3T_EC_KSPLIT, D3T_WG3, D3T_WG2_TR, D3T_GRAD_BF16, D3T_SIDE_MIN_ROWS, D3T_RED_TAIL, D3T_VOX_ROWS, D3T_C2_NW16_KB, D3T_BQ_GRID,
+              D3T_C2_STATIC, D3T_GRU_RT1, D3T_HG_RT1, D3T_GRU4, D3T_C2_INTERLEAVE, D3T_BN_FUSED_ROWS, D3T_KMAP16, D3T_BN_FUSED_BIG, D3T_HG_CLASS_SPLIT, D3T_HG_SPLITK, D3T_BN_PART2, D3T_CL_HOOK,
+              D3T_CL_SPEC, D3T_TD_FUSE_GATES, D3T_SIDE2, D3T_SORT_ONESWEEP_MIN, D3T_BQ_HALF, D3T_C3, D3T_COUNT };
 int d3_tune(int key);
 
 // exclusive int32 scan / total via rocPRIM (implemented in scan_sort.hip)

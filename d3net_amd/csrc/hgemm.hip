@@ -266,125 +266,6 @@ __global__ __launch_bounds__(256) void hg_gemm_tiled_kernel(const HgBatch batch)
             }
 }
 
-// bf16 x 3 form of the tiled kernel (round 4).  The fp32 matrix rate is 1/16 of the bf16 rate, and the tall problems (the
-// classifier over all time steps, the listener's projections over 96 x 128 tokens, their gradients) spend their time in
-// v_mfma_f32_16x16x4_f32.  Here every fp32 operand is split once, on its way into LDS, into hi = bf16(x) and lo = bf16(x - hi)
-// and a product is three v_mfma_f32_16x16x32_bf16 -- lo*hi + hi*lo + hi*hi, fp32 accumulate: the dropped lo*lo term and the
-// rounding of lo are ~2^-17 relative per product (fp32 itself: 2^-24), i.e. ~1e-5 relative on a dot product -- two orders below
-// the 1e-3 the heads are held to -- at 12 bf16 MFMAs per 64 x 64 x 32 slab and wave instead of 32 fp32 ones (192 vs 1024
-// matrix-core cycles).  Measured (profiles/r04): 152 -> 140 us per launch in the joint step, 26 -> 23 us in the speaker step --
-// the 64 x 64 tile moves 16 KB per 262 kFLOP slab and is bound by L2 traffic, not by the matrix rate.  NOT adopted: the switch
-// D3_HG_BF16X3 is off by default (the heads stay exact fp32); minkowski.set_exact forces it off.
-typedef __bf16 hg_bf16x8 __attribute__((ext_vector_type(8)));
-#define HT3_RP (HT_BK + 8)     // LDS row pitch in bf16: 80-byte rows, 16-byte aligned k groups
-__device__ __forceinline__ unsigned short hg_bf16_rne(float x) {
-    unsigned int u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ void hg_split4(const f32x4 v, uint2 &hi, uint2 &lo) {
-    unsigned short h[4], l[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        h[q] = hg_bf16_rne(v[q]);
-        l[q] = hg_bf16_rne(v[q] - __uint_as_float((unsigned int)h[q] << 16));
-    }
-    hi = make_uint2((unsigned int)h[0] | ((unsigned int)h[1] << 16), (unsigned int)h[2] | ((unsigned int)h[3] << 16));
-    lo = make_uint2((unsigned int)l[0] | ((unsigned int)l[1] << 16), (unsigned int)l[2] | ((unsigned int)l[3] << 16));
-}
-__global__ __launch_bounds__(256) void hg_gemm_tiled3_kernel(const HgBatch batch) {
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[2][HT_BM][HT3_RP], Al[2][HT_BM][HT3_RP], Bh[2][HT_BN][HT3_RP], Bl[2][HT_BN][HT3_RP];
-    const d3_gemm_prob &p = batch.p[blockIdx.z];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * HT_BM, n0 = blockIdx.x * HT_BN;
-    if (m0 >= p.M || n0 >= p.N) return;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;        // this wave's quarter
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int sr = t >> 2, sk = (t & 3) * 4;
-    f32x4 ra[HT_KQ], rb[HT_KQ];
-    auto fetch = [&](const d3_gemm_seg &sg, int kb) {
-        const int row = m0 + sr, col = n0 + sr;
-        const bool av = row < p.M, bv = col < p.N;
-        const long long ar = av ? (sg.ia ? (long long)sg.ia[row] : (long long)row) : 0;
-        const float *ab = sg.a_kmajor ? sg.A + ar : sg.A + ar * sg.lda;
-        const float *bb = sg.b_kmajor ? sg.B + (bv ? col : 0) : sg.B + (long long)(bv ? col : 0) * sg.ldb;
-        const int avec = (!sg.a_kmajor && (sg.lda & 3) == 0 && (((size_t)sg.A) & 15) == 0) ? 1 : 0;
-        const int bvec = (!sg.b_kmajor && (sg.ldb & 3) == 0 && (((size_t)sg.B) & 15) == 0) ? 1 : 0;
-#pragma unroll
-        for (int u = 0; u < HT_KQ; u++) {
-            const int k0 = kb * HT_BK + u * 16 + sk;
-            ra[u] = hg_load4(ab, sg.lda, sg.a_kmajor, avec, k0, sg.K, av);
-            rb[u] = hg_load4(bb, sg.ldb, sg.b_kmajor, bvec, k0, sg.K, bv);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < HT_KQ; u++) {
-            uint2 h, l;
-            hg_split4(ra[u], h, l);
-            *(uint2 *)&Ah[buf][sr][u * 16 + sk] = h; *(uint2 *)&Al[buf][sr][u * 16 + sk] = l;
-            hg_split4(rb[u], h, l);
-            *(uint2 *)&Bh[buf][sr][u * 16 + sk] = h; *(uint2 *)&Bl[buf][sr][u * 16 + sk] = l;
-        }
-    };
-    int nslab = 0;
-    for (int s = 0; s < p.nseg; s++) nslab += (p.seg[s].K + HT_BK - 1) / HT_BK;
-    auto locate = [&](int slab, int &sidx, int &kb) {
-        sidx = 0; kb = slab;
-        while (sidx < p.nseg - 1 && kb >= (p.seg[sidx].K + HT_BK - 1) / HT_BK) { kb -= (p.seg[sidx].K + HT_BK - 1) / HT_BK; sidx++; }
-    };
-    int sidx, kb;
-    locate(0, sidx, kb);
-    fetch(p.seg[sidx], kb);
-    stash(0);
-    __syncthreads();
-    for (int slab = 0; slab < nslab; slab++) {
-        const int buf = slab & 1;
-        if (slab + 1 < nslab) { locate(slab + 1, sidx, kb); fetch(p.seg[sidx], kb); }      // in flight behind the MFMAs below
-        // lane (i, g): eight consecutive k (g * 8 ..) of row / column i -- the whole 32-deep slab is ONE bf16 MFMA per tile
-        hg_bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            ah[mt] = *(const hg_bf16x8 *)&Ah[buf][wm + mt * 16 + i][g * 8];
-            al[mt] = *(const hg_bf16x8 *)&Al[buf][wm + mt * 16 + i][g * 8];
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            bh[nt] = *(const hg_bf16x8 *)&Bh[buf][wn + nt * 16 + i][g * 8];
-            bl[nt] = *(const hg_bf16x8 *)&Bl[buf][wn + nt * 16 + i][g * 8];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-            }
-        if (slab + 1 < nslab) stash(buf ^ 1);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int row = m0 + wm + mt * 16 + g * 4 + q, c = n0 + wn + nt * 16 + i;
-                if (row >= p.M || c >= p.N) continue;
-                float v = acc[mt][nt][q];
-                if (p.bias) v += p.bias[c];
-                if (p.add) v += p.add[(long long)row * p.ldadd + c];
-                if (p.relu && v < 0.f) v = 0.f;
-                const long long orow = p.perm_nb > 0 ? (long long)(row % p.perm_nb) * p.perm_s + row / p.perm_nb : (long long)row;
-                float *o = p.C + orow * p.ldc + c;
-                *o = p.accum ? *o + v : v;
-            }
-}
 
 static int hg_check(const d3_gemm_prob &p) {
     if (p.nseg < 1 || p.nseg > 3 || p.M < 0 || p.N < 1 || !p.C) return D3_ERR_ARG;
@@ -483,7 +364,7 @@ static int hg_splitk(const d3_gemm_prob &p, hipStream_t s) {
 }
 static bool hg_wants_splitk(const d3_gemm_prob &p) {
     const int cap = d3_tune(D3T_HG_SPLITK);          // the switch's value is the largest number of 16 x 16 output tiles
-    if (cap <= 0 || p.nseg != 1 || p.seg[0].ia || p.M <= 32) return false;
+    if (cap <= 0 || p.nseg != 1 || p.seg[0].ia || p.M <= 32 || p.gru) return false;      // (a gate epilogue runs on complete sums only: ADVICE r5)
     const long long tiles16 = (long long)((p.N + 15) / 16) * ((p.M + 15) / 16);
     return p.seg[0].K >= HG_KS_MINK && tiles16 <= cap;
 }
@@ -580,10 +461,7 @@ static int hg_launch_batch(const d3_gemm_prob *probs, int nprobs, hipStream_t s)
         if (tiles16 < 2048) {    // few tiles: still split K so that the chip is covered
             HG_SPLIT(2, (maxM + 31) / 32);
         } else {
-            const bool tiled = d3_tune(D3T_HG_TILED) != 0;   // (A/B)
-            if (tiled && d3_tune(D3T_HG_BF16X3) != 0) { variant[0] = 2; hg_gemm_tiled3_kernel<<<dim3((ctiles * 16 + HT_BN - 1) / HT_BN, (maxM + HT_BM - 1) / HT_BM, nprobs), 256, 0, s>>>(b); }
-            else if (tiled) hg_gemm_tiled_kernel<<<dim3((ctiles * 16 + HT_BN - 1) / HT_BN, (maxM + HT_BM - 1) / HT_BM, nprobs), 256, 0, s>>>(b);
-            else { variant[0] = 1; variant[1] = 4; variant[2] = 0; hg_gemm_kernel<4, false, 4><<<dim3((ctiles + 3) / 4, (maxM + 63) / 64, nprobs), 256, 0, s>>>(b); }
+            hg_gemm_tiled_kernel<<<dim3((ctiles * 16 + HT_BN - 1) / HT_BN, (maxM + HT_BM - 1) / HT_BM, nprobs), 256, 0, s>>>(b);
         }
     }
 #undef HG_SPLIT

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(MEANW_WAVES(NPROD) * 64) void sec_mean_pc_kernel(co
     if (rpc == 0) return;                                    // (C <= 64 on this path: rpc >= 16)
     const long long base = (long long)start * C, total = (long long)(end - start) * C;
     const int nchunk = (int)((total + cf - 1) / cf);
-    const int nround = (nchunk + MEANW_PROD_ - 1) / MEANW_PROD;
+    const int nround = (nchunk + MEANW_PROD_ - 1) / MEANW_PROD_;
     const unsigned int invC = (65536u + C - 1) / C;          // f / C for f < 1024 (exact: f * invC < 2^26, C <= 64)
     float mean = 0.f;
     if (NPROD > 3 && wave == 0) __builtin_amdgcn_s_setprio(3);

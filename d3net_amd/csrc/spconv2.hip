@@ -149,55 +149,7 @@ struct Conv2Args {
     const float *bnx; const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
     int ldbx, bn_relu; float bn_eps;
     int bnx_bf16;               // D3_CONV_BNXBF16: bnx is stored as bf16 (a single-consumer convolution output, round 6)
-    // last-workgroup finalize of the partials (no separate reduction launch): fin_mode 1 = forward batch statistics
-    // (mean, biased var, running update), 2 = BatchNorm-backward sums (+ dgamma / dbeta)
-    int *fin_counter; int fin_mode, fin_M, fin_accum;
-    float *fin_a, *fin_b, *fin_c, *fin_d; float fin_momentum;
 };
-
-// Called by every workgroup after its partial row is written.  The last one to arrive (device-scope ticket) reduces all
-// rows: one wave per channel, lanes stride over the rows, fp64, fixed order -- the same arithmetic as the stand-alone
-// finalize kernels.  The per-XCD L2s are not coherent inside a kernel and an agent-scope release fence writes back the
-// whole L2 (measured: 2.3x slower convolutions with a __threadfence() per workgroup), so the partial rows and the
-// ticket travel as agent-scope (write-through / L2-bypassing) accesses instead and only completion order is enforced.
-__device__ __forceinline__ void c2_part_store(float *p, float v) {
-    __hip_atomic_store((int *)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float c2_part_load(const float *p) {
-    return __int_as_float(__hip_atomic_load((const int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void c2_last_block_finalize(const Conv2Args &a, int total_blocks, int nparts, int *flagS) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial stores have completed
-    __syncthreads();
-    if (threadIdx.x == 0) *flagS = (atomicAdd(a.fin_counter, 1) == total_blocks - 1) ? 1 : 0;
-    __syncthreads();
-    if (!*flagS) return;
-    const int Wd = a.NT * 16, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = threadIdx.x >> 6; c < a.Cout; c += nw) {
-        double sa = 0., sb = 0.;
-        for (int b = lane; b < nparts; b += 64) {
-            sa += (double)c2_part_load(&a.part[(size_t)b * 2 * Wd + c]);
-            sb += (double)c2_part_load(&a.part[(size_t)b * 2 * Wd + Wd + c]);
-        }
-        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
-        if (lane != 0) continue;
-        if (a.fin_mode == 1) {
-            const double M = (double)a.fin_M, m = sa / M;
-            double v = sb / M - m * m;
-            if (v < 0.) v = 0.;
-            a.fin_a[c] = (float)m; a.fin_b[c] = (float)v;
-            if (a.fin_c) {
-                a.fin_c[c] = (1.f - a.fin_momentum) * a.fin_c[c] + a.fin_momentum * (float)m;
-                a.fin_d[c] = (1.f - a.fin_momentum) * a.fin_d[c] + a.fin_momentum * (float)(v * (M / (a.fin_M > 1 ? M - 1. : 1.)));
-            }
-        } else {
-            a.fin_a[c] = (float)sa; a.fin_a[a.Cout + c] = (float)sb;
-            if (a.fin_c) a.fin_c[c] = (a.fin_accum ? a.fin_c[c] : 0.f) + (float)sa;   // dbeta
-            if (a.fin_b) a.fin_b[c] = (a.fin_accum ? a.fin_b[c] : 0.f) + (float)sb;   // dgamma
-        }
-    }
-    if (threadIdx.x == 0) *a.fin_counter = 0;
-}
 
 __device__ __forceinline__ bf16x8_t c2_zero() {
     uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -287,25 +239,16 @@ __device__ __forceinline__ void c2_wload(const unsigned short *Wb, int e, uint4 
 // KT / ST > 0: kernel size and slots per offset (Cin / 8) known at compile time (round 3: the shapes that carry the step -- K = 27
 // with 16 / 32 / 64 input channels): the reduction loop is fully unrolled and every (offset, channel group) of a step is a
 // constant per lane group -- the ~10 index instructions in front of each gather fold away.
-// KS > 1 (round 5, the stem): KS waves share one tile and split its 27 offsets; the NW / KS tiles of a workgroup's turn -- and with
-// them the XCD's window of rows in flight -- shrink by KS.  The stem's window was (32 workgroups x 16 tiles x 16 rows) = 8192 rows
-// plus a +-1 x-slab halo of 272-byte rows, ~2.7 MB beside the table and the outputs in a 4 MB L2 with the workgroups a turn apart:
-// measured 990 MB of L2-miss traffic per launch against 249 MB algorithmic.  Sibling waves hand their partial accumulator to the
-// tile's first wave through their own (by then dead) kernel-map slot in LDS; flags in LDS, no workgroup barrier.
-__device__ __forceinline__ void c2_lds_wait_eq(int *p, int v) {
-    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
-}
 // CMP (round 5, the statically shaped instances): the offsets NO row of the tile has are dropped before the reduction loop.  The
 // kernel is bound by the dependent round trips of a wave (table -> gathers -> products, one per batch), not by a throughput: with
 // the rows in raster order a 16-row tile of the 2 cm level uses 15.9 of the 27 offsets on average (a planar patch: 9), so the
 // batches of a tile shrink from 14 to ~8 (stem) / from 2 to mostly 1 (16 -> 16).  One 27-lane pass over the tile's table in LDS
 // gives the mask; the live offsets are then taken from it with scalar instructions (no list in memory).
-template <int NT, bool WLDS, bool XBF, int NW, bool F32M, int KT, int ST, bool T16, int KS, bool CMP = false>
+template <int NT, bool WLDS, bool XBF, int NW, bool F32M, int KT, int ST, bool T16, bool CMP = false>
 __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
-    static_assert(!CMP || (KT == 27 && (ST == 2 || ST >= 4) && KS == 1), "offset compaction: the statically shaped instances");
+    static_assert(!CMP || (KT == 27 && (ST == 2 || ST >= 4)), "offset compaction: the statically shaped instances");
     static_assert(!T16 || KT == 27, "the 16-bit kernel map is read by the statically shaped K = 27 instances");
-    static_assert(KS == 1 || (KS == 4 && NT == 1 && KT == 27 && ST >= 4 && NW == 16), "the offset split is built for the stem");
-    constexpr int NWT = NW / KS;        // tiles of a workgroup's turn
+    constexpr int NWT = NW;             // tiles of a workgroup's turn
     static_assert(!(F32M && XBF), "fp32 MFMA needs fp32 gathers");
     static_assert((KT > 0) == (ST > 0), "static shapes fix both the kernel size and the channel groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -315,14 +258,11 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
     constexpr int KB = ST >= 4 ? (Q >= 5 ? 2 : (8 / Q > 0 ? 8 / Q : 1)) : 1;
     constexpr int U = ST >= 4 ? KB * Q : (!XBF && NT <= 2) ? (NW == 16 ? 4 : C2_F32_U) : C2_U(NT);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, g = lane >> 4;
-    const int slot = KS > 1 ? wave / KS : wave, kpart = KS > 1 ? wave % KS : 0;
+    const int slot = wave;
     const int K = KT ? KT : a.K, S = ST ? ST : a.S;
     const size_t wbytes = WLDS ? (size_t)K * S * NT * (F32M ? 512 : 256) : 0;
     int *tblS = (int *)(smem + wbytes) + wave * C2_TBL_INTS;
     float *redS = (float *)(smem + wbytes + NW * C2_TBL_INTS * 4);
-    // (offset split) ready[wave]: the iteration whose partial accumulator sits in that wave's table slot; done[slot]: the iteration
-    // the tile's first wave has consumed -- in the spare words behind the statistics rows (word 0 there is the finalize flag)
-    int *readyS = (int *)(redS + NW * 2 * NT * 16) + 4, *doneS = readyS + NW;
     const unsigned short *Wb = WLDS ? (const unsigned short *)smem : a.Wp;
     const int nb = gridDim.x, b = blockIdx.x;
     const int lb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
@@ -360,7 +300,6 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
         }                                                                                                     \
     }
     if (C2_PREFETCH) C2_LOAD_TBL(tg0 * NWT + slot)
-    if (KS > 1 && t < NW + NWT) readyS[t] = 0;
     float4 *bnS = (float4 *)(smem + wbytes + C2_WAVE_LDS_BASE(NT, NW));   // (mean, 1/std, gamma, beta) per channel
     if (a.bnx && t < NT * 16) {
         float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -393,16 +332,11 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
     if (lane == 0) tblS[C2_TBL_SENT] = -1;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, C2_RSRC_FLAGS);
 
-    int kiter = 0;
     for (int tg = tg0; tg < tg1; tg += tstride) {
         const int tile = tg * NWT + slot;
-        if (tile >= a.ntiles) continue;   // wave-uniform (and the same for the KS waves of a tile); there is no workgroup barrier inside this loop
+        if (tile >= a.ntiles) continue;   // wave-uniform; there is no workgroup barrier inside this loop
         const int row0 = tile * 16;
         if (!C2_PREFETCH) C2_LOAD_TBL(tile)
-        if (KS > 1) {
-            if (kpart != 0 && kiter > 0) c2_lds_wait_eq(&doneS[slot], kiter);     // my previous partial has been read: the slot is mine again
-            kiter++;
-        }
         if constexpr (t16) {
 #pragma unroll
             for (int it = 0; it < 4; it++) {
@@ -462,7 +396,7 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
                 }                                                                                             \
             }                                                                                                 \
         }
-        if (HOIST && (KS == 1 || kpart == 0)) { C2_EPI_LOAD(0) }
+        if (HOIST) { C2_EPI_LOAD(0) }
         // (CMP: ko[] = the live offsets of this batch, taken from the mask; KT = none)
         constexpr int NKO = !CMP ? 1 : (ST >= 4 ? KB : 2 * U);
         auto batch = [&](const int m0, const int (&ko)[NKO]) __attribute__((always_inline)) {
@@ -585,23 +519,6 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
                 for (int j = 0; j < NKO; j++) { ko[j] = m ? (int)__builtin_ctz(m) : KT; m &= m - 1u; }
                 batch(0, ko);
             }
-        } else if constexpr (KS > 1) {
-            // offsets [0, 8), [8, 14), [14, 20), [20, 27) (KB = 2 offsets per batch: 4 / 3 / 3 / 3.5 batches)
-            static_assert(KB == 2, "offset ranges of the split are whole batches");
-            const int kb = kpart == 0 ? 0 : 2 + 6 * kpart, ke = kpart == 0 ? 8 : kpart == 3 ? KT : 8 + 6 * kpart;
-#pragma unroll 1
-            for (int k0 = kb; k0 < ke; k0 += KB) batch(k0, ko0);
-            if (kpart != 0) {      // the partial accumulator into my own table slot (its entries are in registers or consumed)
-                ((f32x4 *)tblS)[lane] = acc[0];
-                __hip_atomic_store(&readyS[wave], kiter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
-            }
-#pragma unroll
-            for (int p = 1; p < KS; p++) {      // fixed order: deterministic
-                c2_lds_wait_eq(&readyS[wave + p], kiter);
-                acc[0] += ((const f32x4 *)(tblS + p * C2_TBL_INTS))[lane];
-            }
-            __hip_atomic_store(&doneS[slot], kiter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if constexpr (ST >= 4 && (KT * Q > 56 || NT >= 3)) {   // (the stem: 135 steps; >= 48 output channels -- unrolled completely they spill)
 #pragma unroll 1
             for (int k0 = 0; k0 < KT; k0 += KB) batch(k0, ko0);
@@ -667,29 +584,20 @@ __device__ __forceinline__ void spconv_fwd2_body(const Conv2Args &a) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; w++) s += redS[w * 2 * NT * 16 + t];
-            if (a.fin_counter) c2_part_store(&a.part[(long long)b * 2 * NT * 16 + t], s);
-            else a.part[(long long)b * 2 * NT * 16 + t] = s;
+            a.part[(long long)b * 2 * NT * 16 + t] = s;
             if (a.part2) unsafeAtomicAdd(&a.part2[(b % C2_P2_ROWS) * 2 * NT * 16 + t], (double)s);
         }
-        if (a.fin_counter)   // (flag word: the spare LDS behind the statistics rows; no static LDS in front of the dynamic region)
-            c2_last_block_finalize(a, (int)gridDim.x, (int)gridDim.x, (int *)(redS + NW * 2 * NT * 16));
     }
 }
 template <int NT, bool WLDS, bool XBF, int NW = 4, bool F32M = false, int KT = 0, int ST = 0, bool T16 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, XBF) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_kernel(const Conv2Args a) {
-    spconv_fwd2_body<NT, WLDS, XBF, NW, F32M, KT, ST, T16, 1>(a);
+    spconv_fwd2_body<NT, WLDS, XBF, NW, F32M, KT, ST, T16>(a);
 }
 // the statically shaped instances (K = 27, bf16 rows, weights in LDS) with the tile's dead offsets dropped (CMP above)
 template <int NT, int NW, int ST, bool T16>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? C2_OCC(NT, true) : 4, NW == 4 ? 8 : 4))) void spconv_fwd2_c_kernel(const Conv2Args a) {
-    spconv_fwd2_body<NT, true, true, NW, false, 27, ST, T16, 1, true>(a);
+    spconv_fwd2_body<NT, true, true, NW, false, 27, ST, T16, true>(a);
 }
-// the offset-split form (K = 27, bf16 rows, weights in LDS, one column tile, 16 waves: the stem)
-template <int ST, bool T16, int KS>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void spconv_fwd2_ks_kernel(const Conv2Args a) {
-    spconv_fwd2_body<1, true, true, 16, false, 27, ST, T16, KS>(a);
-}
-
 // Workgroup-per-tile kernel (few-row levels): grid = (16-row tiles, column groups of NTW 16-wide tiles).  The
 // W = blockDim.x/64 waves split the MFMA steps of the tile, their accumulators are summed through LDS in wave order,
 // and the workgroup owns complete output columns: no atomics, no cross-workgroup reduction, deterministic.
@@ -862,15 +770,15 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             for (int row = 0; row < 16; row++) s += (t < CW) ? finS[row * CW + cl] : fin2S[row * CW + cl];
             if (n0 * 16 + cl < a.NT * 16) {
                 float *pp = &a.part[(long long)blockIdx.x * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl];
-                if (a.fin_counter) c2_part_store(pp, s); else *pp = s;
+                *pp = s;
                 if (a.part2) unsafeAtomicAdd(&a.part2[(long long)(blockIdx.x % C2_P2_ROWS) * 2 * a.NT * 16 + (t < CW ? 0 : a.NT * 16) + n0 * 16 + cl], (double)s);
             }
         }
-        if (a.fin_counter) c2_last_block_finalize(a, (int)(gridDim.x * gridDim.y), (int)gridDim.x, (int *)(kmaskS + 1));
     }
 }
 
 #define C2_NW16_MAXNT 4      // 16-wave variants are instantiated for <= 4 column tiles
+#define C2_GRIDCAP 1024      // persistent workgroups per convolution launch; levels of fewer 16-row tiles run the workgroup-per-tile kernel
 static int c2_ncu() {
     static int n = 0;
     if (!n) { int dev = 0; hipDeviceProp_t pr; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
@@ -886,11 +794,11 @@ static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout, bool f32 = false
     if (ntiles >= 1024) {
         p.split = 0; p.W = 1;
         // 16 waves around ONE LDS copy of a large weight set (one workgroup per CU), 4 waves per workgroup otherwise
-        const size_t big_from = (size_t)d3_tune(D3T_C2_NW16_KB) * 1024, lds_max = (size_t)d3_tune(D3T_C2_WLDS_KB) * 1024;
+        const size_t big_from = (size_t)d3_tune(D3T_C2_NW16_KB) * 1024, lds_max = (size_t)160 * 1024;
         if (NT <= C2_NW16_MAXNT && wbytes >= big_from && wbytes + C2_WAVE_LDS_BYTES(NT, 16) <= lds_max && wbytes + C2_WAVE_LDS_BYTES(NT, 16) <= 160 * 1024)
             p.nw = 16;
         const int ntg = (ntiles + p.nw - 1) / p.nw;
-        int cap = d3_tune(D3T_C2_GRIDCAP);   // (experiments)
+        int cap = C2_GRIDCAP;
         if (p.nw == 16) cap = c2_ncu();      // LDS admits one such workgroup per CU
         const int per = (ntg + cap - 1) / cap;
         p.grid = (ntg + per - 1) / per;
@@ -977,11 +885,10 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
     static bool attr_done_dev[64] = {false};
     if (c2_attr_needed(attr_done_dev))
         D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    // the tile's dead offsets dropped (spconv_fwd2_c_kernel): 1 = the stem only (5 steps per offset: 266 -> 231 us at 649 k rows), 2 = every
-    // statically shaped instance (measured SLOWER below 64 input channels -- 16 -> 16: 34.5 -> 50.4 us, 32 -> 32: 68.5 -> 73 us: the
-    // mask pass and the run-time offsets cost more than the dropped steps save; gpurun_out/r05_j44)
-    const int cmp_mode = d3_tune(D3T_C2_COMPACT);
-    if (cmp_mode >= 2 || (cmp_mode == 1 && ST == 17)) {
+    // the stem (136 -> 16: five products per offset) drops the offsets no row of a 16-row tile has before its reduction loop
+    // (spconv_fwd2_c_kernel: 266 -> 231 us at 649 k rows; for the 16 / 32-channel instances the mask pass cost more than the dropped
+    // steps saved -- measured in round 5 -- and they run spconv_fwd3_kernel on the lane table since round 6 anyway)
+    if constexpr (ST == 17) {
         static bool attrc_done_dev[64] = {false};
         if (c2_attr_needed(attrc_done_dev)) {
             D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_c_kernel<NT, NW, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -994,30 +901,7 @@ static int launch_fwd2_static(const Conv2Args &a, const Conv2Plan &p, hipStream_
         return 0;
     }
     c2_inst(NT, 1, 1, NW, 0, 27, ST);
-    if (a.tbl16) {
-        static bool attr16_done_dev[64] = {false};
-        if (c2_attr_needed(attr16_done_dev))
-            D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        c2_inst(NT, 1, 1, NW, 0, 27, ST + 1000);     // (+ 1000: the T16 template flag, unpacked by bench.py's kernel naming)
-        spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST, true><<<p.grid, 64 * NW, p.lds, s>>>(a);
-        g_t16_launches++;
-        D3_LAUNCH_CHECK();
-        return 0;
-    }
     spconv_fwd2_kernel<NT, true, true, NW, false, 27, ST><<<p.grid, 64 * NW, p.lds, s>>>(a);
-    D3_LAUNCH_CHECK();
-    return 0;
-}
-template <int ST>
-static int launch_fwd2_ks(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
-    static bool attr_done_dev[64] = {false};
-    if (c2_attr_needed(attr_done_dev)) {
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_ks_kernel<ST, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_fwd2_ks_kernel<ST, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    c2_inst(1, 1, 1, 16, 0, 27, ST + (a.tbl16 ? 1000 : 0) + 2000);     // (+ 2000: the offset-split kernel, see bench.py's kernel naming)
-    if (a.tbl16) { spconv_fwd2_ks_kernel<ST, true, 4><<<p.grid, 1024, p.lds, s>>>(a); g_t16_launches++; }
-    else spconv_fwd2_ks_kernel<ST, false, 4><<<p.grid, 1024, p.lds, s>>>(a);
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -1028,7 +912,6 @@ static int launch_fwd2(const Conv2Args &a, const Conv2Plan &p, hipStream_t s) {
         if constexpr (NT == 1) {
             if (a.S == 2 && p.nw == 4) return launch_fwd2_static<1, 4, 2>(a, p, s);      // 16 -> 16
             if (a.S == 4 && p.nw == 16) return launch_fwd2_static<1, 16, 4>(a, p, s);    // 32 -> 16
-            if (a.S == 17 && p.nw == 16 && d3_tune(D3T_C2_KSPLIT) != 0) return launch_fwd2_ks<17>(a, p, s);   // the stem, offsets split over 4 waves
             if (a.S == 17 && p.nw == 16) return launch_fwd2_static<1, 16, 17>(a, p, s);  // the stem: 134 (+2) -> 16
         }
         if constexpr (NT == 2) {
@@ -1108,11 +991,9 @@ static thread_local double *g_next_part2 = nullptr;
 void d3_spconv_next_part2(double *part2) { g_next_part2 = part2; }
 
 struct Conv2Bn { const float *x, *mean, *var, *gamma, *beta; int ldx, relu; float eps; int xbf16; };
-struct Conv2Fin { int *counter; int mode, M, accum; float *a, *b, *c, *d; float momentum; };
 
 static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res, int ldr,
-                     float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, const Conv2Fin *fin,
-                     void *stream) {
+                     float *part, int Min, int Mout, int K, int Cin, int Cout, int flags, const Conv2Bn *bn, void *stream) {
     D3_CLEAR();
     const void *tbl16 = g_next_tbl16, *tblq = g_next_tblq;      // the hints belong to THIS call, whatever it does with them
     g_next_tbl16 = nullptr; g_next_tblq = nullptr;
@@ -1127,10 +1008,10 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
     if ((xbf16 && (ldx & 7)) || (!xbf16 && (ldx & 3)) || ldx < Cin || ldo < Cout) return D3_ERR_ARG;
     if ((Cout & 3) || (ldo & 3) || (res && (ldr & 3))) return D3_ERR_ARG;   // float4 epilogue
     hipStream_t s = d3_stream(stream);
-    // round 6: the big levels' K = 27 layers on the lane table (spconv3.hip) -- bf16 rows, no accumulate-into, no in-launch finalize
-    if (tblq && tbl && K == 27 && xbf16 && !f32 && !(flags & D3_CONV_ACCUM) && !fin && d3_tune(D3T_C3) != 0 &&
+    // round 6: the big levels' K = 27 layers on the lane table (spconv3.hip) -- bf16 rows, no accumulate-into
+    if (tblq && tbl && K == 27 && xbf16 && !f32 && !(flags & D3_CONV_ACCUM) && d3_tune(D3T_C3) != 0 &&
         (d3_tune(D3T_C3) == 1 || (d3_tune(D3T_C3) == 2 && !bn) || (d3_tune(D3T_C3) == 3 && bn) || (d3_tune(D3T_C3) == 4 && !bn && !res) || (d3_tune(D3T_C3) == 5 && res)) &&      // (2 .. 5: debugging -- forward only / data gradients only / plain forward / residual forward)
-        Mout >= d3_tune(D3T_C2_GRIDCAP) * 16 && d3_spconv_fwd3_nparts(Mout, Cin, Cout) > 0 && !(bn && res)) {
+        Mout >= C2_GRIDCAP * 16 && d3_spconv_fwd3_nparts(Mout, Cin, Cout) > 0 && !(bn && res)) {
         Conv3Bn b3;
         if (bn) b3 = Conv3Bn{bn->x, bn->mean, bn->var, bn->gamma, bn->beta, bn->ldx, bn->relu, bn->xbf16, bn->eps};
         int np = 0;
@@ -1159,11 +1040,6 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
         if (bn->ldx & 3) return D3_ERR_ARG;
         a.bnx = bn->x; a.bn_mean = bn->mean; a.bn_var = bn->var; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
         a.ldbx = bn->ldx; a.bn_relu = bn->relu; a.bn_eps = bn->eps; a.bnx_bf16 = bn->xbf16;
-    }
-    a.fin_counter = nullptr; a.fin_mode = 0; a.fin_M = 0; a.fin_accum = 0; a.fin_a = a.fin_b = a.fin_c = a.fin_d = nullptr; a.fin_momentum = 0.f;
-    if (fin && part) {
-        a.fin_counter = fin->counter; a.fin_mode = fin->mode; a.fin_M = fin->M; a.fin_accum = fin->accum;
-        a.fin_a = fin->a; a.fin_b = fin->b; a.fin_c = fin->c; a.fin_d = fin->d; a.fin_momentum = fin->momentum;
     }
     const Conv2Plan p = conv2_plan(Mout, K, Cin, Cout, f32 != 0);
     g_last_nparts = p.grid;
@@ -1208,7 +1084,7 @@ static int conv2_run(const void *x, int ldx, const int *tbl, const void *Wp, flo
 extern "C" int d3_spconv_fwd2(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo,
                               const float *res, int ldr, float *part, int Min, int Mout, int K, int Cin, int Cout,
                               int flags, void *stream) {
-    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, nullptr, stream);
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, stream);
 }
 
 // Data gradient of a BatchNorm -> ReLU -> convolution unit with the BatchNorm backward reductions fused in: the stored
@@ -1220,28 +1096,7 @@ extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, cons
                                     const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
                                     int flags, void *stream) {
     Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps, (flags & D3_CONV_BNXBF16) ? 1 : 0};
-    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, nullptr, stream);
-}
-
-// fwd2 / fwd2_bnbwd with the reduction of the partials done by the last workgroup to finish (no finalize launch).
-// counter: one zero-initialised int, left at zero.  mode 1: mean / var (C each) <- batch statistics of the stored
-// values over M rows; running_mean / running_var updated with `momentum` when non-NULL (d3_bn_stats semantics).
-// mode 2 (with the bnbwd arguments): sums (2C) = (sum g, sum g*xhat); dgamma / dbeta written (accumulated with accum).
-extern "C" int d3_spconv_fwd2_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
-                                  int ldr, float *part, int *counter, float *mean, float *var, float *running_mean,
-                                  float *running_var, float momentum, int Min, int Mout, int K, int Cin, int Cout, int flags,
-                                  void *stream) {
-    Conv2Fin fin{counter, 1, Mout, 0, mean, var, running_mean, running_var, momentum};
-    return conv2_run(x, ldx, tbl, Wp, out, ldo, res, ldr, part, Min, Mout, K, Cin, Cout, flags, nullptr, &fin, stream);
-}
-extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
-                                        const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
-                                        const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma,
-                                        float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
-                                        void *stream) {
-    Conv2Bn bn{bnx, mean, var, gamma, beta, ldbx, relu, eps, (flags & D3_CONV_BNXBF16) ? 1 : 0};
-    Conv2Fin fin{counter, 2, Mout, accum, sums, dgamma, dbeta, nullptr, 0.f};
-    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, &fin, stream);
+    return conv2_run(x, ldx, tbl, Wp, out, ldo, nullptr, 0, part, Min, Mout, K, Cin, Cout, flags, &bn, stream);
 }
 
 // ------------------------------------------------------------------------------ weight gradient
@@ -1869,7 +1724,7 @@ struct Wg3Cfg { int mt, nt, k, gx, nw, ow, kg, s; };
     X(3, 3, 27, 1, 9, 3, 1, 1)   /* 48 -> 48, level 2 */                       \
     X(3, 3, 27, 1, 9, 1, 3, 2)                                                 \
     X(3, 6, 27, 0, 9, 1, 3, 2)   /* 96 -> 48 */
-/* (S: sub-chunks of 32 rows per iteration, i.e. gathers in flight per wave -- swept per shape with D3_WG3_S.)  Measured and left to
+/* (S: sub-chunks of 32 rows per iteration, i.e. gathers in flight per wave -- swept per shape in round 3.)  Measured and left to
  * the other kernels (tools/wgrad_bench.py, profiles/r02_k): the stem 136 -> 16 (the 16-wave wide-stationary kernel: 208 us against
  * 273 us here at 649 k rows) and the stride-2 pairs of level 2 and deeper (within noise) */
 #define WG3_ROW(MT, NT, KV, GXV, NW, OW, KG, SV) {MT, NT, KV, GXV, NW, OW, KG, SV},
@@ -1890,7 +1745,6 @@ static int wg3_splits(const Wg3Cfg &c, int Ms, int Mg, int K, int Cg, int Cs, in
     const double alg = (double)Ms * K * 4 + (double)Mg * Cg * (gbf ? 2 : 4) + (double)Ms * Cs * (sbf ? 2 : 4);
     double cap = 0.25 * alg; if (cap < 16.0 * 1048576) cap = 16.0 * 1048576;
     int target = wg3_ncu();
-    if (d3_tune(D3T_WG3_R) > 0) target = d3_tune(D3T_WG3_R);   // (experiments)
     int R = target / c.kg; if (R < 1) R = 1;
     const int capR = (int)(cap / (double)wsz);
     *capped = R > capR;
@@ -1906,15 +1760,10 @@ static const Wg3Cfg *wg3_pick(int Ms, int Mg, int K, int Cg, int Cs, int Cin, in
     // 32-bit buffer offsets: operand extents with up to 2x row pitch (views of concatenated buffers)
     if ((long long)Mg * Cg * 2 * (gbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * Cs * 2 * (sbf ? 2 : 4) >= (1ll << 31) || (long long)Ms * K * 4 >= (1ll << 31)) return nullptr;
     const int mt = Cg / 16, nt = (Cs + 15) / 16;
-    const int want_s = d3_tune(D3T_WG3_S);                             // (experiments: prefer the variants with this S)
-    bool have_s = false;
-    for (const Wg3Cfg &c : wg3_cfgs)
-        if (c.mt == mt && c.nt == nt && c.k == K && c.gx == (gx ? 1 : 0) && c.s == want_s) have_s = true;
     const Wg3Cfg *best = nullptr;
     int best_wgs = 0;
     for (const Wg3Cfg &c : wg3_cfgs)
         if (c.mt == mt && c.nt == nt && c.k == K && c.gx == (gx ? 1 : 0)) {
-            if (have_s && c.s != want_s) continue;
             int cpw; bool capped;
             const int wgs = wg3_splits(c, Ms, Mg, K, Cg, Cs, Cin, Cout, gbf, sbf, &cpw, &capped) * c.kg;
             if (!capped) return &c;              // the first (fewest offset groups) whose splits fill the chip within the budget

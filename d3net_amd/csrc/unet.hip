@@ -647,9 +647,6 @@ struct OpD {
     size_t bpart_off; int bparts;     // BNACT: gradient-arena offset / count of those partials
     size_t part2_off, bpart2_off;     // second-level fp64 tables (UN_P2_ROWS rows; inside the per-call zeroed regions): producer ops / BNACT backward
     int wg_hazard;                    // CONV: its output gradient buffer is accumulated into in place later in the backward
-    int fin_bn;                       // CONV: BNACT whose batch statistics this conv's last workgroup finalizes (-1: none)
-    int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
-    size_t cnt_off, bcnt_off;         // ticket counters (arena / gradient arena)
     size_t wpart_off, wpart_bytes; int wsplits;   // CONV: weight-gradient partials in the gradient arena
     int use_shadow;                   // CONV: reads its output gradient from the bf16 shadow of that (fp32) gradient buffer
     int write_shadow;                 // BNACT: its backward apply also writes the bf16 shadow of the buffer it finalises
@@ -663,14 +660,12 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
-    std::vector<int> gabf;            // per buffer: the gradient of an activation buffer (one BatchNorm writer, one convolution reader) is stored as bf16
     std::vector<int> gshadow;         // per buffer: width of the bf16 shadow of (a column window of) its fp32 gradient, 0 = none
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
-    bool planned = false, lastblock = false;
-    int lb_rows = 0;                  // convolutions with at most this many output rows finalize the BatchNorm statistics themselves
+    bool planned = false;
     bool f32 = false;                 // every buffer fp32: reference-precision program (D3_CONV_F32 kernels, no bf16 gradients)
-    size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
+    size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // the second-level partial tables' regions (zeroed once per call)
     // packing jobs (device copy refreshed when a parameter pointer or the arena moves)
     std::vector<PackJob> jobs;
     PackJob *jobs_dev = nullptr;
@@ -708,15 +703,6 @@ extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, cons
                                     const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                                     const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
                                     int flags, void *stream);
-extern "C" int d3_spconv_fwd2_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
-                                  int ldr, float *part, int *counter, float *mean, float *var, float *running_mean,
-                                  float *running_var, float momentum, int Min, int Mout, int K, int Cin, int Cout, int flags,
-                                  void *stream);
-extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
-                                        const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
-                                        const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma,
-                                        float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
-                                        void *stream);
 extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
@@ -744,7 +730,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.part2_off = 0; o.bpart2_off = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.part2_off = 0; o.bpart2_off = 0; o.wg_hazard = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -824,22 +810,6 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             if (q.type == OP_CONV && q.res_mode == 2 && groot(q.res) == r) o.wg_hazard = 1;
         }
     }
-    // a BatchNorm whose statistics come from exactly one convolution covering exactly its channels: that convolution's
-    // last workgroup CAN finalize them (no finalize launch).  Measured on MI355X (canonical scene): forward 2.4 -> 3.4 ms,
-    // backward 5.4 -> 5.7 ms -- every workgroup has to wait for its write-through partial row and take a memory-side
-    // ticket before it retires, which costs more than the 160 tiny finalize launches it saves.  Off unless
-    // D3_LASTBLOCK_FINALIZE=1 (kept for hardware with a coherent L2).
-    // Round 3: per convolution instead of per network -- at the deep levels (a few thousand rows, a few dozen workgroups,
-    // every kernel at the launch floor) the ticket costs nothing measurable and the chain conv -> finalize -> apply loses a
-    // launch: D3_LASTBLOCK_ROWS is the row count up to which a convolution finalizes its own statistics.
-    n->lastblock = d3_tune(D3T_LASTBLOCK_FINALIZE) == 1;
-    n->lb_rows = n->lastblock ? 0x7fffffff : d3_tune(D3T_LASTBLOCK_ROWS);
-    for (size_t j = 0; j < n->ops.size(); j++) {
-        OpD &b = n->ops[j];
-        if (b.type != OP_BNACT || b.srcs.size() != 1) continue;
-        OpD &p = n->ops[b.srcs[0].op];
-        if (p.type == OP_CONV && p.fin_bn < 0 && b.srcs[0].c0 == 0 && b.srcs[0].cn == n->T[b.in].C) { p.fin_bn = (int)j; b.fin_by = b.srcs[0].op; }
-    }
     // BN -> ReLU -> conv units: the conv's data gradient does the BatchNorm-backward reductions in its epilogue
     for (size_t i = 0; i < n->ops.size(); i++) {
         OpD &o = n->ops[i];
@@ -880,41 +850,6 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
                 }
             }
             if (ok && nprod == 1 && ncons == 1) n->gbf[b] = 1;
-        }
-    }
-    // Round 4: the same for the gradient of an ACTIVATION buffer (BatchNorm -> ReLU output, bf16 in the forward): written once by
-    // the data gradient of the one convolution that reads the activation, read once by that BatchNorm's backward.  The convolution's
-    // epilogue takes the BatchNorm-backward partial sums from the unrounded values and stores bf16 (D3_CONV_OUTBF16); the apply pass
-    // reads 2 bytes per element instead of 4.  MEASURED, NOT ADOPTED (D3_ACT_GRAD_BF16 = 0 by default): the gradient arena of the bench batch
-    // shrinks 1.99 -> 1.62 GB, i.e. 0.74 GB less traffic per backward, and the step does not move (19.07 vs 19.00 ms over three
-    // alternating runs; rocprofv3: data-gradient kernels -2 %, the BatchNorm backward unchanged -- at these sizes it is bound by
-    // its per-workgroup reduction of the partial table and by latency, not by the 2 of 16 bytes per element).  fp32 stays.
-    n->gabf.assign(n->B.size(), 0);
-    {
-        const bool on = d3_tune(D3T_ACT_GRAD_BF16) != 0 && !n->f32;
-        for (size_t b = 0; on && b < n->B.size(); b++) {
-            if (n->galias[b] >= 0 || n->gbf[b]) continue;
-            if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
-            bool ok = n->B[b].dtype == 1;
-            for (size_t x = 0; x < n->B.size(); x++)
-                if (n->galias[x] >= 0 && n->T[n->galias[x]].buf == (int)b) ok = false;
-            int nprod = 0, ncons = 0;
-            for (auto &o : n->ops) {
-                if (o.type == OP_PADCAST && n->T[o.out].buf == (int)b) ok = false;
-                if (o.type == OP_STATS) continue;
-                if (o.type == OP_CONV && o.res >= 0 && n->T[o.res].buf == (int)b) ok = false;
-                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.out].buf == (int)b) {
-                    const TensorD &t = n->T[o.out];
-                    nprod++;
-                    if (o.type != OP_BNACT || t.coff != 0 || t.C != n->B[b].width || (t.C & 7)) ok = false;
-                }
-                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.in].buf == (int)b) {
-                    const TensorD &t = n->T[o.in];
-                    ncons++;
-                    if (o.type != OP_CONV || o.in_grad_mode != 1 || t.coff != 0 || t.C != n->B[b].width || o.CinW != t.C) ok = false;
-                }
-            }
-            if (ok && nprod == 1 && ncons == 1) n->gabf[b] = 1;
         }
     }
     // Residual-stream gradients stay fp32 (they are accumulated in place and feed fp32 consumers), but the convolution that
@@ -964,17 +899,9 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             }
         }
     }
-    {   // weight gradients run on their own stream.  Round 2 gave it the lowest priority (the data-gradient chain of the caller's
-        // stream then wins when both want the machine: -0.3 ms).  Round 3 measured what that does once the process owns more
-        // streams (an executor created after others exist; six idle streams created before the executors, as RCCL's would be): the
-        // low-priority queue is starved -- 18.3 -> 21.7 ms per bf16 step, 19 -> 27 ms for the fp32 backward whose weight gradients
-        // ARE the critical path -- while a plain stream measures the same 18.4 ms in both situations.  Plain by default
-        // (D3_SIDE_PRIO=1: lowest priority).
-        int lo = 0, hi = 0;
-        if (d3_tune(D3T_SIDE_PRIO) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-            hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo);
-        else
-            hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
+    {   // weight gradients run on their own (plain-priority) streams.  A lowest-priority stream won 0.3 ms in round 2 and was starved once
+        // the process owned more streams in round 3 (18.3 -> 21.7 ms per step): plain it is
+        hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
         hipStreamCreateWithFlags(&n->side2, hipStreamNonBlocking);
     }
     return n;
@@ -1081,7 +1008,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     for (auto &b : n->B) {
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
         const size_t bi = &b - &n->B[0];
-        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * ((n->gbf[bi] || n->gabf[bi]) ? 2 : 4));
+        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[bi] ? 2 : 4));
         if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * n->gshadow[bi] * 2); }
     }
     size_t bnscr = 0, wgws = 16;
@@ -1121,14 +1048,12 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     }
     for (auto &o : n->ops) if (o.type == OP_CONV) { o.wpart_off = goff; goff += o.wpart_bytes; }
     n->cnt_off0 = off;
-    for (auto &o : n->ops) if (o.type == OP_CONV) { o.cnt_off = off; off += 4; }
     off = d3_align(off);
     // second-level partial tables (round 5) live in the same zeroed-once-per-call region as the ticket counters: no extra fill launch
     for (auto &o : n->ops)
         if ((o.type == OP_CONV || o.type == OP_STATS) && o.nparts > 0) { o.part2_off = off; off += d3_align((size_t)UN_P2_ROWS * 2 * o.partw * 8); }
     n->cnt_bytes = off - n->cnt_off0;
     n->bcnt_off0 = goff;
-    for (auto &o : n->ops) if (o.type == OP_BNACT) { o.bcnt_off = goff; goff += 4; }
     goff = d3_align(goff);
     for (auto &o : n->ops) {
         if (o.type != OP_BNACT || o.fused_by < 0) continue;
@@ -1267,17 +1192,8 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                 d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], use_p2 || !part ? n->ok16[(size_t)o.mlevel] : nullptr);
             if (part && use_p2) d3_spconv_next_part2((double *)(arena + o.part2_off));
             int rc;
-            if (part && o.fin_bn >= 0 && Mout <= n->lb_rows) {
-                const OpD &b = n->ops[o.fin_bn];
-                float *mean = (float *)(arena + b.state_off), *var = mean + o.Cout;
-                rc = d3_spconv_fwd2_fin(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
-                                        res, ldr, part, (int *)(arena + o.cnt_off), mean, var,
-                                        b.rmean >= 0 ? (float *)params[b.rmean] : nullptr, b.rvar >= 0 ? (float *)params[b.rvar] : nullptr,
-                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | (to.dtype == 1 ? D3_CONV_OUTBF16 : 0), stream);
-            } else {
-                rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
-                                    res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | (to.dtype == 1 ? D3_CONV_OUTBF16 : 0), stream);
-            }
+            rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
+                                res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | (to.dtype == 1 ? D3_CONV_OUTBF16 : 0), stream);
             if (rc) return rc;
             if (part) o.nparts = d3_spconv_last_nparts();      // (rows actually written: the kernel depends on the tables at hand)
         } else if (o.type == OP_BNACT) {
@@ -1298,7 +1214,7 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                 // (with the second-level tables the reduction is 16 rows whatever the producer's grid was: no size limit)
                 const long long part_floats = use_p2 ? 0ll : 2ll * ss[0].nparts * ss[0].cn + (o.srcs.size() > 1 ? 2ll * ss[1].nparts * ss[1].cn : 0ll);
                 const int fs_big = d3_tune(D3T_BN_FUSED_BIG);
-                if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
+                if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS) {
                     // statistics + normalisation in one launch (un_bn_fused_small_kernel); big levels: up to 512 workgroups
                     int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows ? 32 : (fs_big > 1 ? fs_big : 512));
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
@@ -1310,7 +1226,7 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                                                                               tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
                     continue;
                 }
-                if (M > 0 && !(o.fin_by >= 0 && M <= n->lb_rows))
+                if (M > 0)
                     un_bn_finalize_kernel<<<(C + 3) / 4, 256, 0, s>>>(ss[0], ss[1], M, C, mean, var,
                                                                    o.rmean >= 0 ? (float *)params[o.rmean] : nullptr,
                                                                    o.rvar >= 0 ? (float *)params[o.rvar] : nullptr, o.momentum);
@@ -1348,7 +1264,7 @@ static float *gptr(const Net *n, char *garena, const float *gout, float *gin, in
     }
     ld = n->B[t->buf].width;
     root = t->buf;
-    if (n->gbf[t->buf] || n->gabf[t->buf]) {          // (whole-buffer views only: coff == 0)
+    if (n->gbf[t->buf]) {          // (whole-buffer views only: coff == 0)
         if (bf16) *bf16 = 1;
         return (float *)(garena + n->B[t->buf].goff);
     }
@@ -1388,12 +1304,11 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
     hipStream_t ws_stream = use_side ? n->side : s;
     std::map<int, hipEvent_t> pending;   // gradient buffer root -> event after its last side-stream reader
     bool side_used = false;
-    const int side_op_rows = d3_tune(D3T_SIDE_OP_ROWS);     // convolutions with fewer rows keep their weight gradient on the caller's stream
     bool main_wgrads = false;                               // ... and the batched reduction (side stream) is ordered behind them by one event
     auto wait_pending = [&](int root) {
         if (!use_side) return;
         auto it = pending.find(root);
-        if (it != pending.end()) { if (d3_tune(D3T_UNSAFE_NO_HAZARD_WAIT) == 0) hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
+        if (it != pending.end()) { hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
     };
     if (n->bcnt_bytes) D3_CHECK(hipMemsetAsync(garena + n->bcnt_off0, 0, n->bcnt_bytes, s));
     const bool use_p2 = d3_tune(D3T_BN_PART2) != 0;
@@ -1469,7 +1384,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             float *go32 = go;                      // (the residual add below reads the fp32 buffer)
             const int ldgo32 = ldgo;
             if (o.use_shadow && root_o >= 0 && n->gshadow[root_o]) { go = (float *)(garena + n->gshadow_off[root_o]); gobf = 1; ldgo = n->gshadow[root_o]; }   // dense (M, C) bf16
-            const bool op_side = use_side && (Min > Mout ? Min : Mout) >= side_op_rows;
+            const bool op_side = use_side;
             hipEvent_t e1 = nullptr;
             if (pgrads[o.w] != nullptr && op_side) {      // dy is complete here
                 e1 = n->next_event();
@@ -1479,7 +1394,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             // data gradient
             if (o.in_grad_mode) {
                 int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
-                const int obf = gibf ? D3_CONV_OUTBF16 : 0;          // (activation gradients with one writer and one reader: Net::gabf)
+                const int obf = gibf ? D3_CONV_OUTBF16 : 0;
                 if (root_i >= 0) wait_pending(root_i);
                 const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && (n->k3_16[(size_t)o.mlevel] || n->ok16[(size_t)o.mlevel]);
                 if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], (use_p2 || o.bn_of_in < 0) ? n->ok16[(size_t)o.mlevel] : nullptr);
@@ -1489,15 +1404,9 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                     const TensorD &tx = n->T[b.in];
                     float *mean = (float *)(arena + b.state_off), *var = mean + tx.C;
                     if (use_p2) d3_spconv_next_part2((double *)(garena + b.bpart2_off));
-                    if (Min > n->lb_rows)
-                        rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
-                                                  (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf | (tx.dtype == 1 ? D3_CONV_BNXBF16 : 0), stream);
-                    else
-                    rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
-                                                  (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                                  (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
-                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf | (tx.dtype == 1 ? D3_CONV_BNXBF16 : 0), stream);
+                    rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
+                                              (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
+                                              (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf | (tx.dtype == 1 ? D3_CONV_BNXBF16 : 0), stream);
                     if (!rc) n->ops[o.bn_of_in].bparts = d3_spconv_last_nparts();
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
@@ -1544,6 +1453,10 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 }
                 if (rc) return rc;
                 if (op_side && root_o >= 0 && o.wg_hazard) {
+                    //  one event per gradient-buffer root: if an earlier reader of this root on the OTHER side stream is still
+                    // pending, this stream waits for it first, so that the recorded event covers both readers
+                    auto prev = pending.find(root_o);
+                    if (prev != pending.end()) D3_CHECK(hipStreamWaitEvent(wst, prev->second, 0));
                     hipEvent_t e2 = n->next_event();
                     if (!e2) return D3_ERR_OVERFLOW;
                     D3_CHECK(hipEventRecord(e2, wst));
@@ -1561,7 +1474,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
             const int fs_rows_b = d3_tune(D3T_BN_FUSED_ROWS);
-            if (o.fused_by >= 0 && M > n->lb_rows && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
+            if (o.fused_by >= 0 && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
                 (use_p2 || 2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS)) {
                 // the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
                 int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows_b ? 32 : (d3_tune(D3T_BN_FUSED_BIG) > 1 ? d3_tune(D3T_BN_FUSED_BIG) : 512));
@@ -1584,9 +1497,8 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 continue;
             }
             if (o.fused_by >= 0) {   // reductions (and the ReLU mask) done by the consumer conv's data gradient
-                if (M > n->lb_rows)
-                    un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
-                                                                   pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
+                un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
+                                                               pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
                 relu = 0;
             } else {
                 const int nb = bn_blocks2(M, C);

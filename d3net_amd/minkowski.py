@@ -35,22 +35,11 @@ _EXACT_FMA = False   # with _EXACT: the one-thread-per-output FMA validation ker
 
 
 def set_exact(flag):
-    """Select the reference-precision kernels: exact fp32 convolutions (fp32 MFMA) instead of bf16 MFMA, and the exact fp32 MFMA
-    form of the heads' tall GEMMs instead of the bf16 x 3 split (csrc/hgemm.hip)."""
-    global _EXACT, _HG_X3_DEFAULT
+    """Select the reference-precision kernels: exact fp32 convolutions (fp32 MFMA) instead of bf16 MFMA.  (The heads' GEMMs are
+    exact fp32 MFMA in both modes.)"""
+    global _EXACT
     _EXACT = bool(flag)
-    try:        # (the library may not be built yet when a CPU-only test flips the flag)
-        L = _lib.lib()
-        if _HG_X3_DEFAULT is None:
-            v = C.c_int(0)
-            L.d3_tuning_get(b"D3_HG_BF16X3", C.byref(v))
-            _HG_X3_DEFAULT = int(v.value)
-        L.d3_tuning_set(b"D3_HG_BF16X3", 0 if _EXACT else _HG_X3_DEFAULT)
-    except Exception:
-        pass
 
-
-_HG_X3_DEFAULT = None
 
 # Precision policy (round 4).  TRAINING steps run bf16 MFMA operands (what bench.py times; BASELINE.json's configs name bf16 / fp16);
 # EVALUATION (module.eval(): validation_step, forward(), every reported mAP / CIDEr / Acc) runs the reference-precision kernels by
@@ -85,30 +74,17 @@ def exact_for(training, name=None):
 
 
 class heads_exact_for:
-    """`with heads_exact_for(training):` -- the heads' GEMM mode follows the same policy as the U-Nets: an evaluation forward that
-    runs the fp32 twin executors must not run the heads on the bf16 x 3 split either (set_exact() switched
-    D3_HG_BF16X3 off, exact_for() did not).  A no-op in training mode and when the split is off anyway (the default)."""
+    """`with heads_exact_for(training):` -- kept as the one place where the heads' arithmetic would follow the evaluation policy of
+    the U-Nets; the heads' GEMMs are exact fp32 MFMA in every mode (round 4's bf16 x 3 split was measured, not adopted, and removed in
+    round 6), so this is a no-op context."""
 
     def __init__(self, training):
-        self.on = (not training) and _EVAL_EXACT and not _EXACT
-        self.prev = None
+        self.training = training
 
     def __enter__(self):
-        if self.on:
-            try:
-                L = _lib.lib()
-                v = C.c_int(0)
-                L.d3_tuning_get(b"D3_HG_BF16X3", C.byref(v))
-                if v.value:
-                    self.prev = int(v.value)
-                    L.d3_tuning_set(b"D3_HG_BF16X3", 0)
-            except Exception:
-                self.prev = None
         return self
 
     def __exit__(self, *exc):
-        if self.prev is not None:
-            _lib.lib().d3_tuning_set(b"D3_HG_BF16X3", self.prev)
         return False
 
 

@@ -99,11 +99,10 @@ class _Done:
 class _Prefetch:
     """ticket of PointGroup.prefetch(): the weight-independent input stage of a LATER step (voxel features, the backbone's coordinate
     pyramid and kernel maps) built on a side stream while the current step runs"""
-    __slots__ = ("inputs", "future", "cm", "voxel_feats", "event", "error", "stage2")
+    __slots__ = ("inputs", "future", "cm", "voxel_feats", "event", "error")
 
     def __init__(self, inputs):
         self.inputs, self.future, self.cm, self.voxel_feats, self.event, self.error = inputs, None, None, None, None, None
-        self.stage2 = None      # thread-less form: the second half (pyramid counts -> kernel maps, padded stem operand), run later in the step
 
 
 PREFETCH_MODE = 3   # InputPrefetcher: 0 off; where in the current step the next batch's input stage starts: 1 clustering begins, 2 at once,
@@ -129,8 +128,6 @@ class InputPrefetcher:
         return cur
 
 
-PREFETCH_THREAD = 1     # 1: the input prefetch on a helper thread; 0: from the step's own thread in two halves (PointGroup._kick_prefetch)
-CLUSTER_THREAD = 0      # 1: the shifted clustering branch on a helper thread (rounds 2-4); 0: both branches from the step's thread (begin / end)
 PREFETCH_TIMEOUT_S = 120
 PREFETCH_PADCAST = 1    # (A/B switch: the prefetch stage also prepares the stem's padded bf16 operand)
 SELECT_WITH_OFFSETS = 1  # (A/B switch) the object points' batch offsets come out of the cluster_select launch (0: six library launches behind it)
@@ -325,35 +322,6 @@ class PointGroup(nn.Module):
         gate = torch.cuda.Event()
         gate.record(cur)
         training = self.training
-        if not PREFETCH_THREAD:
-            # Thread-less form (round 5): the step's own thread enqueues the stage on a side stream in two halves -- here everything up
-            # to the pyramid's row-count copy (begin_pyramid + the voxel pooling), and at a later point of the step (_finish_prefetch:
-            # behind ScoreNet, or at the consumer) the half that needs those counts on the host, which have long arrived by then.
-            key = (dev.index, "prefetch")
-            if key not in self._streams:
-                self._streams[key] = torch.cuda.Stream(device=dev)
-            side = self._streams[key]
-            with torch.cuda.stream(side):
-                side.wait_event(gate)
-                cm, vf = self._input_stage(t.inputs)
-            t.cm, t.voxel_feats = cm, vf
-
-            def stage2():
-                with torch.cuda.stream(side):
-                    if cm is not None:
-                        ex = self._exec("backbone", exact=ME.exact_for(training, "backbone"))
-                        ex.maps(cm)
-                        if PREFETCH_PADCAST:
-                            cm.padded_input = ex.pad_input(vf)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                t.event = ev
-            t.stage2 = stage2
-            t.future = _Done()
-            self._pf_inflight = None
-            self.__dict__["_pf_half"] = t
-            return
-
         def work():
             try:
                 with torch.cuda.device(dev):
@@ -377,16 +345,6 @@ class PointGroup(nn.Module):
         t.future = _prefetch_worker().submit(work)
         self._pf_inflight = t.future
 
-    def _finish_prefetch(self, t=None):
-        """second half of a thread-less prefetch (no-op otherwise)"""
-        t = t if t is not None else self.__dict__.get("_pf_half")
-        if t is None or t.stage2 is None:
-            return
-        if self.__dict__.get("_pf_half") is t:
-            self.__dict__["_pf_half"] = None
-        f, t.stage2 = t.stage2, None
-        f()
-
     def _take_prefetch(self, t, data_dict):
         """-> (cm, voxel_feats) of ticket t for THIS data_dict, or None (never started, or built from other tensors)"""
         if self._pf_pending is t:
@@ -403,7 +361,6 @@ class PointGroup(nn.Module):
         t.inputs = None
         if t.error is not None:
             raise t.error
-        self._finish_prefetch(t)          # (thread-less form whose step never reached the second half's hook)
         # The ticket before the previous one is released here.  Its blocks go back to the side stream's pool, so no helper whose gate
         # was recorded before that ticket's last use may still be allocating: the newest helper (the only one that can be running) is
         # waited for first -- it finished long ago unless two detector passes per step are prefetched back to back.
@@ -641,7 +598,7 @@ class PointGroup(nn.Module):
                 _mark("cl_prepare")
                 self._kick_prefetch("cluster")          # (a pending input prefetch starts here: the clustering leaves most of the chip idle)
                 cur = torch.cuda.current_stream()
-                if self.concurrent_clustering and not CLUSTER_THREAD and pointgroup_ops.ballquery_padded_fits(coords_.shape[0]):
+                if self.concurrent_clustering and pointgroup_ops.ballquery_padded_fits(coords_.shape[0]):
                     # Round 5: BOTH branches from this thread -- begin (everything enqueued: ball query, count kernels, the fill with
                     # its sizes read on the device), begin, then the two ends (each waits for its count's event only).  The helper
                     # thread of rounds 2-4 sat on the critical path with its wake-ups and interpreter-lock hand-overs.
@@ -651,17 +608,30 @@ class PointGroup(nn.Module):
                     def begin(xyz, mean_active, tag):
                         padded = pointgroup_ops.ballquery_batch_p_padded(xyz, batch_idxs_, batch_offsets_, self.cluster_radius, ws_tag=tag)
                         return pointgroup_ops.bfs_cluster_begin(semantic_preds_, padded[0], padded[1], self.cluster_npoint_thre, True, ws_tag=tag)
-                    with torch.cuda.stream(side):
-                        hs = begin(shifted_xyz, self.cluster_shift_meanActive, "s")       # (the longer chain first)
-                    hm = begin(coords_, self.cluster_meanActive, "m")
-                    _mark("cl_ballquery")
-                    self._kick_prefetch("bfs")
-                    self._early_point_losses(data_dict)
-                    first = pointgroup_ops.bfs_cluster_end(hm)
-                    _mark("cl_bfs")
-                    with torch.cuda.stream(side):
-                        shifted = pointgroup_ops.bfs_cluster_end(hs)
-                    cur.wait_stream(side)
+                    hs = hm = None
+                    try:
+                        with torch.cuda.stream(side):
+                            hs = begin(shifted_xyz, self.cluster_shift_meanActive, "s")       # (the longer chain first)
+                        hm = begin(coords_, self.cluster_meanActive, "m")
+                        _mark("cl_ballquery")
+                        self._kick_prefetch("bfs")
+                        self._early_point_losses(data_dict)
+                        h, hm = hm, None
+                        first = pointgroup_ops.bfs_cluster_end(h)
+                        _mark("cl_bfs")
+                        with torch.cuda.stream(side):
+                            h, hs = hs, None
+                            shifted = pointgroup_ops.bfs_cluster_end(h)
+                    finally:
+                        #  an exception between the begins and their ends must not leak the tickets (pinned buffer, event) nor
+                        # let this stream run ahead of the side stream's speculative fill, which still writes the tickets' tensors
+                        for h in (hm, hs):
+                            if h is not None:
+                                try:
+                                    pointgroup_ops.bfs_cluster_end(h)
+                                except Exception:
+                                    pass
+                        cur.wait_stream(side)
                     for t in shifted:
                         t.record_stream(cur)
                 elif self.concurrent_clustering:      # (also: batches beyond the padded lists' range, whose compact form has a host wait per branch)
@@ -709,7 +679,6 @@ class PointGroup(nn.Module):
             score_feats = self._run_unet("score_net", self.score_net, proposals_voxel_feats)
             _mark("score_net_fwd")
             self._kick_prefetch("scorenet")
-            self._finish_prefetch()           # (thread-less prefetch: its pyramid counts have arrived; kernel maps + padded operand now)
             # Host work that does not depend on the proposals goes HERE: the device still has the cluster voxelisation and
             # ScoreNet queued, so the point losses' ~20 small launches and the slot permutation's CPU draw cost no device time;
             # after the `nonzero` below the queue is empty and every host microsecond is an idle device microsecond.

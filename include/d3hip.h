@@ -309,17 +309,6 @@ int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, const void *Wp,
                          const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                          const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout, int flags,
                          void *stream);
-/* the two above with the partials reduced by the last workgroup to finish (device-scope ticket + fences) instead of a
- * separate finalize launch.  counter: one zero-initialised int (left at zero).  _fin: mean / var (+ running statistics,
- * d3_bn_stats semantics) of the stored values; _bnbwd_fin: sums (2C) = (sum g, sum g*xhat), dgamma / dbeta written
- * (accumulated with accum != 0). */
-int d3_spconv_fwd2_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res, int ldr,
-                       float *part, int *counter, float *mean, float *var, float *running_mean, float *running_var,
-                       float momentum, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
-int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
-                             const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
-                             const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma, float *dbeta,
-                             int accum, int Min, int Mout, int K, int Cin, int Cout, int flags, void *stream);
 /* Third-generation K = 27 forward / data-gradient kernel (round 6, csrc/spconv3.hip; replaces MinkowskiConvolution forward and
  * its data gradient at the stride-1 kernel-3 layers: model/common.py:38,41,66; model/pointgroup.py:70): x (Min, ldx) bf16,
  * tq = the level's lane table (d3_kmap_k3_packq), Wp = d3_spconv_pack fragments (K = 27), out (Mout, ldo) fp32 or bf16

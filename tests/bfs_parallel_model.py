@@ -103,54 +103,3 @@ def bfs_cluster_parallel_model(sem, idx, start_len, threshold):
             offs.append(offs[-1] + len(q))
             cid += 1
     return np.array(out_idx, np.int32).reshape(-1, 2), np.array(offs, np.int32)
-
-
-def bfs_order_keys(seed, own, sem, idx, start_len, T=512, qmax=4095):
-    """model of cl_bfs3_kernel (round 5): a lane group of a batch owns frontier node a; every list entry k bids for its target
-    with key = (batch number, node position a in the batch, list position k) through a min-reduction on disc[target]; the bid that
-    is still there after the batch discovered the node (a word claimed by an earlier batch is smaller than every key of this one =
-    visited).  Batches hold <= T frontier nodes; winners are ranked in key order = (parent queue position, list position) = the
-    reference's FIFO order; batch numbers wrap at qmax (visited words are renumbered to batch 0)."""
-    start, ln = start_len[:, 0], start_len[:, 1]
-    INF = (1 << 62)
-    disc = {seed: (0, 0, 0)}
-    queue = [seed]
-    lo, hi, q = 0, 1, 1
-    size = int((own == own[seed]).sum())
-    while lo < hi and hi < size:
-        for fb in range(lo, hi, T):                       # batches of the frontier
-            nb = min(T, hi - fb)
-            keys = []
-            for a in range(nb):                           # claim
-                u = queue[fb + a]
-                for k, j in enumerate(idx[start[u]:start[u] + ln[u]]):
-                    if sem[j] == sem[u] and own[j] == own[u]:
-                        key = (q, a, k)
-                        if disc.get(int(j), (INF, 0, 0)) > key:
-                            disc[int(j)] = key
-                        keys.append((key, int(j)))
-            for key, j in keys:                           # check + enqueue (keys are generated in ascending order)
-                if disc[j] == key:
-                    queue.append(j)
-            q += 1
-            if q == qmax:
-                disc = {j: (0, 0, 0) for j in disc}
-                q = 1
-        lo, hi = hi, len(queue)
-    return queue
-
-
-def bfs_cluster_keys_model(sem, idx, start_len, threshold, **kw):
-    n = len(sem)
-    own = owners(sem, idx, start_len)
-    sizes = np.bincount(own, minlength=n)
-    out_idx, offs = [], [0]
-    cid = 0
-    for s in range(n):
-        if own[s] == s and sizes[s] >= threshold:
-            q = bfs_order_keys(s, own, sem, idx, start_len, **kw)
-            assert len(q) == sizes[s], (len(q), sizes[s])
-            out_idx += [(cid, v) for v in q]
-            offs.append(offs[-1] + len(q))
-            cid += 1
-    return np.array(out_idx, np.int32).reshape(-1, 2), np.array(offs, np.int32)

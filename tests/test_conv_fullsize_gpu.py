@@ -150,45 +150,6 @@ def test_fwd2_big_kernel_forward_and_epilogues(dev, canon, level, kind, cin, cou
     assert relerr(acc, refb + res) < 1e-4
 
 
-@pytest.mark.parametrize("level,cin,cout", [(0, 16, 16), (0, 32, 16), (0, 136, 16), (0, 16, 32), (1, 32, 32), (1, 64, 32)])
-def test_fwd2_offset_compaction_and_offset_split_equal_the_plain_kernel(dev, canon, level, cin, cout):
-    """Round 5: spconv_fwd2_c_kernel (the offsets no row of a 16-row tile has are dropped before the reduction loop: D3_C2_COMPACT,
-    1 = the stem only, 2 = every statically shaped instance) adds the same products in the same order as the plain kernel --
-    outputs and BatchNorm partials are bit-equal; spconv_fwd2_ks_kernel (the stem, D3_C2_KSPLIT=1: four waves per tile, a quarter of
-    the offsets each, partial sums through LDS) adds them in another order -- equal to fp32 rounding."""
-    from d3net_amd import _lib
-    L = _lib.lib()
-    tbl_f, _, Min, Mout, K, _, _ = _geom(canon, level, "k3")
-    rng = np.random.default_rng(900 + level * 100 + cin + cout)
-    x = torch.from_numpy(rng.standard_normal((Min, cin)).astype(np.float32)).bfloat16().to(dev)
-    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)).to(dev).contiguous()
-    res = torch.from_numpy(rng.standard_normal((Mout, cout)).astype(np.float32)).to(dev)
-    wp = _pack(L, W, 0, dev)
-    nparts = L.d3_spconv_fwd2_nparts(Mout, K, cin, cout)
-    pw = (cout + 15) // 16 * 16
-
-    def run():
-        out = torch.full((Mout, cout), float("nan"), device=dev)
-        part = torch.full((nparts, 2, pw), float("nan"), device=dev)
-        _fwd2(L, x, tbl_f, wp, out, Mout, K, cin, cout, flags=XBF16, res=res, part=part)
-        torch.cuda.synchronize()
-        return out, part[:L.d3_spconv_last_nparts(), :, :cout].clone()
-    try:
-        assert L.d3_tuning_set(b"D3_C2_KSPLIT", 0) == 0 and L.d3_tuning_set(b"D3_C2_COMPACT", 0) == 0
-        o0, p0 = run()
-        assert bool(torch.isfinite(o0).all())
-        for mode in (1, 2):
-            assert L.d3_tuning_set(b"D3_C2_COMPACT", mode) == 0
-            o, pp = run()
-            assert torch.equal(o, o0) and torch.equal(pp, p0), (mode, cin, cout)
-        if cin == 136:
-            assert L.d3_tuning_set(b"D3_C2_COMPACT", 0) == 0 and L.d3_tuning_set(b"D3_C2_KSPLIT", 1) == 0
-            o, pp = run()
-            assert relerr(o, o0) < 1e-5 and relerr(pp, p0) < 1e-5
-    finally:
-        L.d3_tuning_set(b"D3_C2_KSPLIT", 0); L.d3_tuning_set(b"D3_C2_COMPACT", 1)
-
-
 @pytest.mark.parametrize("level,kind,cin,cout", [c for c in CASES if c[2] != 136])
 def test_fwd2_big_kernel_data_gradient_and_bn_backward_epilogue(dev, canon, level, kind, cin, cout):
     """dgrad = the same kernel over the transposed map with W^T (packed with FLIPK | TRANSW); and, as the data gradient of

@@ -242,7 +242,8 @@ def _detector_step(dev, scene, seed=0):
 
 def test_int16_kernel_maps_are_bit_identical_to_the_dense_tables(dev):
     """Round 4: the K = 27 convolutions of the big levels read their kernel map as int16 deltas (csrc/coordmap.hip
-    cm_pack16_kernel; forward / data gradient: the T16 instances of spconv_fwd2_kernel, weight gradient: spconv_wgrad3_kernel).
+    cm_pack16_kernel; the stem's forward: spconv_fwd2_c_kernel, weight gradients: spconv_wgrad3_kernel; the other forward / data-gradient
+    launches of the big levels read the lane table, round 6 -- switched off here).
     Same neighbours, same order, same arithmetic: a whole detector step (loss, every backbone parameter gradient, the point
     logits) must be BIT-identical with D3_KMAP16 on and off -- and the 16-bit path must really have run."""
     from d3net_amd import _lib, synthetic as S
@@ -258,7 +259,7 @@ def test_int16_kernel_maps_are_bit_identical_to_the_dense_tables(dev):
             res[on] = _detector_step(dev, scene) + (L.d3_spconv_t16_launches() - n0,)
     finally:
         L.d3_tuning_set(b"D3_KMAP16", 1); L.d3_tuning_set(b"D3_C3", 1)
-    assert res[1][3] >= 20, ("launches that read a 16-bit table", res[1][3])      # level 0: stem + 11 convs forward, their gradients
+    assert res[1][3] >= 10, ("launches that read a 16-bit table", res[1][3])      # the stem's forward + the weight gradients of level 0
     assert res[0][3] == 0
     assert res[1][0] == res[0][0], (res[1][0], res[0][0])
     assert torch.equal(res[1][1], res[0][1]), "backbone parameter gradients"
@@ -340,27 +341,6 @@ def test_few_row_batchnorm_in_one_launch_matches_the_separate_kernels(dev):
     assert abs(res[16384][0] - res[0][0]) <= 1e-5 * abs(res[0][0]), (res[16384][0], res[0][0])
     assert l2err(res[16384][2], res[0][2]) < 1e-3
     assert l2err(res[16384][1], res[0][1]) < 5e-2          # (bf16 chains decorrelate: see the module docstring; a wrong kernel gives O(1))
-
-
-def test_bf16_activation_gradients_stay_at_the_bf16_noise_floor(dev):
-    """Round 4 (csrc/unet.hip Net::gabf, D3_ACT_GRAD_BF16): the gradient of a BatchNorm -> ReLU activation that one convolution reads
-    is stored as bf16 between that convolution's data gradient (which takes the BatchNorm-backward sums from the unrounded values)
-    and the BatchNorm's backward apply.  Same forward (loss identical); the backward differs by one bf16 rounding per element per
-    layer: parameter gradients within the bf16-chain bound of this module (5e-2; a wrong stride or dtype gives O(1)).  The switch
-    is off by default (measured neutral on the step: DESIGN.md 9); this keeps its code path honest."""
-    from d3net_amd import _lib, synthetic as S
-    L = _lib.lib()
-    scene = S.small_scene(dims=(64, 48, 32), n_boxes=4, seed=7)
-    res = {}
-    try:
-        for on in (1, 0):
-            assert L.d3_tuning_set(b"D3_ACT_GRAD_BF16", on) == 0
-            res[on] = _detector_step(dev, scene)
-    finally:
-        L.d3_tuning_set(b"D3_ACT_GRAD_BF16", 0)
-    assert res[1][0] == res[0][0], (res[1][0], res[0][0])
-    assert l2err(res[1][2], res[0][2]) < 2e-2
-    assert l2err(res[1][1], res[0][1]) < 5e-2
 
 
 def test_second_level_batchnorm_partials_match_the_full_table_reduction(dev):

@@ -1,8 +1,6 @@
 """d3_hgemm (csrc/hgemm.hip): the fp32 matrix-core GEMM family behind the speaker / listener heads, against torch fp64 on the
 host.  v_mfma_f32_16x16x4_f32 is exact fp32 with fp32 accumulation: tolerance 2e-6 * sqrt(K) relative to the output scale
-(summation order only).  Round 4: the tall problems (64 x 64 tiled kernel) have a bf16 x 3 split form behind D3_HG_BF16X3 (off by default: measured, not adopted) (hi*hi + hi*lo + lo*hi on
-v_mfma_f32_16x16x32_bf16, fp32 accumulate): every test runs in both modes (`x3` fixture); the split is held to 4e-5 of the
-output scale (per product <= 3 * 2^-18 relative: the dropped lo*lo term and the two roundings of lo).  Shapes are those of model/caption_module.py:72-133 (batch 32, hidden 512, emb 300, feat 128,
+(summation order only).  Shapes are those of model/caption_module.py:72-133 (batch 32, hidden 512, emb 300, feat 128,
 vocabulary 3004), model/graph_module.py:101-108 and their gradients."""
 import ctypes as C
 
@@ -12,17 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-_X3 = [False]
-
-
-@pytest.fixture(params=[0, 1], ids=["fp32-mfma", "bf16x3"], autouse=True)
-def x3(request):
-    from d3net_amd import _lib
-    L = _lib.lib()
-    L.d3_tuning_set(b"D3_HG_BF16X3", request.param)
-    _X3[0] = bool(request.param)
-    yield request.param
-    L.d3_tuning_set(b"D3_HG_BF16X3", 0)
+_X3 = [False]      # (round 4's bf16 x 3 split form of the tiled kernel was removed in round 6: the heads are exact fp32 MFMA)
 
 
 def _seg(A, B, K, ia=None, a_km=False, b_km=False):

@@ -155,30 +155,3 @@ def test_parallel_bfs_model_truncated_lists():
     ci, co = o.bfs_cluster(sem, idx, sl, 5)
     ci2, co2 = model.bfs_cluster_parallel_model(sem, idx, sl, 5)
     assert np.array_equal(ci, ci2) and np.array_equal(co, co2)
-
-
-def test_key_election_bfs_model_equals_the_reference_order():
-    """cl_bfs3_kernel's formulation (round 5: a lane group per frontier node, (batch, node position, list position) min-election in
-    a per-node word) against the sequential oracle: sparse surfaces, blobs with capped (asymmetric) lists, tiny batches (several
-    per level) and a tiny batch-number range (the renumbering of visited words at the wrap)."""
-    rng = np.random.default_rng(16)
-    n = 1500
-    xyz = (rng.random((n, 3)) * np.array([1.0, 1.0, 0.05])).astype(np.float32)
-    sem = rng.integers(1, 3, n).astype(np.int32)
-    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
-    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.06, 50)
-    ci, co = o.bfs_cluster(sem, idx, sl, 5)
-    for kw in (dict(), dict(T=7), dict(T=5, qmax=4)):
-        ci2, co2 = model.bfs_cluster_keys_model(sem, idx, sl, 5, **kw)
-        assert np.array_equal(ci, ci2) and np.array_equal(co, co2), kw
-    n = 2200
-    xyz = rng.normal(0, 0.006, (n, 3)).astype(np.float32)
-    xyz[:, 0] += (rng.integers(0, 2, n) * 0.03).astype(np.float32)
-    sem = rng.integers(1, 3, n).astype(np.int32)
-    bi = np.zeros(n, np.int32); bo = np.array([0, n], np.int32)
-    idx, sl = o.ballquery_batch_p(xyz, bi, bo, 0.03, 300)
-    assert (sl[:, 1] >= 1000).sum() > 100
-    ci, co = o.bfs_cluster(sem, idx, sl, 5)
-    for kw in (dict(), dict(T=100)):
-        ci2, co2 = model.bfs_cluster_keys_model(sem, idx, sl, 5, **kw)
-        assert np.array_equal(ci, ci2) and np.array_equal(co, co2), kw

@@ -512,15 +512,12 @@ def test_bfs_cluster_begin_end_two_in_flight(dev, spec):
         L.d3_tuning_set(b"D3_CL_SPEC", 1)
 
 
-def test_bfs_replay_forms_agree_with_the_oracle(dev):
-    """Round 5: cl_bfs3_kernel (thread per frontier node, key election in LDS words; D3_BFS3=1, the default) and the edge-parallel hash
-    form (cl_bfs2_kernel, D3_BFS3=0) against the sequential oracle on inputs that reach every path of the new kernel: a 190 x 190
-    sheet in shuffled order (36,100 nodes: fits the discovery words; square wavefronts of > 512 nodes -> frontiers read back from the
-    global queue in several batches), a 200 x 200 sheet (40,000 nodes: beyond the words -> stays on cl_bfs2_kernel inside the same
-    call), a loose 3-d blob (lists of 100 - 400 entries: the beyond-registers part of a list) and a dense blob with capped lists
-    (512 x 1000 entries per chunk -> the 64-nodes-at-a-time sub-batches)."""
+def test_bfs_replay_agrees_with_the_oracle_on_wide_frontiers_and_long_lists(dev):
+    """The FIFO replay (cl_bfs2_kernel) against the sequential oracle on inputs that reach its rarely taken paths: a 190 x 190 sheet in
+    shuffled order (36,100 nodes; square wavefronts of > 512 nodes -> frontiers read back from the global queue in several batches),
+    a 200 x 200 sheet (40,000 nodes), a loose 3-d blob (lists of 100 - 400 entries) and a dense blob with capped lists (1000 entries
+    each).  (Round 5's lane-group form cl_bfs3_kernel, bit-exact but 1.3 - 1.7 x slower, was removed in round 6.)"""
     from d3net_amd import pointgroup_ops as P
-    from d3net_amd import _lib
     rng = np.random.default_rng(85)
 
     def sheet(nx, ny, z):
@@ -540,15 +537,10 @@ def test_bfs_replay_forms_agree_with_the_oracle(dev):
     rci, rco = o.bfs_cluster(sem, idx, sl, 50)
     sizes = np.diff(rco)
     assert 36100 in sizes and 40000 in sizes and (sl[:, 1] >= 1000).sum() > 500 and ((sl[:, 1] > 100) & (sl[:, 1] < 1000)).sum() > 500
-    try:
-        for form in (1, 0):
-            assert _lib.lib().d3_tuning_set(b"D3_BFS3", form) == 0
-            for asc in (False, True):
-                ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, asc)
-                assert np.array_equal(N(co), rco), (form, asc)
-                assert np.array_equal(N(ci), rci), (form, asc, int((N(ci) != rci).any(1).argmax()))
-    finally:
-        _lib.lib().d3_tuning_set(b"D3_BFS3", 0)
+    for asc in (False, True):
+        ci, co = P.bfs_cluster(T(sem, dev), T(idx, dev), T(sl, dev), 50, asc)
+        assert np.array_equal(N(co), rco), asc
+        assert np.array_equal(N(ci), rci), (asc, int((N(ci) != rci).any(1).argmax()))
 
 
 def test_bfs_cluster_no_clusters(dev):

@@ -42,11 +42,8 @@ def _step(model, batch):
     return loss.detach().clone(), d, grads
 
 
-@pytest.mark.parametrize("at,thread", [("cluster", 1), ("start", 1), ("bfs", 0), ("start", 0)])
-def test_prefetched_step_equals_inline(dev, setup, at, thread, monkeypatch):
-    """(thread = 0: the thread-less form -- the step's own thread enqueues the stage on a side stream in two halves)"""
-    from d3net_amd import pointgroup as PG
-    monkeypatch.setattr(PG, "PREFETCH_THREAD", thread)
+@pytest.mark.parametrize("at", ["cluster", "start", "bfs"])
+def test_prefetched_step_equals_inline(dev, setup, at):
     model = setup["model"]
     state = {k: v.clone() for k, v in model.state_dict().items()}
     # inline reference: batch A then batch B
