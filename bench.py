@@ -183,7 +183,10 @@ def kernel_family(name):
     """the kernel function a rocprofv3 name belongs to; the entry points that share spconv_fwd2_body (csrc/spconv2.hip: the
     wave-per-tile forward / data-gradient convolution) count as ONE function, under the name the earlier rounds' records carry"""
     base = name.split("<")[0].replace("void ", "").strip('" ')
-    return "spconv_fwd2_kernel" if base in ("spconv_fwd2_c_kernel", "spconv_fwd2_ks_kernel") else base
+    # round 6: spconv_fwd3_kernel (csrc/spconv3.hip, the K = 27 layers of the big levels on the lane table) is the third generation of
+    # the same function -- the wave-per-tile forward / data-gradient convolution; the second generation keeps the stem, the stride-2 /
+    # transposed / 1x1 layers and the shapes without an instance.  One family, named after both.
+    return "spconv_fwd3_kernel+spconv_fwd2_kernel" if base in ("spconv_fwd2_c_kernel", "spconv_fwd2_kernel", "spconv_fwd3_kernel") else base
 
 
 def prof_kernel_name(fam, t):
@@ -191,12 +194,12 @@ def prof_kernel_name(fam, t):
     t = [int(v) for v in t]
     if fam == 0:
         nt, wlds, xbf, nw, f32, kt, st = t[5:12]
-        st, fl = st % 1000, st // 1000            # (the record packs flags into the ST tag: + 1000 the T16 template flag, + 2000 / + 4000 the kernel)
+        st, fl = st % 1000, st // 1000            # (the record packs flags into the ST tag: + 1000 the T16 template flag, + 4000 / + 8000 the kernel)
         t16 = bool(fl & 1)
+        if fl & 8:      # spconv_fwd3_kernel<ST, NT, EPI, OBF, BXBF, NW, QC>: EPI / (OBF | BXBF << 1) / QC ride in the WLDS / XBF / F32M slots
+            return "spconv_fwd3_kernel<%d, %d, %d, %s, %s, %d, %d>" % (st, nt, wlds, _b(xbf & 1), _b(xbf & 2), nw, f32)
         if fl & 4:
             return "spconv_fwd2_c_kernel<%d, %d, %d, %s>" % (nt, nw, st, _b(t16))
-        if fl & 2:
-            return "spconv_fwd2_ks_kernel<%d, %s, 4>" % (st, _b(t16))
         return "spconv_fwd2_kernel<%d, %s, %s, %d, %s, %d, %d, %s>" % (nt, _b(wlds), _b(xbf), nw, _b(f32), kt, st, _b(t16))
     if fam == 2:
         return "spconv_fwd2_split_kernel<%d, %s, %s>" % (t[5], _b(t[6]), _b(t[7]))
@@ -204,7 +207,7 @@ def prof_kernel_name(fam, t):
         return {3: "spconv_wgrad3_kernel", 2: "spconv_wgrad2_kernel", 1: "spconv_wgrad2_wide_kernel", 32: "spconv_wgrad_f32_kernel"}.get(t[5], "spconv_wgrad")
     if fam == 3:
         if t[4] in (0, 2):
-            return "hg_gemm_tiled_kernel" if t[4] == 0 else "hg_gemm_tiled3_kernel"
+            return "hg_gemm_tiled_kernel"
         return "hg_gemm_kernel<%d, %s, %d>" % (t[5], _b(t[6] > 0), max(t[6], 4))
     if fam == 4:
         return "td_gru4_fwd_kernel<1>"
@@ -434,7 +437,9 @@ def cpu_baseline_child(config, threads=0):
     print(json.dumps({"value": 1.0 / dt, "unit": "scenes/sec", "cores": cores, "kind": "port",
                       "sample": "1 scene (of the step's %d; %d points) x (%d warm-up + %d timed) steps, forward+loss+backward+AdamW: %s "
                                 "through oracle/ (torch-CPU gather-mm sparse conv and the reference's brute-force ball query on %d "
-                                "threads; BFS / segment ops single-threaded): %.1f s per step" %
+                                "threads; BFS / segment ops single-threaded): %.1f s per step.  Deviation from BASELINE.md section 2 (>= 3 warm-up "
+                                "+ >= 10 timed steps at os.cpu_count() threads): a bounded sample (the default run must finish within minutes; a "
+                                "step is seconds) at the best thread count of the sweep 8 / 16 / 32 (256 hardware threads: ~1000x slower)" %
                                 (1 if config == "detector" else 4, cpu["locs"].shape[0], CPU_WARMUP_STEPS, CPU_TIMED_STEPS, what, cores, dt)}), flush=True)
 
 
@@ -747,7 +752,9 @@ def main():
                     ceiling["t_%d_scenes_ms" % n32] = json.loads(cl)["ms_per_step"]
                     ceiling["ratio_%d" % n32] = ceiling["t_%d_scenes_ms" % n32] / t4
                     break
-                ceiling["error_%d" % n32] = " ".join((r.stderr or "").split())[-120:]
+                err = r.stderr or ""
+                ceiling["error_%d" % n32] = ("n/a: nActive > INT_MAX under teacher offsets (D3_ERR_RANGE, the reference's `int nActive`)"
+                                             if ("D3_ERR_RANGE" in err or "-2" in err[-400:]) else "n/a: child failed (%s)" % " ".join(err.split())[-60:])
         except Exception as e:      # (never lose the bench line over the side measurement)
             ceiling = dict(ceiling or {}, error=repr(e)[:200])
 

@@ -443,7 +443,8 @@ int d3_conv3_run(const void *x, int ldx, const void *tq, const void *Wp, void *o
 #undef C3_CASE
     if (nparts_out) *nparts_out = grid;
     if (pr) {
-        const int dims[12] = {Min, Mout, 27, Cin, Cout, NT, 1, 1, p.nw, 0, 27, ST + 8000};      // (+ 8000: spconv_fwd3_kernel, see bench.py's kernel naming)
+        const int dims[12] = {Min, Mout, 27, Cin, Cout, NT, epi, (obf ? 1 : 0) | (bxbf ? 2 : 0), p.nw, p.qc, 27, ST + 8000};      // (+ 8000: spconv_fwd3_kernel; EPI / OBF | BXBF << 1 / QC in the
+                                                                                                                               //  WLDS / XBF / F32M slots: bench.py's kernel naming)
         for (int i = 0; i < 12; i++) d3_prof_tag(pr, i, dims[i]);
     }
     d3_prof_end(pr, s);

@@ -30,11 +30,15 @@ def test_kernel_names_are_rocprofv3_names():
     assert bench.prof_kernel_name(0, tags) == "spconv_fwd2_kernel<1, true, true, 4, false, 27, 2, false>"
     tags[11] = 1002                                         # the T16 template flag travels in the ST tag
     assert bench.prof_kernel_name(0, tags) == "spconv_fwd2_kernel<1, true, true, 4, false, 27, 2, true>"
-    # round 5: the other entry points of the same kernel body (+ 4000 offset compaction, + 2000 offset split), one family
+    # the stem's entry point of the same kernel body (+ 4000: offset compaction) and the third generation (+ 8000: spconv_fwd3_kernel,
+    # round 6 -- EPI / OBF | BXBF << 1 / QC ride in the WLDS / XBF / F32M slots of the record): one family
     assert bench.prof_kernel_name(0, [0, 0, 27, 136, 16, 1, 1, 1, 16, 0, 27, 5017]) == "spconv_fwd2_c_kernel<1, 16, 17, true>"
     assert bench.prof_kernel_name(0, [0, 0, 27, 136, 16, 1, 1, 1, 16, 0, 27, 4017]) == "spconv_fwd2_c_kernel<1, 16, 17, false>"
-    assert bench.prof_kernel_name(0, [0, 0, 27, 136, 16, 1, 1, 1, 16, 0, 27, 3017]) == "spconv_fwd2_ks_kernel<17, true, 4>"
-    assert bench.kernel_family("spconv_fwd2_c_kernel<1, 16, 17, true>") == "spconv_fwd2_kernel" == bench.kernel_family("void spconv_fwd2_ks_kernel<17, true, 4>")
+    assert bench.prof_kernel_name(0, [0, 0, 27, 16, 16, 1, 2, 2, 4, 7, 27, 8002]) == "spconv_fwd3_kernel<2, 1, 2, false, true, 4, 7>"
+    assert bench.prof_kernel_name(0, [0, 0, 27, 32, 32, 2, 0, 1, 8, 2, 27, 8004]) == "spconv_fwd3_kernel<4, 2, 0, true, false, 8, 2>"
+    fam = "spconv_fwd3_kernel+spconv_fwd2_kernel"
+    assert bench.kernel_family("spconv_fwd2_c_kernel<1, 16, 17, true>") == fam == bench.kernel_family("void spconv_fwd3_kernel<2, 1, 0, false, false, 4, 7>")
+    assert bench.kernel_family("spconv_fwd2_kernel<1, true, true, 4, false, 0, 0, false>") == fam
     assert bench.kernel_family("spconv_fwd2_split_kernel<4, true, false>") == "spconv_fwd2_split_kernel" and bench.kernel_family("cl_bfs2_kernel") == "cl_bfs2_kernel"
     assert bench.prof_kernel_name(2, [0, 0, 27, 64, 64, 4, 1, 0, -1, 0, 0, 0]) == "spconv_fwd2_split_kernel<4, true, false>"
     assert bench.prof_kernel_name(3, [4096, 128, 128, 1, 0, 0, 0, 0, 0, 0, 0, 0]) == "hg_gemm_tiled_kernel"

@@ -15,17 +15,17 @@ for path in sys.argv[1:3]:
         # kernel names contain commas (template arguments): the four numeric / counter fields are the last four
         name, counter, launches, _mean, total = line.rstrip("\n").rsplit(",", 4)
         base = name.split("<")[0].strip('"').replace("void ", "")
-        if base in ("spconv_fwd2_c_kernel", "spconv_fwd2_ks_kernel"):      # (entry points of one kernel body: bench.kernel_family)
-            base = "spconv_fwd2_kernel"
+        if base in ("spconv_fwd2_c_kernel", "spconv_fwd2_kernel", "spconv_fwd3_kernel"):      # (one kernel function, two generations: bench.kernel_family)
+            base = "spconv_fwd3_kernel+spconv_fwd2_kernel"
         full = name.strip('"').replace("void ", "")
         b = inst[full][counter]
         b[0] += int(launches); b[1] += float(total)
         a = acc[base][counter]
         a[0] += int(launches); a[1] += float(total)
 out = {}
-for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel", "cl_bfs2_kernel",
+for k in ("spconv_fwd3_kernel+spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel", "cl_bfs2_kernel",
           "un_bn_apply_kernel", "un_bn_bwd_apply_kernel", "un_bn_fused_small_kernel", "un_bn_bwd_fused_small_kernel", "hg_gemm_kernel", "hg_gemm_tiled_kernel",
-          "hg_gemm_tiled3_kernel", "td_gru4_fwd_kernel", "cl_push_kernel", "cl_union_kernel", "bqg_query_kernel", "bq_scan_kernel"):
+          "td_gru4_fwd_kernel", "cl_push_kernel", "cl_union_kernel", "bqg_query_kernel", "bq_scan_kernel"):
     if k not in acc:
         continue
     f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
@@ -37,11 +37,11 @@ for k in ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kerne
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_round.sh), bench.py --steps 2 "
                       "--warmup 1 (the bench default workload unless the file name says otherwise); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B "
                       "per 128-B request: MI355X_MICROARCH.md HBM section)"}
-BASES = ("spconv_fwd2_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel",
-         "hg_gemm_kernel", "hg_gemm_tiled_kernel", "hg_gemm_tiled3_kernel", "td_gru4_fwd_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel", "un_bn_bwd_apply_kernel",
+BASES = ("spconv_fwd2_kernel", "spconv_fwd3_kernel", "spconv_fwd2_split_kernel", "spconv_wgrad3_kernel", "spconv_wgrad2_kernel", "spconv_wgrad2_wide_kernel",
+         "hg_gemm_kernel", "hg_gemm_tiled_kernel", "td_gru4_fwd_kernel", "cl_bfs2_kernel", "un_bn_apply_kernel", "un_bn_bwd_apply_kernel",
          "un_bn_fused_small_kernel", "un_bn_bwd_fused_small_kernel")
 for full, v in inst.items():
-    if full in out or full.split("<")[0] not in BASES + ("spconv_fwd2_c_kernel", "spconv_fwd2_ks_kernel"):
+    if full in out or full.split("<")[0] not in BASES + ("spconv_fwd2_c_kernel",):
         continue
     f, w = v["FETCH_SIZE"], v["WRITE_SIZE"]
     if not f[0] or not w[0]:
