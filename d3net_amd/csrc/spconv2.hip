@@ -632,7 +632,11 @@ __global__ __launch_bounds__(1024) void spconv_fwd2_split_kernel(const Conv2Args
             if (a.res) e_res[i] = a.res[(long long)u * a.ldr + col];                                          \
             if (a.accum) e_out[i] = a.out[(long long)u * a.ldo + col];                                        \
             if (a.bnx) {                                                                                      \
-                e_bnx[i] = a.bnx_bf16 ? __uint_as_float((unsigned int)((const unsigned short *)a.bnx)[(long long)u * a.ldbx + col] << 16) : a.bnx[(long long)u * a.ldbx + col]; \
+                {   /* fp32, or bf16 (round 6): ONE 32-bit load either way -- the word that holds the element */              \
+                    const long long bi_ = (long long)u * a.ldbx + col;                                                \
+                    const unsigned int bw_ = ((const unsigned int *)a.bnx)[a.bnx_bf16 ? (bi_ >> 1) : bi_];            \
+                    e_bnx[i] = __uint_as_float(a.bnx_bf16 ? ((bi_ & 1) ? (bw_ & 0xFFFF0000u) : (bw_ << 16)) : bw_);   \
+                }                                                                                                     \
                 e_mean[i] = a.bn_mean[col]; e_var[i] = a.bn_var[col]; \
                 if (a.bn_relu) { e_gam[i] = a.bn_gamma[col]; e_bet[i] = a.bn_beta[col]; }                     \
             }                                                                                                 \
@@ -809,6 +813,10 @@ static Conv2Plan conv2_plan(int Mout, int K, int Cin, int Cout, bool f32 = false
         // few tiles: one column tile per workgroup (the gather is repeated per column group, from L2)
         if (ntiles < 256) p.ntw = 1; else if (NT > 4) p.ntw = (NT + 1) / 2;
         if (p.ntw > 7) p.ntw = 7;
+        // (round 6: the 4-tile instance of the workgroup-per-tile kernel spills at its 128-register budget since the last-block finalize left
+        // its tail -- 78 registers before, 128 + 64 B of scratch after, 13 -> 20 us per launch; the 5-tile instance, 86 registers, serves 64
+        // columns with its fifth tile idle)
+        if (p.ntw == 4) p.ntw = 5;
         p.gy = (NT + p.ntw - 1) / p.ntw;
         const int steps = K * (Cin / 8) / 4 + 1;     // upper bound of MFMA steps per tile
         int W = ntiles * p.gy >= 512 ? 4 : 8;
