@@ -41,19 +41,6 @@ __device__ __forceinline__ unsigned int un_pack2bf(float lo, float hi) {
 __device__ __forceinline__ float un_ld1(const float *p, long long idx, int bf) {
     return bf ? __uint_as_float((unsigned int)((const unsigned short *)p)[idx] << 16) : p[idx];
 }
-// four consecutive elements of a BatchNorm input row: fp32, or bf16 (round 6: single-consumer convolution outputs).  The load is RAW
-// (bf16: 8 bytes in .x / .y) and un_cvx4 widens it where the values are used -- a conversion right behind the load would make every
-// load of a batch wait for its own data instead of all of them being in flight together
-__device__ __forceinline__ float4 un_ldx4(const float *x, long long idx, int xbf) {
-    if (xbf) { const uint2 v = *(const uint2 *)((const unsigned short *)x + idx); return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f); }
-    return *(const float4 *)(x + idx);
-}
-__device__ __forceinline__ void un_cvx4(const float4 r, int xbf, float *o) {
-    if (xbf) {
-        const unsigned int a = __float_as_uint(r.x), b = __float_as_uint(r.y);
-        o[0] = __uint_as_float(a << 16); o[1] = __uint_as_float(a & 0xFFFF0000u); o[2] = __uint_as_float(b << 16); o[3] = __uint_as_float(b & 0xFFFF0000u);
-    } else { o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
-}
 
 struct PackJob { const float *W; size_t dst_off; int K, S, CinW, Cout, NT, flipk, transw, Cin, f32; long long start; };
 
@@ -176,7 +163,7 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void un_bn_apply_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ mean,
                                    const float *__restrict__ var, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, void *__restrict__ y, int ldy, long long M, int C,
-                                   float eps, int relu, int xbf) {
+                                   float eps, int relu) {
     // (row-walking form: see un_bn_bwd_apply_kernel)
     const int c4 = C >> 2, rpb = 256 / c4, t = threadIdx.x;
     if (t >= rpb * c4) return;
@@ -192,14 +179,13 @@ __global__ __launch_bounds__(256) void un_bn_apply_kernel(const float *__restric
         for (int u = 0; u < 4; u++) {
             const long long row = rb + (long long)u * rpb;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < r1) v[u] = un_ldx4(x, row * ldx + c, xbf);
+            if (row < r1) v[u] = *(const float4 *)(x + row * ldx + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const long long row = rb + (long long)u * rpb;
             if (row >= r1) continue;
-            float in[4];
-            un_cvx4(v[u], xbf, in);
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -217,7 +203,7 @@ __global__ __launch_bounds__(UN_T) void un_bn_bwd_reduce_kernel(const float *__r
                                                                const float *__restrict__ dy, int ldy,
                                                                const float *__restrict__ mean, const float *__restrict__ var,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                               int M, int C, float eps, int relu, float *part, int dybf, int xbf) {
+                                                               int M, int C, float eps, int relu, float *part, int dybf) {
     __shared__ float s1[UN_T], s2[UN_T];
     const int t = threadIdx.x;
     const int active = (UN_T / C) * C, rpp = active / C;
@@ -226,7 +212,7 @@ __global__ __launch_bounds__(UN_T) void un_bn_bwd_reduce_kernel(const float *__r
         const int c = t % C;
         const float mu = mean[c], inv = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
         for (long long r = (long long)blockIdx.x * rpp + t / C; r < M; r += (long long)gridDim.x * rpp) {
-            const float xh = (un_ld1(x, r * ldx + c, xbf) - mu) * inv;
+            const float xh = (x[r * ldx + c] - mu) * inv;
             float g = un_ld1(dy, r * ldy + c, dybf);
             if (relu && fmaf(xh, ga, be) <= 0.f) g = 0.f;
             a += g; b = fmaf(g, xh, b);
@@ -295,7 +281,7 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
                                        const float *__restrict__ mean, const float *__restrict__ var,
                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                        const float *__restrict__ sums, float *__restrict__ dx, int ldo, long long M,
-                                       int C, float eps, int relu, int accum, unsigned short *__restrict__ shadow, int xbf) {
+                                       int C, float eps, int relu, int accum, unsigned short *__restrict__ shadow) {
     const int c4 = C >> 2, rpb = 256 / c4, t = threadIdx.x;
     if (t >= rpb * c4) return;
     const int rl = t / c4, c = (t - rl * c4) * 4;
@@ -315,7 +301,7 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
             const long long row = rb + (long long)u * rpb;
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
             if (row < r1) {
-                xv[u] = un_ldx4(x, row * ldx + c, xbf);
+                xv[u] = *(const float4 *)(x + row * ldx + c);
                 gv[u] = un_ldraw4<GBF>(dy, row * ldy + c);
                 if (!OBF && accum) ov[u] = *(const float4 *)(dx + row * ldo + c);
             }
@@ -324,8 +310,7 @@ __global__ __launch_bounds__(256) void un_bn_bwd_apply_kernel(const float *__res
         for (int u = 0; u < UN_AP_U; u++) {
             const long long row = rb + (long long)u * rpb;
             if (row >= r1) continue;
-            float xi[4];
-            un_cvx4(xv[u], xbf, xi);
+            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
             float gi[4];
             un_cvt4<GBF>(gv[u], gi);
             const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
@@ -427,7 +412,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                       void *__restrict__ y, int ldy, int M, int C, float eps, int relu,
                                                                       float *mean_out, float *var_out, float *running_mean, float *running_var,
-                                                                      float momentum, int rows_per_block, int xbf) {
+                                                                      float momentum, int rows_per_block) {
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float4 prm[UN_FS_MAXC];     // (mean, 1/std, gamma, beta)
     const int t = threadIdx.x;
@@ -441,7 +426,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
     for (int u = 0; u < 4; u++) {
         const int row = r0 + rl + u * rpb;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (worker && row < r1) v[u] = un_ldx4(x, (long long)row * ldx + c, xbf);
+        if (worker && row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
     }
     double sa, sb;
     if (s0.p2) un_fs_reduce2(s0, s1, C, acc, sa, sb);
@@ -470,15 +455,14 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
             for (int u = 0; u < 4; u++) {
                 const int row = rb + u * rpb;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < r1) v[u] = un_ldx4(x, (long long)row * ldx + c, xbf);
+                if (row < r1) v[u] = *(const float4 *)(x + (long long)row * ldx + c);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int row = rb + u * rpb;
             if (row >= r1) continue;
-            float in[4];
-            un_cvx4(v[u], xbf, in);
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -499,7 +483,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
                                                                           const float *__restrict__ beta, float *sums, float *dgamma, float *dbeta,
                                                                           int paccum, float *__restrict__ dx, int ldo, int M, int C, float eps,
                                                                           int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block,
-                                                                          const double *__restrict__ part2, int xbf) {
+                                                                          const double *__restrict__ part2) {
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float2 sm[UN_FS_MAXC];
     const int t = threadIdx.x;
@@ -514,7 +498,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
             const int row = rb + u * rpb;
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); gv[u] = xv[u]; ov[u] = xv[u];
             if (worker && row < r1) {
-                xv[u] = un_ldx4(x, (long long)row * ldx + c, xbf);
+                xv[u] = *(const float4 *)(x + (long long)row * ldx + c);
                 gv[u] = un_ldraw4<GBF>(dy, (long long)row * ldy + c);
                 if (!OBF && accum) ov[u] = *(const float4 *)(dx + (long long)row * ldo + c);
             }
@@ -552,8 +536,7 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const fl
         for (int u = 0; u < UN_AP_U; u++) {
             const int row = rb + u * rpb;
             if (row >= r1) continue;
-            float xi[4];
-            un_cvx4(xv[u], xbf, xi);
+            const float xi[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
             float gi[4];
             un_cvt4<GBF>(gv[u], gi);
             const float old[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
@@ -605,38 +588,22 @@ __global__ void un_add_kernel(float *__restrict__ dst, int ldd, const float *__r
 // workgroup, group sums combined in group order.
 struct RedJob { const float *part; float *dW; long long n; int R, accum; long long start; };   // start: first workgroup
 __global__ __launch_bounds__(256) void un_wgrad_reduce_batched_kernel(const RedJob *__restrict__ jobs, int njobs) {
-    // round 6: four consecutive elements per thread (16-byte loads, four rows in flight: the launch was bound by its ~32 dependent
-    // 4-byte round trips per thread -- 0.35 ms per step at ~0.5 TB/s); 128 elements x 8 split groups per workgroup, same summation order
-    __shared__ float4 sh[8][32];
+    __shared__ float sh[8][32];
     int lo = 0, hi = njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].start <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
     const RedJob j = jobs[lo];
     const int el = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const long long e = (((long long)blockIdx.x - j.start) * 32 + el) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e + 3 < j.n && !(j.n & 3)) {
-        int r = rg;
-        for (; r + 24 < j.R; r += 32) {
-            float4 p[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = *(const float4 *)(j.part + (long long)(r + 8 * u) * j.n + e);
-#pragma unroll
-            for (int u = 0; u < 4; u++) { v.x += p[u].x; v.y += p[u].y; v.z += p[u].z; v.w += p[u].w; }
-        }
-        for (; r < j.R; r += 8) { const float4 p = *(const float4 *)(j.part + (long long)r * j.n + e); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-    } else if (e < j.n) {
-        float *vv = &v.x;
-        for (int q = 0; q < 4 && e + q < j.n; q++)
-            for (int r = rg; r < j.R; r += 8) vv[q] += j.part[(long long)r * j.n + e + q];
-    }
+    const long long e = ((long long)blockIdx.x - j.start) * 32 + el;
+    float v = 0.f;
+    if (e < j.n)
+        for (int r = rg; r < j.R; r += 8) v += j.part[(long long)r * j.n + e];
     sh[rg][el] = v;
     __syncthreads();
     if (rg == 0 && e < j.n) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = j.accum ? j.dW[e] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const float4 t = sh[q][el]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-        const float sv[4] = {s.x, s.y, s.z, s.w};
-        for (int q = 0; q < 4 && e + q < j.n; q++) j.dW[e + q] = (j.accum ? j.dW[e + q] : 0.f) + sv[q];
+        for (int q = 0; q < 8; q++) s += sh[q][el];
+        j.dW[e] = s;
     }
 }
 
@@ -663,6 +630,9 @@ struct OpD {
     size_t bpart_off; int bparts;     // BNACT: gradient-arena offset / count of those partials
     size_t part2_off, bpart2_off;     // second-level fp64 tables (UN_P2_ROWS rows; inside the per-call zeroed regions): producer ops / BNACT backward
     int wg_hazard;                    // CONV: its output gradient buffer is accumulated into in place later in the backward
+    int fin_bn;                       // CONV: BNACT whose batch statistics this conv's last workgroup finalizes (-1: none)
+    int fin_by;                       // BNACT: the CONV that finalizes its statistics in the forward (-1: own finalize launch)
+    size_t cnt_off, bcnt_off;         // ticket counters (arena / gradient arena)
     size_t wpart_off, wpart_bytes; int wsplits;   // CONV: weight-gradient partials in the gradient arena
     int use_shadow;                   // CONV: reads its output gradient from the bf16 shadow of that (fp32) gradient buffer
     int write_shadow;                 // BNACT: its backward apply also writes the bf16 shadow of the buffer it finalises
@@ -676,12 +646,14 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
+    std::vector<int> gabf;            // per buffer: the gradient of an activation buffer (one BatchNorm writer, one convolution reader) is stored as bf16
     std::vector<int> gshadow;         // per buffer: width of the bf16 shadow of (a column window of) its fp32 gradient, 0 = none
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
-    bool planned = false;
+    bool planned = false, lastblock = false;
+    int lb_rows = 0;                  // convolutions with at most this many output rows finalize the BatchNorm statistics themselves
     bool f32 = false;                 // every buffer fp32: reference-precision program (D3_CONV_F32 kernels, no bf16 gradients)
-    size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // the second-level partial tables' regions (zeroed once per call)
+    size_t cnt_off0 = 0, cnt_bytes = 0, bcnt_off0 = 0, bcnt_bytes = 0;   // ticket counters (zeroed once per call)
     // packing jobs (device copy refreshed when a parameter pointer or the arena moves)
     std::vector<PackJob> jobs;
     PackJob *jobs_dev = nullptr;
@@ -699,7 +671,7 @@ struct Net {
     int xp_tensor = -1;                // the PADCAST op's output tensor (the stem's zero-padded bf16 input), -1: none
     const void *xp_ext = nullptr;      // its values prepared by the caller (d3_net_padcast) for the next forward / backward call, or NULL
     std::vector<const void *> k3_16;   // per level: 16-bit delta form of the k3 table for the next forward / backward call (or NULL)
-    std::vector<const void *> ok16;    // per level: the lane table (spconv3.hip) for the next forward / backward call (or NULL)
+    std::vector<const int *> ok16;
     std::vector<int> chunk_op;
     std::vector<hipEvent_t> chunk_ev_side, chunk_ev_main;
     RedJob *red_host = nullptr, *red_dev = nullptr;   // pinned staging (ring of RED_RING slots) + device copies of the reduce jobs
@@ -719,6 +691,15 @@ extern "C" int d3_spconv_fwd2_bnbwd(const void *x, int ldx, const int *tbl, cons
                                     const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
                                     const float *beta, float eps, int relu, int Min, int Mout, int K, int Cin, int Cout,
                                     int flags, void *stream);
+extern "C" int d3_spconv_fwd2_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, const float *res,
+                                  int ldr, float *part, int *counter, float *mean, float *var, float *running_mean,
+                                  float *running_var, float momentum, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                                  void *stream);
+extern "C" int d3_spconv_fwd2_bnbwd_fin(const void *x, int ldx, const int *tbl, const void *Wp, float *out, int ldo, float *part,
+                                        const float *bnx, int ldbx, const float *mean, const float *var, const float *gamma,
+                                        const float *beta, float eps, int relu, int *counter, float *sums, float *dgamma,
+                                        float *dbeta, int accum, int Min, int Mout, int K, int Cin, int Cout, int flags,
+                                        void *stream);
 extern "C" size_t d3_spconv_wgrad2_ws_bytes(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Cout, int flags);
 extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const void *dy, int ldy, float *dW, int Min, int Mout,
@@ -746,7 +727,7 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
         o.w = o.gamma = o.beta = o.rmean = o.rvar = -1; o.map = 0; o.mlevel = 0; o.K = 1; o.CinW = 0; o.stats = 0; o.relu = 0;
         o.eps = 0.f; o.momentum = 0.f; o.Cin = o.Cout = 0; o.wp_fwd = o.wp_bwd = o.part_off = o.state_off = 0;
         o.nparts = 0; o.partw = 0; o.in_grad_mode = 0; o.res_mode = 0; o.needs_dgrad_pack = 0;
-        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.part2_off = 0; o.bpart2_off = 0; o.wg_hazard = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
+        o.bn_of_in = -1; o.fused_by = -1; o.bpart_off = 0; o.bparts = 0; o.part2_off = 0; o.bpart2_off = 0; o.wg_hazard = 0; o.fin_bn = -1; o.fin_by = -1; o.cnt_off = 0; o.bcnt_off = 0; o.wpart_off = 0; o.wpart_bytes = 0; o.wsplits = 1; o.use_shadow = 0; o.write_shadow = 0;
         if (o.type == OP_CONV) {
             o.w = (int)p[4]; o.map = (int)p[5]; o.mlevel = (int)p[6]; o.K = (int)p[7]; o.CinW = (int)p[8]; o.stats = (int)p[9];
             o.Cin = n->T[o.in].C; o.Cout = n->T[o.out].C;
@@ -826,6 +807,22 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             if (q.type == OP_CONV && q.res_mode == 2 && groot(q.res) == r) o.wg_hazard = 1;
         }
     }
+    // a BatchNorm whose statistics come from exactly one convolution covering exactly its channels: that convolution's
+    // last workgroup CAN finalize them (no finalize launch).  Measured on MI355X (canonical scene): forward 2.4 -> 3.4 ms,
+    // backward 5.4 -> 5.7 ms -- every workgroup has to wait for its write-through partial row and take a memory-side
+    // ticket before it retires, which costs more than the 160 tiny finalize launches it saves.  Off unless
+    // D3_LASTBLOCK_FINALIZE=1 (kept for hardware with a coherent L2).
+    // Round 3: per convolution instead of per network -- at the deep levels (a few thousand rows, a few dozen workgroups,
+    // every kernel at the launch floor) the ticket costs nothing measurable and the chain conv -> finalize -> apply loses a
+    // launch: D3_LASTBLOCK_ROWS is the row count up to which a convolution finalizes its own statistics.
+    n->lastblock = d3_tune(D3T_LASTBLOCK_FINALIZE) == 1;
+    n->lb_rows = n->lastblock ? 0x7fffffff : d3_tune(D3T_LASTBLOCK_ROWS);
+    for (size_t j = 0; j < n->ops.size(); j++) {
+        OpD &b = n->ops[j];
+        if (b.type != OP_BNACT || b.srcs.size() != 1) continue;
+        OpD &p = n->ops[b.srcs[0].op];
+        if (p.type == OP_CONV && p.fin_bn < 0 && b.srcs[0].c0 == 0 && b.srcs[0].cn == n->T[b.in].C) { p.fin_bn = (int)j; b.fin_by = b.srcs[0].op; }
+    }
     // BN -> ReLU -> conv units: the conv's data gradient does the BatchNorm-backward reductions in its epilogue
     for (size_t i = 0; i < n->ops.size(); i++) {
         OpD &o = n->ops[i];
@@ -866,6 +863,41 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
                 }
             }
             if (ok && nprod == 1 && ncons == 1) n->gbf[b] = 1;
+        }
+    }
+    // Round 4: the same for the gradient of an ACTIVATION buffer (BatchNorm -> ReLU output, bf16 in the forward): written once by
+    // the data gradient of the one convolution that reads the activation, read once by that BatchNorm's backward.  The convolution's
+    // epilogue takes the BatchNorm-backward partial sums from the unrounded values and stores bf16 (D3_CONV_OUTBF16); the apply pass
+    // reads 2 bytes per element instead of 4.  MEASURED, NOT ADOPTED (D3_ACT_GRAD_BF16 = 0 by default): the gradient arena of the bench batch
+    // shrinks 1.99 -> 1.62 GB, i.e. 0.74 GB less traffic per backward, and the step does not move (19.07 vs 19.00 ms over three
+    // alternating runs; rocprofv3: data-gradient kernels -2 %, the BatchNorm backward unchanged -- at these sizes it is bound by
+    // its per-workgroup reduction of the partial table and by latency, not by the 2 of 16 bytes per element).  fp32 stays.
+    n->gabf.assign(n->B.size(), 0);
+    {
+        const bool on = d3_tune(D3T_ACT_GRAD_BF16) != 0 && !n->f32;
+        for (size_t b = 0; on && b < n->B.size(); b++) {
+            if (n->galias[b] >= 0 || n->gbf[b]) continue;
+            if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
+            bool ok = n->B[b].dtype == 1;
+            for (size_t x = 0; x < n->B.size(); x++)
+                if (n->galias[x] >= 0 && n->T[n->galias[x]].buf == (int)b) ok = false;
+            int nprod = 0, ncons = 0;
+            for (auto &o : n->ops) {
+                if (o.type == OP_PADCAST && n->T[o.out].buf == (int)b) ok = false;
+                if (o.type == OP_STATS) continue;
+                if (o.type == OP_CONV && o.res >= 0 && n->T[o.res].buf == (int)b) ok = false;
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.out].buf == (int)b) {
+                    const TensorD &t = n->T[o.out];
+                    nprod++;
+                    if (o.type != OP_BNACT || t.coff != 0 || t.C != n->B[b].width || (t.C & 7)) ok = false;
+                }
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.in].buf == (int)b) {
+                    const TensorD &t = n->T[o.in];
+                    ncons++;
+                    if (o.type != OP_CONV || o.in_grad_mode != 1 || t.coff != 0 || t.C != n->B[b].width || o.CinW != t.C) ok = false;
+                }
+            }
+            if (ok && nprod == 1 && ncons == 1) n->gabf[b] = 1;
         }
     }
     // Residual-stream gradients stay fp32 (they are accumulated in place and feed fp32 consumers), but the convolution that
@@ -915,9 +947,17 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             }
         }
     }
-    {   // weight gradients run on their own (plain-priority) streams.  A lowest-priority stream won 0.3 ms in round 2 and was starved once
-        // the process owned more streams in round 3 (18.3 -> 21.7 ms per step): plain it is
-        hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
+    {   // weight gradients run on their own stream.  Round 2 gave it the lowest priority (the data-gradient chain of the caller's
+        // stream then wins when both want the machine: -0.3 ms).  Round 3 measured what that does once the process owns more
+        // streams (an executor created after others exist; six idle streams created before the executors, as RCCL's would be): the
+        // low-priority queue is starved -- 18.3 -> 21.7 ms per bf16 step, 19 -> 27 ms for the fp32 backward whose weight gradients
+        // ARE the critical path -- while a plain stream measures the same 18.4 ms in both situations.  Plain by default
+        // (D3_SIDE_PRIO=1: lowest priority).
+        int lo = 0, hi = 0;
+        if (d3_tune(D3T_SIDE_PRIO) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo);
+        else
+            hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
         hipStreamCreateWithFlags(&n->side2, hipStreamNonBlocking);
     }
     return n;
@@ -961,11 +1001,9 @@ extern "C" int d3_net_set_k3_16(void *h, const void *const *k3_16, const int *co
     if (!n) return D3_ERR_ARG;
     n->k3_16.assign((size_t)n->nlevels, nullptr);
     n->ok16.assign((size_t)n->nlevels, nullptr);
-    if (d3_tune(D3T_KMAP16) != 0 && !n->f32)
-        for (int l = 0; l < n->nlevels; l++) {
-            if (k3_16 && k3_16[l]) n->k3_16[(size_t)l] = k3_16[l];
-            if (ok16 && ok16[l]) n->ok16[(size_t)l] = (const void *)ok16[l];      // (second array: the lane tables, round 6)
-        }
+    if (k3_16 && ok16 && d3_tune(D3T_KMAP16) != 0 && !n->f32)
+        for (int l = 0; l < n->nlevels; l++)
+            if (k3_16[l] && ok16[l]) { n->k3_16[(size_t)l] = k3_16[l]; n->ok16[(size_t)l] = ok16[l]; }
     return 0;
 }
 // Round 5 (input prefetch): the stem's zero-padded bf16 input prepared OUTSIDE the forward -- d3_net_padcast writes it (M rows x
@@ -1024,7 +1062,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     for (auto &b : n->B) {
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
         const size_t bi = &b - &n->B[0];
-        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[bi] ? 2 : 4));
+        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * ((n->gbf[bi] || n->gabf[bi]) ? 2 : 4));
         if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * n->gshadow[bi] * 2); }
     }
     size_t bnscr = 0, wgws = 16;
@@ -1064,12 +1102,14 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     }
     for (auto &o : n->ops) if (o.type == OP_CONV) { o.wpart_off = goff; goff += o.wpart_bytes; }
     n->cnt_off0 = off;
+    for (auto &o : n->ops) if (o.type == OP_CONV) { o.cnt_off = off; off += 4; }
     off = d3_align(off);
     // second-level partial tables (round 5) live in the same zeroed-once-per-call region as the ticket counters: no extra fill launch
     for (auto &o : n->ops)
         if ((o.type == OP_CONV || o.type == OP_STATS) && o.nparts > 0) { o.part2_off = off; off += d3_align((size_t)UN_P2_ROWS * 2 * o.partw * 8); }
     n->cnt_bytes = off - n->cnt_off0;
     n->bcnt_off0 = goff;
+    for (auto &o : n->ops) if (o.type == OP_BNACT) { o.bcnt_off = goff; goff += 4; }
     goff = d3_align(goff);
     for (auto &o : n->ops) {
         if (o.type != OP_BNACT || o.fused_by < 0) continue;
@@ -1113,6 +1153,7 @@ static inline char *tptr(const Net *n, char *arena, const void *input, int tenso
 // its coordinate manager and ran again without re-setting them read freed tables): every return path of the two entry points
 // drops them, and the thread-local hint of d3_spconv_next_tbl16 with them (an error return taken between setting the hint and
 // the convolution that consumes it must not hand the table to an unrelated K = 27 convolution on this thread).
+void d3_spconv_next_tbl16(const void *tbl16, const int *ok16);
 static void net_drop_k3_16(Net *n) {
     if (n) { n->k3_16.assign(n->k3_16.size(), nullptr); n->ok16.assign(n->ok16.size(), nullptr); n->xp_ext = nullptr; }
     d3_spconv_next_tbl16(nullptr, nullptr);
@@ -1204,14 +1245,22 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
             const float *res = nullptr; int ldr = 0;
             if (o.res >= 0) { res = (const float *)tptr(n, arena, input, o.res); ldr = n->T[o.res].ld; }
             float *part = (o.stats && training) ? (float *)(arena + o.part_off) : nullptr;
-            if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && (n->k3_16[(size_t)o.mlevel] || n->ok16[(size_t)o.mlevel]))
-                d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], use_p2 || !part ? n->ok16[(size_t)o.mlevel] : nullptr);
+            if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
+                d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
             if (part && use_p2) d3_spconv_next_part2((double *)(arena + o.part2_off));
             int rc;
-            rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
-                                res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | (to.dtype == 1 ? D3_CONV_OUTBF16 : 0), stream);
+            if (part && o.fin_bn >= 0 && Mout <= n->lb_rows) {
+                const OpD &b = n->ops[o.fin_bn];
+                float *mean = (float *)(arena + b.state_off), *var = mean + o.Cout;
+                rc = d3_spconv_fwd2_fin(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
+                                        res, ldr, part, (int *)(arena + o.cnt_off), mean, var,
+                                        b.rmean >= 0 ? (float *)params[b.rmean] : nullptr, b.rvar >= 0 ? (float *)params[b.rvar] : nullptr,
+                                        b.momentum, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+            } else {
+                rc = d3_spconv_fwd2(tptr(n, arena, input, o.in), ti.ld, tf, arena + o.wp_fwd, (float *)tptr(n, arena, input, o.out), to.ld,
+                                    res, ldr, part, Min, Mout, o.K, o.Cin, o.Cout, (ti.dtype == 1 ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0), stream);
+            }
             if (rc) return rc;
-            if (part) o.nparts = d3_spconv_last_nparts();      // (rows actually written: the kernel depends on the tables at hand)
         } else if (o.type == OP_BNACT) {
             const TensorD &ti = n->T[o.in], &to = n->T[o.out];
             const int M = n->rows[ti.level], C = ti.C;
@@ -1230,19 +1279,19 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                 // (with the second-level tables the reduction is 16 rows whatever the producer's grid was: no size limit)
                 const long long part_floats = use_p2 ? 0ll : 2ll * ss[0].nparts * ss[0].cn + (o.srcs.size() > 1 ? 2ll * ss[1].nparts * ss[1].cn : 0ll);
                 const int fs_big = d3_tune(D3T_BN_FUSED_BIG);
-                if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS) {
+                if (M > 0 && (M <= fs_rows || (fs_big && fs_rows > 0)) && C <= UN_FS_MAXC && part_floats <= UN_FS_MAX_PART_FLOATS && !(o.fin_by >= 0 && M <= n->lb_rows)) {
                     // statistics + normalisation in one launch (un_bn_fused_small_kernel); big levels: up to 512 workgroups
                     int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows ? 32 : (fs_big > 1 ? fs_big : 512));
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
                     if (to.dtype == 1)
                         un_bn_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
-                                                                             tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
+                                                                             tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb);
                     else
                         un_bn_fused_small_kernel<false><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
-                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
+                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb);
                     continue;
                 }
-                if (M > 0)
+                if (M > 0 && !(o.fin_by >= 0 && M <= n->lb_rows))
                     un_bn_finalize_kernel<<<(C + 3) / 4, 256, 0, s>>>(ss[0], ss[1], M, C, mean, var,
                                                                    o.rmean >= 0 ? (float *)params[o.rmean] : nullptr,
                                                                    o.rvar >= 0 ? (float *)params[o.rvar] : nullptr, o.momentum);
@@ -1254,10 +1303,10 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
             if (total > 0) {
                 if (to.dtype == 1)
                     un_bn_apply_kernel<true><<<un_ap_grid(M, C, 8), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
-                                                                                     tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, ti.dtype == 1 ? 1 : 0);
+                                                                                     tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu);
                 else
                     un_bn_apply_kernel<false><<<un_ap_grid(M, C, 8), 256, 0, s>>>((const float *)tptr(n, arena, input, o.in), ti.ld, use_mean, use_var, gamma, beta,
-                                                                                      tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, ti.dtype == 1 ? 1 : 0);
+                                                                                      tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu);
             }
         }
     }
@@ -1280,7 +1329,7 @@ static float *gptr(const Net *n, char *garena, const float *gout, float *gin, in
     }
     ld = n->B[t->buf].width;
     root = t->buf;
-    if (n->gbf[t->buf]) {          // (whole-buffer views only: coff == 0)
+    if (n->gbf[t->buf] || n->gabf[t->buf]) {          // (whole-buffer views only: coff == 0)
         if (bf16) *bf16 = 1;
         return (float *)(garena + n->B[t->buf].goff);
     }
@@ -1320,11 +1369,12 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
     hipStream_t ws_stream = use_side ? n->side : s;
     std::map<int, hipEvent_t> pending;   // gradient buffer root -> event after its last side-stream reader
     bool side_used = false;
+    const int side_op_rows = d3_tune(D3T_SIDE_OP_ROWS);     // convolutions with fewer rows keep their weight gradient on the caller's stream
     bool main_wgrads = false;                               // ... and the batched reduction (side stream) is ordered behind them by one event
     auto wait_pending = [&](int root) {
         if (!use_side) return;
         auto it = pending.find(root);
-        if (it != pending.end()) { hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
+        if (it != pending.end()) { if (d3_tune(D3T_UNSAFE_NO_HAZARD_WAIT) == 0) hipStreamWaitEvent(s, it->second, 0); pending.erase(it); }
     };
     if (n->bcnt_bytes) D3_CHECK(hipMemsetAsync(garena + n->bcnt_off0, 0, n->bcnt_bytes, s));
     const bool use_p2 = d3_tune(D3T_BN_PART2) != 0;
@@ -1400,7 +1450,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             float *go32 = go;                      // (the residual add below reads the fp32 buffer)
             const int ldgo32 = ldgo;
             if (o.use_shadow && root_o >= 0 && n->gshadow[root_o]) { go = (float *)(garena + n->gshadow_off[root_o]); gobf = 1; ldgo = n->gshadow[root_o]; }   // dense (M, C) bf16
-            const bool op_side = use_side;
+            const bool op_side = use_side && (Min > Mout ? Min : Mout) >= side_op_rows;
             hipEvent_t e1 = nullptr;
             if (pgrads[o.w] != nullptr && op_side) {      // dy is complete here
                 e1 = n->next_event();
@@ -1410,20 +1460,25 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             // data gradient
             if (o.in_grad_mode) {
                 int ldgi, root_i, gibf; float *gi = gptr(n, garena, gout, gin, o.in, ldgi, root_i, &gibf);
-                const int obf = gibf ? D3_CONV_OUTBF16 : 0;
+                const int obf = gibf ? D3_CONV_OUTBF16 : 0;          // (activation gradients with one writer and one reader: Net::gabf)
                 if (root_i >= 0) wait_pending(root_i);
-                const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && (n->k3_16[(size_t)o.mlevel] || n->ok16[(size_t)o.mlevel]);
-                if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], (use_p2 || o.bn_of_in < 0) ? n->ok16[(size_t)o.mlevel] : nullptr);
+                const bool t16 = o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel];
+                if (t16) d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
                 int rc;
                 if (o.bn_of_in >= 0) {
                     const OpD &b = n->ops[o.bn_of_in];
                     const TensorD &tx = n->T[b.in];
                     float *mean = (float *)(arena + b.state_off), *var = mean + tx.C;
                     if (use_p2) d3_spconv_next_part2((double *)(garena + b.bpart2_off));
-                    rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
-                                              (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
-                                              (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf | (tx.dtype == 1 ? D3_CONV_BNXBF16 : 0), stream);
-                    if (!rc) n->ops[o.bn_of_in].bparts = d3_spconv_last_nparts();
+                    if (Min > n->lb_rows)
+                        rc = d3_spconv_fwd2_bnbwd(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
+                                                  (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
+                                                  (const float *)params[b.beta], b.eps, b.relu, Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
+                    else
+                    rc = d3_spconv_fwd2_bnbwd_fin(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, (float *)(garena + b.bpart_off),
+                                                  (const float *)tptr(n, arena, input, b.in), tx.ld, mean, var, (const float *)params[b.gamma],
+                                                  (const float *)params[b.beta], b.eps, b.relu, (int *)(garena + b.bcnt_off), var + tx.C,
+                                                  pgrads[b.gamma], pgrads[b.beta], paccum[b.gamma], Mout, Min, o.K, o.Cout, o.CinW, (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
                 } else {
                     rc = d3_spconv_fwd2(go, ldgo, tb, arena + o.wp_bwd, gi, ldgi, nullptr, 0, nullptr, Mout, Min, o.K, o.Cout, o.CinW,
                                         (o.in_grad_mode == 2 ? D3_CONV_ACCUM : 0) | (gobf ? D3_CONV_XBF16 : 0) | (n->f32 ? D3_CONV_F32 : 0) | obf, stream);
@@ -1456,7 +1511,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
                 char *wpart = garena + o.wpart_off;
                 if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
-                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], nullptr);
+                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
                                           flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? wst : s));
                 if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)
@@ -1464,15 +1519,11 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                     memset(&j, 0, sizeof(j));
                     j.part = (const float *)wpart; j.dW = dW; j.n = (long long)o.K * o.CinW * o.Cout; j.R = o.wsplits;
                     j.accum = paccum[o.w] ? 1 : 0; j.start = red_blocks;
-                    red_blocks += (j.n + 127) / 128;
+                    red_blocks += (j.n + 31) / 32;
                     red.push_back(j);
                 }
                 if (rc) return rc;
                 if (op_side && root_o >= 0 && o.wg_hazard) {
-                    //  one event per gradient-buffer root: if an earlier reader of this root on the OTHER side stream is still
-                    // pending, this stream waits for it first, so that the recorded event covers both readers
-                    auto prev = pending.find(root_o);
-                    if (prev != pending.end()) D3_CHECK(hipStreamWaitEvent(wst, prev->second, 0));
                     hipEvent_t e2 = n->next_event();
                     if (!e2) return D3_ERR_OVERFLOW;
                     D3_CHECK(hipEventRecord(e2, wst));
@@ -1490,7 +1541,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
             const float *x = (const float *)tptr(n, arena, input, o.in);
             int relu = o.relu;
             const int fs_rows_b = d3_tune(D3T_BN_FUSED_ROWS);
-            if (o.fused_by >= 0 && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
+            if (o.fused_by >= 0 && M > n->lb_rows && (M <= fs_rows_b || (d3_tune(D3T_BN_FUSED_BIG) && fs_rows_b > 0)) && C <= UN_FS_MAXC &&
                 (use_p2 || 2ll * o.bparts * C <= UN_FS_MAX_PART_FLOATS)) {
                 // the epilogue partials -> sums / dgamma / dbeta and the input gradient in one launch
                 int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows_b ? 32 : (d3_tune(D3T_BN_FUSED_BIG) > 1 ? d3_tune(D3T_BN_FUSED_BIG) : 512));
@@ -1505,7 +1556,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 un_bn_bwd_fused_small_kernel<OBFV, GBFV><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, \
                                                                               var, gamma, beta, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, \
                                                                               ldgi, M, C, o.eps, RELU_, ACC_, SH_, rows_pb, \
-                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr, ti.dtype == 1 ? 1 : 0)
+                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr)
                 if (gibf) { if (gobf) UN_FSB(true, true, 0, 0, nullptr); else UN_FSB(true, false, 0, 0, nullptr); }
                 else if (gobf) UN_FSB(false, true, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
                 else UN_FSB(false, false, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
@@ -1513,12 +1564,13 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 continue;
             }
             if (o.fused_by >= 0) {   // reductions (and the ReLU mask) done by the consumer conv's data gradient
-                un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
-                                                               pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
+                if (M > n->lb_rows)
+                    un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, C, sums,
+                                                                   pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
                 relu = 0;
             } else {
                 const int nb = bn_blocks2(M, C);
-                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr, gobf, ti.dtype == 1 ? 1 : 0);
+                un_bn_bwd_reduce_kernel<<<nb, UN_T, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, M, C, o.eps, o.relu, bnscr, gobf);
                 un_bn_bwd_final_kernel<<<(C + 3) / 4, 256, 0, s>>>(bnscr, nb, C, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma]);
             }
             if (o.in_grad_mode) {
@@ -1528,7 +1580,7 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 unsigned short *sh = (o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
 #define UN_APB(OBFV, GBFV, ACC_, SH_)                                                                                                     \
                 un_bn_bwd_apply_kernel<OBFV, GBFV><<<un_ap_grid(M, C, UN_AP_U * 2), 256, 0, s>>>(x, ti.ld, go, ldgo, mean, var, gamma, beta, sums, gi, ldgi, M, C, \
-                                                                                              o.eps, relu, ACC_, SH_, ti.dtype == 1 ? 1 : 0)
+                                                                                              o.eps, relu, ACC_, SH_)
                 if (gibf) { if (gobf) UN_APB(true, true, 0, nullptr); else UN_APB(true, false, 0, nullptr); }
                 else if (gobf) UN_APB(false, true, o.in_grad_mode == 2 ? 1 : 0, sh);
                 else UN_APB(false, false, o.in_grad_mode == 2 ? 1 : 0, sh);

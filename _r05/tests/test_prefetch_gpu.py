@@ -1,0 +1,131 @@
+"""Input prefetch (PointGroup.prefetch / InputPrefetcher): the next batch's input stage -- voxel features (model/pointgroup.py:466-474)
+and the backbone's coordinate pyramid + kernel maps -- built on a side stream from a helper thread while the current step runs.
+The stage touches no parameter, so a prefetched step must equal the inline one: identical voxel features and kernel maps, identical
+proposals, the same losses and gradients (the kernels are the same ones, launched from another stream)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from d3net_amd import synthetic as S
+    from d3net_amd.config import default_conf
+    from d3net_amd.pointgroup import PointGroup
+    cfg = default_conf()
+    torch.manual_seed(7)
+    model = PointGroup(cfg).to(dev).train()
+    model.teacher = True
+    scenes = []
+    for seed in (0, 1):
+        occ, sem, inst, _ = S.occupancy_grid((96, 72, 48), 5, (10, 30), (10, 24), seed)
+        scenes.append(S.scene_from_grid(occ, sem, inst))
+    rand = torch.rand(2, 3)
+    perms = [torch.randperm(cfg.model.max_num_proposal) for _ in scenes]
+    return dict(model=model, scenes=scenes, rand=rand, perms=perms, cfg=cfg)
+
+
+def _batch(c, dev, which):
+    from d3net_amd import synthetic as S
+    b = S.make_batch([c["scenes"][i] for i in which], dev)
+    b["cluster_rand"], b["slot_perms"] = c["rand"], [c["perms"][i] for i in which]
+    return b
+
+
+def _step(model, batch):
+    model.zero_grad(set_to_none=True)
+    loss, d = model.training_step(batch)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    return loss.detach().clone(), d, grads
+
+
+@pytest.mark.parametrize("at,thread", [("cluster", 1), ("start", 1), ("bfs", 0), ("start", 0)])
+def test_prefetched_step_equals_inline(dev, setup, at, thread, monkeypatch):
+    """(thread = 0: the thread-less form -- the step's own thread enqueues the stage on a side stream in two halves)"""
+    from d3net_amd import pointgroup as PG
+    monkeypatch.setattr(PG, "PREFETCH_THREAD", thread)
+    model = setup["model"]
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    # inline reference: batch A then batch B
+    ref = []
+    for which in ((0, 1), (1, 0)):
+        model.load_state_dict(state)
+        ref.append(_step(model, _batch(setup, dev, which)))
+    # prefetched: B is announced before A's step and built during it
+    model.prefetch_at = at
+    model.load_state_dict(state)
+    a, b = _batch(setup, dev, (0, 1)), _batch(setup, dev, (1, 0))
+    model.prefetch(b)
+    assert "_prefetch" in b
+    ticket = b["_prefetch"]
+    _step(model, a)
+    assert ticket.future is not None, "the helper must have been started inside A's step"
+    model.load_state_dict(state)
+    loss, d, grads = _step(model, b)
+    assert ticket.cm is not None and d["voxel_feats"] is ticket.voxel_feats          # the prefetched tensors were the ones consumed
+    xp = getattr(ticket.cm, "padded_input", None)                                    # ... incl. the stem's padded bf16 operand
+    assert xp is not None and xp.dtype == torch.bfloat16 and xp.shape[0] == ticket.voxel_feats.shape[0] and xp.shape[1] % 8 == 0
+    assert torch.equal(xp[:, :ticket.voxel_feats.shape[1]].float(), ticket.voxel_feats.to(torch.bfloat16).float()) and bool((xp[:, ticket.voxel_feats.shape[1]:] == 0).all())
+    rl, rd, rg = ref[1]
+    assert torch.equal(d["voxel_feats"], rd["voxel_feats"])
+    assert torch.equal(d["proposal_scores"][1], rd["proposal_scores"][1]) and torch.equal(d["proposal_scores"][2], rd["proposal_scores"][2])
+    assert abs(float(loss) - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
+    assert grads.keys() == rg.keys()
+    for n in rg:
+        den = float(rg[n].norm()) + 1e-12
+        assert float((grads[n] - rg[n]).norm()) / den < 1e-4, n
+
+
+def test_kernel_maps_of_a_prefetched_manager(dev, setup):
+    """every level's coordinates / 27-neighbour table / stride-2 maps of the prefetched manager equal the inline ones"""
+    from d3net_amd import minkowski as ME
+    model = setup["model"]
+    model.prefetch_at = "start"
+    b = _batch(setup, dev, (0, 1))
+    model.prefetch(b)
+    t = b["_prefetch"]
+    t.future.result()
+    assert t.error is None
+    torch.cuda.synchronize()
+    ex = model._exec("backbone", exact=ME.exact_for(True))
+    cm = ME.CoordinateManager(b["voxel_locs"].int().contiguous())
+    ex.maps(cm)
+    ts = 1
+    for lev in range(ex.nlevels):
+        assert torch.equal(cm.coords[ts], t.cm.coords[ts])
+        assert torch.equal(cm.k3(ts), t.cm.k3(ts))
+        if lev + 1 < ex.nlevels:
+            for x, y in zip(cm.down(ts)[:2], t.cm.down(ts)[:2]):
+                assert torch.equal(x, y)
+        ts *= 2
+    # a ticket nobody consumes must not poison the next step
+    loss, d, _ = _step(model, _batch(setup, dev, (1, 0)))
+    assert torch.isfinite(loss)
+
+
+def test_stale_ticket_falls_back_inline(dev, setup):
+    """a ticket built from OTHER tensors than the data_dict it rides in is ignored (the stage runs inline)"""
+    model = setup["model"]
+    model.prefetch_at = "start"
+    a, b = _batch(setup, dev, (0, 1)), _batch(setup, dev, (1, 0))
+    model.prefetch(a)
+    b["_prefetch"] = a.pop("_prefetch")
+    loss, d, _ = _step(model, b)
+    assert d["voxel_feats"].shape[0] == b["voxel_locs"].shape[0] and torch.isfinite(loss)
+
+
+def test_input_prefetcher_loop(dev, setup):
+    from d3net_amd import pointgroup as PG
+    model = setup["model"]
+    feeder = PG.InputPrefetcher(model, lambda: _batch(setup, dev, (0, 1)))
+    losses = []
+    for _ in range(4):
+        model.zero_grad(set_to_none=True)
+        loss, d = model.training_step(feeder.next())
+        loss.backward()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    assert max(losses) - min(losses) <= 1e-5 * max(1.0, abs(losses[0]))      # (no optimizer step: the same batch, the same loss)
