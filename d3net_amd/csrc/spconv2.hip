@@ -1520,6 +1520,7 @@ struct Wg3Args {
     unsigned int invs;                     // ceil(65536 / Cs8)
     int rss, dss, imgs;                    // stationary image (wg2_img)
     const void *tbl16; const int *ok16; unsigned int t16bytes;   // optional 16-bit delta form of tbl (KV = 27; see spconv_fwd2_kernel)
+    const unsigned int *recm; int ntiles;  // optional tile records of the lane table (spconv3.hip): word 7 >> 5 = live-offset mask of 16 rows
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -1593,8 +1594,13 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
     for (int i = 0; i < TL; i++) erow[i] = (t + i * NTH) / KV;
     u32x4_t sv[SU][SE];
+    unsigned int mw_next = 0xFFFFFFFFu;  // lane l < 2 * S: record word 7 of the iteration's l-th 16-row tile (no records: every offset live)
     auto prefetch = [&](int it) {
         const unsigned int row0 = (unsigned int)it * (32 * S);
+        if (a.recm) {
+            const int tile = it * (2 * S) + lane;
+            mw_next = (lane < 2 * S && tile < a.ntiles) ? a.recm[(size_t)tile * 8 + 7] : 0u;
+        }
         if (t16) {
 #pragma unroll
             for (int i = 0; i < TL; i++) {
@@ -1637,6 +1643,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
                 else v = make_uint4(sv[i][0].x, sv[i][0].y, sv[i][0].z, sv[i][0].w);
                 *(uint4 *)(smem + st_off + s_img[i]) = v;
             }
+        // offsets no row of a 32-row sub-chunk has a neighbour at are skipped whole (gathers, image, products): scalar masks
+        unsigned int live[S];
+#pragma unroll
+        for (int s = 0; s < S; s++)
+            live[s] = (__builtin_amdgcn_readlane(mw_next, 2 * s) | __builtin_amdgcn_readlane(mw_next, 2 * s + 1)) >> 5;
         __syncthreads();
         if (it + 1 < it_end) prefetch(it + 1);
         // this wave's gathers: OW offsets x S sub-chunks x MT units per lane, all in flight together
@@ -1647,6 +1658,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
             if (FULL || k < KV) {   // wave-uniform (scalar)
 #pragma unroll
                 for (int s = 0; s < S; s++)
+                    if ((live[s] >> k) & 1u)
 #pragma unroll
                     for (int q = 0; q < MT; q++) {
                         const int idx = *(const int *)(smem + tb_off + ((s * 32 + g_row[q]) * KV + k) * 4);
@@ -1662,7 +1674,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
             for (int j = 0; j < OW; j++) {
                 const int k = k0 + j * NW;
-                if (FULL || k < KV) {
+                if ((FULL || k < KV) && ((live[s] >> k) & 1u)) {
 #pragma unroll
                     for (int q = 0; q < MT; q++) {
                         uint4 v;
@@ -1687,7 +1699,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
                 for (int j = 0; j < OW; j++) {
                     const int k = k0 + j * NW;
-                    if (FULL || k < KV) {
+                    if ((FULL || k < KV) && ((live[s] >> k) & 1u)) {
 #pragma unroll
                         for (int mi = 0; mi < MT; mi++)
                             acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][mi], bv, acc[j][mi][ni], 0, 0, 0);
@@ -2022,7 +2034,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
                                 int Mout, int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes,
                                 void *stream) {
     D3_CLEAR();
-    const void *tbl16 = g_next_tbl16; const int *ok16 = nullptr;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
+    const void *tbl16 = g_next_tbl16, *tblq = g_next_tblq; const int *ok16 = nullptr;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
     g_next_tbl16 = nullptr; g_next_tblq = nullptr;
     if (K < 1 || K > C2_MAXK || Cin < 8 || Cout < 8 || (Cin & 7) || (Cout & 7) || Cin > 224 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -2084,6 +2096,8 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         b.G = a.G; b.Sm = a.Sm; b.tbl = tbl; b.dst = (float *)ws;
         b.gbytes = (unsigned int)gb; b.sbytes = (unsigned int)sb; b.tbytes = (unsigned int)((long long)Ms * K * 4);
         b.tbl16 = (tbl16 && K == 27) ? tbl16 : nullptr; b.ok16 = ok16; b.t16bytes = (unsigned int)((long long)Ms * K * 2);
+        b.recm = nullptr; b.ntiles = (Ms + 15) / 16;
+        if (tblq && K == 27 && d3_tune(D3T_WG3) != 2) b.recm = (const unsigned int *)((const char *)tblq + (size_t)b.ntiles * 1024);
         if (b.tbl16) g_t16_launches++;
         b.growb = a.ldg * (a.gbf16 ? 2 : 4); b.srowb = a.lds * (a.sbf16 ? 2 : 4);
         b.Ms = Ms; b.Cs8 = Cs / 8; b.cpw = p.cpw; b.flipk = a.flipk; b.Cin = CinW; b.Cout = Cout; b.K = K;
