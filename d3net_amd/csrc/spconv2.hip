@@ -1520,7 +1520,6 @@ struct Wg3Args {
     unsigned int invs;                     // ceil(65536 / Cs8)
     int rss, dss, imgs;                    // stationary image (wg2_img)
     const void *tbl16; const int *ok16; unsigned int t16bytes;   // optional 16-bit delta form of tbl (KV = 27; see spconv_fwd2_kernel)
-    const unsigned int *recm; int ntiles;  // optional tile records of the lane table (spconv3.hip): word 7 >> 5 = live-offset mask of 16 rows
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -1535,8 +1534,9 @@ __device__ __forceinline__ uint4 wg3_cvt8(const u32x4_t lo, const u32x4_t hi) {
 // as bf16 (the executor's single-consumer gradient buffers), else fp32 and converted on the way into LDS.
 // NW * OW * KG >= KV; with equality (27 = 9 waves x 3 offsets, 8 = 4 x 2 = 8 x 1) no wave carries an idle offset slot.
 typedef v4s16_t __attribute__((address_space(3))) *wg3_lds_p;
-template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX, bool DYBF>
+template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX, bool DYBF, bool T16>
 __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a) {
+    static_assert(!T16 || KV == 27, "the 16-bit table exists for the 27-offset maps only");
     constexpr int NTH = NW * 64;
     constexpr int TE = S * 32 * KV;                                    // kernel-map entries per iteration
     constexpr int TL = (TE + NTH - 1) / NTH;                           //   ... per thread
@@ -1556,7 +1556,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
     const int lbg = gs_off + wg2_lane_base(RSBG, DG, r, g), lbs = wg2_lane_base(a.rss, a.dss, r, g);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.G, 0, a.gbytes, WG3_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Sm, 0, a.sbytes, WG3_RSRC_FLAGS);
-    const bool t16 = KV == 27 && a.tbl16 != nullptr;      // (uniform; validated by the caller)
+    constexpr bool t16 = T16;                             // (a compile-time form: a run-time choice put both table loops into the iteration
+                                                          //  and a full vmcnt(0) between the table loads and the gathers)
     const __amdgpu_buffer_rsrc_t rt = t16 ? __builtin_amdgcn_make_buffer_rsrc((void *)a.tbl16, 0, a.t16bytes, WG3_RSRC_FLAGS)
                                           : __builtin_amdgcn_make_buffer_rsrc((void *)a.tbl, 0, a.tbytes, WG3_RSRC_FLAGS);
     const int nit = (a.Ms + 32 * S - 1) / (32 * S);
@@ -1594,22 +1595,14 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
     for (int i = 0; i < TL; i++) erow[i] = (t + i * NTH) / KV;
     u32x4_t sv[SU][SE];
-    unsigned int mw_next = 0xFFFFFFFFu;  // lane l < 2 * S: record word 7 of the iteration's l-th 16-row tile (no records: every offset live)
     auto prefetch = [&](int it) {
         const unsigned int row0 = (unsigned int)it * (32 * S);
-        if (a.recm) {
-            const int tile = it * (2 * S) + lane;
-            mw_next = (lane < 2 * S && tile < a.ntiles) ? a.recm[(size_t)tile * 8 + 7] : 0u;
-        }
-        if (t16) {
+        if constexpr (t16) {
 #pragma unroll
             for (int i = 0; i < TL; i++) {
                 const int e = t + i * NTH;
                 tv[i] = 0;
-                if (TL * NTH == TE || e < TE) {
-                    const int d = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rt, (row0 * KV + e) * 2u, 0, 0);   // (beyond the table: 0)
-                    tv[i] = d == -32768 ? -1 : (int)row0 + erow[i] + d;
-                }
+                if (TL * NTH == TE || e < TE) tv[i] = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rt, (row0 * KV + e) * 2u, 0, 0);   // (beyond the table: 0; decoded where it is stored)
             }
         } else {
 #pragma unroll
@@ -1633,7 +1626,9 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
         for (int i = 0; i < TL; i++) {
             const int e = t + i * NTH;
-            if (TL * NTH == TE || e < TE) *(int *)(smem + tb_off + e * 4) = tv[i];
+            // (the 16-bit delta is decoded HERE, an iteration after its load was issued: decoding in prefetch() made every wave wait for the
+            // table's round trip before it could issue its gathers)
+            if (TL * NTH == TE || e < TE) *(int *)(smem + tb_off + e * 4) = !t16 ? tv[i] : (tv[i] == -32768 ? -1 : it * (32 * S) + erow[i] + tv[i]);
         }
 #pragma unroll
         for (int i = 0; i < SU; i++)
@@ -1643,11 +1638,6 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
                 else v = make_uint4(sv[i][0].x, sv[i][0].y, sv[i][0].z, sv[i][0].w);
                 *(uint4 *)(smem + st_off + s_img[i]) = v;
             }
-        // offsets no row of a 32-row sub-chunk has a neighbour at are skipped whole (gathers, image, products): scalar masks
-        unsigned int live[S];
-#pragma unroll
-        for (int s = 0; s < S; s++)
-            live[s] = (__builtin_amdgcn_readlane(mw_next, 2 * s) | __builtin_amdgcn_readlane(mw_next, 2 * s + 1)) >> 5;
         __syncthreads();
         if (it + 1 < it_end) prefetch(it + 1);
         // this wave's gathers: OW offsets x S sub-chunks x MT units per lane, all in flight together
@@ -1658,7 +1648,6 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
             if (FULL || k < KV) {   // wave-uniform (scalar)
 #pragma unroll
                 for (int s = 0; s < S; s++)
-                    if ((live[s] >> k) & 1u)
 #pragma unroll
                     for (int q = 0; q < MT; q++) {
                         const int idx = *(const int *)(smem + tb_off + ((s * 32 + g_row[q]) * KV + k) * 4);
@@ -1674,7 +1663,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
             for (int j = 0; j < OW; j++) {
                 const int k = k0 + j * NW;
-                if ((FULL || k < KV) && ((live[s] >> k) & 1u)) {
+                if (FULL || k < KV) {
 #pragma unroll
                     for (int q = 0; q < MT; q++) {
                         uint4 v;
@@ -1699,7 +1688,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_wgrad3_kernel(const Wg3Args a)
 #pragma unroll
                 for (int j = 0; j < OW; j++) {
                     const int k = k0 + j * NW;
-                    if ((FULL || k < KV) && ((live[s] >> k) & 1u)) {
+                    if (FULL || k < KV) {
 #pragma unroll
                         for (int mi = 0; mi < MT; mi++)
                             acc[j][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][mi], bv, acc[j][mi][ni], 0, 0, 0);
@@ -1746,7 +1735,8 @@ struct Wg3Cfg { int mt, nt, k, gx, nw, ow, kg, s; };
     X(3, 6, 27, 0, 9, 1, 3, 2)   /* 96 -> 48 */
 /* (S: sub-chunks of 32 rows per iteration, i.e. gathers in flight per wave -- swept per shape in round 3.)  Measured and left to
  * the other kernels (tools/wgrad_bench.py, profiles/r02_k): the stem 136 -> 16 (the 16-wave wide-stationary kernel: 208 us against
- * 273 us here at 649 k rows) and the stride-2 pairs of level 2 and deeper (within noise) */
+ * 273 us here at 649 k rows) and the stride-2 pairs of level 2 and deeper (within noise).  Round 6: two 7-wave workgroups per compute unit for
+ * 16 -> 16 (4 offsets per wave, S = 3: 128 VGPRs) ran 68 us against 45 us for the one 9-wave workgroup (gpurun_out/r06_j30): not kept */
 #define WG3_ROW(MT, NT, KV, GXV, NW, OW, KG, SV) {MT, NT, KV, GXV, NW, OW, KG, SV},
 static const Wg3Cfg wg3_cfgs[] = {WG3_CONFIGS(WG3_ROW)};
 #undef WG3_ROW
@@ -1999,16 +1989,25 @@ extern "C" int d3_spconv_wgrad2_splits(int Min, int Mout, int K, int Cin, int Co
     return wg2_plan_flags(Min, Mout, K, Cin, Cout, flags).R;
 }
 
+template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX, bool DYBF, bool T16>
+static int launch_wg3_i(const Wg3Args &a, const Wg2Plan &p, hipStream_t s) {
+    static bool attr_done_dev[64] = {false};
+    if (c2_attr_needed(attr_done_dev))
+        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, DYBF, T16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, DYBF, T16><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
+    return 0;
+}
 template <int MT, int NT, int KV, int NW, int OW, int KG, int S, bool GX>
 static int launch_wg3(const Wg3Args &a, const Wg2Plan &p, bool dybf, hipStream_t s) {
     static_assert(NW * OW * KG >= KV, "offsets not covered");
-    static bool attr_done_dev[64] = {false};
-    if (c2_attr_needed(attr_done_dev)) {
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        D3_CHECK(hipFuncSetAttribute((const void *)spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    int rc;
+    if constexpr (KV == 27) {
+        if (a.tbl16) rc = dybf ? launch_wg3_i<MT, NT, KV, NW, OW, KG, S, GX, true, true>(a, p, s) : launch_wg3_i<MT, NT, KV, NW, OW, KG, S, GX, false, true>(a, p, s);
+        else rc = dybf ? launch_wg3_i<MT, NT, KV, NW, OW, KG, S, GX, true, false>(a, p, s) : launch_wg3_i<MT, NT, KV, NW, OW, KG, S, GX, false, false>(a, p, s);
+    } else {
+        rc = dybf ? launch_wg3_i<MT, NT, KV, NW, OW, KG, S, GX, true, false>(a, p, s) : launch_wg3_i<MT, NT, KV, NW, OW, KG, S, GX, false, false>(a, p, s);
     }
-    if (dybf) spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, true><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
-    else spconv_wgrad3_kernel<MT, NT, KV, NW, OW, KG, S, GX, false><<<dim3(p.R, KG), NW * 64, p.lds, s>>>(a);
+    if (rc) return rc;
     D3_LAUNCH_CHECK();
     return 0;
 }
@@ -2034,7 +2033,7 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
                                 int Mout, int K, int Cin, int Cout, int CinW, int flags, void *ws, size_t ws_bytes,
                                 void *stream) {
     D3_CLEAR();
-    const void *tbl16 = g_next_tbl16, *tblq = g_next_tblq; const int *ok16 = nullptr;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
+    const void *tbl16 = g_next_tbl16; const int *ok16 = nullptr;      // (the hint of d3_spconv_next_tbl16 belongs to this call)
     g_next_tbl16 = nullptr; g_next_tblq = nullptr;
     if (K < 1 || K > C2_MAXK || Cin < 8 || Cout < 8 || (Cin & 7) || (Cout & 7) || Cin > 224 || Cout > 224) return D3_ERR_ARG;
     if (tbl == nullptr && K != 1) return D3_ERR_ARG;
@@ -2096,8 +2095,6 @@ extern "C" int d3_spconv_wgrad2(const void *x, int ldx, const int *tbl, const vo
         b.G = a.G; b.Sm = a.Sm; b.tbl = tbl; b.dst = (float *)ws;
         b.gbytes = (unsigned int)gb; b.sbytes = (unsigned int)sb; b.tbytes = (unsigned int)((long long)Ms * K * 4);
         b.tbl16 = (tbl16 && K == 27) ? tbl16 : nullptr; b.ok16 = ok16; b.t16bytes = (unsigned int)((long long)Ms * K * 2);
-        b.recm = nullptr; b.ntiles = (Ms + 15) / 16;
-        if (tblq && K == 27 && d3_tune(D3T_WG3) != 2) b.recm = (const unsigned int *)((const char *)tblq + (size_t)b.ntiles * 1024);
         if (b.tbl16) g_t16_launches++;
         b.growb = a.ldg * (a.gbf16 ? 2 : 4); b.srowb = a.lds * (a.sbf16 ? 2 : 4);
         b.Ms = Ms; b.Cs8 = Cs / 8; b.cpw = p.cpw; b.flipk = a.flipk; b.Cin = CinW; b.Cout = Cout; b.K = K;

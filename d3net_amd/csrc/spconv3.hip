@@ -52,7 +52,7 @@ __device__ __forceinline__ float c3_bf_hi(unsigned int w) { return __uint_as_flo
 // offset k_{4q+g}:
 //   tq[(tile * 64 + g * 16 + r) * 8 + q] = nbr[tile * 16 + r][k_{4q+g}] - tile * 16 + 32768   (uint16; 0xFFFF: absent / pad)
 // and the tile's record (8 words behind the lane tables: rec[tile * 8 + w]) lists the offsets: byte g of word q < 7 = k_{4q+g},
-// word 7 = lq | live mask << 5 (bit k: offset k is live; the weight-gradient kernel skips the others).  Raster-ordered rows of a 2 cm indoor level have ~16 of 27 offsets live per tile (a planar patch: 9), so the
+// word 7 = lq.  Raster-ordered rows of a 2 cm indoor level have ~16 of 27 offsets live per tile (a planar patch: 9), so the
 // kernel issues 4 - 5 gather groups per tile instead of 7 -- the texture addresser's cycles (16 per 64-lane 16-byte load whether
 // the lanes are in range or not: TA busy 73 % of the 16 -> 16 launch with all 7 groups, profiles/r06_*) are what bounds it.
 // *okq is cleared when an entry does not fit [1, 65534].  One wave per tile.
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void c3_packq_kernel(const int *__restrict__ n
     if (lane < 7) {
         const int *id = &idsS[w][4 * lane];
         rec[(size_t)tile * 8 + lane] = (unsigned int)id[0] | ((unsigned int)id[1] << 8) | ((unsigned int)id[2] << 16) | ((unsigned int)id[3] << 24);
-    } else if (lane == 7) rec[(size_t)tile * 8 + 7] = (unsigned int)((L + 3) / 4) | (m << 5);
+    } else if (lane == 7) rec[(size_t)tile * 8 + 7] = (unsigned int)((L + 3) / 4);
     if (__any(bad) && lane == 0) *okq = 0;
 }
 __global__ void c3_set1_kernel(int *p) { *p = 1; }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_fwd3_kernel(const Conv3Args a,
         unsigned int idq[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) idq[i] = (unsigned int)__builtin_amdgcn_readfirstlane((int)ids[i]);
-        const int lq = __builtin_amdgcn_readfirstlane((int)(ids[7] & 7u));
+        const int lq = __builtin_amdgcn_readfirstlane((int)ids[7]);
         // ---- epilogue operands that do not depend on the products: requested ahead of the gathers
         c3_f32x4 e_res[NT];
         uint2 e_bx16[NT];

@@ -17,7 +17,7 @@ const Entry kTable[D3T_COUNT] = {
     {"D3_BFS_NO_STAR", 0},          // 1: force the BFS level loop for every cluster (tests)
     {"D3_BFS_DEBUG", 0},            // 1: clustering debug dumps
     {"D3_EC_KSPLIT", 1},            // 0: EdgeConv weight gradients as one problem
-    {"D3_WG3", 1},                  // 0: second-generation weight-gradient kernel; 2: third generation without the live-offset masks
+    {"D3_WG3", 1},                  // 0: second-generation weight-gradient kernel
     {"D3_WG2_TR", 1},               // 0: first LDS staging scheme of the second-generation weight gradient
     {"D3_GRAD_BF16", 1},            // 0: every gradient buffer in fp32
     {"D3_SIDE_MIN_ROWS", 32768},    // level-0 rows from which the weight gradients run on the side stream

@@ -1455,8 +1455,8 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 float *dW = pgrads[o.w];
                 // (the stem's x carries zero-padded channels: dW has CinW rows per offset)
                 char *wpart = garena + o.wpart_off;
-                if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && (n->k3_16[(size_t)o.mlevel] || n->ok16[(size_t)o.mlevel]))
-                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], n->ok16[(size_t)o.mlevel]);
+                if (o.map == MAP_K3 && (size_t)o.mlevel < n->k3_16.size() && n->k3_16[(size_t)o.mlevel])
+                    d3_spconv_next_tbl16(n->k3_16[(size_t)o.mlevel], nullptr);
                 int rc = d3_spconv_wgrad2(tptr(n, arena, input, o.in), ti.ld, tw, go, ldgo, dW, Min, Mout, o.K, o.Cin, o.Cout, o.CinW,
                                           flags | D3_CONV_NOREDUCE, wpart, o.wpart_bytes, (void *)(op_side ? wst : s));
                 if (o.wsplits > 1 || paccum[o.w] || n->f32) {   // (a single bf16-path split without accumulation was written to dW directly)

@@ -58,3 +58,12 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|libpgoracle|pg_oracle", t, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_switch_table_stays_small(built_lib):
+    """the library's measurement / cross-check switches live in ONE table (csrc/tuning.hip): at most 30, every name unique"""
+    from d3net_amd import _lib
+    l = _lib.lib()
+    n = l.d3_tuning_count()
+    names = [l.d3_tuning_name(i) for i in range(n)]
+    assert n <= 30 and len(set(names)) == n and all(x.startswith(b"D3_") for x in names), names

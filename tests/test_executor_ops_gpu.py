@@ -301,26 +301,6 @@ def test_lane_table_kernel_equals_the_dense_table_kernels_to_fp32_rounding(dev):
     assert cosine > 0.7 and 0.8 < float(g1.norm() / g0.norm()) < 1.25, (cosine, float(g1.norm() / g0.norm()))
 
 
-def test_weight_gradient_skips_dead_offsets_bit_exactly(dev):
-    """Round 6: spconv_wgrad3_kernel reads the live-offset masks of the lane table's tile records and skips (gathers, LDS image,
-    products) every (32-row sub-chunk, offset) pair no row has a neighbour at -- contributions that are exact zeros: a whole detector
-    step with the masks (D3_WG3=1) and without (D3_WG3=2) gives bit-identical losses, gradients and logits."""
-    from d3net_amd import _lib, synthetic as S
-    L = _lib.lib()
-    occ, sem, inst, _ = S.occupancy_grid()
-    scene = S.scene_from_grid(occ, sem, inst)
-    res = {}
-    try:
-        for mode in (1, 2):
-            assert L.d3_tuning_set(b"D3_WG3", mode) == 0
-            res[mode] = _detector_step(dev, scene)
-    finally:
-        L.d3_tuning_set(b"D3_WG3", 1)
-    assert res[1][0] == res[2][0]
-    assert torch.equal(res[1][1], res[2][1]), "backbone parameter gradients"
-    assert torch.equal(res[1][2], res[2][2]), "point logits"
-
-
 def test_int16_kernel_map_refuses_far_neighbours(dev):
     """a row order whose neighbours are more than 32767 rows apart does not fit int16 deltas: the validity flag of
     d3_kmap_k3_pack16 is 0 and the coordinate manager hands out no 16-bit table (the convolutions keep the dense one)"""
