@@ -422,12 +422,13 @@ __device__ __forceinline__ void un_fs_reduce2(const StatSrc &s0, const StatSrc &
     sa = 0.; sb = 0.;
     if (t < C) { sa = acc[t]; sb = acc[C + t]; }
 }
-template <bool BF16>
+template <bool BF16, bool XBF>      // XBF: the input rows are bf16 (a compile-time form: the run-time choice cost 2 us per launch)
 __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, StatSrc s1, const float *__restrict__ x, int ldx,
                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                       void *__restrict__ y, int ldy, int M, int C, float eps, int relu,
                                                                       float *mean_out, float *var_out, float *running_mean, float *running_var,
-                                                                      float momentum, int rows_per_block, int xbf) {
+                                                                      float momentum, int rows_per_block) {
+    constexpr int xbf = XBF ? 1 : 0;
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float4 prm[UN_FS_MAXC];     // (mean, 1/std, gamma, beta)
     const int t = threadIdx.x;
@@ -492,14 +493,15 @@ __global__ __launch_bounds__(UN_FS_T) void un_bn_fused_small_kernel(StatSrc s0, 
 }
 // backward twin: sum g / sum g*xhat from the data gradient's epilogue partials (width C) -> sums, dgamma / dbeta (workgroup 0),
 // then dx = gamma*inv*(g - mean(g) - xhat*mean(g*xhat)) for this workgroup's rows (the arithmetic of un_bn_bwd_apply_kernel)
-template <bool OBF, bool GBF>
+template <bool OBF, bool GBF, bool XBF>
 __global__ __launch_bounds__(UN_FS_T) void un_bn_bwd_fused_small_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ x, int ldx,
                                                                           const float *__restrict__ dy, int ldy, const float *__restrict__ mean,
                                                                           const float *__restrict__ var, const float *__restrict__ gamma,
                                                                           const float *__restrict__ beta, float *sums, float *dgamma, float *dbeta,
                                                                           int paccum, float *__restrict__ dx, int ldo, int M, int C, float eps,
                                                                           int relu, int accum, unsigned short *__restrict__ shadow, int rows_per_block,
-                                                                          const double *__restrict__ part2, int xbf) {
+                                                                          const double *__restrict__ part2) {
+    constexpr int xbf = XBF ? 1 : 0;
     __shared__ double acc[UN_FS_T * 4 * 2];
     __shared__ float2 sm[UN_FS_MAXC];
     const int t = threadIdx.x;
@@ -1234,12 +1236,12 @@ static int net_forward_impl(void *h, const void *const *params, const int *const
                     // statistics + normalisation in one launch (un_bn_fused_small_kernel); big levels: up to 512 workgroups
                     int G, rows_pb; un_fs_grid(M, C, G, rows_pb, M <= fs_rows ? 32 : (fs_big > 1 ? fs_big : 512));
                     float *rm = o.rmean >= 0 ? (float *)params[o.rmean] : nullptr, *rv = o.rvar >= 0 ? (float *)params[o.rvar] : nullptr;
-                    if (to.dtype == 1)
-                        un_bn_fused_small_kernel<true><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
-                                                                             tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
-                    else
-                        un_bn_fused_small_kernel<false><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta,
-                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb, ti.dtype == 1 ? 1 : 0);
+#define UN_FSF(OBFV, XBFV)                                                                                                             \
+                    un_bn_fused_small_kernel<OBFV, XBFV><<<G, UN_FS_T, 0, s>>>(ss[0], ss[1], (const float *)tptr(n, arena, input, o.in), ti.ld, gamma, beta, \
+                                                                              tptr(n, arena, input, o.out), to.ld, M, C, o.eps, o.relu, mean, var, rm, rv, o.momentum, rows_pb)
+                    if (to.dtype == 1) { if (ti.dtype == 1) UN_FSF(true, true); else UN_FSF(true, false); }
+                    else { if (ti.dtype == 1) UN_FSF(false, true); else UN_FSF(false, false); }
+#undef UN_FSF
                     continue;
                 }
                 if (M > 0)
@@ -1501,14 +1503,16 @@ static int net_backward_impl(void *h, const void *const *params, const int *cons
                 }
                 unsigned short *sh = (o.in_grad_mode && o.write_shadow && root_i >= 0 && n->gshadow[root_i] == C) ? (unsigned short *)(garena + n->gshadow_off[root_i]) : nullptr;
                 if (!o.in_grad_mode) G = 1;
-#define UN_FSB(OBFV, GBFV, RELU_, ACC_, SH_)                                                                                          \
-                un_bn_bwd_fused_small_kernel<OBFV, GBFV><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, \
+#define UN_FSB2(OBFV, GBFV, XBFV, RELU_, ACC_, SH_)                                                                                   \
+                un_bn_bwd_fused_small_kernel<OBFV, GBFV, XBFV><<<G, UN_FS_T, 0, s>>>((const float *)(garena + o.bpart_off), o.bparts, x, ti.ld, go, ldgo, mean, \
                                                                               var, gamma, beta, sums, pgrads[o.gamma], pgrads[o.beta], paccum[o.gamma], gi, \
                                                                               ldgi, M, C, o.eps, RELU_, ACC_, SH_, rows_pb, \
-                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr, ti.dtype == 1 ? 1 : 0)
+                                                                              use_p2 ? (const double *)(garena + o.bpart2_off) : nullptr)
+#define UN_FSB(OBFV, GBFV, RELU_, ACC_, SH_) do { if (ti.dtype == 1) UN_FSB2(OBFV, GBFV, true, RELU_, ACC_, SH_); else UN_FSB2(OBFV, GBFV, false, RELU_, ACC_, SH_); } while (0)
                 if (gibf) { if (gobf) UN_FSB(true, true, 0, 0, nullptr); else UN_FSB(true, false, 0, 0, nullptr); }
                 else if (gobf) UN_FSB(false, true, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
                 else UN_FSB(false, false, 0, o.in_grad_mode == 2 ? 1 : 0, sh);
+#undef UN_FSB2
 #undef UN_FSB
                 continue;
             }

@@ -212,6 +212,8 @@ class PointGroup(nn.Module):
         # test hooks: override predictions before clustering ("teacher" switch of SURVEY.md 8(d))
         self.teacher = False
         self.concurrent_clustering = True
+        self.padded_list_budget = None      # bytes; None: 35 % of the device's memory (_padded_list_budget)
+        self._mem_total = {}
         self._streams = {}
         # native executors (csrc/unet.hip) for the two sparse U-Nets: one C-ABI call per forward / backward instead of
         # one python call per module.  Built lazily; the module tree above stays the owner of every parameter.
@@ -229,6 +231,16 @@ class PointGroup(nn.Module):
         # forward() as well, right behind the losses themselves: in the clustering stage the chip is mostly idle, in the backward these
         # ~15 launches sit on the critical path between ScoreNet's and the backbone's backward (0.35 ms of the 4-scene step)
         self.early_point_grads = True
+
+    def _padded_list_budget(self, device):
+        """bytes the padded ball-query lists + BFS records of one forward may take (pointgroup_ops.padded_clustering_bytes);
+        `self.padded_list_budget` overrides the default of 35 % of the device's memory"""
+        if self.padded_list_budget is not None:
+            return int(self.padded_list_budget)
+        key = device.index
+        if key not in self._mem_total:
+            self._mem_total[key] = int(torch.cuda.get_device_properties(device).total_memory)
+        return int(0.35 * self._mem_total[key])
 
     def _side_stream(self, device):
         key = (device.index, threading.get_ident())
@@ -580,9 +592,15 @@ class PointGroup(nn.Module):
                         data_dict["locs"], cluster_offsets.detach(), semantic_preds, batch_idxs, object_idxs)
                     batch_offsets_ = self.get_batch_offsets(batch_idxs_, batch_size)
 
+                # padded (sync-free) lists cost 20 KB per object point and branch whatever nActive is: beyond the budget (default: 35 % of
+                # the device's memory -- 100 GB on MI355X, above the lists' own 2.1 M-point range) the branches use the compact form
+                budget = self._padded_list_budget(coords_.device)
+                padded_ok = pointgroup_ops.ballquery_padded_fits(coords_.shape[0]) and \
+                    pointgroup_ops.padded_clustering_bytes(coords_.shape[0], 2) <= budget
+
                 def cluster_branch(xyz, mean_active, marks=False):
                     # (padded lists: same neighbours, no host round trip for nActive; bfs_cluster reads either form)
-                    padded = pointgroup_ops.ballquery_batch_p_padded(xyz, batch_idxs_, batch_offsets_, self.cluster_radius)
+                    padded = pointgroup_ops.ballquery_batch_p_padded(xyz, batch_idxs_, batch_offsets_, self.cluster_radius) if padded_ok else None
                     idx_, start_len_ = padded if padded is not None else pointgroup_ops.ballquery_batch_p(
                         xyz, batch_idxs_, batch_offsets_, self.cluster_radius, mean_active)
                     if marks:
@@ -598,7 +616,7 @@ class PointGroup(nn.Module):
                 _mark("cl_prepare")
                 self._kick_prefetch("cluster")          # (a pending input prefetch starts here: the clustering leaves most of the chip idle)
                 cur = torch.cuda.current_stream()
-                if self.concurrent_clustering and pointgroup_ops.ballquery_padded_fits(coords_.shape[0]):
+                if self.concurrent_clustering and padded_ok:
                     # Round 5: BOTH branches from this thread -- begin (everything enqueued: ball query, count kernels, the fill with
                     # its sizes read on the device), begin, then the two ends (each waits for its count's event only).  The helper
                     # thread of rounds 2-4 sat on the critical path with its wake-ups and interpreter-lock hand-overs.

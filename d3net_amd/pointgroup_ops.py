@@ -244,6 +244,14 @@ def ballquery_padded_fits(n, max_bytes=None):
     return n > 0 and n * cap <= 0x7FFFFFFF and (max_bytes is None or n * cap * 4 <= max_bytes)
 
 
+def padded_clustering_bytes(n, branches=2):
+    """device bytes the padded clustering of n object points holds at its peak: per branch the n * cap neighbour slots (4 B) and the
+    BFS replay's edge records sized from the same capacity (d3_bfs_cluster_erec_bytes: 16 B per slot) -- 20 KB per point and branch,
+    whatever the real nActive is.  PointGroup.forward keeps this under its `padded_list_budget` and falls back to the
+    compact lists (`ballquery_batch_p`) beyond it"""
+    return int(branches) * int(n) * _lib.lib().d3_ballquery_cap() * 20
+
+
 def ballquery_batch_p_padded(coords, batch_idxs, batch_offsets, radius, max_bytes=None, ws_tag=""):
     """Sync-free ball query for callers that hand the result straight to `bfs_cluster`: every point owns a fixed slot
     of `cap` entries (start_len[q] = (s * cap, len) with s = q, or the leader of q's clique cell whose list q shares:

@@ -126,3 +126,35 @@ def test_input_prefetcher_loop(dev, setup):
         losses.append(float(loss))
     torch.cuda.synchronize()
     assert max(losses) - min(losses) <= 1e-5 * max(1.0, abs(losses[0]))      # (no optimizer step: the same batch, the same loss)
+
+
+def test_padded_list_budget_falls_back_to_the_compact_lists(dev, setup):
+    """ADVICE r5: the padded (sync-free) ball-query lists + BFS records take 20 KB per object point and branch whatever nActive is;
+    beyond `padded_list_budget` the clustering runs on the compact lists (`ballquery_batch_p`, a host read per branch) -- same
+    proposals, same loss, same gradients"""
+    from d3net_amd import pointgroup_ops as P
+    model = setup["model"]
+    assert P.padded_clustering_bytes(1_200_000, 2) == 2 * 1_200_000 * 1000 * 20
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = []
+    for budget in (None, 1):
+        model.load_state_dict(state)
+        model.padded_list_budget = budget
+        calls = {"n": 0}
+        orig = P.ballquery_batch_p
+
+        def counted(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        P.ballquery_batch_p = counted
+        try:
+            res.append(_step(model, _batch(setup, dev, (0, 1))) + (calls["n"],))
+        finally:
+            P.ballquery_batch_p = orig
+            model.padded_list_budget = None
+    (l0, d0, g0, n0), (l1, d1, g1, n1) = res
+    assert n0 == 0 and n1 == 2, (n0, n1)          # both branches took the compact form under the 1-byte budget
+    assert torch.equal(d0["proposal_scores"][1], d1["proposal_scores"][1]) and torch.equal(d0["proposal_scores"][2], d1["proposal_scores"][2])
+    assert abs(float(l0) - float(l1)) <= 1e-6 * max(1.0, abs(float(l0)))
+    for n in g0:
+        assert float((g0[n] - g1[n]).norm()) <= 1e-5 * (float(g0[n].norm()) + 1e-12), n
