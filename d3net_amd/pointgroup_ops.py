@@ -44,7 +44,7 @@ def _ptr(t):
 def _workspace(nbytes, device, tag):
     """A cached, growing device scratch buffer per (device, tag, host thread, current stream)."""
     # per host thread AND per stream: the two clustering branches of PointGroup.forward run concurrently on their own streams, from
-    # two threads (CLUSTER_THREAD) or from one -- and a call may return with kernels that read its workspace still in flight
+    # two threads (the helper-thread fallback beyond the padded lists' budget) or from one -- and a call may return with kernels that read its workspace still in flight
     # (d3_bfs_cluster_run's speculative fill), so one thread driving two streams must never hand both the same buffer (r05_f: the
     # 16-scene batch, whose lists go the compact way, faulted exactly so)
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag, threading.get_ident(),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """d3_hgemm on the batched shapes of the captioner's classifier and its gradients (992 rows = 31 steps x 32 captions, hidden 512,
-vocabulary 3004), the three operand forms, tiled kernel vs wave-per-tile kernel (D3_HG_TILED read once per process: run twice).
+vocabulary 3004), the three operand forms.
 usage: python tools/hgemm_bench.py"""
 import ctypes as C
 import os
@@ -40,7 +40,6 @@ dlog = torch.randn(R, V, device=dev); dx = torch.empty(R, H, device=dev); dW = t
 cases = [("logits = x W^T          (992 x 3004, K 512)", _prob([_seg(x, W, H)], R, V, out), 2.0 * R * V * H),
          ("dx = dlog W             (992 x 512, K 3004, B k-major)", _prob([_seg(dlog, W, V, b_km=True)], R, H, dx), 2.0 * R * V * H),
          ("dW = dlog^T x           (3004 x 512, K 992, both k-major)", _prob([_seg(dlog, x, R, a_km=True, b_km=True)], V, H, dW), 2.0 * R * V * H)]
-print("D3_HG_TILED=%s" % os.environ.get("D3_HG_TILED", "1"))
 for name, p, fl in cases:
     us = run(p)
     print("%-62s %8.1f us  %6.1f TFLOP/s" % (name, us, fl / us / 1e6))
