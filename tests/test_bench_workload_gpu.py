@@ -10,7 +10,7 @@ V = 3004, 8 descriptions per scene -- `bench.make_scenes("speaker", 0)`), agains
       against the four single-scene runs: every integer output of the detector (voxel coordinates / maps, cluster
       membership in BFS order, cluster offsets, batch ids, point counts) is bit-equal to the per-scene results put
       together the way the reference's merge does (model/pointgroup.py:299-316);
-  (c) the level-0 convolution kernels at the 649 k rows of that batch against oracle/sparse_oracle.py (the canonical
+  (c) the level-0 convolution kernels (both generations: lane-table and dense-table) at the 649 k rows of that batch against oracle/sparse_oracle.py (the canonical
       143 k-row cases are in tests/test_conv_fullsize_gpu.py).
 Reference step: model/pipeline.py:152-185, model/pointgroup.py:266-370,466-479, model/caption_module.py:510-687,
 lib/captioning/loss_helper.py:177-224.
@@ -260,13 +260,26 @@ def canon(dev, bench_setup):
     ref_child = np.full((Mo, 8), -1); ref_child[parent, kidx] = np.arange(M)
     assert np.array_equal(up.cpu().numpy(), ref_up) and np.array_equal(child.cpu().numpy(), ref_child)
     assert M > 600000
-    return {0: dict(M=M, Mo=Mo, nbr=nbr, child=child, up=up, onbr=onbr, parent=parent, kidx=kidx)}
+    import test_conv3_gpu as T3
+    from d3net_amd import _lib
+    tq, ok = T3._packq(_lib.lib(), nbr, dev)          # the lane table of the 649 k-row map (spconv_fwd3_kernel, round 6)
+    assert ok == 1
+    return {0: dict(M=M, Mo=Mo, nbr=nbr, child=child, up=up, onbr=onbr, parent=parent, kidx=kidx, tq=tq)}
 
 
 @pytest.mark.parametrize("kind,cin,cout", [("k3", 16, 16), ("k3", 32, 16), ("k3", 136, 16), ("down", 16, 32), ("up", 32, 16)])
 def test_bench_batch_level0_forward(dev, canon, kind, cin, cout):
     import test_conv_fullsize_gpu as T
     T.test_fwd2_big_kernel_forward_and_epilogues(dev, canon, 0, kind, cin, cout)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 16), (16, 32)])
+def test_bench_batch_level0_lane_table_kernel(dev, canon, cin, cout):
+    """the lane-table kernel (what the bench step runs for these layers) at the batch's 649 k rows: forward with its epilogues and the
+    data gradient with the BatchNorm-backward epilogue, 1e-4 against the bf16-mode oracle"""
+    import test_conv3_gpu as T3
+    T3.test_fwd3_forward_and_epilogues(dev, canon, 0, cin, cout)
+    T3.test_fwd3_data_gradient_with_bn_backward_epilogue(dev, canon, 0, cin, cout)
 
 
 @pytest.mark.parametrize("kind,cin,cout", [("k3", 16, 16), ("k3", 32, 16), ("down", 16, 32)])
