@@ -279,9 +279,7 @@ def roofline_object(name, r, traffic_table, stride):
     dense fp32 GEMM of the heads (hg_gemm*) is MFMA-bound work priced against the 157.3 TFLOP/s fp32-MFMA peak, its byte-side
     fraction quoted beside it"""
     mfma = r["family"] == 3
-    # hg_gemm_tiled3_kernel: every algorithmic fp32 product is three bf16 MFMA products (hi*hi + hi*lo + lo*hi): its matrix-core
-    # ceiling in ALGORITHMIC flops is a third of the dense bf16 peak
-    mfma_peak = MFMA_BF16_PEAK_TFLOPS / 3.0 if name.startswith("hg_gemm_tiled3") else MFMA_F32_PEAK_TFLOPS
+    mfma_peak = MFMA_F32_PEAK_TFLOPS
     o = {"bound": "mfma" if mfma else "hbm", "kernel": name,
          "achieved": r["achieved_tflops"] if mfma else r["achieved_gbs"],
          "peak": mfma_peak if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s"}

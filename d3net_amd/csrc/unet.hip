@@ -678,6 +678,7 @@ struct Net {
     std::vector<int> rows;
     std::vector<int> galias;          // per buffer: tensor id whose gradient view this buffer's gradient aliases, or -1
     std::vector<int> gbf;             // per buffer: its gradient is stored as bf16 (single producer conv, single BatchNorm consumer)
+    std::vector<int> gabf;            // per buffer: the gradient of an activation buffer (one BatchNorm writer, one convolution reader) is stored as bf16
     std::vector<int> gshadow;         // per buffer: width of the bf16 shadow of (a column window of) its fp32 gradient, 0 = none
     std::vector<size_t> gshadow_off;  //   its offset in the gradient arena
     size_t arena_bytes = 0, grad_bytes = 0, ws_bytes = 0, bnscr_off = 0, wgws_off = 0, bnscr_bytes = 0, wgws_bytes = 0;
@@ -870,6 +871,40 @@ extern "C" void *d3_net_create(const int64_t *prog, int nops, const int64_t *ten
             if (ok && nprod == 1 && ncons == 1) n->gbf[b] = 1;
         }
     }
+    // The same for the gradient of an ACTIVATION buffer (BatchNorm -> ReLU output, bf16 in the forward): written once by the data
+    // gradient of the one convolution that reads the activation, read once by that BatchNorm's backward.  The convolution's epilogue
+    // takes the BatchNorm-backward partial sums from the unrounded values and stores bf16 (D3_CONV_OUTBF16); the apply pass reads 2
+    // bytes per element instead of 4.  Round 4 measured it neutral (the BatchNorm backward was bound by its reduction of the partial
+    // table then) and left it off; with the second-level tables and the lane-table data gradient it is worth 3 - 7 % on both kernels of
+    // levels 0 - 1 (rocprofv3, gpurun_out/r06_j34: 20.4 -> 19.4 us and 25.7 -> 24.0 us) and 0.7 GB less traffic per backward: on since round 6.
+    n->gabf.assign(n->B.size(), 0);
+    {
+        const bool on = !n->f32;
+        for (size_t b = 0; on && b < n->B.size(); b++) {
+            if (n->galias[b] >= 0 || n->gbf[b]) continue;
+            if (n->out_tensor >= 0 && n->T[n->out_tensor].buf == (int)b) continue;
+            bool ok = n->B[b].dtype == 1;
+            for (size_t x = 0; x < n->B.size(); x++)
+                if (n->galias[x] >= 0 && n->T[n->galias[x]].buf == (int)b) ok = false;
+            int nprod = 0, ncons = 0;
+            for (auto &o : n->ops) {
+                if (o.type == OP_PADCAST && n->T[o.out].buf == (int)b) ok = false;
+                if (o.type == OP_STATS) continue;
+                if (o.type == OP_CONV && o.res >= 0 && n->T[o.res].buf == (int)b) ok = false;
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.out].buf == (int)b) {
+                    const TensorD &t = n->T[o.out];
+                    nprod++;
+                    if (o.type != OP_BNACT || t.coff != 0 || t.C != n->B[b].width || (t.C & 7)) ok = false;
+                }
+                if ((o.type == OP_CONV || o.type == OP_BNACT) && n->T[o.in].buf == (int)b) {
+                    const TensorD &t = n->T[o.in];
+                    ncons++;
+                    if (o.type != OP_CONV || o.in_grad_mode != 1 || t.coff != 0 || t.C != n->B[b].width || o.CinW != t.C) ok = false;
+                }
+            }
+            if (ok && nprod == 1 && ncons == 1) n->gabf[b] = 1;
+        }
+    }
     // Residual-stream gradients stay fp32 (they are accumulated in place and feed fp32 consumers), but the convolution that
     // reads one as ITS output gradient uses it as a bf16 MFMA operand, gathered 27 times per row.  Where the last kernel to
     // touch the buffer before that read is a BatchNorm backward apply over the whole buffer (the first BatchNorm of the next
@@ -1026,7 +1061,7 @@ extern "C" int d3_net_plan(void *h, const int *rows, size_t *arena_bytes, size_t
     for (auto &b : n->B) {
         b.off = off; off += d3_align((size_t)n->rows[b.level] * b.width * esize(b.dtype));
         const size_t bi = &b - &n->B[0];
-        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * (n->gbf[bi] ? 2 : 4));
+        b.goff = goff; if (b.need_grad) goff += d3_align((size_t)n->rows[b.level] * b.width * ((n->gbf[bi] || n->gabf[bi]) ? 2 : 4));
         if (n->gshadow[bi]) { n->gshadow_off[bi] = goff; goff += d3_align((size_t)n->rows[b.level] * n->gshadow[bi] * 2); }
     }
     size_t bnscr = 0, wgws = 16;
@@ -1282,7 +1317,7 @@ static float *gptr(const Net *n, char *garena, const float *gout, float *gin, in
     }
     ld = n->B[t->buf].width;
     root = t->buf;
-    if (n->gbf[t->buf]) {          // (whole-buffer views only: coff == 0)
+    if (n->gbf[t->buf] || n->gabf[t->buf]) {          // (whole-buffer views only: coff == 0)
         if (bf16) *bf16 = 1;
         return (float *)(garena + n->B[t->buf].goff);
     }
